@@ -1,0 +1,272 @@
+/*
+ * vio_amd.h — C ABI of the MI355X-native VIO hot path.
+ *
+ * This is the drop-in boundary behind VINS-Mobile's two per-frame entry points
+ * (all citations are into /root/reference/VINS_ios unless another root is named):
+ *
+ *   front-end  FeatureTracker::readImage            feature_tracker.hpp:59, feature_tracker.cpp:162-310
+ *   back-end   VINS::processIMU / VINS::solve_ceres  VINS.hpp:153,163-164, VINS.cpp:333-375,480-831
+ *
+ * Conventions
+ *   - plain pointers and sizes, caller-owned host buffers, no C++/torch types;
+ *   - every function returns VIO_OK (0) or a negative VIO_E* code, never throws;
+ *   - one context per sequence (or per batch); contexts are thread-compatible,
+ *     not thread-safe (the reference objects are not re-entrant either:
+ *     static n_id feature_tracker.cpp:11, static sqrt_info projection_facor.cpp:11);
+ *   - all matrices are row-major; quaternions are stored x y z w exactly like
+ *     para_Pose (VINS.cpp:93-101);
+ *   - the product path needs a gfx950 device: there is no CPU fallback inside
+ *     this library (the CPU restatement lives in oracle/ and is test-only).
+ */
+#ifndef VIO_AMD_H
+#define VIO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIO_ABI_VERSION 1
+
+#define VIO_OK 0
+#define VIO_EINVAL (-1)   /* bad argument / inconsistent sizes            */
+#define VIO_ENODEV (-2)   /* no gfx950 device / HIP runtime error         */
+#define VIO_ENOMEM (-3)   /* host or device allocation failed             */
+#define VIO_ECAP (-4)     /* problem exceeds the context's capacity       */
+#define VIO_ESTATE (-5)   /* call order violated                          */
+
+#define VIO_SIZE_POSE 7       /* global_param.hpp:30 */
+#define VIO_SIZE_SPEEDBIAS 9  /* global_param.hpp:31 */
+#define VIO_MAX_PRIOR_BLOCKS 96
+
+/* ------------------------------------------------------------------------- */
+/* Runtime configuration (the reference's compile-time macros and per-device
+ * globals: global_param.hpp:23-58, global_param.cpp:24-131,
+ * feature_tracker.hpp:24-29).                                                */
+typedef struct VioConfig {
+  int32_t window_size;    /* WINDOW_SIZE (10); frames in window P = W+1       */
+  int32_t max_features;   /* capacity of inv_depth (NUM_OF_F = 1000)          */
+  int32_t max_factors;    /* capacity of the projection-factor list           */
+  int32_t max_iterations; /* options.max_num_iterations (10) VINS.cpp:645     */
+  int32_t image_rows;     /* ROW (640)                                        */
+  int32_t image_cols;     /* COL (480)                                        */
+  int32_t max_corners;    /* MAX_CNT (70)                                     */
+  int32_t min_dist;       /* MIN_DIST (30)                                    */
+  int32_t freq;           /* FREQ (3): publish every freq-th frame            */
+  int32_t lk_win;         /* LK window (21)        feature_tracker.cpp:181    */
+  int32_t lk_levels;      /* maxLevel (3)          feature_tracker.cpp:181    */
+  int32_t lk_max_iters;   /* TermCriteria COUNT (30) OpenCV default           */
+  double lk_eps;          /* TermCriteria EPS (0.01)                          */
+  double lk_min_eig;      /* minEigThreshold (1e-4)                           */
+  double quality_level;   /* goodFeaturesToTrack qualityLevel (0.01) :263     */
+  double f_threshold;     /* F_THRESHOLD (1.0 px)                             */
+  double f_confidence;    /* RANSAC confidence (0.99)                         */
+  double fx, fy, cx, cy;  /* FOCUS_LENGTH_X/Y, PX, PY                         */
+  double gravity;         /* GRAVITY 9.805                                    */
+  double acc_n, acc_w, gyr_n, gyr_w; /* ACC_N 0.5, ACC_W 2e-3, GYR_N 0.2, GYR_W 4e-5 */
+  double cauchy_a;        /* CauchyLoss(1.0)       VINS.cpp:485               */
+} VioConfig;
+
+/* Fills *cfg with the reference's iPhone7P values at W=10
+ * (global_param.cpp:27-42, feature_tracker.hpp:24-29).                       */
+void vio_config_default(VioConfig *cfg);
+
+/* ------------------------------------------------------------------------- */
+/* IMU pre-integration between two frames: the public state of
+ * IntegrationBase (integration_base.h:200-221) after the last push_back.     */
+typedef struct VioPreintegration {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4]; /* x y z w */
+  double delta_v[3];
+  double linearized_ba[3];
+  double linearized_bg[3];
+  double jacobian[225];   /* 15x15 row-major, order O_P,O_R,O_V,O_BA,O_BG     */
+  double covariance[225]; /* 15x15 row-major                                  */
+} VioPreintegration;
+
+/* Linearized prior = the kept side of MarginalizationInfo
+ * (marginalization_factor.hpp:66-88): r = r0 + J0*dx.                        */
+#define VIO_BLOCK_POSE 0
+#define VIO_BLOCK_SPEEDBIAS 1
+#define VIO_BLOCK_EXPOSE 2
+typedef struct VioPrior {
+  int32_t n;        /* residual rows = sum of kept local sizes (info->n)      */
+  int32_t n_blocks; /* keep_block_size.size()                                 */
+  int32_t block_kind[VIO_MAX_PRIOR_BLOCKS];   /* VIO_BLOCK_*                  */
+  int32_t block_index[VIO_MAX_PRIOR_BLOCKS];  /* frame index the block is
+                          bound to in the *next* window (after addr_shift,
+                          VINS.cpp:760-769); 0 for the extrinsic             */
+  int32_t block_offset[VIO_MAX_PRIOR_BLOCKS]; /* keep_block_idx - m           */
+  double *block_x0;              /* [n_blocks][9] keep_block_data, 7- and
+                                    9-sized blocks left-aligned               */
+  double *linearized_jacobians;  /* [n][n] row-major                          */
+  double *linearized_residuals;  /* [n]                                       */
+} VioPrior;
+
+#define VIO_MARGIN_OLD 0        /* VINS.hpp MarginalizationFlag               */
+#define VIO_MARGIN_SECOND_NEW 1
+#define VIO_MARGIN_NONE 2       /* skip the marginalization step              */
+
+/* One sliding window as solve_ceres sees it after old2new() (VINS.cpp:505).  */
+typedef struct VioWindow {
+  int32_t window_size; /* W */
+  int32_t n_features;  /* rows of inv_depth in use = getFeatureCount()        */
+  int32_t n_factors;   /* M projection factors, grouped by feature in
+                          ascending feature order as VINS.cpp:528-567 emits
+                          them, loop factors (target == W+1) included          */
+  int32_t marginalization_flag; /* VIO_MARGIN_*                                */
+  double *pose;        /* [(W+1)][7] para_Pose        in: initial, out: see below */
+  double *speed_bias;  /* [(W+1)][9] para_SpeedBias                            */
+  double *ex_pose;     /* [7] para_Ex_Pose[0] (constant block)                 */
+  double *inv_depth;   /* [n_features] para_Feature                            */
+  const int32_t *factor_host;    /* [M] imu_i                                  */
+  const int32_t *factor_target;  /* [M] imu_j; W+1 selects loop_pose           */
+  const int32_t *factor_feature; /* [M] feature_index                          */
+  const double *factor_pts_i;    /* [M][3] */
+  const double *factor_pts_j;    /* [M][3] */
+  const VioPreintegration *preint; /* [W]; preint[k] links frame k -> k+1
+                                      (pre_integrations[k+1], VINS.cpp:516-521) */
+  const VioPrior *prior;         /* NULL when last_marginalization_info == nullptr */
+  int32_t loop_frame;  /* -1: no loop constraint; else window index i whose
+                          pose initialises loop_pose (VINS.cpp:590-596)         */
+  double *loop_pose;   /* [7] front_pose.loop_pose, out: optimised              */
+  /* new2old() gauge anchor (VINS.cpp:133-155). 0: use pose[0] as passed in.    */
+  int32_t use_origin_override;
+  double origin_yaw_deg; /* Utility::R2ypr(last_R_old).x()                      */
+  double origin_p[3];    /* last_P_old                                          */
+  /* outputs --------------------------------------------------------------- */
+  /* pose / speed_bias / inv_depth are overwritten with the state after
+   * new2old() re-expressed in para_* form (what the second old2new() at
+   * VINS.cpp:693 produces). raw_* (optional, may be NULL) receive the arrays
+   * exactly as ceres::Solve left them.                                        */
+  double *raw_pose;       /* [(W+1)][7] or NULL */
+  double *raw_speed_bias; /* [(W+1)][9] or NULL */
+  double *raw_inv_depth;  /* [n_features] or NULL */
+  VioPrior *next_prior;   /* caller-allocated buffers sized for
+                             vio_prior_capacity(W); NULL to skip               */
+} VioWindow;
+
+#define VIO_MAX_TRACE 64
+typedef struct VioSolveStats {
+  double initial_cost;
+  double final_cost;     /* summary.final_cost VINS.cpp:660 */
+  int32_t iterations;    /* iteration records incl. iteration 0 */
+  int32_t termination;   /* 0 NO_CONVERGENCE, 1 CONVERGENCE, 2 FAILURE */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  /* per-iteration trace (IterationSummary, CS/include/ceres/iteration_callback.h) */
+  double it_cost[VIO_MAX_TRACE];
+  double it_radius[VIO_MAX_TRACE];
+  double it_step_norm[VIO_MAX_TRACE];
+  double it_relative_decrease[VIO_MAX_TRACE];
+  double it_gradient_max_norm[VIO_MAX_TRACE];
+  int32_t it_flags[VIO_MAX_TRACE]; /* bit0 step_is_valid, bit1 step_is_successful */
+} VioSolveStats;
+
+/* Upper bound of prior dimension for a window of size W: every pose (6),
+ * every speed-bias (9) and the extrinsic (6).                                */
+int32_t vio_prior_capacity(int32_t window_size);
+
+/* ------------------------------------------------------------------------- */
+/* Back-end                                                                   */
+typedef struct vio_backend vio_backend_t;
+
+/* max_batch = number of independent windows one launch may carry.            */
+int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **out);
+void vio_backend_destroy(vio_backend_t *be);
+
+/* IntegrationBase(acc_0, gyr_0, ba, bg) followed by n push_back(dt, acc, gyr)
+ * (integration_base.h:20-45, VINS.cpp:333-358). Host-side, IMU-rate path.     */
+int vio_preintegrate(const VioConfig *cfg, const double acc_0[3], const double gyr_0[3],
+                     const double ba[3], const double bg[3], int32_t n,
+                     const double *dt, const double *acc, const double *gyr,
+                     VioPreintegration *out);
+
+/* solve_ceres(buf_num) for `n` independent windows in one device launch
+ * (VINS.cpp:480-831). buf_num only selected a wall-clock budget in the
+ * reference (VINS.cpp:648-653); it is accepted and ignored (no time limit, so
+ * results are deterministic).                                                */
+int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n,
+                              int32_t buf_num, VioSolveStats *stats /* [n] or NULL */);
+
+/* Resident-batch API for throughput runs: pack + upload once, launch many
+ * times from the same initial state, download when wanted. `stream` is a
+ * hipStream_t (or NULL for the library's own stream).                        */
+int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n);
+int vio_backend_launch(vio_backend_t *be, void *stream);
+int vio_backend_sync(vio_backend_t *be);
+int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats);
+/* Average device time (ms) of the solve kernel over the launches since the
+ * last call, measured with HIP events on the launch stream.                  */
+int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches);
+
+/* ------------------------------------------------------------------------- */
+/* Front-end                                                                  */
+typedef struct vio_frontend vio_frontend_t;
+
+typedef struct VioObs {      /* one entry of image_msg (feature_tracker.cpp:300-306) */
+  int32_t id;
+  double x, y, z;            /* ((u-PX)/fx, (v-PY)/fy, 1) */
+} VioObs;
+
+typedef struct VioTrackViz { /* good_pts / track_len (UI only), optional */
+  float *good_pts;           /* [cap][2] */
+  double *track_len;         /* [cap]    */
+  int32_t cap;
+  int32_t n;
+} VioTrackViz;
+
+/* n_seq independent trackers (sequences) share one context and one launch.   */
+int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out);
+void vio_frontend_destroy(vio_frontend_t *fe);
+
+/* readImage for sequence `seq` (feature_tracker.cpp:162-310). `publish` is the
+ * caller's img_cnt == 0 (ViewController.mm:467,494). out_obs has room for
+ * cfg->max_corners entries.                                                  */
+int vio_frontend_read_image(vio_frontend_t *fe, int32_t seq, const uint8_t *gray,
+                            int32_t rows, int32_t cols, int32_t stride, double header,
+                            int32_t publish, VioObs *out_obs, int32_t *n_obs,
+                            VioTrackViz *viz /* may be NULL */);
+
+/* Batched form: one frame for every sequence in one set of launches.
+ * gray = n_seq images, each rows*stride bytes, back to back.                 */
+int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows,
+                             int32_t cols, int32_t stride, const double *headers,
+                             int32_t publish, VioObs *out_obs /* [n_seq][max_corners] */,
+                             int32_t *n_obs /* [n_seq] */);
+
+/* Resident form for throughput runs: frames already in HBM.                  */
+int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t n_frames,
+                               int32_t rows, int32_t cols, int32_t stride);
+int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t publish,
+                               void *stream);
+int vio_frontend_sync(vio_frontend_t *fe);
+int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches);
+
+/* Introspection of tracker state (cur_pts / ids / track_cnt,
+ * feature_tracker.hpp:72-75) for parity tests.                               */
+int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts /* [cap][2] */,
+                           int32_t *ids, int32_t *track_cnt, int32_t cap, int32_t *n);
+
+/* Stand-alone operators of the front-end (each is one reference call site),
+ * exposed so they can be parity-tested in isolation:
+ *   calcOpticalFlowPyrLK  feature_tracker.cpp:181
+ *   goodFeaturesToTrack   feature_tracker.cpp:263
+ *   findFundamentalMat    feature_tracker.cpp:95,198                          */
+int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next,
+                  int32_t rows, int32_t cols, int32_t stride, const float *prev_pts,
+                  int32_t n, float *next_pts, uint8_t *status, float *err);
+int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *mask,
+                      int32_t rows, int32_t cols, int32_t stride, int32_t max_corners,
+                      float *corners /* [max_corners][2] */, int32_t *n_corners);
+int vio_fundamental_ransac(const VioConfig *cfg, const float *pts1, const float *pts2,
+                           int32_t n, uint8_t *inlier_mask);
+
+const char *vio_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIO_AMD_H */
