@@ -1,0 +1,373 @@
+"""ctypes mirror of include/vio_amd.h — the C ABI of the MI355X VIO hot path.
+
+Only plumbing lives here: struct layouts, numpy <-> struct marshalling and a loader for the product
+shared library (``csrc/libvio_amd.so``).  The same structs are understood by the test-only checkers
+under ``oracle/`` (``libvio_oracle.so``, ``_ref/libvio_ref.so``), which is what lets tests hand
+bit-identical inputs to the reference, the CPU restatement and the HIP path.
+
+Reference interface mirrored: FeatureTracker::readImage (VINS_ios/feature_tracker.hpp:59) and
+VINS::solve_ceres (VINS_ios/VINS.hpp:153).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+VIO_OK = 0
+VIO_EINVAL, VIO_ENODEV, VIO_ENOMEM, VIO_ECAP, VIO_ESTATE = -1, -2, -3, -4, -5
+VIO_MAX_PRIOR_BLOCKS = 96
+VIO_MAX_TRACE = 64
+VIO_BLOCK_POSE, VIO_BLOCK_SPEEDBIAS, VIO_BLOCK_EXPOSE = 0, 1, 2
+VIO_MARGIN_OLD, VIO_MARGIN_SECOND_NEW, VIO_MARGIN_NONE = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class VioConfig(C.Structure):
+    _fields_ = [
+        ("window_size", C.c_int32), ("max_features", C.c_int32), ("max_factors", C.c_int32),
+        ("max_iterations", C.c_int32), ("image_rows", C.c_int32), ("image_cols", C.c_int32),
+        ("max_corners", C.c_int32), ("min_dist", C.c_int32), ("freq", C.c_int32),
+        ("lk_win", C.c_int32), ("lk_levels", C.c_int32), ("lk_max_iters", C.c_int32),
+        ("lk_eps", C.c_double), ("lk_min_eig", C.c_double), ("quality_level", C.c_double),
+        ("f_threshold", C.c_double), ("f_confidence", C.c_double),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("gravity", C.c_double), ("acc_n", C.c_double), ("acc_w", C.c_double),
+        ("gyr_n", C.c_double), ("gyr_w", C.c_double), ("cauchy_a", C.c_double),
+    ]
+
+
+def default_config(**kw):
+    """The reference's iPhone7P values (global_param.cpp:27-42, feature_tracker.hpp:24-29)."""
+    c = VioConfig(
+        window_size=10, max_features=1000, max_factors=8192, max_iterations=10,
+        image_rows=640, image_cols=480, max_corners=70, min_dist=30, freq=3,
+        lk_win=21, lk_levels=3, lk_max_iters=30, lk_eps=0.01, lk_min_eig=1e-4,
+        quality_level=0.01, f_threshold=1.0, f_confidence=0.99,
+        fx=526.600, fy=526.678, cx=243.481, cy=315.280,
+        gravity=9.805, acc_n=0.5, acc_w=0.002, gyr_n=0.2, gyr_w=4.0e-5, cauchy_a=1.0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class VioPreintegration(C.Structure):
+    _fields_ = [
+        ("sum_dt", C.c_double), ("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4),
+        ("delta_v", C.c_double * 3), ("linearized_ba", C.c_double * 3),
+        ("linearized_bg", C.c_double * 3), ("jacobian", C.c_double * 225),
+        ("covariance", C.c_double * 225),
+    ]
+
+
+PREINT_DOUBLES = C.sizeof(VioPreintegration) // 8  # 467
+
+
+class VioPrior(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("n_blocks", C.c_int32),
+        ("block_kind", C.c_int32 * VIO_MAX_PRIOR_BLOCKS),
+        ("block_index", C.c_int32 * VIO_MAX_PRIOR_BLOCKS),
+        ("block_offset", C.c_int32 * VIO_MAX_PRIOR_BLOCKS),
+        ("block_x0", _dp), ("linearized_jacobians", _dp), ("linearized_residuals", _dp),
+    ]
+
+
+class VioWindow(C.Structure):
+    _fields_ = [
+        ("window_size", C.c_int32), ("n_features", C.c_int32), ("n_factors", C.c_int32),
+        ("marginalization_flag", C.c_int32),
+        ("pose", _dp), ("speed_bias", _dp), ("ex_pose", _dp), ("inv_depth", _dp),
+        ("factor_host", _ip), ("factor_target", _ip), ("factor_feature", _ip),
+        ("factor_pts_i", _dp), ("factor_pts_j", _dp),
+        ("preint", C.POINTER(VioPreintegration)), ("prior", C.POINTER(VioPrior)),
+        ("loop_frame", C.c_int32), ("loop_pose", _dp),
+        ("use_origin_override", C.c_int32), ("origin_yaw_deg", C.c_double),
+        ("origin_p", C.c_double * 3),
+        ("raw_pose", _dp), ("raw_speed_bias", _dp), ("raw_inv_depth", _dp),
+        ("next_prior", C.POINTER(VioPrior)),
+    ]
+
+
+class VioSolveStats(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("iterations", C.c_int32), ("termination", C.c_int32),
+        ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("it_cost", C.c_double * VIO_MAX_TRACE), ("it_radius", C.c_double * VIO_MAX_TRACE),
+        ("it_step_norm", C.c_double * VIO_MAX_TRACE),
+        ("it_relative_decrease", C.c_double * VIO_MAX_TRACE),
+        ("it_gradient_max_norm", C.c_double * VIO_MAX_TRACE),
+        ("it_flags", C.c_int32 * VIO_MAX_TRACE),
+    ]
+
+
+class VioObs(C.Structure):
+    _fields_ = [("id", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+def prior_capacity(W):
+    return 6 * (W + 1) + 9 * (W + 1) + 6
+
+
+def _ptr(a, ty=_dp):
+    return a.ctypes.data_as(ty)
+
+
+class Prior:
+    """numpy-backed VioPrior (kept side of MarginalizationInfo)."""
+
+    def __init__(self, W=None, cap=None):
+        cap = cap if cap is not None else prior_capacity(W)
+        self.cap = cap
+        self.x0 = np.zeros((VIO_MAX_PRIOR_BLOCKS, 9))
+        self.J = np.zeros(cap * cap)
+        self.r = np.zeros(cap)
+        self.c = VioPrior()
+        self.c.block_x0 = _ptr(self.x0)
+        self.c.linearized_jacobians = _ptr(self.J)
+        self.c.linearized_residuals = _ptr(self.r)
+
+    @property
+    def n(self):
+        return self.c.n
+
+    @property
+    def n_blocks(self):
+        return self.c.n_blocks
+
+    def blocks(self):
+        """[(kind, index, offset, local_size)]"""
+        out = []
+        for b in range(self.c.n_blocks):
+            k = self.c.block_kind[b]
+            out.append((k, self.c.block_index[b], self.c.block_offset[b], 9 if k == VIO_BLOCK_SPEEDBIAS else 6))
+        return out
+
+    def jac(self):
+        n = self.c.n
+        return self.J[: n * n].reshape(n, n)
+
+    def res(self):
+        return self.r[: self.c.n]
+
+    def canonical(self):
+        """Column-order independent form: (H, b, x0) with blocks sorted by (kind, index).
+
+        The reference's column order depends on unordered_map iteration over pointer keys
+        (marginalization_factor.cpp:182-200,302-319); H = J0^T J0 and b = J0^T r0 are what the
+        next solve actually consumes, and they are invariant to that order and to eigenvector signs.
+        """
+        J, r = self.jac(), self.res()
+        order = sorted(self.blocks(), key=lambda t: (t[0], t[1]))
+        cols = np.concatenate([np.arange(o, o + s) for (_, _, o, s) in order]) if order else np.zeros(0, int)
+        Jc = J[:, cols]
+        x0 = {}
+        for b, (k, i, o, s) in enumerate(self.blocks()):
+            x0[(k, i)] = self.x0[b, : (9 if k == VIO_BLOCK_SPEEDBIAS else 7)].copy()
+        return Jc.T @ Jc, Jc.T @ r, [(k, i, x0[(k, i)]) for (k, i, _, _) in order]
+
+    def copy(self):
+        p = Prior(cap=self.cap)
+        p.x0[:] = self.x0
+        p.J[:] = self.J
+        p.r[:] = self.r
+        p.c.n, p.c.n_blocks = self.c.n, self.c.n_blocks
+        for b in range(VIO_MAX_PRIOR_BLOCKS):
+            p.c.block_kind[b] = self.c.block_kind[b]
+            p.c.block_index[b] = self.c.block_index[b]
+            p.c.block_offset[b] = self.c.block_offset[b]
+        return p
+
+    def to_npz_dict(self, prefix):
+        n, nb = self.c.n, self.c.n_blocks
+        return {
+            prefix + "n": np.int32(n), prefix + "n_blocks": np.int32(nb),
+            prefix + "kind": np.array(self.c.block_kind[:nb], np.int32),
+            prefix + "index": np.array(self.c.block_index[:nb], np.int32),
+            prefix + "offset": np.array(self.c.block_offset[:nb], np.int32),
+            prefix + "x0": self.x0[:nb].copy(), prefix + "J": self.jac().copy(), prefix + "r": self.res().copy(),
+        }
+
+    @staticmethod
+    def from_npz_dict(d, prefix, W):
+        p = Prior(W)
+        n, nb = int(d[prefix + "n"]), int(d[prefix + "n_blocks"])
+        p.c.n, p.c.n_blocks = n, nb
+        for b in range(nb):
+            p.c.block_kind[b] = int(d[prefix + "kind"][b])
+            p.c.block_index[b] = int(d[prefix + "index"][b])
+            p.c.block_offset[b] = int(d[prefix + "offset"][b])
+        p.x0[:nb] = d[prefix + "x0"]
+        p.J[: n * n] = np.asarray(d[prefix + "J"]).ravel()
+        p.r[:n] = d[prefix + "r"]
+        return p
+
+
+class Window:
+    """numpy-backed VioWindow: one sliding window as solve_ceres sees it after old2new()."""
+
+    def __init__(self, W, pose, speed_bias, ex_pose, inv_depth, factor_host, factor_target,
+                 factor_feature, pts_i, pts_j, preint, prior=None, marginalization_flag=VIO_MARGIN_OLD,
+                 loop_frame=-1):
+        P = W + 1
+        self.W = W
+        self.pose = np.ascontiguousarray(pose, np.float64).reshape(P, 7).copy()
+        self.speed_bias = np.ascontiguousarray(speed_bias, np.float64).reshape(P, 9).copy()
+        self.ex_pose = np.ascontiguousarray(ex_pose, np.float64).reshape(7).copy()
+        self.inv_depth = np.ascontiguousarray(inv_depth, np.float64).ravel().copy()
+        self.factor_host = np.ascontiguousarray(factor_host, np.int32).copy()
+        self.factor_target = np.ascontiguousarray(factor_target, np.int32).copy()
+        self.factor_feature = np.ascontiguousarray(factor_feature, np.int32).copy()
+        self.pts_i = np.ascontiguousarray(pts_i, np.float64).reshape(-1, 3).copy()
+        self.pts_j = np.ascontiguousarray(pts_j, np.float64).reshape(-1, 3).copy()
+        # preint: float64 array [W, PREINT_DOUBLES] with the exact VioPreintegration layout
+        self.preint = np.ascontiguousarray(preint, np.float64).reshape(W, PREINT_DOUBLES).copy()
+        self.prior = prior
+        self.marginalization_flag = marginalization_flag
+        self.loop_frame = loop_frame
+        self.loop_pose = np.zeros(7)
+        self.use_origin_override = 0
+        self.origin_yaw_deg = 0.0
+        self.origin_p = np.zeros(3)
+        self.raw_pose = np.zeros((P, 7))
+        self.raw_speed_bias = np.zeros((P, 9))
+        self.raw_inv_depth = np.zeros(len(self.inv_depth))
+        self.next_prior = Prior(W)
+
+    @property
+    def n_features(self):
+        return len(self.inv_depth)
+
+    @property
+    def n_factors(self):
+        return len(self.factor_host)
+
+    def copy(self):
+        w = Window(self.W, self.pose, self.speed_bias, self.ex_pose, self.inv_depth, self.factor_host,
+                   self.factor_target, self.factor_feature, self.pts_i, self.pts_j, self.preint,
+                   self.prior.copy() if self.prior is not None else None, self.marginalization_flag,
+                   self.loop_frame)
+        w.use_origin_override = self.use_origin_override
+        w.origin_yaw_deg = self.origin_yaw_deg
+        w.origin_p = self.origin_p.copy()
+        return w
+
+    def fill_struct(self, c):
+        c.window_size = self.W
+        c.n_features = self.n_features
+        c.n_factors = self.n_factors
+        c.marginalization_flag = self.marginalization_flag
+        c.pose, c.speed_bias = _ptr(self.pose), _ptr(self.speed_bias)
+        c.ex_pose, c.inv_depth = _ptr(self.ex_pose), _ptr(self.inv_depth)
+        c.factor_host = _ptr(self.factor_host, _ip)
+        c.factor_target = _ptr(self.factor_target, _ip)
+        c.factor_feature = _ptr(self.factor_feature, _ip)
+        c.factor_pts_i, c.factor_pts_j = _ptr(self.pts_i), _ptr(self.pts_j)
+        c.preint = C.cast(self.preint.ctypes.data, C.POINTER(VioPreintegration))
+        c.prior = C.pointer(self.prior.c) if self.prior is not None else C.POINTER(VioPrior)()
+        c.loop_frame = self.loop_frame
+        c.loop_pose = _ptr(self.loop_pose)
+        c.use_origin_override = self.use_origin_override
+        c.origin_yaw_deg = self.origin_yaw_deg
+        for k in range(3):
+            c.origin_p[k] = self.origin_p[k]
+        c.raw_pose, c.raw_speed_bias = _ptr(self.raw_pose), _ptr(self.raw_speed_bias)
+        c.raw_inv_depth = _ptr(self.raw_inv_depth)
+        c.next_prior = C.pointer(self.next_prior.c)
+        return c
+
+    def struct(self):
+        return self.fill_struct(VioWindow())
+
+    # ---- fixtures -------------------------------------------------------------------------------
+    def to_npz_dict(self):
+        d = dict(W=np.int32(self.W), pose=self.pose, speed_bias=self.speed_bias, ex_pose=self.ex_pose,
+                 inv_depth=self.inv_depth, factor_host=self.factor_host, factor_target=self.factor_target,
+                 factor_feature=self.factor_feature, pts_i=self.pts_i, pts_j=self.pts_j, preint=self.preint,
+                 marginalization_flag=np.int32(self.marginalization_flag), loop_frame=np.int32(self.loop_frame),
+                 has_prior=np.int32(self.prior is not None))
+        if self.prior is not None:
+            d.update(self.prior.to_npz_dict("prior_"))
+        return d
+
+    @staticmethod
+    def from_npz_dict(d):
+        W = int(d["W"])
+        prior = Prior.from_npz_dict(d, "prior_", W) if int(d["has_prior"]) else None
+        return Window(W, d["pose"], d["speed_bias"], d["ex_pose"], d["inv_depth"], d["factor_host"],
+                      d["factor_target"], d["factor_feature"], d["pts_i"], d["pts_j"], d["preint"], prior,
+                      int(d["marginalization_flag"]), int(d["loop_frame"]))
+
+
+def stats_to_dict(s):
+    n = min(s.iterations, VIO_MAX_TRACE)
+    return dict(initial_cost=s.initial_cost, final_cost=s.final_cost, iterations=s.iterations,
+                termination=s.termination, num_successful_steps=s.num_successful_steps,
+                num_unsuccessful_steps=s.num_unsuccessful_steps,
+                it_cost=np.array(s.it_cost[:n]), it_radius=np.array(s.it_radius[:n]),
+                it_step_norm=np.array(s.it_step_norm[:n]),
+                it_relative_decrease=np.array(s.it_relative_decrease[:n]),
+                it_gradient_max_norm=np.array(s.it_gradient_max_norm[:n]),
+                it_flags=np.array(s.it_flags[:n], np.int32))
+
+
+# ---- library loading -----------------------------------------------------------------------------
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "csrc", "libvio_amd.so")
+
+
+def bind_backend_solver(lib, prefix):
+    """Declares `<prefix>_solve_window(cfg, window, stats)` / preintegrate on a checker library."""
+    f = getattr(lib, prefix + "_solve_window")
+    f.argtypes = [C.POINTER(VioConfig), C.POINTER(VioWindow), C.POINTER(VioSolveStats)]
+    f.restype = C.c_int
+    g = getattr(lib, prefix + "_preintegrate")
+    g.argtypes = [C.POINTER(VioConfig), _dp, _dp, _dp, _dp, C.c_int32, _dp, _dp, _dp, C.POINTER(VioPreintegration)]
+    g.restype = C.c_int
+    return f, g
+
+
+def preintegrate_with(fn, cfg, acc0, gyr0, ba, bg, dt, acc, gyr):
+    """Runs a `*_preintegrate` entry point; returns the struct as a float64 row (PREINT_DOUBLES)."""
+    out = np.zeros(PREINT_DOUBLES)
+    a = [np.ascontiguousarray(x, np.float64) for x in (acc0, gyr0, ba, bg, dt, acc, gyr)]
+    rc = fn(C.byref(cfg), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), len(a[4]), _ptr(a[4]), _ptr(a[5]),
+            _ptr(a[6]), C.cast(out.ctypes.data, C.POINTER(VioPreintegration)))
+    if rc != VIO_OK:
+        raise RuntimeError("preintegrate failed rc=%d" % rc)
+    return out
+
+
+_product = None
+
+
+def load_product():
+    """Loads csrc/libvio_amd.so. Fails loudly when the HIP extension was not built: there is no
+    CPU fallback for the product path."""
+    global _product
+    if _product is not None:
+        return _product
+    if not os.path.exists(PRODUCT_LIB):
+        raise RuntimeError("HIP extension missing: %s (run __graft_entry__.build())" % PRODUCT_LIB)
+    lib = C.CDLL(PRODUCT_LIB)
+    vp = C.c_void_p
+    lib.vio_version.restype = C.c_char_p
+    lib.vio_config_default.argtypes = [C.POINTER(VioConfig)]
+    lib.vio_prior_capacity.argtypes = [C.c_int32]
+    lib.vio_prior_capacity.restype = C.c_int32
+    lib.vio_backend_create.argtypes = [C.POINTER(VioConfig), C.c_int32, C.POINTER(vp)]
+    lib.vio_backend_destroy.argtypes = [vp]
+    lib.vio_backend_destroy.restype = None
+    lib.vio_preintegrate.argtypes = [C.POINTER(VioConfig), _dp, _dp, _dp, _dp, C.c_int32, _dp, _dp, _dp,
+                                     C.POINTER(VioPreintegration)]
+    lib.vio_backend_solve_windows.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.c_int32,
+                                              C.POINTER(VioSolveStats)]
+    lib.vio_backend_upload.argtypes = [vp, C.POINTER(VioWindow), C.c_int32]
+    lib.vio_backend_launch.argtypes = [vp, vp]
+    lib.vio_backend_sync.argtypes = [vp]
+    lib.vio_backend_download.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.POINTER(VioSolveStats)]
+    lib.vio_backend_kernel_ms.argtypes = [vp, _dp, _ip]
+    _product = lib
+    return lib
