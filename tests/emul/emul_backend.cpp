@@ -1,0 +1,68 @@
+// tests/emul/emul_backend.cpp — TEST-ONLY host emulation of the HIP back-end kernel.
+//
+// Compiles vins-mobile_amd/csrc/solver_core.h with -DVIO_EMUL: the SPMD phase code runs with one "thread" and
+// no barriers, through the very same pack / make_view / carve_work / unpack code the device path uses. It exists
+// so that index arithmetic and control flow of the kernel can be debugged where there is no GPU. It is NOT part
+// of the product library, is never loaded by the package, and is not a CPU fallback: vins-mobile_amd/ fails
+// loudly without the HIP extension.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "batch.h"
+#include "marg_core.h"
+
+using namespace vio;
+
+extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveStats *stats) {
+  bool any_loop = false;
+  for (int k = 0; k < win->n_factors; k++)
+    if (win->factor_target[k] == win->window_size + 1) any_loop = true;
+  HostBatch hb;
+  hb.resize(make_dims(*cfg, win->window_size, win->n_features, win->n_factors, any_loop), 1);
+  int rc = pack_window(hb, 0, *win);
+  if (rc != VIO_OK) return rc;
+  const BatchStrides &s = hb.s;
+  std::vector<double> scratch(s.scratch), hm(s.hm), out_pose(s.out_pose), out_sb(s.out_sb), out_feat(s.out_feat),
+      raw_pose(s.out_pose), raw_sb(s.out_sb), raw_feat(s.out_feat), out_loop(7), stats_d(s.stats_d);
+  std::vector<int> stats_i(s.stats_i);
+  MargOut mo;
+  std::vector<double> m_scratch(marg_scratch_doubles(hb.d.Wcap)), m_x0(9 * kMaxPriorBlocks), m_J((size_t)hb.d.Ncap * hb.d.Ncap),
+      m_r(hb.d.Ncap);
+  std::vector<int> m_int(4 + 3 * kMaxPriorBlocks);
+  BatchPtrs B;
+  B.n = 1, B.d = hb.d, B.s = s;
+  B.hdr = hb.hdr.data(), B.hdr_d = hb.hdr_d.data();
+  B.pose = hb.pose.data(), B.sb = hb.sb.data(), B.ex = hb.ex.data(), B.feat = hb.feat.data();
+  B.fhost = hb.fhost.data(), B.ftarget = hb.ftarget.data(), B.ffeat = hb.ffeat.data();
+  B.pts_i = hb.pts_i.data(), B.pts_j = hb.pts_j.data(), B.preint = hb.preint.data();
+  B.pr_kind = hb.pr_kind.data(), B.pr_index = hb.pr_index.data(), B.pr_offset = hb.pr_offset.data();
+  B.pr_x0 = hb.pr_x0.data(), B.pr_J = hb.pr_J.data(), B.pr_r = hb.pr_r.data();
+  B.scratch = scratch.data(), B.hm = hm.data();
+  B.out_pose = out_pose.data(), B.out_sb = out_sb.data(), B.out_feat = out_feat.data();
+  B.raw_pose = raw_pose.data(), B.raw_sb = raw_sb.data(), B.raw_feat = raw_feat.data(), B.out_loop = out_loop.data();
+  B.stats_d = stats_d.data(), B.stats_i = stats_i.data();
+
+  WinView v = make_view(B, 0);
+  size_t bytes = carve_work(B.d, true, 64, nullptr, nullptr, nullptr, nullptr);
+  std::vector<double> lds(bytes / sizeof(double) + 2);
+  Work w;
+  Ctx cx;
+  cx.tid = 0, cx.nt = 1;
+  size_t state_end = 0;
+  carve_work(B.d, true, 64, lds.data(), nullptr, &w, &cx, &state_end);
+  solve_window(cx, v, w);
+
+  mo.n = m_int.data(), mo.kind = m_int.data() + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
+  mo.x0 = m_x0.data(), mo.J = m_J.data(), mo.r = m_r.data(), mo.scratch = m_scratch.data(), mo.ncap = hb.d.Ncap;
+  size_t mbytes = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr);
+  std::vector<double> mlds(mbytes / sizeof(double) + 2);
+  MargWork mw;
+  carve_marg(B.d, true, mlds.data(), nullptr, &mw);
+  marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
+
+  unpack_window(s, 0, out_pose.data(), out_sb.data(), out_feat.data(), raw_pose.data(), raw_sb.data(),
+                raw_feat.data(), out_loop.data(), stats_d.data(), stats_i.data(), *win, stats);
+  if (win->next_prior) unpack_prior(mo, *win->next_prior);
+  return VIO_OK;
+}

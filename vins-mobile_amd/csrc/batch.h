@@ -1,0 +1,271 @@
+// batch.h — HBM layout of a batch of windows, the per-window view the kernel builds from it, the LDS working-set
+// layout, and the host-side pack / unpack between the C ABI structs (include/vio_amd.h) and the flat arrays.
+//
+// Layout: structure-of-arrays across the batch with fixed per-window capacities (Wcap, Fcap, Mcap, Ncap) so that
+// window b of every array sits at base + b * stride: one launch covers the whole batch, blockIdx.x = window.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "solver_core.h"
+#include "vio_amd.h"
+
+namespace vio {
+
+constexpr int kHdrInts = 12;
+enum { H_W = 0, H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_PRIOR_N, H_PRIOR_NB, H_USE_ORIGIN };
+constexpr int kHdrDoubles = 4;
+constexpr int kMaxPriorBlocks = VIO_MAX_PRIOR_BLOCKS;
+
+struct BatchDims {
+  int Wcap, Pcap, Fcap, Mcap, Ncap, Fpad, n6cap, nblk_cap;
+  int max_iter;
+  double s_info, gravity, cauchy_b;
+};
+
+// Wcap/Fcap/Mcap: largest window / feature / factor count in the batch; any_loop: some window carries a loop pose
+// (one extra 6-dof block).
+inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, bool any_loop) {
+  BatchDims d;
+  d.Wcap = Wcap, d.Pcap = Wcap + 1, d.Fcap = Fcap > 0 ? Fcap : 1, d.Mcap = Mcap > 0 ? Mcap : 1;
+  d.Ncap = 15 * d.Pcap + 6;
+  d.Fpad = (d.Fcap + 7) / 8 * 8;
+  d.n6cap = 6 * (d.Pcap + 1);  // pose groups 0..P-1 plus one more: loop pose (solve) / extrinsic (marginalization)
+  d.nblk_cap = d.Pcap + (any_loop ? 1 : 0);
+  d.max_iter = cfg.max_iterations;
+  d.s_info = cfg.fx / 1.5;  // ProjectionFactor::sqrt_info = FOCUS_LENGTH_X / 1.5 (VINS.cpp:31)
+  d.gravity = cfg.gravity;
+  d.cauchy_b = cfg.cauchy_a * cfg.cauchy_a;
+  return d;
+}
+
+// Element counts per window of every array (strides).
+struct BatchStrides {
+  size_t pose, sb, ex, feat, fint, pts, preint, pr_int, pr_x0, pr_J, pr_r;
+  size_t scratch, hm;
+  size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
+  // offsets inside the per-window scratch block (doubles)
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT;
+};
+
+inline BatchStrides make_strides(const BatchDims &d) {
+  BatchStrides s;
+  s.pose = 7 * (size_t)d.Pcap, s.sb = 9 * (size_t)d.Pcap, s.ex = 7, s.feat = d.Fcap;
+  s.fint = d.Mcap, s.pts = 3 * (size_t)d.Mcap, s.preint = (size_t)d.Wcap * kPreintDoubles;
+  s.pr_int = kMaxPriorBlocks, s.pr_x0 = 9 * (size_t)kMaxPriorBlocks, s.pr_J = (size_t)d.Ncap * d.Ncap, s.pr_r = d.Ncap;
+  size_t o = 0;
+  s.s_info = o, o += (size_t)d.Wcap * 225;
+  s.s_aug = o, o += (size_t)d.Wcap * 450;
+  s.s_J = o, o += (size_t)d.Wcap * 450;
+  s.s_M = o, o += (size_t)d.Wcap * 450;
+  s.s_r = o, o += (size_t)d.Wcap * 15;
+  s.s_Mr = o, o += (size_t)d.Wcap * 15;
+  s.s_prJT = o, o += (size_t)d.Ncap * d.Ncap;
+  s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
+  s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
+  s.scratch = (o + 7) / 8 * 8;
+  s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB;
+  s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
+  s.stats_d = kStatsDoubles, s.stats_i = kStatsInts;
+  return s;
+}
+
+// Base pointers (device or host, depending on who fills it).
+struct BatchPtrs {
+  int n;
+  BatchDims d;
+  BatchStrides s;
+  const int *hdr;         // [n][kHdrInts]
+  const double *hdr_d;    // [n][kHdrDoubles]
+  const double *pose, *sb, *ex, *feat;
+  const int *fhost, *ftarget, *ffeat;
+  const double *pts_i, *pts_j, *preint;
+  const int *pr_kind, *pr_index, *pr_offset;
+  const double *pr_x0, *pr_J, *pr_r;
+  double *scratch;   // [n][s.scratch]
+  double *hm;        // [n][s.hm] (only used when the matrix does not fit LDS)
+  double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop, *stats_d;
+  int *stats_i;
+};
+
+VIO_HD WinView make_view(const BatchPtrs &B, int b) {
+  WinView v;
+  const int *h = B.hdr + (size_t)b * kHdrInts;
+  const double *hd = B.hdr_d + (size_t)b * kHdrDoubles;
+  v.W = h[H_W], v.P = v.W + 1, v.F = h[H_F], v.M = h[H_M];
+  v.has_loop = h[H_HAS_LOOP], v.loop_frame = h[H_LOOP_FRAME], v.marg_flag = h[H_MARG];
+  v.prior_n = h[H_PRIOR_N], v.prior_nb = h[H_PRIOR_NB];
+  v.np = kBS * v.P + (v.has_loop ? 6 : 0);
+  v.nblk = v.P + (v.has_loop ? 1 : 0);
+  v.max_iter = B.d.max_iter;
+  v.Fpad = B.d.Fpad;
+  v.npose6 = 6 * (v.P + (v.has_loop ? 1 : 0));
+  v.s_info = B.d.s_info, v.gravity = B.d.gravity, v.cauchy_b = B.d.cauchy_b;
+  v.pose0 = B.pose + b * B.s.pose, v.sb0 = B.sb + b * B.s.sb, v.ex = B.ex + b * B.s.ex, v.feat0 = B.feat + b * B.s.feat;
+  v.fhost = B.fhost + b * B.s.fint, v.ftarget = B.ftarget + b * B.s.fint, v.ffeat = B.ffeat + b * B.s.fint;
+  v.pts_i = B.pts_i + b * B.s.pts, v.pts_j = B.pts_j + b * B.s.pts;
+  v.preint = B.preint + b * B.s.preint;
+  v.pr_kind = B.pr_kind + b * B.s.pr_int, v.pr_index = B.pr_index + b * B.s.pr_int;
+  v.pr_offset = B.pr_offset + b * B.s.pr_int;
+  v.pr_x0 = B.pr_x0 + b * B.s.pr_x0, v.pr_J = B.pr_J + b * B.s.pr_J, v.pr_r = B.pr_r + b * B.s.pr_r;
+  v.use_origin = h[H_USE_ORIGIN];
+  v.origin_yaw = hd[0], v.origin_p[0] = hd[1], v.origin_p[1] = hd[2], v.origin_p[2] = hd[3];
+  double *sc = B.scratch + b * B.s.scratch;
+  v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
+  v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prJT = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
+  v.WT = sc + B.s.s_WT;
+  v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
+  v.out_feat = B.out_feat + b * B.s.out_feat;
+  v.raw_pose = B.raw_pose + b * B.s.out_pose, v.raw_sb = B.raw_sb + b * B.s.out_sb;
+  v.raw_feat = B.raw_feat + b * B.s.out_feat, v.out_loop = B.out_loop + b * B.s.out_loop;
+  v.stats_d = B.stats_d + b * B.s.stats_d, v.stats_i = B.stats_i + b * B.s.stats_i;
+  return v;
+}
+
+// ---- LDS working set ------------------------------------------------------------------------------------
+// Carves `base` (LDS, 16-byte aligned) into the Work arrays for capacities d. When lds_matrix is false the matrix
+// lives in global memory (hm_global). Returns the number of bytes used.
+VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, double *base, double *hm_global,
+                         Work *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
+  size_t o = 0;
+  const size_t npc = (size_t)d.nblk_cap * kBS;  // padded pose-side length
+  const size_t F = d.Fcap;
+  auto take = [&](size_t n) {
+    double *p = base ? base + o : nullptr;
+    o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
+    return p;
+  };
+  // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
+  double *xpose = take(7 * (size_t)(d.Pcap + 1)), *xsb = take(9 * (size_t)d.Pcap), *xfeat = take(F);
+  double *ex = take(8);
+  double *red = take((size_t)nthreads / 64 + 2);
+  if (state_end_doubles) *state_end_doubles = o;
+  double *hm = nullptr;
+  if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
+  double *cpose = take(7 * (size_t)(d.Pcap + 1)), *csb = take(9 * (size_t)d.Pcap), *cfeat = take(F);
+  double *gp = take(npc), *gf = take(F), *sp = take(npc), *sf = take(F), *dp = take(npc), *df = take(F);
+  double *gdp = take(npc), *gdf = take(F), *gnp = take(npc), *gnf = take(F), *stp = take(npc), *stf = take(F);
+  double *hdiag = take(npc), *hff = take(F), *ef = take(F), *ldinv = take(npc), *t1 = take(npc), *t2 = take(npc);
+  double *tf = take(F), *prdx = take(d.Ncap), *prr = take(d.Ncap);
+  double *prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
+  double *flag = take(2);
+  if (w) {
+    w->Hm = lds_matrix ? hm : hm_global;
+    w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
+    w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->df = df, w->gdp = gdp, w->gdf = gdf;
+    w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef;
+    w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
+    w->prcol = reinterpret_cast<int *>(prcol), w->flag = reinterpret_cast<int *>(flag);
+  }
+  if (cx) cx->red = red;
+  return o * sizeof(double);
+}
+
+// ---- host-side staging ---------------------------------------------------------------------------------
+struct HostBatch {
+  BatchDims d;
+  BatchStrides s;
+  int n = 0;
+  std::vector<int> hdr, fhost, ftarget, ffeat, pr_kind, pr_index, pr_offset;
+  std::vector<double> hdr_d, pose, sb, ex, feat, pts_i, pts_j, preint, pr_x0, pr_J, pr_r;
+  void resize(const BatchDims &dims, int n_) {
+    d = dims, s = make_strides(dims), n = n_;
+    hdr.assign((size_t)n * kHdrInts, 0), hdr_d.assign((size_t)n * kHdrDoubles, 0.0);
+    pose.assign(n * s.pose, 0.0), sb.assign(n * s.sb, 0.0), ex.assign(n * s.ex, 0.0), feat.assign(n * s.feat, 1.0);
+    fhost.assign(n * s.fint, 0), ftarget.assign(n * s.fint, 0), ffeat.assign(n * s.fint, 0);
+    pts_i.assign(n * s.pts, 0.0), pts_j.assign(n * s.pts, 0.0), preint.assign(n * s.preint, 0.0);
+    pr_kind.assign(n * s.pr_int, 0), pr_index.assign(n * s.pr_int, 0), pr_offset.assign(n * s.pr_int, 0);
+    pr_x0.assign(n * s.pr_x0, 0.0), pr_J.assign(n * s.pr_J, 0.0), pr_r.assign(n * s.pr_r, 0.0);
+  }
+};
+
+// Validates one window against the capacities and writes it into slot b. Returns VIO_OK / VIO_EINVAL / VIO_ECAP.
+inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
+  const BatchDims &d = hb.d;
+  const BatchStrides &s = hb.s;
+  const int W = w.window_size, P = W + 1, F = w.n_features, M = w.n_factors;
+  if (W < 1 || F < 0 || M < 0 || !w.pose || !w.speed_bias || !w.ex_pose || !w.preint) return VIO_EINVAL;
+  if (W > d.Wcap || F > d.Fcap || M > d.Mcap) return VIO_ECAP;
+  if ((F > 0 && !w.inv_depth) || (M > 0 && (!w.factor_host || !w.factor_target || !w.factor_feature ||
+                                            !w.factor_pts_i || !w.factor_pts_j)))
+    return VIO_EINVAL;
+  int has_loop = 0;
+  for (int k = 0; k < M; k++) {
+    int h = w.factor_host[k], t = w.factor_target[k], f = w.factor_feature[k];
+    if (f < 0 || f >= F || h < 0 || h >= P || t < 0 || t > P) return VIO_EINVAL;
+    if (t == P) has_loop = 1;
+  }
+  if (has_loop && (w.loop_frame < 0 || w.loop_frame >= W)) return VIO_EINVAL;
+  int *h = &hb.hdr[(size_t)b * kHdrInts];
+  h[H_W] = W, h[H_F] = F, h[H_M] = M, h[H_HAS_LOOP] = has_loop, h[H_LOOP_FRAME] = w.loop_frame;
+  h[H_MARG] = w.marginalization_flag, h[H_USE_ORIGIN] = w.use_origin_override;
+  double *hd = &hb.hdr_d[(size_t)b * kHdrDoubles];
+  hd[0] = w.origin_yaw_deg, hd[1] = w.origin_p[0], hd[2] = w.origin_p[1], hd[3] = w.origin_p[2];
+  memcpy(&hb.pose[b * s.pose], w.pose, sizeof(double) * 7 * P);
+  memcpy(&hb.sb[b * s.sb], w.speed_bias, sizeof(double) * 9 * P);
+  memcpy(&hb.ex[b * s.ex], w.ex_pose, sizeof(double) * 7);
+  if (F) memcpy(&hb.feat[b * s.feat], w.inv_depth, sizeof(double) * F);
+  if (M) {
+    memcpy(&hb.fhost[b * s.fint], w.factor_host, sizeof(int) * M);
+    memcpy(&hb.ftarget[b * s.fint], w.factor_target, sizeof(int) * M);
+    memcpy(&hb.ffeat[b * s.fint], w.factor_feature, sizeof(int) * M);
+    memcpy(&hb.pts_i[b * s.pts], w.factor_pts_i, sizeof(double) * 3 * M);
+    memcpy(&hb.pts_j[b * s.pts], w.factor_pts_j, sizeof(double) * 3 * M);
+  }
+  static_assert(sizeof(VioPreintegration) == kPreintDoubles * sizeof(double), "VioPreintegration layout");
+  memcpy(&hb.preint[b * s.preint], w.preint, sizeof(VioPreintegration) * W);
+  h[H_PRIOR_N] = 0, h[H_PRIOR_NB] = 0;
+  if (w.prior && w.prior->n > 0) {
+    const VioPrior *p = w.prior;
+    if (p->n > d.Ncap || p->n_blocks > kMaxPriorBlocks) return VIO_ECAP;
+    if (!p->block_x0 || !p->linearized_jacobians || !p->linearized_residuals) return VIO_EINVAL;
+    for (int k = 0; k < p->n_blocks; k++) {
+      int kind = p->block_kind[k], idx = p->block_index[k], o = p->block_offset[k];
+      int ls = kind == VIO_BLOCK_SPEEDBIAS ? 9 : 6;
+      if (kind < 0 || kind > 2 || idx < 0 || idx >= P || o < 0 || o + ls > p->n) return VIO_EINVAL;
+      hb.pr_kind[b * s.pr_int + k] = kind, hb.pr_index[b * s.pr_int + k] = idx, hb.pr_offset[b * s.pr_int + k] = o;
+    }
+    h[H_PRIOR_N] = p->n, h[H_PRIOR_NB] = p->n_blocks;
+    memcpy(&hb.pr_x0[b * s.pr_x0], p->block_x0, sizeof(double) * 9 * p->n_blocks);
+    memcpy(&hb.pr_J[b * s.pr_J], p->linearized_jacobians, sizeof(double) * p->n * p->n);
+    memcpy(&hb.pr_r[b * s.pr_r], p->linearized_residuals, sizeof(double) * p->n);
+  }
+  return VIO_OK;
+}
+
+// Copies one window's results (host copies of the output arrays) back into the caller's structs.
+inline void unpack_window(const BatchStrides &s, int b, const double *out_pose, const double *out_sb,
+                          const double *out_feat, const double *raw_pose, const double *raw_sb,
+                          const double *raw_feat, const double *out_loop, const double *stats_d, const int *stats_i,
+                          VioWindow &w, VioSolveStats *st) {
+  const int P = w.window_size + 1, F = w.n_features;
+  memcpy(w.pose, out_pose + b * s.out_pose, sizeof(double) * 7 * P);
+  memcpy(w.speed_bias, out_sb + b * s.out_sb, sizeof(double) * 9 * P);
+  if (F) memcpy(w.inv_depth, out_feat + b * s.out_feat, sizeof(double) * F);
+  if (w.raw_pose) memcpy(w.raw_pose, raw_pose + b * s.out_pose, sizeof(double) * 7 * P);
+  if (w.raw_speed_bias) memcpy(w.raw_speed_bias, raw_sb + b * s.out_sb, sizeof(double) * 9 * P);
+  if (w.raw_inv_depth && F) memcpy(w.raw_inv_depth, raw_feat + b * s.out_feat, sizeof(double) * F);
+  bool has_loop = false;
+  for (int k = 0; k < w.n_factors; k++)
+    if (w.factor_target[k] == P) has_loop = true;
+  if (has_loop && w.loop_pose) memcpy(w.loop_pose, out_loop + b * s.out_loop, sizeof(double) * 7);
+  if (st) {
+    const double *sd = stats_d + b * s.stats_d;
+    const int *si = stats_i + b * s.stats_i;
+    memset(st, 0, sizeof(*st));
+    st->initial_cost = sd[0], st->final_cost = sd[1];
+    st->iterations = si[0], st->termination = si[1], st->num_successful_steps = si[2];
+    st->num_unsuccessful_steps = si[3];
+    for (int i = 0; i < kMaxTrace && i < VIO_MAX_TRACE; i++) {
+      st->it_cost[i] = sd[4 + i], st->it_radius[i] = sd[4 + kMaxTrace + i];
+      st->it_step_norm[i] = sd[4 + 2 * kMaxTrace + i], st->it_relative_decrease[i] = sd[4 + 3 * kMaxTrace + i];
+      st->it_gradient_max_norm[i] = sd[4 + 4 * kMaxTrace + i], st->it_flags[i] = si[4 + i];
+    }
+  }
+}
+
+}  // namespace vio

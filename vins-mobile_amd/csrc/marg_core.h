@@ -1,0 +1,333 @@
+// marg_core.h — building the next linearized prior on the device (SPMD phase code, same conventions as
+// solver_core.h). Runs in the same launch right after the solve + new2old, on the gauge-fixed state.
+//
+// Reference: MarginalizationInfo::{preMarginalize, marginalize} (VINS_ios/marginalization_factor.cpp:118-300) at the
+// two call sites in VINS::solve_ceres (VINS_ios/VINS.cpp:690-774 MARGIN_OLD, :776-830 MARGIN_SECOND_NEW).
+//
+// Route. The reference forms A = sum J^T J, b = sum J^T r over {prior, IMU(0,1), projections hosted at frame 0},
+// orders the dropped blocks first and computes
+//     A' = Arr - Arm Amm^+ Amr,  b' = br - Arm Amm^+ bm,  J0 = sqrt(S) V^T,  r0 = sqrt(S)^-1 V^T b'   (A' = V S V^T)
+// with two dense symmetric eigendecompositions whose eigenvalues <= 1e-8 are cut. The next solve consumes the prior
+// only through J0^T J0 = A'_+ , J0^T r0 = b'_+ and |r0|^2. Any factor A'_+ = J0^T J0 serves, so the device does ONE
+// Cholesky-type factorization of A with the dropped variables first and b carried along:
+//     A = L L^T  =>  the trailing block of L is L' with L' L'^T = A',  forward substitution gives r0 = L'^-1 b',
+//     J0 = L'^T.
+// Landmarks hosted at frame 0 (1x1 blocks) are eliminated analytically first, exactly like in the solver. The
+// eigenvalue cut becomes a pivot cut: a pivot <= max(1e-8, 1e-12 * original diagonal) marks a direction without
+// information (gauge directions, blocks that no factor touches); its row of L is zeroed and skipped, which is what
+// the pseudo-inverse / zeroed eigenvalue does in the reference up to rounding noise.
+#pragma once
+
+#include "solver_core.h"
+
+namespace vio {
+
+struct MargOut {
+  int *n;        // [4]: n, n_blocks, m (dropped dims), pos
+  int *kind, *index, *offset;  // [kMaxPriorBlocks]
+  double *x0;    // [kMaxPriorBlocks][9]
+  double *J;     // [n][n] row-major
+  double *r;     // [n]
+  double *scratch;  // global: dense matrix when it does not fit LDS
+  int ncap;         // capacity of J (ncap x ncap) and r
+};
+
+struct MargWork {
+  double *Am;    // pos x pos row-major, leading dimension ld
+  int ld;
+  double *bm;    // pos
+  double *tol;   // pos
+  double *hff, *gf, *einv;  // F
+  double *prdx, *prr;       // prior_n
+  int *col_pose;  // [P+1]: first dense column of pose i (-1: not involved); entry P unused
+  int *col_sb;    // [P]
+  int *col_ex;    // [1]
+  int *pcol;      // prior column -> dense column: prior_n
+  int *meta;      // [4]: pos, m, n, nblocks
+};
+
+VIO_HD constexpr int kMargMaxPos(int W) { return 15 + 6 * W + 15; }
+
+VIO_HD size_t marg_scratch_doubles(const int Wcap) {
+  size_t p = (size_t)kMargMaxPos(Wcap);
+  return p * p + 8;
+}
+
+// LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
+// is preserved; everything behind it is re-used. Returns bytes used (base may be null to just measure).
+template <class Dims>
+VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, double *base_after_state, double *am_global, MargWork *m) {
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    double *p = base_after_state ? base_after_state + o : nullptr;
+    o += (n + 1) & ~(size_t)1;
+    return p;
+  };
+  const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Fcap;
+  double *Am = lds_matrix ? take(pos * pos) : nullptr;
+  double *bm = take(pos), *tol = take(pos), *hff = take(F), *gf = take(F), *einv = take(F);
+  double *prdx = take(d.Ncap), *prr = take(d.Ncap);
+  double *ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
+  if (m) {
+    m->Am = lds_matrix ? Am : am_global, m->ld = (int)pos, m->bm = bm, m->tol = tol;
+    m->hff = hff, m->gf = gf, m->einv = einv, m->prdx = prdx, m->prr = prr;
+    int *ip = reinterpret_cast<int *>(ints);
+    m->col_pose = ip, m->col_sb = ip + d.Pcap + 1, m->col_ex = m->col_sb + d.Pcap;
+    m->pcol = m->col_ex + 1, m->meta = m->pcol + d.Ncap;
+  }
+  return o * sizeof(double);
+}
+
+VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const double *xpose, const double *xsb,
+                                     const double *xfeat, const double *ex, MargWork &m, const MargOut &out) {
+  const int W = v.W, P = v.P, F = v.F;
+  const int flag = v.marg_flag;
+  const int pn = v.prior_n;
+  // ---- which variant runs (uniform across the block) ---------------------------------------------------
+  bool run = (flag == 0);
+  if (flag == 1) {
+    // MARGIN_SECOND_NEW only when the prior references para_Pose[W-1] (VINS.cpp:778-779)
+    bool touches = false;
+    for (int b = 0; b < v.prior_nb; b++)
+      if (v.pr_kind[b] == 0 && v.pr_index[b] == W - 1) touches = true;
+    run = pn > 0 && touches;
+  }
+  if (!run) {
+    if (cx.tid == 0) out.n[0] = -1, out.n[1] = 0, out.n[2] = 0, out.n[3] = 0;
+    return;
+  }
+  // ---- involved blocks and their dense columns: dropped first, then kept in (pose.., speed-bias.., extrinsic) order
+  if (cx.tid == 0) {
+    for (int i = 0; i <= P; i++) m.col_pose[i] = -1;
+    for (int i = 0; i < P; i++) m.col_sb[i] = -1;
+    m.col_ex[0] = -1;
+    // mark involvement with -2
+    for (int b = 0; b < v.prior_nb; b++) {
+      int kind = v.pr_kind[b], idx = v.pr_index[b];
+      if (kind == 0) m.col_pose[idx] = -2;
+      else if (kind == 1) m.col_sb[idx] = -2;
+      else m.col_ex[0] = -2;
+    }
+    if (flag == 0) {
+      m.col_pose[0] = m.col_sb[0] = m.col_pose[1] = m.col_sb[1] = -2;
+      for (int k = 0; k < v.M; k++)
+        if (v.fhost[k] == 0 && v.ftarget[k] != P) m.col_pose[v.ftarget[k]] = -2, m.col_ex[0] = -2;
+    }
+    int pos = 0, nblocks = 0;
+    // dropped
+    if (flag == 0) {
+      m.col_pose[0] = pos, pos += 6;
+      m.col_sb[0] = pos, pos += 9;
+    } else {
+      m.col_pose[W - 1] = pos, pos += 6;
+    }
+    const int mdrop = pos;
+    auto keep = [&](int kind, int idx, int col, int new_index) {
+      out.kind[nblocks] = kind, out.index[nblocks] = new_index, out.offset[nblocks] = col - mdrop;
+      double *x0 = out.x0 + 9 * nblocks;
+      for (int q = 0; q < 9; q++) x0[q] = 0.0;
+      const double *src = kind == 0 ? xpose + 7 * idx : kind == 1 ? xsb + 9 * idx : ex;
+      int gs = kind == 1 ? 9 : 7;
+      for (int q = 0; q < gs; q++) x0[q] = src[q];
+      nblocks++;
+    };
+    // addr_shift: MARGIN_OLD i -> i-1 (VINS.cpp:760-769); SECOND_NEW W -> W-1, others unchanged (:804-823)
+    for (int i = 0; i < P; i++)
+      if (m.col_pose[i] == -2) {
+        m.col_pose[i] = pos;
+        keep(0, i, pos, flag == 0 ? i - 1 : (i == W ? W - 1 : i));
+        pos += 6;
+      }
+    for (int i = 0; i < P; i++)
+      if (m.col_sb[i] == -2) {
+        m.col_sb[i] = pos;
+        keep(1, i, pos, flag == 0 ? i - 1 : (i == W ? W - 1 : i));
+        pos += 9;
+      }
+    if (m.col_ex[0] == -2) {
+      m.col_ex[0] = pos;
+      keep(2, 0, pos, 0);
+      pos += 6;
+    }
+    m.meta[0] = pos, m.meta[1] = mdrop, m.meta[2] = pos - mdrop, m.meta[3] = nblocks;
+  }
+  VIO_SYNC();
+  const int pos = m.meta[0], mdrop = m.meta[1], n = m.meta[2], nblocks = m.meta[3];
+  const int ld = m.ld;
+  if (pos > ld || n > out.ncap) {  // more kept speed-bias blocks than any reference-made prior carries
+    if (cx.tid == 0) out.n[0] = -2, out.n[1] = 0, out.n[2] = mdrop, out.n[3] = pos;
+    return;
+  }
+  VIO_PARFOR(q, pos * ld) m.Am[q] = 0.0;
+  VIO_PARFOR(q, pos) m.bm[q] = 0.0;
+  VIO_PARFOR(f, F) m.hff[f] = 0.0, m.gf[f] = 0.0;
+  const int n6 = 6 * (P + 1);  // WT row groups: poses 0..P-1 at 6 i, extrinsic at 6 P
+  if (flag == 0) VIO_PARFOR(q, n6 * v.Fpad) v.WT[q] = 0.0;
+  VIO_SYNC();
+  // ---- prior as a factor (MarginalizationFactor evaluated at the current state) ------------------------
+  if (pn > 0) {
+    VIO_PARFOR(b, v.prior_nb) {
+      int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+      const double *x0 = v.pr_x0 + 9 * b;
+      int base = kind == 0 ? m.col_pose[idx] : kind == 1 ? m.col_sb[idx] : m.col_ex[0];
+      int ls = kind == 1 ? 9 : 6;
+      for (int k = 0; k < ls; k++) m.pcol[o + k] = base + k;
+      if (kind == 0) prior_block_dx(7, xpose + 7 * idx, x0, m.prdx + o);
+      else if (kind == 1) prior_block_dx(9, xsb + 9 * idx, x0, m.prdx + o);
+      else prior_block_dx(7, ex, x0, m.prdx + o);
+    }
+    VIO_SYNC();
+    VIO_PARFOR(i, pn) {
+      double s = v.pr_r[i];
+      for (int j = 0; j < pn; j++) s += v.prJT[j * pn + i] * m.prdx[j];
+      m.prr[i] = s;
+    }
+    VIO_SYNC();
+    VIO_PARFOR(a, pn) {
+      double g = 0;
+      for (int k = 0; k < pn; k++) g += v.pr_J[k * pn + a] * m.prr[k];
+      m.bm[m.pcol[a]] = g;
+    }
+    VIO_PARFOR(q, pn * pn) {
+      int a = q / pn, b = q % pn;
+      m.Am[m.pcol[a] * ld + m.pcol[b]] = v.prH0[q];
+    }
+    VIO_SYNC();
+  }
+  if (flag == 0) {
+    // ---- IMUFactor(pre_integrations[1]) on (pose0, sb0, pose1, sb1) ------------------------------------
+    if (cx.tid == 0)
+      imu_eval_raw(v.gravity, v.preint, xpose, xsb, xpose + 7, xsb + 9, v.imu_r, v.imu_J);
+    VIO_SYNC();
+    VIO_PARFOR(r, 15) {
+      const double *info = v.imu_info + r * 15;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += info[k] * v.imu_r[k];
+      v.imu_Mr[r] = s;
+    }
+    VIO_PARFOR(q, 450) {
+      int r = q / 30, c = q % 30;
+      const double *info = v.imu_info + r * 15;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += info[k] * v.imu_J[k * 30 + c];
+      v.imu_M[q] = s;
+    }
+    VIO_SYNC();
+    // local column a in [0,30): pose0 | sb0 | pose1 | sb1
+    VIO_PARFOR(q, 900) {
+      int a = q / 30, b = q % 30;
+      int ca = a < 6 ? m.col_pose[0] + a : a < 15 ? m.col_sb[0] + a - 6 : a < 21 ? m.col_pose[1] + a - 15 : m.col_sb[1] + a - 21;
+      int cb = b < 6 ? m.col_pose[0] + b : b < 15 ? m.col_sb[0] + b - 6 : b < 21 ? m.col_pose[1] + b - 15 : m.col_sb[1] + b - 21;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += v.imu_J[k * 30 + a] * v.imu_M[k * 30 + b];
+      VIO_ATOMIC_ADD(m.Am + ca * ld + cb, s);
+    }
+    VIO_PARFOR(a, 30) {
+      int ca = a < 6 ? m.col_pose[0] + a : a < 15 ? m.col_sb[0] + a - 6 : a < 21 ? m.col_pose[1] + a - 15 : m.col_sb[1] + a - 21;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += v.imu_J[k * 30 + a] * v.imu_Mr[k];
+      VIO_ATOMIC_ADD(m.bm + ca, s);
+    }
+    // ---- projections hosted at frame 0: blocks (pose0, pose_t, extrinsic, feature), Cauchy-corrected
+    //      (ResidualBlockInfo::Evaluate, marginalization_factor.cpp:45-76, rho'' < 0 branch)
+    const double cc = 1.0 / v.cauchy_b;
+    VIO_PARFOR(k, v.M) {
+      int t = v.ftarget[k], f = v.ffeat[k];
+      if (v.fhost[k] != 0 || t == P) continue;
+      double r[2], Ji[12], Jj[12], Jex[12], Jl[2];
+      projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj,
+                      Jex, Jl);
+      double sq = r[0] * r[0] + r[1] * r[1];
+      double sr = sqrt(1.0 / (1.0 + sq * cc));
+      for (int q = 0; q < 12; q++) Ji[q] *= sr, Jj[q] *= sr, Jex[q] *= sr;
+      Jl[0] *= sr, Jl[1] *= sr, r[0] *= sr, r[1] *= sr;
+      const double *Js[3] = {Ji, Jj, Jex};
+      int cols[3] = {m.col_pose[0], m.col_pose[t], m.col_ex[0]};
+      int wrow[3] = {0, 6 * t, 6 * P};
+      for (int x = 0; x < 3; x++)
+        for (int a = 0; a < 6; a++) {
+          VIO_ATOMIC_ADD(m.bm + cols[x] + a, Js[x][a] * r[0] + Js[x][6 + a] * r[1]);
+          VIO_ATOMIC_ADD(v.WT + (wrow[x] + a) * v.Fpad + f, Js[x][a] * Jl[0] + Js[x][6 + a] * Jl[1]);
+          for (int y = 0; y < 3; y++)
+            for (int b = 0; b < 6; b++)
+              VIO_ATOMIC_ADD(m.Am + (cols[x] + a) * ld + cols[y] + b, Js[x][a] * Js[y][b] + Js[x][6 + a] * Js[y][6 + b]);
+        }
+      VIO_ATOMIC_ADD(m.hff + f, Jl[0] * Jl[0] + Jl[1] * Jl[1]);
+      VIO_ATOMIC_ADD(m.gf + f, Jl[0] * r[0] + Jl[1] * r[1]);
+    }
+    VIO_SYNC();
+    // ---- eliminate the landmarks hosted at frame 0 (pseudo-inverse: e <= eps contributes nothing) --------
+    VIO_PARFOR(f, F) m.einv[f] = m.hff[f] > 1e-8 ? 1.0 / m.hff[f] : 0.0;
+    VIO_SYNC();
+    // pose-type groups: g in [0, P] -> (WT row base 6 g, dense column base)
+    const int ng = P + 1;
+    VIO_PARFOR(q, (6 * ng) * (6 * ng)) {
+      int a = q / (6 * ng), b = q % (6 * ng);
+      int ga = a / 6, gb = b / 6;
+      int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
+      if (ca < 0 || cb < 0) continue;
+      const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
+      double s = 0;
+      for (int f = 0; f < F; f++) s += wa[f] * wb[f] * m.einv[f];
+      m.Am[(ca + a % 6) * ld + cb + b % 6] -= s;
+    }
+    VIO_PARFOR(a, 6 * ng) {
+      int ga = a / 6;
+      int ca = ga == P ? m.col_ex[0] : m.col_pose[ga];
+      if (ca < 0) continue;
+      const double *wa = v.WT + a * v.Fpad;
+      double s = 0;
+      for (int f = 0; f < F; f++) s += wa[f] * m.gf[f] * m.einv[f];
+      m.bm[ca + a % 6] -= s;
+    }
+    VIO_SYNC();
+  }
+  // ---- Cholesky with pivot cut, b carried along (forward substitution) --------------------------------
+  VIO_PARFOR(j, pos) m.tol[j] = fmax(1e-8, 1e-12 * m.Am[j * ld + j]);
+  VIO_SYNC();
+  for (int j = 0; j < pos; j++) {
+    double piv = m.Am[j * ld + j];
+    bool skip = !(piv > m.tol[j]);
+    double d = skip ? 0.0 : sqrt(piv);
+    double inv = skip ? 0.0 : 1.0 / d;
+    double yj = m.bm[j] * inv;
+    VIO_SYNC();  // everyone has read the pivot and b_j before they are overwritten
+    VIO_PARFOR(i, pos - j) {
+      int r = j + i;
+      if (i == 0) m.Am[j * ld + j] = d, m.bm[j] = yj;
+      else m.Am[r * ld + j] *= inv;
+    }
+    VIO_SYNC();
+    const int rem = pos - j - 1;
+    VIO_PARFOR(q, rem * rem) {
+      int i = j + 1 + q / rem, k = j + 1 + q % rem;
+      if (k <= i) m.Am[i * ld + k] -= m.Am[i * ld + j] * m.Am[k * ld + j];
+    }
+    VIO_PARFOR(i, rem) m.bm[j + 1 + i] -= m.Am[(j + 1 + i) * ld + j] * yj;
+    VIO_SYNC();
+  }
+  // ---- outputs: J0 = L'^T (upper triangular), r0 = y' ---------------------------------------------------
+  VIO_PARFOR(q, n * n) {
+    int r = q / n, c = q % n;
+    out.J[q] = c >= r ? m.Am[(mdrop + c) * ld + mdrop + r] : 0.0;
+  }
+  VIO_PARFOR(i, n) out.r[i] = m.bm[mdrop + i];
+  if (cx.tid == 0) out.n[0] = n, out.n[1] = nblocks, out.n[2] = mdrop, out.n[3] = pos;
+  VIO_SYNC();
+}
+
+inline void unpack_prior(const MargOut &mo, VioPrior &p) {
+  p.n = mo.n[0];
+  p.n_blocks = mo.n[1];
+  if (p.n <= 0) {
+    p.n_blocks = 0;
+    return;
+  }
+  for (int b = 0; b < p.n_blocks; b++)
+    p.block_kind[b] = mo.kind[b], p.block_index[b] = mo.index[b], p.block_offset[b] = mo.offset[b];
+  memcpy(p.block_x0, mo.x0, sizeof(double) * 9 * p.n_blocks);
+  memcpy(p.linearized_jacobians, mo.J, sizeof(double) * p.n * p.n);
+  memcpy(p.linearized_residuals, mo.r, sizeof(double) * p.n);
+}
+
+}  // namespace vio

@@ -1,0 +1,1158 @@
+// solver_core.h — the sliding-window solve as single-source SPMD "phase" code.
+//
+// One workgroup solves one window (VINS::solve_ceres, VINS_ios/VINS.cpp:480-831): factor evaluation, normal
+// equations, landmark Schur complement, dense Cholesky of the reduced system, Ceres' trust-region/dogleg loop and
+// the new2old gauge fix all run inside one launch with no host round trip. The batch dimension (independent
+// sequences) is the grid.
+//
+// The code is written as barrier-separated parallel-for phases (VIO_PARFOR / VIO_SYNC). Under hipcc it is the
+// body of the gfx950 kernel in vio_backend.hip; with -DVIO_EMUL (tests only, never in the product library) the same
+// source runs with one "thread" on the host so that index maths and control flow can be debugged without a GPU.
+//
+// Algorithm notes (what differs from the reference's *route*, not its result):
+//  * Ceres materialises a scaled Jacobian J_s = J diag(scale). Everything the minimizer needs is a function of
+//    H = J^T J, g = J^T r and the cost, so H and g are accumulated straight from the factors (LDS atomics) and J is
+//    never stored: ||J_s[:,c]||^2 = scale_c^2 H_cc, J_s^T r = scale g, |J_s v|^2 = v^T (S H S) v.
+//  * Elimination set = all features (1x1 e-blocks); the reduced system is 15(W+1) [+6 loop pose] and lives in LDS
+//    as a block-lower matrix of 15x15 blocks (frame i -> [pose 6 | speed-bias 9]).
+//  * After S = L L^T the quadratic forms v^T (S H S + mu D^2) v that the Cauchy point and model_cost_change need
+//    are evaluated as sum_f e_f (v_f + w_f^T v_p / e_f)^2 + |L^T v_p|^2, so the un-factored matrix is not kept.
+//  * IMUFactor's sqrt_info = LLT(cov^-1).L^T (imu_factor.h:72) is recomputed by the reference on every
+//    Evaluate; it is constant during a solve, so cov^-1 is formed once and H += J^T cov^-1 J, g += J^T cov^-1 r,
+//    cost += r^T cov^-1 r / 2 are used (identical to whitening by any square root of cov^-1).
+//  * MarginalizationFactor's Jacobian J0 is constant: H0 = J0^T J0 is formed once per solve.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "vio_math.h"
+
+#ifdef VIO_EMUL
+#define VIO_DEV inline
+#define VIO_SYNC() ((void)0)
+#define VIO_ATOMIC_ADD(p, v) (*(p) += (v))
+#else
+#define VIO_DEV __device__ __forceinline__
+#define VIO_SYNC() __syncthreads()
+#define VIO_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#endif
+#define VIO_PARFOR(i, n) for (int i = (int)cx.tid; i < (int)(n); i += (int)cx.nt)
+
+namespace vio {
+
+constexpr int kBS = 15;          // reduced-system block size: pose 6 + speed-bias 9
+constexpr int kBB = kBS * kBS;   // 225
+constexpr int kPreintDoubles = 467;
+constexpr int kMaxTrace = 64;
+constexpr int kStatsDoubles = 4 + 5 * kMaxTrace;  // initial, final, (it_cost, radius, step_norm, rel, gmax)[64]
+constexpr int kStatsInts = 4 + kMaxTrace;         // iterations, termination, n_ok, n_bad, flags[64]
+
+struct Ctx {
+  int tid, nt;
+  double *red;  // LDS scratch for block reductions: [nt/64 + 1]
+};
+
+// Per-window view of the packed batch (all pointers device-global unless noted).
+struct WinView {
+  int W, P, F, M, np, nblk, has_loop, loop_frame, marg_flag, max_iter;
+  int prior_n, prior_nb;
+  int Fpad;      // leading dimension of WT (F rounded up to a multiple of 8)
+  int npose6;    // 6 * (P + has_loop): rows of WT
+  double s_info, gravity, cauchy_b;
+  const double *pose0, *sb0, *ex, *feat0;
+  const int *fhost, *ftarget, *ffeat;
+  const double *pts_i, *pts_j;
+  const double *preint;
+  const int *pr_kind, *pr_index, *pr_offset;
+  const double *pr_x0, *pr_J, *pr_r;
+  int use_origin;
+  double origin_yaw, origin_p[3];
+  // scratch
+  double *imu_info;  // [W][225]  sym(cov^-1)
+  double *imu_aug;   // [W][15*30] Gauss-Jordan work area
+  double *imu_J;     // [W][15*30]
+  double *imu_M;     // [W][15*30]
+  double *imu_r;     // [W][15]
+  double *imu_Mr;    // [W][15]
+  double *prJT;      // [n*n]  J0 transposed
+  double *prH0;      // [n*n]  J0^T J0
+  double *WT;        // [npose6][Fpad]  H_pf transposed: row = 6*frame + c, col = feature
+  // outputs
+  double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
+  double *stats_d;
+  int *stats_i;
+};
+
+// LDS (or emulated) working set; all arrays sized by the launcher from the dims.
+struct Work {
+  double *Hm;     // block-lower matrix: nblk(nblk+1)/2 blocks of 225 (LDS when it fits, else global)
+  double *xpose, *xsb, *xfeat;   // current iterate: (P+1)*7, P*9, F
+  double *cpose, *csb, *cfeat;   // candidate
+  double *ex;                    // 7
+  double *gp, *gf;               // unscaled gradient J^T r: np, F
+  double *sp, *sf;               // Jacobi scaling
+  double *dp, *df;               // dogleg diagonal
+  double *gdp, *gdf;             // gradient in d-scaled space
+  double *gnp, *gnf;             // Gauss-Newton step in d-scaled space
+  double *stp, *stf;             // trust-region step (J_s coordinates), later delta
+  double *hdiag, *hff;           // diag(H_pp), H_ff (unscaled)
+  double *ef;                    // e_f = sf^2 hff + mu df^2
+  double *ldinv;                 // 1 / L_ii
+  double *t1, *t2;               // np temporaries
+  double *tf;                    // F temporary
+  double *prdx, *prr;            // prior dx / residual: prior_n each
+  int *prcol;                    // prior column -> reduced parameter (-1 constant): prior_n
+  int *flag;                     // [4] block-uniform flags
+};
+
+VIO_DEV int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kBB; }
+VIO_DEV int off_pose(const WinView &v, int i) { return kBS * i; }  // loop pose: i == P -> 15 P
+VIO_DEV int off_sb(int i) { return kBS * i + 6; }
+// address of element (i, j) of the block-lower matrix, i >= j (diagonal blocks store the full 15x15)
+VIO_DEV double *mat_at(double *Hm, int i, int j) {
+  int bi = i / kBS, bj = j / kBS;
+  return Hm + blk_off(bi, bj) + (i - bi * kBS) * kBS + (j - bj * kBS);
+}
+
+// ---- block reduction: every thread receives the same sum (fixed order => deterministic) -------------
+VIO_DEV double block_sum(const Ctx &cx, double v) {
+#ifdef VIO_EMUL
+  return v;
+#else
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  VIO_SYNC();  // protects cx.red against the previous reduction's readers
+  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = v;
+  VIO_SYNC();
+  double s = 0;
+  for (int w = 0; w < (cx.nt >> 6); w++) s += cx.red[w];
+  return s;
+#endif
+}
+VIO_DEV double block_max(const Ctx &cx, double v) {
+#ifdef VIO_EMUL
+  return v;
+#else
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  VIO_SYNC();
+  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = v;
+  VIO_SYNC();
+  double s = cx.red[0];
+  for (int w = 1; w < (cx.nt >> 6); w++) s = fmax(s, cx.red[w]);
+  return s;
+#endif
+}
+
+// =====================================================================================================
+// Factors
+// =====================================================================================================
+
+// ProjectionFactor::Evaluate (projection_facor.cpp:16-99) in local coordinates. Jex optional.
+VIO_DEV void projection_eval(double s_info, const double *pose_i, const double *pose_j, const double *ex,
+                             double inv_dep, const double *pts_i, const double *pts_j, bool jac, double *r,
+                             double *Ji, double *Jj, double *Jex, double *Jl) {
+  Quat Qi = qfrom_pose(pose_i), Qj = qfrom_pose(pose_j), qic = qfrom_pose(ex);
+  double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};
+  double t[3], p_imu_i[3], p_w[3], p_imu_j[3], p_c_j[3];
+  qrot(qic, pc_i, t);
+  for (int k = 0; k < 3; k++) p_imu_i[k] = t[k] + ex[k];
+  qrot(Qi, p_imu_i, t);
+  for (int k = 0; k < 3; k++) p_w[k] = t[k] + pose_i[k];
+  double d[3] = {p_w[0] - pose_j[0], p_w[1] - pose_j[1], p_w[2] - pose_j[2]};
+  qrot(qinv(Qj), d, p_imu_j);
+  double e[3] = {p_imu_j[0] - ex[0], p_imu_j[1] - ex[1], p_imu_j[2] - ex[2]};
+  qrot(qinv(qic), e, p_c_j);
+  double dep_j = p_c_j[2];
+  r[0] = s_info * (p_c_j[0] / dep_j - pts_j[0]);
+  r[1] = s_info * (p_c_j[1] / dep_j - pts_j[1]);
+  if (!jac) return;
+  double Ri[9], Rj[9], ric[9], ricT[9], RjT[9];
+  qtoR(Qi, Ri), qtoR(Qj, Rj), qtoR(qic, ric);
+  mat3T(ric, ricT), mat3T(Rj, RjT);
+  double red[6] = {s_info * (1. / dep_j), 0, s_info * (-p_c_j[0] / (dep_j * dep_j)),
+                   0, s_info * (1. / dep_j), s_info * (-p_c_j[1] / (dep_j * dep_j))};
+  double A[9], B[9], S[9], T9[9];
+  mat3mul(ricT, RjT, A);
+  mat3mul(A, Ri, B);
+  skew3(p_imu_i, S);
+  mat3mul(B, S, T9);
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++) {
+      Ji[i * 6 + j] = red[i * 3] * A[j] + red[i * 3 + 1] * A[3 + j] + red[i * 3 + 2] * A[6 + j];
+      Ji[i * 6 + 3 + j] = -(red[i * 3] * T9[j] + red[i * 3 + 1] * T9[3 + j] + red[i * 3 + 2] * T9[6 + j]);
+    }
+  skew3(p_imu_j, S);
+  mat3mul(ricT, S, T9);
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++) {
+      Jj[i * 6 + j] = -(red[i * 3] * A[j] + red[i * 3 + 1] * A[3 + j] + red[i * 3 + 2] * A[6 + j]);
+      Jj[i * 6 + 3 + j] = red[i * 3] * T9[j] + red[i * 3 + 1] * T9[3 + j] + red[i * 3 + 2] * T9[6 + j];
+    }
+  double Bric[9], v3[3];
+  mat3mul(B, ric, Bric);
+  if (Jex) {  // projection_facor.cpp:76-86 (the extrinsic is a kept block of the marginalization prior)
+    double RjTRi[9], M1[9], C1[9], Spc[9], T1[9], v[3], Sv[9], u[3], w3[3], Sw[9];
+    mat3mul(RjT, Ri, RjTRi);
+    for (int i = 0; i < 9; i++) M1[i] = RjTRi[i] - (i % 4 == 0);
+    mat3mul(ricT, M1, C1);
+    skew3(pc_i, Spc);
+    mat3mul(Bric, Spc, T1);
+    mat3vec(Bric, pc_i, v);
+    skew3(v, Sv);
+    mat3vec(Ri, ex, u);
+    for (int k = 0; k < 3; k++) u[k] += pose_i[k] - pose_j[k];
+    mat3vec(RjT, u, w3);
+    for (int k = 0; k < 3; k++) w3[k] -= ex[k];
+    mat3vec(ricT, w3, u);
+    skew3(u, Sw);
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 3; j++) {
+        Jex[i * 6 + j] = red[i * 3] * C1[j] + red[i * 3 + 1] * C1[3 + j] + red[i * 3 + 2] * C1[6 + j];
+        double c0 = -T1[j] + Sv[j] + Sw[j], c1 = -T1[3 + j] + Sv[3 + j] + Sw[3 + j],
+               c2 = -T1[6 + j] + Sv[6 + j] + Sw[6 + j];
+        Jex[i * 6 + 3 + j] = red[i * 3] * c0 + red[i * 3 + 1] * c1 + red[i * 3 + 2] * c2;
+      }
+  }
+  mat3vec(Bric, pts_i, v3);
+  for (int i = 0; i < 2; i++)
+    Jl[i] = (red[i * 3] * v3[0] + red[i * 3 + 1] * v3[1] + red[i * 3 + 2] * v3[2]) * -1.0 / (inv_dep * inv_dep);
+}
+
+// Raw (un-whitened) IMU residual and, if Jraw != NULL, the dense 15x30 Jacobian [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]
+// (imu_factor.h:68-180 before the sqrt_info multiplication; integration_base.h:171-198).
+VIO_DEV void imu_eval_raw(double gravity, const double *pre, const double *pose_i, const double *sb_i,
+                          const double *pose_j, const double *sb_j, double *res, double *Jraw) {
+  const double sum_dt = pre[0];
+  const double *delta_p = pre + 1, *delta_q = pre + 4, *delta_v = pre + 8, *lin_ba = pre + 11, *lin_bg = pre + 14;
+  const double *J = pre + 17;
+  const double *Pi = pose_i, *Pj = pose_j, *Vi = sb_i, *Bai = sb_i + 3, *Bgi = sb_i + 6, *Vj = sb_j,
+               *Baj = sb_j + 3, *Bgj = sb_j + 6;
+  Quat Qi = qfrom_pose(pose_i), Qj = qfrom_pose(pose_j);
+  Quat dq{delta_q[0], delta_q[1], delta_q[2], delta_q[3]};
+  double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      dp_dba[i * 3 + j] = J[(0 + i) * 15 + 9 + j];
+      dp_dbg[i * 3 + j] = J[(0 + i) * 15 + 12 + j];
+      dq_dbg[i * 3 + j] = J[(3 + i) * 15 + 12 + j];
+      dv_dba[i * 3 + j] = J[(6 + i) * 15 + 9 + j];
+      dv_dbg[i * 3 + j] = J[(6 + i) * 15 + 12 + j];
+    }
+  double dba[3], dbg[3], th[3], t1[3], t2[3], cdv[3], cdp[3];
+  for (int k = 0; k < 3; k++) dba[k] = Bai[k] - lin_ba[k], dbg[k] = Bgi[k] - lin_bg[k];
+  mat3vec(dq_dbg, dbg, th);
+  Quat cdq = qmul(dq, Quat{th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0});
+  mat3vec(dv_dba, dba, t1), mat3vec(dv_dbg, dbg, t2);
+  for (int k = 0; k < 3; k++) cdv[k] = delta_v[k] + t1[k] + t2[k];
+  mat3vec(dp_dba, dba, t1), mat3vec(dp_dbg, dbg, t2);
+  for (int k = 0; k < 3; k++) cdp[k] = delta_p[k] + t1[k] + t2[k];
+  const double T = sum_dt;
+  const double G[3] = {0, 0, gravity};
+  Quat Qi_inv = qinv(Qi);
+  double a[3], b[3], ra[3], rb[3];
+  for (int k = 0; k < 3; k++) {
+    a[k] = 0.5 * G[k] * T * T + Pj[k] - Pi[k] - Vi[k] * T;
+    b[k] = G[k] * T + Vj[k] - Vi[k];
+  }
+  qrot(Qi_inv, a, ra), qrot(Qi_inv, b, rb);
+  Quat qr = qmul(qinv(cdq), qmul(Qi_inv, Qj));
+  for (int k = 0; k < 3; k++) {
+    res[0 + k] = ra[k] - cdp[k];
+    res[6 + k] = rb[k] - cdv[k];
+    res[9 + k] = Baj[k] - Bai[k];
+    res[12 + k] = Bgj[k] - Bgi[k];
+  }
+  res[3] = 2 * qr.x, res[4] = 2 * qr.y, res[5] = 2 * qr.z;
+  if (!Jraw) return;
+  for (int i = 0; i < 450; i++) Jraw[i] = 0.0;
+  double Rinv[9], M[9], S[9], Mq[9];
+  qtoR(Qi_inv, Rinv);
+  // columns: pose_i [0,6), sb_i [6,15), pose_j [15,21), sb_j [21,30)
+  const int ld = 30, cpi = 0, csi = 6, cpj = 15, csj = 21;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(0 + i) * ld + cpi + j] = -Rinv[i * 3 + j];
+  skew3(ra, S);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(0 + i) * ld + cpi + 3 + j] = S[i * 3 + j];
+  qleft_qright33(qmul(qinv(Qj), Qi), cdq, M);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(3 + i) * ld + cpi + 3 + j] = -M[i * 3 + j];
+  skew3(rb, S);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(6 + i) * ld + cpi + 3 + j] = S[i * 3 + j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Jraw[(0 + i) * ld + csi + 0 + j] = -Rinv[i * 3 + j] * T;
+      Jraw[(0 + i) * ld + csi + 3 + j] = -dp_dba[i * 3 + j];
+      Jraw[(0 + i) * ld + csi + 6 + j] = -dp_dbg[i * 3 + j];
+      Jraw[(6 + i) * ld + csi + 0 + j] = -Rinv[i * 3 + j];
+      Jraw[(6 + i) * ld + csi + 3 + j] = -dv_dba[i * 3 + j];
+      Jraw[(6 + i) * ld + csi + 6 + j] = -dv_dbg[i * 3 + j];
+      Jraw[(9 + i) * ld + csi + 3 + j] = -(double)(i == j);
+      Jraw[(12 + i) * ld + csi + 6 + j] = -(double)(i == j);
+    }
+  qleft33(qmul(qmul(qinv(Qj), Qi), cdq), M);
+  mat3mul(M, dq_dbg, Mq);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(3 + i) * ld + csi + 6 + j] = -Mq[i * 3 + j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(0 + i) * ld + cpj + j] = Rinv[i * 3 + j];
+  qleft33(qmul(qmul(qinv(cdq), Qi_inv), Qj), M);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Jraw[(3 + i) * ld + cpj + 3 + j] = M[i * 3 + j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Jraw[(6 + i) * ld + csj + 0 + j] = Rinv[i * 3 + j];
+      Jraw[(9 + i) * ld + csj + 3 + j] = (double)(i == j);
+      Jraw[(12 + i) * ld + csj + 6 + j] = (double)(i == j);
+    }
+}
+
+// dx of one prior block (marginalization_factor.cpp:349-367)
+VIO_DEV void prior_block_dx(int gsize, const double *x, const double *x0, double *dx) {
+  if (gsize != 7) {
+    for (int k = 0; k < gsize; k++) dx[k] = x[k] - x0[k];
+    return;
+  }
+  for (int k = 0; k < 3; k++) dx[k] = x[k] - x0[k];
+  Quat q = qmul(qinv(qfrom_pose(x0)), qfrom_pose(x));
+  double sgn = (q.w >= 0) ? 1.0 : -1.0;
+  dx[3] = sgn * 2.0 * q.x, dx[4] = sgn * 2.0 * q.y, dx[5] = sgn * 2.0 * q.z;
+}
+
+// =====================================================================================================
+// One-off setup per solve
+// =====================================================================================================
+
+// cov^-1 for every IMU factor: Gauss-Jordan with partial pivoting on [cov | I] (the same elimination order as the
+// CPU restatement, so the two agree bit for bit), then the lower triangle is mirrored (Eigen's LLT only reads it).
+VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v) {
+  const int W = v.W;
+  VIO_PARFOR(q, W * 450) {
+    int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
+    v.imu_aug[q] = c < 15 ? v.preint[f * kPreintDoubles + 242 + r * 15 + c] : (double)(c - 15 == r);
+  }
+  VIO_SYNC();
+  for (int c = 0; c < 15; c++) {
+    // pivot search + row swap: one thread per factor (15 compares), then normalisation and elimination in parallel
+    VIO_PARFOR(f, W) {
+      double *A = v.imu_aug + f * 450;
+      int piv = c;
+      for (int r = c + 1; r < 15; r++)
+        if (fabs(A[r * 30 + c]) > fabs(A[piv * 30 + c])) piv = r;
+      if (piv != c)
+        for (int j = 0; j < 30; j++) {
+          double t = A[c * 30 + j];
+          A[c * 30 + j] = A[piv * 30 + j];
+          A[piv * 30 + j] = t;
+        }
+      double d = A[c * 30 + c];
+      for (int j = 0; j < 30; j++) A[c * 30 + j] /= d;
+      // stash the multipliers of this column (they are overwritten during elimination)
+      for (int r = 0; r < 15; r++) v.imu_Mr[f * 15 + r] = A[r * 30 + c];
+    }
+    VIO_SYNC();
+    VIO_PARFOR(q, W * 450) {
+      int f = q / 450, e = q % 450, r = e / 30, j = e % 30;
+      if (r != c) {
+        double fac = v.imu_Mr[f * 15 + r];
+        if (fac != 0.0) v.imu_aug[q] -= fac * v.imu_aug[f * 450 + c * 30 + j];
+      }
+    }
+    VIO_SYNC();
+  }
+  VIO_PARFOR(q, W * 225) {
+    int f = q / 225, e = q % 225, r = e / 15, c = e % 15;
+    int rr = r >= c ? r : c, cc = r >= c ? c : r;  // lower triangle mirrored
+    v.imu_info[q] = v.imu_aug[f * 450 + rr * 30 + 15 + cc];
+  }
+  VIO_SYNC();
+}
+
+// Prior constants: column map, J0^T (for coalesced mat-vecs) and H0 = J0^T J0.
+VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, Work &w) {
+  const int n = v.prior_n;
+  if (n <= 0) return;
+  VIO_PARFOR(a, n) w.prcol[a] = -1;
+  VIO_SYNC();
+  VIO_PARFOR(b, v.prior_nb) {
+    int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+    if (kind == 0)
+      for (int k = 0; k < 6; k++) w.prcol[o + k] = off_pose(v, idx) + k;
+    else if (kind == 1)
+      for (int k = 0; k < 9; k++) w.prcol[o + k] = off_sb(idx) + k;
+  }
+  VIO_PARFOR(q, n * n) {
+    int r = q / n, c = q % n;
+    v.prJT[c * n + r] = v.pr_J[q];
+  }
+  VIO_SYNC();
+  VIO_PARFOR(q, n * n) {
+    int a = q / n, b = q % n;
+    double s = 0;
+    for (int k = 0; k < n; k++) s += v.pr_J[k * n + a] * v.pr_J[k * n + b];
+    v.prH0[q] = s;
+  }
+  VIO_SYNC();
+}
+
+// =====================================================================================================
+// Evaluation: cost, and (jac) H -> w.Hm (lower blocks), WT, hff, gp, gf, hdiag
+// =====================================================================================================
+VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *sb,
+                        const double *feat, bool jac) {
+  const int np = v.np;
+  double cost = 0.0;  // per-thread partial, reduced at the end
+  if (jac) {
+    const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
+    VIO_PARFOR(q, nmat) w.Hm[q] = 0.0;
+    VIO_PARFOR(q, np) w.gp[q] = 0.0;
+    VIO_PARFOR(q, v.F) w.gf[q] = 0.0, w.hff[q] = 0.0;
+    VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
+  }
+  // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
+  const int n = v.prior_n;
+  if (n > 0) {
+    VIO_PARFOR(b, v.prior_nb) {
+      int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+      const double *x0 = v.pr_x0 + 9 * b;
+      if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
+      else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
+      else prior_block_dx(7, w.ex, x0, w.prdx + o);
+    }
+    VIO_SYNC();
+    VIO_PARFOR(i, n) {
+      double s = v.pr_r[i];
+      for (int j = 0; j < n; j++) s += v.prJT[j * n + i] * w.prdx[j];
+      w.prr[i] = s;
+      cost += 0.5 * s * s;
+    }
+  }
+  VIO_SYNC();  // Hm / gp zeroed, prr ready
+  if (jac && n > 0) {
+    VIO_PARFOR(a, n) {
+      int pa = w.prcol[a];
+      if (pa >= 0) {
+        double g = 0;
+        for (int k = 0; k < n; k++) g += v.pr_J[k * n + a] * w.prr[k];
+        w.gp[pa] = g;  // unique writer per parameter; factors add atomically after the next barrier
+      }
+    }
+    VIO_PARFOR(q, n * n) {
+      int a = q / n, b = q % n;
+      int pa = w.prcol[a], pb = w.prcol[b];
+      if (pa >= 0 && pb >= 0 && (pa > pb || (pa == pb)))
+        *mat_at(w.Hm, pa, pb) = v.prH0[q];
+      else if (pa >= 0 && pb >= 0 && pa / kBS == pb / kBS)
+        *mat_at(w.Hm, pa, pb) = v.prH0[q];  // upper part of a diagonal block (kept consistent)
+    }
+    VIO_SYNC();
+  }
+  // ---- IMU factors -------------------------------------------------------------------------------
+  VIO_PARFOR(f, v.W) {
+    imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
+                 sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
+  }
+  VIO_SYNC();
+  VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
+    int f = q / 15, r = q % 15;
+    const double *info = v.imu_info + f * 225 + r * 15;
+    const double *rr = v.imu_r + f * 15;
+    double s = 0;
+    for (int k = 0; k < 15; k++) s += info[k] * rr[k];
+    v.imu_Mr[q] = s;
+    cost += 0.5 * s * rr[r];
+  }
+  if (jac) {
+    VIO_PARFOR(q, v.W * 450) {  // M = info * Jraw
+      int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
+      const double *info = v.imu_info + f * 225 + r * 15;
+      const double *Jr = v.imu_J + f * 450 + c;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += info[k] * Jr[k * 30];
+      v.imu_M[q] = s;
+    }
+    VIO_SYNC();
+    VIO_PARFOR(q, v.W * 900) {  // H[15f + a][15f + b] += sum_k Jraw[k][a] M[k][b], lower part (and diag blocks full)
+      int f = q / 900, e = q % 900, a = e / 30, b = e % 30;
+      bool same_blk = (a / 15) == (b / 15);
+      if (a >= b || same_blk) {
+        const double *Ja = v.imu_J + f * 450 + a, *Mb = v.imu_M + f * 450 + b;
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mb[k * 30];
+        if (a >= b) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + a, 15 * f + b), s);
+        else VIO_ATOMIC_ADD(w.Hm + blk_off(f + a / 15, f + a / 15) + (a % 15) * kBS + (b % 15), s);
+      }
+    }
+    VIO_PARFOR(q, v.W * 30) {
+      int f = q / 30, a = q % 30;
+      const double *Ja = v.imu_J + f * 450 + a, *Mr = v.imu_Mr + f * 15;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
+      VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
+    }
+  }
+  // ---- projection factors with CauchyLoss (CSI/loss_function.cc:72-79, CSI/corrector.cc:81-129) -----
+  const double bb = v.cauchy_b, cc = 1.0 / bb;
+  VIO_PARFOR(k, v.M) {
+    int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
+    double r[2], Ji[12], Jj[12], Jl[2];
+    projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, jac, r,
+                    Ji, Jj, nullptr, Jl);
+    double sq = r[0] * r[0] + r[1] * r[1];
+    double sum = 1.0 + sq * cc;
+    double inv = 1.0 / sum;
+    cost += 0.5 * bb * log(sum);
+    if (jac) {
+      double rho1 = fmax(inv, 2.2250738585072014e-308);
+      double sr = sqrt(rho1);
+      for (int q = 0; q < 12; q++) Ji[q] *= sr, Jj[q] *= sr;
+      Jl[0] *= sr, Jl[1] *= sr, r[0] *= sr, r[1] *= sr;
+      int oi = off_pose(v, h), oj = off_pose(v, t);
+      double *Hii = w.Hm + blk_off(oi / kBS, oi / kBS), *Hjj = w.Hm + blk_off(oj / kBS, oj / kBS);
+      for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) {
+          VIO_ATOMIC_ADD(Hii + a * kBS + b, Ji[a] * Ji[b] + Ji[6 + a] * Ji[6 + b]);
+          VIO_ATOMIC_ADD(Hjj + a * kBS + b, Jj[a] * Jj[b] + Jj[6 + a] * Jj[6 + b]);
+        }
+      // cross block in the lower triangle: rows = later frame
+      if (oj > oi) {
+        double *Hji = w.Hm + blk_off(oj / kBS, oi / kBS);
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 6; b++) VIO_ATOMIC_ADD(Hji + a * kBS + b, Jj[a] * Ji[b] + Jj[6 + a] * Ji[6 + b]);
+      } else if (oi > oj) {
+        double *Hij = w.Hm + blk_off(oi / kBS, oj / kBS);
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 6; b++) VIO_ATOMIC_ADD(Hij + a * kBS + b, Ji[a] * Jj[b] + Ji[6 + a] * Jj[6 + b]);
+      }
+      int ri = 6 * h, rj = 6 * t;  // WT rows (t == P for the loop pose)
+      for (int c = 0; c < 6; c++) {
+        VIO_ATOMIC_ADD(w.gp + oi + c, Ji[c] * r[0] + Ji[6 + c] * r[1]);
+        VIO_ATOMIC_ADD(w.gp + oj + c, Jj[c] * r[0] + Jj[6 + c] * r[1]);
+        VIO_ATOMIC_ADD(v.WT + (ri + c) * v.Fpad + f, Ji[c] * Jl[0] + Ji[6 + c] * Jl[1]);
+        VIO_ATOMIC_ADD(v.WT + (rj + c) * v.Fpad + f, Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]);
+      }
+      VIO_ATOMIC_ADD(w.hff + f, Jl[0] * Jl[0] + Jl[1] * Jl[1]);
+      VIO_ATOMIC_ADD(w.gf + f, Jl[0] * r[0] + Jl[1] * r[1]);
+    }
+  }
+  double total = block_sum(cx, cost);  // contains barriers: all atomics above are complete afterwards
+  if (jac) {
+    VIO_PARFOR(i, np) w.hdiag[i] = *mat_at(w.Hm, i, i);
+    VIO_SYNC();
+  }
+  return total;
+}
+
+// =====================================================================================================
+// Linear algebra on the block-lower matrix
+// =====================================================================================================
+
+// In place: Hm <- S Hm S + diag(Dp^2) on the pose side, then subtracts the landmark Schur term
+// sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
+// Returns false if some e_f <= 0.
+VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, double mu) {
+  const int np = v.np, F = v.F;
+  // padding rows/cols of the last block (loop pose uses 6 of 15): unit diagonal
+  const int ntot = v.nblk * kBS;
+  VIO_PARFOR(f, F) {
+    double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
+    w.ef[f] = e;
+    w.tf[f] = w.sf[f] * w.gf[f] / e;  // gs_f / e_f
+  }
+  // scale WT in place: ws[a][f] = WT[a][f] sp[par(a)] sf[f]
+  VIO_PARFOR(q, v.npose6 * v.Fpad) {
+    int a = q / v.Fpad, f = q % v.Fpad;
+    if (f < F) {
+      int fr = a / 6, c = a % 6;
+      v.WT[q] *= w.sp[kBS * fr + c] * w.sf[f];
+    }
+  }
+  const int nblocks = v.nblk * (v.nblk + 1) / 2;
+  VIO_PARFOR(q, nblocks * kBB) {
+    int blk = q / kBB, e = q % kBB, r = e / kBS, c = e % kBS;
+    // invert blk = bi (bi+1)/2 + bj
+    int bi = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= blk) bi++;
+    while (bi * (bi + 1) / 2 > blk) bi--;
+    int bj = blk - bi * (bi + 1) / 2;
+    int i = bi * kBS + r, j = bj * kBS + c;
+    double val = 0.0;
+    if (i < np && j < np) {
+      val = w.sp[i] * w.Hm[q] * w.sp[j];
+      if (i == j) val += mu * w.dp[i] * w.dp[i];
+    } else if (i == j) {
+      val = 1.0;
+    }
+    w.Hm[q] = val;
+  }
+  (void)ntot;
+  VIO_SYNC();
+  bool ok = true;
+  VIO_PARFOR(f, F) if (!(w.ef[f] > 0.0)) w.flag[0] = 1;
+  // Schur term on the pose-pose 6x6 sub-blocks (dense in frames): VALU version, one thread per entry
+  const int n6 = v.npose6;
+  VIO_PARFOR(q, n6 * n6) {
+    int a = q / n6, b = q % n6;
+    int fa = a / 6, fb = b / 6;
+    int i = kBS * fa + a % 6, j = kBS * fb + b % 6;
+    if (i >= j || fa == fb) {
+      const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
+      double s = 0;
+      for (int f = 0; f < F; f++) s += wa[f] * wb[f] / w.ef[f];
+      if (i >= j) *mat_at(w.Hm, i, j) -= s;
+      else w.Hm[blk_off(fa, fa) + (a % 6) * kBS + (b % 6)] -= s;
+    }
+  }
+  VIO_PARFOR(i, np) w.t1[i] = w.sp[i] * w.gp[i];
+  VIO_SYNC();
+  VIO_PARFOR(a, n6) {
+    const double *wa = v.WT + a * v.Fpad;
+    double s = 0;
+    for (int f = 0; f < F; f++) s += wa[f] * w.tf[f];
+    w.t1[kBS * (a / 6) + a % 6] -= s;
+  }
+  VIO_SYNC();
+  if (w.flag[0]) ok = false;
+  return ok;
+}
+
+// Blocked Cholesky (block 15) of the block-lower matrix in place: lower blocks <- L; the strict upper triangle of
+// each diagonal block receives inv(L_kk) transposed, ldinv the reciprocal diagonal. false when a pivot is <= 0
+// (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
+VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w) {
+  const int nb = v.nblk;
+  for (int k = 0; k < nb; k++) {
+    double *D = w.Hm + blk_off(k, k);
+    // (a) diagonal block: factor + invert. Small and serial in nature: one thread (wave-cooperative version later).
+    if (cx.tid == 0) {
+      bool good = true;
+      for (int c = 0; c < kBS && good; c++) {
+        double x = D[c * kBS + c];
+        for (int p = 0; p < c; p++) x -= D[c * kBS + p] * D[c * kBS + p];
+        if (!(x > 0.0)) { good = false; break; }
+        x = sqrt(x);
+        D[c * kBS + c] = x;
+        for (int i = c + 1; i < kBS; i++) {
+          double s = D[i * kBS + c];
+          for (int p = 0; p < c; p++) s -= D[i * kBS + p] * D[c * kBS + p];
+          D[i * kBS + c] = s / x;
+        }
+      }
+      if (!good) w.flag[1] = 1;
+      else {
+        // X = inv(L): X[r][c], r >= c; stored X[r][c] (r > c) at D[c][r], diagonal in ldinv
+        for (int c = 0; c < kBS; c++) {
+          double xc[kBS];
+          for (int r = c; r < kBS; r++) {
+            double s = (r == c) ? 1.0 : 0.0;
+            for (int p = c; p < r; p++) s -= D[r * kBS + p] * xc[p];
+            xc[r] = s / D[r * kBS + r];
+          }
+          w.ldinv[k * kBS + c] = xc[c];
+          for (int r = c + 1; r < kBS; r++) D[c * kBS + r] = xc[r];
+        }
+      }
+    }
+    VIO_SYNC();
+    if (w.flag[1]) return false;
+    // (b) panel: L_ik = A_ik inv(L_kk)^T for i > k. Items are (i, r, c); chunks hold whole rows so that the
+    //     in-place update never reads a value another chunk has already overwritten.
+    const int rows = (nb - k - 1) * kBS;
+    const int chunk_rows = cx.nt / kBS > 0 ? cx.nt / kBS : 1;
+    for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
+      int item = cx.tid;
+      int lr = item / kBS, c = item % kBS;
+      double val = 0;
+      bool active = lr < chunk_rows && r0 + lr < rows;
+      double *Arow = nullptr;
+      if (active) {
+        int gr = r0 + lr;
+        int i = k + 1 + gr / kBS, r = gr % kBS;
+        Arow = w.Hm + blk_off(i, k) + r * kBS;
+        double s = Arow[c] * w.ldinv[k * kBS + c];
+        for (int m = 0; m < c; m++) s += Arow[m] * D[m * kBS + c];  // inv(L)[c][m] stored at D[m][c]
+        val = s;
+      }
+#ifdef VIO_EMUL
+      // one emulated thread: walk the chunk's items sequentially, highest column first (reads only lower columns)
+      for (int it2 = (chunk_rows * kBS) - 1; it2 >= 0; it2--) {
+        int lr2 = it2 / kBS, c2 = it2 % kBS;
+        if (r0 + lr2 >= rows) continue;
+        int gr = r0 + lr2;
+        int i = k + 1 + gr / kBS, r = gr % kBS;
+        double *Ar = w.Hm + blk_off(i, k) + r * kBS;
+        double s = Ar[c2] * w.ldinv[k * kBS + c2];
+        for (int m = 0; m < c2; m++) s += Ar[m] * D[m * kBS + c2];
+        Ar[c2] = s;
+      }
+      (void)val, (void)Arow, (void)active;
+#else
+      VIO_SYNC();
+      if (active) Arow[c] = val;
+      VIO_SYNC();
+#endif
+    }
+    // (c) trailing update: A_ij -= L_ik L_jk^T for i >= j > k
+    const int nt_blk = nb - k - 1;
+    const int npairs = nt_blk * (nt_blk + 1) / 2;
+    VIO_PARFOR(q, npairs * kBB) {
+      int pr = q / kBB, e = q % kBB, r = e / kBS, c = e % kBS;
+      int li = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+      while ((li + 1) * (li + 2) / 2 <= pr) li++;
+      while (li * (li + 1) / 2 > pr) li--;
+      int lj = pr - li * (li + 1) / 2;
+      int i = k + 1 + li, j = k + 1 + lj;
+      const double *Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
+      double s = 0;
+      for (int m = 0; m < kBS; m++) s += Li[m] * Lj[m];
+      w.Hm[blk_off(i, j) + e] -= s;
+    }
+    VIO_SYNC();
+  }
+  return true;
+}
+
+// x <- (L L^T)^-1 x on w.t1 (length nblk*15; padding entries are zero)
+VIO_DEV void cholesky_solve(const Ctx &cx, const WinView &v, Work &w, double *x) {
+  const int nb = v.nblk;
+  // forward: L y = b
+  for (int k = 0; k < nb; k++) {
+    const double *D = w.Hm + blk_off(k, k);
+    // y_k = inv(L_kk) b_k
+    double yv = 0;
+    if (cx.tid < kBS) {
+      int r = cx.tid;
+      double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
+      for (int c = 0; c < r; c++) s += D[c * kBS + r] * x[k * kBS + c];
+      yv = s;
+    }
+#ifdef VIO_EMUL
+    {
+      double tmp[kBS];
+      for (int r = 0; r < kBS; r++) {
+        double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
+        for (int c = 0; c < r; c++) s += D[c * kBS + r] * x[k * kBS + c];
+        tmp[r] = s;
+      }
+      for (int r = 0; r < kBS; r++) x[k * kBS + r] = tmp[r];
+      (void)yv;
+    }
+#else
+    VIO_SYNC();
+    if (cx.tid < kBS) x[k * kBS + cx.tid] = yv;
+    VIO_SYNC();
+#endif
+    VIO_PARFOR(q, (nb - k - 1) * kBS) {
+      int i = k + 1 + q / kBS, r = q % kBS;
+      const double *Lr = w.Hm + blk_off(i, k) + r * kBS;
+      double s = 0;
+      for (int m = 0; m < kBS; m++) s += Lr[m] * x[k * kBS + m];
+      x[i * kBS + r] -= s;
+    }
+    VIO_SYNC();
+  }
+  // backward: L^T z = y
+  for (int k = nb - 1; k >= 0; k--) {
+    const double *D = w.Hm + blk_off(k, k);
+    // z_k = inv(L_kk)^T y_k : z[r] = sum_{c >= r} X[c][r] y[c]
+    double zv = 0;
+    if (cx.tid < kBS) {
+      int r = cx.tid;
+      double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
+      for (int c = r + 1; c < kBS; c++) s += D[r * kBS + c] * x[k * kBS + c];  // X[c][r] stored at D[r][c]
+      zv = s;
+    }
+#ifdef VIO_EMUL
+    {
+      double tmp[kBS];
+      for (int r = 0; r < kBS; r++) {
+        double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
+        for (int c = r + 1; c < kBS; c++) s += D[r * kBS + c] * x[k * kBS + c];
+        tmp[r] = s;
+      }
+      for (int r = 0; r < kBS; r++) x[k * kBS + r] = tmp[r];
+      (void)zv;
+    }
+#else
+    VIO_SYNC();
+    if (cx.tid < kBS) x[k * kBS + cx.tid] = zv;
+    VIO_SYNC();
+#endif
+    // y_j -= L_kj^T z_k for j < k
+    VIO_PARFOR(q, k * kBS) {
+      int j = q / kBS, c = q % kBS;
+      const double *Lkj = w.Hm + blk_off(k, j);
+      double s = 0;
+      for (int m = 0; m < kBS; m++) s += Lkj[m * kBS + c] * x[k * kBS + m];
+      x[j * kBS + c] -= s;
+    }
+    VIO_SYNC();
+  }
+}
+
+// q(v) = v^T (S H S + mu D^2) v through the factorization: sum_f e_f (v_f + ws_f^T v_p / e_f)^2 + |L^T v_p|^2
+VIO_DEV double quad_form(const Ctx &cx, const WinView &v, Work &w, const double *vp, const double *vf) {
+  const int np = v.np, F = v.F;
+  double acc = 0;
+  VIO_PARFOR(f, F) {
+    double s = 0;
+    for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * vp[kBS * (a / 6) + a % 6];
+    double u = vf[f] + s / w.ef[f];
+    acc += w.ef[f] * u * u;
+  }
+  VIO_PARFOR(j, np) {
+    // (L^T v)_j = sum_{i >= j} L[i][j] v_i
+    int bj = j / kBS, cj = j % kBS;
+    double s = 0;
+    const double *D = w.Hm + blk_off(bj, bj);
+    for (int r = cj; r < kBS; r++) {
+      int i = bj * kBS + r;
+      if (i < np) s += D[r * kBS + cj] * vp[i];
+    }
+    for (int bi = bj + 1; bi < v.nblk; bi++) {
+      const double *B = w.Hm + blk_off(bi, bj);
+      for (int r = 0; r < kBS; r++) {
+        int i = bi * kBS + r;
+        if (i < np) s += B[r * kBS + cj] * vp[i];
+      }
+    }
+    acc += s * s;
+  }
+  return block_sum(cx, acc);
+}
+
+// PoseLocalParameterization::Plus on all blocks: c = x [+] (delta_p, delta_f)
+VIO_DEV void apply_plus(const Ctx &cx, const WinView &v, Work &w, const double *dpv, const double *dfv) {
+  const int npose = v.P + v.has_loop;
+  VIO_PARFOR(i, npose) {
+    const double *p0 = w.xpose + 7 * i;
+    const double *d = dpv + off_pose(v, i);
+    double *p = w.cpose + 7 * i;
+    for (int k = 0; k < 3; k++) p[k] = p0[k] + d[k];
+    Quat q = qnormalized(qmul(qfrom_pose(p0), Quat{d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0}));
+    p[3] = q.x, p[4] = q.y, p[5] = q.z, p[6] = q.w;
+  }
+  VIO_PARFOR(q, v.P * 9) w.csb[q] = w.xsb[q] + dpv[off_sb(q / 9) + q % 9];
+  VIO_PARFOR(f, v.F) w.cfeat[f] = w.xfeat[f] + dfv[f];
+  VIO_SYNC();
+}
+
+// norms over the reduced program's (global-size) parameters: |a - b|_2 / |a - b|_inf / |a|_2
+VIO_DEV void state_norms(const Ctx &cx, const WinView &v, const double *apose, const double *asb, const double *afeat,
+                         const double *bpose, const double *bsb, const double *bfeat, double *l2, double *linf) {
+  double s = 0, m = 0;
+  const int npose = v.P + v.has_loop;
+  VIO_PARFOR(q, npose * 7) {
+    double d = apose[q] - (bpose ? bpose[q] : 0.0);
+    s += d * d, m = fmax(m, fabs(d));
+  }
+  VIO_PARFOR(q, v.P * 9) {
+    double d = asb[q] - (bsb ? bsb[q] : 0.0);
+    s += d * d, m = fmax(m, fabs(d));
+  }
+  VIO_PARFOR(q, v.F) {
+    double d = afeat[q] - (bfeat ? bfeat[q] : 0.0);
+    s += d * d, m = fmax(m, fabs(d));
+  }
+  *l2 = sqrt(block_sum(cx, s));
+  if (linf) *linf = block_max(cx, m);
+}
+
+// =====================================================================================================
+// TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
+// =====================================================================================================
+VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
+  const int np = v.np, F = v.F;
+  double *sd = v.stats_d;
+  int *si = v.stats_i;
+  auto record = [&](int i, double cost, double radius, double step_norm, double rel, double gmax, bool valid,
+                    bool ok) {
+    if (cx.tid == 0 && i < kMaxTrace) {
+      sd[4 + i] = cost, sd[4 + kMaxTrace + i] = radius, sd[4 + 2 * kMaxTrace + i] = step_norm;
+      sd[4 + 3 * kMaxTrace + i] = rel, sd[4 + 4 * kMaxTrace + i] = gmax;
+      si[4 + i] = (valid ? 1 : 0) | (ok ? 2 : 0);
+    }
+  };
+  // |x - Plus(x, -g)|_inf (trust_region_minimizer.cc:270-284)
+  auto grad_max_norm = [&]() {
+    VIO_PARFOR(i, np) w.t2[i] = -w.gp[i];
+    VIO_PARFOR(f, F) w.tf[f] = -w.gf[f];
+    VIO_SYNC();
+    apply_plus(cx, v, w, w.t2, w.tf);
+    double l2, linf;
+    state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &l2, &linf);
+    return linf;
+  };
+
+  double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+  double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
+  VIO_PARFOR(i, np) w.sp[i] = 1.0 / (1.0 + sqrt(w.hdiag[i]));  // Jacobi scaling, :239-254
+  VIO_PARFOR(f, F) w.sf[f] = 1.0 / (1.0 + sqrt(w.hff[f]));
+  VIO_SYNC();
+  double gmax = grad_max_norm();
+  double radius = 1e4, mu = 1e-8;
+  const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
+  bool reuse = false, last_ok = true, have_factor = false;
+  double dogleg_step_norm = 0, alpha = 0;
+  int it = 0, n_ok = 1, n_bad = 0, invalid_run = 0, termination = 0, recorded = 1;
+  double ev_min = x_cost, ev_cur = x_cost, ev_ref = x_cost, ev_cand = x_cost, ev_acc_ref = 0, ev_acc_cand = 0;
+  double min_rec = x_cost;
+  record(0, x_cost, radius, 0, 0, gmax, true, true);
+  if (cx.tid == 0) sd[0] = x_cost;
+  double gd_sq = 0, mu_used = mu;
+
+  while (true) {
+    if (it >= v.max_iter) break;
+    if (last_ok && gmax <= 1e-10) { termination = 1; break; }
+    if (radius <= 1e-32) { termination = 1; break; }
+    it++;
+    bool solver_ok = true;
+    if (!reuse) {
+      reuse = true;
+      double part = 0;
+      VIO_PARFOR(i, np) {
+        double c = w.sp[i] * w.sp[i] * w.hdiag[i];
+        double d = sqrt(fmin(fmax(c, 1e-6), 1e32));
+        w.dp[i] = d;
+        double g = w.sp[i] * w.gp[i] / d;
+        w.gdp[i] = g;
+        part += g * g;
+      }
+      VIO_PARFOR(f, F) {
+        double c = w.sf[f] * w.sf[f] * w.hff[f];
+        double d = sqrt(fmin(fmax(c, 1e-6), 1e32));
+        w.df[f] = d;
+        double g = w.sf[f] * w.gf[f] / d;
+        w.gdf[f] = g;
+        part += g * g;
+      }
+      gd_sq = block_sum(cx, part);
+      // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
+      solver_ok = false;
+      bool first_try = true;
+      while (mu < max_mu) {
+        if (!first_try) {
+          // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
+          evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+        }
+        first_try = false;
+        if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
+        VIO_SYNC();
+        bool ok = build_reduced_system(cx, v, w, mu);
+        if (ok) ok = cholesky_blocks(cx, v, w);
+        if (ok) {
+          cholesky_solve(cx, v, w, w.t1);  // y_p
+          // back-substitute features: y_f = (gs_f - ws_f^T y_p) / e_f ; GN = -d * y
+          double bad = 0;
+          VIO_PARFOR(f, F) {
+            double s = 0;
+            for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * w.t1[kBS * (a / 6) + a % 6];
+            double y = w.tf[f] - s / w.ef[f];
+            w.gnf[f] = -w.df[f] * y;
+            if (!isfinite(y)) bad = 1;
+          }
+          VIO_PARFOR(i, np) {
+            double y = w.t1[i];
+            w.gnp[i] = -w.dp[i] * y;
+            if (!isfinite(y)) bad = 1;
+          }
+          if (block_max(cx, bad) > 0) ok = false;
+        }
+        if (ok) { solver_ok = true; mu_used = mu; have_factor = true; break; }
+        mu *= mu_inc;
+      }
+      if (solver_ok) {
+        // Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192)
+        double part2 = 0;
+        VIO_PARFOR(i, np) {
+          double u = w.gdp[i] / w.dp[i];
+          w.t2[i] = u;
+          part2 += mu_used * w.dp[i] * w.dp[i] * u * u;
+        }
+        VIO_PARFOR(f, F) {
+          double u = w.gdf[f] / w.df[f];
+          w.stf[f] = u;
+          part2 += mu_used * w.df[f] * w.df[f] * u * u;
+        }
+        VIO_SYNC();
+        double reg = block_sum(cx, part2);
+        double qf = quad_form(cx, v, w, w.t2, w.stf);
+        alpha = gd_sq / (qf - reg);
+      }
+    }
+    (void)have_factor;
+    bool step_valid = false;
+    double model_cost_change = 0;
+    if (solver_ok) {
+      // ComputeTraditionalDoglegStep (dogleg_strategy.cc:199-255)
+      double p1 = 0, p2 = 0;
+      VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += w.gdp[i] * w.gnp[i];
+      VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += w.gdf[f] * w.gnf[f];
+      double gnn2 = block_sum(cx, p1), gdot = block_sum(cx, p2);
+      double gradient_norm = sqrt(gd_sq), gauss_newton_norm = sqrt(gnn2);
+      double ca, cb;
+      bool need_norm = false;
+      if (gauss_newton_norm <= radius) {
+        ca = 0, cb = 1, dogleg_step_norm = gauss_newton_norm;
+      } else if (gradient_norm * alpha >= radius) {
+        ca = -(radius / gradient_norm), cb = 0, dogleg_step_norm = radius;
+      } else {
+        double b_dot_a = -alpha * gdot;
+        double a_squared_norm = pow(alpha * gradient_norm, 2.0);
+        double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + pow(gauss_newton_norm, 2);
+        double c = b_dot_a - a_squared_norm;
+        double d = sqrt(c * c + b_minus_a_squared_norm * (pow(radius, 2.0) - a_squared_norm));
+        double beta = (c <= 0) ? (d - c) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d + c);
+        ca = -alpha * (1.0 - beta), cb = beta;
+        need_norm = true;
+      }
+      double pn = 0, psg = 0, preg = 0;
+      VIO_PARFOR(i, np) {
+        double s = ca * w.gdp[i] + cb * w.gnp[i];
+        pn += s * s;
+        double st = s / w.dp[i];
+        w.stp[i] = st;
+        psg += st * w.sp[i] * w.gp[i];
+        preg += mu_used * w.dp[i] * w.dp[i] * st * st;
+      }
+      VIO_PARFOR(f, F) {
+        double s = ca * w.gdf[f] + cb * w.gnf[f];
+        pn += s * s;
+        double st = s / w.df[f];
+        w.stf[f] = st;
+        psg += st * w.sf[f] * w.gf[f];
+        preg += mu_used * w.df[f] * w.df[f] * st * st;
+      }
+      VIO_SYNC();
+      double n2 = block_sum(cx, pn), sg = block_sum(cx, psg), reg = block_sum(cx, preg);
+      if (need_norm) dogleg_step_norm = sqrt(n2);
+      // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416)
+      double shs = quad_form(cx, v, w, w.stp, w.stf) - reg;
+      model_cost_change = -sg - 0.5 * shs;
+      step_valid = model_cost_change > 0.0;
+    }
+    if (!step_valid) {
+      if (++invalid_run >= 5) { termination = 2; break; }
+      mu *= mu_inc;
+      reuse = false;
+      last_ok = false;
+      n_bad++;
+      record(it, x_cost, radius, 0, 0, gmax, false, false);
+      recorded = it + 1, min_rec = fmin(min_rec, x_cost);
+      // the matrix buffer holds a factorization: H must be rebuilt before the next build_reduced_system
+      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+      continue;
+    }
+    invalid_run = 0;
+    VIO_PARFOR(i, np) w.t2[i] = w.stp[i] * w.sp[i];  // delta = step * scale
+    VIO_PARFOR(f, F) w.tf[f] = w.stf[f] * w.sf[f];
+    VIO_SYNC();
+    apply_plus(cx, v, w, w.t2, w.tf);
+    double cand_cost = evaluate(cx, v, w, w.cpose, w.csb, w.cfeat, false);
+    if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    double step_norm, dummy;
+    state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { termination = 1; break; }      // ParameterToleranceReached
+    double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * x_cost) { termination = 1; break; }       // FunctionToleranceReached
+    double rel = (ev_cur - cand_cost) / model_cost_change;                    // StepQuality
+    double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
+    double rho = fmax(rel, hist);
+    if (rho > 1e-3) {
+      VIO_PARFOR(q, (v.P + v.has_loop) * 7) w.xpose[q] = w.cpose[q];
+      VIO_PARFOR(q, v.P * 9) w.xsb[q] = w.csb[q];
+      VIO_PARFOR(q, F) w.xfeat[q] = w.cfeat[q];
+      VIO_SYNC();
+      state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
+      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+      gmax = grad_max_norm();
+      if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
+      if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
+      mu = fmax(min_mu, 2.0 * mu / mu_inc);
+      reuse = false;
+      ev_cur = cand_cost, ev_acc_cand += model_cost_change, ev_acc_ref += model_cost_change;
+      if (ev_cur < ev_min) ev_min = ev_cur, ev_cand = ev_cur, ev_acc_cand = 0;
+      else if (ev_cur > ev_cand) ev_cand = ev_cur, ev_acc_cand = 0;
+      ev_ref = ev_cand, ev_acc_ref = ev_acc_cand;
+      last_ok = true;
+      n_ok++;
+      record(it, x_cost, radius, step_norm, rho, gmax, true, true);
+      recorded = it + 1, min_rec = fmin(min_rec, x_cost);
+    } else {
+      radius *= 0.5;                                                          // StepRejected
+      reuse = true;
+      last_ok = false;
+      n_bad++;
+      record(it, cand_cost, radius, step_norm, rho, 0.0, true, false);
+      recorded = it + 1, min_rec = fmin(min_rec, cand_cost);
+    }
+  }
+  if (cx.tid == 0) {
+    sd[1] = min_rec;
+    si[0] = recorded, si[1] = termination, si[2] = n_ok, si[3] = n_bad;
+  }
+  VIO_SYNC();
+}
+
+// =====================================================================================================
+// Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs
+// =====================================================================================================
+VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
+  const int P = v.P, F = v.F;
+  VIO_PARFOR(q, P * 7) w.xpose[q] = v.pose0[q];
+  VIO_PARFOR(q, P * 9) w.xsb[q] = v.sb0[q];
+  VIO_PARFOR(q, F) w.xfeat[q] = v.feat0[q];
+  VIO_PARFOR(q, 7) w.ex[q] = v.ex[q];
+  if (v.has_loop) VIO_PARFOR(q, 7) w.xpose[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
+  VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
+  if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
+  VIO_SYNC();
+  setup_imu_info(cx, v);
+  setup_prior(cx, v, w);
+
+  minimize(cx, v, w);
+
+  VIO_PARFOR(q, P * 7) v.raw_pose[q] = w.xpose[q];
+  VIO_PARFOR(q, P * 9) v.raw_sb[q] = w.xsb[q];
+  VIO_PARFOR(q, F) v.raw_feat[q] = w.xfeat[q];
+  if (v.has_loop) VIO_PARFOR(q, 7) v.out_loop[q] = w.xpose[7 * P + q];
+  VIO_SYNC();
+  // ---- new2old (VINS.cpp:131-212) followed by old2new (VINS.cpp:89-129) ----------------------------
+  double R0in[9], ypr0[3], R00[9], ypr00[3], rot_diff[9];
+  qtoR(qnormalized(qfrom_pose(v.pose0)), R0in);
+  R2ypr(R0in, ypr0);
+  double origin_yaw = v.use_origin ? v.origin_yaw : ypr0[0];
+  double op[3] = {v.use_origin ? v.origin_p[0] : v.pose0[0], v.use_origin ? v.origin_p[1] : v.pose0[1],
+                  v.use_origin ? v.origin_p[2] : v.pose0[2]};
+  qtoR(qfrom_pose(w.xpose), R00);
+  R2ypr(R00, ypr00);
+  double yd[3] = {origin_yaw - ypr00[0], 0, 0};
+  ypr2R(yd, rot_diff);
+  double p0[3] = {w.xpose[0], w.xpose[1], w.xpose[2]};
+  VIO_SYNC();
+  VIO_PARFOR(i, P) {
+    const double *pp = w.xpose + 7 * i, *sbv = w.xsb + 9 * i;
+    double Rq[9], Rs[9], d[3] = {pp[0] - p0[0], pp[1] - p0[1], pp[2] - p0[2]}, Ps[3], Vs[3];
+    qtoR(qnormalized(qfrom_pose(pp)), Rq);
+    mat3mul(rot_diff, Rq, Rs);
+    mat3vec(rot_diff, d, Ps);
+    mat3vec(rot_diff, sbv, Vs);
+    Quat q = RtoQ(Rs);
+    double *po = w.cpose + 7 * i, *so = w.csb + 9 * i;
+    for (int k = 0; k < 3; k++) po[k] = Ps[k] + op[k], so[k] = Vs[k];
+    po[3] = q.x, po[4] = q.y, po[5] = q.z, po[6] = q.w;
+    for (int k = 3; k < 9; k++) so[k] = sbv[k];
+  }
+  VIO_PARFOR(f, F) {  // setDepth / getDepthVector round trip (feature_manager.cpp:300-349)
+    double estimated_depth = 1.0 / w.xfeat[f];
+    w.cfeat[f] = 1. / estimated_depth;
+  }
+  VIO_SYNC();
+  VIO_PARFOR(q, P * 7) v.out_pose[q] = w.cpose[q], w.xpose[q] = w.cpose[q];
+  VIO_PARFOR(q, P * 9) v.out_sb[q] = w.csb[q], w.xsb[q] = w.csb[q];
+  VIO_PARFOR(q, F) v.out_feat[q] = w.cfeat[q], w.xfeat[q] = w.cfeat[q];
+  VIO_SYNC();
+}
+
+}  // namespace vio

@@ -1,0 +1,389 @@
+// vio_backend.hip — gfx950 kernels and C ABI of the sliding-window back-end (include/vio_amd.h).
+//
+// One workgroup (512 threads = 8 wave64) owns one window for the whole of VINS::solve_ceres
+// (VINS_ios/VINS.cpp:480-831): solve, new2old, marginalization. The reduced 15(W+1) system lives in LDS
+// (119 KB of the CU's 160 KB at W = 10); the batch of independent sequences is the grid, so a launch of >= 256
+// windows fills the chip and each XCD's L2 only ever sees its own windows' scratch.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "batch.h"
+#include "marg_core.h"
+#include "vio_amd.h"
+
+using namespace vio;
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr size_t kLdsLimit = 160 * 1024;
+
+struct MargPtrs {
+  int *ints;        // [n][4 + 3 * kMaxPriorBlocks]
+  double *x0;       // [n][9 * kMaxPriorBlocks]
+  double *J;        // [n][Ncap * Ncap]
+  double *r;        // [n][Ncap]
+  double *scratch;  // [n][marg_scratch] (global matrix variant only)
+  size_t s_ints, s_x0, s_J, s_r, s_scratch;
+};
+
+template <bool LDS_MATRIX>
+__global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargPtrs MP) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = blockIdx.x;
+  WinView v = make_view(B, b);
+  Work w;
+  Ctx cx;
+  cx.tid = threadIdx.x, cx.nt = blockDim.x;
+  size_t state_end = 0;
+  carve_work(B.d, LDS_MATRIX, blockDim.x, smem, B.hm + (size_t)b * B.s.hm, &w, &cx, &state_end);
+  solve_window(cx, v, w);
+
+  MargOut mo;
+  int *mi = MP.ints + (size_t)b * MP.s_ints;
+  mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
+  mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
+  mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
+  mo.ncap = B.d.Ncap;
+  MargWork mw;
+  carve_marg(B.d, LDS_MATRIX, smem + state_end, mo.scratch, &mw);
+  __syncthreads();
+  marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
+}
+
+#define HIP_OK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      fprintf(stderr, "vio_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return VIO_ENODEV;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n && p) return VIO_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return VIO_ENOMEM;
+    n = count;
+    return VIO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+  }
+};
+
+}  // namespace
+
+struct vio_backend {
+  VioConfig cfg;
+  int max_batch = 0;
+  hipStream_t stream = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  // current batch
+  int n = 0;
+  bool uploaded = false;
+  bool lds_matrix = true;
+  size_t lds_bytes = 0;
+  HostBatch hb;
+  BatchPtrs B;
+  MargPtrs MP;
+  DevBuf<int> d_hdr, d_fhost, d_ftarget, d_ffeat, d_pr_kind, d_pr_index, d_pr_offset, d_stats_i, d_m_ints;
+  DevBuf<double> d_hdr_d, d_pose, d_sb, d_ex, d_feat, d_pts_i, d_pts_j, d_preint, d_pr_x0, d_pr_J, d_pr_r, d_scratch,
+      d_hm, d_out_pose, d_out_sb, d_out_feat, d_raw_pose, d_raw_sb, d_raw_feat, d_out_loop, d_stats_d, d_m_x0, d_m_J,
+      d_m_r, d_m_scratch;
+  // host copies of the outputs
+  std::vector<double> h_out_pose, h_out_sb, h_out_feat, h_raw_pose, h_raw_sb, h_raw_feat, h_out_loop, h_stats_d, h_m_x0,
+      h_m_J, h_m_r;
+  std::vector<int> h_stats_i, h_m_ints;
+};
+
+extern "C" {
+
+const char *vio_version(void) { return "vio_amd 0.1 (gfx950)"; }
+
+void vio_config_default(VioConfig *c) {
+  // iPhone7P, global_param.cpp:27-42; feature_tracker.hpp:24-29; global_param.hpp:28-58
+  c->window_size = 10, c->max_features = 1000, c->max_factors = 8192, c->max_iterations = 10;
+  c->image_rows = 640, c->image_cols = 480, c->max_corners = 70, c->min_dist = 30, c->freq = 3;
+  c->lk_win = 21, c->lk_levels = 3, c->lk_max_iters = 30, c->lk_eps = 0.01, c->lk_min_eig = 1e-4;
+  c->quality_level = 0.01, c->f_threshold = 1.0, c->f_confidence = 0.99;
+  c->fx = 526.600, c->fy = 526.678, c->cx = 243.481, c->cy = 315.280;
+  c->gravity = 9.805, c->acc_n = 0.5, c->acc_w = 0.002, c->gyr_n = 0.2, c->gyr_w = 4.0e-5, c->cauchy_a = 1.0;
+}
+
+int32_t vio_prior_capacity(int32_t window_size) { return 15 * (window_size + 1) + 6; }
+
+int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **out) {
+  if (!cfg || !out || max_batch < 1) return VIO_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    fprintf(stderr, "vio_amd: no HIP device visible; the back-end has no CPU fallback\n");
+    return VIO_ENODEV;
+  }
+  vio_backend *be = new vio_backend();
+  be->cfg = *cfg;
+  be->max_batch = max_batch;
+  if (hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete be;
+    return VIO_ENODEV;
+  }
+  *out = be;
+  return VIO_OK;
+}
+
+void vio_backend_destroy(vio_backend_t *be) {
+  if (!be) return;
+  (void)hipStreamSynchronize(be->stream);
+  for (auto &e : be->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
+  DevBuf<int> *ib[] = {&be->d_hdr, &be->d_fhost, &be->d_ftarget, &be->d_ffeat, &be->d_pr_kind, &be->d_pr_index,
+                       &be->d_pr_offset, &be->d_stats_i, &be->d_m_ints};
+  for (auto *b : ib) b->release();
+  DevBuf<double> *db[] = {&be->d_hdr_d, &be->d_pose, &be->d_sb, &be->d_ex, &be->d_feat, &be->d_pts_i, &be->d_pts_j,
+                          &be->d_preint, &be->d_pr_x0, &be->d_pr_J, &be->d_pr_r, &be->d_scratch, &be->d_hm,
+                          &be->d_out_pose, &be->d_out_sb, &be->d_out_feat, &be->d_raw_pose, &be->d_raw_sb,
+                          &be->d_raw_feat, &be->d_out_loop, &be->d_stats_d, &be->d_m_x0, &be->d_m_J, &be->d_m_r,
+                          &be->d_m_scratch};
+  for (auto *b : db) b->release();
+  (void)hipStreamDestroy(be->stream);
+  delete be;
+}
+
+int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
+  if (!be || !windows || n < 1) return VIO_EINVAL;
+  if (n > be->max_batch) return VIO_ECAP;
+  int Wmax = 1, Fmax = 1, Mmax = 1, Nmax = 0;
+  bool any_loop = false;
+  for (int b = 0; b < n; b++) {
+    const VioWindow &w = windows[b];
+    if (w.window_size < 1 || w.n_features < 0 || w.n_factors < 0) return VIO_EINVAL;
+    if (w.window_size > be->cfg.window_size || w.n_features > be->cfg.max_features ||
+        w.n_factors > be->cfg.max_factors)
+      return VIO_ECAP;
+    Wmax = std::max(Wmax, w.window_size), Fmax = std::max(Fmax, w.n_features), Mmax = std::max(Mmax, w.n_factors);
+    if (w.prior) Nmax = std::max(Nmax, w.prior->n);
+    if (w.factor_target)
+      for (int k = 0; k < w.n_factors; k++)
+        if (w.factor_target[k] == w.window_size + 1) any_loop = true;
+  }
+  BatchDims d = make_dims(be->cfg, Wmax, Fmax, Mmax, any_loop);
+  d.Ncap = std::max(6 * Wmax + 15, Nmax);
+  be->hb.resize(d, n);
+  for (int b = 0; b < n; b++) {
+    int rc = pack_window(be->hb, b, windows[b]);
+    if (rc != VIO_OK) return rc;
+  }
+  const BatchStrides &s = be->hb.s;
+  // LDS or global matrix: both phases must fit the CU's 160 KB
+  size_t state_end = 0;
+  size_t bytes_solver = carve_work(d, true, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
+  size_t bytes_marg = state_end * sizeof(double) + carve_marg(d, true, (double *)nullptr, nullptr, nullptr);
+  be->lds_matrix = std::max(bytes_solver, bytes_marg) <= kLdsLimit;
+  if (!be->lds_matrix) {
+    bytes_solver = carve_work(d, false, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
+    bytes_marg = state_end * sizeof(double) + carve_marg(d, false, (double *)nullptr, nullptr, nullptr);
+    if (std::max(bytes_solver, bytes_marg) > kLdsLimit) return VIO_ECAP;
+  }
+  be->lds_bytes = std::max(bytes_solver, bytes_marg);
+
+  const size_t N = (size_t)n;
+  const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
+#define ENSURE(buf, count)                 \
+  do {                                     \
+    int rc_ = (buf).ensure(count);         \
+    if (rc_ != VIO_OK) return rc_;         \
+  } while (0)
+  ENSURE(be->d_hdr, N * kHdrInts);
+  ENSURE(be->d_hdr_d, N * kHdrDoubles);
+  ENSURE(be->d_pose, N * s.pose);
+  ENSURE(be->d_sb, N * s.sb);
+  ENSURE(be->d_ex, N * s.ex);
+  ENSURE(be->d_feat, N * s.feat);
+  ENSURE(be->d_fhost, N * s.fint);
+  ENSURE(be->d_ftarget, N * s.fint);
+  ENSURE(be->d_ffeat, N * s.fint);
+  ENSURE(be->d_pts_i, N * s.pts);
+  ENSURE(be->d_pts_j, N * s.pts);
+  ENSURE(be->d_preint, N * s.preint);
+  ENSURE(be->d_pr_kind, N * s.pr_int);
+  ENSURE(be->d_pr_index, N * s.pr_int);
+  ENSURE(be->d_pr_offset, N * s.pr_int);
+  ENSURE(be->d_pr_x0, N * s.pr_x0);
+  ENSURE(be->d_pr_J, N * s.pr_J);
+  ENSURE(be->d_pr_r, N * s.pr_r);
+  ENSURE(be->d_scratch, N * s.scratch);
+  ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);
+  ENSURE(be->d_out_pose, N * s.out_pose);
+  ENSURE(be->d_out_sb, N * s.out_sb);
+  ENSURE(be->d_out_feat, N * s.out_feat);
+  ENSURE(be->d_raw_pose, N * s.out_pose);
+  ENSURE(be->d_raw_sb, N * s.out_sb);
+  ENSURE(be->d_raw_feat, N * s.out_feat);
+  ENSURE(be->d_out_loop, N * s.out_loop);
+  ENSURE(be->d_stats_d, N * s.stats_d);
+  ENSURE(be->d_stats_i, N * s.stats_i);
+  ENSURE(be->d_m_ints, N * m_ints);
+  ENSURE(be->d_m_x0, N * 9 * kMaxPriorBlocks);
+  ENSURE(be->d_m_J, N * (size_t)d.Ncap * d.Ncap);
+  ENSURE(be->d_m_r, N * (size_t)d.Ncap);
+  ENSURE(be->d_m_scratch, m_scr ? N * m_scr : 1);
+#undef ENSURE
+  hipStream_t st = be->stream;
+#define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
+  H2D(be->d_hdr, be->hb.hdr);
+  H2D(be->d_hdr_d, be->hb.hdr_d);
+  H2D(be->d_pose, be->hb.pose);
+  H2D(be->d_sb, be->hb.sb);
+  H2D(be->d_ex, be->hb.ex);
+  H2D(be->d_feat, be->hb.feat);
+  H2D(be->d_fhost, be->hb.fhost);
+  H2D(be->d_ftarget, be->hb.ftarget);
+  H2D(be->d_ffeat, be->hb.ffeat);
+  H2D(be->d_pts_i, be->hb.pts_i);
+  H2D(be->d_pts_j, be->hb.pts_j);
+  H2D(be->d_preint, be->hb.preint);
+  H2D(be->d_pr_kind, be->hb.pr_kind);
+  H2D(be->d_pr_index, be->hb.pr_index);
+  H2D(be->d_pr_offset, be->hb.pr_offset);
+  H2D(be->d_pr_x0, be->hb.pr_x0);
+  H2D(be->d_pr_J, be->hb.pr_J);
+  H2D(be->d_pr_r, be->hb.pr_r);
+#undef H2D
+  HIP_OK(hipStreamSynchronize(st));
+
+  BatchPtrs &B = be->B;
+  B.n = n, B.d = d, B.s = s;
+  B.hdr = be->d_hdr.p, B.hdr_d = be->d_hdr_d.p;
+  B.pose = be->d_pose.p, B.sb = be->d_sb.p, B.ex = be->d_ex.p, B.feat = be->d_feat.p;
+  B.fhost = be->d_fhost.p, B.ftarget = be->d_ftarget.p, B.ffeat = be->d_ffeat.p;
+  B.pts_i = be->d_pts_i.p, B.pts_j = be->d_pts_j.p, B.preint = be->d_preint.p;
+  B.pr_kind = be->d_pr_kind.p, B.pr_index = be->d_pr_index.p, B.pr_offset = be->d_pr_offset.p;
+  B.pr_x0 = be->d_pr_x0.p, B.pr_J = be->d_pr_J.p, B.pr_r = be->d_pr_r.p;
+  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p;
+  B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
+  B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
+  B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
+  MargPtrs &MP = be->MP;
+  MP.ints = be->d_m_ints.p, MP.x0 = be->d_m_x0.p, MP.J = be->d_m_J.p, MP.r = be->d_m_r.p;
+  MP.scratch = m_scr ? be->d_m_scratch.p : nullptr;
+  MP.s_ints = m_ints, MP.s_x0 = 9 * kMaxPriorBlocks, MP.s_J = (size_t)d.Ncap * d.Ncap, MP.s_r = d.Ncap;
+  MP.s_scratch = m_scr;
+  be->n = n;
+  be->uploaded = true;
+  return VIO_OK;
+}
+
+int vio_backend_launch(vio_backend_t *be, void *stream) {
+  if (!be) return VIO_EINVAL;
+  if (!be->uploaded) return VIO_ESTATE;
+  hipStream_t st = stream ? (hipStream_t)stream : be->stream;
+  if (be->events_used == be->events.size()) {
+    if (be->events.size() >= 4096) {  // recycle: fold what is pending into nothing (caller did not ask for it)
+      be->events_used = 0;
+    } else {
+      hipEvent_t a, b;
+      HIP_OK(hipEventCreate(&a));
+      HIP_OK(hipEventCreate(&b));
+      be->events.push_back({a, b});
+    }
+  }
+  auto &ev = be->events[be->events_used++];
+  HIP_OK(hipEventRecord(ev.first, st));
+  if (be->lds_matrix) {
+    HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)be->lds_bytes));
+    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP);
+  } else {
+    HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)be->lds_bytes));
+    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP);
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(ev.second, st));
+  return VIO_OK;
+}
+
+int vio_backend_sync(vio_backend_t *be) {
+  if (!be) return VIO_EINVAL;
+  HIP_OK(hipDeviceSynchronize());
+  return VIO_OK;
+}
+
+int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches) {
+  if (!be || !ms_avg || !launches) return VIO_EINVAL;
+  HIP_OK(hipDeviceSynchronize());
+  double sum = 0;
+  for (size_t i = 0; i < be->events_used; i++) {
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, be->events[i].first, be->events[i].second));
+    sum += ms;
+  }
+  *launches = (int32_t)be->events_used;
+  *ms_avg = be->events_used ? sum / be->events_used : 0.0;
+  be->events_used = 0;
+  return VIO_OK;
+}
+
+int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats) {
+  if (!be || !windows) return VIO_EINVAL;
+  if (!be->uploaded || n != be->n) return VIO_ESTATE;
+  HIP_OK(hipDeviceSynchronize());
+#define D2H(dst, src)                                                                              \
+  do {                                                                                             \
+    (dst).resize((src).n);                                                                         \
+    HIP_OK(hipMemcpy((dst).data(), (src).p, (src).n * sizeof((dst)[0]), hipMemcpyDeviceToHost));   \
+  } while (0)
+  D2H(be->h_out_pose, be->d_out_pose);
+  D2H(be->h_out_sb, be->d_out_sb);
+  D2H(be->h_out_feat, be->d_out_feat);
+  D2H(be->h_raw_pose, be->d_raw_pose);
+  D2H(be->h_raw_sb, be->d_raw_sb);
+  D2H(be->h_raw_feat, be->d_raw_feat);
+  D2H(be->h_out_loop, be->d_out_loop);
+  D2H(be->h_stats_d, be->d_stats_d);
+  D2H(be->h_stats_i, be->d_stats_i);
+  D2H(be->h_m_ints, be->d_m_ints);
+  D2H(be->h_m_x0, be->d_m_x0);
+  D2H(be->h_m_J, be->d_m_J);
+  D2H(be->h_m_r, be->d_m_r);
+#undef D2H
+  const BatchStrides &s = be->hb.s;
+  for (int b = 0; b < n; b++) {
+    unpack_window(s, b, be->h_out_pose.data(), be->h_out_sb.data(), be->h_out_feat.data(), be->h_raw_pose.data(),
+                  be->h_raw_sb.data(), be->h_raw_feat.data(), be->h_out_loop.data(), be->h_stats_d.data(),
+                  be->h_stats_i.data(), windows[b], stats ? stats + b : nullptr);
+    if (windows[b].next_prior) {
+      MargOut mo;
+      int *mi = be->h_m_ints.data() + (size_t)b * be->MP.s_ints;
+      mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
+      mo.x0 = be->h_m_x0.data() + (size_t)b * be->MP.s_x0;
+      mo.J = be->h_m_J.data() + (size_t)b * be->MP.s_J;
+      mo.r = be->h_m_r.data() + (size_t)b * be->MP.s_r;
+      mo.scratch = nullptr, mo.ncap = be->B.d.Ncap;
+      unpack_prior(mo, *windows[b].next_prior);
+    }
+  }
+  return VIO_OK;
+}
+
+int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n, int32_t buf_num, VioSolveStats *stats) {
+  (void)buf_num;  // wall-clock budget selector in the reference (VINS.cpp:648-653); no time limit here
+  int rc = vio_backend_upload(be, windows, n);
+  if (rc != VIO_OK) return rc;
+  rc = vio_backend_launch(be, nullptr);
+  if (rc != VIO_OK) return rc;
+  return vio_backend_download(be, windows, n, stats);
+}
+
+}  // extern "C"
