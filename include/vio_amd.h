@@ -202,6 +202,16 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
  * last call, measured with HIP events on the launch stream.                  */
 int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches);
 
+/* Per-stage device cycle counters of the solve kernel: the kernel-side counterpart
+ * of the reference's TS()/TE() printf timers (global_param.hpp:85-92, VINS.cpp:657-662,
+ * 753-758). Enable before vio_backend_upload; read after a launch. Stage order:
+ * setup_imu, setup_prior, eval_prior, eval_imu, eval_proj, scale, schur, rhs,
+ * cholesky, tri_solve, quad_form, dogleg, cost_eval, new2old, marg_build,
+ * marg_chol, total (shader-clock cycles, thread 0 of the window's workgroup).  */
+#define VIO_N_STAGES 17
+int vio_backend_set_profile(vio_backend_t *be, int32_t enable);
+int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles, int32_t n_stages);
+
 /* ------------------------------------------------------------------------- */
 /* Front-end                                                                  */
 typedef struct vio_frontend vio_frontend_t;

@@ -48,7 +48,7 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   std::vector<double> lds(bytes / sizeof(double) + 2);
   Work w;
   Ctx cx;
-  cx.tid = 0, cx.nt = 1;
+  cx.tid = 0, cx.nt = 1, cx.prof = nullptr;
   size_t state_end = 0;
   carve_work(B.d, true, 64, lds.data(), nullptr, &w, &cx, &state_end);
   solve_window(cx, v, w);

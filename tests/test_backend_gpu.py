@@ -101,6 +101,7 @@ def test_determinism_and_resident_api(solver_cache):
     cfg, w, d = H.load_golden_window("win_c2_easy")
     solver = get_solver(solver_cache, cfg)
     ws = [w.copy() for _ in range(4)]
+    solver.kernel_ms()  # drain timings of earlier launches
     solver.upload(ws)
     solver.launch()
     solver.launch()  # relaunch from the same resident inputs

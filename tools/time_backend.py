@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Quick device timing of the window-solve kernel at config-2 shape (W=10, 150 features, ~800 factors)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("vins-mobile_amd")
+abi, synth, backend = pkg.abi, pkg.synth, pkg.backend
+
+
+def main():
+    batches = [int(x) for x in sys.argv[1:]] or [1, 64, 256, 512, 1024]
+    cfg = abi.default_config()
+    pre = lambda *a: backend.preintegrate(cfg, *a)
+    uniq = [synth.make_window(cfg, pre, seed=42 + i) for i in range(16)]
+    solver = backend.WindowSolver(cfg, max_batch=max(batches))
+    solver.set_profile(True)
+    ws = [uniq[0].copy()]
+    solver.upload(ws)
+    solver.launch()
+    solver.sync()
+    cyc = solver.stage_cycles(0)
+    tot = max(1, cyc["total"])
+    print("stage cycles (1 window): " + ", ".join("%s=%d(%.1f%%)" % (k, c, 100.0 * c / tot) for k, c in cyc.items()))
+    solver.set_profile(False)
+    for B in batches:
+        ws = [uniq[i % len(uniq)].copy() for i in range(B)]
+        solver.upload(ws)
+        solver.launch()
+        solver.sync()
+        solver.kernel_ms()
+        t0 = time.time()
+        reps = 5
+        for _ in range(reps):
+            solver.launch()
+        solver.sync()
+        wall = (time.time() - t0) / reps
+        ms, n = solver.kernel_ms()
+        st = solver.download(ws)
+        print("B=%5d kernel %.3f ms (wall %.3f ms) -> %.0f solves/s, %.1f us/solve/CU-slot; iters %s final cost %.4f" % (
+            B, ms, wall * 1e3, B / (ms * 1e-3), ms * 1e3 / max(1, -(-B // 256)), st[0]["iterations"], st[0]["final_cost"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,8 @@ VIO_MAX_PRIOR_BLOCKS = 96
 VIO_MAX_TRACE = 64
 VIO_BLOCK_POSE, VIO_BLOCK_SPEEDBIAS, VIO_BLOCK_EXPOSE = 0, 1, 2
 VIO_MARGIN_OLD, VIO_MARGIN_SECOND_NEW, VIO_MARGIN_NONE = 0, 1, 2
+STAGES = ["setup_imu", "setup_prior", "eval_prior", "eval_imu", "eval_proj", "scale", "schur", "rhs", "cholesky",
+          "tri_solve", "quad_form", "dogleg", "cost_eval", "new2old", "marg_build", "marg_chol", "total"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -369,5 +371,7 @@ def load_product():
     lib.vio_backend_sync.argtypes = [vp]
     lib.vio_backend_download.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.POINTER(VioSolveStats)]
     lib.vio_backend_kernel_ms.argtypes = [vp, _dp, _ip]
+    lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
+    lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib
     return lib

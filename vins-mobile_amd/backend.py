@@ -71,6 +71,15 @@ class WindowSolver:
         self._check(self.lib.vio_backend_download(self._h, arr, len(windows), stats), "download")
         return [abi.stats_to_dict(s) for s in stats]
 
+    def set_profile(self, enable=True):
+        self._check(self.lib.vio_backend_set_profile(self._h, 1 if enable else 0), "set_profile")
+
+    def stage_cycles(self, window=0):
+        """Per-stage shader-clock cycles of one window's workgroup (see VIO_N_STAGES in include/vio_amd.h)."""
+        out = (C.c_int64 * len(abi.STAGES))()
+        self._check(self.lib.vio_backend_stage_cycles(self._h, window, out, len(abi.STAGES)), "stage_cycles")
+        return dict(zip(abi.STAGES, [int(x) for x in out]))
+
     def kernel_ms(self):
         ms = C.c_double()
         n = C.c_int32()

@@ -282,6 +282,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
     }
     VIO_SYNC();
   }
+  stamp(cx, ST_MARG_BUILD);
   // ---- Cholesky with pivot cut, b carried along (forward substitution) --------------------------------
   VIO_PARFOR(j, pos) m.tol[j] = fmax(1e-8, 1e-12 * m.Am[j * ld + j]);
   VIO_SYNC();
@@ -314,6 +315,10 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
   VIO_PARFOR(i, n) out.r[i] = m.bm[mdrop + i];
   if (cx.tid == 0) out.n[0] = n, out.n[1] = nblocks, out.n[2] = mdrop, out.n[3] = pos;
   VIO_SYNC();
+  stamp(cx, ST_MARG_CHOL);
+#ifndef VIO_EMUL
+  if (cx.prof && cx.tid == 0) cx.prof[ST_TOTAL] += cx.prof[ST_COUNT - 1];
+#endif
 }
 
 inline void unpack_prior(const MargOut &mo, VioPrior &p) {

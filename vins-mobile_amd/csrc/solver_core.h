@@ -48,10 +48,30 @@ constexpr int kMaxTrace = 64;
 constexpr int kStatsDoubles = 4 + 5 * kMaxTrace;  // initial, final, (it_cost, radius, step_norm, rel, gmax)[64]
 constexpr int kStatsInts = 4 + kMaxTrace;         // iterations, termination, n_ok, n_bad, flags[64]
 
+// Per-stage cycle counters (the kernel-side counterpart of the reference's TS/TE timers, global_param.hpp:85-92).
+enum Stage {
+  ST_SETUP_IMU = 0, ST_SETUP_PRIOR, ST_EVAL_PRIOR, ST_EVAL_IMU, ST_EVAL_PROJ, ST_SCALE, ST_SCHUR, ST_RHS, ST_CHOL,
+  ST_TRISOLVE, ST_QUADFORM, ST_DOGLEG, ST_COST_EVAL, ST_NEW2OLD, ST_MARG_BUILD, ST_MARG_CHOL, ST_TOTAL, ST_COUNT = 24
+};
+
 struct Ctx {
   int tid, nt;
-  double *red;  // LDS scratch for block reductions: [nt/64 + 1]
+  double *red;        // LDS scratch for block reductions: [nt/64 + 1]
+  long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
 };
+
+// Charges the cycles since the previous stamp to `stage` (thread 0 only; call between barriers).
+VIO_DEV void stamp(const Ctx &cx, int stage) {
+#ifndef VIO_EMUL
+  if (cx.prof && cx.tid == 0) {
+    long long t = clock64();
+    cx.prof[stage] += t - cx.prof[ST_COUNT - 1];
+    cx.prof[ST_COUNT - 1] = t;
+  }
+#else
+  (void)cx, (void)stage;
+#endif
+}
 
 // Per-window view of the packed batch (all pointers device-global unless noted).
 struct WinView {
@@ -448,6 +468,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
     }
     VIO_SYNC();
   }
+  stamp(cx, jac ? ST_EVAL_PRIOR : ST_COST_EVAL);
   // ---- IMU factors -------------------------------------------------------------------------------
   VIO_PARFOR(f, v.W) {
     imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
@@ -491,6 +512,10 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
       for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
       VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
     }
+  }
+  if (jac) {
+    VIO_SYNC();
+    stamp(cx, ST_EVAL_IMU);
   }
   // ---- projection factors with CauchyLoss (CSI/loss_function.cc:72-79, CSI/corrector.cc:81-129) -----
   const double bb = v.cauchy_b, cc = 1.0 / bb;
@@ -541,6 +566,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
     VIO_PARFOR(i, np) w.hdiag[i] = *mat_at(w.Hm, i, i);
     VIO_SYNC();
   }
+  stamp(cx, jac ? ST_EVAL_PROJ : ST_COST_EVAL);
   return total;
 }
 
@@ -588,6 +614,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
   }
   (void)ntot;
   VIO_SYNC();
+  stamp(cx, ST_SCALE);
   bool ok = true;
   VIO_PARFOR(f, F) if (!(w.ef[f] > 0.0)) w.flag[0] = 1;
   // Schur term on the pose-pose 6x6 sub-blocks (dense in frames): VALU version, one thread per entry
@@ -606,6 +633,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
   }
   VIO_PARFOR(i, np) w.t1[i] = w.sp[i] * w.gp[i];
   VIO_SYNC();
+  stamp(cx, ST_SCHUR);
   VIO_PARFOR(a, n6) {
     const double *wa = v.WT + a * v.Fpad;
     double s = 0;
@@ -613,6 +641,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
     w.t1[kBS * (a / 6) + a % 6] -= s;
   }
   VIO_SYNC();
+  stamp(cx, ST_RHS);
   if (w.flag[0]) ok = false;
   return ok;
 }
@@ -941,6 +970,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
         VIO_SYNC();
         bool ok = build_reduced_system(cx, v, w, mu);
         if (ok) ok = cholesky_blocks(cx, v, w);
+        stamp(cx, ST_CHOL);
         if (ok) {
           cholesky_solve(cx, v, w, w.t1);  // y_p
           // back-substitute features: y_f = (gs_f - ws_f^T y_p) / e_f ; GN = -d * y
@@ -958,6 +988,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
             if (!isfinite(y)) bad = 1;
           }
           if (block_max(cx, bad) > 0) ok = false;
+          stamp(cx, ST_TRISOLVE);
         }
         if (ok) { solver_ok = true; mu_used = mu; have_factor = true; break; }
         mu *= mu_inc;
@@ -977,7 +1008,9 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
         }
         VIO_SYNC();
         double reg = block_sum(cx, part2);
+        stamp(cx, ST_DOGLEG);
         double qf = quad_form(cx, v, w, w.t2, w.stf);
+        stamp(cx, ST_QUADFORM);
         alpha = gd_sq / (qf - reg);
       }
     }
@@ -1028,7 +1061,9 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       double n2 = block_sum(cx, pn), sg = block_sum(cx, psg), reg = block_sum(cx, preg);
       if (need_norm) dogleg_step_norm = sqrt(n2);
       // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416)
+      stamp(cx, ST_DOGLEG);
       double shs = quad_form(cx, v, w, w.stp, w.stf) - reg;
+      stamp(cx, ST_QUADFORM);
       model_cost_change = -sg - 0.5 * shs;
       step_valid = model_cost_change > 0.0;
     }
@@ -1049,6 +1084,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
     VIO_PARFOR(f, F) w.tf[f] = w.stf[f] * w.sf[f];
     VIO_SYNC();
     apply_plus(cx, v, w, w.t2, w.tf);
+    stamp(cx, ST_DOGLEG);
     double cand_cost = evaluate(cx, v, w, w.cpose, w.csb, w.cfeat, false);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     double step_norm, dummy;
@@ -1079,6 +1115,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       n_ok++;
       record(it, x_cost, radius, step_norm, rho, gmax, true, true);
       recorded = it + 1, min_rec = fmin(min_rec, x_cost);
+      stamp(cx, ST_DOGLEG);
     } else {
       radius *= 0.5;                                                          // StepRejected
       reuse = true;
@@ -1108,8 +1145,17 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
   VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
   if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
   VIO_SYNC();
+#ifndef VIO_EMUL
+  if (cx.prof && cx.tid == 0) {
+    for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = 0;
+    cx.prof[ST_COUNT - 1] = clock64();
+    cx.prof[ST_TOTAL] = -cx.prof[ST_COUNT - 1];
+  }
+#endif
   setup_imu_info(cx, v);
+  stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, v, w);
+  stamp(cx, ST_SETUP_PRIOR);
 
   minimize(cx, v, w);
 
@@ -1153,6 +1199,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
   VIO_PARFOR(q, P * 9) v.out_sb[q] = w.csb[q], w.xsb[q] = w.csb[q];
   VIO_PARFOR(q, F) v.out_feat[q] = w.cfeat[q], w.xfeat[q] = w.cfeat[q];
   VIO_SYNC();
+  stamp(cx, ST_NEW2OLD);
 }
 
 }  // namespace vio

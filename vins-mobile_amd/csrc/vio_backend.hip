@@ -30,6 +30,7 @@ struct MargPtrs {
   double *r;        // [n][Ncap]
   double *scratch;  // [n][marg_scratch] (global matrix variant only)
   size_t s_ints, s_x0, s_J, s_r, s_scratch;
+  long long *prof;  // [n][ST_COUNT] or null
 };
 
 template <bool LDS_MATRIX>
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   Work w;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
+  cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
   size_t state_end = 0;
   carve_work(B.d, LDS_MATRIX, blockDim.x, smem, B.hm + (size_t)b * B.s.hm, &w, &cx, &state_end);
   solve_window(cx, v, w);
@@ -95,7 +97,9 @@ struct vio_backend {
   int n = 0;
   bool uploaded = false;
   bool lds_matrix = true;
+  bool profile = false;
   size_t lds_bytes = 0;
+  DevBuf<long long> d_prof;
   HostBatch hb;
   BatchPtrs B;
   MargPtrs MP;
@@ -156,6 +160,7 @@ void vio_backend_destroy(vio_backend_t *be) {
                           &be->d_raw_feat, &be->d_out_loop, &be->d_stats_d, &be->d_m_x0, &be->d_m_J, &be->d_m_r,
                           &be->d_m_scratch};
   for (auto *b : db) b->release();
+  be->d_prof.release();
   (void)hipStreamDestroy(be->stream);
   delete be;
 }
@@ -279,6 +284,12 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   MP.scratch = m_scr ? be->d_m_scratch.p : nullptr;
   MP.s_ints = m_ints, MP.s_x0 = 9 * kMaxPriorBlocks, MP.s_J = (size_t)d.Ncap * d.Ncap, MP.s_r = d.Ncap;
   MP.s_scratch = m_scr;
+  MP.prof = nullptr;
+  if (be->profile) {
+    int rcp = be->d_prof.ensure(N * ST_COUNT);
+    if (rcp != VIO_OK) return rcp;
+    MP.prof = be->d_prof.p;
+  }
   be->n = n;
   be->uploaded = true;
   return VIO_OK;
@@ -332,6 +343,23 @@ int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches) 
   *launches = (int32_t)be->events_used;
   *ms_avg = be->events_used ? sum / be->events_used : 0.0;
   be->events_used = 0;
+  return VIO_OK;
+}
+
+int vio_backend_set_profile(vio_backend_t *be, int32_t enable) {
+  if (!be) return VIO_EINVAL;
+  be->profile = enable != 0;
+  be->uploaded = false;  // takes effect at the next upload
+  return VIO_OK;
+}
+
+int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles, int32_t n_stages) {
+  if (!be || !cycles || n_stages < 1) return VIO_EINVAL;
+  if (!be->uploaded || !be->profile || window < 0 || window >= be->n) return VIO_ESTATE;
+  HIP_OK(hipDeviceSynchronize());
+  long long tmp[ST_COUNT];
+  HIP_OK(hipMemcpy(tmp, be->d_prof.p + (size_t)window * ST_COUNT, sizeof(tmp), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n_stages; i++) cycles[i] = i < ST_COUNT ? (int64_t)tmp[i] : 0;
   return VIO_OK;
 }
 
