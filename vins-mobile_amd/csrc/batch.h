@@ -149,7 +149,9 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, doub
   double *cpose = take(7 * (size_t)(d.Pcap + 1)), *csb = take(9 * (size_t)d.Pcap), *cfeat = take(F);
   double *gp = take(npc), *gf = take(F), *sp = take(npc), *sf = take(F), *dp = take(npc), *df = take(F);
   double *gdp = take(npc), *gdf = take(F), *gnp = take(npc), *gnf = take(F), *stp = take(npc), *stf = take(F);
-  double *hdiag = take(npc), *hff = take(F), *ef = take(F), *ldinv = take(npc), *t1 = take(npc), *t2 = take(npc);
+  double *hdiag = take(npc), *hff = take(F), *ef = take(F), *einv = take(F), *ldinv = take(npc), *t1 = take(npc),
+         *t2 = take(npc);
+  double *blk = take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1);
   double *tf = take(F), *prdx = take(d.Ncap), *prr = take(d.Ncap);
   double *prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
   double *flag = take(2);
@@ -157,7 +159,8 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, doub
     w->Hm = lds_matrix ? hm : hm_global;
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
     w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->df = df, w->gdp = gdp, w->gdf = gdf;
-    w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef;
+    w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef, w->einv = einv;
+    w->blk_ij = reinterpret_cast<int *>(blk);
     w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
     w->prcol = reinterpret_cast<int *>(prcol), w->flag = reinterpret_cast<int *>(flag);
   }

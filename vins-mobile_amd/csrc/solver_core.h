@@ -117,7 +117,8 @@ struct Work {
   double *gnp, *gnf;             // Gauss-Newton step in d-scaled space
   double *stp, *stf;             // trust-region step (J_s coordinates), later delta
   double *hdiag, *hff;           // diag(H_pp), H_ff (unscaled)
-  double *ef;                    // e_f = sf^2 hff + mu df^2
+  double *ef, *einv;             // e_f = sf^2 hff + mu df^2 and its reciprocal
+  int *blk_ij;                   // block index -> (bi << 8) | bj
   double *ldinv;                 // 1 / L_ii
   double *t1, *t2;               // np temporaries
   double *tf;                    // F temporary
@@ -573,246 +574,310 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
 // =====================================================================================================
 // Linear algebra on the block-lower matrix
 // =====================================================================================================
+#ifndef VIO_EMUL
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C. Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives
+// D[(l>>4) + 4 r][l&15] in element r (the f64 C/D map differs from the f32 one, cdna_hip_programming.md §3).
+VIO_DEV v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// Value of x held by `lane` (compile-time constant) broadcast to the whole wave through SGPRs.
+VIO_DEV double lane_bcast(double x, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// sqrt(x) and 1/sqrt(x) from v_rsq_f64 + Newton (the hardware seed carries ~single precision).
+VIO_DEV void sqrt_rsqrt(double x, double &d, double &inv) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  double s = x * y;
+  s = fma(0.5 * y, fma(-s, s, x), s);
+  d = s, inv = y;
+}
+
+// C(15x15) -= A(15x15) B(15x15)^T with four MFMAs (blocks padded to 16 with zeros on the fly).
+VIO_DEV void mfma_block_update(double *C, const double *A, const double *B, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    int kk = 4 * s + kq;
+    bool ok = (i < kBS) && (kk < kBS);
+    int idx = ok ? i * kBS + kk : 0;
+    double a = A[idx], b = B[idx];
+    a = ok ? a : 0.0, b = ok ? b : 0.0;
+    acc = mfma_f64(a, b, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int row = kq + 4 * r;
+    if (row < kBS && i < kBS) C[row * kBS + i] -= acc[r];
+  }
+}
+
+// Cholesky of one 15x15 diagonal block by ONE wave: lane r keeps row r in registers, pivots travel through
+// v_readlane. Writes L (lower) back and 1/L_cc to ldinv_k. Returns false if a pivot is <= 0.
+VIO_DEV bool potrf15_wave(double *D, double *ldinv_k, int lane) {
+  double a[kBS];
+#pragma unroll
+  for (int c = 0; c < kBS; c++) a[c] = (lane < kBS && c <= lane) ? D[(lane < kBS ? lane : 0) * kBS + c] : 0.0;
+  bool good = true;
+#pragma unroll
+  for (int c = 0; c < kBS; c++) {
+    double x = lane_bcast(a[c], c);
+    good = good && (x > 0.0);
+    double d, inv;
+    sqrt_rsqrt(x, d, inv);
+    a[c] = (lane == c) ? d : a[c] * inv;
+    if (lane == c) ldinv_k[c] = inv;
+#pragma unroll
+    for (int j = c + 1; j < kBS; j++) {
+      double ljc = lane_bcast(a[c], j);
+      a[j] = fma(-a[c], ljc, a[j]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kBS; c++)
+    if (lane < kBS && c <= lane) D[lane * kBS + c] = a[c];
+  return good;
+}
+
+// x <- L_kk^-T x for one diagonal block by one wave: lane c keeps column c of L.
+VIO_DEV void trsv15T_wave(const double *D, const double *ldinv_k, double *x, int lane) {
+  double col[kBS];
+  const int lc = lane < kBS ? lane : 0;
+#pragma unroll
+  for (int r = 0; r < kBS; r++) col[r] = (lane < kBS && r >= lane) ? D[r * kBS + lc] : 0.0;
+  double acc = lane < kBS ? x[lc] : 0.0;
+  const double di = lane < kBS ? ldinv_k[lc] : 0.0;
+#pragma unroll
+  for (int r = kBS - 1; r >= 0; r--) {
+    double xr = lane_bcast(acc * di, r);  // x_r is final once every x_{r'>r} has been subtracted
+    if (lane == r) acc = xr;              // keep the solved value
+    else acc = fma(-col[r], xr, acc);     // lanes c < r: y_c -= L[r][c] x_r  (col[r] = 0 for lanes >= r)
+  }
+  if (lane < kBS) x[lane] = acc;
+}
+#endif  // !VIO_EMUL
 
 // In place: Hm <- S Hm S + diag(Dp^2) on the pose side, then subtracts the landmark Schur term
 // sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
 // Returns false if some e_f <= 0.
 VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, double mu) {
   const int np = v.np, F = v.F;
-  // padding rows/cols of the last block (loop pose uses 6 of 15): unit diagonal
-  const int ntot = v.nblk * kBS;
   VIO_PARFOR(f, F) {
     double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
+    double ei = 1.0 / e;
     w.ef[f] = e;
-    w.tf[f] = w.sf[f] * w.gf[f] / e;  // gs_f / e_f
+    w.einv[f] = ei;
+    w.tf[f] = w.sf[f] * w.gf[f] * ei;  // gs_f / e_f
+    if (!(e > 0.0)) w.flag[0] = 1;
   }
   // scale WT in place: ws[a][f] = WT[a][f] sp[par(a)] sf[f]
   VIO_PARFOR(q, v.npose6 * v.Fpad) {
-    int a = q / v.Fpad, f = q % v.Fpad;
+    int a = q / v.Fpad, f = q - a * v.Fpad;
     if (f < F) {
-      int fr = a / 6, c = a % 6;
+      int fr = a / 6, c = a - 6 * fr;
       v.WT[q] *= w.sp[kBS * fr + c] * w.sf[f];
     }
   }
   const int nblocks = v.nblk * (v.nblk + 1) / 2;
   VIO_PARFOR(q, nblocks * kBB) {
-    int blk = q / kBB, e = q % kBB, r = e / kBS, c = e % kBS;
-    // invert blk = bi (bi+1)/2 + bj
-    int bi = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= blk) bi++;
-    while (bi * (bi + 1) / 2 > blk) bi--;
-    int bj = blk - bi * (bi + 1) / 2;
-    int i = bi * kBS + r, j = bj * kBS + c;
+    int blk = q / kBB, e = q - blk * kBB, r = e / kBS, c = e - r * kBS;
+    int bij = w.blk_ij[blk];
+    int i = (bij >> 8) * kBS + r, j = (bij & 255) * kBS + c;
     double val = 0.0;
     if (i < np && j < np) {
       val = w.sp[i] * w.Hm[q] * w.sp[j];
       if (i == j) val += mu * w.dp[i] * w.dp[i];
     } else if (i == j) {
-      val = 1.0;
+      val = 1.0;  // padding of the last block (loop pose uses 6 of 15)
     }
     w.Hm[q] = val;
   }
-  (void)ntot;
+  VIO_PARFOR(i, v.nblk * kBS) w.t1[i] = i < np ? w.sp[i] * w.gp[i] : 0.0;
   VIO_SYNC();
   stamp(cx, ST_SCALE);
-  bool ok = true;
-  VIO_PARFOR(f, F) if (!(w.ef[f] > 0.0)) w.flag[0] = 1;
-  // Schur term on the pose-pose 6x6 sub-blocks (dense in frames): VALU version, one thread per entry
   const int n6 = v.npose6;
-  VIO_PARFOR(q, n6 * n6) {
-    int a = q / n6, b = q % n6;
-    int fa = a / 6, fb = b / 6;
-    int i = kBS * fa + a % 6, j = kBS * fb + b % 6;
-    if (i >= j || fa == fb) {
+#ifdef VIO_EMUL
+  for (int a = 0; a < n6; a++)
+    for (int b = 0; b <= a; b++) {
+      int i = kBS * (a / 6) + a % 6, j = kBS * (b / 6) + b % 6;
       const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
       double s = 0;
-      for (int f = 0; f < F; f++) s += wa[f] * wb[f] / w.ef[f];
-      if (i >= j) *mat_at(w.Hm, i, j) -= s;
-      else w.Hm[blk_off(fa, fa) + (a % 6) * kBS + (b % 6)] -= s;
+      for (int f = 0; f < F; f++) s += wa[f] * w.einv[f] * wb[f];
+      *mat_at(w.Hm, i, j) -= s;
+    }
+#else
+  {
+    // Landmark Schur complement as a GEMM on the matrix cores: C(n6 x n6, lower tiles) = (Ws E^-1) Ws^T, K = F.
+    const int T = (n6 + 15) / 16, npairs = T * (T + 1) / 2;
+    const int wave = cx.tid >> 6, lane = cx.tid & 63, nw = cx.nt >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int ksteps = (F + 3) / 4;
+    for (int p = wave; p < npairs; p += nw) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
+      const int tj = p - ti * (ti + 1) / 2;
+      const int ra = 16 * ti + li, rb = 16 * tj + li;
+      const bool va = ra < n6, vb = rb < n6;
+      const double *pa = v.WT + (size_t)(va ? ra : 0) * v.Fpad;
+      const double *pb = v.WT + (size_t)(vb ? rb : 0) * v.Fpad;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int s = 0; s < ksteps; s++) {
+        int f = 4 * s + kq;
+        bool vf = f < F;
+        int fc = vf ? f : 0;
+        double a = pa[fc] * w.einv[fc], b = pb[fc];
+        a = (va && vf) ? a : 0.0, b = (vb && vf) ? b : 0.0;
+        acc = mfma_f64(a, b, acc);
+      }
+      const int bcol = 16 * tj + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int arow = 16 * ti + kq + 4 * r;
+        if (arow < n6 && bcol < n6) {
+          int i = kBS * (arow / 6) + arow % 6, j = kBS * (bcol / 6) + bcol % 6;
+          if (i >= j) *mat_at(w.Hm, i, j) -= acc[r];
+        }
+      }
     }
   }
-  VIO_PARFOR(i, np) w.t1[i] = w.sp[i] * w.gp[i];
-  VIO_SYNC();
+#endif
   stamp(cx, ST_SCHUR);
-  VIO_PARFOR(a, n6) {
-    const double *wa = v.WT + a * v.Fpad;
+  // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets
+  const int nch = 8, chunk = (F + nch - 1) / nch;
+  VIO_PARFOR(q, n6 * nch) {
+    int a = q / nch, ch = q - a * nch;
+    const double *wa = v.WT + (size_t)a * v.Fpad;
+    int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
     double s = 0;
-    for (int f = 0; f < F; f++) s += wa[f] * w.tf[f];
-    w.t1[kBS * (a / 6) + a % 6] -= s;
+#pragma unroll 4
+    for (int f = f0; f < f1; f++) s += wa[f] * w.tf[f];
+    VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -s);
   }
   VIO_SYNC();
   stamp(cx, ST_RHS);
-  if (w.flag[0]) ok = false;
-  return ok;
+  return w.flag[0] == 0;
 }
 
-// Blocked Cholesky (block 15) of the block-lower matrix in place: lower blocks <- L; the strict upper triangle of
-// each diagonal block receives inv(L_kk) transposed, ldinv the reciprocal diagonal. false when a pivot is <= 0
-// (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
-VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w) {
+// Blocked right-looking Cholesky (block 15) of the block-lower matrix in place, with the right-hand side carried
+// along: on return the lower blocks hold L, ldinv = 1 / L_ii and rhs = L^-1 rhs (forward substitution).
+//   POTRF  one wave, rows in registers, pivots through v_readlane
+//   TRSM   one thread per panel row (the rhs is one more row), substitution against L_kk
+//   SYRK   trailing blocks A_ij -= L_ik L_jk^T on the matrix cores, one block per wave at a time
+// false when a pivot is <= 0 (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
+VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *rhs) {
   const int nb = v.nblk;
   for (int k = 0; k < nb; k++) {
     double *D = w.Hm + blk_off(k, k);
-    // (a) diagonal block: factor + invert. Small and serial in nature: one thread (wave-cooperative version later).
-    if (cx.tid == 0) {
-      bool good = true;
-      for (int c = 0; c < kBS && good; c++) {
-        double x = D[c * kBS + c];
-        for (int p = 0; p < c; p++) x -= D[c * kBS + p] * D[c * kBS + p];
-        if (!(x > 0.0)) { good = false; break; }
-        x = sqrt(x);
-        D[c * kBS + c] = x;
-        for (int i = c + 1; i < kBS; i++) {
-          double s = D[i * kBS + c];
-          for (int p = 0; p < c; p++) s -= D[i * kBS + p] * D[c * kBS + p];
-          D[i * kBS + c] = s / x;
-        }
+#ifdef VIO_EMUL
+    for (int c = 0; c < kBS; c++) {
+      double x = D[c * kBS + c];
+      for (int p = 0; p < c; p++) x -= D[c * kBS + p] * D[c * kBS + p];
+      if (!(x > 0.0)) return false;
+      x = sqrt(x);
+      D[c * kBS + c] = x;
+      w.ldinv[k * kBS + c] = 1.0 / x;
+      for (int i = c + 1; i < kBS; i++) {
+        double s = D[i * kBS + c];
+        for (int p = 0; p < c; p++) s -= D[i * kBS + p] * D[c * kBS + p];
+        D[i * kBS + c] = s / x;
       }
-      if (!good) w.flag[1] = 1;
-      else {
-        // X = inv(L): X[r][c], r >= c; stored X[r][c] (r > c) at D[c][r], diagonal in ldinv
-        for (int c = 0; c < kBS; c++) {
-          double xc[kBS];
-          for (int r = c; r < kBS; r++) {
-            double s = (r == c) ? 1.0 : 0.0;
-            for (int p = c; p < r; p++) s -= D[r * kBS + p] * xc[p];
-            xc[r] = s / D[r * kBS + r];
-          }
-          w.ldinv[k * kBS + c] = xc[c];
-          for (int r = c + 1; r < kBS; r++) D[c * kBS + r] = xc[r];
-        }
-      }
+    }
+#else
+    if ((cx.tid >> 6) == 0) {
+      bool good = potrf15_wave(D, w.ldinv + k * kBS, cx.tid & 63);
+      if (!good && cx.tid == 0) w.flag[1] = 1;
     }
     VIO_SYNC();
     if (w.flag[1]) return false;
-    // (b) panel: L_ik = A_ik inv(L_kk)^T for i > k. Items are (i, r, c); chunks hold whole rows so that the
-    //     in-place update never reads a value another chunk has already overwritten.
-    const int rows = (nb - k - 1) * kBS;
-    const int chunk_rows = cx.nt / kBS > 0 ? cx.nt / kBS : 1;
-    for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
-      int item = cx.tid;
-      int lr = item / kBS, c = item % kBS;
-      double val = 0;
-      bool active = lr < chunk_rows && r0 + lr < rows;
-      double *Arow = nullptr;
-      if (active) {
-        int gr = r0 + lr;
-        int i = k + 1 + gr / kBS, r = gr % kBS;
-        Arow = w.Hm + blk_off(i, k) + r * kBS;
-        double s = Arow[c] * w.ldinv[k * kBS + c];
-        for (int m = 0; m < c; m++) s += Arow[m] * D[m * kBS + c];  // inv(L)[c][m] stored at D[m][c]
-        val = s;
-      }
-#ifdef VIO_EMUL
-      // one emulated thread: walk the chunk's items sequentially, highest column first (reads only lower columns)
-      for (int it2 = (chunk_rows * kBS) - 1; it2 >= 0; it2--) {
-        int lr2 = it2 / kBS, c2 = it2 % kBS;
-        if (r0 + lr2 >= rows) continue;
-        int gr = r0 + lr2;
-        int i = k + 1 + gr / kBS, r = gr % kBS;
-        double *Ar = w.Hm + blk_off(i, k) + r * kBS;
-        double s = Ar[c2] * w.ldinv[k * kBS + c2];
-        for (int m = 0; m < c2; m++) s += Ar[m] * D[m * kBS + c2];
-        Ar[c2] = s;
-      }
-      (void)val, (void)Arow, (void)active;
-#else
-      VIO_SYNC();
-      if (active) Arow[c] = val;
-      VIO_SYNC();
 #endif
+    // TRSM: x L_kk^T = a for every row below the diagonal block and for the rhs segment
+    const int nrows = (nb - k - 1) * kBS + 1;
+    VIO_PARFOR(row, nrows) {
+      double *Ar = row < nrows - 1 ? w.Hm + blk_off(k + 1 + row / kBS, k) + (row % kBS) * kBS : rhs + k * kBS;
+      double x[kBS];
+#pragma unroll
+      for (int c = 0; c < kBS; c++) x[c] = Ar[c];
+#pragma unroll
+      for (int c = 0; c < kBS; c++) {
+        double s = x[c];
+#pragma unroll
+        for (int m = 0; m < c; m++) s = fma(-x[m], D[c * kBS + m], s);
+        x[c] = s * w.ldinv[k * kBS + c];
+      }
+#pragma unroll
+      for (int c = 0; c < kBS; c++) Ar[c] = x[c];
     }
-    // (c) trailing update: A_ij -= L_ik L_jk^T for i >= j > k
-    const int nt_blk = nb - k - 1;
-    const int npairs = nt_blk * (nt_blk + 1) / 2;
-    VIO_PARFOR(q, npairs * kBB) {
-      int pr = q / kBB, e = q % kBB, r = e / kBS, c = e % kBS;
-      int li = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    VIO_SYNC();
+    // trailing update
+    const int ntb = nb - k - 1;
+    VIO_PARFOR(q, ntb * kBS) {  // rhs_i -= L_ik y_k
+      int i = k + 1 + q / kBS, r = q % kBS;
+      const double *Lr = w.Hm + blk_off(i, k) + r * kBS;
+      double s = 0;
+#pragma unroll
+      for (int m = 0; m < kBS; m++) s += Lr[m] * rhs[k * kBS + m];
+      rhs[i * kBS + r] -= s;
+    }
+    const int npairs = ntb * (ntb + 1) / 2;
+#ifdef VIO_EMUL
+    for (int pr = 0; pr < npairs; pr++) {
+      int li = 0;
       while ((li + 1) * (li + 2) / 2 <= pr) li++;
-      while (li * (li + 1) / 2 > pr) li--;
       int lj = pr - li * (li + 1) / 2;
       int i = k + 1 + li, j = k + 1 + lj;
-      const double *Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
-      double s = 0;
-      for (int m = 0; m < kBS; m++) s += Li[m] * Lj[m];
-      w.Hm[blk_off(i, j) + e] -= s;
+      for (int r = 0; r < kBS; r++)
+        for (int c = 0; c < kBS; c++) {
+          const double *Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
+          double s = 0;
+          for (int m = 0; m < kBS; m++) s += Li[m] * Lj[m];
+          w.Hm[blk_off(i, j) + r * kBS + c] -= s;
+        }
     }
+#else
+    {
+      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+      for (int pr = wave; pr < npairs; pr += nw) {
+        int li = 0;
+        while ((li + 1) * (li + 2) / 2 <= pr) li++;
+        const int lj = pr - li * (li + 1) / 2;
+        const int i = k + 1 + li, j = k + 1 + lj;
+        mfma_block_update(w.Hm + blk_off(i, j), w.Hm + blk_off(i, k), w.Hm + blk_off(j, k), lane);
+      }
+    }
+#endif
     VIO_SYNC();
   }
   return true;
 }
 
-// x <- (L L^T)^-1 x on w.t1 (length nblk*15; padding entries are zero)
-VIO_DEV void cholesky_solve(const Ctx &cx, const WinView &v, Work &w, double *x) {
+// x <- L^-T x (backward substitution; the forward half rode along with the factorization)
+VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, Work &w, double *x) {
   const int nb = v.nblk;
-  // forward: L y = b
-  for (int k = 0; k < nb; k++) {
-    const double *D = w.Hm + blk_off(k, k);
-    // y_k = inv(L_kk) b_k
-    double yv = 0;
-    if (cx.tid < kBS) {
-      int r = cx.tid;
-      double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
-      for (int c = 0; c < r; c++) s += D[c * kBS + r] * x[k * kBS + c];
-      yv = s;
-    }
-#ifdef VIO_EMUL
-    {
-      double tmp[kBS];
-      for (int r = 0; r < kBS; r++) {
-        double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
-        for (int c = 0; c < r; c++) s += D[c * kBS + r] * x[k * kBS + c];
-        tmp[r] = s;
-      }
-      for (int r = 0; r < kBS; r++) x[k * kBS + r] = tmp[r];
-      (void)yv;
-    }
-#else
-    VIO_SYNC();
-    if (cx.tid < kBS) x[k * kBS + cx.tid] = yv;
-    VIO_SYNC();
-#endif
-    VIO_PARFOR(q, (nb - k - 1) * kBS) {
-      int i = k + 1 + q / kBS, r = q % kBS;
-      const double *Lr = w.Hm + blk_off(i, k) + r * kBS;
-      double s = 0;
-      for (int m = 0; m < kBS; m++) s += Lr[m] * x[k * kBS + m];
-      x[i * kBS + r] -= s;
-    }
-    VIO_SYNC();
-  }
-  // backward: L^T z = y
   for (int k = nb - 1; k >= 0; k--) {
     const double *D = w.Hm + blk_off(k, k);
-    // z_k = inv(L_kk)^T y_k : z[r] = sum_{c >= r} X[c][r] y[c]
-    double zv = 0;
-    if (cx.tid < kBS) {
-      int r = cx.tid;
-      double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
-      for (int c = r + 1; c < kBS; c++) s += D[r * kBS + c] * x[k * kBS + c];  // X[c][r] stored at D[r][c]
-      zv = s;
-    }
 #ifdef VIO_EMUL
-    {
-      double tmp[kBS];
-      for (int r = 0; r < kBS; r++) {
-        double s = w.ldinv[k * kBS + r] * x[k * kBS + r];
-        for (int c = r + 1; c < kBS; c++) s += D[r * kBS + c] * x[k * kBS + c];
-        tmp[r] = s;
-      }
-      for (int r = 0; r < kBS; r++) x[k * kBS + r] = tmp[r];
-      (void)zv;
+    for (int c = kBS - 1; c >= 0; c--) {
+      double s = x[k * kBS + c];
+      for (int r = c + 1; r < kBS; r++) s -= D[r * kBS + c] * x[k * kBS + r];
+      x[k * kBS + c] = s * w.ldinv[k * kBS + c];
     }
 #else
-    VIO_SYNC();
-    if (cx.tid < kBS) x[k * kBS + cx.tid] = zv;
+    if ((cx.tid >> 6) == 0) trsv15T_wave(D, w.ldinv + k * kBS, x + k * kBS, cx.tid & 63);
     VIO_SYNC();
 #endif
-    // y_j -= L_kj^T z_k for j < k
-    VIO_PARFOR(q, k * kBS) {
+    VIO_PARFOR(q, k * kBS) {  // y_j -= L_kj^T x_k for j < k
       int j = q / kBS, c = q % kBS;
       const double *Lkj = w.Hm + blk_off(k, j);
       double s = 0;
+#pragma unroll
       for (int m = 0; m < kBS; m++) s += Lkj[m * kBS + c] * x[k * kBS + m];
       x[j * kBS + c] -= s;
     }
@@ -969,10 +1034,10 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
         VIO_SYNC();
         bool ok = build_reduced_system(cx, v, w, mu);
-        if (ok) ok = cholesky_blocks(cx, v, w);
+        if (ok) ok = cholesky_blocks(cx, v, w, w.t1);
         stamp(cx, ST_CHOL);
         if (ok) {
-          cholesky_solve(cx, v, w, w.t1);  // y_p
+          cholesky_backsolve(cx, v, w, w.t1);  // y_p
           // back-substitute features: y_f = (gs_f - ws_f^T y_p) / e_f ; GN = -d * y
           double bad = 0;
           VIO_PARFOR(f, F) {
@@ -1144,6 +1209,11 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
   if (v.has_loop) VIO_PARFOR(q, 7) w.xpose[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
   VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
   if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
+  VIO_PARFOR(q, v.nblk * (v.nblk + 1) / 2) {
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= q) bi++;
+    w.blk_ij[q] = (bi << 8) | (q - bi * (bi + 1) / 2);
+  }
   VIO_SYNC();
 #ifndef VIO_EMUL
   if (cx.prof && cx.tid == 0) {
