@@ -228,7 +228,6 @@ typedef struct VioTrackViz { /* good_pts / track_len (UI only), optional */
   int32_t n;
 } VioTrackViz;
 
-#ifdef VIO_FRONTEND_DRAFT /* declarations become live as the kernels land (keeps header == exported symbols) */
 /* n_seq independent trackers (sequences) share one context and one launch.   */
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out);
 void vio_frontend_destroy(vio_frontend_t *fe);
@@ -274,7 +273,6 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
                       float *corners /* [max_corners][2] */, int32_t *n_corners);
 int vio_fundamental_ransac(const VioConfig *cfg, const float *pts1, const float *pts2,
                            int32_t n, uint8_t *inlier_mask);
-#endif /* VIO_FRONTEND_DRAFT */
 
 const char *vio_version(void);
 

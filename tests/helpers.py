@@ -28,6 +28,20 @@ def oracle_lib():
         lib = C.CDLL(so)
         lib.oracle_eval_projection.argtypes = [C.POINTER(abi.VioConfig)] + [_dp] * 8
         lib.oracle_eval_imu.argtypes = [C.POINTER(abi.VioConfig), C.POINTER(abi.VioPreintegration)] + [_dp] * 6
+        u8p, fp, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        cfgp = C.POINTER(abi.VioConfig)
+        lib.oracle_pyr_down.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, u8p]
+        lib.oracle_klt_track.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, fp, u8p, fp]
+        lib.oracle_min_eigen_map.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, fp]
+        lib.oracle_good_features.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, ip]
+        lib.oracle_fundamental_ransac.argtypes = [cfgp, fp, fp, C.c_int32, u8p]
+        lib.oracle_tracker_create.restype = C.c_void_p
+        lib.oracle_tracker_create.argtypes = [cfgp]
+        lib.oracle_tracker_destroy.argtypes = [C.c_void_p]
+        lib.oracle_tracker_read_image.argtypes = [C.c_void_p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                                  C.POINTER(abi.VioObs), ip]
+        lib.oracle_tracker_get_state.argtypes = [C.c_void_p, fp, ip, ip, C.c_int32, ip]
+        lib.oracle_set_lk_accum_mode.argtypes = [C.c_int]
         _oracle = lib
     return _oracle
 
@@ -110,3 +124,65 @@ def check_solution(got_w, got_s, d, tol, tol_prior=None, check_trace=True):
         assert relerr(bg, br) < tp
         for (_, _, a), (_, _, b) in zip(xg, xr):
             assert np.abs(a - b).max() < tol
+
+
+# ---- front-end oracle wrappers -----------------------------------------------------------------------
+_u8p, _fp, _ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+
+def oracle_klt(cfg, prev, nxt, pts):
+    lib = oracle_lib()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    n = len(pts)
+    out, st, err = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+    lib.oracle_klt_track(C.byref(cfg), prev.ctypes.data_as(_u8p), nxt.ctypes.data_as(_u8p), prev.shape[0], prev.shape[1],
+                         prev.shape[1], pts.ctypes.data_as(_fp), n, out.ctypes.data_as(_fp), st.ctypes.data_as(_u8p),
+                         err.ctypes.data_as(_fp))
+    return out, st, err
+
+
+def oracle_good_features(cfg, img, mask, max_corners):
+    lib = oracle_lib()
+    corners = np.zeros((max_corners, 2), np.float32)
+    n = C.c_int32()
+    mp = np.ascontiguousarray(mask, np.uint8).ctypes.data_as(_u8p) if mask is not None else None
+    lib.oracle_good_features(C.byref(cfg), img.ctypes.data_as(_u8p), mp, img.shape[0], img.shape[1], img.shape[1],
+                             max_corners, corners.ctypes.data_as(_fp), C.byref(n))
+    return corners[: n.value].copy()
+
+
+def oracle_ransac(cfg, p1, p2):
+    lib = oracle_lib()
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    m = np.zeros(len(p1), np.uint8)
+    lib.oracle_fundamental_ransac(C.byref(cfg), p1.ctypes.data_as(_fp), p2.ctypes.data_as(_fp), len(p1), m.ctypes.data_as(_u8p))
+    return m
+
+
+class OracleTracker:
+    def __init__(self, cfg):
+        self.lib, self.cfg = oracle_lib(), cfg
+        self.h = self.lib.oracle_tracker_create(C.byref(cfg))
+
+    def read_image(self, img, publish):
+        cap = self.cfg.max_corners
+        obs = (abi.VioObs * cap)()
+        n = C.c_int32()
+        rc = self.lib.oracle_tracker_read_image(self.h, img.ctypes.data_as(_u8p), img.shape[0], img.shape[1], img.shape[1],
+                                                0.0, 1 if publish else 0, obs, C.byref(n))
+        assert rc == 0, rc
+        ids = np.array([obs[i].id for i in range(n.value)], np.int32)
+        xyz = np.array([[obs[i].x, obs[i].y, obs[i].z] for i in range(n.value)]).reshape(n.value, 3)
+        return ids, xyz
+
+    def state(self):
+        cap = self.cfg.max_corners
+        pts, ids, cnt = np.zeros((cap, 2), np.float32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = C.c_int32()
+        self.lib.oracle_tracker_get_state(self.h, pts.ctypes.data_as(_fp), ids.ctypes.data_as(_ip), cnt.ctypes.data_as(_ip),
+                                          cap, C.byref(n))
+        return pts[: n.value].copy(), ids[: n.value].copy(), cnt[: n.value].copy()
+
+    def close(self):
+        self.lib.oracle_tracker_destroy(self.h)

@@ -12,7 +12,6 @@ from helpers import abi
 def declared_symbols():
     txt = open(os.path.join(H.ROOT, "include", "vio_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    txt = re.sub(r"#ifdef VIO_FRONTEND_DRAFT.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vio_[a-z0-9_]+)\s*\(", txt)))
 
 

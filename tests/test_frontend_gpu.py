@@ -1,0 +1,131 @@
+"""GPU parity tests of the HIP KLT front-end against the CPU oracle (OpenCV-3.0 semantics, parity unpinned: the
+oracle is its own reference). Integer and index work is compared bit-exactly; the float stages of LK and of the
+min-eigen map use the same IEEE operation sequence on both sides (no FMA contraction) and are compared exactly too."""
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import abi, synth, pkg
+
+pytestmark = pytest.mark.gpu
+fe = pkg.frontend
+
+
+@pytest.fixture(scope="module")
+def stream():
+    frames, aff = synth.make_image_stream(5, 7, rows=640, cols=480)
+    return frames, aff
+
+
+def test_klt_track_bit_exact(stream):
+    frames, _ = stream
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    pts = H.oracle_good_features(cfg, frames[0], None, 150)
+    assert len(pts) == 150
+    # add sub-pixel starts, points near / outside the border and a point in a flat region
+    rng = np.random.default_rng(1)
+    pts = pts + rng.uniform(-0.5, 0.5, pts.shape).astype(np.float32)
+    extra = np.array([[2.3, 3.1], [478.6, 638.2], [-30.0, 50.0], [500.0, 700.0], [240.0, 1.0]], np.float32)
+    pts = np.vstack([pts, extra])
+    got, gst, gerr = fe.klt_track(cfg, frames[0], frames[1], pts)
+    ref, rst, rerr = H.oracle_klt(cfg, frames[0], frames[1], pts)
+    assert (gst == rst).all()
+    assert rst.sum() >= 150
+    ok = rst > 0
+    assert np.array_equal(got[ok], ref[ok]), np.abs(got[ok] - ref[ok]).max()
+    assert np.array_equal(gerr[ok], rerr[ok])
+
+
+def test_klt_small_image_and_levels():
+    frames, _ = synth.make_image_stream(9, 2, rows=120, cols=96)  # only 2 pyramid levels hold a 21x21 window
+    cfg = abi.default_config(max_corners=40, min_dist=10, image_rows=120, image_cols=96)
+    pts = H.oracle_good_features(cfg, frames[0], None, 40)
+    got, gst, _ = fe.klt_track(cfg, frames[0], frames[1], pts)
+    ref, rst, _ = H.oracle_klt(cfg, frames[0], frames[1], pts)
+    assert (gst == rst).all() and np.array_equal(got[rst > 0], ref[rst > 0])
+
+
+def test_good_features_identical(stream):
+    frames, _ = stream
+    cfg = abi.default_config(max_corners=150, min_dist=30)
+    for mask in (None, "discs"):
+        m = None
+        if mask:
+            m = np.full(frames[0].shape, 255, np.uint8)
+            m[100:300, 50:250] = 0
+            m[:, 400:] = 0
+        got = fe.good_features(cfg, frames[2], m, 150)
+        ref = H.oracle_good_features(cfg, frames[2], m, 150)
+        assert len(ref) > 50
+        assert np.array_equal(got, ref)
+
+
+def test_good_features_flat_image_and_empty_mask():
+    cfg = abi.default_config(max_corners=50)
+    flat = np.full((640, 480), 128, np.uint8)
+    assert len(fe.good_features(cfg, flat, None, 50)) == 0
+    frames, _ = synth.make_image_stream(3, 1)
+    assert len(fe.good_features(cfg, frames[0], np.zeros((640, 480), np.uint8), 50)) == 0
+
+
+def test_fundamental_ransac_identical(stream):
+    frames, _ = stream
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    p1 = H.oracle_good_features(cfg, frames[0], None, 150)
+    p2, st, _ = H.oracle_klt(cfg, frames[0], frames[1], p1)
+    p1, p2 = p1[st > 0], p2[st > 0].copy()
+    rng = np.random.default_rng(0)
+    bad = rng.choice(len(p1), 15, replace=False)
+    p2[bad] += (rng.uniform(5, 25, (15, 2)) * rng.choice([-1, 1], (15, 2))).astype(np.float32)
+    got, ref = fe.fundamental_ransac(cfg, p1, p2), H.oracle_ransac(cfg, p1, p2)
+    assert np.array_equal(got, ref)
+    assert ref.sum() < len(p1) and ref.sum() > len(p1) - 30
+    # fewer than 15 points: everything is kept (LMedS branch of OpenCV 3.0 not restated)
+    assert fe.fundamental_ransac(cfg, p1[:10], p2[:10]).all()
+
+
+def test_tracker_sequence_matches_oracle():
+    """readImage over a 3-sequence batch for 10 frames (FREQ = 3 publish cadence)."""
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    S, T = 3, 10
+    streams = [synth.make_image_stream(20 + s, T, rows=640, cols=480)[0] for s in range(S)]
+    trk = fe.FeatureTracker(cfg, n_seq=S)
+    oracles = [H.OracleTracker(cfg) for _ in range(S)]
+    for f in range(T):
+        publish = f % 3 == 0
+        frames = np.stack([streams[s][f] for s in range(S)])
+        got = trk.read_images(frames, publish)
+        for s in range(S):
+            rids, rxyz = oracles[s].read_image(streams[s][f], publish)
+            gids, gxyz = got[s]
+            assert np.array_equal(gids, rids), (f, s)
+            assert np.array_equal(gxyz, rxyz), (f, s)
+            gp, gi, gc = trk.state(s)
+            rp, ri, rc = oracles[s].state()
+            assert np.array_equal(gi, ri) and np.array_equal(gc, rc), (f, s)
+            assert np.array_equal(gp, rp), (f, s, np.abs(gp - rp).max())
+        if publish:
+            assert len(got[0][0]) > 100
+    trk.close()
+    for o in oracles:
+        o.close()
+
+
+def test_resident_stepping_equals_read_images():
+    cfg = abi.default_config(max_corners=100, min_dist=25)
+    S, T = 2, 4
+    streams = np.stack([np.stack([synth.make_image_stream(40 + s, T)[0][f] for s in range(S)]) for f in range(T)])
+    a = fe.FeatureTracker(cfg, n_seq=S)
+    b = fe.FeatureTracker(cfg, n_seq=S)
+    a.upload_frames(streams)
+    for f in range(T):
+        a.step(f, f % 3 == 0)
+        b.read_images(streams[f], f % 3 == 0)
+    a.sync()
+    for s in range(S):
+        pa, ia, ca = a.state(s)
+        pb, ib, cb = b.state(s)
+        assert np.array_equal(pa, pb) and np.array_equal(ia, ib) and np.array_equal(ca, cb)
+    ms, n = a.kernel_ms()
+    assert n == T and ms > 0
+    a.close(), b.close()

@@ -371,6 +371,23 @@ def load_product():
     lib.vio_backend_sync.argtypes = [vp]
     lib.vio_backend_download.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.POINTER(VioSolveStats)]
     lib.vio_backend_kernel_ms.argtypes = [vp, _dp, _ip]
+    u8p, fp = C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    cfgp = C.POINTER(VioConfig)
+    lib.vio_frontend_create.argtypes = [cfgp, C.c_int32, C.POINTER(vp)]
+    lib.vio_frontend_destroy.argtypes = [vp]
+    lib.vio_frontend_destroy.restype = None
+    lib.vio_frontend_read_image.argtypes = [vp, C.c_int32, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                            C.POINTER(VioObs), _ip, vp]
+    lib.vio_frontend_read_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32,
+                                             C.POINTER(VioObs), _ip]
+    lib.vio_frontend_upload_frames.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.vio_frontend_step_resident.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.vio_frontend_sync.argtypes = [vp]
+    lib.vio_frontend_kernel_ms.argtypes = [vp, _dp, _ip]
+    lib.vio_frontend_get_state.argtypes = [vp, C.c_int32, fp, _ip, _ip, C.c_int32, _ip]
+    lib.vio_klt_track.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, fp, u8p, fp]
+    lib.vio_good_features.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, _ip]
+    lib.vio_fundamental_ransac.argtypes = [cfgp, fp, fp, C.c_int32, u8p]
     lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
     lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib
