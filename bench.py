@@ -81,11 +81,14 @@ def main():
     rows, cols = cfg.image_rows, cfg.image_cols
 
     # ---- synthetic inputs (seed = 42 + sequence id; a few unique streams / windows tiled over the batch) ----------
+    # this rank owns global sequences rank, rank + world, ... (multi.sequences_of_rank); seeds follow the ids
     n_unique, T = 4, 4
-    uniq_frames = [synth.make_image_stream(42 + rank * 1000 + u, T, rows=rows, cols=cols)[0] for u in range(n_unique)]
+    my_ids = pkg.multi.sequences_of_rank(S * world, rank, world)
+    uniq_frames = [synth.make_image_stream(pkg.multi.seed_of_sequence(my_ids[u]), T, rows=rows, cols=cols)[0]
+                   for u in range(n_unique)]
     frames = np.stack([np.stack([uniq_frames[s % n_unique][f] for s in range(S)]) for f in range(T)])
     pre = lambda *a: backend.preintegrate(cfg, *a)
-    uniq_w = [synth.make_window(cfg, pre, seed=42 + rank * 1000 + u, n_features=150) for u in range(8)]
+    uniq_w = [synth.make_window(cfg, pre, seed=pkg.multi.seed_of_sequence(my_ids[u]), n_features=150) for u in range(8)]
     windows = [uniq_w[s % len(uniq_w)].copy() for s in range(S)]
 
     fe = frontend.FeatureTracker(cfg, n_seq=S)
@@ -114,9 +117,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = pkg.multi.max_over_ranks(dist, dt, device="cuda")
 
     fe_ms, _ = fe.kernel_ms()
     be_ms, _ = be.kernel_ms()

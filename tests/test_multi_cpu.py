@@ -1,0 +1,48 @@
+"""world_size-2 gloo test of the replica-parallel bookkeeping used by bench.py --gpus N (no GPU needed)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import helpers as H
+
+
+def test_partition_is_disjoint_and_complete():
+    m = H.pkg.multi if hasattr(H.pkg, "multi") else __import__("importlib").import_module("vins-mobile_amd.multi")
+    for n, w in ((64, 8), (10, 3), (5, 8)):
+        parts = [m.sequences_of_rank(n, r, w) for r in range(w)]
+        flat = sorted(s for p in parts for s in p)
+        assert flat == list(range(n))
+        assert all(s % w == r for r, p in enumerate(parts) for s in p)
+    assert m.seed_of_sequence(0) == 42
+
+
+def test_two_rank_gloo_barrier_and_max(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import importlib, os, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        m = importlib.import_module("vins-mobile_amd.multi")
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        mine = m.sequences_of_rank(64, rank, world)
+        dist.barrier()
+        dt = m.max_over_ranks(dist, 1.0 + rank)           # slowest rank defines the step time
+        rate = m.aggregate_rate(dist, len(mine) * 10, 1.0 + rank)
+        assert dt == float(world), dt
+        assert abs(rate - 64 * 10 / world) < 1e-9, rate
+        dist.destroy_process_group()
+        print("ok", rank)
+    """ % H.ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
