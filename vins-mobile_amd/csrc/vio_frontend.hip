@@ -56,23 +56,38 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 // ---- pyrDown: separable [1 4 6 4 1], BORDER_REFLECT_101, (v + 128) >> 8 -------------------------------
-__global__ void pyr_down_kernel(const uint8_t *src_base, uint8_t *dst_base, size_t seq_stride, int srows, int scols,
-                                int drows, int dcols) {
+// One workgroup = 64x8 output pixels: the (2*64+4) x (2*8+4) source patch goes through LDS once, the horizontal pass
+// leaves 20 rows of integer sums in LDS, the vertical pass writes the tile.
+constexpr int kPdW = 64, kPdH = 8;
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *src_base, uint8_t *dst_base, size_t seq_stride,
+                                                       int srows, int scols, int drows, int dcols) {
+  constexpr int SW = 2 * kPdW + 4, SH = 2 * kPdH + 4;
+  __shared__ uint8_t patch[SH][SW + 4];
+  __shared__ int hsum[SH][kPdW + 1];
   const uint8_t *src = src_base + (size_t)blockIdx.z * seq_stride;
   uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
-  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dcols || y >= drows) return;
-  int cx[5], v = 0;
-#pragma unroll
-  for (int k = 0; k < 5; k++) cx[k] = reflect101(2 * x + k - 2, scols);
-  const int wv[5] = {1, 4, 6, 4, 1};
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const uint8_t *row = src + (size_t)reflect101(2 * y + k - 2, srows) * scols;
-    int h = row[cx[0]] + 4 * row[cx[1]] + 6 * row[cx[2]] + 4 * row[cx[3]] + row[cx[4]];
-    v += wv[k] * h;
+  const int ox = blockIdx.x * kPdW, oy = blockIdx.y * kPdH;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < SH * SW; e += 256) {
+    int ly = e / SW, lx = e - ly * SW;
+    int y = reflect101(min(2 * oy + ly - 2, 2 * srows - 2), srows), x = reflect101(min(2 * ox + lx - 2, 2 * scols - 2), scols);
+    patch[ly][lx] = src[(size_t)y * scols + x];
   }
-  dst[(size_t)y * dcols + x] = (uint8_t)((v + 128) >> 8);
+  __syncthreads();
+  for (int e = tid; e < SH * kPdW; e += 256) {
+    int ly = e / kPdW, lx = e - ly * kPdW;
+    const uint8_t *r = &patch[ly][2 * lx];
+    hsum[ly][lx] = r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4];
+  }
+  __syncthreads();
+  for (int e = tid; e < kPdH * kPdW; e += 256) {
+    int ly = e / kPdW, lx = e - ly * kPdW;
+    int x = ox + lx, y = oy + ly;
+    if (x < dcols && y < drows) {
+      int v = hsum[2 * ly][lx] + 4 * hsum[2 * ly + 1][lx] + 6 * hsum[2 * ly + 2][lx] + 4 * hsum[2 * ly + 3][lx] + hsum[2 * ly + 4][lx];
+      dst[(size_t)y * dcols + x] = (uint8_t)((v + 128) >> 8);
+    }
+  }
 }
 
 // ---- pyramidal LK -------------------------------------------------------------------------------------
@@ -85,10 +100,23 @@ struct LkParams {
   float min_eig;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Wave-wide integer sum on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips. The total lands
+// in lane 63 and is broadcast through an SGPR.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8   -> lane 15 of each row = row sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// Exact sum over the wave of per-lane partials |p| < 2^30: split into 16-bit low part and high part so that both
+// 32-bit reductions cannot overflow; returned as a double holding the exact integer.
+__device__ __forceinline__ double wave_sum_exact(int p) {
+  int lo = p & 0xffff, hi = p >> 16;
+  int slo = wave_sum_i32(lo), shi = wave_sum_i32(hi);
+  return (double)shi * 65536.0 + (double)slo;
 }
 
 __device__ __forceinline__ void scharr_at(const uint8_t *im, int rows, int cols, int y, int x, int &dx, int &dy) {
@@ -117,14 +145,35 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &iw00, int &iw0
   iw11 = (1 << kWBits) - iw00 - iw01 - iw10;
 }
 
+// LDS staging of one wave: the 24x24 template neighbourhood of I, its 22x22 Scharr derivative image and a
+// (21+1+2*kJMargin)^2 region of J around the current estimate. Waves of a workgroup are independent (one feature
+// each); LDS traffic of a wave is ordered, so a wave-level fence is all the synchronisation staging needs.
+constexpr int kIP = kWin + 3;              // 24: window + 1 (bilinear) + 2 (Scharr halo)
+constexpr int kDP = kWin + 1;              // 22: derivative positions
+constexpr int kJMargin = 3;
+constexpr int kJP = kWin + 1 + 2 * kJMargin;  // 28
+struct LkWaveLds {
+  uint8_t I[kIP][kIP];
+  short2 dI[kDP][kDP];
+  uint8_t J[kJP][kJP];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One wave per feature. prev/next pyramids: per sequence `pyr_bytes` apart. pts arrays: [seq][cap][2].
 __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, const uint8_t *next_pyr, LkParams P,
                                                        const int *n_pts, const float *prev_pts, float *next_pts,
                                                        uint8_t *status, float *err) {
+  __shared__ LkWaveLds lds_all[4];
   const int seq = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int pt = blockIdx.x * (blockDim.x >> 6) + wave;
   if (pt >= n_pts[seq]) return;
+  LkWaveLds &L = lds_all[wave];
   const uint8_t *pp = prev_pyr + (size_t)seq * P.ld.pyr_bytes, *np = next_pyr + (size_t)seq * P.ld.pyr_bytes;
   const size_t pidx = ((size_t)seq * P.cap + pt) * 2;
   const float ptx = prev_pts[pidx], pty = prev_pts[pidx + 1];
@@ -153,27 +202,49 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     float a = px - ipx, b = py - ipy;
     int iw00, iw01, iw10, iw11;
     lk_weights(a, b, iw00, iw01, iw10, iw11);
+    // stage I on [ipx-1, ipx+23) x [ipy-1, ipy+23) (BORDER_REFLECT_101), then its Scharr derivatives on
+    // [ipx, ipx+22) x [ipy, ipy+22): zero outside the image (copyMakeBorder BORDER_CONSTANT of derivI)
+    wave_lds_fence();  // previous level's readers are done
+    for (int e = lane; e < kIP * kIP; e += 64) {
+      int ly = e / kIP, lx = e - ly * kIP;
+      int y = reflect101(ipy - 1 + ly, rows), x = reflect101(ipx - 1 + lx, cols);
+      L.I[ly][lx] = I[(size_t)y * cols + x];
+    }
+    wave_lds_fence();
+    for (int e = lane; e < kDP * kDP; e += 64) {
+      int ly = e / kDP, lx = e - ly * kDP;
+      int Y = ipy + ly, X = ipx + lx;
+      short2 d = make_short2(0, 0);
+      if (X >= 0 && X < cols && Y >= 0 && Y < rows) {
+        // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
+        int p00 = L.I[ly][lx], p01 = L.I[ly][lx + 1], p02 = L.I[ly][lx + 2];
+        int p10 = L.I[ly + 1][lx], p12 = L.I[ly + 1][lx + 2];
+        int p20 = L.I[ly + 2][lx], p21 = L.I[ly + 2][lx + 1], p22 = L.I[ly + 2][lx + 2];
+        d.x = (short)(3 * (p02 - p00) + 10 * (p12 - p10) + 3 * (p22 - p20));
+        d.y = (short)(3 * (p20 - p00) + 10 * (p21 - p01) + 3 * (p22 - p02));
+      }
+      L.dI[ly][lx] = d;
+    }
+    wave_lds_fence();
     // template patch + derivatives for this lane's window pixels, kept in registers across the iterations
     short Iv[NPX], Ix[NPX], Iy[NPX];
-    double s11 = 0, s12 = 0, s22 = 0;
+    int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: 7 products of |v| <= 4080^2 fit 32 bits
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       int e = lane + 64 * q;
       Iv[q] = Ix[q] = Iy[q] = 0;
       if (e < kWin * kWin) {
         int y = e / kWin, x = e - y * kWin;
-        int X = ipx + x, Y = ipy + y;
-        int ival = bilin_u8(I, rows, cols, Y, X, iw00, iw01, iw10, iw11);
-        int dx00, dy00, dx01, dy01, dx10, dy10, dx11, dy11;
-        scharr_at(I, rows, cols, Y, X, dx00, dy00), scharr_at(I, rows, cols, Y, X + 1, dx01, dy01);
-        scharr_at(I, rows, cols, Y + 1, X, dx10, dy10), scharr_at(I, rows, cols, Y + 1, X + 1, dx11, dy11);
-        int ixval = descale(dx00 * iw00 + dx01 * iw01 + dx10 * iw10 + dx11 * iw11, kWBits);
-        int iyval = descale(dy00 * iw00 + dy01 * iw01 + dy10 * iw10 + dy11 * iw11, kWBits);
+        int ival = descale(L.I[y + 1][x + 1] * iw00 + L.I[y + 1][x + 2] * iw01 + L.I[y + 2][x + 1] * iw10 + L.I[y + 2][x + 2] * iw11,
+                           kWBits - 5);
+        short2 d00 = L.dI[y][x], d01 = L.dI[y][x + 1], d10 = L.dI[y + 1][x], d11 = L.dI[y + 1][x + 1];
+        int ixval = descale(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, kWBits);
+        int iyval = descale(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, kWBits);
         Iv[q] = (short)ival, Ix[q] = (short)ixval, Iy[q] = (short)iyval;
-        s11 += (double)(ixval * ixval), s12 += (double)(ixval * iyval), s22 += (double)(iyval * iyval);
+        p11 += ixval * ixval, p12 += ixval * iyval, p22 += iyval * iyval;
       }
     }
-    s11 = wave_sum(s11), s12 = wave_sum(s12), s22 = wave_sum(s22);  // exact integer sums
+    const double s11 = wave_sum_exact(p11), s12 = wave_sum_exact(p12), s22 = wave_sum_exact(p22);  // exact integer sums
     float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * kWin * kWin);
@@ -184,25 +255,44 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     D = 1.f / D;
     qx -= half, qy -= half;
     float pdx = 0.f, pdy = 0.f;
+    int jox = 0, joy = 0;      // origin of the staged J region
+    bool j_staged = false;
+    auto stage_j = [&](int iqx, int iqy) {
+      jox = iqx - kJMargin, joy = iqy - kJMargin;
+      wave_lds_fence();
+      for (int e = lane; e < kJP * kJP; e += 64) {
+        int ly = e / kJP, lx = e - ly * kJP;
+        int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
+        int x = reflect101(min(max(jox + lx, -cols + 1), 2 * cols - 2), cols);
+        L.J[ly][lx] = J[(size_t)y * cols + x];
+      }
+      wave_lds_fence();
+      j_staged = true;
+    };
+    auto sample_j = [&](int iqx, int iqy, int x, int y) {  // bilinear J at window pixel (x, y), staged region
+      int ly = iqy - joy + y, lx = iqx - jox + x;
+      return descale(L.J[ly][lx] * iw00 + L.J[ly][lx + 1] * iw01 + L.J[ly + 1][lx] * iw10 + L.J[ly + 1][lx + 1] * iw11, kWBits - 5);
+    };
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
       if (iqx < -kWin || iqx >= cols || iqy < -kWin || iqy >= rows) {
         if (level == 0) st = false;
         break;
       }
+      if (!j_staged || iqx < jox || iqx > jox + 2 * kJMargin || iqy < joy || iqy > joy + 2 * kJMargin) stage_j(iqx, iqy);
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
-      double sb1 = 0, sb2 = 0;
+      int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, 7 pixels per lane: fits 32 bits
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
         int e = lane + 64 * q;
         if (e < kWin * kWin) {
           int y = e / kWin, x = e - y * kWin;
-          int diff = bilin_u8(J, rows, cols, iqy + y, iqx + x, iw00, iw01, iw10, iw11) - Iv[q];
-          sb1 += (double)(diff * Ix[q]), sb2 += (double)(diff * Iy[q]);
+          int diff = sample_j(iqx, iqy, x, y) - Iv[q];
+          pb1 += diff * Ix[q], pb2 += diff * Iy[q];
         }
       }
-      sb1 = wave_sum(sb1), sb2 = wave_sum(sb2);
+      const double sb1 = wave_sum_exact(pb1), sb2 = wave_sum_exact(pb2);
       float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
       qx += ddx, qy += ddy;
@@ -221,19 +311,19 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
         st = false;
         continue;
       }
+      if (!j_staged || iex < jox || iex > jox + 2 * kJMargin || iey < joy || iey > joy + 2 * kJMargin) stage_j(iex, iey);
       float aa = ex - iex, bb = ey - iey;
       lk_weights(aa, bb, iw00, iw01, iw10, iw11);
-      double se = 0;
+      int pe = 0;
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
         int e = lane + 64 * q;
         if (e < kWin * kWin) {
           int y = e / kWin, x = e - y * kWin;
-          int diff = bilin_u8(J, rows, cols, iey + y, iex + x, iw00, iw01, iw10, iw11) - Iv[q];
-          se += (double)abs(diff);
+          pe += abs(sample_j(iex, iey, x, y) - Iv[q]);
         }
       }
-      se = wave_sum(se);
+      const int se = wave_sum_i32(pe);  // <= 441 * 16320 < 2^23
       er = (float)se * 1.f / (32 * kWin * kWin);
     }
   }
@@ -389,7 +479,7 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
-constexpr int kHypBatch = 32;  // hypotheses generated / evaluated per round
+constexpr int kHypBatch = 16;  // hypotheses generated / evaluated per round
 
 struct RansacShared {
   float ms1[kHypBatch][14], ms2[kHypBatch][14];
@@ -397,6 +487,8 @@ struct RansacShared {
   int nmodels[kHypBatch];
   int good[kHypBatch][3];
   int valid[kHypBatch];  // subset found
+  int coll[kHypBatch];   // speculative subset failed checkSubset
+  unsigned long long rng_before[kHypBatch];
   unsigned long long rng_state;
   int niters, max_good, best_h, best_k, iter, done, failed_first;
   double bestF[9];
@@ -421,37 +513,59 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
   __syncthreads();
   const float t = thresh * thresh;
   while (true) {
-    // ---- phase 1: draw the next kHypBatch subsets sequentially (one RNG stream)
+    // ---- phase 1: draw the next kHypBatch subsets sequentially (one RNG stream). The draws are cheap integer
+    //      work; checkSubset (collinearity, 2 x 15 cross products in double) is evaluated in parallel afterwards.
+    //      Subsets are drawn speculatively as if every check passed, which is the same RNG consumption; if one fails
+    //      (rare) the tail from that hypothesis is redrawn with the full serial semantics.
+    auto draw = [&](unsigned long long &st, int h, bool with_check) {
+      int idx[7], i = 0, iters = 0;
+      const int max_attempts = 10000;
+      for (; iters < max_attempts; iters++) {
+        for (i = 0; i < model_points && iters < max_attempts;) {
+          int idx_i = 0;
+          for (;;) {
+            st = (unsigned long long)(unsigned)st * 4164903690U + (unsigned)(st >> 32);
+            idx_i = idx[i] = (int)((unsigned)st % (unsigned)count);
+            int j;
+            for (j = 0; j < i; j++)
+              if (idx_i == idx[j]) break;
+            if (j == i) break;
+          }
+          S.ms1[h][2 * i] = m1[2 * idx_i], S.ms1[h][2 * i + 1] = m1[2 * idx_i + 1];
+          S.ms2[h][2 * i] = m2[2 * idx_i], S.ms2[h][2 * i + 1] = m2[2 * idx_i + 1];
+          i++;
+        }
+        if (with_check && i == model_points && (have_collinear_dev(S.ms1[h], i) || have_collinear_dev(S.ms2[h], i))) continue;
+        break;
+      }
+      return (i == model_points && iters < max_attempts) ? 1 : 0;
+    };
     if (tid == 0) {
       unsigned long long st = S.rng_state;
       for (int h = 0; h < kHypBatch; h++) {
-        int idx[7], i = 0, iters = 0;
-        const int max_attempts = 10000;
-        for (; iters < max_attempts; iters++) {
-          for (i = 0; i < model_points && iters < max_attempts;) {
-            int idx_i = 0;
-            for (;;) {
-              st = (unsigned long long)(unsigned)st * 4164903690U + (unsigned)(st >> 32);
-              idx_i = idx[i] = (int)((unsigned)st % (unsigned)count);
-              int j;
-              for (j = 0; j < i; j++)
-                if (idx_i == idx[j]) break;
-              if (j == i) break;
-            }
-            S.ms1[h][2 * i] = m1[2 * idx_i], S.ms1[h][2 * i + 1] = m1[2 * idx_i + 1];
-            S.ms2[h][2 * i] = m2[2 * idx_i], S.ms2[h][2 * i + 1] = m2[2 * idx_i + 1];
-            i++;
-          }
-          if (i == model_points && (have_collinear_dev(S.ms1[h], i) || have_collinear_dev(S.ms2[h], i))) continue;
-          break;
-        }
-        S.valid[h] = (i == model_points && iters < max_attempts) ? 1 : 0;
-        if (!S.valid[h]) {
-          for (int hh = h + 1; hh < kHypBatch; hh++) S.valid[hh] = 0;
-          break;
-        }
+        S.rng_before[h] = st;
+        S.valid[h] = draw(st, h, false);
       }
       S.rng_state = st;
+    }
+    __syncthreads();
+    if (tid < kHypBatch) S.coll[tid] = (have_collinear_dev(S.ms1[tid], 7) || have_collinear_dev(S.ms2[tid], 7)) ? 1 : 0;
+    __syncthreads();
+    if (tid == 0) {
+      int first = -1;
+      for (int h = 0; h < kHypBatch && first < 0; h++)
+        if (S.coll[h]) first = h;
+      if (first >= 0) {
+        unsigned long long st = S.rng_before[first];
+        for (int h = first; h < kHypBatch; h++) {
+          S.valid[h] = draw(st, h, true);
+          if (!S.valid[h]) {
+            for (int hh = h + 1; hh < kHypBatch; hh++) S.valid[hh] = 0;
+            break;
+          }
+        }
+        S.rng_state = st;
+      }
     }
     __syncthreads();
     // ---- phase 2: 7-point models, one thread per hypothesis
@@ -683,22 +797,6 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
   }
 }
 
-// mask.setTo(255) happens with a memset; one workgroup paints one filled circle.
-__global__ void paint_mask_kernel(uint8_t *mask, size_t seq_stride, int rows, int cols, const int *kept_xy, const int *n_kept,
-                                  int cap, const int *hw, int radius) {
-  const int seq = blockIdx.y, k = blockIdx.x;
-  if (k >= n_kept[seq]) return;
-  const int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
-  uint8_t *m = mask + (size_t)seq * seq_stride;
-  const int side = 2 * radius + 1;
-  for (int e = threadIdx.x; e < side * side; e += blockDim.x) {
-    int dy = e / side - radius, dx = e % side - radius;
-    int y = cy + dy, x = cx + dx;
-    int h = hw[radius + dy];
-    if (y >= 0 && y < rows && x >= 0 && x < cols && dx >= -h && dx <= h) m[(size_t)y * cols + x] = 0;
-  }
-}
-
 // ---- goodFeaturesToTrack -----------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ordered_bits(float v) {  // monotone float -> uint map (atomicMax on it)
   unsigned u = __float_as_uint(v);
@@ -709,95 +807,164 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
 }
 
 constexpr int kTile = 16;
+constexpr int kMaxTileDiscs = 32;  // kept discs that can overlap one 16x16 tile (min distance between them applies)
 
-// cornerMinEigenVal(blockSize 3, ksize 3) and the masked maximum. One workgroup = one 16x16 tile.
-__global__ __launch_bounds__(256) void min_eigen_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
-                                                        size_t mask_stride, float *eig_base, unsigned *max_bits, int rows,
-                                                        int cols) {
-  __shared__ float sxx[kTile + 2][kTile + 2], sxy[kTile + 2][kTile + 2], syy[kTile + 2][kTile + 2];
+// goodFeaturesToTrack front half, fused: cornerMinEigenVal (Sobel/1/3060 -> products -> 3x3 box -> min eigenvalue),
+// the masked maximum (minMaxLoc) and the candidate test "equal to its 3x3 maximum, inside the mask, 1-px border
+// excluded". The eigenvalue map never goes to memory: a 16x16 tile computes products on a 20x20 halo and eigenvalues
+// on an 18x18 halo in LDS. The mask is either an image (stand-alone operator) or evaluated analytically from the
+// discs setMask painted (feature_tracker.cpp:80): no mask image, memset or paint pass on the tracker path.
+// The quality threshold needs the global maximum, so it is applied later by the selection kernel.
+template <bool IMG_MASK>
+__global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
+                                                     size_t mask_stride, const int *kept_xy, const int *n_kept, int cap,
+                                                     const int *hw, int radius, unsigned *max_bits, int rows, int cols,
+                                                     unsigned long long *cand_base, int seg_cap, int *n_cand) {
+  constexpr int PS = kTile + 6, CS = kTile + 4, ES = kTile + 2;  // source patch 22, product grid 20, eigen grid 18
+  __shared__ float src[PS][PS + 1];
+  __shared__ float sxx[CS][CS + 1], sxy[CS][CS + 1], syy[CS][CS + 1];
+  __shared__ float seig[ES][ES + 1];
+  __shared__ int disc[kMaxTileDiscs][2];
+  __shared__ int n_disc;
   __shared__ unsigned smax;
+  __shared__ int s_ncand, s_base;
+  __shared__ unsigned long long s_cand[kTile * kTile];
   const int seq = blockIdx.z;
   const uint8_t *img = img_base + (size_t)seq * img_stride;
-  const uint8_t *mask = mask_base + (size_t)seq * mask_stride;
-  float *eig = eig_base + (size_t)seq * rows * cols;
   const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
   const int tid = threadIdx.y * kTile + threadIdx.x;
-  if (tid == 0) smax = 0;
+  if (tid == 0) smax = 0, n_disc = 0, s_ncand = 0;
+  // source patch in EXTENDED coordinates [x0-3, x0+19) x [y0-3, y0+19): value = img(reflect101(coord))
+  for (int e = tid; e < PS * PS; e += kTile * kTile) {
+    int ly = e / PS, lx = e - ly * PS;
+    int y = reflect101(min(max(y0 + ly - 3, -rows + 1), 2 * rows - 2), rows);
+    int x = reflect101(min(max(x0 + lx - 3, -cols + 1), 2 * cols - 2), cols);
+    src[ly][lx] = (float)img[(size_t)y * cols + x];
+  }
+  __syncthreads();
+  if (!IMG_MASK) {  // discs that can touch this tile
+    const int nk = n_kept[seq];
+    for (int k = tid; k < nk; k += kTile * kTile) {
+      int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
+      if (cx + radius >= x0 && cx - radius < x0 + kTile && cy + radius >= y0 && cy - radius < y0 + kTile) {
+        int slot = atomicAdd(&n_disc, 1);
+        if (slot < kMaxTileDiscs) disc[slot][0] = cx, disc[slot][1] = cy;
+      }
+    }
+  }
   const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
   const float s2 = s * 2.f;
-  // derivative products on the (kTile+2)^2 halo; halo positions outside the image take the REFLECTED position's value
-  for (int e = tid; e < (kTile + 2) * (kTile + 2); e += kTile * kTile) {
-    int ly = e / (kTile + 2), lx = e - ly * (kTile + 2);
-    int y = reflect101(y0 + ly - 1, rows), x = reflect101(x0 + lx - 1, cols);
-    // clamp far-out tiles (partial tiles at the image edge)
-    y = min(max(y, 0), rows - 1), x = min(max(x, 0), cols - 1);
-    int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows), xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
-    const uint8_t *r0 = img + (size_t)ym * cols, *r1 = img + (size_t)y * cols, *r2 = img + (size_t)yp * cols;
-    float d0 = (float)((int)r0[xp] - (int)r0[xm]), d1 = (float)((int)r1[xp] - (int)r1[xm]), d2 = (float)((int)r2[xp] - (int)r2[xm]);
-    float dx = s2 * d1 + s * (d0 + d2);
-    float t0 = s2 * (float)r0[x] + s * ((float)r0[xm] + (float)r0[xp]);
-    float t2 = s2 * (float)r2[x] + s * ((float)r2[xm] + (float)r2[xp]);
-    float dy = t2 - t0;
+  // derivative products on the 20x20 grid (extended coords [x0-2, x0+18)); a grid position outside the image takes the
+  // value of its REFLECTED position (boxFilter BORDER_REFLECT_101 acts on the product images)
+  for (int e = tid; e < CS * CS; e += kTile * kTile) {
+    int ly = e / CS, lx = e - ly * CS;
+    int y = reflect101(min(max(y0 + ly - 2, -rows + 1), 2 * rows - 2), rows);
+    int x = reflect101(min(max(x0 + lx - 2, -cols + 1), 2 * cols - 2), cols);
+    int py = y - (y0 - 3), px = x - (x0 - 3);  // patch-local index of the (in-image) position
+    float dx, dy;
+    if (py >= 1 && py < PS - 1 && px >= 1 && px < PS - 1) {
+      float d0 = src[py - 1][px + 1] - src[py - 1][px - 1], d1 = src[py][px + 1] - src[py][px - 1],
+            d2 = src[py + 1][px + 1] - src[py + 1][px - 1];
+      dx = s2 * d1 + s * (d0 + d2);
+      float t0 = s2 * src[py - 1][px] + s * (src[py - 1][px - 1] + src[py - 1][px + 1]);
+      float t2 = s2 * src[py + 1][px] + s * (src[py + 1][px - 1] + src[py + 1][px + 1]);
+      dy = t2 - t0;
+    } else {  // reflected position fell outside the staged patch (only at partial edge tiles): read the image
+      int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows), xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+      const uint8_t *r0 = img + (size_t)ym * cols, *r1 = img + (size_t)y * cols, *r2 = img + (size_t)yp * cols;
+      float d0 = (float)((int)r0[xp] - (int)r0[xm]), d1 = (float)((int)r1[xp] - (int)r1[xm]), d2 = (float)((int)r2[xp] - (int)r2[xm]);
+      dx = s2 * d1 + s * (d0 + d2);
+      float t0 = s2 * (float)r0[x] + s * ((float)r0[xm] + (float)r0[xp]);
+      float t2 = s2 * (float)r2[x] + s * ((float)r2[xm] + (float)r2[xp]);
+      dy = t2 - t0;
+    }
     sxx[ly][lx] = dx * dx, sxy[ly][lx] = dx * dy, syy[ly][lx] = dy * dy;
   }
   __syncthreads();
-  const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-  if (x < cols && y < rows) {
-    const int lx = threadIdx.x + 1, ly = threadIdx.y + 1;
+  // eigenvalues on the 18x18 grid (extended coords [x0-1, x0+17)); only in-image positions are ever consumed
+  for (int e = tid; e < ES * ES; e += kTile * kTile) {
+    int ly = e / ES, lx = e - ly * ES;
+    int cy = ly + 1, cx = lx + 1;  // centre in the product grid
     float a, b, c;
     {
-      float r0 = (sxx[ly - 1][lx - 1] + sxx[ly - 1][lx]) + sxx[ly - 1][lx + 1];
-      float r1 = (sxx[ly][lx - 1] + sxx[ly][lx]) + sxx[ly][lx + 1];
-      float r2 = (sxx[ly + 1][lx - 1] + sxx[ly + 1][lx]) + sxx[ly + 1][lx + 1];
+      float r0 = (sxx[cy - 1][cx - 1] + sxx[cy - 1][cx]) + sxx[cy - 1][cx + 1];
+      float r1 = (sxx[cy][cx - 1] + sxx[cy][cx]) + sxx[cy][cx + 1];
+      float r2 = (sxx[cy + 1][cx - 1] + sxx[cy + 1][cx]) + sxx[cy + 1][cx + 1];
       a = ((r0 + r1) + r2) * 0.5f;
     }
     {
-      float r0 = (sxy[ly - 1][lx - 1] + sxy[ly - 1][lx]) + sxy[ly - 1][lx + 1];
-      float r1 = (sxy[ly][lx - 1] + sxy[ly][lx]) + sxy[ly][lx + 1];
-      float r2 = (sxy[ly + 1][lx - 1] + sxy[ly + 1][lx]) + sxy[ly + 1][lx + 1];
+      float r0 = (sxy[cy - 1][cx - 1] + sxy[cy - 1][cx]) + sxy[cy - 1][cx + 1];
+      float r1 = (sxy[cy][cx - 1] + sxy[cy][cx]) + sxy[cy][cx + 1];
+      float r2 = (sxy[cy + 1][cx - 1] + sxy[cy + 1][cx]) + sxy[cy + 1][cx + 1];
       b = (r0 + r1) + r2;
     }
     {
-      float r0 = (syy[ly - 1][lx - 1] + syy[ly - 1][lx]) + syy[ly - 1][lx + 1];
-      float r1 = (syy[ly][lx - 1] + syy[ly][lx]) + syy[ly][lx + 1];
-      float r2 = (syy[ly + 1][lx - 1] + syy[ly + 1][lx]) + syy[ly + 1][lx + 1];
+      float r0 = (syy[cy - 1][cx - 1] + syy[cy - 1][cx]) + syy[cy - 1][cx + 1];
+      float r1 = (syy[cy][cx - 1] + syy[cy][cx]) + syy[cy][cx + 1];
+      float r2 = (syy[cy + 1][cx - 1] + syy[cy + 1][cx]) + syy[cy + 1][cx + 1];
       c = ((r0 + r1) + r2) * 0.5f;
     }
-    float v = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-    eig[(size_t)y * cols + x] = v;
-    if (mask[(size_t)y * cols + x]) atomicMax(&smax, ordered_bits(v));
+    seig[ly][lx] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
   }
   __syncthreads();
-  if (tid == 0 && smax) atomicMax(&max_bits[seq], smax);
-}
-
-// Candidates: value > quality * max, equal to its 3x3 maximum, inside the mask, 1-px border excluded.
-__global__ __launch_bounds__(256) void corner_candidates_kernel(const float *eig_base, const uint8_t *mask_base,
-                                                                size_t mask_stride, const unsigned *max_bits, double quality,
-                                                                int rows, int cols, unsigned long long *cand_base,
-                                                                int cand_cap, int *n_cand) {
-  const int seq = blockIdx.z;
-  const float *eig = eig_base + (size_t)seq * rows * cols;
-  const uint8_t *mask = mask_base + (size_t)seq * mask_stride;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x < 1 || y < 1 || x >= cols - 1 || y >= rows - 1) return;
-  const unsigned mb = max_bits[seq];
-  if (mb == 0) return;  // empty mask
-  const float thr = (float)((double)from_ordered_bits(mb) * quality);
-  const float v = eig[(size_t)y * cols + x];
-  if (!(v > thr) || !mask[(size_t)y * cols + x]) return;
-  float m = v;
+  const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+  bool is_cand = false;
+  float v = 0.f;
+  unsigned my_max = 0;
+  if (x < cols && y < rows) {
+    v = seig[threadIdx.y + 1][threadIdx.x + 1];
+    bool unmasked;
+    if (IMG_MASK) {
+      unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + x] != 0;
+    } else {
+      unmasked = true;
+      const int nd = min(n_disc, kMaxTileDiscs);
+      for (int k = 0; k < nd; k++) {
+        int dy = y - disc[k][1], dx = x - disc[k][0];
+        if (dy >= -radius && dy <= radius) {
+          int h = hw[radius + dy];
+          if (dx >= -h && dx <= h) unmasked = false;
+        }
+      }
+    }
+    if (unmasked) {
+      my_max = ordered_bits(v);
+      if (x >= 1 && y >= 1 && x < cols - 1 && y < rows - 1 && v > 0.f) {
+        float m = v;
 #pragma unroll
-  for (int dy = -1; dy <= 1; dy++)
+        for (int dy = 0; dy < 3; dy++)
 #pragma unroll
-    for (int dx = -1; dx <= 1; dx++) m = fmaxf(m, eig[(size_t)(y + dy) * cols + x + dx]);
-  if (v != m) return;
-  int slot = atomicAdd(&n_cand[seq], 1);
-  if (slot < cand_cap) {
-    unsigned idx = (unsigned)(y * cols + x);
-    // key: larger value first, then smaller raster index (v > 0 here, so its bit pattern is monotone)
-    cand_base[(size_t)seq * cand_cap + slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+          for (int dx = 0; dx < 3; dx++) m = fmaxf(m, seig[threadIdx.y + dy][threadIdx.x + dx]);
+        is_cand = v == m;
+      }
+    }
   }
+  // masked maximum: wave max on the DPP/shuffle network, then one LDS atomic per wave
+  {
+    unsigned m = my_max;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((tid & 63) == 0 && m) atomicMax(&smax, m);
+  }
+  // candidates: collected per workgroup in LDS, appended with ONE global atomic per workgroup
+  if (is_cand) {
+    int slot = atomicAdd(&s_ncand, 1);
+    unsigned idx = (unsigned)(y * cols + x);
+    s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+  }
+  __syncthreads();
+  // every tile row of a sequence owns a segment of the candidate list and a counter / maximum slot, so the global
+  // atomics of one address come from the <= cols/16 tiles of that row only
+  const int nseg = gridDim.y;
+  const size_t segi = (size_t)seq * nseg + blockIdx.y;
+  const int nc = s_ncand;
+  if (tid == 0 && nc) s_base = atomicAdd(&n_cand[segi], nc);
+  __syncthreads();
+  if (tid < nc) {
+    int slot = s_base + tid;
+    if (slot < seg_cap) cand_base[segi * seg_cap + slot] = s_cand[tid];
+  }
+  if (tid == 0 && smax) atomicMax(&max_bits[segi], smax);
 }
 
 struct SelectParams {
@@ -806,33 +973,70 @@ struct SelectParams {
   double fx, fy, cx, cy;
 };
 
-// Greedy pick in sorted order with the min-distance rule == repeat { take the best alive candidate; kill everything
-// closer than min_dist }. Then addPoints / updateID / image_msg and the end-of-publish copies.
-__global__ __launch_bounds__(256) void corner_select_kernel(unsigned long long *cand_base, int cand_cap, const int *n_cand,
-                                                            SelectParams P, float *forw_pts, float *cur_pts, float *pre_pts,
-                                                            int *ids, int *track_cnt, int *n_forw, int *n_pts, int *n_id,
-                                                            VioObs *obs, int *n_obs) {
-  __shared__ unsigned long long red[256];
-  __shared__ int s_n;
+constexpr int kSelThreads = 512;
+constexpr int kSelLds = 8192;  // candidate keys kept in LDS (64 KB); larger lists are processed in place in HBM
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// goodFeaturesToTrack back half: quality threshold, then greedy pick in sorted order with the min-distance rule
+// == repeat { take the best alive candidate; kill everything closer than min_dist }. Then addPoints / updateID /
+// image_msg and the end-of-publish copies (feature_tracker.cpp:271-307).
+__global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned long long *cand_base, int seg_cap, int nseg,
+                                                                    const int *n_cand, const unsigned *max_bits,
+                                                                    double quality, SelectParams P, float *forw_pts,
+                                                                    float *cur_pts, float *pre_pts, int *ids, int *track_cnt,
+                                                                    int *n_forw, int *n_pts, int *n_id, VioObs *obs,
+                                                                    int *n_obs) {
+  __shared__ unsigned long long keys[kSelLds];
+  __shared__ unsigned long long red[kSelThreads / 64];
+  __shared__ int s_n, s_cnt;
   const int seq = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  unsigned long long *cand = cand_base + (size_t)seq * cand_cap;
-  const int nc = min(n_cand[seq], cand_cap);
+  unsigned long long *cand = cand_base + (size_t)seq * nseg * seg_cap;  // nseg segments of seg_cap keys
   const size_t base = (size_t)seq * P.cap;
   int n = n_forw[seq];
   const int want = P.max_corners - n;
   const float md2 = P.min_dist * P.min_dist;
-  if (tid == 0) s_n = n;
+  unsigned mb = 0;
+  for (int g = 0; g < nseg; g++) mb = max(mb, max_bits[(size_t)seq * nseg + g]);
+  const float thr = mb ? (float)((double)from_ordered_bits(mb) * quality) : 3.4e38f;
+  if (tid == 0) s_n = n, s_cnt = 0;
   __syncthreads();
+  // threshold(eig, maxVal * qualityLevel, THRESH_TOZERO): keep v > thr. Unused tail slots of every segment are
+  // zeroed so that the in-place (HBM) path can scan the whole nseg * seg_cap range.
+  const int total = nseg * seg_cap;
+  for (int i = tid; i < total; i += nt) {
+    int g = i / seg_cap, j = i - g * seg_cap;
+    int cnt = min(n_cand[(size_t)seq * nseg + g], seg_cap);
+    unsigned long long k = j < cnt ? cand[i] : 0;
+    if (k && __uint_as_float((unsigned)(k >> 32)) > thr) {
+      int slot = atomicAdd(&s_cnt, 1);
+      if (slot < kSelLds) keys[slot] = k;
+    } else {
+      cand[i] = 0;
+    }
+  }
+  __syncthreads();
+  const bool in_lds = s_cnt <= kSelLds;
+  unsigned long long *K = in_lds ? keys : cand;
+  const int nc = in_lds ? s_cnt : total;
   for (int round = 0; round < want; round++) {
     unsigned long long best = 0;
-    for (int i = tid; i < nc; i += nt) best = cand[i] > best ? cand[i] : best;
-    red[tid] = best;
-    __syncthreads();
-    for (int o = nt / 2; o > 0; o >>= 1) {
-      if (tid < o) red[tid] = red[tid + o] > red[tid] ? red[tid + o] : red[tid];
-      __syncthreads();
+    for (int i = tid; i < nc; i += nt) {
+      unsigned long long k = K[i];
+      best = k > best ? k : best;
     }
+    best = wave_max_u64(best);
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
     best = red[0];
+    for (int w = 1; w < nt / 64; w++) best = red[w] > best ? red[w] : best;
     __syncthreads();
     if (best == 0) break;
     const unsigned bidx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
@@ -844,16 +1048,16 @@ __global__ __launch_bounds__(256) void corner_select_kernel(unsigned long long *
     }
     if (P.min_dist >= 1.f) {
       for (int i = tid; i < nc; i += nt) {
-        unsigned long long c = cand[i];
+        unsigned long long c = K[i];
         if (c) {
           unsigned idx = 0xffffffffu - (unsigned)(c & 0xffffffffu);
           float dx = (float)((int)(idx % P.cols) - bx), dy = (float)((int)(idx / P.cols) - by);
-          if (dx * dx + dy * dy < md2) cand[i] = 0;
+          if (dx * dx + dy * dy < md2) K[i] = 0;
         }
       }
     } else {
       for (int i = tid; i < nc; i += nt)
-        if (cand[i] == best) cand[i] = 0;
+        if (K[i] == best) K[i] = 0;
     }
     __syncthreads();
   }
@@ -911,11 +1115,10 @@ struct vio_frontend {
   uint8_t *pyr[2] = {nullptr, nullptr};  // [n_seq][pyr_bytes]; cur = pyr[cur_idx], forw = pyr[1 - cur_idx]
   int cur_idx = 0;
   bool have_img = false;
-  uint8_t *mask = nullptr;      // [n_seq][rows*cols]
-  float *eig = nullptr;         // [n_seq][rows*cols]
+  uint8_t *mask = nullptr;      // [rows*cols], only the stand-alone vio_good_features uses a mask image
   unsigned *max_bits = nullptr;
   unsigned long long *cand = nullptr;
-  int cand_cap = 0;
+  int nseg = 0, seg_cap = 0;  // candidate list: one segment per 16-row tile band
   int *n_cand = nullptr;
   float *cur_pts = nullptr, *pre_pts = nullptr, *forw_pts = nullptr, *lk_err = nullptr;
   int *ids = nullptr, *track_cnt = nullptr, *n_pts = nullptr, *n_forw = nullptr, *n_id = nullptr, *kept_xy = nullptr,
@@ -943,7 +1146,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   uint8_t *forw = fe->pyr[fidx];
   HIP_OK(hipMemcpy2DAsync(forw, fe->ld.pyr_bytes, d_frames, img_bytes, img_bytes, S, hipMemcpyDeviceToDevice, st));
   for (int l = 1; l < fe->ld.levels; l++) {
-    dim3 blk(32, 8), grd((fe->ld.cols[l] + 31) / 32, (fe->ld.rows[l] + 7) / 8, S);
+    dim3 blk(256), grd((fe->ld.cols[l] + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, S);
     hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, forw + fe->ld.off[l - 1], forw + fe->ld.off[l], fe->ld.pyr_bytes,
                        fe->ld.rows[l - 1], fe->ld.cols[l - 1], fe->ld.rows[l], fe->ld.cols[l]);
   }
@@ -970,22 +1173,18 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   hipLaunchKernelGGL(track_update_kernel, dim3(S), dim3(256), shm, st, A, publish);
   if (publish) {
-    HIP_OK(hipMemsetAsync(fe->mask, 255, (size_t)S * img_bytes, st));
-    HIP_OK(hipMemsetAsync(fe->max_bits, 0, sizeof(unsigned) * S, st));
-    HIP_OK(hipMemsetAsync(fe->n_cand, 0, sizeof(int) * S, st));
-    hipLaunchKernelGGL(paint_mask_kernel, dim3(cap, S), dim3(256), 0, st, fe->mask, img_bytes, rows, cols, fe->kept_xy,
-                       fe->n_kept, cap, fe->hw, fe->cfg.min_dist);
-    dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, (rows + kTile - 1) / kTile, S);
-    hipLaunchKernelGGL(min_eigen_kernel, tg, tb, 0, st, forw, fe->ld.pyr_bytes, fe->mask, img_bytes, fe->eig, fe->max_bits,
-                       rows, cols);
-    dim3 cb(32, 8), cg((cols + 31) / 32, (rows + 7) / 8, S);
-    hipLaunchKernelGGL(corner_candidates_kernel, cg, cb, 0, st, fe->eig, fe->mask, img_bytes, fe->max_bits,
-                       fe->cfg.quality_level, rows, cols, fe->cand, fe->cand_cap, fe->n_cand);
+    HIP_OK(hipMemsetAsync(fe->max_bits, 0, sizeof(unsigned) * S * fe->nseg, st));
+    HIP_OK(hipMemsetAsync(fe->n_cand, 0, sizeof(int) * S * fe->nseg, st));
+    dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, fe->nseg, S);
+    hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
+                       fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
+                       fe->seg_cap, fe->n_cand);
     SelectParams SP;
     SP.cap = cap, SP.rows = rows, SP.cols = cols, SP.max_corners = fe->cfg.max_corners, SP.min_dist = (float)fe->cfg.min_dist;
     SP.fx = fe->cfg.fx, SP.fy = fe->cfg.fy, SP.cx = fe->cfg.cx, SP.cy = fe->cfg.cy;
-    hipLaunchKernelGGL(corner_select_kernel, dim3(S), dim3(256), 0, st, fe->cand, fe->cand_cap, fe->n_cand, SP, fe->forw_pts,
-                       fe->cur_pts, fe->pre_pts, fe->ids, fe->track_cnt, fe->n_forw, fe->n_pts, fe->n_id, fe->obs, fe->n_obs);
+    hipLaunchKernelGGL(corner_select_kernel, dim3(S), dim3(kSelThreads), 0, st, fe->cand, fe->seg_cap, fe->nseg, fe->n_cand,
+                       fe->max_bits, fe->cfg.quality_level, SP, fe->forw_pts, fe->cur_pts, fe->pre_pts, fe->ids,
+                       fe->track_cnt, fe->n_forw, fe->n_pts, fe->n_id, fe->obs, fe->n_obs);
   }
   HIP_OK(hipGetLastError());
   fe->cur_idx = fidx;  // cur_img = forw_img (:284)
@@ -1019,18 +1218,17 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   }
   ld.pyr_bytes = (off + 255) & ~(size_t)255;
   const size_t S = n_seq, px = (size_t)cfg->image_rows * cfg->image_cols, cap = fe->cap;
-  fe->cand_cap = (int)std::min<size_t>(px / 4, 1 << 17);
+  fe->nseg = (cfg->image_rows + kTile - 1) / kTile;
+  fe->seg_cap = kTile * cfg->image_cols / 4;  // a 3x3 local maximum can occupy at most one pixel in four
   int rc = VIO_OK;
   if (hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking) != hipSuccess) rc = VIO_ENODEV;
 #define ALLOC(ptr, count) \
   if (rc == VIO_OK) rc = dev_alloc(&(ptr), (count))
   ALLOC(fe->pyr[0], S * ld.pyr_bytes);
   ALLOC(fe->pyr[1], S * ld.pyr_bytes);
-  ALLOC(fe->mask, S * px);
-  ALLOC(fe->eig, S * px);
-  ALLOC(fe->max_bits, S);
-  ALLOC(fe->cand, S * fe->cand_cap);
-  ALLOC(fe->n_cand, S);
+  ALLOC(fe->max_bits, S * fe->nseg);
+  ALLOC(fe->cand, S * fe->nseg * fe->seg_cap);
+  ALLOC(fe->n_cand, S * fe->nseg);
   ALLOC(fe->cur_pts, S * cap * 2);
   ALLOC(fe->pre_pts, S * cap * 2);
   ALLOC(fe->forw_pts, S * cap * 2);
@@ -1069,7 +1267,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
 void vio_frontend_destroy(vio_frontend_t *fe) {
   if (!fe) return;
   (void)hipDeviceSynchronize();
-  void *ptrs[] = {fe->pyr[0], fe->pyr[1], fe->mask, fe->eig, fe->max_bits, fe->cand, fe->n_cand, fe->cur_pts, fe->pre_pts,
+  void *ptrs[] = {fe->pyr[0], fe->pyr[1], fe->mask, fe->max_bits, fe->cand, fe->n_cand, fe->cur_pts, fe->pre_pts,
                   fe->forw_pts, fe->lk_err, fe->ids, fe->track_cnt, fe->n_pts, fe->n_forw, fe->n_id, fe->kept_xy, fe->n_kept,
                   fe->n_obs, fe->lk_status, fe->obs, fe->hw, fe->frames};
   for (void *p : ptrs)
@@ -1212,7 +1410,7 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
     uint8_t *dst = fe->pyr[k];
     if (hipMemcpyAsync(dst, d + k * px, px, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(VIO_ENODEV);
     for (int l = 1; l < fe->ld.levels; l++) {
-      dim3 blk(32, 8), grd((fe->ld.cols[l] + 31) / 32, (fe->ld.rows[l] + 7) / 8, 1);
+      dim3 blk(256), grd((fe->ld.cols[l] + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, 1);
       hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, dst + fe->ld.off[l - 1], dst + fe->ld.off[l], fe->ld.pyr_bytes,
                          fe->ld.rows[l - 1], fe->ld.cols[l - 1], fe->ld.rows[l], fe->ld.cols[l]);
     }
@@ -1248,23 +1446,24 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
   const size_t px = (size_t)rows * cols;
   hipStream_t st = fe->stream;
   if (hipMemcpy2D(fe->pyr[0], cols, img, stride, cols, rows, hipMemcpyHostToDevice) != hipSuccess) return fail(VIO_ENODEV);
+  if (dev_alloc(&fe->mask, px) != VIO_OK) return fail(VIO_ENOMEM);
   if (mask) {
     if (hipMemcpy2D(fe->mask, cols, mask, stride, cols, rows, hipMemcpyHostToDevice) != hipSuccess) return fail(VIO_ENODEV);
   } else if (hipMemset(fe->mask, 255, px) != hipSuccess) {
     return fail(VIO_ENODEV);
   }
-  if (hipMemset(fe->max_bits, 0, sizeof(unsigned)) != hipSuccess || hipMemset(fe->n_cand, 0, sizeof(int)) != hipSuccess)
+  if (hipMemset(fe->max_bits, 0, sizeof(unsigned) * fe->nseg) != hipSuccess ||
+      hipMemset(fe->n_cand, 0, sizeof(int) * fe->nseg) != hipSuccess)
     return fail(VIO_ENODEV);
-  dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, (rows + kTile - 1) / kTile, 1);
-  hipLaunchKernelGGL(min_eigen_kernel, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->eig, fe->max_bits, rows, cols);
-  dim3 cb(32, 8), cg((cols + 31) / 32, (rows + 7) / 8, 1);
-  hipLaunchKernelGGL(corner_candidates_kernel, cg, cb, 0, st, fe->eig, fe->mask, px, fe->max_bits, c.quality_level, rows, cols,
-                     fe->cand, fe->cand_cap, fe->n_cand);
+  dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, fe->nseg, 1);
+  hipLaunchKernelGGL(detect_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
+                     fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand);
   SelectParams SP;
   SP.cap = fe->cap, SP.rows = rows, SP.cols = cols, SP.max_corners = max_corners, SP.min_dist = (float)c.min_dist;
   SP.fx = c.fx, SP.fy = c.fy, SP.cx = c.cx, SP.cy = c.cy;
-  hipLaunchKernelGGL(corner_select_kernel, dim3(1), dim3(256), 0, st, fe->cand, fe->cand_cap, fe->n_cand, SP, fe->forw_pts,
-                     fe->cur_pts, fe->pre_pts, fe->ids, fe->track_cnt, fe->n_forw, fe->n_pts, fe->n_id, fe->obs, fe->n_obs);
+  hipLaunchKernelGGL(corner_select_kernel, dim3(1), dim3(kSelThreads), 0, st, fe->cand, fe->seg_cap, fe->nseg, fe->n_cand, fe->max_bits,
+                     c.quality_level, SP, fe->forw_pts, fe->cur_pts, fe->pre_pts, fe->ids, fe->track_cnt, fe->n_forw, fe->n_pts,
+                     fe->n_id, fe->obs, fe->n_obs);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);
   int n = 0;
   if (hipMemcpy(&n, fe->n_pts, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(VIO_ENODEV);
