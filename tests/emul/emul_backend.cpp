@@ -7,6 +7,7 @@
 // loudly without the HIP extension.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "batch.h"
@@ -35,6 +36,8 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   B.hdr = hb.hdr.data(), B.hdr_d = hb.hdr_d.data();
   B.pose = hb.pose.data(), B.sb = hb.sb.data(), B.ex = hb.ex.data(), B.feat = hb.feat.data();
   B.fhost = hb.fhost.data(), B.ftarget = hb.ftarget.data(), B.ffeat = hb.ffeat.data();
+  B.fslot = hb.fslot.data(), B.fstart = hb.fstart.data();
+  B.pair_h = hb.pair_h.data(), B.pair_t = hb.pair_t.data(), B.pair_s0 = hb.pair_s0.data(), B.pair_s1 = hb.pair_s1.data();
   B.pts_i = hb.pts_i.data(), B.pts_j = hb.pts_j.data(), B.preint = hb.preint.data();
   B.pr_kind = hb.pr_kind.data(), B.pr_index = hb.pr_index.data(), B.pr_offset = hb.pr_offset.data();
   B.pr_x0 = hb.pr_x0.data(), B.pr_J = hb.pr_J.data(), B.pr_r = hb.pr_r.data();
@@ -55,10 +58,13 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
 
   mo.n = m_int.data(), mo.kind = m_int.data() + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
   mo.x0 = m_x0.data(), mo.J = m_J.data(), mo.r = m_r.data(), mo.scratch = m_scratch.data(), mo.ncap = hb.d.Ncap;
-  size_t mbytes = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr);
+  // doubles behind the iterate: the device's 160 KB when the dense matrix fits, else matrix + a 512-slot staging area
+  size_t core = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr, 0) / sizeof(double);
+  const size_t avail = std::max<size_t>(20480, core + 512 * kMargSlot + 64);
+  size_t mbytes = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr, avail);
   std::vector<double> mlds(mbytes / sizeof(double) + 2);
   MargWork mw;
-  carve_marg(B.d, true, mlds.data(), nullptr, &mw);
+  carve_marg(B.d, true, mlds.data(), nullptr, &mw, avail);
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 
   unpack_window(s, 0, out_pose.data(), out_sb.data(), out_feat.data(), raw_pose.data(), raw_sb.data(),

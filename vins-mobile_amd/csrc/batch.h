@@ -17,12 +17,12 @@
 namespace vio {
 
 constexpr int kHdrInts = 12;
-enum { H_W = 0, H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_PRIOR_N, H_PRIOR_NB, H_USE_ORIGIN };
+enum { H_W = 0, H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_PRIOR_N, H_PRIOR_NB, H_USE_ORIGIN, H_NPAIRS, H_NSLOTS };
 constexpr int kHdrDoubles = 4;
 constexpr int kMaxPriorBlocks = VIO_MAX_PRIOR_BLOCKS;
 
 struct BatchDims {
-  int Wcap, Pcap, Fcap, Mcap, Ncap, Fpad, n6cap, nblk_cap;
+  int Wcap, Pcap, Fcap, Mcap, Ncap, Fpad, n6cap, nblk_cap, pair_cap;
   int max_iter;
   double s_info, gravity, cauchy_b;
 };
@@ -36,6 +36,7 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
   d.Fpad = (d.Fcap + 7) / 8 * 8;
   d.n6cap = 6 * (d.Pcap + 1);  // pose groups 0..P-1 plus one more: loop pose (solve) / extrinsic (marginalization)
   d.nblk_cap = d.Pcap + (any_loop ? 1 : 0);
+  d.pair_cap = (d.Pcap + 1) * (d.Pcap + 2) / 2;  // distinct (host, target) pairs incl. the loop pose
   d.max_iter = cfg.max_iterations;
   d.s_info = cfg.fx / 1.5;  // ProjectionFactor::sqrt_info = FOCUS_LENGTH_X / 1.5 (VINS.cpp:31)
   d.gravity = cfg.gravity;
@@ -45,17 +46,18 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
 
 // Element counts per window of every array (strides).
 struct BatchStrides {
-  size_t pose, sb, ex, feat, fint, pts, preint, pr_int, pr_x0, pr_J, pr_r;
+  size_t pose, sb, ex, feat, fint, pts, preint, pr_int, pr_x0, pr_J, pr_r, fstart, pair;
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
   BatchStrides s;
   s.pose = 7 * (size_t)d.Pcap, s.sb = 9 * (size_t)d.Pcap, s.ex = 7, s.feat = d.Fcap;
   s.fint = d.Mcap, s.pts = 3 * (size_t)d.Mcap, s.preint = (size_t)d.Wcap * kPreintDoubles;
+  s.fstart = (size_t)d.Fcap + 1, s.pair = d.pair_cap;
   s.pr_int = kMaxPriorBlocks, s.pr_x0 = 9 * (size_t)kMaxPriorBlocks, s.pr_J = (size_t)d.Ncap * d.Ncap, s.pr_r = d.Ncap;
   size_t o = 0;
   s.s_info = o, o += (size_t)d.Wcap * 225;
@@ -67,6 +69,8 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_prJT = o, o += (size_t)d.Ncap * d.Ncap;
   s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
   s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
+  s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
+  s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
   s.scratch = (o + 7) / 8 * 8;
   s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB;
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -83,6 +87,7 @@ struct BatchPtrs {
   const double *hdr_d;    // [n][kHdrDoubles]
   const double *pose, *sb, *ex, *feat;
   const int *fhost, *ftarget, *ffeat;
+  const int *fslot, *fstart, *pair_h, *pair_t, *pair_s0, *pair_s1;
   const double *pts_i, *pts_j, *preint;
   const int *pr_kind, *pr_index, *pr_offset;
   const double *pr_x0, *pr_J, *pr_r;
@@ -107,6 +112,10 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.s_info = B.d.s_info, v.gravity = B.d.gravity, v.cauchy_b = B.d.cauchy_b;
   v.pose0 = B.pose + b * B.s.pose, v.sb0 = B.sb + b * B.s.sb, v.ex = B.ex + b * B.s.ex, v.feat0 = B.feat + b * B.s.feat;
   v.fhost = B.fhost + b * B.s.fint, v.ftarget = B.ftarget + b * B.s.fint, v.ffeat = B.ffeat + b * B.s.fint;
+  v.fslot = B.fslot + b * B.s.fint, v.fstart = B.fstart + b * B.s.fstart;
+  v.pair_h = B.pair_h + b * B.s.pair, v.pair_t = B.pair_t + b * B.s.pair;
+  v.pair_s0 = B.pair_s0 + b * B.s.pair, v.pair_s1 = B.pair_s1 + b * B.s.pair;
+  v.npairs = h[H_NPAIRS], v.nslots = h[H_NSLOTS], v.n6cap = B.d.n6cap;
   v.pts_i = B.pts_i + b * B.s.pts, v.pts_j = B.pts_j + b * B.s.pts;
   v.preint = B.preint + b * B.s.preint;
   v.pr_kind = B.pr_kind + b * B.s.pr_int, v.pr_index = B.pr_index + b * B.s.pr_int;
@@ -117,7 +126,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prJT = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
-  v.WT = sc + B.s.s_WT;
+  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP;
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
   v.raw_pose = B.raw_pose + b * B.s.out_pose, v.raw_sb = B.raw_sb + b * B.s.out_sb;
@@ -173,13 +182,15 @@ struct HostBatch {
   BatchDims d;
   BatchStrides s;
   int n = 0;
-  std::vector<int> hdr, fhost, ftarget, ffeat, pr_kind, pr_index, pr_offset;
+  std::vector<int> hdr, fhost, ftarget, ffeat, pr_kind, pr_index, pr_offset, fslot, fstart, pair_h, pair_t, pair_s0, pair_s1;
   std::vector<double> hdr_d, pose, sb, ex, feat, pts_i, pts_j, preint, pr_x0, pr_J, pr_r;
   void resize(const BatchDims &dims, int n_) {
     d = dims, s = make_strides(dims), n = n_;
     hdr.assign((size_t)n * kHdrInts, 0), hdr_d.assign((size_t)n * kHdrDoubles, 0.0);
     pose.assign(n * s.pose, 0.0), sb.assign(n * s.sb, 0.0), ex.assign(n * s.ex, 0.0), feat.assign(n * s.feat, 1.0);
     fhost.assign(n * s.fint, 0), ftarget.assign(n * s.fint, 0), ffeat.assign(n * s.fint, 0);
+    fslot.assign(n * s.fint, 0), fstart.assign(n * s.fstart, 0);
+    pair_h.assign(n * s.pair, 0), pair_t.assign(n * s.pair, 0), pair_s0.assign(n * s.pair, 0), pair_s1.assign(n * s.pair, 0);
     pts_i.assign(n * s.pts, 0.0), pts_j.assign(n * s.pts, 0.0), preint.assign(n * s.preint, 0.0);
     pr_kind.assign(n * s.pr_int, 0), pr_index.assign(n * s.pr_int, 0), pr_offset.assign(n * s.pr_int, 0);
     pr_x0.assign(n * s.pr_x0, 0.0), pr_J.assign(n * s.pr_J, 0.0), pr_r.assign(n * s.pr_r, 0.0);
@@ -199,8 +210,38 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
   int has_loop = 0;
   for (int k = 0; k < M; k++) {
     int h = w.factor_host[k], t = w.factor_target[k], f = w.factor_feature[k];
-    if (f < 0 || f >= F || h < 0 || h >= P || t < 0 || t > P) return VIO_EINVAL;
+    if (f < 0 || f >= F || h < 0 || h >= P || t < 0 || t > P || t == h) return VIO_EINVAL;
+    if (k > 0 && f < w.factor_feature[k - 1]) return VIO_EINVAL;  // factors come grouped by ascending feature
     if (t == P) has_loop = 1;
+  }
+  {
+    // Device-side accumulation layout: factors bucketed by (host, target) pair, each bucket padded to an even number
+    // of slots (one MFMA step consumes two factors = four Jacobian rows), plus the factor range of every feature.
+    const int np1 = P + 1;
+    std::vector<int> cnt((size_t)np1 * np1, 0), start((size_t)np1 * np1, 0), fill((size_t)np1 * np1, 0);
+    for (int k = 0; k < M; k++) cnt[(size_t)w.factor_host[k] * np1 + w.factor_target[k]]++;
+    int npairs = 0, slot = 0;
+    for (int hh = 0; hh < np1; hh++)
+      for (int tt = 0; tt < np1; tt++) {
+        int c = cnt[(size_t)hh * np1 + tt];
+        if (!c) continue;
+        if (npairs >= d.pair_cap) return VIO_ECAP;
+        start[(size_t)hh * np1 + tt] = slot;
+        hb.pair_h[b * s.pair + npairs] = hh, hb.pair_t[b * s.pair + npairs] = tt;
+        hb.pair_s0[b * s.pair + npairs] = slot;
+        slot += (c + 1) & ~1;
+        hb.pair_s1[b * s.pair + npairs] = slot;
+        npairs++;
+      }
+    for (int k = 0; k < M; k++) {
+      size_t key = (size_t)w.factor_host[k] * np1 + w.factor_target[k];
+      hb.fslot[b * s.fint + k] = start[key] + fill[key]++;
+    }
+    int *fs = &hb.fstart[b * s.fstart];
+    for (int f = 0; f <= F; f++) fs[f] = 0;
+    for (int k = 0; k < M; k++) fs[w.factor_feature[k] + 1]++;
+    for (int f = 0; f < F; f++) fs[f + 1] += fs[f];
+    hb.hdr[(size_t)b * kHdrInts + H_NPAIRS] = npairs, hb.hdr[(size_t)b * kHdrInts + H_NSLOTS] = slot;
   }
   if (has_loop && (w.loop_frame < 0 || w.loop_frame >= W)) return VIO_EINVAL;
   int *h = &hb.hdr[(size_t)b * kHdrInts];

@@ -44,19 +44,25 @@ struct MargWork {
   int *col_ex;    // [1]
   int *pcol;      // prior column -> dense column: prior_n
   int *meta;      // [4]: pos, m, n, nblocks
+  double *stage;  // staging of robustified Jacobian rows for the Gram products (LDS when it fits)
+  int stage_slots;
 };
+
+constexpr int kMargRowX = 6;                                   // extrinsic Jacobian row
+constexpr int kMargSlot = kSlotStride + 2 * kMargRowX + 1;     // [Ji Jj r Jl] x2 + pad, [Jex] x2 + pad = 42
 
 VIO_HD constexpr int kMargMaxPos(int W) { return 15 + 6 * W + 15; }
 
 VIO_HD size_t marg_scratch_doubles(const int Wcap) {
   size_t p = (size_t)kMargMaxPos(Wcap);
-  return p * p + 8;
+  return p * p + 8 + 512 * 64;  // dense matrix + Jacobian-row staging (global-matrix variant)
 }
 
 // LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
 // is preserved; everything behind it is re-used. Returns bytes used (base may be null to just measure).
 template <class Dims>
-VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, double *base_after_state, double *am_global, MargWork *m) {
+VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, double *base_after_state, double *am_global, MargWork *m,
+                         size_t avail_doubles = 0) {
   size_t o = 0;
   auto take = [&](size_t n) {
     double *p = base_after_state ? base_after_state + o : nullptr;
@@ -68,7 +74,19 @@ VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, double *base_after_stat
   double *bm = take(pos), *tol = take(pos), *hff = take(F), *gf = take(F), *einv = take(F);
   double *prdx = take(d.Ncap), *prr = take(d.Ncap);
   double *ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
+  // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows;
+  // in the global-matrix variant the staging area follows the matrix in the scratch buffer
+  size_t stage_slots = 0;
+  double *stage = nullptr;
+  if (lds_matrix) {
+    if (avail_doubles > o + kMargSlot * 2) stage_slots = ((avail_doubles - o) / kMargSlot) & ~(size_t)1;
+    stage = take(stage_slots * kMargSlot);
+  } else {
+    stage_slots = 512;
+    stage = am_global ? am_global + pos * pos + 8 : nullptr;
+  }
   if (m) {
+    m->stage = stage, m->stage_slots = (int)stage_slots;
     m->Am = lds_matrix ? Am : am_global, m->ld = (int)pos, m->bm = bm, m->tol = tol;
     m->hff = hff, m->gf = gf, m->einv = einv, m->prdx = prdx, m->prr = prr;
     int *ip = reinterpret_cast<int *>(ints);
@@ -229,31 +247,159 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
       VIO_ATOMIC_ADD(m.bm + ca, s);
     }
     // ---- projections hosted at frame 0: blocks (pose0, pose_t, extrinsic, feature), Cauchy-corrected
-    //      (ResidualBlockInfo::Evaluate, marginalization_factor.cpp:45-76, rho'' < 0 branch)
+    //      (ResidualBlockInfo::Evaluate, marginalization_factor.cpp:45-76, rho'' < 0 branch).
+    //      Same scheme as the solver: rows staged in (0,t)-bucket order, one Gram product per bucket on the matrix
+    //      cores: [Ji Jj r Jl]^T [Ji Jj r Jl], Jex^T [Ji Jj r Jl] and Jex^T Jex.
     const double cc = 1.0 / v.cauchy_b;
-    VIO_PARFOR(k, v.M) {
-      int t = v.ftarget[k], f = v.ffeat[k];
-      if (v.fhost[k] != 0 || t == P) continue;
-      double r[2], Ji[12], Jj[12], Jex[12], Jl[2];
-      projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj,
-                      Jex, Jl);
-      double sq = r[0] * r[0] + r[1] * r[1];
-      double sr = sqrt(1.0 / (1.0 + sq * cc));
-      for (int q = 0; q < 12; q++) Ji[q] *= sr, Jj[q] *= sr, Jex[q] *= sr;
-      Jl[0] *= sr, Jl[1] *= sr, r[0] *= sr, r[1] *= sr;
-      const double *Js[3] = {Ji, Jj, Jex};
-      int cols[3] = {m.col_pose[0], m.col_pose[t], m.col_ex[0]};
-      int wrow[3] = {0, 6 * t, 6 * P};
-      for (int x = 0; x < 3; x++)
-        for (int a = 0; a < 6; a++) {
-          VIO_ATOMIC_ADD(m.bm + cols[x] + a, Js[x][a] * r[0] + Js[x][6 + a] * r[1]);
-          VIO_ATOMIC_ADD(v.WT + (wrow[x] + a) * v.Fpad + f, Js[x][a] * Jl[0] + Js[x][6 + a] * Jl[1]);
-          for (int y = 0; y < 3; y++)
-            for (int b = 0; b < 6; b++)
-              VIO_ATOMIC_ADD(m.Am + (cols[x] + a) * ld + cols[y] + b, Js[x][a] * Js[y][b] + Js[x][6 + a] * Js[y][6 + b]);
+    int S0 = 0, nb0 = 0;  // buckets (0, t < P) come first in the (host, target) order
+    for (int p = 0; p < v.npairs; p++)
+      if (v.pair_h[p] == 0 && v.pair_t[p] != P) S0 = v.pair_s1[p], nb0 = p + 1;
+    double *G = m.stage;
+    const int CH = m.stage_slots;
+    if (CH < 2) {  // launcher guarantees staging space; never loop forever on a bad carve
+      if (cx.tid == 0) out.n[0] = -3, out.n[1] = 0;
+      return;
+    }
+    double fw0[6] = {0, 0, 0, 0, 0, 0}, fwx[6] = {0, 0, 0, 0, 0, 0}, fe = 0, fgf = 0;
+    bool ftouched = false;
+    const bool one_thread_per_feature = F <= (int)cx.nt;
+    // dense-matrix add, lower triangle only
+    auto add_lower = [&](int ra, int ca, double val) {
+      if (ra >= ca) VIO_ATOMIC_ADD(m.Am + ra * ld + ca, val);
+      else VIO_ATOMIC_ADD(m.Am + ca * ld + ra, val);
+    };
+    for (int c0 = 0; c0 < S0; c0 += CH) {
+      const int nsl = S0 - c0 < CH ? S0 - c0 : CH;
+      VIO_PARFOR(q, nsl * kMargSlot) G[q] = 0.0;
+      VIO_SYNC();
+      VIO_PARFOR(k, v.M) {
+        int t = v.ftarget[k], f = v.ffeat[k];
+        if (v.fhost[k] != 0 || t == P) continue;
+        const int slot = v.fslot[k] - c0;
+        if (slot < 0 || slot >= CH) continue;
+        double r[2], Ji[12], Jj[12], Jex[12], Jl[2];
+        projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj,
+                        Jex, Jl);
+        double sq = r[0] * r[0] + r[1] * r[1];
+        double sr = sqrt(1.0 / (1.0 + sq * cc));
+        double *g = G + slot * kMargSlot, *gx = g + kSlotStride;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            g[rr * kRowLen + c] = Ji[rr * 6 + c] * sr, g[rr * kRowLen + 6 + c] = Jj[rr * 6 + c] * sr;
+            gx[rr * kMargRowX + c] = Jex[rr * 6 + c] * sr;
+          }
+          g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
         }
-      VIO_ATOMIC_ADD(m.hff + f, Jl[0] * Jl[0] + Jl[1] * Jl[1]);
-      VIO_ATOMIC_ADD(m.gf + f, Jl[0] * r[0] + Jl[1] * r[1]);
+#pragma unroll
+        for (int c = 0; c < 6; c++)  // target-frame coupling: one writer per (feature, frame)
+          v.WT[(6 * t + c) * v.Fpad + f] = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
+      }
+      VIO_SYNC();
+      // one element of the three Gram matrices of bucket (0, t)
+      auto flush1 = [&](int t, int row, int col, double val) {  // G1^T G1
+        const int c0p = m.col_pose[0], ctp = m.col_pose[t];
+        if (row < 6) {
+          if (col <= row) VIO_ATOMIC_ADD(m.Am + (c0p + row) * ld + c0p + col, val);
+        } else if (row < 12) {
+          if (col < 6) add_lower(ctp + row - 6, c0p + col, val);
+          else if (col < 12 && col <= row) VIO_ATOMIC_ADD(m.Am + (ctp + row - 6) * ld + ctp + col - 6, val);
+        } else if (row == 12) {
+          if (col < 6) VIO_ATOMIC_ADD(m.bm + c0p + col, val);
+          else if (col < 12) VIO_ATOMIC_ADD(m.bm + ctp + col - 6, val);
+        }
+      };
+      auto flush2 = [&](int t, int row, int col, double val) {  // Gx^T G1: rows = extrinsic components
+        if (row >= 6) return;
+        const int cx0 = m.col_ex[0];
+        if (col < 6) add_lower(cx0 + row, m.col_pose[0] + col, val);
+        else if (col < 12) add_lower(cx0 + row, m.col_pose[t] + col - 6, val);
+        else if (col == 12) VIO_ATOMIC_ADD(m.bm + cx0 + row, val);
+      };
+      auto flush3 = [&](int row, int col, double val) {  // Gx^T Gx
+        if (row < 6 && col <= row) VIO_ATOMIC_ADD(m.Am + (m.col_ex[0] + row) * ld + m.col_ex[0] + col, val);
+      };
+#ifdef VIO_EMUL
+      for (int p = 0; p < nb0; p++) {
+        if (v.pair_h[p] != 0 || v.pair_t[p] == P) continue;
+        int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+        if (s_lo >= s_hi) continue;
+        const int t = v.pair_t[p];
+        for (int row = 0; row < 14; row++)
+          for (int col = 0; col < 14; col++) {
+            double d1 = 0, d2 = 0, d3 = 0;
+            for (int sl = s_lo; sl < s_hi; sl++)
+              for (int rr = 0; rr < 2; rr++) {
+                const double *g = G + (sl - c0) * kMargSlot, *gx = g + kSlotStride;
+                d1 += g[rr * kRowLen + row] * g[rr * kRowLen + col];
+                if (row < 6) d2 += gx[rr * kMargRowX + row] * g[rr * kRowLen + col];
+                if (row < 6 && col < 6) d3 += gx[rr * kMargRowX + row] * gx[rr * kMargRowX + col];
+              }
+            flush1(t, row, col, d1), flush2(t, row, col, d2), flush3(row, col, d3);
+          }
+      }
+#else
+      {
+        const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+        const int li = lane & 15, kq = lane >> 4;
+        for (int p = wave; p < nb0; p += nw) {
+          if (v.pair_h[p] != 0 || v.pair_t[p] == P) continue;
+          int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+          if (s_lo >= s_hi) continue;
+          v4d a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
+          const bool lv = li < kRowLen, lx = li < kMargRowX;
+          const double *g = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
+          const double *gx = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
+          for (int sl = s_lo; sl < s_hi; sl += 2, g += 2 * kMargSlot, gx += 2 * kMargSlot) {
+            double a = *g, x = *gx;
+            a = lv ? a : 0.0, x = lx ? x : 0.0;
+            a1 = mfma_f64(a, a, a1), a2 = mfma_f64(x, a, a2), a3 = mfma_f64(x, x, a3);
+          }
+          const int t = v.pair_t[p];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; r4++) {
+            flush1(t, kq + 4 * r4, li, a1[r4]), flush2(t, kq + 4 * r4, li, a2[r4]), flush3(kq + 4 * r4, li, a3[r4]);
+          }
+        }
+      }
+#endif
+      // per-feature sums: host coupling, extrinsic coupling, H_ff, g_f
+      VIO_PARFOR(f, F) {
+        double w0[6] = {0, 0, 0, 0, 0, 0}, wx[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;
+        bool touched = false;
+        for (int k = v.fstart[f]; k < v.fstart[f + 1]; k++) {
+          if (v.fhost[k] != 0 || v.ftarget[k] == P) continue;
+          const int slot = v.fslot[k] - c0;
+          if (slot < 0 || slot >= CH) continue;
+          touched = true;
+          const double *g = G + slot * kMargSlot, *gx = g + kSlotStride;
+#pragma unroll
+          for (int rr = 0; rr < 2; rr++) {
+            double jl = g[rr * kRowLen + 13];
+#pragma unroll
+            for (int c = 0; c < 6; c++) w0[c] += g[rr * kRowLen + c] * jl, wx[c] += gx[rr * kMargRowX + c] * jl;
+            e += jl * jl, gf += jl * g[rr * kRowLen + 12];
+          }
+        }
+        if (!touched) continue;
+        if (one_thread_per_feature) {
+          ftouched = true, fe += e, fgf += gf;
+#pragma unroll
+          for (int c = 0; c < 6; c++) fw0[c] += w0[c], fwx[c] += wx[c];
+        } else {
+          m.hff[f] += e, m.gf[f] += gf;
+#pragma unroll
+          for (int c = 0; c < 6; c++) v.WT[c * v.Fpad + f] += w0[c], v.WT[(6 * P + c) * v.Fpad + f] += wx[c];
+        }
+      }
+      VIO_SYNC();
+    }
+    if (one_thread_per_feature && (int)cx.tid < F && ftouched) {
+      const int f = cx.tid;
+      m.hff[f] = fe, m.gf[f] = fgf;
+#pragma unroll
+      for (int c = 0; c < 6; c++) v.WT[c * v.Fpad + f] = fw0[c], v.WT[(6 * P + c) * v.Fpad + f] = fwx[c];
     }
     VIO_SYNC();
     // ---- eliminate the landmarks hosted at frame 0 (pseudo-inverse: e <= eps contributes nothing) --------
@@ -261,16 +407,60 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
     VIO_SYNC();
     // pose-type groups: g in [0, P] -> (WT row base 6 g, dense column base)
     const int ng = P + 1;
-    VIO_PARFOR(q, (6 * ng) * (6 * ng)) {
-      int a = q / (6 * ng), b = q % (6 * ng);
-      int ga = a / 6, gb = b / 6;
-      int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
-      if (ca < 0 || cb < 0) continue;
-      const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
-      double s = 0;
-      for (int f = 0; f < F; f++) s += wa[f] * wb[f] * m.einv[f];
-      m.Am[(ca + a % 6) * ld + cb + b % 6] -= s;
+#ifdef VIO_EMUL
+    for (int a = 0; a < 6 * ng; a++)
+      for (int b = 0; b <= a; b++) {
+        int ga = a / 6, gb = b / 6;
+        int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
+        if (ca < 0 || cb < 0) continue;
+        const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
+        double sacc = 0;
+        for (int f = 0; f < F; f++) sacc += wa[f] * m.einv[f] * wb[f];
+        int ra = ca + a % 6, rb = cb + b % 6;
+        if (ra >= rb) m.Am[ra * ld + rb] -= sacc;
+        else m.Am[rb * ld + ra] -= sacc;
+      }
+#else
+    {
+      // (W E^-1) W^T over the pose-type index space as a GEMM on the matrix cores, like the solver's Schur term
+      const int n6m = 6 * ng, T = (n6m + 15) / 16, npairs_t = T * (T + 1) / 2;
+      const int wave = cx.tid >> 6, lane = cx.tid & 63, nw = cx.nt >> 6;
+      const int li = lane & 15, kq = lane >> 4;
+      const int ksteps = (F + 3) / 4;
+      for (int p = wave; p < npairs_t; p += nw) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
+        const int tj = p - ti * (ti + 1) / 2;
+        const int ra = 16 * ti + li, rb = 16 * tj + li;
+        const bool va = ra < n6m, vb = rb < n6m;
+        const double *pa = v.WT + (size_t)(va ? ra : 0) * v.Fpad, *pb = v.WT + (size_t)(vb ? rb : 0) * v.Fpad;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int st = 0; st < ksteps; st++) {
+          int f = 4 * st + kq;
+          bool vf = f < F;
+          int fc = vf ? f : 0;
+          double a = pa[fc] * m.einv[fc], b = pb[fc];
+          a = (va && vf) ? a : 0.0, b = (vb && vf) ? b : 0.0;
+          acc = mfma_f64(a, b, acc);
+        }
+        const int bcol = 16 * tj + li;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          int arow = 16 * ti + kq + 4 * r4;
+          if (arow < n6m && bcol < n6m && bcol <= arow) {
+            int ga = arow / 6, gb = bcol / 6;
+            int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
+            if (ca >= 0 && cb >= 0) {
+              int rr = ca + arow % 6, cc2 = cb + bcol % 6;
+              if (rr >= cc2) m.Am[rr * ld + cc2] -= acc[r4];
+              else m.Am[cc2 * ld + rr] -= acc[r4];
+            }
+          }
+        }
+      }
     }
+#endif
     VIO_PARFOR(a, 6 * ng) {
       int ga = a / 6;
       int ca = ga == P ? m.col_ex[0] : m.col_pose[ga];

@@ -51,7 +51,8 @@ constexpr int kStatsInts = 4 + kMaxTrace;         // iterations, termination, n_
 // Per-stage cycle counters (the kernel-side counterpart of the reference's TS/TE timers, global_param.hpp:85-92).
 enum Stage {
   ST_SETUP_IMU = 0, ST_SETUP_PRIOR, ST_EVAL_PRIOR, ST_EVAL_IMU, ST_EVAL_PROJ, ST_SCALE, ST_SCHUR, ST_RHS, ST_CHOL,
-  ST_TRISOLVE, ST_QUADFORM, ST_DOGLEG, ST_COST_EVAL, ST_NEW2OLD, ST_MARG_BUILD, ST_MARG_CHOL, ST_TOTAL, ST_COUNT = 24
+  ST_TRISOLVE, ST_QUADFORM, ST_DOGLEG, ST_COST_EVAL, ST_NEW2OLD, ST_MARG_BUILD, ST_MARG_CHOL, ST_TOTAL,
+  ST_P_ZERO, ST_P_FACT, ST_P_GRAM, ST_P_FEAT, ST_C_POTRF, ST_C_TRSM, ST_COUNT = 24
 };
 
 struct Ctx {
@@ -82,6 +83,10 @@ struct WinView {
   double s_info, gravity, cauchy_b;
   const double *pose0, *sb0, *ex, *feat0;
   const int *fhost, *ftarget, *ffeat;
+  const int *fslot;                     // factor -> slot in the (host,target)-bucketed, even-padded staging order
+  const int *fstart;                    // [F+1] factor range of every feature
+  const int *pair_h, *pair_t, *pair_s0, *pair_s1;  // [npairs] bucket -> frames and slot range
+  int npairs, nslots, n6cap;
   const double *pts_i, *pts_j;
   const double *preint;
   const int *pr_kind, *pr_index, *pr_offset;
@@ -98,6 +103,8 @@ struct WinView {
   double *prJT;      // [n*n]  J0 transposed
   double *prH0;      // [n*n]  J0^T J0
   double *WT;        // [npose6][Fpad]  H_pf transposed: row = 6*frame + c, col = feature
+  double *WTf;       // [F][n6cap]      the same, feature-major (operand layout of the Schur GEMM)
+  double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
   double *stats_d;
@@ -417,163 +424,7 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, Work &w) {
   VIO_SYNC();
 }
 
-// =====================================================================================================
-// Evaluation: cost, and (jac) H -> w.Hm (lower blocks), WT, hff, gp, gf, hdiag
-// =====================================================================================================
-VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *sb,
-                        const double *feat, bool jac) {
-  const int np = v.np;
-  double cost = 0.0;  // per-thread partial, reduced at the end
-  if (jac) {
-    const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
-    VIO_PARFOR(q, nmat) w.Hm[q] = 0.0;
-    VIO_PARFOR(q, np) w.gp[q] = 0.0;
-    VIO_PARFOR(q, v.F) w.gf[q] = 0.0, w.hff[q] = 0.0;
-    VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
-  }
-  // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
-  const int n = v.prior_n;
-  if (n > 0) {
-    VIO_PARFOR(b, v.prior_nb) {
-      int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
-      const double *x0 = v.pr_x0 + 9 * b;
-      if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
-      else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
-      else prior_block_dx(7, w.ex, x0, w.prdx + o);
-    }
-    VIO_SYNC();
-    VIO_PARFOR(i, n) {
-      double s = v.pr_r[i];
-      for (int j = 0; j < n; j++) s += v.prJT[j * n + i] * w.prdx[j];
-      w.prr[i] = s;
-      cost += 0.5 * s * s;
-    }
-  }
-  VIO_SYNC();  // Hm / gp zeroed, prr ready
-  if (jac && n > 0) {
-    VIO_PARFOR(a, n) {
-      int pa = w.prcol[a];
-      if (pa >= 0) {
-        double g = 0;
-        for (int k = 0; k < n; k++) g += v.pr_J[k * n + a] * w.prr[k];
-        w.gp[pa] = g;  // unique writer per parameter; factors add atomically after the next barrier
-      }
-    }
-    VIO_PARFOR(q, n * n) {
-      int a = q / n, b = q % n;
-      int pa = w.prcol[a], pb = w.prcol[b];
-      if (pa >= 0 && pb >= 0 && (pa > pb || (pa == pb)))
-        *mat_at(w.Hm, pa, pb) = v.prH0[q];
-      else if (pa >= 0 && pb >= 0 && pa / kBS == pb / kBS)
-        *mat_at(w.Hm, pa, pb) = v.prH0[q];  // upper part of a diagonal block (kept consistent)
-    }
-    VIO_SYNC();
-  }
-  stamp(cx, jac ? ST_EVAL_PRIOR : ST_COST_EVAL);
-  // ---- IMU factors -------------------------------------------------------------------------------
-  VIO_PARFOR(f, v.W) {
-    imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
-                 sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
-  }
-  VIO_SYNC();
-  VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
-    int f = q / 15, r = q % 15;
-    const double *info = v.imu_info + f * 225 + r * 15;
-    const double *rr = v.imu_r + f * 15;
-    double s = 0;
-    for (int k = 0; k < 15; k++) s += info[k] * rr[k];
-    v.imu_Mr[q] = s;
-    cost += 0.5 * s * rr[r];
-  }
-  if (jac) {
-    VIO_PARFOR(q, v.W * 450) {  // M = info * Jraw
-      int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
-      const double *info = v.imu_info + f * 225 + r * 15;
-      const double *Jr = v.imu_J + f * 450 + c;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += info[k] * Jr[k * 30];
-      v.imu_M[q] = s;
-    }
-    VIO_SYNC();
-    VIO_PARFOR(q, v.W * 900) {  // H[15f + a][15f + b] += sum_k Jraw[k][a] M[k][b], lower part (and diag blocks full)
-      int f = q / 900, e = q % 900, a = e / 30, b = e % 30;
-      bool same_blk = (a / 15) == (b / 15);
-      if (a >= b || same_blk) {
-        const double *Ja = v.imu_J + f * 450 + a, *Mb = v.imu_M + f * 450 + b;
-        double s = 0;
-        for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mb[k * 30];
-        if (a >= b) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + a, 15 * f + b), s);
-        else VIO_ATOMIC_ADD(w.Hm + blk_off(f + a / 15, f + a / 15) + (a % 15) * kBS + (b % 15), s);
-      }
-    }
-    VIO_PARFOR(q, v.W * 30) {
-      int f = q / 30, a = q % 30;
-      const double *Ja = v.imu_J + f * 450 + a, *Mr = v.imu_Mr + f * 15;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
-      VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
-    }
-  }
-  if (jac) {
-    VIO_SYNC();
-    stamp(cx, ST_EVAL_IMU);
-  }
-  // ---- projection factors with CauchyLoss (CSI/loss_function.cc:72-79, CSI/corrector.cc:81-129) -----
-  const double bb = v.cauchy_b, cc = 1.0 / bb;
-  VIO_PARFOR(k, v.M) {
-    int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
-    double r[2], Ji[12], Jj[12], Jl[2];
-    projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, jac, r,
-                    Ji, Jj, nullptr, Jl);
-    double sq = r[0] * r[0] + r[1] * r[1];
-    double sum = 1.0 + sq * cc;
-    double inv = 1.0 / sum;
-    cost += 0.5 * bb * log(sum);
-    if (jac) {
-      double rho1 = fmax(inv, 2.2250738585072014e-308);
-      double sr = sqrt(rho1);
-      for (int q = 0; q < 12; q++) Ji[q] *= sr, Jj[q] *= sr;
-      Jl[0] *= sr, Jl[1] *= sr, r[0] *= sr, r[1] *= sr;
-      int oi = off_pose(v, h), oj = off_pose(v, t);
-      double *Hii = w.Hm + blk_off(oi / kBS, oi / kBS), *Hjj = w.Hm + blk_off(oj / kBS, oj / kBS);
-      for (int a = 0; a < 6; a++)
-        for (int b = 0; b < 6; b++) {
-          VIO_ATOMIC_ADD(Hii + a * kBS + b, Ji[a] * Ji[b] + Ji[6 + a] * Ji[6 + b]);
-          VIO_ATOMIC_ADD(Hjj + a * kBS + b, Jj[a] * Jj[b] + Jj[6 + a] * Jj[6 + b]);
-        }
-      // cross block in the lower triangle: rows = later frame
-      if (oj > oi) {
-        double *Hji = w.Hm + blk_off(oj / kBS, oi / kBS);
-        for (int a = 0; a < 6; a++)
-          for (int b = 0; b < 6; b++) VIO_ATOMIC_ADD(Hji + a * kBS + b, Jj[a] * Ji[b] + Jj[6 + a] * Ji[6 + b]);
-      } else if (oi > oj) {
-        double *Hij = w.Hm + blk_off(oi / kBS, oj / kBS);
-        for (int a = 0; a < 6; a++)
-          for (int b = 0; b < 6; b++) VIO_ATOMIC_ADD(Hij + a * kBS + b, Ji[a] * Jj[b] + Ji[6 + a] * Jj[6 + b]);
-      }
-      int ri = 6 * h, rj = 6 * t;  // WT rows (t == P for the loop pose)
-      for (int c = 0; c < 6; c++) {
-        VIO_ATOMIC_ADD(w.gp + oi + c, Ji[c] * r[0] + Ji[6 + c] * r[1]);
-        VIO_ATOMIC_ADD(w.gp + oj + c, Jj[c] * r[0] + Jj[6 + c] * r[1]);
-        VIO_ATOMIC_ADD(v.WT + (ri + c) * v.Fpad + f, Ji[c] * Jl[0] + Ji[6 + c] * Jl[1]);
-        VIO_ATOMIC_ADD(v.WT + (rj + c) * v.Fpad + f, Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]);
-      }
-      VIO_ATOMIC_ADD(w.hff + f, Jl[0] * Jl[0] + Jl[1] * Jl[1]);
-      VIO_ATOMIC_ADD(w.gf + f, Jl[0] * r[0] + Jl[1] * r[1]);
-    }
-  }
-  double total = block_sum(cx, cost);  // contains barriers: all atomics above are complete afterwards
-  if (jac) {
-    VIO_PARFOR(i, np) w.hdiag[i] = *mat_at(w.Hm, i, i);
-    VIO_SYNC();
-  }
-  stamp(cx, jac ? ST_EVAL_PROJ : ST_COST_EVAL);
-  return total;
-}
-
-// =====================================================================================================
-// Linear algebra on the block-lower matrix
-// =====================================================================================================
+// ---- wave-level device helpers (matrix cores, v_readlane) ------------------------------------------
 #ifndef VIO_EMUL
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -664,10 +515,321 @@ VIO_DEV void trsv15T_wave(const double *D, const double *ldinv_k, double *x, int
 }
 #endif  // !VIO_EMUL
 
+// =====================================================================================================
+// Evaluation: cost, and (jac) H -> w.Hm (lower blocks), WT / WTf, hff, gp, gf, hdiag
+// =====================================================================================================
+constexpr int kRowLen = 14;      // staged Jacobian row: Ji(6) Jj(6) r Jl
+constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 1 pad (odd stride: conflict-free LDS writes)
+
+// One element D[row][col] of a (host,target) bucket's Gram matrix G^T G, G = [Ji(6) | Jj(6) | r | Jl | 0 0] per row:
+// host-host, target-target and target-host 6x6 blocks go to the pose-pose accumulator PP, row 12 is J^T r.
+VIO_DEV void gram_flush(const WinView &v, Work &w, int h, int t, int row, int col, double val) {
+  if (row < 6) {
+    if (col <= row) VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + h) * 36 + row * 6 + col, val);
+  } else if (row < 12) {
+    if (col < 6) {
+      if (t > h) VIO_ATOMIC_ADD(v.PP + (t * (t + 1) / 2 + h) * 36 + (row - 6) * 6 + col, val);
+      else VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + t) * 36 + col * 6 + (row - 6), val);
+    } else if (col < 12 && col <= row) {
+      VIO_ATOMIC_ADD(v.PP + (t * (t + 1) / 2 + t) * 36 + (row - 6) * 6 + (col - 6), val);
+    }
+  } else if (row == 12) {
+    if (col < 6) VIO_ATOMIC_ADD(w.gp + off_pose(v, h) + col, val);
+    else if (col < 12) VIO_ATOMIC_ADD(w.gp + off_pose(v, t) + col - 6, val);
+  }
+}
+
+// Projection factors with Jacobians. The (not yet assembled) matrix buffer is used as a staging area: every factor
+// writes its two robustified Jacobian rows into its slot of the (host,target)-bucketed order; each bucket's
+// J^T J / J^T r is then ONE Gram product on the matrix cores (the operand fetch of an MFMA step is 64 consecutive
+// doubles of the staging area, and A and B are the same registers), instead of ~90 scattered atomics per factor.
+// Per-feature sums (host coupling w_h, H_ff, g_f) are gathered by one thread per feature. Returns the cost partial.
+VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *feat,
+                               bool have_scale) {
+  const double bb = v.cauchy_b, cc = 1.0 / bb;
+  double cost = 0.0;
+  double *G = w.Hm;
+  const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
+  const int CH = (nmat / kSlotStride) & ~1;
+  // per-feature sums of this thread's feature (valid when F <= nt: feature f <-> thread f), carried across chunks
+  double fwh[6] = {0, 0, 0, 0, 0, 0}, fe = 0, fgf = 0;
+  int fh = -1;
+  const bool one_thread_per_feature = v.F <= (int)cx.nt;
+  for (int c0 = 0; c0 < v.nslots; c0 += CH) {
+    const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
+    VIO_PARFOR(q, nsl * kSlotStride) G[q] = 0.0;
+    VIO_SYNC();
+    stamp(cx, ST_P_ZERO);
+    VIO_PARFOR(k, v.M) {
+      const int slot = v.fslot[k] - c0;
+      if (slot < 0 || slot >= CH) continue;
+      int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
+      double r[2], Ji[12], Jj[12], Jl[2];
+      projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji,
+                      Jj, nullptr, Jl);
+      double sq = r[0] * r[0] + r[1] * r[1];
+      double sum = 1.0 + sq * cc;
+      cost += 0.5 * bb * log(sum);
+      double sr = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));  // Corrector: rho'' < 0 => scale by sqrt(rho')
+      double *g = G + slot * kSlotStride;
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) g[rr * kRowLen + c] = Ji[rr * 6 + c] * sr, g[rr * kRowLen + 6 + c] = Jj[rr * 6 + c] * sr;
+        g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
+      }
+      // target-frame coupling w_t = Jj^T Jl: one writer per (feature, frame)
+      const double sfv = have_scale ? w.sf[f] : 1.0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double val = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
+        if (have_scale) val *= w.sp[off_pose(v, t) + c] * sfv;
+        v.WT[(6 * t + c) * v.Fpad + f] = val;
+        v.WTf[f * v.n6cap + 6 * t + c] = val;
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_P_FACT);
+#ifdef VIO_EMUL
+    for (int p = 0; p < v.npairs; p++) {
+      int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+      if (s_lo >= s_hi) continue;
+      for (int row = 0; row < 13; row++)
+        for (int col = 0; col < 12; col++) {
+          double d = 0;
+          for (int sl = s_lo; sl < s_hi; sl++)
+            for (int rr = 0; rr < 2; rr++)
+              d += G[(sl - c0) * kSlotStride + rr * kRowLen + row] * G[(sl - c0) * kSlotStride + rr * kRowLen + col];
+          gram_flush(v, w, v.pair_h[p], v.pair_t[p], row, col, d);
+        }
+    }
+#else
+    {
+      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+      const int li = lane & 15, kq = lane >> 4;
+      for (int p = wave; p < v.npairs; p += nw) {
+        int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+        if (s_lo >= s_hi) continue;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const bool lv = li < kRowLen;  // operand columns 14, 15 of the 16-wide tile are zero
+        const double *g = G + (s_lo - c0 + (kq >> 1)) * kSlotStride + (kq & 1) * kRowLen + (lv ? li : 0);
+        v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+        int sl = s_lo;
+        for (; sl + 6 < s_hi; sl += 8, g += 8 * kSlotStride) {  // 4 steps per trip: loads first, two accumulators
+          double a0 = g[0], a1 = g[2 * kSlotStride], a2 = g[4 * kSlotStride], a3 = g[6 * kSlotStride];
+          a0 = lv ? a0 : 0.0, a1 = lv ? a1 : 0.0, a2 = lv ? a2 : 0.0, a3 = lv ? a3 : 0.0;
+          acc = mfma_f64(a0, a0, acc), acc2 = mfma_f64(a1, a1, acc2);
+          acc = mfma_f64(a2, a2, acc), acc2 = mfma_f64(a3, a3, acc2);
+        }
+        for (; sl < s_hi; sl += 2, g += 2 * kSlotStride) {
+          double a = *g;
+          a = lv ? a : 0.0;
+          acc = mfma_f64(a, a, acc);
+        }
+        acc += acc2;
+        const int h = v.pair_h[p], t = v.pair_t[p];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) gram_flush(v, w, h, t, kq + 4 * r4, li, acc[r4]);
+      }
+    }
+#endif
+    VIO_SYNC();
+    stamp(cx, ST_P_GRAM);
+    // per-feature sums over the feature's factors staged in this chunk: w_h += Ji^T Jl, H_ff += Jl^T Jl, g_f += Jl^T r
+    VIO_PARFOR(f, v.F) {
+      double wh[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;
+      int h = -1;
+      for (int k = v.fstart[f]; k < v.fstart[f + 1]; k++) {
+        const int slot = v.fslot[k] - c0;
+        if (slot < 0 || slot >= CH) continue;
+        h = v.fhost[k];
+        const double *g = G + slot * kSlotStride;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          double jl = g[rr * kRowLen + 13];
+#pragma unroll
+          for (int c = 0; c < 6; c++) wh[c] += g[rr * kRowLen + c] * jl;
+          e += jl * jl, gf += jl * g[rr * kRowLen + 12];
+        }
+      }
+      if (one_thread_per_feature) {
+        if (h >= 0) {
+          fh = h, fe += e, fgf += gf;
+#pragma unroll
+          for (int c = 0; c < 6; c++) fwh[c] += wh[c];
+        }
+      } else if (h >= 0) {  // more features than threads: accumulate through memory (entries were zeroed)
+        w.hff[f] += e, w.gf[f] += gf;
+        const double sfv = have_scale ? w.sf[f] : 1.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double val = have_scale ? wh[c] * w.sp[off_pose(v, h) + c] * sfv : wh[c];
+          v.WT[(6 * h + c) * v.Fpad + f] += val;
+          v.WTf[f * v.n6cap + 6 * h + c] += val;
+        }
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_P_FEAT);
+  }
+  if (one_thread_per_feature && (int)cx.tid < v.F) {
+    const int f = cx.tid;
+    w.hff[f] = fe, w.gf[f] = fgf;
+    if (fh >= 0) {
+      const double sfv = have_scale ? w.sf[f] : 1.0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double val = have_scale ? fwh[c] * w.sp[off_pose(v, fh) + c] * sfv : fwh[c];
+        v.WT[(6 * fh + c) * v.Fpad + f] = val;
+        v.WTf[f * v.n6cap + 6 * fh + c] = val;
+      }
+    }
+  }
+  return cost;
+}
+
+VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *sb,
+                        const double *feat, bool jac, bool have_scale = false) {
+  const int np = v.np;
+  double cost = 0.0;  // per-thread partial, reduced at the end
+  if (jac) {
+    const int nF = v.P + v.has_loop;
+    VIO_PARFOR(q, np) w.gp[q] = 0.0;
+    VIO_PARFOR(q, v.F) w.gf[q] = 0.0, w.hff[q] = 0.0;
+    if (!have_scale || v.F > (int)cx.nt) {
+      // the (feature, frame) entries every evaluation writes are the same; they are all assigned (not accumulated)
+      // when each feature has its own thread, so zeroing is needed once (first evaluation of the solve)
+      VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
+      VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
+    }
+    VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;
+    VIO_SYNC();
+    cost += projections_jac(cx, v, w, pose, feat, have_scale);
+    stamp(cx, ST_EVAL_PROJ);
+    const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
+    VIO_PARFOR(q, nmat) w.Hm[q] = 0.0;
+  }
+  // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
+  const int n = v.prior_n;
+  if (n > 0) {
+    VIO_PARFOR(b, v.prior_nb) {
+      int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+      const double *x0 = v.pr_x0 + 9 * b;
+      if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
+      else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
+      else prior_block_dx(7, w.ex, x0, w.prdx + o);
+    }
+    VIO_SYNC();
+    VIO_PARFOR(i, n) {
+      double s = v.pr_r[i];
+      for (int j = 0; j < n; j++) s += v.prJT[j * n + i] * w.prdx[j];
+      w.prr[i] = s;
+      cost += 0.5 * s * s;
+    }
+  }
+  VIO_SYNC();  // Hm zeroed, prr ready
+  if (jac) {
+    if (n > 0) {
+      VIO_PARFOR(a, n) {
+        int pa = w.prcol[a];
+        if (pa >= 0) {
+          double g = 0;
+          for (int k = 0; k < n; k++) g += v.pr_J[k * n + a] * w.prr[k];
+          w.gp[pa] += g;  // unique writer per parameter in this phase
+        }
+      }
+      VIO_PARFOR(q, n * n) {
+        int a = q / n, b = q - a * n;
+        int pa = w.prcol[a], pb = w.prcol[b];
+        if (pa >= 0 && pb >= 0 && pa >= pb) *mat_at(w.Hm, pa, pb) = v.prH0[q];
+      }
+      VIO_SYNC();
+    }
+    // pose-pose blocks of the projection factors
+    const int nF = v.P + v.has_loop;
+    VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) {
+      int blk = q / 36, e = q - blk * 36, r = e / 6, c = e - r * 6;
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= blk) a++;
+      int b = blk - a * (a + 1) / 2;
+      if (a != b || r >= c) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
+    }
+    VIO_SYNC();
+  }
+  stamp(cx, jac ? ST_EVAL_PRIOR : ST_COST_EVAL);
+  // ---- IMU factors -------------------------------------------------------------------------------
+  VIO_PARFOR(f, v.W) {
+    imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
+                 sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
+  }
+  VIO_SYNC();
+  VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
+    int f = q / 15, r = q % 15;
+    const double *info = v.imu_info + f * 225 + r * 15;
+    const double *rr = v.imu_r + f * 15;
+    double s = 0;
+    for (int k = 0; k < 15; k++) s += info[k] * rr[k];
+    v.imu_Mr[q] = s;
+    cost += 0.5 * s * rr[r];
+  }
+  if (jac) {
+    VIO_PARFOR(q, v.W * 450) {  // M = info * Jraw
+      int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
+      const double *info = v.imu_info + f * 225 + r * 15;
+      const double *Jr = v.imu_J + f * 450 + c;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += info[k] * Jr[k * 30];
+      v.imu_M[q] = s;
+    }
+    VIO_SYNC();
+    VIO_PARFOR(q, v.W * 465) {  // H[15f + a][15f + b] += sum_k Jraw[k][a] M[k][b], lower triangle of the 30x30
+      int f = q / 465, e = q - f * 465;
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= e) a++;
+      int b = e - a * (a + 1) / 2;
+      const double *Ja = v.imu_J + f * 450 + a, *Mb = v.imu_M + f * 450 + b;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mb[k * 30];
+      VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + a, 15 * f + b), s);
+    }
+    VIO_PARFOR(q, v.W * 30) {
+      int f = q / 30, a = q % 30;
+      const double *Ja = v.imu_J + f * 450 + a, *Mr = v.imu_Mr + f * 15;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
+      VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
+    }
+    VIO_SYNC();
+    stamp(cx, ST_EVAL_IMU);
+  } else {
+    // ---- projection factors, cost only: CauchyLoss rho = b log(1 + s / b) (CSI/loss_function.cc:72-79) ----------
+    const double bb = v.cauchy_b, cc = 1.0 / bb;
+    VIO_PARFOR(k, v.M) {
+      int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
+      double r[2];
+      projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, false, r,
+                      nullptr, nullptr, nullptr, nullptr);
+      cost += 0.5 * bb * log(1.0 + (r[0] * r[0] + r[1] * r[1]) * cc);
+    }
+  }
+  double total = block_sum(cx, cost);  // contains barriers
+  if (jac) {
+    VIO_PARFOR(i, np) w.hdiag[i] = *mat_at(w.Hm, i, i);
+    VIO_SYNC();
+  }
+  stamp(cx, ST_COST_EVAL);
+  return total;
+}
+
+// =====================================================================================================
+// Linear algebra on the block-lower matrix
+// =====================================================================================================
+
 // In place: Hm <- S Hm S + diag(Dp^2) on the pose side, then subtracts the landmark Schur term
 // sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
 // Returns false if some e_f <= 0.
-VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, double mu) {
+VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, double mu, bool &wt_scaled) {
   const int np = v.np, F = v.F;
   VIO_PARFOR(f, F) {
     double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
@@ -677,13 +839,24 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
     w.tf[f] = w.sf[f] * w.gf[f] * ei;  // gs_f / e_f
     if (!(e > 0.0)) w.flag[0] = 1;
   }
-  // scale WT in place: ws[a][f] = WT[a][f] sp[par(a)] sf[f]
-  VIO_PARFOR(q, v.npose6 * v.Fpad) {
-    int a = q / v.Fpad, f = q - a * v.Fpad;
-    if (f < F) {
-      int fr = a / 6, c = a - 6 * fr;
-      v.WT[q] *= w.sp[kBS * fr + c] * w.sf[f];
+  // scale the landmark coupling in place (both layouts): ws[a][f] = WT[a][f] sp[par(a)] sf[f]. Only after the very
+  // first evaluation: once the Jacobi scaling is known the factors write scaled values directly.
+  if (!wt_scaled) {
+    VIO_PARFOR(q, v.npose6 * v.Fpad) {
+      int a = q / v.Fpad, f = q - a * v.Fpad;
+      if (f < F) {
+        int fr = a / 6, c = a - 6 * fr;
+        v.WT[q] *= w.sp[kBS * fr + c] * w.sf[f];
+      }
     }
+    VIO_PARFOR(q, F * v.n6cap) {
+      int f = q / v.n6cap, a = q - f * v.n6cap;
+      if (a < v.npose6) {
+        int fr = a / 6, c = a - 6 * fr;
+        v.WTf[q] *= w.sp[kBS * fr + c] * w.sf[f];
+      }
+    }
+    wt_scaled = true;
   }
   const int nblocks = v.nblk * (v.nblk + 1) / 2;
   VIO_PARFOR(q, nblocks * kBB) {
@@ -725,15 +898,14 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
       const int tj = p - ti * (ti + 1) / 2;
       const int ra = 16 * ti + li, rb = 16 * tj + li;
       const bool va = ra < n6, vb = rb < n6;
-      const double *pa = v.WT + (size_t)(va ? ra : 0) * v.Fpad;
-      const double *pb = v.WT + (size_t)(vb ? rb : 0) * v.Fpad;
+      const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
       v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
       for (int s = 0; s < ksteps; s++) {
         int f = 4 * s + kq;
         bool vf = f < F;
         int fc = vf ? f : 0;
-        double a = pa[fc] * w.einv[fc], b = pb[fc];
+        double a = pa[(size_t)fc * v.n6cap] * w.einv[fc], b = pb[(size_t)fc * v.n6cap];
         a = (va && vf) ? a : 0.0, b = (vb && vf) ? b : 0.0;
         acc = mfma_f64(a, b, acc);
       }
@@ -753,7 +925,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
   // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets
   const int nch = 8, chunk = (F + nch - 1) / nch;
   VIO_PARFOR(q, n6 * nch) {
-    int a = q / nch, ch = q - a * nch;
+    int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
     const double *wa = v.WT + (size_t)a * v.Fpad;
     int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
     double s = 0;
@@ -798,6 +970,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
     VIO_SYNC();
     if (w.flag[1]) return false;
 #endif
+    stamp(cx, ST_C_POTRF);
     // TRSM: x L_kk^T = a for every row below the diagonal block and for the rhs segment
     const int nrows = (nb - k - 1) * kBS + 1;
     VIO_PARFOR(row, nrows) {
@@ -816,6 +989,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
       for (int c = 0; c < kBS; c++) Ar[c] = x[c];
     }
     VIO_SYNC();
+    stamp(cx, ST_C_TRSM);
     // trailing update
     const int ntb = nb - k - 1;
     VIO_PARFOR(q, ntb * kBS) {  // rhs_i -= L_ik y_k
@@ -891,6 +1065,7 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, Work &w, const double 
   double acc = 0;
   VIO_PARFOR(f, F) {
     double s = 0;
+#pragma unroll 6
     for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * vp[kBS * (a / 6) + a % 6];
     double u = vf[f] + s / w.ef[f];
     acc += w.ef[f] * u * u;
@@ -979,7 +1154,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
     return linf;
   };
 
-  double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+  double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, false);
+  bool wt_scaled = false;  // WT / WTf still carry unscaled values after the first evaluation
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
   VIO_PARFOR(i, np) w.sp[i] = 1.0 / (1.0 + sqrt(w.hdiag[i]));  // Jacobi scaling, :239-254
   VIO_PARFOR(f, F) w.sf[f] = 1.0 / (1.0 + sqrt(w.hff[f]));
@@ -1028,12 +1204,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       while (mu < max_mu) {
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
-          evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+          evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+          wt_scaled = true;
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
         VIO_SYNC();
-        bool ok = build_reduced_system(cx, v, w, mu);
+        bool ok = build_reduced_system(cx, v, w, mu, wt_scaled);
         if (ok) ok = cholesky_blocks(cx, v, w, w.t1);
         stamp(cx, ST_CHOL);
         if (ok) {
@@ -1042,6 +1219,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
           double bad = 0;
           VIO_PARFOR(f, F) {
             double s = 0;
+#pragma unroll 6
             for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * w.t1[kBS * (a / 6) + a % 6];
             double y = w.tf[f] - s / w.ef[f];
             w.gnf[f] = -w.df[f] * y;
@@ -1141,7 +1319,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       record(it, x_cost, radius, 0, 0, gmax, false, false);
       recorded = it + 1, min_rec = fmin(min_rec, x_cost);
       // the matrix buffer holds a factorization: H must be rebuilt before the next build_reduced_system
-      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+      wt_scaled = true;
       continue;
     }
     invalid_run = 0;
@@ -1166,7 +1345,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       VIO_PARFOR(q, F) w.xfeat[q] = w.cfeat[q];
       VIO_SYNC();
       state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
-      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true);
+      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+      wt_scaled = true;
       gmax = grad_max_norm();
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);

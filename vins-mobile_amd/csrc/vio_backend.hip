@@ -34,7 +34,7 @@ struct MargPtrs {
 };
 
 template <bool LDS_MATRIX>
-__global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargPtrs MP) {
+__global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   WinView v = make_view(B, b);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
   mo.ncap = B.d.Ncap;
   MargWork mw;
-  carve_marg(B.d, LDS_MATRIX, smem + state_end, mo.scratch, &mw);
+  carve_marg(B.d, LDS_MATRIX, smem + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
   __syncthreads();
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 }
@@ -103,7 +103,8 @@ struct vio_backend {
   HostBatch hb;
   BatchPtrs B;
   MargPtrs MP;
-  DevBuf<int> d_hdr, d_fhost, d_ftarget, d_ffeat, d_pr_kind, d_pr_index, d_pr_offset, d_stats_i, d_m_ints;
+  DevBuf<int> d_hdr, d_fhost, d_ftarget, d_ffeat, d_pr_kind, d_pr_index, d_pr_offset, d_stats_i, d_m_ints, d_fslot,
+      d_fstart, d_pair_h, d_pair_t, d_pair_s0, d_pair_s1;
   DevBuf<double> d_hdr_d, d_pose, d_sb, d_ex, d_feat, d_pts_i, d_pts_j, d_preint, d_pr_x0, d_pr_J, d_pr_r, d_scratch,
       d_hm, d_out_pose, d_out_sb, d_out_feat, d_raw_pose, d_raw_sb, d_raw_feat, d_out_loop, d_stats_d, d_m_x0, d_m_J,
       d_m_r, d_m_scratch;
@@ -152,7 +153,8 @@ void vio_backend_destroy(vio_backend_t *be) {
   (void)hipStreamSynchronize(be->stream);
   for (auto &e : be->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   DevBuf<int> *ib[] = {&be->d_hdr, &be->d_fhost, &be->d_ftarget, &be->d_ffeat, &be->d_pr_kind, &be->d_pr_index,
-                       &be->d_pr_offset, &be->d_stats_i, &be->d_m_ints};
+                       &be->d_pr_offset, &be->d_stats_i, &be->d_m_ints, &be->d_fslot, &be->d_fstart, &be->d_pair_h,
+                       &be->d_pair_t, &be->d_pair_s0, &be->d_pair_s1};
   for (auto *b : ib) b->release();
   DevBuf<double> *db[] = {&be->d_hdr_d, &be->d_pose, &be->d_sb, &be->d_ex, &be->d_feat, &be->d_pts_i, &be->d_pts_j,
                           &be->d_preint, &be->d_pr_x0, &be->d_pr_J, &be->d_pr_r, &be->d_scratch, &be->d_hm,
@@ -193,14 +195,16 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   // LDS or global matrix: both phases must fit the CU's 160 KB
   size_t state_end = 0;
   size_t bytes_solver = carve_work(d, true, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-  size_t bytes_marg = state_end * sizeof(double) + carve_marg(d, true, (double *)nullptr, nullptr, nullptr);
-  be->lds_matrix = std::max(bytes_solver, bytes_marg) <= kLdsLimit;
+  size_t bytes_marg = state_end * sizeof(double) + carve_marg(d, true, (double *)nullptr, nullptr, nullptr, 0);
+  // the marginalization phase additionally wants >= 64 staging slots behind its dense matrix
+  be->lds_matrix = std::max(bytes_solver, bytes_marg + 64 * kMargSlot * sizeof(double)) <= kLdsLimit;
   if (!be->lds_matrix) {
     bytes_solver = carve_work(d, false, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-    bytes_marg = state_end * sizeof(double) + carve_marg(d, false, (double *)nullptr, nullptr, nullptr);
+    bytes_marg = state_end * sizeof(double) + carve_marg(d, false, (double *)nullptr, nullptr, nullptr, 0);
     if (std::max(bytes_solver, bytes_marg) > kLdsLimit) return VIO_ECAP;
   }
-  be->lds_bytes = std::max(bytes_solver, bytes_marg);
+  // the marginalization phase stages Jacobian rows in whatever LDS is left: give the launch the whole CU budget
+  be->lds_bytes = be->lds_matrix ? kLdsLimit : std::max(bytes_solver, bytes_marg);
 
   const size_t N = (size_t)n;
   const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
@@ -218,6 +222,12 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   ENSURE(be->d_fhost, N * s.fint);
   ENSURE(be->d_ftarget, N * s.fint);
   ENSURE(be->d_ffeat, N * s.fint);
+  ENSURE(be->d_fslot, N * s.fint);
+  ENSURE(be->d_fstart, N * s.fstart);
+  ENSURE(be->d_pair_h, N * s.pair);
+  ENSURE(be->d_pair_t, N * s.pair);
+  ENSURE(be->d_pair_s0, N * s.pair);
+  ENSURE(be->d_pair_s1, N * s.pair);
   ENSURE(be->d_pts_i, N * s.pts);
   ENSURE(be->d_pts_j, N * s.pts);
   ENSURE(be->d_preint, N * s.preint);
@@ -255,6 +265,12 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   H2D(be->d_fhost, be->hb.fhost);
   H2D(be->d_ftarget, be->hb.ftarget);
   H2D(be->d_ffeat, be->hb.ffeat);
+  H2D(be->d_fslot, be->hb.fslot);
+  H2D(be->d_fstart, be->hb.fstart);
+  H2D(be->d_pair_h, be->hb.pair_h);
+  H2D(be->d_pair_t, be->hb.pair_t);
+  H2D(be->d_pair_s0, be->hb.pair_s0);
+  H2D(be->d_pair_s1, be->hb.pair_s1);
   H2D(be->d_pts_i, be->hb.pts_i);
   H2D(be->d_pts_j, be->hb.pts_j);
   H2D(be->d_preint, be->hb.preint);
@@ -272,6 +288,8 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   B.hdr = be->d_hdr.p, B.hdr_d = be->d_hdr_d.p;
   B.pose = be->d_pose.p, B.sb = be->d_sb.p, B.ex = be->d_ex.p, B.feat = be->d_feat.p;
   B.fhost = be->d_fhost.p, B.ftarget = be->d_ftarget.p, B.ffeat = be->d_ffeat.p;
+  B.fslot = be->d_fslot.p, B.fstart = be->d_fstart.p;
+  B.pair_h = be->d_pair_h.p, B.pair_t = be->d_pair_t.p, B.pair_s0 = be->d_pair_s0.p, B.pair_s1 = be->d_pair_s1.p;
   B.pts_i = be->d_pts_i.p, B.pts_j = be->d_pts_j.p, B.preint = be->d_preint.p;
   B.pr_kind = be->d_pr_kind.p, B.pr_index = be->d_pr_index.p, B.pr_offset = be->d_pr_offset.p;
   B.pr_x0 = be->d_pr_x0.p, B.pr_J = be->d_pr_J.p, B.pr_r = be->d_pr_r.p;
@@ -314,11 +332,13 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (be->lds_matrix) {
     HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)be->lds_bytes));
-    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP);
+    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP,
+                       (int)(be->lds_bytes / sizeof(double)));
   } else {
     HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)be->lds_bytes));
-    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP);
+    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP,
+                       (int)(be->lds_bytes / sizeof(double)));
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ev.second, st));
