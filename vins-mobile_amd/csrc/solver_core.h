@@ -157,6 +157,20 @@ VIO_DEV double block_sum(const Ctx &cx, double v) {
   return s;
 #endif
 }
+// Three sums with one pair of barriers.
+VIO_DEV void block_sum3(const Ctx &cx, double &a, double &b, double &c) {
+#ifndef VIO_EMUL
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64), b += __shfl_xor(b, o, 64), c += __shfl_xor(c, o, 64);
+  VIO_SYNC();
+  const int nw = cx.nt >> 6;
+  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = a, cx.red[nw + (cx.tid >> 6)] = b, cx.red[2 * nw + (cx.tid >> 6)] = c;
+  VIO_SYNC();
+  a = b = c = 0;
+  for (int w = 0; w < nw; w++) a += cx.red[w], b += cx.red[nw + w], c += cx.red[2 * nw + w];
+#else
+  (void)cx, (void)a, (void)b, (void)c;
+#endif
+}
 VIO_DEV double block_max(const Ctx &cx, double v) {
 #ifdef VIO_EMUL
   return v;
@@ -292,7 +306,7 @@ VIO_DEV void imu_eval_raw(double gravity, const double *pre, const double *pose_
   }
   res[3] = 2 * qr.x, res[4] = 2 * qr.y, res[5] = 2 * qr.z;
   if (!Jraw) return;
-  for (int i = 0; i < 450; i++) Jraw[i] = 0.0;
+  // Jraw was zeroed once per solve (setup_imu_info); every evaluation overwrites the same non-zero 3x3 blocks
   double Rinv[9], M[9], S[9], Mq[9];
   qtoR(Qi_inv, Rinv);
   // columns: pose_i [0,6), sb_i [6,15), pose_j [15,21), sb_j [21,30)
@@ -394,6 +408,7 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v) {
     int rr = r >= c ? r : c, cc = r >= c ? c : r;  // lower triangle mirrored
     v.imu_info[q] = v.imu_aug[f * 450 + rr * 30 + 15 + cc];
   }
+  VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
   VIO_SYNC();
 }
 
@@ -1265,7 +1280,9 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
       double p1 = 0, p2 = 0;
       VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += w.gdp[i] * w.gnp[i];
       VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += w.gdf[f] * w.gnf[f];
-      double gnn2 = block_sum(cx, p1), gdot = block_sum(cx, p2);
+      double pdummy = 0;
+      block_sum3(cx, p1, p2, pdummy);
+      double gnn2 = p1, gdot = p2;
       double gradient_norm = sqrt(gd_sq), gauss_newton_norm = sqrt(gnn2);
       double ca, cb;
       bool need_norm = false;
@@ -1301,7 +1318,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
         preg += mu_used * w.df[f] * w.df[f] * st * st;
       }
       VIO_SYNC();
-      double n2 = block_sum(cx, pn), sg = block_sum(cx, psg), reg = block_sum(cx, preg);
+      block_sum3(cx, pn, psg, preg);
+      double n2 = pn, sg = psg, reg = preg;
       if (need_norm) dogleg_step_norm = sqrt(n2);
       // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416)
       stamp(cx, ST_DOGLEG);
