@@ -47,9 +47,9 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   B.stats_d = stats_d.data(), B.stats_i = stats_i.data();
 
   WinView v = make_view(B, 0);
-  size_t bytes = carve_work(B.d, true, 64, nullptr, nullptr, nullptr, nullptr);
+  size_t bytes = carve_work<double *>(B.d, true, 64, nullptr, nullptr, nullptr, nullptr);
   std::vector<double> lds(bytes / sizeof(double) + 2);
-  Work w;
+  WorkT<double *> w;
   Ctx cx;
   cx.tid = 0, cx.nt = 1, cx.prof = nullptr;
   size_t state_end = 0;
@@ -59,11 +59,11 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   mo.n = m_int.data(), mo.kind = m_int.data() + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
   mo.x0 = m_x0.data(), mo.J = m_J.data(), mo.r = m_r.data(), mo.scratch = m_scratch.data(), mo.ncap = hb.d.Ncap;
   // doubles behind the iterate: the device's 160 KB when the dense matrix fits, else matrix + a 512-slot staging area
-  size_t core = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr, 0) / sizeof(double);
+  size_t core = carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, 0) / sizeof(double);
   const size_t avail = std::max<size_t>(20480, core + 512 * kMargSlot + 64);
-  size_t mbytes = carve_marg(B.d, true, (double *)nullptr, nullptr, nullptr, avail);
+  size_t mbytes = carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, avail);
   std::vector<double> mlds(mbytes / sizeof(double) + 2);
-  MargWork mw;
+  MargWorkT<double *> mw;
   carve_marg(B.d, true, mlds.data(), nullptr, &mw, avail);
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 

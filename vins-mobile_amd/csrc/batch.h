@@ -138,40 +138,54 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
 // ---- LDS working set ------------------------------------------------------------------------------------
 // Carves `base` (LDS, 16-byte aligned) into the Work arrays for capacities d. When lds_matrix is false the matrix
 // lives in global memory (hm_global). Returns the number of bytes used.
-VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, double *base, double *hm_global,
-                         Work *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
+template <class MP>
+struct MatPick;
+template <>
+struct MatPick<double *> {
+  static VIO_HD double *get(bool lds_matrix, ldsd l, double *g) { return lds_matrix ? (double *)l : g; }
+};
+#ifndef VIO_EMUL
+template <>
+struct MatPick<ldsd> {
+  static VIO_HD ldsd get(bool, ldsd l, double *) { return l; }
+};
+#endif
+
+template <class MP>
+VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global,
+                         WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // padded pose-side length
   const size_t F = d.Fcap;
   auto take = [&](size_t n) {
-    double *p = base ? base + o : nullptr;
+    ldsd p = base + o;  // (a null base only measures; the pointers are then never used)
     o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
     return p;
   };
   // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
-  double *xpose = take(7 * (size_t)(d.Pcap + 1)), *xsb = take(9 * (size_t)d.Pcap), *xfeat = take(F);
-  double *ex = take(8);
-  double *red = take(3 * ((size_t)nthreads / 64) + 2);
+  ldsd xpose = take(7 * (size_t)(d.Pcap + 1)), xsb = take(9 * (size_t)d.Pcap), xfeat = take(F);
+  ldsd ex = take(8);
+  ldsd red = take(3 * ((size_t)nthreads / 64) + 2);
   if (state_end_doubles) *state_end_doubles = o;
-  double *hm = nullptr;
+  ldsd hm = nullptr;
   if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
-  double *cpose = take(7 * (size_t)(d.Pcap + 1)), *csb = take(9 * (size_t)d.Pcap), *cfeat = take(F);
-  double *gp = take(npc), *gf = take(F), *sp = take(npc), *sf = take(F), *dp = take(npc), *df = take(F);
-  double *gdp = take(npc), *gdf = take(F), *gnp = take(npc), *gnf = take(F), *stp = take(npc), *stf = take(F);
-  double *hdiag = take(npc), *hff = take(F), *ef = take(F), *einv = take(F), *ldinv = take(npc), *t1 = take(npc),
-         *t2 = take(npc);
-  double *blk = take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1);
-  double *tf = take(F), *prdx = take(d.Ncap), *prr = take(d.Ncap);
-  double *prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
-  double *flag = take(2);
+  ldsd cpose = take(7 * (size_t)(d.Pcap + 1)), csb = take(9 * (size_t)d.Pcap), cfeat = take(F);
+  ldsd gp = take(npc), gf = take(F), sp = take(npc), sf = take(F), dp = take(npc), df = take(F);
+  ldsd gdp = take(npc), gdf = take(F), gnp = take(npc), gnf = take(F), stp = take(npc), stf = take(F);
+  ldsd hdiag = take(npc), hff = take(F), ef = take(F), einv = take(F), ldinv = take(npc), t1 = take(npc),
+         t2 = take(npc);
+  ldsd blk = take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1);
+  ldsd tf = take(F), prdx = take(d.Ncap), prr = take(d.Ncap);
+  ldsd prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
+  ldsd flag = take(2);
   if (w) {
-    w->Hm = lds_matrix ? hm : hm_global;
+    w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
     w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->df = df, w->gdp = gdp, w->gdf = gdf;
     w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef, w->einv = einv;
-    w->blk_ij = reinterpret_cast<int *>(blk);
+    w->blk_ij = reinterpret_cast<ldsi>(blk);
     w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
-    w->prcol = reinterpret_cast<int *>(prcol), w->flag = reinterpret_cast<int *>(flag);
+    w->prcol = reinterpret_cast<ldsi>(prcol), w->flag = reinterpret_cast<ldsi>(flag);
   }
   if (cx) cx->red = red;
   return o * sizeof(double);

@@ -32,19 +32,20 @@ struct MargOut {
   int ncap;         // capacity of J (ncap x ncap) and r
 };
 
-struct MargWork {
-  double *Am;    // pos x pos row-major, leading dimension ld
+template <class MP>
+struct MargWorkT {
+  MP Am;         // pos x pos row-major, leading dimension ld (LDS when it fits, else global)
   int ld;
-  double *bm;    // pos
-  double *tol;   // pos
-  double *hff, *gf, *einv;  // F
-  double *prdx, *prr;       // prior_n
-  int *col_pose;  // [P+1]: first dense column of pose i (-1: not involved); entry P unused
-  int *col_sb;    // [P]
-  int *col_ex;    // [1]
-  int *pcol;      // prior column -> dense column: prior_n
-  int *meta;      // [4]: pos, m, n, nblocks
-  double *stage;  // staging of robustified Jacobian rows for the Gram products (LDS when it fits)
+  ldsd bm;       // pos
+  ldsd tol;      // pos
+  ldsd hff, gf, einv;  // F
+  ldsd prdx, prr;      // prior_n
+  ldsi col_pose;  // [P+1]: first dense column of pose i (-1: not involved); entry P unused
+  ldsi col_sb;    // [P]
+  ldsi col_ex;    // [1]
+  ldsi pcol;      // prior column -> dense column: prior_n
+  ldsi meta;      // [4]: pos, m, n, nblocks
+  MP stage;       // staging of robustified Jacobian rows for the Gram products (same memory space as Am)
   int stage_slots;
 };
 
@@ -60,44 +61,46 @@ VIO_HD size_t marg_scratch_doubles(const int Wcap) {
 
 // LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
 // is preserved; everything behind it is re-used. Returns bytes used (base may be null to just measure).
-template <class Dims>
-VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, double *base_after_state, double *am_global, MargWork *m,
+template <class MP, class Dims>
+VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, double *am_global, MargWorkT<MP> *m,
                          size_t avail_doubles = 0) {
   size_t o = 0;
   auto take = [&](size_t n) {
-    double *p = base_after_state ? base_after_state + o : nullptr;
+    ldsd p = base_after_state + o;
     o += (n + 1) & ~(size_t)1;
     return p;
   };
   const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Fcap;
-  double *Am = lds_matrix ? take(pos * pos) : nullptr;
-  double *bm = take(pos), *tol = take(pos), *hff = take(F), *gf = take(F), *einv = take(F);
-  double *prdx = take(d.Ncap), *prr = take(d.Ncap);
-  double *ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
+  ldsd Am = lds_matrix ? take(pos * pos) : nullptr;
+  ldsd bm = take(pos), tol = take(pos), hff = take(F), gf = take(F), einv = take(F);
+  ldsd prdx = take(d.Ncap), prr = take(d.Ncap);
+  ldsd ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
   // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows;
   // in the global-matrix variant the staging area follows the matrix in the scratch buffer
   size_t stage_slots = 0;
-  double *stage = nullptr;
+  ldsd stage = nullptr;
+  double *stage_global = nullptr;
   if (lds_matrix) {
     if (avail_doubles > o + kMargSlot * 2) stage_slots = ((avail_doubles - o) / kMargSlot) & ~(size_t)1;
     stage = take(stage_slots * kMargSlot);
   } else {
     stage_slots = 512;
-    stage = am_global ? am_global + pos * pos + 8 : nullptr;
+    stage_global = am_global ? am_global + pos * pos + 8 : nullptr;
   }
   if (m) {
-    m->stage = stage, m->stage_slots = (int)stage_slots;
-    m->Am = lds_matrix ? Am : am_global, m->ld = (int)pos, m->bm = bm, m->tol = tol;
+    m->stage = MatPick<MP>::get(lds_matrix, stage, stage_global), m->stage_slots = (int)stage_slots;
+    m->Am = MatPick<MP>::get(lds_matrix, Am, am_global), m->ld = (int)pos, m->bm = bm, m->tol = tol;
     m->hff = hff, m->gf = gf, m->einv = einv, m->prdx = prdx, m->prr = prr;
-    int *ip = reinterpret_cast<int *>(ints);
+    ldsi ip = reinterpret_cast<ldsi>(ints);
     m->col_pose = ip, m->col_sb = ip + d.Pcap + 1, m->col_ex = m->col_sb + d.Pcap;
     m->pcol = m->col_ex + 1, m->meta = m->pcol + d.Ncap;
   }
   return o * sizeof(double);
 }
 
-VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const double *xpose, const double *xsb,
-                                     const double *xfeat, const double *ex, MargWork &m, const MargOut &out) {
+template <class MW>
+VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpose, cldsd xsb, cldsd xfeat, cldsd ex,
+                                     MW &m, const MargOut &out) {
   const int W = v.W, P = v.P, F = v.F;
   const int flag = v.marg_flag;
   const int pn = v.prior_n;
@@ -144,7 +147,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
       out.kind[nblocks] = kind, out.index[nblocks] = new_index, out.offset[nblocks] = col - mdrop;
       double *x0 = out.x0 + 9 * nblocks;
       for (int q = 0; q < 9; q++) x0[q] = 0.0;
-      const double *src = kind == 0 ? xpose + 7 * idx : kind == 1 ? xsb + 9 * idx : ex;
+      cldsd src = kind == 0 ? xpose + 7 * idx : kind == 1 ? xsb + 9 * idx : ex;
       int gs = kind == 1 ? 9 : 7;
       for (int q = 0; q < gs; q++) x0[q] = src[q];
       nblocks++;
@@ -254,7 +257,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
     int S0 = 0, nb0 = 0;  // buckets (0, t < P) come first in the (host, target) order
     for (int p = 0; p < v.npairs; p++)
       if (v.pair_h[p] == 0 && v.pair_t[p] != P) S0 = v.pair_s1[p], nb0 = p + 1;
-    double *G = m.stage;
+    auto G = m.stage;
     const int CH = m.stage_slots;
     if (CH < 2) {  // launcher guarantees staging space; never loop forever on a bad carve
       if (cx.tid == 0) out.n[0] = -3, out.n[1] = 0;
@@ -282,7 +285,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
                         Jex, Jl);
         double sq = r[0] * r[0] + r[1] * r[1];
         double sr = sqrt(1.0 / (1.0 + sq * cc));
-        double *g = G + slot * kMargSlot, *gx = g + kSlotStride;
+        auto g = G + slot * kMargSlot; auto gx = g + kSlotStride;
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
@@ -331,7 +334,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
             double d1 = 0, d2 = 0, d3 = 0;
             for (int sl = s_lo; sl < s_hi; sl++)
               for (int rr = 0; rr < 2; rr++) {
-                const double *g = G + (sl - c0) * kMargSlot, *gx = g + kSlotStride;
+                auto g = G + (sl - c0) * kMargSlot; auto gx = g + kSlotStride;
                 d1 += g[rr * kRowLen + row] * g[rr * kRowLen + col];
                 if (row < 6) d2 += gx[rr * kMargRowX + row] * g[rr * kRowLen + col];
                 if (row < 6 && col < 6) d3 += gx[rr * kMargRowX + row] * gx[rr * kMargRowX + col];
@@ -349,8 +352,8 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
           if (s_lo >= s_hi) continue;
           v4d a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
           const bool lv = li < kRowLen, lx = li < kMargRowX;
-          const double *g = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
-          const double *gx = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
+          auto g = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
+          auto gx = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
           for (int sl = s_lo; sl < s_hi; sl += 2, g += 2 * kMargSlot, gx += 2 * kMargSlot) {
             double a = *g, x = *gx;
             a = lv ? a : 0.0, x = lx ? x : 0.0;
@@ -373,7 +376,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, const doub
           const int slot = v.fslot[k] - c0;
           if (slot < 0 || slot >= CH) continue;
           touched = true;
-          const double *g = G + slot * kMargSlot, *gx = g + kSlotStride;
+          auto g = G + slot * kMargSlot; auto gx = g + kSlotStride;
 #pragma unroll
           for (int rr = 0; rr < 2; rr++) {
             double jl = g[rr * kRowLen + 13];

@@ -31,15 +31,38 @@
 #ifdef VIO_EMUL
 #define VIO_DEV inline
 #define VIO_SYNC() ((void)0)
-#define VIO_ATOMIC_ADD(p, v) (*(p) += (v))
+#define VIO_ATOMIC_ADD(p, v) ::vio::atomic_add((p), (v))
 #else
 #define VIO_DEV __device__ __forceinline__
 #define VIO_SYNC() __syncthreads()
-#define VIO_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define VIO_ATOMIC_ADD(p, v) ::vio::atomic_add((p), (v))
 #endif
 #define VIO_PARFOR(i, n) for (int i = (int)cx.tid; i < (int)(n); i += (int)cx.nt)
 
+// LDS pointers carry their address space in the type: generic pointers make hipcc emit flat_load/flat_store for every
+// LDS access (no ds_read/ds_write at all in the first version of this kernel), which is several times slower.
+#ifdef VIO_EMUL
+#define VIO_AS3
+#else
+#define VIO_AS3 __attribute__((address_space(3)))
+#endif
+
 namespace vio {
+
+typedef VIO_AS3 double *ldsd;
+typedef const VIO_AS3 double *cldsd;
+typedef VIO_AS3 int *ldsi;
+
+#ifdef VIO_EMUL
+inline void atomic_add(double *p, double v) { *p += v; }
+#else
+__device__ __forceinline__ void atomic_add(ldsd p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void atomic_add(double *p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // only this workgroup touches its scratch
+}
+#endif
 
 constexpr int kBS = 15;          // reduced-system block size: pose 6 + speed-bias 9
 constexpr int kBB = kBS * kBS;   // 225
@@ -52,12 +75,14 @@ constexpr int kStatsInts = 4 + kMaxTrace;         // iterations, termination, n_
 enum Stage {
   ST_SETUP_IMU = 0, ST_SETUP_PRIOR, ST_EVAL_PRIOR, ST_EVAL_IMU, ST_EVAL_PROJ, ST_SCALE, ST_SCHUR, ST_RHS, ST_CHOL,
   ST_TRISOLVE, ST_QUADFORM, ST_DOGLEG, ST_COST_EVAL, ST_NEW2OLD, ST_MARG_BUILD, ST_MARG_CHOL, ST_TOTAL,
-  ST_P_ZERO, ST_P_FACT, ST_P_GRAM, ST_P_FEAT, ST_C_POTRF, ST_C_TRSM, ST_COUNT = 24
+  ST_P_ZERO, ST_P_FACT, ST_P_GRAM, ST_P_FEAT, ST_C_POTRF, ST_C_TRSM,
+  ST_X0, ST_X1, ST_X2, ST_X3, ST_X4, ST_X5, ST_X6, ST_X7, ST_X8, ST_X9, ST_X10, ST_X11,  // scratch stages for ad-hoc profiling
+  ST_COUNT = 36
 };
 
 struct Ctx {
   int tid, nt;
-  double *red;        // LDS scratch for block reductions: [nt/64 + 1]
+  ldsd red;           // LDS scratch for block reductions: [3 nt/64 + 2]
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
 };
 
@@ -111,34 +136,39 @@ struct WinView {
   int *stats_i;
 };
 
-// LDS (or emulated) working set; all arrays sized by the launcher from the dims.
-struct Work {
-  double *Hm;     // block-lower matrix: nblk(nblk+1)/2 blocks of 225 (LDS when it fits, else global)
-  double *xpose, *xsb, *xfeat;   // current iterate: (P+1)*7, P*9, F
-  double *cpose, *csb, *cfeat;   // candidate
-  double *ex;                    // 7
-  double *gp, *gf;               // unscaled gradient J^T r: np, F
-  double *sp, *sf;               // Jacobi scaling
-  double *dp, *df;               // dogleg diagonal
-  double *gdp, *gdf;             // gradient in d-scaled space
-  double *gnp, *gnf;             // Gauss-Newton step in d-scaled space
-  double *stp, *stf;             // trust-region step (J_s coordinates), later delta
-  double *hdiag, *hff;           // diag(H_pp), H_ff (unscaled)
-  double *ef, *einv;             // e_f = sf^2 hff + mu df^2 and its reciprocal
-  int *blk_ij;                   // block index -> (bi << 8) | bj
-  double *ldinv;                 // 1 / L_ii
-  double *t1, *t2;               // np temporaries
-  double *tf;                    // F temporary
-  double *prdx, *prr;            // prior dx / residual: prior_n each
-  int *prcol;                    // prior column -> reduced parameter (-1 constant): prior_n
-  int *flag;                     // [4] block-uniform flags
+// LDS (or emulated) working set; all arrays sized by the launcher from the dims. MP is the pointer type of the matrix
+// buffer: LDS when it fits (ldsd), else global (double *).
+template <class MP>
+struct WorkT {
+  typedef MP mat_ptr;
+  MP Hm;          // block-lower matrix: nblk(nblk+1)/2 blocks of 225
+  ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
+  ldsd cpose, csb, cfeat;   // candidate
+  ldsd ex;                  // 7
+  ldsd gp, gf;              // unscaled gradient J^T r: np, F
+  ldsd sp, sf;              // Jacobi scaling
+  ldsd dp, df;              // dogleg diagonal
+  ldsd gdp, gdf;            // gradient in d-scaled space
+  ldsd gnp, gnf;            // Gauss-Newton step in d-scaled space
+  ldsd stp, stf;            // trust-region step (J_s coordinates), later delta
+  ldsd hdiag, hff;          // diag(H_pp), H_ff (unscaled)
+  ldsd ef, einv;            // e_f = sf^2 hff + mu df^2 and its reciprocal
+  ldsi blk_ij;              // block index -> (bi << 8) | bj
+  ldsd ldinv;               // 1 / L_ii
+  ldsd t1, t2;              // np temporaries
+  ldsd tf;                  // F temporary
+  ldsd prdx, prr;           // prior dx / residual: prior_n each
+  ldsi prcol;               // prior column -> reduced parameter (-1 constant): prior_n
+  ldsi flag;                // [4] block-uniform flags
 };
+
 
 VIO_DEV int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kBB; }
 VIO_DEV int off_pose(const WinView &v, int i) { return kBS * i; }  // loop pose: i == P -> 15 P
 VIO_DEV int off_sb(int i) { return kBS * i + 6; }
 // address of element (i, j) of the block-lower matrix, i >= j (diagonal blocks store the full 15x15)
-VIO_DEV double *mat_at(double *Hm, int i, int j) {
+template <class MP>
+VIO_DEV MP mat_at(MP Hm, int i, int j) {
   int bi = i / kBS, bj = j / kBS;
   return Hm + blk_off(bi, bj) + (i - bi * kBS) * kBS + (j - bj * kBS);
 }
@@ -190,10 +220,11 @@ VIO_DEV double block_max(const Ctx &cx, double v) {
 // =====================================================================================================
 
 // ProjectionFactor::Evaluate (projection_facor.cpp:16-99) in local coordinates. Jex optional.
-VIO_DEV void projection_eval(double s_info, const double *pose_i, const double *pose_j, const double *ex,
-                             double inv_dep, const double *pts_i, const double *pts_j, bool jac, double *r,
-                             double *Ji, double *Jj, double *Jex, double *Jl) {
-  Quat Qi = qfrom_pose(pose_i), Qj = qfrom_pose(pose_j), qic = qfrom_pose(ex);
+template <class PA, class PE>
+VIO_DEV void projection_eval(double s_info, PA pose_i, PA pose_j, PE ex, double inv_dep, const double *pts_i,
+                             const double *pts_j, bool jac, double *r, double *Ji, double *Jj, double *Jex, double *Jl) {
+  Quat Qi{pose_i[3], pose_i[4], pose_i[5], pose_i[6]}, Qj{pose_j[3], pose_j[4], pose_j[5], pose_j[6]},
+      qic{ex[3], ex[4], ex[5], ex[6]};
   double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};
   double t[3], p_imu_i[3], p_w[3], p_imu_j[3], p_c_j[3];
   qrot(qic, pc_i, t);
@@ -241,7 +272,8 @@ VIO_DEV void projection_eval(double s_info, const double *pose_i, const double *
     mat3mul(Bric, Spc, T1);
     mat3vec(Bric, pc_i, v);
     skew3(v, Sv);
-    mat3vec(Ri, ex, u);
+    double exv[3] = {ex[0], ex[1], ex[2]};
+    mat3vec(Ri, exv, u);
     for (int k = 0; k < 3; k++) u[k] += pose_i[k] - pose_j[k];
     mat3vec(RjT, u, w3);
     for (int k = 0; k < 3; k++) w3[k] -= ex[k];
@@ -262,14 +294,14 @@ VIO_DEV void projection_eval(double s_info, const double *pose_i, const double *
 
 // Raw (un-whitened) IMU residual and, if Jraw != NULL, the dense 15x30 Jacobian [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]
 // (imu_factor.h:68-180 before the sqrt_info multiplication; integration_base.h:171-198).
-VIO_DEV void imu_eval_raw(double gravity, const double *pre, const double *pose_i, const double *sb_i,
-                          const double *pose_j, const double *sb_j, double *res, double *Jraw) {
+template <class PA>
+VIO_DEV void imu_eval_raw(double gravity, const double *pre, PA pose_i, PA sb_i, PA pose_j, PA sb_j, double *res,
+                          double *Jraw) {
   const double sum_dt = pre[0];
   const double *delta_p = pre + 1, *delta_q = pre + 4, *delta_v = pre + 8, *lin_ba = pre + 11, *lin_bg = pre + 14;
   const double *J = pre + 17;
-  const double *Pi = pose_i, *Pj = pose_j, *Vi = sb_i, *Bai = sb_i + 3, *Bgi = sb_i + 6, *Vj = sb_j,
-               *Baj = sb_j + 3, *Bgj = sb_j + 6;
-  Quat Qi = qfrom_pose(pose_i), Qj = qfrom_pose(pose_j);
+  PA Pi = pose_i, Pj = pose_j, Vi = sb_i, Bai = sb_i + 3, Bgi = sb_i + 6, Vj = sb_j, Baj = sb_j + 3, Bgj = sb_j + 6;
+  Quat Qi{pose_i[3], pose_i[4], pose_i[5], pose_i[6]}, Qj{pose_j[3], pose_j[4], pose_j[5], pose_j[6]};
   Quat dq{delta_q[0], delta_q[1], delta_q[2], delta_q[3]};
   double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
   for (int i = 0; i < 3; i++)
@@ -351,13 +383,14 @@ VIO_DEV void imu_eval_raw(double gravity, const double *pre, const double *pose_
 }
 
 // dx of one prior block (marginalization_factor.cpp:349-367)
-VIO_DEV void prior_block_dx(int gsize, const double *x, const double *x0, double *dx) {
+template <class PX, class PD>
+VIO_DEV void prior_block_dx(int gsize, PX x, const double *x0, PD dx) {
   if (gsize != 7) {
     for (int k = 0; k < gsize; k++) dx[k] = x[k] - x0[k];
     return;
   }
   for (int k = 0; k < 3; k++) dx[k] = x[k] - x0[k];
-  Quat q = qmul(qinv(qfrom_pose(x0)), qfrom_pose(x));
+  Quat q = qmul(qinv(qfrom_pose(x0)), Quat{x[3], x[4], x[5], x[6]});
   double sgn = (q.w >= 0) ? 1.0 : -1.0;
   dx[3] = sgn * 2.0 * q.x, dx[4] = sgn * 2.0 * q.y, dx[5] = sgn * 2.0 * q.z;
 }
@@ -413,7 +446,8 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v) {
 }
 
 // Prior constants: column map, J0^T (for coalesced mat-vecs) and H0 = J0^T J0.
-VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, Work &w) {
+template <class WK>
+VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
   const int n = v.prior_n;
   if (n <= 0) return;
   VIO_PARFOR(a, n) w.prcol[a] = -1;
@@ -466,7 +500,8 @@ VIO_DEV void sqrt_rsqrt(double x, double &d, double &inv) {
 }
 
 // C(15x15) -= A(15x15) B(15x15)^T with four MFMAs (blocks padded to 16 with zeros on the fly).
-VIO_DEV void mfma_block_update(double *C, const double *A, const double *B, int lane) {
+template <class MP>
+VIO_DEV void mfma_block_update(MP C, MP A, MP B, int lane) {
   const int i = lane & 15, kq = lane >> 4;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -487,7 +522,8 @@ VIO_DEV void mfma_block_update(double *C, const double *A, const double *B, int 
 
 // Cholesky of one 15x15 diagonal block by ONE wave: lane r keeps row r in registers, pivots travel through
 // v_readlane. Writes L (lower) back and 1/L_cc to ldinv_k. Returns false if a pivot is <= 0.
-VIO_DEV bool potrf15_wave(double *D, double *ldinv_k, int lane) {
+template <class MP>
+VIO_DEV bool potrf15_wave(MP D, ldsd ldinv_k, int lane) {
   double a[kBS];
 #pragma unroll
   for (int c = 0; c < kBS; c++) a[c] = (lane < kBS && c <= lane) ? D[(lane < kBS ? lane : 0) * kBS + c] : 0.0;
@@ -513,7 +549,8 @@ VIO_DEV bool potrf15_wave(double *D, double *ldinv_k, int lane) {
 }
 
 // x <- L_kk^-T x for one diagonal block by one wave: lane c keeps column c of L.
-VIO_DEV void trsv15T_wave(const double *D, const double *ldinv_k, double *x, int lane) {
+template <class MP>
+VIO_DEV void trsv15T_wave(MP D, cldsd ldinv_k, ldsd x, int lane) {
   double col[kBS];
   const int lc = lane < kBS ? lane : 0;
 #pragma unroll
@@ -528,6 +565,112 @@ VIO_DEV void trsv15T_wave(const double *D, const double *ldinv_k, double *x, int
   }
   if (lane < kBS) x[lane] = acc;
 }
+
+// Operand fetch for C -= A B^T on 15x15 row-major blocks: lane l supplies X[l&15][4s + (l>>4)] (zero-padded to 16).
+template <class MP>
+VIO_DEV void load_operand15(MP X, int lane, double out[4]) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int kk = 4 * s + kq;
+    const bool ok = (i < kBS) && (kk < kBS);
+    const double x = X[ok ? i * kBS + kk : 0];
+    out[s] = ok ? x : 0.0;
+  }
+}
+
+// Two independent block updates C0 -= A0 B0^T, C1 -= A1 B1^T by one wave: the two MFMA chains interleave and every
+// operand load is in flight before the first matrix instruction issues.
+template <class MP>
+VIO_DEV void mfma_block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool second, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+  double a0[4], b0[4], a1[4], b1[4];
+  load_operand15(A0, lane, a0), load_operand15(B0, lane, b0);
+  load_operand15(A1, lane, a1), load_operand15(B1, lane, b1);
+  v4d acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = kq + 4 * r;
+    const bool ok = row < kBS && i < kBS;
+    const int idx = ok ? row * kBS + i : 0;
+    acc0[r] = C0[idx], acc1[r] = C1[idx];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    acc0 = mfma_f64(-a0[s], b0[s], acc0);
+    acc1 = mfma_f64(-a1[s], b1[s], acc1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = kq + 4 * r;
+    if (row < kBS && i < kBS) {
+      C0[row * kBS + i] = acc0[r];
+      if (second) C1[row * kBS + i] = acc1[r];
+    }
+  }
+}
+
+// Cholesky of one 15x15 diagonal block AND the inverse of its factor by one wave, entirely on the matrix cores.
+// The block lives in the f64 accumulator layout (lane (kq, n), element r <-> D[kq + 4r][n]) as a full symmetric matrix;
+// pivot c: row c of D sits in the 16 lanes kq == (c & 3), element c >> 2, which is exactly where the A and the B operand
+// of k-slot (c & 3) are fetched from, so the rank-1 update D -= l l^T is ONE v_mfma with a = b = l and no data movement.
+// ET (initially I) receives the same eliminations, ET -= l e^T with e = ET[c][:] / L_cc, which leaves e = row c of
+// L^-1. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
+// triangle (D[n][c] = Linv[c][n], n < c), 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
+template <class MP>
+VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  v4d A, E;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    const bool ok = m < kBS && n < kBS;
+    const int hi = m > n ? m : n, lo = m > n ? n : m;
+    const double x = D[ok ? hi * kBS + lo : 0];
+    A[r] = ok ? x : 0.0;
+    E[r] = (m == n) ? 1.0 : 0.0;
+  }
+  bool good = true;
+#pragma unroll
+  for (int c = 0; c < kBS; c++) {
+    const double dcc = lane_bcast(A[c >> 2], 16 * (c & 3) + c);
+    good = good && (dcc > 0.0);
+    double d, inv;
+    sqrt_rsqrt(dcc, d, inv);
+    const bool sel = kq == (c & 3);
+    double a = sel ? A[c >> 2] * inv : 0.0;  // l[n] = L[n][c]
+    const double e = sel ? E[c >> 2] * inv : 0.0;  // Linv[c][n]
+    if (sel && n == c) a = d;
+    if (sel && n < kBS) D[n * kBS + c] = (n >= c) ? a : e;
+    if (sel && n == c) ldinv_k[c] = inv;
+    A = mfma_f64(-a, a, A);
+    E = mfma_f64(-a, e, E);
+  }
+  return good;
+}
+
+// TRSM on the matrix cores: A_ik <- A_ik L_kk^-T with the inverse left behind by potrf15_inv_wave.
+template <class MP>
+VIO_DEV void trsm15_mfma(MP Aik, MP Dkk, cldsd ldinv_k, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  double a[4];
+  load_operand15(Aik, lane, a);
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int kk = 4 * s + kq;
+    const bool lower = n < kBS && kk < n;
+    const double off = Dkk[lower ? kk * kBS + n : 0];
+    const double dg = ldinv_k[n < kBS ? n : 0];
+    const double b = lower ? off : ((n < kBS && kk == n) ? dg : 0.0);  // Linv[n][kk]
+    acc = mfma_f64(a[s], b, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = kq + 4 * r;
+    if (row < kBS && n < kBS) Aik[row * kBS + n] = acc[r];
+  }
+}
 #endif  // !VIO_EMUL
 
 // =====================================================================================================
@@ -538,7 +681,8 @@ constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 
 
 // One element D[row][col] of a (host,target) bucket's Gram matrix G^T G, G = [Ji(6) | Jj(6) | r | Jl | 0 0] per row:
 // host-host, target-target and target-host 6x6 blocks go to the pose-pose accumulator PP, row 12 is J^T r.
-VIO_DEV void gram_flush(const WinView &v, Work &w, int h, int t, int row, int col, double val) {
+template <class WK>
+VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col, double val) {
   if (row < 6) {
     if (col <= row) VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + h) * 36 + row * 6 + col, val);
   } else if (row < 12) {
@@ -559,11 +703,12 @@ VIO_DEV void gram_flush(const WinView &v, Work &w, int h, int t, int row, int co
 // J^T J / J^T r is then ONE Gram product on the matrix cores (the operand fetch of an MFMA step is 64 consecutive
 // doubles of the staging area, and A and B are the same registers), instead of ~90 scattered atomics per factor.
 // Per-feature sums (host coupling w_h, H_ff, g_f) are gathered by one thread per feature. Returns the cost partial.
-VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *feat,
+template <class WK>
+VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pose, cldsd feat,
                                bool have_scale) {
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
-  double *G = w.Hm;
+  auto G = w.Hm;
   const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
   const int CH = (nmat / kSlotStride) & ~1;
   // per-feature sums of this thread's feature (valid when F <= nt: feature f <-> thread f), carried across chunks
@@ -586,7 +731,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const d
       double sum = 1.0 + sq * cc;
       cost += 0.5 * bb * log(sum);
       double sr = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));  // Corrector: rho'' < 0 => scale by sqrt(rho')
-      double *g = G + slot * kSlotStride;
+      auto g = G + slot * kSlotStride;
 #pragma unroll
       for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
@@ -627,7 +772,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const d
         if (s_lo >= s_hi) continue;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const bool lv = li < kRowLen;  // operand columns 14, 15 of the 16-wide tile are zero
-        const double *g = G + (s_lo - c0 + (kq >> 1)) * kSlotStride + (kq & 1) * kRowLen + (lv ? li : 0);
+        auto g = G + (s_lo - c0 + (kq >> 1)) * kSlotStride + (kq & 1) * kRowLen + (lv ? li : 0);
         v4d acc2 = {0.0, 0.0, 0.0, 0.0};
         int sl = s_lo;
         for (; sl + 6 < s_hi; sl += 8, g += 8 * kSlotStride) {  // 4 steps per trip: loads first, two accumulators
@@ -658,7 +803,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const d
         const int slot = v.fslot[k] - c0;
         if (slot < 0 || slot >= CH) continue;
         h = v.fhost[k];
-        const double *g = G + slot * kSlotStride;
+        auto g = G + slot * kSlotStride;
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
           double jl = g[rr * kRowLen + 13];
@@ -703,8 +848,9 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, Work &w, const d
   return cost;
 }
 
-VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *pose, const double *sb,
-                        const double *feat, bool jac, bool have_scale = false) {
+template <class WK>
+VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, cldsd sb,
+                        cldsd feat, bool jac, bool have_scale = false) {
   const int np = v.np;
   double cost = 0.0;  // per-thread partial, reduced at the end
   if (jac) {
@@ -778,6 +924,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
                  sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
   }
   VIO_SYNC();
+  if (jac) stamp(cx, ST_X0);
   VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
     int f = q / 15, r = q % 15;
     const double *info = v.imu_info + f * 225 + r * 15;
@@ -788,6 +935,56 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
     cost += 0.5 * s * rr[r];
   }
   if (jac) {
+#ifndef VIO_EMUL
+    // One wave per IMU factor on the matrix cores. B = [Jraw | r | 0] (15 x 32, k padded to 16):
+    //   T = info B            (2 column tiles x 4 k-steps)
+    //   G = B^T T             (lower tiles (0,0), (1,0), (1,1)): G[a][b] = (J^T info J)_ab, G[30][b] = (J^T info r)_b
+    // The f64 accumulator layout of T (lane l, element r <-> T[(l>>4)+4r][l&15]) IS the B-operand layout of k-step r,
+    // so T never leaves the registers.
+    {
+      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+      const int n = lane & 15, kq = lane >> 4;
+      for (int f = wave; f < v.W; f += nw) {
+        const double *info = v.imu_info + f * 225, *Jr = v.imu_J + f * 450, *rr = v.imu_r + f * 15;
+        double av[4], bv[2][4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int k = 4 * s4 + kq;
+          const bool kok = k < 15;
+          const int kc = kok ? k : 0;
+          av[s4] = (kok && n < 15) ? info[(n < 15 ? n : 0) * 15 + kc] : 0.0;
+          bv[0][s4] = kok ? Jr[kc * 30 + n] : 0.0;
+          double hi = (n < 14) ? Jr[kc * 30 + 16 + (n < 14 ? n : 0)] : (n == 14 ? rr[kc] : 0.0);
+          bv[1][s4] = kok ? hi : 0.0;
+        }
+        v4d T0 = {0, 0, 0, 0}, T1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) T0 = mfma_f64(av[s4], bv[0][s4], T0), T1 = mfma_f64(av[s4], bv[1][s4], T1);
+        v4d G00 = {0, 0, 0, 0}, G10 = {0, 0, 0, 0}, G11 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          G00 = mfma_f64(bv[0][s4], T0[s4], G00);
+          G10 = mfma_f64(bv[1][s4], T0[s4], G10);
+          G11 = mfma_f64(bv[1][s4], T1[s4], G11);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const int row = kq + 4 * r4;  // within the tile
+          // tile (0,0): rows/cols 0..15
+          if (row >= n) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + row, 15 * f + n), G00[r4]);
+          // tiles (1,x): rows 16..31 -> 16..29 are Jacobian columns, 30 is the residual row
+          const int R = 16 + row;
+          if (R < 30) {
+            VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + R, 15 * f + n), G10[r4]);
+            if (n < 14 && R >= 16 + n) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + R, 15 * f + 16 + n), G11[r4]);
+          } else if (R == 30) {
+            VIO_ATOMIC_ADD(w.gp + 15 * f + n, G10[r4]);
+            if (n < 14) VIO_ATOMIC_ADD(w.gp + 15 * f + 16 + n, G11[r4]);
+          }
+        }
+      }
+    }
+#else
     VIO_PARFOR(q, v.W * 450) {  // M = info * Jraw
       int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
       const double *info = v.imu_info + f * 225 + r * 15;
@@ -804,7 +1001,6 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
       int b = e - a * (a + 1) / 2;
       const double *Ja = v.imu_J + f * 450 + a, *Mb = v.imu_M + f * 450 + b;
       double s = 0;
-#pragma unroll
       for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mb[k * 30];
       VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + a, 15 * f + b), s);
     }
@@ -815,6 +1011,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
       for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
       VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
     }
+#endif
     VIO_SYNC();
     stamp(cx, ST_EVAL_IMU);
   } else {
@@ -844,7 +1041,8 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, Work &w, const double *
 // In place: Hm <- S Hm S + diag(Dp^2) on the pose side, then subtracts the landmark Schur term
 // sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
 // Returns false if some e_f <= 0.
-VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, double mu, bool &wt_scaled) {
+template <class WK>
+VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu, bool &wt_scaled) {
   const int np = v.np, F = v.F;
   VIO_PARFOR(f, F) {
     double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
@@ -955,15 +1153,82 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, Work &w, doub
 
 // Blocked right-looking Cholesky (block 15) of the block-lower matrix in place, with the right-hand side carried
 // along: on return the lower blocks hold L, ldinv = 1 / L_ii and rhs = L^-1 rhs (forward substitution).
-//   POTRF  one wave, rows in registers, pivots through v_readlane
-//   TRSM   one thread per panel row (the rhs is one more row), substitution against L_kk
-//   SYRK   trailing blocks A_ij -= L_ik L_jk^T on the matrix cores, one block per wave at a time
+//   POTRF  one wave, block in the MFMA accumulator layout, one rank-1 v_mfma per pivot; also yields L_kk^-1
+//   TRSM   A_ik L_kk^-T as a matrix-core product, one block per wave (the rhs segment: 15 lanes)
+//   SYRK   trailing blocks A_ij -= L_ik L_jk^T on the matrix cores, two blocks per wave at a time; wave 0 looks
+//          ahead: it updates the next diagonal block first and factors it while the others finish the update
+// (The VIO_EMUL build runs the textbook scalar version of the same factorization.)
 // false when a pivot is <= 0 (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
-VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *rhs) {
+#ifndef VIO_EMUL
+template <class WK>
+VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
+  const int nb = v.nblk;
+  const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+  if (wave == 0) {
+    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.ldinv, lane);
+    if (!good && lane == 0) w.flag[1] = 1;
+  }
+  VIO_SYNC();
+  stamp(cx, ST_C_POTRF);
+  for (int k = 0; k < nb; k++) {
+    if (w.flag[1]) return false;
+    auto D = w.Hm + blk_off(k, k);
+    const int ntb = nb - k - 1;
+    // ---- panel: L_ik = A_ik L_kk^-T (one wave per block), y_k = L_kk^-1 rhs_k (15 lanes of the last wave)
+    for (int bi = wave; bi < ntb; bi += nw) trsm15_mfma(w.Hm + blk_off(k + 1 + bi, k), D, w.ldinv + k * kBS, lane);
+    if (wave == nw - 1) {
+      const int nn = lane < kBS ? lane : 0;
+      double sacc = w.ldinv[k * kBS + nn] * rhs[k * kBS + nn];
+      for (int kk = 0; kk < nn; kk++) sacc = fma(D[kk * kBS + nn], rhs[k * kBS + kk], sacc);
+      if (lane < kBS) rhs[k * kBS + lane] = sacc;  // (all loads of the wave precede this store)
+    }
+    VIO_SYNC();
+    stamp(cx, ST_C_TRSM);
+    // ---- trailing update with look-ahead: wave 0 updates the next diagonal block and factors it at once while the
+    // other waves update the remaining blocks (two at a time each)
+    for (int q = cx.nt - 1 - cx.tid; q < ntb * kBS; q += cx.nt) {  // rhs_i -= L_ik y_k (upper waves)
+      int i = k + 1 + q / kBS, r = q % kBS;
+      auto Lr = w.Hm + blk_off(i, k) + r * kBS;
+      double sacc = 0;
+#pragma unroll
+      for (int m = 0; m < kBS; m++) sacc = fma(Lr[m], rhs[k * kBS + m], sacc);
+      rhs[i * kBS + r] -= sacc;
+    }
+    const int npairs = ntb * (ntb + 1) / 2;
+    if (wave == 0) {
+      if (ntb > 0) {
+        auto Dn = w.Hm + blk_off(k + 1, k + 1), Ln = w.Hm + blk_off(k + 1, k);
+        mfma_block_update(Dn, Ln, Ln, lane);
+        bool good = potrf15_inv_wave(Dn, w.ldinv + (k + 1) * kBS, lane);
+        if (!good && lane == 0) w.flag[1] = 1;
+      }
+    } else {
+      const int stride = nw - 1;
+      for (int pr = wave; pr < npairs; pr += 2 * stride) {
+        const int pr1 = pr + stride;
+        const bool second = pr1 < npairs;
+        const int q1 = second ? pr1 : pr;
+        int li = 0, lj, mi = 0, mj;
+        while ((li + 1) * (li + 2) / 2 <= pr) li++;
+        lj = pr - li * (li + 1) / 2;
+        while ((mi + 1) * (mi + 2) / 2 <= q1) mi++;
+        mj = q1 - mi * (mi + 1) / 2;
+        const int i0 = k + 1 + li, j0 = k + 1 + lj, i1 = k + 1 + mi, j1 = k + 1 + mj;
+        mfma_block_update2(w.Hm + blk_off(i0, j0), w.Hm + blk_off(i0, k), w.Hm + blk_off(j0, k),
+                           w.Hm + blk_off(i1, j1), w.Hm + blk_off(i1, k), w.Hm + blk_off(j1, k), second, lane);
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_X2);
+  }
+  return w.flag[1] == 0;
+}
+#else
+template <class WK>
+VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
   const int nb = v.nblk;
   for (int k = 0; k < nb; k++) {
-    double *D = w.Hm + blk_off(k, k);
-#ifdef VIO_EMUL
+    auto D = w.Hm + blk_off(k, k);
     for (int c = 0; c < kBS; c++) {
       double x = D[c * kBS + c];
       for (int p = 0; p < c; p++) x -= D[c * kBS + p] * D[c * kBS + p];
@@ -977,19 +1242,10 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
         D[i * kBS + c] = s / x;
       }
     }
-#else
-    if ((cx.tid >> 6) == 0) {
-      bool good = potrf15_wave(D, w.ldinv + k * kBS, cx.tid & 63);
-      if (!good && cx.tid == 0) w.flag[1] = 1;
-    }
-    VIO_SYNC();
-    if (w.flag[1]) return false;
-#endif
     stamp(cx, ST_C_POTRF);
     // TRSM: x L_kk^T = a for every row below the diagonal block and for the rhs segment
     const int nrows = (nb - k - 1) * kBS + 1;
-    VIO_PARFOR(row, nrows) {
-      double *Ar = row < nrows - 1 ? w.Hm + blk_off(k + 1 + row / kBS, k) + (row % kBS) * kBS : rhs + k * kBS;
+    auto trsm_row = [&](auto Ar) {
       double x[kBS];
 #pragma unroll
       for (int c = 0; c < kBS; c++) x[c] = Ar[c];
@@ -1002,6 +1258,12 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
       }
 #pragma unroll
       for (int c = 0; c < kBS; c++) Ar[c] = x[c];
+    };
+    VIO_PARFOR(row, nrows) {
+      if (row < nrows - 1)
+        trsm_row(w.Hm + blk_off(k + 1 + row / kBS, k) + (row % kBS) * kBS);
+      else
+        trsm_row(rhs + k * kBS);
     }
     VIO_SYNC();
     stamp(cx, ST_C_TRSM);
@@ -1009,14 +1271,13 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
     const int ntb = nb - k - 1;
     VIO_PARFOR(q, ntb * kBS) {  // rhs_i -= L_ik y_k
       int i = k + 1 + q / kBS, r = q % kBS;
-      const double *Lr = w.Hm + blk_off(i, k) + r * kBS;
+      auto Lr = w.Hm + blk_off(i, k) + r * kBS;
       double s = 0;
 #pragma unroll
       for (int m = 0; m < kBS; m++) s += Lr[m] * rhs[k * kBS + m];
       rhs[i * kBS + r] -= s;
     }
     const int npairs = ntb * (ntb + 1) / 2;
-#ifdef VIO_EMUL
     for (int pr = 0; pr < npairs; pr++) {
       int li = 0;
       while ((li + 1) * (li + 2) / 2 <= pr) li++;
@@ -1024,34 +1285,24 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, Work &w, double *r
       int i = k + 1 + li, j = k + 1 + lj;
       for (int r = 0; r < kBS; r++)
         for (int c = 0; c < kBS; c++) {
-          const double *Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
+          auto Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
           double s = 0;
           for (int m = 0; m < kBS; m++) s += Li[m] * Lj[m];
           w.Hm[blk_off(i, j) + r * kBS + c] -= s;
         }
     }
-#else
-    {
-      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
-      for (int pr = wave; pr < npairs; pr += nw) {
-        int li = 0;
-        while ((li + 1) * (li + 2) / 2 <= pr) li++;
-        const int lj = pr - li * (li + 1) / 2;
-        const int i = k + 1 + li, j = k + 1 + lj;
-        mfma_block_update(w.Hm + blk_off(i, j), w.Hm + blk_off(i, k), w.Hm + blk_off(j, k), lane);
-      }
-    }
-#endif
     VIO_SYNC();
   }
   return true;
 }
+#endif
 
 // x <- L^-T x (backward substitution; the forward half rode along with the factorization)
-VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, Work &w, double *x) {
+template <class WK>
+VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) {
   const int nb = v.nblk;
   for (int k = nb - 1; k >= 0; k--) {
-    const double *D = w.Hm + blk_off(k, k);
+    auto D = w.Hm + blk_off(k, k);
 #ifdef VIO_EMUL
     for (int c = kBS - 1; c >= 0; c--) {
       double s = x[k * kBS + c];
@@ -1059,12 +1310,17 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, Work &w, double
       x[k * kBS + c] = s * w.ldinv[k * kBS + c];
     }
 #else
-    if ((cx.tid >> 6) == 0) trsv15T_wave(D, w.ldinv + k * kBS, x + k * kBS, cx.tid & 63);
+    if ((cx.tid >> 6) == 0) {  // x_k <- L_kk^-T x_k with the stored inverse (row c of the block holds Linv[:][c] above the diagonal)
+      const int c = (cx.tid & 63) < kBS ? (cx.tid & 63) : 0;
+      double sacc = w.ldinv[k * kBS + c] * x[k * kBS + c];
+      for (int r = c + 1; r < kBS; r++) sacc = fma(D[c * kBS + r], x[k * kBS + r], sacc);
+      if ((cx.tid & 63) < kBS) x[k * kBS + c] = sacc;
+    }
     VIO_SYNC();
 #endif
     VIO_PARFOR(q, k * kBS) {  // y_j -= L_kj^T x_k for j < k
       int j = q / kBS, c = q % kBS;
-      const double *Lkj = w.Hm + blk_off(k, j);
+      auto Lkj = w.Hm + blk_off(k, j);
       double s = 0;
 #pragma unroll
       for (int m = 0; m < kBS; m++) s += Lkj[m * kBS + c] * x[k * kBS + m];
@@ -1075,7 +1331,8 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, Work &w, double
 }
 
 // q(v) = v^T (S H S + mu D^2) v through the factorization: sum_f e_f (v_f + ws_f^T v_p / e_f)^2 + |L^T v_p|^2
-VIO_DEV double quad_form(const Ctx &cx, const WinView &v, Work &w, const double *vp, const double *vf) {
+template <class WK>
+VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf) {
   const int np = v.np, F = v.F;
   double acc = 0;
   VIO_PARFOR(f, F) {
@@ -1085,17 +1342,18 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, Work &w, const double 
     double u = vf[f] + s / w.ef[f];
     acc += w.ef[f] * u * u;
   }
+  stamp(cx, ST_X3);
   VIO_PARFOR(j, np) {
     // (L^T v)_j = sum_{i >= j} L[i][j] v_i
     int bj = j / kBS, cj = j % kBS;
     double s = 0;
-    const double *D = w.Hm + blk_off(bj, bj);
+    auto D = w.Hm + blk_off(bj, bj);
     for (int r = cj; r < kBS; r++) {
       int i = bj * kBS + r;
       if (i < np) s += D[r * kBS + cj] * vp[i];
     }
     for (int bi = bj + 1; bi < v.nblk; bi++) {
-      const double *B = w.Hm + blk_off(bi, bj);
+      auto B = w.Hm + blk_off(bi, bj);
       for (int r = 0; r < kBS; r++) {
         int i = bi * kBS + r;
         if (i < np) s += B[r * kBS + cj] * vp[i];
@@ -1107,12 +1365,13 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, Work &w, const double 
 }
 
 // PoseLocalParameterization::Plus on all blocks: c = x [+] (delta_p, delta_f)
-VIO_DEV void apply_plus(const Ctx &cx, const WinView &v, Work &w, const double *dpv, const double *dfv) {
+template <class WK>
+VIO_DEV void apply_plus(const Ctx &cx, const WinView &v, WK &w, cldsd dpv, cldsd dfv) {
   const int npose = v.P + v.has_loop;
   VIO_PARFOR(i, npose) {
-    const double *p0 = w.xpose + 7 * i;
-    const double *d = dpv + off_pose(v, i);
-    double *p = w.cpose + 7 * i;
+    auto p0 = w.xpose + 7 * i;
+    auto d = dpv + off_pose(v, i);
+    auto p = w.cpose + 7 * i;
     for (int k = 0; k < 3; k++) p[k] = p0[k] + d[k];
     Quat q = qnormalized(qmul(qfrom_pose(p0), Quat{d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0}));
     p[3] = q.x, p[4] = q.y, p[5] = q.z, p[6] = q.w;
@@ -1123,8 +1382,8 @@ VIO_DEV void apply_plus(const Ctx &cx, const WinView &v, Work &w, const double *
 }
 
 // norms over the reduced program's (global-size) parameters: |a - b|_2 / |a - b|_inf / |a|_2
-VIO_DEV void state_norms(const Ctx &cx, const WinView &v, const double *apose, const double *asb, const double *afeat,
-                         const double *bpose, const double *bsb, const double *bfeat, double *l2, double *linf) {
+VIO_DEV void state_norms(const Ctx &cx, const WinView &v, cldsd apose, cldsd asb, cldsd afeat, cldsd bpose, cldsd bsb,
+                         cldsd bfeat, double *l2, double *linf) {
   double s = 0, m = 0;
   const int npose = v.P + v.has_loop;
   VIO_PARFOR(q, npose * 7) {
@@ -1146,7 +1405,8 @@ VIO_DEV void state_norms(const Ctx &cx, const WinView &v, const double *apose, c
 // =====================================================================================================
 // TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
 // =====================================================================================================
-VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
+template <class WK>
+VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   const int np = v.np, F = v.F;
   double *sd = v.stats_d;
   int *si = v.stats_i;
@@ -1230,6 +1490,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
         stamp(cx, ST_CHOL);
         if (ok) {
           cholesky_backsolve(cx, v, w, w.t1);  // y_p
+          stamp(cx, ST_X4);
           // back-substitute features: y_f = (gs_f - ws_f^T y_p) / e_f ; GN = -d * y
           double bad = 0;
           VIO_PARFOR(f, F) {
@@ -1398,7 +1659,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, Work &w) {
 // =====================================================================================================
 // Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs
 // =====================================================================================================
-VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
+template <class WK>
+VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   const int P = v.P, F = v.F;
   VIO_PARFOR(q, P * 7) w.xpose[q] = v.pose0[q];
   VIO_PARFOR(q, P * 9) w.xsb[q] = v.sb0[q];
@@ -1446,14 +1708,15 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, Work &w) {
   double p0[3] = {w.xpose[0], w.xpose[1], w.xpose[2]};
   VIO_SYNC();
   VIO_PARFOR(i, P) {
-    const double *pp = w.xpose + 7 * i, *sbv = w.xsb + 9 * i;
+    auto pp = w.xpose + 7 * i, sbv = w.xsb + 9 * i;
     double Rq[9], Rs[9], d[3] = {pp[0] - p0[0], pp[1] - p0[1], pp[2] - p0[2]}, Ps[3], Vs[3];
     qtoR(qnormalized(qfrom_pose(pp)), Rq);
     mat3mul(rot_diff, Rq, Rs);
     mat3vec(rot_diff, d, Ps);
-    mat3vec(rot_diff, sbv, Vs);
+    double vv[3] = {sbv[0], sbv[1], sbv[2]};
+    mat3vec(rot_diff, vv, Vs);
     Quat q = RtoQ(Rs);
-    double *po = w.cpose + 7 * i, *so = w.csb + 9 * i;
+    auto po = w.cpose + 7 * i, so = w.csb + 9 * i;
     for (int k = 0; k < 3; k++) po[k] = Ps[k] + op[k], so[k] = Vs[k];
     po[3] = q.x, po[4] = q.y, po[5] = q.z, po[6] = q.w;
     for (int k = 3; k < 9; k++) so[k] = sbv[k];

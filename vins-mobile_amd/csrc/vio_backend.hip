@@ -38,12 +38,14 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = blockIdx.x;
   WinView v = make_view(B, b);
-  Work w;
+  typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
+  ldsd lds = (ldsd)smem;
+  WorkT<MatP> w;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
   size_t state_end = 0;
-  carve_work(B.d, LDS_MATRIX, blockDim.x, smem, B.hm + (size_t)b * B.s.hm, &w, &cx, &state_end);
+  carve_work(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, &w, &cx, &state_end);
   solve_window(cx, v, w);
 
   MargOut mo;
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
   mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
   mo.ncap = B.d.Ncap;
-  MargWork mw;
-  carve_marg(B.d, LDS_MATRIX, smem + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
+  MargWorkT<MatP> mw;
+  carve_marg(B.d, LDS_MATRIX, lds + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
   __syncthreads();
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 }
@@ -194,13 +196,13 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   const BatchStrides &s = be->hb.s;
   // LDS or global matrix: both phases must fit the CU's 160 KB
   size_t state_end = 0;
-  size_t bytes_solver = carve_work(d, true, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-  size_t bytes_marg = state_end * sizeof(double) + carve_marg(d, true, (double *)nullptr, nullptr, nullptr, 0);
+  size_t bytes_solver = carve_work<ldsd>(d, true, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
+  size_t bytes_marg = state_end * sizeof(double) + carve_marg<ldsd>(d, true, nullptr, nullptr, nullptr, 0);
   // the marginalization phase additionally wants >= 64 staging slots behind its dense matrix
   be->lds_matrix = std::max(bytes_solver, bytes_marg + 64 * kMargSlot * sizeof(double)) <= kLdsLimit;
   if (!be->lds_matrix) {
-    bytes_solver = carve_work(d, false, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-    bytes_marg = state_end * sizeof(double) + carve_marg(d, false, (double *)nullptr, nullptr, nullptr, 0);
+    bytes_solver = carve_work<double *>(d, false, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
+    bytes_marg = state_end * sizeof(double) + carve_marg<double *>(d, false, nullptr, nullptr, nullptr, 0);
     if (std::max(bytes_solver, bytes_marg) > kLdsLimit) return VIO_ECAP;
   }
   // the marginalization phase stages Jacobian rows in whatever LDS is left: give the launch the whole CU budget

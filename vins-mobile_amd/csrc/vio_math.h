@@ -69,7 +69,10 @@ VIO_HD Quat RtoQ(const double R[9]) {
   }
   return q;
 }
-VIO_HD Quat qfrom_pose(const double *p) { return Quat{p[3], p[4], p[5], p[6]}; }
+template <class P>
+VIO_HD Quat qfrom_pose(P p) {
+  return Quat{p[3], p[4], p[5], p[6]};
+}
 
 VIO_HD void mat3mul(const double A[9], const double B[9], double C[9]) {
   for (int i = 0; i < 3; i++)
