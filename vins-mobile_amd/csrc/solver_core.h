@@ -401,7 +401,9 @@ VIO_DEV void prior_block_dx(int gsize, PX x, const double *x0, PD dx) {
 
 // cov^-1 for every IMU factor: Gauss-Jordan with partial pivoting on [cov | I] (the same elimination order as the
 // CPU restatement, so the two agree bit for bit), then the lower triangle is mirrored (Eigen's LLT only reads it).
-VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v) {
+#ifdef VIO_EMUL
+template <class MP>
+VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP) {
   const int W = v.W;
   VIO_PARFOR(q, W * 450) {
     int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
@@ -444,6 +446,75 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v) {
   VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
   VIO_SYNC();
 }
+#else
+// Device form: 32 lanes per factor, lane j keeps column j of [cov | I] in registers through all 15 pivots; the pivot
+// column travels through a 16-double mailbox per factor (in the still unused matrix buffer). Same arithmetic, same
+// order as the loop above.
+template <class MP>
+VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
+  const int W = v.W;
+  VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
+  const int j = cx.tid & 31, slot = cx.tid >> 5, nslots = cx.nt >> 5;
+  for (int f0 = 0; f0 < W; f0 += nslots) {
+    const int f = f0 + slot;
+    const bool act = f < W && j < 30;
+    const int fc = f < W ? f : 0;
+    auto mb = mbox + slot * 32;
+    double x[15];
+#pragma unroll
+    for (int r = 0; r < 15; r++)
+      x[r] = j < 15 ? v.preint[fc * kPreintDoubles + 242 + r * 15 + (j < 15 ? j : 0)] : (double)(j - 15 == r);
+#pragma unroll
+    for (int c = 0; c < 15; c++) {
+      if (j == c) {  // owner of the pivot column: partial pivoting (first maximum), then publish the column
+        int piv = c;
+        double best = fabs(x[c]);
+#pragma unroll
+        for (int r = c + 1; r < 15; r++)
+          if (fabs(x[r]) > best) best = fabs(x[r]), piv = r;
+#pragma unroll
+        for (int r = 0; r < 15; r++) mb[r] = x[r];
+        mb[15] = (double)piv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int piv = (int)mb[15];
+      double m[15];
+#pragma unroll
+      for (int r = 0; r < 15; r++) m[r] = mb[r];  // column c before the swap
+      __builtin_amdgcn_wave_barrier();
+      // swap rows c <-> piv in my column and in the multiplier column
+      double xp = x[c], mp = m[c];
+#pragma unroll
+      for (int r = 0; r < 15; r++) {
+        if (r == piv) xp = x[r], mp = m[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 15; r++) {
+        if (r == piv && r != c) x[r] = x[c], m[r] = m[c];
+      }
+      const double d = mp;  // A[c][c] after the swap
+      x[c] = xp / d;
+      // multipliers are read after the normalisation of row c: A[r][c] for r != c is unchanged by it
+#pragma unroll
+      for (int r = 0; r < 15; r++) {
+        if (r != c) {
+          const double fac = m[r];
+          if (fac != 0.0) x[r] -= fac * x[c];
+        }
+      }
+    }
+    if (act && j >= 15) {
+      const int cc = j - 15;
+#pragma unroll
+      for (int rr = 0; rr < 15; rr++)
+        if (rr >= cc) v.imu_info[f * 225 + rr * 15 + cc] = x[rr], v.imu_info[f * 225 + cc * 15 + rr] = x[rr];
+    }
+  }
+  VIO_SYNC();
+}
+#endif
 
 // Prior constants: column map, J0^T (for coalesced mat-vecs) and H0 = J0^T J0.
 template <class WK>
@@ -1297,70 +1368,110 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
 }
 #endif
 
-// x <- L^-T x (backward substitution; the forward half rode along with the factorization)
+// x <- L^-T x (backward substitution; the forward half rode along with the factorization). One barrier per block
+// column: wave 0 applies step k to segment k-1 first and solves it at once with the stored inverse (above the diagonal
+// of the block, see potrf15_inv_wave) while the other waves apply step k to the segments before it.
 template <class WK>
 VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) {
   const int nb = v.nblk;
+#ifdef VIO_EMUL
   for (int k = nb - 1; k >= 0; k--) {
     auto D = w.Hm + blk_off(k, k);
-#ifdef VIO_EMUL
     for (int c = kBS - 1; c >= 0; c--) {
       double s = x[k * kBS + c];
       for (int r = c + 1; r < kBS; r++) s -= D[r * kBS + c] * x[k * kBS + r];
       x[k * kBS + c] = s * w.ldinv[k * kBS + c];
     }
-#else
-    if ((cx.tid >> 6) == 0) {  // x_k <- L_kk^-T x_k with the stored inverse (row c of the block holds Linv[:][c] above the diagonal)
-      const int c = (cx.tid & 63) < kBS ? (cx.tid & 63) : 0;
-      double sacc = w.ldinv[k * kBS + c] * x[k * kBS + c];
-      for (int r = c + 1; r < kBS; r++) sacc = fma(D[c * kBS + r], x[k * kBS + r], sacc);
-      if ((cx.tid & 63) < kBS) x[k * kBS + c] = sacc;
-    }
-    VIO_SYNC();
-#endif
-    VIO_PARFOR(q, k * kBS) {  // y_j -= L_kj^T x_k for j < k
+    for (int q = 0; q < k * kBS; q++) {  // y_j -= L_kj^T x_k for j < k
       int j = q / kBS, c = q % kBS;
       auto Lkj = w.Hm + blk_off(k, j);
       double s = 0;
-#pragma unroll
       for (int m = 0; m < kBS; m++) s += Lkj[m * kBS + c] * x[k * kBS + m];
       x[j * kBS + c] -= s;
     }
+  }
+#else
+  const int wave = cx.tid >> 6, lane = cx.tid & 63;
+  auto solve_diag = [&](int k) {  // x_k <- L_kk^-T x_k, lanes 0..14 of the calling wave
+    auto D = w.Hm + blk_off(k, k);
+    const int c = lane < kBS ? lane : 0;
+    double sacc = w.ldinv[k * kBS + c] * x[k * kBS + c];
+#pragma unroll
+    for (int r = 1; r < kBS; r++) {
+      const int rr = c + r < kBS ? c + r : c;
+      const double lv = D[c * kBS + rr], xv = x[k * kBS + rr];
+      sacc = fma(c + r < kBS ? lv : 0.0, xv, sacc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kBS) x[k * kBS + c] = sacc;
+  };
+  auto apply = [&](int k, int j, int c) {  // y_j[c] -= (L_kj^T x_k)[c]
+    auto Lkj = w.Hm + blk_off(k, j);
+    double sacc = 0;
+#pragma unroll
+    for (int m = 0; m < kBS; m++) sacc = fma(Lkj[m * kBS + c], x[k * kBS + m], sacc);
+    x[j * kBS + c] -= sacc;
+  };
+  if (wave == 0) solve_diag(nb - 1);
+  VIO_SYNC();
+  for (int k = nb - 1; k >= 1; k--) {
+    if (wave == 0) {
+      if (lane < kBS) apply(k, k - 1, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      solve_diag(k - 1);
+    } else {
+      for (int q = (int)cx.tid - 64; q < (k - 1) * kBS; q += (int)cx.nt - 64) apply(k, q / kBS, q % kBS);
+    }
     VIO_SYNC();
   }
+#endif
 }
 
-// q(v) = v^T (S H S + mu D^2) v through the factorization: sum_f e_f (v_f + ws_f^T v_p / e_f)^2 + |L^T v_p|^2
+// q(v) = v^T (S H S + mu D^2) v through the factorization: sum_f e_f (v_f + ws_f^T v_p / e_f)^2 + |L^T v_p|^2.
+// Both mat-vecs are split into many short items that add into LDS accumulators: w.tf (F) and w.t1 (np) are free at
+// both call sites (the back-substitution has consumed them; the next build_reduced_system rewrites them).
 template <class WK>
 VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf) {
-  const int np = v.np, F = v.F;
-  double acc = 0;
-  VIO_PARFOR(f, F) {
+  const int np = v.np, F = v.F, n6 = v.npose6;
+  VIO_PARFOR(f, F) w.tf[f] = 0.0;
+  VIO_PARFOR(j, v.nblk * kBS) w.t1[j] = 0.0;
+  VIO_SYNC();
+  int nparts = (int)cx.nt / (F > 0 ? F : 1);
+  nparts = nparts < 1 ? 1 : (nparts > 6 ? 6 : nparts);
+  const int per = (n6 + nparts - 1) / nparts;
+  VIO_PARFOR(q, F * nparts) {  // u_f += sum_{a in part} WT[a][f] vp[a]
+    const int part = q / F, f = q - part * F;
+    const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
+    const double *wt = v.WT + f;
     double s = 0;
-#pragma unroll 6
-    for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * vp[kBS * (a / 6) + a % 6];
-    double u = vf[f] + s / w.ef[f];
-    acc += w.ef[f] * u * u;
+#pragma unroll 8
+    for (int a = a0; a < a1; a++) s += wt[(size_t)a * v.Fpad] * vp[kBS * (a / 6) + a % 6];
+    VIO_ATOMIC_ADD(w.tf + f, s);
   }
   stamp(cx, ST_X3);
-  VIO_PARFOR(j, np) {
-    // (L^T v)_j = sum_{i >= j} L[i][j] v_i
-    int bj = j / kBS, cj = j % kBS;
+  const int nblocks = v.nblk * (v.nblk + 1) / 2;
+  VIO_PARFOR(q, nblocks * kBS) {  // (L^T v)_j += sum_r L_(bi,bj)[r][c] v[15 bi + r]
+    const int blk = q / kBS, c = q - blk * kBS;
+    const int bij = w.blk_ij[blk], bi = bij >> 8, bj = bij & 255;
+    auto B = w.Hm + (size_t)blk * kBB;
     double s = 0;
-    auto D = w.Hm + blk_off(bj, bj);
-    for (int r = cj; r < kBS; r++) {
-      int i = bj * kBS + r;
-      if (i < np) s += D[r * kBS + cj] * vp[i];
+#pragma unroll
+    for (int r = 0; r < kBS; r++) {
+      const int i = bi * kBS + r;
+      // diagonal blocks keep L^-1 above the diagonal (cholesky_blocks): only r >= c belongs to L
+      if (i < np && (bi != bj || r >= c)) s += B[r * kBS + c] * vp[i];
     }
-    for (int bi = bj + 1; bi < v.nblk; bi++) {
-      auto B = w.Hm + blk_off(bi, bj);
-      for (int r = 0; r < kBS; r++) {
-        int i = bi * kBS + r;
-        if (i < np) s += B[r * kBS + cj] * vp[i];
-      }
-    }
-    acc += s * s;
+    VIO_ATOMIC_ADD(w.t1 + bj * kBS + c, s);
   }
+  VIO_SYNC();
+  double acc = 0;
+  VIO_PARFOR(f, F) {
+    double u = vf[f] + w.tf[f] / w.ef[f];
+    acc += w.ef[f] * u * u;
+  }
+  VIO_PARFOR(j, np) acc += w.t1[j] * w.t1[j];
   return block_sum(cx, acc);
 }
 
@@ -1682,7 +1793,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
     cx.prof[ST_TOTAL] = -cx.prof[ST_COUNT - 1];
   }
 #endif
-  setup_imu_info(cx, v);
+  setup_imu_info(cx, v, w.Hm);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, v, w);
   stamp(cx, ST_SETUP_PRIOR);
