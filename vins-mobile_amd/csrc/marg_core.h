@@ -129,11 +129,16 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       else if (kind == 1) m.col_sb[idx] = -2;
       else m.col_ex[0] = -2;
     }
-    if (flag == 0) {
-      m.col_pose[0] = m.col_sb[0] = m.col_pose[1] = m.col_sb[1] = -2;
-      for (int k = 0; k < v.M; k++)
-        if (v.fhost[k] == 0 && v.ftarget[k] != P) m.col_pose[v.ftarget[k]] = -2, m.col_ex[0] = -2;
-    }
+    if (flag == 0) m.col_pose[0] = m.col_sb[0] = m.col_pose[1] = m.col_sb[1] = -2;
+  }
+  VIO_SYNC();
+  if (flag == 0) {
+    // frames seen from frame 0: the (host 0, target t) buckets of the factor list (all writers store the same value)
+    VIO_PARFOR(p, v.npairs)
+      if (v.pair_h[p] == 0 && v.pair_t[p] != P) m.col_pose[v.pair_t[p]] = -2, m.col_ex[0] = -2;
+  }
+  VIO_SYNC();
+  if (cx.tid == 0) {
     int pos = 0, nblocks = 0;
     // dropped
     if (flag == 0) {
@@ -215,6 +220,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     }
     VIO_SYNC();
   }
+  stamp(cx, ST_X8);
   if (flag == 0) {
     // ---- IMUFactor(pre_integrations[1]) on (pose0, sb0, pose1, sb1) ------------------------------------
     if (cx.tid == 0)
@@ -249,6 +255,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       for (int k = 0; k < 15; k++) s += v.imu_J[k * 30 + a] * v.imu_Mr[k];
       VIO_ATOMIC_ADD(m.bm + ca, s);
     }
+    stamp(cx, ST_X9);
     // ---- projections hosted at frame 0: blocks (pose0, pose_t, extrinsic, feature), Cauchy-corrected
     //      (ResidualBlockInfo::Evaluate, marginalization_factor.cpp:45-76, rho'' < 0 branch).
     //      Same scheme as the solver: rows staged in (0,t)-bucket order, one Gram product per bucket on the matrix
@@ -300,6 +307,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
           v.WT[(6 * t + c) * v.Fpad + f] = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
       }
       VIO_SYNC();
+      stamp(cx, ST_X10);
       // one element of the three Gram matrices of bucket (0, t)
       auto flush1 = [&](int t, int row, int col, double val) {  // G1^T G1
         const int c0p = m.col_pose[0], ctp = m.col_pose[t];
@@ -367,6 +375,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
         }
       }
 #endif
+      stamp(cx, ST_X11);
       // per-feature sums: host coupling, extrinsic coupling, H_ff, g_f
       VIO_PARFOR(f, F) {
         double w0[6] = {0, 0, 0, 0, 0, 0}, wx[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;
@@ -479,27 +488,39 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   // ---- Cholesky with pivot cut, b carried along (forward substitution) --------------------------------
   VIO_PARFOR(j, pos) m.tol[j] = fmax(1e-8, 1e-12 * m.Am[j * ld + j]);
   VIO_SYNC();
+  // Right-looking, ONE barrier per column: column j stays unscaled in place while the trailing update uses
+  // A_ij A_kj / piv; the scaling L_ij = A_ij / sqrt(piv) happens once at the end. A cut pivot zeroes its column.
   for (int j = 0; j < pos; j++) {
-    double piv = m.Am[j * ld + j];
-    bool skip = !(piv > m.tol[j]);
-    double d = skip ? 0.0 : sqrt(piv);
-    double inv = skip ? 0.0 : 1.0 / d;
-    double yj = m.bm[j] * inv;
-    VIO_SYNC();  // everyone has read the pivot and b_j before they are overwritten
-    VIO_PARFOR(i, pos - j) {
-      int r = j + i;
-      if (i == 0) m.Am[j * ld + j] = d, m.bm[j] = yj;
-      else m.Am[r * ld + j] *= inv;
-    }
-    VIO_SYNC();
+    const double piv = m.Am[j * ld + j];
+    const bool skip = !(piv > m.tol[j]);
+    const double ip = skip ? 0.0 : 1.0 / piv;
+    const double bj = m.bm[j];
     const int rem = pos - j - 1;
-    VIO_PARFOR(q, rem * rem) {
-      int i = j + 1 + q / rem, k = j + 1 + q % rem;
-      if (k <= i) m.Am[i * ld + k] -= m.Am[i * ld + j] * m.Am[k * ld + j];
+    const int rl = cx.nt >= 32 ? 32 : (int)cx.nt, nrow = (int)cx.nt / rl;  // 32 lanes walk one row
+    const int lane_k = (int)cx.tid % rl;
+    for (int i = j + 1 + (int)cx.tid / rl; i < pos; i += nrow) {
+      const double lij = m.Am[i * ld + j] * ip;
+      for (int k = j + 1 + lane_k; k <= i; k += rl) m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
+      if (lane_k == 0) m.bm[i] -= lij * bj;
     }
-    VIO_PARFOR(i, rem) m.bm[j + 1 + i] -= m.Am[(j + 1 + i) * ld + j] * yj;
+    (void)rem;
     VIO_SYNC();
   }
+  // pass 1: 1/sqrt(piv) per column into tol (no longer needed as a threshold), pass 2: scale
+  VIO_PARFOR(j, pos) {
+    const double piv = m.Am[j * ld + j];
+    const bool skip = !(piv > m.tol[j]);
+    m.tol[j] = skip ? 0.0 : 1.0 / sqrt(piv);
+  }
+  VIO_SYNC();
+  VIO_PARFOR(q, pos * pos) {
+    int i = q / pos, j = q - i * pos;
+    if (j > i) continue;
+    const double inv = m.tol[j];
+    m.Am[i * ld + j] = (i == j) ? (inv > 0.0 ? sqrt(m.Am[i * ld + j]) : 0.0) : m.Am[i * ld + j] * inv;
+  }
+  VIO_PARFOR(j, pos) m.bm[j] *= m.tol[j];
+  VIO_SYNC();
   // ---- outputs: J0 = L'^T (upper triangular), r0 = y' ---------------------------------------------------
   VIO_PARFOR(q, n * n) {
     int r = q / n, c = q % n;

@@ -702,9 +702,9 @@ VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
     E[r] = (m == n) ? 1.0 : 0.0;
   }
   bool good = true;
+  double dcc = lane_bcast(A[0], 0);
 #pragma unroll
   for (int c = 0; c < kBS; c++) {
-    const double dcc = lane_bcast(A[c >> 2], 16 * (c & 3) + c);
     good = good && (dcc > 0.0);
     double d, inv;
     sqrt_rsqrt(dcc, d, inv);
@@ -714,6 +714,13 @@ VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
     if (sel && n == c) a = d;
     if (sel && n < kBS) D[n * kBS + c] = (n >= c) ? a : e;
     if (sel && n == c) ldinv_k[c] = inv;
+    if (c + 1 < kBS) {
+      // the next pivot D[c+1][c+1] - l[c+1]^2 is formed ahead of the matrix instruction, so its rsqrt chain runs in
+      // the shadow of the two v_mfma instead of behind them
+      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
+      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
+      dcc = fma(-lnext, lnext, dold);
+    }
     A = mfma_f64(-a, a, A);
     E = mfma_f64(-a, e, E);
   }
@@ -1115,6 +1122,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 template <class WK>
 VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu, bool &wt_scaled) {
   const int np = v.np, F = v.F;
+  stamp(cx, ST_X6);
   VIO_PARFOR(f, F) {
     double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
     double ei = 1.0 / e;
@@ -1142,6 +1150,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     }
     wt_scaled = true;
   }
+  stamp(cx, ST_X7);
   const int nblocks = v.nblk * (v.nblk + 1) / 2;
   VIO_PARFOR(q, nblocks * kBB) {
     int blk = q / kBB, e = q - blk * kBB, r = e / kBS, c = e - r * kBS;
@@ -1273,6 +1282,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
         bool good = potrf15_inv_wave(Dn, w.ldinv + (k + 1) * kBS, lane);
         if (!good && lane == 0) w.flag[1] = 1;
       }
+      stamp(cx, ST_X5);
     } else {
       const int stride = nw - 1;
       for (int pr = wave; pr < npairs; pr += 2 * stride) {
