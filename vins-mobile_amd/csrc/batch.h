@@ -178,6 +178,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   ldsd tf = take(F), prdx = take(d.Ncap), prr = take(d.Ncap);
   ldsd prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
   ldsd flag = take(2);
+  ldsd ppd = take(36 * (size_t)(d.Pcap + 1));
   if (w) {
     w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
@@ -186,6 +187,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
     w->blk_ij = reinterpret_cast<ldsi>(blk);
     w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
     w->prcol = reinterpret_cast<ldsi>(prcol), w->flag = reinterpret_cast<ldsi>(flag);
+    w->ppd = ppd;
   }
   if (cx) cx->red = red;
   return o * sizeof(double);
@@ -229,8 +231,8 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
     if (t == P) has_loop = 1;
   }
   {
-    // Device-side accumulation layout: factors bucketed by (host, target) pair, each bucket padded to an even number
-    // of slots (one MFMA step consumes two factors = four Jacobian rows), plus the factor range of every feature.
+    // Device-side accumulation layout: factors bucketed by (host, target) pair, each bucket starting on an even slot
+    // (one MFMA step consumes two factors = four Jacobian rows; an odd tail is masked, never read), plus the factor range of every feature.
     const int np1 = P + 1;
     std::vector<int> cnt((size_t)np1 * np1, 0), start((size_t)np1 * np1, 0), fill((size_t)np1 * np1, 0);
     for (int k = 0; k < M; k++) cnt[(size_t)w.factor_host[k] * np1 + w.factor_target[k]]++;
@@ -243,8 +245,8 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
         start[(size_t)hh * np1 + tt] = slot;
         hb.pair_h[b * s.pair + npairs] = hh, hb.pair_t[b * s.pair + npairs] = tt;
         hb.pair_s0[b * s.pair + npairs] = slot;
+        hb.pair_s1[b * s.pair + npairs] = slot + c;  // real end; the next bucket starts on an even slot
         slot += (c + 1) & ~1;
-        hb.pair_s1[b * s.pair + npairs] = slot;
         npairs++;
       }
     for (int k = 0; k < M; k++) {

@@ -262,8 +262,8 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     //      cores: [Ji Jj r Jl]^T [Ji Jj r Jl], Jex^T [Ji Jj r Jl] and Jex^T Jex.
     const double cc = 1.0 / v.cauchy_b;
     int S0 = 0, nb0 = 0;  // buckets (0, t < P) come first in the (host, target) order
-    for (int p = 0; p < v.npairs; p++)
-      if (v.pair_h[p] == 0 && v.pair_t[p] != P) S0 = v.pair_s1[p], nb0 = p + 1;
+    for (int p = 0; p < v.npairs && v.pair_h[p] == 0; p++)
+      if (v.pair_t[p] != P) S0 = (v.pair_s1[p] + 1) & ~1, nb0 = p + 1;
     auto G = m.stage;
     const int CH = m.stage_slots;
     if (CH < 2) {  // launcher guarantees staging space; never loop forever on a bad carve
@@ -279,9 +279,6 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       else VIO_ATOMIC_ADD(m.Am + ca * ld + ra, val);
     };
     for (int c0 = 0; c0 < S0; c0 += CH) {
-      const int nsl = S0 - c0 < CH ? S0 - c0 : CH;
-      VIO_PARFOR(q, nsl * kMargSlot) G[q] = 0.0;
-      VIO_SYNC();
       VIO_PARFOR(k, v.M) {
         int t = v.ftarget[k], f = v.ffeat[k];
         if (v.fhost[k] != 0 || t == P) continue;
@@ -363,8 +360,9 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
           auto g = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
           auto gx = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
           for (int sl = s_lo; sl < s_hi; sl += 2, g += 2 * kMargSlot, gx += 2 * kMargSlot) {
-            double a = *g, x = *gx;
-            a = lv ? a : 0.0, x = lx ? x : 0.0;
+            const bool in = sl + (kq >> 1) < s_hi;  // odd tail: the second factor of the step does not exist
+            double a = G[in ? (int)(g - G) : 0], x = G[in ? (int)(gx - G) : 0];
+            a = (lv && in) ? a : 0.0, x = (lx && in) ? x : 0.0;
             a1 = mfma_f64(a, a, a1), a2 = mfma_f64(x, a, a2), a3 = mfma_f64(x, x, a3);
           }
           const int t = v.pair_t[p];

@@ -160,6 +160,7 @@ struct WorkT {
   ldsd prdx, prr;           // prior dx / residual: prior_n each
   ldsi prcol;               // prior column -> reduced parameter (-1 constant): prior_n
   ldsi flag;                // [4] block-uniform flags
+  ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
 };
 
 
@@ -762,13 +763,13 @@ constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 
 template <class WK>
 VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col, double val) {
   if (row < 6) {
-    if (col <= row) VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + h) * 36 + row * 6 + col, val);
+    if (col <= row) VIO_ATOMIC_ADD(w.ppd + h * 36 + row * 6 + col, val);
   } else if (row < 12) {
     if (col < 6) {
       if (t > h) VIO_ATOMIC_ADD(v.PP + (t * (t + 1) / 2 + h) * 36 + (row - 6) * 6 + col, val);
       else VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + t) * 36 + col * 6 + (row - 6), val);
     } else if (col < 12 && col <= row) {
-      VIO_ATOMIC_ADD(v.PP + (t * (t + 1) / 2 + t) * 36 + (row - 6) * 6 + (col - 6), val);
+      VIO_ATOMIC_ADD(w.ppd + t * 36 + (row - 6) * 6 + (col - 6), val);
     }
   } else if (row == 12) {
     if (col < 6) VIO_ATOMIC_ADD(w.gp + off_pose(v, h) + col, val);
@@ -794,9 +795,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   int fh = -1;
   const bool one_thread_per_feature = v.F <= (int)cx.nt;
   for (int c0 = 0; c0 < v.nslots; c0 += CH) {
-    const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
-    VIO_PARFOR(q, nsl * kSlotStride) G[q] = 0.0;
-    VIO_SYNC();
     stamp(cx, ST_P_ZERO);
     VIO_PARFOR(k, v.M) {
       const int slot = v.fslot[k] - c0;
@@ -845,27 +843,43 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     {
       const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
       const int li = lane & 15, kq = lane >> 4;
-      for (int p = wave; p < v.npairs; p += nw) {
-        int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+      // bucket descriptors of this wave's rounds, one round per lane (a dependent global load per round otherwise)
+      const int pl = wave + lane * nw;
+      const bool pv = pl < v.npairs;
+      const int m_s0 = pv ? v.pair_s0[pl] : 0, m_s1 = pv ? v.pair_s1[pl] : 0;
+      const int m_ht = pv ? (v.pair_h[pl] << 16) | v.pair_t[pl] : 0;
+      int round = 0;
+      for (int p = wave; p < v.npairs; p += nw, round++) {
+        const int rl = round & 63;
+        int b_s0 = __builtin_amdgcn_readlane(m_s0, rl), b_s1 = __builtin_amdgcn_readlane(m_s1, rl);
+        int b_ht = __builtin_amdgcn_readlane(m_ht, rl);
+        if (round >= 64) b_s0 = v.pair_s0[p], b_s1 = v.pair_s1[p], b_ht = (v.pair_h[p] << 16) | v.pair_t[p];
+        int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
         if (s_lo >= s_hi) continue;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const bool lv = li < kRowLen;  // operand columns 14, 15 of the 16-wide tile are zero
         auto g = G + (s_lo - c0 + (kq >> 1)) * kSlotStride + (kq & 1) * kRowLen + (lv ? li : 0);
         v4d acc2 = {0.0, 0.0, 0.0, 0.0};
-        int sl = s_lo;
-        for (; sl + 6 < s_hi; sl += 8, g += 8 * kSlotStride) {  // 4 steps per trip: loads first, two accumulators
+        int steps = (s_hi - s_lo) >> 1;  // full two-factor steps; an odd last factor is a masked half step
+        for (; steps >= 4; steps -= 4, g += 8 * kSlotStride) {  // 4 steps per trip: loads first, two accumulators
           double a0 = g[0], a1 = g[2 * kSlotStride], a2 = g[4 * kSlotStride], a3 = g[6 * kSlotStride];
           a0 = lv ? a0 : 0.0, a1 = lv ? a1 : 0.0, a2 = lv ? a2 : 0.0, a3 = lv ? a3 : 0.0;
           acc = mfma_f64(a0, a0, acc), acc2 = mfma_f64(a1, a1, acc2);
           acc = mfma_f64(a2, a2, acc), acc2 = mfma_f64(a3, a3, acc2);
         }
-        for (; sl < s_hi; sl += 2, g += 2 * kSlotStride) {
+        for (; steps > 0; steps--, g += 2 * kSlotStride) {
           double a = *g;
           a = lv ? a : 0.0;
           acc = mfma_f64(a, a, acc);
         }
+        if ((s_hi - s_lo) & 1) {  // lanes kq >= 2 would fetch the slot behind the bucket: never read, operand zero
+          const bool half = lv && kq < 2;
+          double a = G[half ? (int)(g - G) : 0];
+          a = half ? a : 0.0;
+          acc = mfma_f64(a, a, acc);
+        }
         acc += acc2;
-        const int h = v.pair_h[p], t = v.pair_t[p];
+        const int h = b_ht >> 16, t = b_ht & 0xffff;
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) gram_flush(v, w, h, t, kq + 4 * r4, li, acc[r4]);
       }
@@ -942,6 +956,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
     }
     VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;
+    VIO_PARFOR(q, nF * 36) w.ppd[q] = 0.0;
     VIO_SYNC();
     cost += projections_jac(cx, v, w, pose, feat, have_scale);
     stamp(cx, ST_EVAL_PROJ);
@@ -991,7 +1006,8 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       int a = 0;
       while ((a + 1) * (a + 2) / 2 <= blk) a++;
       int b = blk - a * (a + 1) / 2;
-      if (a != b || r >= c) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
+      if (a != b) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
+      else if (r >= c) *mat_at(w.Hm, kBS * a + r, kBS * a + c) += w.ppd[a * 36 + e];
     }
     VIO_SYNC();
   }
