@@ -690,7 +690,7 @@ VIO_DEV void mfma_block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool s
 // L^-1. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
 // triangle (D[n][c] = Linv[c][n], n < c), 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
 template <class MP>
-VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
+VIO_DEV bool potrf15_inv_wave(MP D, MP Lprev, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
 #pragma unroll
@@ -702,19 +702,28 @@ VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
     A[r] = ok ? x : 0.0;
     E[r] = (m == n) ? 1.0 : 0.0;
   }
-  bool good = true;
+  if (with_update) {  // look-ahead: D -= Lprev Lprev^T (the panel block left of D) without a trip through LDS
+    double l[4];
+    load_operand15(Lprev, lane, l);
+#pragma unroll
+    for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
+  }
+  // values this lane will store: pivot c = kq + 4 j lands in element j (L[n][c] for n >= c, Linv[c][n] for n < c)
+  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0, minpiv = 1.0;
   double dcc = lane_bcast(A[0], 0);
 #pragma unroll
   for (int c = 0; c < kBS; c++) {
-    good = good && (dcc > 0.0);
-    double d, inv;
-    sqrt_rsqrt(dcc, d, inv);
+    minpiv = fmin(minpiv, dcc > 0.0 ? dcc : -1.0);  // (a NaN pivot also lands on -1)
+    // 1 / sqrt(dcc): hardware seed (~single precision) + two Newton steps
+    double y = __builtin_amdgcn_rsq(dcc);
+    const double h = 0.5 * dcc;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
     const bool sel = kq == (c & 3);
-    double a = sel ? A[c >> 2] * inv : 0.0;  // l[n] = L[n][c]
-    const double e = sel ? E[c >> 2] * inv : 0.0;  // Linv[c][n]
-    if (sel && n == c) a = d;
-    if (sel && n < kBS) D[n * kBS + c] = (n >= c) ? a : e;
-    if (sel && n == c) ldinv_k[c] = inv;
+    const double a = sel ? A[c >> 2] * y : 0.0;  // l[n] = L[n][c]  (n == c: dcc / sqrt(dcc))
+    const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
+    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+    myinv = (n == c) ? y : myinv;
     if (c + 1 < kBS) {
       // the next pivot D[c+1][c+1] - l[c+1]^2 is formed ahead of the matrix instruction, so its rsqrt chain runs in
       // the shadow of the two v_mfma instead of behind them
@@ -725,7 +734,15 @@ VIO_DEV bool potrf15_inv_wave(MP D, ldsd ldinv_k, int lane) {
     A = mfma_f64(-a, a, A);
     E = mfma_f64(-a, e, E);
   }
-  return good;
+  if (n < kBS) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = kq + 4 * j;
+      if (c < kBS) D[n * kBS + c] = keep[j];
+    }
+    if (kq == 0) ldinv_k[n] = myinv;
+  }
+  return minpiv > 0.0;
 }
 
 // TRSM on the matrix cores: A_ik <- A_ik L_kk^-T with the inverse left behind by potrf15_inv_wave.
@@ -1261,7 +1278,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
   const int nb = v.nblk;
   const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
   if (wave == 0) {
-    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.ldinv, lane);
+    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
     if (!good && lane == 0) w.flag[1] = 1;
   }
   VIO_SYNC();
@@ -1275,7 +1292,13 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
     if (wave == nw - 1) {
       const int nn = lane < kBS ? lane : 0;
       double sacc = w.ldinv[k * kBS + nn] * rhs[k * kBS + nn];
-      for (int kk = 0; kk < nn; kk++) sacc = fma(D[kk * kBS + nn], rhs[k * kBS + kk], sacc);
+#pragma unroll
+      for (int kk = 0; kk < kBS - 1; kk++) {  // unrolled and predicated: the 28 LDS loads are all in flight at once
+        const bool in = kk < nn;
+        const double lv = D[(in ? kk : 0) * kBS + nn], xv = rhs[k * kBS + (in ? kk : 0)];
+        sacc = fma(in ? lv : 0.0, xv, sacc);
+      }
+      __builtin_amdgcn_wave_barrier();
       if (lane < kBS) rhs[k * kBS + lane] = sacc;  // (all loads of the wave precede this store)
     }
     VIO_SYNC();
@@ -1294,8 +1317,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
     if (wave == 0) {
       if (ntb > 0) {
         auto Dn = w.Hm + blk_off(k + 1, k + 1), Ln = w.Hm + blk_off(k + 1, k);
-        mfma_block_update(Dn, Ln, Ln, lane);
-        bool good = potrf15_inv_wave(Dn, w.ldinv + (k + 1) * kBS, lane);
+        bool good = potrf15_inv_wave(Dn, Ln, true, w.ldinv + (k + 1) * kBS, lane);
         if (!good && lane == 0) w.flag[1] = 1;
       }
       stamp(cx, ST_X5);
