@@ -180,6 +180,7 @@ def cpu_baseline(cfg, abi, stream, uniq_windows):
     kind = "reference" if ref is not None else "port"
     solve = abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
     devnull = os.open(os.devnull, os.O_WRONLY)
+    sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference printf()s from marginalization
     try:
@@ -191,6 +192,7 @@ def cpu_baseline(cfg, abi, stream, uniq_windows):
             n_s += 1
         t_solve = (time.perf_counter() - t0) / n_s
     finally:
+        C.CDLL(None).fflush(None)  # the reference's printf()s sit in C stdio's buffer: drain them into /dev/null too
         os.dup2(saved, 1)
         os.close(devnull)
     return {"value": 1.0 / (t_fe + t_solve), "unit": "frames/s", "cores": 1,

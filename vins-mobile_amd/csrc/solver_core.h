@@ -1218,6 +1218,59 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     const int wave = cx.tid >> 6, lane = cx.tid & 63, nw = cx.nt >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int ksteps = (F + 3) / 4;
+    constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
+    if (T <= kT) {
+      // K-split: every wave owns a slice of the features and forms ALL lower tiles from it. A and B operands are the
+      // same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one latency) feeding
+      // 75 matrix instructions; the 8 partial results meet in the matrix through LDS atomics.
+      const int ksw = (ksteps + nw - 1) / nw;
+      const int s_begin = wave * ksw, s_end = s_begin + ksw < ksteps ? s_begin + ksw : ksteps;
+      v4d acc[kT * (kT + 1) / 2];
+#pragma unroll
+      for (int q = 0; q < kT * (kT + 1) / 2; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int s0 = s_begin; s0 < s_end; s0 += 5) {
+        double wv[5][kT], ev[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int f = 4 * (s0 + j) + kq;
+          const int fc = (s0 + j < s_end && f < F) ? f : 0;
+          ev[j] = w.einv[fc];
+#pragma unroll
+          for (int t = 0; t < kT; t++) {
+            const int col = 16 * t + li;
+            wv[j][t] = v.WTf[(size_t)fc * v.n6cap + (col < n6 ? col : 0)];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int f = 4 * (s0 + j) + kq;
+          const bool vf = s0 + j < s_end && f < F;
+#pragma unroll
+          for (int t = 0; t < kT; t++) wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
+#pragma unroll
+          for (int ti = 0; ti < kT; ti++) {
+            const double a = wv[j][ti] * ev[j];
+#pragma unroll
+            for (int tj = 0; tj <= ti; tj++) acc[ti * (ti + 1) / 2 + tj] = mfma_f64(a, wv[j][tj], acc[ti * (ti + 1) / 2 + tj]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < kT; ti++)
+#pragma unroll
+        for (int tj = 0; tj <= ti; tj++) {
+          const int bcol = 16 * tj + li;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int arow = 16 * ti + kq + 4 * r;
+            if (arow < n6 && bcol < n6) {
+              const int i = kBS * (arow / 6) + arow % 6, j = kBS * (bcol / 6) + bcol % 6;
+              if (i >= j) VIO_ATOMIC_ADD(mat_at(w.Hm, i, j), -acc[ti * (ti + 1) / 2 + tj][r]);
+            }
+          }
+        }
+    } else
     for (int p = wave; p < npairs; p += nw) {
       int ti = 0;
       while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
@@ -1225,16 +1278,29 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
       const int ra = 16 * ti + li, rb = 16 * tj + li;
       const bool va = ra < n6, vb = rb < n6;
       const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-      for (int s = 0; s < ksteps; s++) {
-        int f = 4 * s + kq;
-        bool vf = f < F;
-        int fc = vf ? f : 0;
-        double a = pa[(size_t)fc * v.n6cap] * w.einv[fc], b = pb[(size_t)fc * v.n6cap];
-        a = (va && vf) ? a : 0.0, b = (vb && vf) ? b : 0.0;
-        acc = mfma_f64(a, b, acc);
+      v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
+      for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
+        double av[kChunk], bv[kChunk], ev[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
+          const int f = 4 * (s0 + j) + kq;
+          const int fc = (f < F && s0 + j < ksteps) ? f : 0;
+          av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
+        }
+#ifndef VIO_EMUL
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+          const int f = 4 * (s0 + j) + kq;
+          const bool vf = f < F && s0 + j < ksteps;
+          av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
       }
+      acc += acc1;
       const int bcol = 16 * tj + li;
 #pragma unroll
       for (int r = 0; r < 4; r++) {

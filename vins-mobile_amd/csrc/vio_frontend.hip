@@ -989,7 +989,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // == repeat { take the best alive candidate; kill everything closer than min_dist }. Then addPoints / updateID /
 // image_msg and the end-of-publish copies (feature_tracker.cpp:271-307).
 __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned long long *cand_base, int seg_cap, int nseg,
-                                                                    const int *n_cand, const unsigned *max_bits,
+                                                                    int *n_cand, unsigned *max_bits,
                                                                     double quality, SelectParams P, float *forw_pts,
                                                                     float *cur_pts, float *pre_pts, int *ids, int *track_cnt,
                                                                     int *n_forw, int *n_pts, int *n_id, VioObs *obs,
@@ -1023,6 +1023,8 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
     }
   }
   __syncthreads();
+  // this kernel is the only consumer of the per-segment counters: leave them zeroed for the next detection pass
+  for (int g = tid; g < nseg; g += nt) n_cand[(size_t)seq * nseg + g] = 0, max_bits[(size_t)seq * nseg + g] = 0;
   const bool in_lds = s_cnt <= kSelLds;
   unsigned long long *K = in_lds ? keys : cand;
   const int nc = in_lds ? s_cnt : total;
@@ -1125,6 +1127,7 @@ struct vio_frontend {
       *n_kept = nullptr, *hw = nullptr, *n_obs = nullptr;
   uint8_t *lk_status = nullptr;
   VioObs *obs = nullptr;
+  bool attr_set = false;
   // resident frames (throughput runs)
   uint8_t *frames = nullptr;
   int n_frames = 0;
@@ -1138,13 +1141,35 @@ struct vio_frontend {
 
 namespace {
 
+// forw_img = _img for every sequence: packed frames -> level 0 of each sequence's pyramid (16 B per thread when the
+// layout allows it; the runtime's rectangular copy reaches ~140 GB/s on this shape).
+__global__ __launch_bounds__(256) void copy_frames_kernel(const uint8_t *src, size_t src_stride, uint8_t *dst,
+                                                          size_t dst_stride, size_t bytes, int vec_ok) {
+  const int seq = blockIdx.y;
+  const uint8_t *sp = src + (size_t)seq * src_stride;
+  uint8_t *dp = dst + (size_t)seq * dst_stride;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec_ok) {
+    if (i * 16 < bytes) reinterpret_cast<uint4 *>(dp)[i] = reinterpret_cast<const uint4 *>(sp)[i];
+  } else {
+    const size_t b0 = i * 16, b1 = b0 + 16 < bytes ? b0 + 16 : bytes;
+    for (size_t b = b0; b < b1; b++) dp[b] = sp[b];
+  }
+}
+
 int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on device */, int publish, hipStream_t st) {
   const int S = fe->n_seq, rows = fe->cfg.image_rows, cols = fe->cfg.image_cols, cap = fe->cap;
   const size_t img_bytes = (size_t)rows * cols;
   // forw_img = _img : level 0 of the forw pyramid
   const int fidx = fe->have_img ? 1 - fe->cur_idx : fe->cur_idx;
   uint8_t *forw = fe->pyr[fidx];
-  HIP_OK(hipMemcpy2DAsync(forw, fe->ld.pyr_bytes, d_frames, img_bytes, img_bytes, S, hipMemcpyDeviceToDevice, st));
+  {
+    const int vec_ok = img_bytes % 16 == 0 && fe->ld.pyr_bytes % 16 == 0 && (uintptr_t)d_frames % 16 == 0 &&
+                       (uintptr_t)forw % 16 == 0;
+    dim3 grd((unsigned)((img_bytes + 16 * 256 - 1) / (16 * 256)), S);
+    hipLaunchKernelGGL(copy_frames_kernel, grd, dim3(256), 0, st, d_frames, img_bytes, forw, fe->ld.pyr_bytes, img_bytes,
+                       vec_ok);
+  }
   for (int l = 1; l < fe->ld.levels; l++) {
     dim3 blk(256), grd((fe->ld.cols[l] + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, S);
     hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, forw + fe->ld.off[l - 1], forw + fe->ld.off[l], fe->ld.pyr_bytes,
@@ -1170,11 +1195,12 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   A.n_kept = fe->n_kept, A.hw = fe->hw, A.radius = fe->cfg.min_dist, A.f_thresh = (float)fe->cfg.f_threshold;
   A.f_conf = fe->cfg.f_confidence;
   const size_t shm = ((sizeof(TrackShared) + 15) & ~(size_t)15) + sizeof(RansacShared);
-  HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  if (!fe->attr_set) {
+    HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    fe->attr_set = true;
+  }
   hipLaunchKernelGGL(track_update_kernel, dim3(S), dim3(256), shm, st, A, publish);
   if (publish) {
-    HIP_OK(hipMemsetAsync(fe->max_bits, 0, sizeof(unsigned) * S * fe->nseg, st));
-    HIP_OK(hipMemsetAsync(fe->n_cand, 0, sizeof(int) * S * fe->nseg, st));
     dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, fe->nseg, S);
     hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
                        fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
@@ -1249,6 +1275,8 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
     std::vector<int> hw;
     circle_halfwidths(cfg->min_dist, hw);
     bool ok = hipMemcpy(fe->hw, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(fe->max_bits, 0, sizeof(unsigned) * S * fe->nseg) == hipSuccess;
+    ok = ok && hipMemset(fe->n_cand, 0, sizeof(int) * S * fe->nseg) == hipSuccess;
     ok = ok && hipMemset(fe->n_pts, 0, sizeof(int) * S) == hipSuccess;
     ok = ok && hipMemset(fe->n_forw, 0, sizeof(int) * S) == hipSuccess;
     ok = ok && hipMemset(fe->n_id, 0, sizeof(int) * S) == hipSuccess;
