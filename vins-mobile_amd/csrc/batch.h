@@ -165,7 +165,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
   ldsd xpose = take(7 * (size_t)(d.Pcap + 1)), xsb = take(9 * (size_t)d.Pcap), xfeat = take(F);
   ldsd ex = take(8);
-  ldsd red = take(3 * ((size_t)nthreads / 64) + 2);
+  ldsd red = take(6 * ((size_t)nthreads / 64) + 2);
   if (state_end_doubles) *state_end_doubles = o;
   ldsd hm = nullptr;
   if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);

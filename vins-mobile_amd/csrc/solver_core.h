@@ -82,7 +82,8 @@ enum Stage {
 
 struct Ctx {
   int tid, nt;
-  ldsd red;           // LDS scratch for block reductions: [3 nt/64 + 2]
+  ldsd red;           // LDS scratch for block reductions: two halves of [3 nt/64]
+  mutable int red_phase = 0;  // which half the next reduction writes (uniform across the block)
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
 };
 
@@ -174,51 +175,79 @@ VIO_DEV MP mat_at(MP Hm, int i, int j) {
   return Hm + blk_off(bi, bj) + (i - bi * kBS) * kBS + (j - bj * kBS);
 }
 
-// ---- block reduction: every thread receives the same sum (fixed order => deterministic) -------------
+// ---- block reductions: every thread receives the same value ------------------------------------------------------
+// Wave level on the DPP network (row_shr 1/2/4/8, row_bcast 15/31; total in lane 63, broadcast through SGPRs), block
+// level through cx.red. Two alternating halves of cx.red make ONE barrier per reduction enough: a half is rewritten
+// two calls later, and the barrier of the call in between orders that against its last readers.
+#ifndef VIO_EMUL
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_move_f64<0x111, 0xf>(v);
+  v += dpp_move_f64<0x112, 0xf>(v);
+  v += dpp_move_f64<0x114, 0xf>(v);
+  v += dpp_move_f64<0x118, 0xf>(v);
+  v += dpp_move_f64<0x142, 0xa>(v);
+  v += dpp_move_f64<0x143, 0xc>(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {  // operands >= 0 (norms, flags): a shifted-in 0 is neutral
+  v = fmax(v, dpp_move_f64<0x111, 0xf>(v));
+  v = fmax(v, dpp_move_f64<0x112, 0xf>(v));
+  v = fmax(v, dpp_move_f64<0x114, 0xf>(v));
+  v = fmax(v, dpp_move_f64<0x118, 0xf>(v));
+  v = fmax(v, dpp_move_f64<0x142, 0xa>(v));
+  v = fmax(v, dpp_move_f64<0x143, 0xc>(v));
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+#endif
 VIO_DEV double block_sum(const Ctx &cx, double v) {
 #ifdef VIO_EMUL
   return v;
 #else
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  VIO_SYNC();  // protects cx.red against the previous reduction's readers
-  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = v;
+  const int nw = cx.nt >> 6;
+  ldsd red = cx.red + (cx.red_phase ^= 1) * 3 * nw;
+  v = wave_sum_f64(v);
+  if ((cx.tid & 63) == 0) red[cx.tid >> 6] = v;
   VIO_SYNC();
   double s = 0;
-  for (int w = 0; w < (cx.nt >> 6); w++) s += cx.red[w];
+  for (int w = 0; w < nw; w++) s += red[w];
   return s;
 #endif
 }
-// Three sums with one pair of barriers.
+// Three sums with one barrier.
 VIO_DEV void block_sum3(const Ctx &cx, double &a, double &b, double &c) {
 #ifndef VIO_EMUL
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64), b += __shfl_xor(b, o, 64), c += __shfl_xor(c, o, 64);
-  VIO_SYNC();
   const int nw = cx.nt >> 6;
-  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = a, cx.red[nw + (cx.tid >> 6)] = b, cx.red[2 * nw + (cx.tid >> 6)] = c;
+  ldsd red = cx.red + (cx.red_phase ^= 1) * 3 * nw;
+  a = wave_sum_f64(a), b = wave_sum_f64(b), c = wave_sum_f64(c);
+  if ((cx.tid & 63) == 0) red[cx.tid >> 6] = a, red[nw + (cx.tid >> 6)] = b, red[2 * nw + (cx.tid >> 6)] = c;
   VIO_SYNC();
   a = b = c = 0;
-  for (int w = 0; w < nw; w++) a += cx.red[w], b += cx.red[nw + w], c += cx.red[2 * nw + w];
+  for (int w = 0; w < nw; w++) a += red[w], b += red[nw + w], c += red[2 * nw + w];
 #else
   (void)cx, (void)a, (void)b, (void)c;
 #endif
 }
+// Maximum of non-negative values.
 VIO_DEV double block_max(const Ctx &cx, double v) {
 #ifdef VIO_EMUL
   return v;
 #else
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  const int nw = cx.nt >> 6;
+  ldsd red = cx.red + (cx.red_phase ^= 1) * 3 * nw;
+  v = wave_max_f64(v);
+  if ((cx.tid & 63) == 0) red[cx.tid >> 6] = v;
   VIO_SYNC();
-  if ((cx.tid & 63) == 0) cx.red[cx.tid >> 6] = v;
-  VIO_SYNC();
-  double s = cx.red[0];
-  for (int w = 1; w < (cx.nt >> 6); w++) s = fmax(s, cx.red[w]);
+  double s = red[0];
+  for (int w = 1; w < nw; w++) s = fmax(s, red[w]);
   return s;
 #endif
 }
-
-// =====================================================================================================
-// Factors
-// =====================================================================================================
 
 // ProjectionFactor::Evaluate (projection_facor.cpp:16-99) in local coordinates. Jex optional.
 template <class PA, class PE>
@@ -801,7 +830,7 @@ VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col,
 // Per-feature sums (host coupling w_h, H_ff, g_f) are gathered by one thread per feature. Returns the cost partial.
 template <class WK>
 VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pose, cldsd feat,
-                               bool have_scale) {
+                               bool /*later_eval*/) {
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
   auto G = w.Hm;
@@ -832,11 +861,9 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
       }
       // target-frame coupling w_t = Jj^T Jl: one writer per (feature, frame)
-      const double sfv = have_scale ? w.sf[f] : 1.0;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         double val = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
-        if (have_scale) val *= w.sp[off_pose(v, t) + c] * sfv;
         v.WT[(6 * t + c) * v.Fpad + f] = val;
         v.WTf[f * v.n6cap + 6 * t + c] = val;
       }
@@ -929,10 +956,9 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         }
       } else if (h >= 0) {  // more features than threads: accumulate through memory (entries were zeroed)
         w.hff[f] += e, w.gf[f] += gf;
-        const double sfv = have_scale ? w.sf[f] : 1.0;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-          double val = have_scale ? wh[c] * w.sp[off_pose(v, h) + c] * sfv : wh[c];
+          double val = wh[c];
           v.WT[(6 * h + c) * v.Fpad + f] += val;
           v.WTf[f * v.n6cap + 6 * h + c] += val;
         }
@@ -945,10 +971,9 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     const int f = cx.tid;
     w.hff[f] = fe, w.gf[f] = fgf;
     if (fh >= 0) {
-      const double sfv = have_scale ? w.sf[f] : 1.0;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        double val = have_scale ? fwh[c] * w.sp[off_pose(v, fh) + c] * sfv : fwh[c];
+        double val = fwh[c];
         v.WT[(6 * fh + c) * v.Fpad + f] = val;
         v.WTf[f * v.n6cap + 6 * fh + c] = val;
       }
@@ -1153,52 +1178,32 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 // sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
 // Returns false if some e_f <= 0.
 template <class WK>
-VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu, bool &wt_scaled) {
+VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu) {
   const int np = v.np, F = v.F;
   stamp(cx, ST_X6);
+  // Ceres solves (S H S + mu D^2) y = S g with the Jacobi scaling S and D^2 = clamp(diag(S H S)). The same system in
+  // unscaled unknowns z = S y is (H + mu C) z = g with C = D^2 / S^2 (diagonal): no scaling pass over the matrix or
+  // over the landmark coupling W is needed, and y = z / s at the end. (Cholesky is invariant under this diagonal
+  // congruence up to rounding; a non-positive pivot appears in both forms or in neither.)
   VIO_PARFOR(f, F) {
-    double e = w.sf[f] * w.sf[f] * w.hff[f] + mu * w.df[f] * w.df[f];
-    double ei = 1.0 / e;
+    const double c = w.df[f] / w.sf[f];
+    const double e = w.hff[f] + mu * c * c;  // E_f
+    const double ei = 1.0 / e;
     w.ef[f] = e;
     w.einv[f] = ei;
-    w.tf[f] = w.sf[f] * w.gf[f] * ei;  // gs_f / e_f
+    w.tf[f] = w.gf[f] * ei;  // g_f / E_f
     if (!(e > 0.0)) w.flag[0] = 1;
   }
-  // scale the landmark coupling in place (both layouts): ws[a][f] = WT[a][f] sp[par(a)] sf[f]. Only after the very
-  // first evaluation: once the Jacobi scaling is known the factors write scaled values directly.
-  if (!wt_scaled) {
-    VIO_PARFOR(q, v.npose6 * v.Fpad) {
-      int a = q / v.Fpad, f = q - a * v.Fpad;
-      if (f < F) {
-        int fr = a / 6, c = a - 6 * fr;
-        v.WT[q] *= w.sp[kBS * fr + c] * w.sf[f];
-      }
+  VIO_PARFOR(i, v.nblk * kBS) {
+    if (i < np) {
+      const double c = w.dp[i] / w.sp[i];
+      *mat_at(w.Hm, i, i) += mu * c * c;
+      w.t1[i] = w.gp[i];
+    } else {
+      *mat_at(w.Hm, i, i) = 1.0;  // padding of the last block (loop pose uses 6 of 15): rows/columns stay zero
+      w.t1[i] = 0.0;
     }
-    VIO_PARFOR(q, F * v.n6cap) {
-      int f = q / v.n6cap, a = q - f * v.n6cap;
-      if (a < v.npose6) {
-        int fr = a / 6, c = a - 6 * fr;
-        v.WTf[q] *= w.sp[kBS * fr + c] * w.sf[f];
-      }
-    }
-    wt_scaled = true;
   }
-  stamp(cx, ST_X7);
-  const int nblocks = v.nblk * (v.nblk + 1) / 2;
-  VIO_PARFOR(q, nblocks * kBB) {
-    int blk = q / kBB, e = q - blk * kBB, r = e / kBS, c = e - r * kBS;
-    int bij = w.blk_ij[blk];
-    int i = (bij >> 8) * kBS + r, j = (bij & 255) * kBS + c;
-    double val = 0.0;
-    if (i < np && j < np) {
-      val = w.sp[i] * w.Hm[q] * w.sp[j];
-      if (i == j) val += mu * w.dp[i] * w.dp[i];
-    } else if (i == j) {
-      val = 1.0;  // padding of the last block (loop pose uses 6 of 15)
-    }
-    w.Hm[q] = val;
-  }
-  VIO_PARFOR(i, v.nblk * kBS) w.t1[i] = i < np ? w.sp[i] * w.gp[i] : 0.0;
   VIO_SYNC();
   stamp(cx, ST_SCALE);
   const int n6 = v.npose6;
@@ -1543,7 +1548,8 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) 
 #endif
 }
 
-// q(v) = v^T (S H S + mu D^2) v through the factorization: sum_f e_f (v_f + ws_f^T v_p / e_f)^2 + |L^T v_p|^2.
+// q(v) = v^T (S H S + mu D^2) v = (S v)^T (H + mu C) (S v) through the factorization of the unscaled system
+// (build_reduced_system): with u = S v, sum_f E_f (u_f + w_f^T u_p / E_f)^2 + |L^T u_p|^2.
 // Both mat-vecs are split into many short items that add into LDS accumulators: w.tf (F) and w.t1 (np) are free at
 // both call sites (the back-substitution has consumed them; the next build_reduced_system rewrites them).
 template <class WK>
@@ -1561,7 +1567,10 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
     const double *wt = v.WT + f;
     double s = 0;
 #pragma unroll 8
-    for (int a = a0; a < a1; a++) s += wt[(size_t)a * v.Fpad] * vp[kBS * (a / 6) + a % 6];
+    for (int a = a0; a < a1; a++) {
+      const int i = kBS * (a / 6) + a % 6;
+      s += wt[(size_t)a * v.Fpad] * (w.sp[i] * vp[i]);
+    }
     VIO_ATOMIC_ADD(w.tf + f, s);
   }
   stamp(cx, ST_X3);
@@ -1575,14 +1584,14 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
     for (int r = 0; r < kBS; r++) {
       const int i = bi * kBS + r;
       // diagonal blocks keep L^-1 above the diagonal (cholesky_blocks): only r >= c belongs to L
-      if (i < np && (bi != bj || r >= c)) s += B[r * kBS + c] * vp[i];
+      if (i < np && (bi != bj || r >= c)) s += B[r * kBS + c] * (w.sp[i] * vp[i]);
     }
     VIO_ATOMIC_ADD(w.t1 + bj * kBS + c, s);
   }
   VIO_SYNC();
   double acc = 0;
   VIO_PARFOR(f, F) {
-    double u = vf[f] + w.tf[f] / w.ef[f];
+    double u = w.sf[f] * vf[f] + w.tf[f] / w.ef[f];
     acc += w.ef[f] * u * u;
   }
   VIO_PARFOR(j, np) acc += w.t1[j] * w.t1[j];
@@ -1655,7 +1664,6 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   };
 
   double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, false);
-  bool wt_scaled = false;  // WT / WTf still carry unscaled values after the first evaluation
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
   VIO_PARFOR(i, np) w.sp[i] = 1.0 / (1.0 + sqrt(w.hdiag[i]));  // Jacobi scaling, :239-254
   VIO_PARFOR(f, F) w.sf[f] = 1.0 / (1.0 + sqrt(w.hff[f]));
@@ -1705,29 +1713,28 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
           evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
-          wt_scaled = true;
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
         VIO_SYNC();
-        bool ok = build_reduced_system(cx, v, w, mu, wt_scaled);
+        bool ok = build_reduced_system(cx, v, w, mu);
         if (ok) ok = cholesky_blocks(cx, v, w, w.t1);
         stamp(cx, ST_CHOL);
         if (ok) {
           cholesky_backsolve(cx, v, w, w.t1);  // y_p
           stamp(cx, ST_X4);
-          // back-substitute features: y_f = (gs_f - ws_f^T y_p) / e_f ; GN = -d * y
+          // back-substitute features: z_f = (g_f - w_f^T z_p) / E_f ; y = z / s ; GN = -d * y
           double bad = 0;
           VIO_PARFOR(f, F) {
             double s = 0;
 #pragma unroll 6
             for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * w.t1[kBS * (a / 6) + a % 6];
-            double y = w.tf[f] - s / w.ef[f];
+            double y = (w.tf[f] - s / w.ef[f]) / w.sf[f];
             w.gnf[f] = -w.df[f] * y;
             if (!isfinite(y)) bad = 1;
           }
           VIO_PARFOR(i, np) {
-            double y = w.t1[i];
+            double y = w.t1[i] / w.sp[i];
             w.gnp[i] = -w.dp[i] * y;
             if (!isfinite(y)) bad = 1;
           }
@@ -1824,7 +1831,6 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       recorded = it + 1, min_rec = fmin(min_rec, x_cost);
       // the matrix buffer holds a factorization: H must be rebuilt before the next build_reduced_system
       evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
-      wt_scaled = true;
       continue;
     }
     invalid_run = 0;
@@ -1850,7 +1856,6 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       VIO_SYNC();
       state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
       x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
-      wt_scaled = true;
       gmax = grad_max_norm();
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
