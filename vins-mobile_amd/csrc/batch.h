@@ -50,7 +50,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -71,6 +71,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
+  s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
   s.scratch = (o + 7) / 8 * 8;
   s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB;
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -127,6 +128,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prJT = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
   v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP;
+  v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
   v.raw_pose = B.raw_pose + b * B.s.out_pose, v.raw_sb = B.raw_sb + b * B.s.out_sb;
@@ -179,6 +181,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   ldsd prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
   ldsd flag = take(2);
   ldsd ppd = take(36 * (size_t)(d.Pcap + 1));
+  ldsd rot = take(9 * (size_t)(d.Pcap + 2));
   if (w) {
     w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
@@ -188,6 +191,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
     w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
     w->prcol = reinterpret_cast<ldsi>(prcol), w->flag = reinterpret_cast<ldsi>(flag);
     w->ppd = ppd;
+    w->rot = rot;
   }
   if (cx) cx->red = red;
   return o * sizeof(double);

@@ -130,6 +130,7 @@ struct WinView {
   double *prH0;      // [n*n]  J0^T J0
   double *WT;        // [npose6][Fpad]  H_pf transposed: row = 6*frame + c, col = feature
   double *WTf;       // [F][n6cap]      the same, feature-major (operand layout of the Schur GEMM)
+  int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
@@ -161,6 +162,7 @@ struct WorkT {
   ldsd prdx, prr;           // prior dx / residual: prior_n each
   ldsi prcol;               // prior column -> reduced parameter (-1 constant): prior_n
   ldsi flag;                // [4] block-uniform flags
+  ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
   ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
 };
 
@@ -320,6 +322,60 @@ VIO_DEV void projection_eval(double s_info, PA pose_i, PA pose_j, PE ex, double 
   mat3vec(Bric, pts_i, v3);
   for (int i = 0; i < 2; i++)
     Jl[i] = (red[i * 3] * v3[0] + red[i * 3 + 1] * v3[1] + red[i * 3 + 2] * v3[2]) * -1.0 / (inv_dep * inv_dep);
+}
+
+// The same factor from rotation MATRICES prepared once per evaluation (w.rot: one per frame, then r_ic), for the
+// solver's inner loops: four mat-vecs for the residual and, with jac, (reduce A) chained through R_i and r_ic instead
+// of five dense 3x3 products. Equal to projection_eval up to rounding (different association of the same products).
+template <class PR, class PA, class PE>
+VIO_DEV void projection_eval_rot(double s_info, PR Ri_, PA pose_i, PR Rj_, PA pose_j, PR ric_, PE ex, double inv_dep,
+                                 const double *pts_i, const double *pts_j, bool jac, double *r, double *Ji, double *Jj,
+                                 double *Jl) {
+  double Ri[9], Rj[9], ric[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Ri[k] = Ri_[k], Rj[k] = Rj_[k], ric[k] = ric_[k];
+  const double tic[3] = {ex[0], ex[1], ex[2]};
+  const double pi3[3] = {pts_i[0], pts_i[1], pts_i[2]};
+  const double pc_i[3] = {pi3[0] / inv_dep, pi3[1] / inv_dep, pi3[2] / inv_dep};
+  double p_imu_i[3], p_w[3], p_imu_j[3], p_c_j[3], d[3], e[3];
+  for (int a = 0; a < 3; a++) p_imu_i[a] = ric[3 * a] * pc_i[0] + ric[3 * a + 1] * pc_i[1] + ric[3 * a + 2] * pc_i[2] + tic[a];
+  for (int a = 0; a < 3; a++) p_w[a] = Ri[3 * a] * p_imu_i[0] + Ri[3 * a + 1] * p_imu_i[1] + Ri[3 * a + 2] * p_imu_i[2] + pose_i[a];
+  for (int a = 0; a < 3; a++) d[a] = p_w[a] - pose_j[a];
+  for (int a = 0; a < 3; a++) p_imu_j[a] = Rj[a] * d[0] + Rj[3 + a] * d[1] + Rj[6 + a] * d[2];  // R_j^T d
+  for (int a = 0; a < 3; a++) e[a] = p_imu_j[a] - tic[a];
+  for (int a = 0; a < 3; a++) p_c_j[a] = ric[a] * e[0] + ric[3 + a] * e[1] + ric[6 + a] * e[2];  // r_ic^T e
+  const double dep_j = p_c_j[2];
+  r[0] = s_info * (p_c_j[0] / dep_j - pts_j[0]);
+  r[1] = s_info * (p_c_j[1] / dep_j - pts_j[1]);
+  if (!jac) return;
+  // reduce (2x3, projection_facor.cpp:46-50) has the sparsity [s/z 0 -s x/z^2 ; 0 s/z -s y/z^2]
+  const double rz = s_info * (1. / dep_j), rx = s_info * (-p_c_j[0] / (dep_j * dep_j)), ry = s_info * (-p_c_j[1] / (dep_j * dep_j));
+  double A[9];  // r_ic^T R_j^T
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) A[3 * a + b] = ric[a] * Rj[3 * b] + ric[3 + a] * Rj[3 * b + 1] + ric[6 + a] * Rj[3 * b + 2];
+  double RA[6], RB[6], RC[6], RT[6];
+  for (int b = 0; b < 3; b++) RA[b] = rz * A[b] + rx * A[6 + b], RA[3 + b] = rz * A[3 + b] + ry * A[6 + b];  // reduce A
+  for (int i = 0; i < 2; i++)
+    for (int b = 0; b < 3; b++) {
+      RB[3 * i + b] = RA[3 * i] * Ri[b] + RA[3 * i + 1] * Ri[3 + b] + RA[3 * i + 2] * Ri[6 + b];        // reduce A R_i
+      RT[3 * i + b] = (i == 0 ? rz * ric[3 * b] : rz * ric[3 * b + 1]) + (i == 0 ? rx : ry) * ric[3 * b + 2];  // reduce r_ic^T
+    }
+  for (int i = 0; i < 2; i++)
+    for (int b = 0; b < 3; b++)
+      RC[3 * i + b] = RB[3 * i] * ric[b] + RB[3 * i + 1] * ric[3 + b] + RB[3 * i + 2] * ric[6 + b];     // reduce A R_i r_ic
+  for (int i = 0; i < 2; i++) {
+    const double *u = RB + 3 * i, *t = RT + 3 * i;
+    // u skew(p) = (u1 p2 - u2 p1, u2 p0 - u0 p2, u0 p1 - u1 p0)
+    Ji[i * 6 + 0] = RA[3 * i], Ji[i * 6 + 1] = RA[3 * i + 1], Ji[i * 6 + 2] = RA[3 * i + 2];
+    Ji[i * 6 + 3] = -(u[1] * p_imu_i[2] - u[2] * p_imu_i[1]);
+    Ji[i * 6 + 4] = -(u[2] * p_imu_i[0] - u[0] * p_imu_i[2]);
+    Ji[i * 6 + 5] = -(u[0] * p_imu_i[1] - u[1] * p_imu_i[0]);
+    Jj[i * 6 + 0] = -RA[3 * i], Jj[i * 6 + 1] = -RA[3 * i + 1], Jj[i * 6 + 2] = -RA[3 * i + 2];
+    Jj[i * 6 + 3] = t[1] * p_imu_j[2] - t[2] * p_imu_j[1];
+    Jj[i * 6 + 4] = t[2] * p_imu_j[0] - t[0] * p_imu_j[2];
+    Jj[i * 6 + 5] = t[0] * p_imu_j[1] - t[1] * p_imu_j[0];
+    Jl[i] = (RC[3 * i] * pi3[0] + RC[3 * i + 1] * pi3[1] + RC[3 * i + 2] * pi3[2]) * -1.0 / (inv_dep * inv_dep);
+  }
 }
 
 // Raw (un-whitened) IMU residual and, if Jraw != NULL, the dense 15x30 Jacobian [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]
@@ -842,13 +898,14 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   const bool one_thread_per_feature = v.F <= (int)cx.nt;
   for (int c0 = 0; c0 < v.nslots; c0 += CH) {
     stamp(cx, ST_P_ZERO);
-    VIO_PARFOR(k, v.M) {
-      const int slot = v.fslot[k] - c0;
-      if (slot < 0 || slot >= CH) continue;
+    const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
+    VIO_PARFOR(slot, nsl) {  // slot order: every lane of every wave has a factor (bar the odd tails)
+      const int k = v.sfact[c0 + slot];
+      if (k < 0) continue;
       int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
       double r[2], Ji[12], Jj[12], Jl[2];
-      projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji,
-                      Jj, nullptr, Jl);
+      projection_eval_rot(v.s_info, w.rot + 9 * h, pose + 7 * h, w.rot + 9 * t, pose + 7 * t, w.rot + 9 * (v.P + 1), w.ex,
+                          feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj, Jl);
       double sq = r[0] * r[0] + r[1] * r[1];
       double sum = 1.0 + sq * cc;
       cost += 0.5 * bb * log(sum);
@@ -987,6 +1044,14 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
                         cldsd feat, bool jac, bool have_scale = false) {
   const int np = v.np;
   double cost = 0.0;  // per-thread partial, reduced at the end
+  VIO_PARFOR(i, v.P + v.has_loop + 1) {  // rotation matrices for the projection factors (consumed after a barrier)
+    const bool is_ex = i == v.P + v.has_loop;
+    double R[9];
+    if (is_ex) qtoR(Quat{w.ex[3], w.ex[4], w.ex[5], w.ex[6]}, R);
+    else qtoR(Quat{pose[7 * i + 3], pose[7 * i + 4], pose[7 * i + 5], pose[7 * i + 6]}, R);
+    auto dst = w.rot + 9 * (is_ex ? v.P + 1 : i);
+    for (int k = 0; k < 9; k++) dst[k] = R[k];
+  }
   if (jac) {
     const int nF = v.P + v.has_loop;
     VIO_PARFOR(q, np) w.gp[q] = 0.0;
@@ -1156,8 +1221,8 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     VIO_PARFOR(k, v.M) {
       int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
       double r[2];
-      projection_eval(v.s_info, pose + 7 * h, pose + 7 * t, w.ex, feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, false, r,
-                      nullptr, nullptr, nullptr, nullptr);
+      projection_eval_rot(v.s_info, w.rot + 9 * h, pose + 7 * h, w.rot + 9 * t, pose + 7 * t, w.rot + 9 * (v.P + 1), w.ex,
+                          feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, false, r, nullptr, nullptr, nullptr);
       cost += 0.5 * bb * log(1.0 + (r[0] * r[0] + r[1] * r[1]) * cc);
     }
   }
@@ -1912,6 +1977,9 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
     cx.prof[ST_TOTAL] = -cx.prof[ST_COUNT - 1];
   }
 #endif
+  VIO_PARFOR(q, v.nslots) v.sfact[q] = -1;
+  VIO_SYNC();
+  VIO_PARFOR(k, v.M) v.sfact[v.fslot[k]] = k;
   setup_imu_info(cx, v, w.Hm);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, v, w);
