@@ -251,6 +251,24 @@ VIO_DEV double block_max(const Ctx &cx, double v) {
 #endif
 }
 
+// W lives in global memory (L2): a dependent load costs ~3k cycles here, so the mat-vecs with W fetch a whole strip
+// (up to kWStrip entries, predicated) before the first multiply. Strided form: column f of WT (stride Fpad).
+constexpr int kWStrip = 24;
+VIO_DEV void wt_strip_load(const double *p, size_t stride, int n, double x[kWStrip]) {
+#pragma unroll
+  for (int j = 0; j < kWStrip; j++) x[j] = p[(size_t)(j < n ? j : 0) * stride];
+#ifndef VIO_EMUL
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// Splits n6 rows over the threads available per feature: (feature, part) items, <= kWStrip rows per part.
+VIO_DEV void wt_parts(int nt, int F, int n6, int &nparts, int &per) {
+  nparts = nt / (F > 0 ? F : 1);
+  const int need = (n6 + kWStrip - 1) / kWStrip;
+  nparts = nparts < need ? need : (nparts > 6 ? 6 : nparts);
+  per = (n6 + nparts - 1) / nparts;
+}
+
 // ProjectionFactor::Evaluate (projection_facor.cpp:16-99) in local coordinates. Jex optional.
 template <class PA, class PE>
 VIO_DEV void projection_eval(double s_info, PA pose_i, PA pose_j, PE ex, double inv_dep, const double *pts_i,
@@ -1385,14 +1403,15 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 #endif
   stamp(cx, ST_SCHUR);
   // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets
-  const int nch = 8, chunk = (F + nch - 1) / nch;
+  const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
   VIO_PARFOR(q, n6 * nch) {
     int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
-    const double *wa = v.WT + (size_t)a * v.Fpad;
     int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
-    double s = 0;
-#pragma unroll 4
-    for (int f = f0; f < f1; f++) s += wa[f] * w.tf[f];
+    double x[kWStrip], s = 0;
+    const int nb = f1 - f0 > 0 ? f1 - f0 : 0;  // <= kWStrip by the choice of nch
+    wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
+#pragma unroll
+    for (int j = 0; j < kWStrip; j++) s += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
     VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -s);
   }
   VIO_SYNC();
@@ -1623,18 +1642,20 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
   VIO_PARFOR(f, F) w.tf[f] = 0.0;
   VIO_PARFOR(j, v.nblk * kBS) w.t1[j] = 0.0;
   VIO_SYNC();
-  int nparts = (int)cx.nt / (F > 0 ? F : 1);
-  nparts = nparts < 1 ? 1 : (nparts > 6 ? 6 : nparts);
-  const int per = (n6 + nparts - 1) / nparts;
+  int nparts, per;
+  wt_parts((int)cx.nt, F, n6, nparts, per);
   VIO_PARFOR(q, F * nparts) {  // u_f += sum_{a in part} WT[a][f] vp[a]
     const int part = q / F, f = q - part * F;
     const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
-    const double *wt = v.WT + f;
-    double s = 0;
-#pragma unroll 8
-    for (int a = a0; a < a1; a++) {
-      const int i = kBS * (a / 6) + a % 6;
-      s += wt[(size_t)a * v.Fpad] * (w.sp[i] * vp[i]);
+    double x[kWStrip], s = 0;
+    for (int b0 = a0; b0 < a1; b0 += kWStrip) {
+      const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
+      wt_strip_load(v.WT + (size_t)b0 * v.Fpad + f, v.Fpad, nb, x);
+#pragma unroll
+      for (int j = 0; j < kWStrip; j++) {
+        const int a = b0 + (j < nb ? j : 0), i = kBS * (a / 6) + a % 6;
+        s += (j < nb ? x[j] : 0.0) * (w.sp[i] * vp[i]);
+      }
     }
     VIO_ATOMIC_ADD(w.tf + f, s);
   }
@@ -1790,11 +1811,30 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
           stamp(cx, ST_X4);
           // back-substitute features: z_f = (g_f - w_f^T z_p) / E_f ; y = z / s ; GN = -d * y
           double bad = 0;
+          VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p from the (feature, part) items
+          VIO_SYNC();
+          {
+            int nparts, per;
+            wt_parts((int)cx.nt, F, v.npose6, nparts, per);
+            VIO_PARFOR(q, F * nparts) {
+              const int part = q / F, f = q - part * F;
+              const int a0 = part * per, a1 = a0 + per < v.npose6 ? a0 + per : v.npose6;
+              double x[kWStrip], s = 0;
+              for (int b0 = a0; b0 < a1; b0 += kWStrip) {
+                const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
+                wt_strip_load(v.WT + (size_t)b0 * v.Fpad + f, v.Fpad, nb, x);
+#pragma unroll
+                for (int j = 0; j < kWStrip; j++) {
+                  const int a = b0 + (j < nb ? j : 0);
+                  s += (j < nb ? x[j] : 0.0) * w.t1[kBS * (a / 6) + a % 6];
+                }
+              }
+              VIO_ATOMIC_ADD(w.gnf + f, s);
+            }
+          }
+          VIO_SYNC();
           VIO_PARFOR(f, F) {
-            double s = 0;
-#pragma unroll 6
-            for (int a = 0; a < v.npose6; a++) s += v.WT[a * v.Fpad + f] * w.t1[kBS * (a / 6) + a % 6];
-            double y = (w.tf[f] - s / w.ef[f]) / w.sf[f];
+            double y = (w.tf[f] - w.gnf[f] / w.ef[f]) / w.sf[f];
             w.gnf[f] = -w.df[f] * y;
             if (!isfinite(y)) bad = 1;
           }
