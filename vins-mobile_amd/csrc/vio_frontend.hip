@@ -806,166 +806,146 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-constexpr int kTile = 16;
-constexpr int kMaxTileDiscs = 32;  // kept discs that can overlap one 16x16 tile (min distance between them applies)
-
 // goodFeaturesToTrack front half, fused: cornerMinEigenVal (Sobel/1/3060 -> products -> 3x3 box -> min eigenvalue),
 // the masked maximum (minMaxLoc) and the candidate test "equal to its 3x3 maximum, inside the mask, 1-px border
-// excluded". The eigenvalue map never goes to memory: a 16x16 tile computes products on a 20x20 halo and eigenvalues
-// on an 18x18 halo in LDS. The mask is either an image (stand-alone operator) or evaluated analytically from the
-// discs setMask painted (feature_tracker.cpp:80): no mask image, memset or paint pass on the tracker path.
+// excluded". Nothing but the candidates goes to memory and nothing is staged in LDS:
+//   * a wave owns 64 consecutive columns (60 outputs + 2 halo each side) and walks down a strip of kDetR rows;
+//   * each lane forms the derivative products of ITS column for one row from nine image bytes (row addresses are
+//     scalar, a product position outside the image takes the value of its reflected position: boxFilter's
+//     BORDER_REFLECT_101 acts on the product images);
+//   * horizontal neighbours travel on the DPP network (wave_shr / wave_shl), vertical neighbours are the previous two
+//     rows kept in registers: box sums, eigenvalues and the 3x3 maximum all slide down the strip;
+//   * the mask is either an image (stand-alone operator) or the discs setMask painted (feature_tracker.cpp:80),
+//     rasterised once per workgroup into one 64-bit word per (wave, row).
 // The quality threshold needs the global maximum, so it is applied later by the selection kernel.
+constexpr int kDetW = 60;      // output columns per wave
+constexpr int kDetWaves = 4;   // waves per workgroup, side by side
+constexpr int kDetR = 32;      // output rows per strip
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define LANE_LEFT(v) dpp_f32<0x138>(v)   /* wave_shr:1 -> value of lane - 1 */
+#define LANE_RIGHT(v) dpp_f32<0x130>(v)  /* wave_shl:1 -> value of lane + 1 */
+
 template <bool IMG_MASK>
 __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
                                                      size_t mask_stride, const int *kept_xy, const int *n_kept, int cap,
                                                      const int *hw, int radius, unsigned *max_bits, int rows, int cols,
                                                      unsigned long long *cand_base, int seg_cap, int *n_cand) {
-  constexpr int PS = kTile + 6, CS = kTile + 4, ES = kTile + 2;  // source patch 22, product grid 20, eigen grid 18
-  __shared__ float src[PS][PS + 1];
-  __shared__ float sxx[CS][CS + 1], sxy[CS][CS + 1], syy[CS][CS + 1];
-  __shared__ float seig[ES][ES + 1];
-  __shared__ int disc[kMaxTileDiscs][2];
-  __shared__ int n_disc;
+  constexpr int kCandLds = kDetWaves * kDetW * kDetR / 4 + 64;  // a 3x3 maximum occupies at most one pixel in four
+  __shared__ unsigned long long s_mask[kDetWaves][kDetR];
+  __shared__ unsigned long long s_cand[kCandLds];
   __shared__ unsigned smax;
   __shared__ int s_ncand, s_base;
-  __shared__ unsigned long long s_cand[kTile * kTile];
-  const int seq = blockIdx.z;
+  const int seq = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint8_t *img = img_base + (size_t)seq * img_stride;
-  const int x0 = blockIdx.x * kTile, y0 = blockIdx.y * kTile;
-  const int tid = threadIdx.y * kTile + threadIdx.x;
-  if (tid == 0) smax = 0, n_disc = 0, s_ncand = 0;
-  // source patch in EXTENDED coordinates [x0-3, x0+19) x [y0-3, y0+19): value = img(reflect101(coord))
-  for (int e = tid; e < PS * PS; e += kTile * kTile) {
-    int ly = e / PS, lx = e - ly * PS;
-    int y = reflect101(min(max(y0 + ly - 3, -rows + 1), 2 * rows - 2), rows);
-    int x = reflect101(min(max(x0 + lx - 3, -cols + 1), 2 * cols - 2), cols);
-    src[ly][lx] = (float)img[(size_t)y * cols + x];
-  }
+  const int XB = blockIdx.x * (kDetWaves * kDetW), Y0 = blockIdx.y * kDetR;
+  const int X0 = XB + wave * kDetW;  // first output column of this wave; lane l <-> extended column X0 - 2 + l
+  if (tid == 0) smax = 0, s_ncand = 0;
+  if (tid < kDetWaves * kDetR) s_mask[tid / kDetR][tid % kDetR] = 0ull;
   __syncthreads();
-  if (!IMG_MASK) {  // discs that can touch this tile
-    const int nk = n_kept[seq];
-    for (int k = tid; k < nk; k += kTile * kTile) {
-      int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
-      if (cx + radius >= x0 && cx - radius < x0 + kTile && cy + radius >= y0 && cy - radius < y0 + kTile) {
-        int slot = atomicAdd(&n_disc, 1);
-        if (slot < kMaxTileDiscs) disc[slot][0] = cx, disc[slot][1] = cy;
+  if (!IMG_MASK) {
+    // disc rows that cross this workgroup's strip -> bits of the (wave, row) words
+    const int nk = n_kept[seq], span = 2 * radius + 1;
+    for (int k = 0; k < nk; k++) {
+      const int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
+      if (cy + radius < Y0 || cy - radius >= Y0 + kDetR || cx + radius < XB - 2 || cx - radius >= XB + kDetWaves * kDetW + 2)
+        continue;  // uniform across the workgroup
+      for (int it = tid; it < span * kDetWaves; it += 256) {
+        const int dyi = it % span, wv = it / span;
+        const int r = cy + dyi - radius - Y0;
+        if (r < 0 || r >= kDetR) continue;
+        const int h = hw[dyi];
+        const int l0 = max(cx - h - (XB + wv * kDetW - 2), 0), l1 = min(cx + h - (XB + wv * kDetW - 2), 63);
+        if (l0 > l1) continue;
+        const unsigned long long bits = (l1 - l0 == 63 ? ~0ull : ((1ull << (l1 - l0 + 1)) - 1ull)) << l0;
+        atomicOr(&s_mask[wv][r], bits);
       }
     }
+    __syncthreads();
   }
   const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
   const float s2 = s * 2.f;
-  // derivative products on the 20x20 grid (extended coords [x0-2, x0+18)); a grid position outside the image takes the
-  // value of its REFLECTED position (boxFilter BORDER_REFLECT_101 acts on the product images)
-  for (int e = tid; e < CS * CS; e += kTile * kTile) {
-    int ly = e / CS, lx = e - ly * CS;
-    int y = reflect101(min(max(y0 + ly - 2, -rows + 1), 2 * rows - 2), rows);
-    int x = reflect101(min(max(x0 + lx - 2, -cols + 1), 2 * cols - 2), cols);
-    int py = y - (y0 - 3), px = x - (x0 - 3);  // patch-local index of the (in-image) position
-    float dx, dy;
-    if (py >= 1 && py < PS - 1 && px >= 1 && px < PS - 1) {
-      float d0 = src[py - 1][px + 1] - src[py - 1][px - 1], d1 = src[py][px + 1] - src[py][px - 1],
-            d2 = src[py + 1][px + 1] - src[py + 1][px - 1];
-      dx = s2 * d1 + s * (d0 + d2);
-      float t0 = s2 * src[py - 1][px] + s * (src[py - 1][px - 1] + src[py - 1][px + 1]);
-      float t2 = s2 * src[py + 1][px] + s * (src[py + 1][px - 1] + src[py + 1][px + 1]);
-      dy = t2 - t0;
-    } else {  // reflected position fell outside the staged patch (only at partial edge tiles): read the image
-      int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows), xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
-      const uint8_t *r0 = img + (size_t)ym * cols, *r1 = img + (size_t)y * cols, *r2 = img + (size_t)yp * cols;
-      float d0 = (float)((int)r0[xp] - (int)r0[xm]), d1 = (float)((int)r1[xp] - (int)r1[xm]), d2 = (float)((int)r2[xp] - (int)r2[xm]);
-      dx = s2 * d1 + s * (d0 + d2);
-      float t0 = s2 * (float)r0[x] + s * ((float)r0[xm] + (float)r0[xp]);
-      float t2 = s2 * (float)r2[x] + s * ((float)r2[xm] + (float)r2[xp]);
-      dy = t2 - t0;
-    }
-    sxx[ly][lx] = dx * dx, sxy[ly][lx] = dx * dy, syy[ly][lx] = dy * dy;
-  }
-  __syncthreads();
-  // eigenvalues on the 18x18 grid (extended coords [x0-1, x0+17)); only in-image positions are ever consumed
-  for (int e = tid; e < ES * ES; e += kTile * kTile) {
-    int ly = e / ES, lx = e - ly * ES;
-    int cy = ly + 1, cx = lx + 1;  // centre in the product grid
-    float a, b, c;
-    {
-      float r0 = (sxx[cy - 1][cx - 1] + sxx[cy - 1][cx]) + sxx[cy - 1][cx + 1];
-      float r1 = (sxx[cy][cx - 1] + sxx[cy][cx]) + sxx[cy][cx + 1];
-      float r2 = (sxx[cy + 1][cx - 1] + sxx[cy + 1][cx]) + sxx[cy + 1][cx + 1];
-      a = ((r0 + r1) + r2) * 0.5f;
-    }
-    {
-      float r0 = (sxy[cy - 1][cx - 1] + sxy[cy - 1][cx]) + sxy[cy - 1][cx + 1];
-      float r1 = (sxy[cy][cx - 1] + sxy[cy][cx]) + sxy[cy][cx + 1];
-      float r2 = (sxy[cy + 1][cx - 1] + sxy[cy + 1][cx]) + sxy[cy + 1][cx + 1];
-      b = (r0 + r1) + r2;
-    }
-    {
-      float r0 = (syy[cy - 1][cx - 1] + syy[cy - 1][cx]) + syy[cy - 1][cx + 1];
-      float r1 = (syy[cy][cx - 1] + syy[cy][cx]) + syy[cy][cx + 1];
-      float r2 = (syy[cy + 1][cx - 1] + syy[cy + 1][cx]) + syy[cy + 1][cx + 1];
-      c = ((r0 + r1) + r2) * 0.5f;
-    }
-    seig[ly][lx] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-  }
-  __syncthreads();
-  const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-  bool is_cand = false;
-  float v = 0.f;
+  // this lane's column (reflected like the product image) and its two neighbours for the Sobel taps
+  const int xe = X0 - 2 + lane;
+  const int xr = reflect101(min(max(xe, -cols + 1), 2 * cols - 2), cols);
+  const int xm = reflect101(xr - 1, cols), xp = reflect101(xr + 1, cols);
+  float hxx0 = 0.f, hxx1 = 0.f, hxy0 = 0.f, hxy1 = 0.f, hyy0 = 0.f, hyy1 = 0.f;  // horizontal sums of rows -2, -1
+  float e0 = 0.f, e1 = 0.f;                                                        // eigenvalues of rows -2, -1
   unsigned my_max = 0;
-  if (x < cols && y < rows) {
-    v = seig[threadIdx.y + 1][threadIdx.x + 1];
-    bool unmasked;
-    if (IMG_MASK) {
-      unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + x] != 0;
-    } else {
-      unmasked = true;
-      const int nd = min(n_disc, kMaxTileDiscs);
-      for (int k = 0; k < nd; k++) {
-        int dy = y - disc[k][1], dx = x - disc[k][0];
-        if (dy >= -radius && dy <= radius) {
-          int h = hw[radius + dy];
-          if (dx >= -h && dx <= h) unmasked = false;
+  const bool out_lane = lane >= 2 && lane < 2 + kDetW && xe < cols;
+  for (int step = 0; step < kDetR + 4; step++) {
+    const int ye = Y0 - 2 + step;  // extended product row (uniform)
+    const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
+    const int ym = reflect101(yr - 1, rows), yp = reflect101(yr + 1, rows);
+    const uint8_t *r0 = img + (size_t)ym * cols, *r1 = img + (size_t)yr * cols, *r2 = img + (size_t)yp * cols;
+    const float a00 = (float)r0[xm], a01 = (float)r0[xr], a02 = (float)r0[xp];
+    const float a10 = (float)r1[xm], a12 = (float)r1[xp];
+    const float a20 = (float)r2[xm], a21 = (float)r2[xr], a22 = (float)r2[xp];
+    const float d0 = a02 - a00, d1 = a12 - a10, d2 = a22 - a20;
+    const float dx = s2 * d1 + s * (d0 + d2);
+    const float t0 = s2 * a01 + s * (a00 + a02);
+    const float t2 = s2 * a21 + s * (a20 + a22);
+    const float dy = t2 - t0;
+    const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
+    // 3-tap horizontal sums (left + centre) + right, then the 3-row vertical sums (top + middle) + bottom
+    const float hxx2 = (LANE_LEFT(pxx) + pxx) + LANE_RIGHT(pxx);
+    const float hxy2 = (LANE_LEFT(pxy) + pxy) + LANE_RIGHT(pxy);
+    const float hyy2 = (LANE_LEFT(pyy) + pyy) + LANE_RIGHT(pyy);
+    float e2 = 0.f;
+    if (step >= 2) {  // eigenvalue of extended row ye - 1
+      const float a = ((hxx0 + hxx1) + hxx2) * 0.5f;
+      const float b = (hxy0 + hxy1) + hxy2;
+      const float c = ((hyy0 + hyy1) + hyy2) * 0.5f;
+      e2 = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    }
+    if (step >= 4) {  // output row ye - 2: centre e1, neighbours e0 / e2 and the lanes left and right
+      const int y = ye - 2, r = step - 4;
+      float m = fmaxf(fmaxf(e0, e1), e2);
+      m = fmaxf(m, fmaxf(LANE_LEFT(m), LANE_RIGHT(m)));
+      if (out_lane && y < rows) {
+        const float v = e1;
+        bool unmasked;
+        if (IMG_MASK) unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + xe] != 0;
+        else unmasked = ((s_mask[wave][r] >> lane) & 1ull) == 0ull;
+        if (unmasked) {
+          my_max = max(my_max, ordered_bits(v));
+          if (xe >= 1 && y >= 1 && xe < cols - 1 && y < rows - 1 && v > 0.f && v == m) {
+            const int slot = atomicAdd(&s_ncand, 1);
+            const unsigned idx = (unsigned)(y * cols + xe);
+            if (slot < kCandLds) s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+          }
         }
       }
     }
-    if (unmasked) {
-      my_max = ordered_bits(v);
-      if (x >= 1 && y >= 1 && x < cols - 1 && y < rows - 1 && v > 0.f) {
-        float m = v;
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++) m = fmaxf(m, seig[threadIdx.y + dy][threadIdx.x + dx]);
-        is_cand = v == m;
-      }
-    }
+    hxx0 = hxx1, hxx1 = hxx2, hxy0 = hxy1, hxy1 = hxy2, hyy0 = hyy1, hyy1 = hyy2;
+    e0 = e1, e1 = e2;
   }
   // masked maximum: wave max on the DPP/shuffle network, then one LDS atomic per wave
   {
     unsigned m = my_max;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((tid & 63) == 0 && m) atomicMax(&smax, m);
-  }
-  // candidates: collected per workgroup in LDS, appended with ONE global atomic per workgroup
-  if (is_cand) {
-    int slot = atomicAdd(&s_ncand, 1);
-    unsigned idx = (unsigned)(y * cols + x);
-    s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+    if (lane == 0 && m) atomicMax(&smax, m);
   }
   __syncthreads();
-  // every tile row of a sequence owns a segment of the candidate list and a counter / maximum slot, so the global
-  // atomics of one address come from the <= cols/16 tiles of that row only
+  // every strip of a sequence owns a segment of the candidate list and a counter / maximum slot, so the global
+  // atomics of one address come from the few workgroups of that strip only
   const int nseg = gridDim.y;
   const size_t segi = (size_t)seq * nseg + blockIdx.y;
-  const int nc = s_ncand;
+  const int nc = min(s_ncand, kCandLds);
   if (tid == 0 && nc) s_base = atomicAdd(&n_cand[segi], nc);
   __syncthreads();
-  if (tid < nc) {
-    int slot = s_base + tid;
-    if (slot < seg_cap) cand_base[segi * seg_cap + slot] = s_cand[tid];
+  for (int i = tid; i < nc; i += 256) {
+    const int slot = s_base + i;
+    if (slot < seg_cap) cand_base[segi * seg_cap + slot] = s_cand[i];
   }
   if (tid == 0 && smax) atomicMax(&max_bits[segi], smax);
 }
+#undef LANE_LEFT
+#undef LANE_RIGHT
 
 struct SelectParams {
   int cap, rows, cols, max_corners;
@@ -1120,7 +1100,7 @@ struct vio_frontend {
   uint8_t *mask = nullptr;      // [rows*cols], only the stand-alone vio_good_features uses a mask image
   unsigned *max_bits = nullptr;
   unsigned long long *cand = nullptr;
-  int nseg = 0, seg_cap = 0;  // candidate list: one segment per 16-row tile band
+  int nseg = 0, seg_cap = 0;  // candidate list: one segment per strip of kDetR rows
   int *n_cand = nullptr;
   float *cur_pts = nullptr, *pre_pts = nullptr, *forw_pts = nullptr, *lk_err = nullptr;
   int *ids = nullptr, *track_cnt = nullptr, *n_pts = nullptr, *n_forw = nullptr, *n_id = nullptr, *kept_xy = nullptr,
@@ -1201,7 +1181,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   }
   hipLaunchKernelGGL(track_update_kernel, dim3(S), dim3(256), shm, st, A, publish);
   if (publish) {
-    dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, fe->nseg, S);
+    dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
     hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
                        fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
                        fe->seg_cap, fe->n_cand);
@@ -1244,8 +1224,8 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   }
   ld.pyr_bytes = (off + 255) & ~(size_t)255;
   const size_t S = n_seq, px = (size_t)cfg->image_rows * cfg->image_cols, cap = fe->cap;
-  fe->nseg = (cfg->image_rows + kTile - 1) / kTile;
-  fe->seg_cap = kTile * cfg->image_cols / 4;  // a 3x3 local maximum can occupy at most one pixel in four
+  fe->nseg = (cfg->image_rows + kDetR - 1) / kDetR;
+  fe->seg_cap = kDetR * cfg->image_cols / 4;  // a 3x3 local maximum can occupy at most one pixel in four
   int rc = VIO_OK;
   if (hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking) != hipSuccess) rc = VIO_ENODEV;
 #define ALLOC(ptr, count) \
@@ -1483,7 +1463,7 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
   if (hipMemset(fe->max_bits, 0, sizeof(unsigned) * fe->nseg) != hipSuccess ||
       hipMemset(fe->n_cand, 0, sizeof(int) * fe->nseg) != hipSuccess)
     return fail(VIO_ENODEV);
-  dim3 tb(kTile, kTile), tg((cols + kTile - 1) / kTile, fe->nseg, 1);
+  dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, 1);
   hipLaunchKernelGGL(detect_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
                      fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand);
   SelectParams SP;
