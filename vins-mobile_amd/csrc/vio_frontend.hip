@@ -152,11 +152,15 @@ constexpr int kIP = kWin + 3;              // 24: window + 1 (bilinear) + 2 (Sch
 constexpr int kDP = kWin + 1;              // 22: derivative positions
 constexpr int kJMargin = 3;
 constexpr int kJP = kWin + 1 + 2 * kJMargin;  // 28
+constexpr int kJS = kJP + 2;                  // row stride of the staged J region (16-bit elements)
 struct LkWaveLds {
   uint8_t I[kIP][kIP];
   short2 dI[kDP][kDP];
-  uint8_t J[kJP][kJP];
+  // 16 bits per pixel: a 32-bit LDS read at a pixel yields (J[x], J[x+1]) as the two halves of one v_dot2_u32_u16
+  // operand, so a bilinear sample is two reads and two dot instructions (weights < 2^15, products < 2^22)
+  uint16_t J[kJP][kJS];
 };
+typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -180,6 +184,12 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
   const float half = (kWin - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   const int NPX = (kWin * kWin + 63) / 64;  // 7 window pixels per lane
+  int joff[NPX];  // this lane's window pixels as element offsets into the staged J region
+#pragma unroll
+  for (int q = 0; q < NPX; q++) {
+    const int e = min(lane + 64 * q, kWin * kWin - 1);
+    joff[q] = (e / kWin) * kJS + (e % kWin);
+  }
   bool st = true;
   float er = 0.f;
   float nxx = 0.f, nxy = 0.f;
@@ -264,14 +274,18 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
         int ly = e / kJP, lx = e - ly * kJP;
         int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
         int x = reflect101(min(max(jox + lx, -cols + 1), 2 * cols - 2), cols);
-        L.J[ly][lx] = J[(size_t)y * cols + x];
+        L.J[ly][lx] = (uint16_t)J[(size_t)y * cols + x];
       }
       wave_lds_fence();
       j_staged = true;
     };
-    auto sample_j = [&](int iqx, int iqy, int x, int y) {  // bilinear J at window pixel (x, y), staged region
-      int ly = iqy - joy + y, lx = iqx - jox + x;
-      return descale(L.J[ly][lx] * iw00 + L.J[ly][lx + 1] * iw01 + L.J[ly + 1][lx] * iw10 + L.J[ly + 1][lx + 1] * iw11, kWBits - 5);
+    const uint16_t *Jl = &L.J[0][0];
+    auto sample_j = [&](int base, int q, lk_us2 wtop, lk_us2 wbot) {  // bilinear J at this lane's q-th window pixel
+      lk_us2 top, bot;
+      __builtin_memcpy(&top, Jl + base + joff[q], 4);
+      __builtin_memcpy(&bot, Jl + base + joff[q] + kJS, 4);
+      const unsigned acc = __builtin_amdgcn_udot2(top, wtop, __builtin_amdgcn_udot2(bot, wbot, 0u, false), false);
+      return descale((int)acc, kWBits - 5);
     };
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
@@ -283,12 +297,12 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
       int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, 7 pixels per lane: fits 32 bits
+      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
+      const int jbase = (iqy - joy) * kJS + (iqx - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        int e = lane + 64 * q;
-        if (e < kWin * kWin) {
-          int y = e / kWin, x = e - y * kWin;
-          int diff = sample_j(iqx, iqy, x, y) - Iv[q];
+        if (lane + 64 * q < kWin * kWin) {
+          int diff = sample_j(jbase, q, wtop, wbot) - Iv[q];
           pb1 += diff * Ix[q], pb2 += diff * Iy[q];
         }
       }
@@ -315,13 +329,11 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       float aa = ex - iex, bb = ey - iey;
       lk_weights(aa, bb, iw00, iw01, iw10, iw11);
       int pe = 0;
+      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
+      const int jbase = (iey - joy) * kJS + (iex - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        int e = lane + 64 * q;
-        if (e < kWin * kWin) {
-          int y = e / kWin, x = e - y * kWin;
-          pe += abs(sample_j(iex, iey, x, y) - Iv[q]);
-        }
+        if (lane + 64 * q < kWin * kWin) pe += abs(sample_j(jbase, q, wtop, wbot) - Iv[q]);
       }
       const int se = wave_sum_i32(pe);  // <= 441 * 16320 < 2^23
       er = (float)se * 1.f / (32 * kWin * kWin);
