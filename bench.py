@@ -27,6 +27,12 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
+# Memory-side traffic of vio_window_kernel per window from the PMC passes of this very workload
+# (profiles/r01_b_pmc_hbm.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, 256 windows per launch):
+# FETCH_SIZE 923288 KB (doubled: gfx950 reports half the bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 944112 KB.
+# bench.py cannot collect counters itself; the figure is only attached when the profiled configuration is the one run.
+PMC_TRAFFIC_BYTES_PER_WINDOW = (2 * 923288.4 + 944111.8) * 1024.0 / 256.0
+PMC_TRAFFIC_CONFIG = (10, 150)  # (window size, features) the passes were taken on
 
 
 def algorithmic_flops_per_solve(W, M, n_prior, iters):
@@ -59,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sequences", type=int, default=256, help="independent sequences resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
+                    help="1: tracker and solver kernels in order on one HIP stream; 2: each on its own stream")
     ap.add_argument("--only", choices=["both", "frontend", "backend"], default="both",
                     help="profiling aid: run one half alone (the reported value is then NOT the benchmark metric)")
     args = ap.parse_args()
@@ -99,11 +107,15 @@ def main():
     be.upload(windows)
     pingpong = list(range(T)) + list(range(T - 2, 0, -1))  # consecutive frames stay adjacent in time
 
+    # Both halves fill the chip on their own (the solver holds every CU's LDS), so running them back to back on one
+    # stream beats letting two streams interleave their kernels.
+    one = torch.cuda.Stream().cuda_stream if args.streams == 1 else None
+
     def step(k):
         if args.only != "backend":
-            fe.step(pingpong[k % len(pingpong)], publish=True)
+            fe.step(pingpong[k % len(pingpong)], publish=True, stream=one)
         if args.only != "frontend":
-            be.launch()
+            be.launch(stream=one)
 
     for k in range(args.warmup):
         step(k)
@@ -147,8 +159,10 @@ def main():
                        "sequences_per_gpu": S, "gn_iterations": iters, "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms}},
             "roofline": {"kernel": "vio_window_kernel (solve + new2old + marginalization, one workgroup per window)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None},
-            "roofline_frontend": {"kernel": "front-end step (pyr_down + lk_track + track_update + min_eigen + corner select)",
+                         "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": PMC_TRAFFIC_BYTES_PER_WINDOW * S if (cfg.window_size, 150) == PMC_TRAFFIC_CONFIG else None,
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_b_pmc_hbm.txt)"},
+            "roofline_frontend": {"kernel": "front-end step (copy + pyr_down x3 + lk_track + track_update + detect + corner_select)",
                                   "bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
         }

@@ -15,8 +15,11 @@
 //    never stored: ||J_s[:,c]||^2 = scale_c^2 H_cc, J_s^T r = scale g, |J_s v|^2 = v^T (S H S) v.
 //  * Elimination set = all features (1x1 e-blocks); the reduced system is 15(W+1) [+6 loop pose] and lives in LDS
 //    as a block-lower matrix of 15x15 blocks (frame i -> [pose 6 | speed-bias 9]).
-//  * After S = L L^T the quadratic forms v^T (S H S + mu D^2) v that the Cauchy point and model_cost_change need
-//    are evaluated as sum_f e_f (v_f + w_f^T v_p / e_f)^2 + |L^T v_p|^2, so the un-factored matrix is not kept.
+//  * The Jacobi-scaled system (S H S + mu D^2) y = S g is solved as (H + mu C) z = g, C = D^2 / S^2, y = z / s: no
+//    scaling pass over the matrix or the landmark coupling (build_reduced_system).
+//  * After H + mu C = L L^T the quadratic forms v^T (S H S + mu D^2) v that the Cauchy point and model_cost_change
+//    need are evaluated with u = S v as sum_f E_f (u_f + w_f^T u_p / E_f)^2 + |L^T u_p|^2, so the un-factored matrix
+//    is not kept.
 //  * IMUFactor's sqrt_info = LLT(cov^-1).L^T (imu_factor.h:72) is recomputed by the reference on every
 //    Evaluate; it is constant during a solve, so cov^-1 is formed once and H += J^T cov^-1 J, g += J^T cov^-1 r,
 //    cost += r^T cov^-1 r / 2 are used (identical to whitening by any square root of cov^-1).
