@@ -6,10 +6,12 @@
 //   lk_track_kernel        calcOpticalFlowPyrLK, one wave64 per feature, all levels    (feature_tracker.cpp:181)
 //   track_update_kernel    inBorder + reduceVector + findFundamentalMat(RANSAC) [+ rejectWithF, track_cnt++, setMask]
 //                                                                                      (feature_tracker.cpp:183-205,235-255)
-//   paint_mask_kernel      cv::circle(mask, pt, MIN_DIST, 0, -1)                        (feature_tracker.cpp:80)
-//   min_eigen_kernel       cornerMinEigenVal of goodFeaturesToTrack + masked maximum    (feature_tracker.cpp:263)
-//   corner_candidates_kernel / corner_select_kernel   threshold, 3x3 non-max, sorted greedy min-distance pick,
-//                          addPoints, updateID, image_msg                               (feature_tracker.cpp:263-307)
+//   detect_kernel          goodFeaturesToTrack front half, fused: cornerMinEigenVal, masked maximum, 3x3 non-max and
+//                          the setMask discs evaluated analytically (cv::circle(mask, pt, MIN_DIST, 0, -1))
+//                                                                                      (feature_tracker.cpp:80,263)
+//   corner_select_kernel   quality threshold, sorted greedy min-distance pick, addPoints, updateID, image_msg
+//                                                                                      (feature_tracker.cpp:263-307)
+//   copy_frames_kernel     forw_img = _img                                              (feature_tracker.cpp:165-170)
 // Arithmetic follows the OpenCV 3.0 integer/float sequences restated in oracle/vio_oracle_frontend.cpp so the two
 // agree bit for bit; sums that OpenCV accumulates in float (LK's A and b) are accumulated exactly.
 #include <hip/hip_runtime.h>
