@@ -129,3 +129,52 @@ def test_resident_stepping_equals_read_images():
     ms, n = a.kernel_ms()
     assert n == T and ms > 0
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("rows,cols,corners,min_dist,T", [
+    (250, 333, 60, 12, 5),     # neither a multiple of the 32-row strips nor of the 60-column waves of detect_kernel
+    (97, 61, 20, 8, 4),        # one partial strip row, one partial wave; 2 pyramid levels
+    (720, 1280, 300, 30, 3),   # BASELINE configs[2] frame geometry and feature count
+])
+def test_tracker_sequence_other_geometries(rows, cols, corners, min_dist, T):
+    """Tracker state and published observations stay bit-identical to the oracle on frame sizes that leave partial
+    strips / waves / tiles in every kernel."""
+    cfg = abi.default_config(max_corners=corners, min_dist=min_dist, image_rows=rows, image_cols=cols)
+    S = 2
+    streams = [synth.make_image_stream(70 + s, T, rows=rows, cols=cols)[0] for s in range(S)]
+    trk = fe.FeatureTracker(cfg, n_seq=S)
+    oracles = [H.OracleTracker(cfg) for _ in range(S)]
+    for f in range(T):
+        publish = f % 2 == 0
+        got = trk.read_images(np.stack([streams[s][f] for s in range(S)]), publish)
+        for s in range(S):
+            rids, rxyz = oracles[s].read_image(streams[s][f], publish)
+            gids, gxyz = got[s]
+            assert np.array_equal(gids, rids), (f, s)
+            assert np.array_equal(gxyz, rxyz), (f, s)
+            gp, gi, gc = trk.state(s)
+            rp, ri, rc = oracles[s].state()
+            assert np.array_equal(gi, ri) and np.array_equal(gc, rc), (f, s)
+            assert np.array_equal(gp, rp), (f, s, np.abs(gp - rp).max())
+        if publish:
+            assert len(got[0][0]) > corners // 4
+    trk.close()
+    for o in oracles:
+        o.close()
+
+
+def test_good_features_mask_image_odd_size():
+    """Stand-alone goodFeaturesToTrack with a mask IMAGE (detect_kernel<true>) on an odd-sized frame."""
+    rows, cols = 203, 187
+    frames, _ = synth.make_image_stream(91, 1, rows=rows, cols=cols)
+    cfg = abi.default_config(max_corners=80, min_dist=9, image_rows=rows, image_cols=cols)
+    rng = np.random.default_rng(3)
+    m = np.full((rows, cols), 255, np.uint8)
+    for _ in range(12):
+        y, x = rng.integers(0, rows), rng.integers(0, cols)
+        m[max(0, y - 15):y + 15, max(0, x - 20):x + 20] = 0
+    for mask in (None, m):
+        got = fe.good_features(cfg, frames[0], mask, 80)
+        ref = H.oracle_good_features(cfg, frames[0], mask, 80)
+        assert np.array_equal(got, ref)
+    assert len(got) > 10
