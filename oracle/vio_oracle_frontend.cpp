@@ -21,7 +21,8 @@
 //  * setMask's std::sort on track_cnt is likewise unspecified for ties; a stable sort is used.
 //  * 7-point null space: OpenCV takes the last two right singular vectors of the 7x9 system; here the null space
 //    comes from Gauss-Jordan elimination with complete pivoting. The set of candidate F matrices is basis-invariant.
-//  * fewer than 15 correspondences: OpenCV 3.0.0 switches to LMedS; not restated — all points are kept.
+//  * fewer than 15 correspondences: OpenCV 3.0.0 switches to LMedS (fundam.cpp); restated below from the published
+//    3.0.0 algorithm (ptsetreg.cpp LMeDSPointSetRegistrator::run), like the RANSAC path.
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -486,10 +487,95 @@ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : cv_round(num / denom);
 }
 
+// FMEstimatorCallback::computeError for one correspondence (float, as the error Mat is CV_32F)
+float epipolar_error(const double *F, float fx1, float fy1, float fx2, float fy2) {
+  double a, b, c, d1, d2, s1, s2;
+  double x1 = fx1, y1 = fy1, x2 = fx2, y2 = fy2;
+  a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  s2 = 1. / (a * a + b * b);
+  d2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6], b = F[1] * x2 + F[4] * y2 + F[7], c = F[2] * x2 + F[5] * y2 + F[8];
+  s1 = 1. / (a * a + b * b);
+  d1 = x1 * a + y1 * b + c;
+  return (float)std::max(d1 * d1 * s1, d2 * d2 * s2);
+}
+
+// getSubset(..., maxAttempts = 10000), checkPartialSubsets == false (ptsetreg.cpp), shared by both registrators
+bool get_subset(CvRng &rng, const float *m1, const float *m2, int count, float ms1[14], float ms2[14]) {
+  const int model_points = 7, max_attempts = 10000;
+  int idx[7], i = 0, iters = 0;
+  for (; iters < max_attempts; iters++) {
+    for (i = 0; i < model_points && iters < max_attempts;) {
+      int idx_i = 0;
+      for (;;) {
+        idx_i = idx[i] = rng.uniform(0, count);
+        int j;
+        for (j = 0; j < i; j++)
+          if (idx_i == idx[j]) break;
+        if (j == i) break;
+      }
+      ms1[2 * i] = m1[2 * idx_i], ms1[2 * i + 1] = m1[2 * idx_i + 1];
+      ms2[2 * i] = m2[2 * idx_i], ms2[2 * i + 1] = m2[2 * idx_i + 1];
+      i++;
+    }
+    if (i == model_points && (have_collinear(ms1, i) || have_collinear(ms2, i))) continue;
+    break;
+  }
+  return i == model_points && iters < max_attempts;
+}
+
+// LMeDSPointSetRegistrator::run (ptsetreg.cpp, OpenCV 3.0.0): outlierRatio 0.45, niters fixed up front (300 for
+// confidence 0.99 and 7-point models), the model with the smallest median error wins (strictly smaller, so the first
+// of equals), inliers = error <= sigma^2 with sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(median).
+bool fundamental_lmeds(const float *m1, const float *m2, int count, double confidence, uint8_t *out_mask) {
+  const int model_points = 7, max_iters = 1000;
+  const int niters = ransac_update_num_iters(confidence, 0.45, model_points, max_iters);
+  CvRng rng((uint64_t)-1);
+  double min_median = 1.7976931348623157e308, best[9];
+  float ms1[14], ms2[14];
+  std::vector<float> err(count);
+  for (int iter = 0; iter < niters; iter++) {
+    if (!get_subset(rng, m1, m2, count, ms1, ms2)) {
+      if (iter == 0) {
+        for (int q = 0; q < count; q++) out_mask[q] = 1;
+        return false;
+      }
+      break;
+    }
+    double F[27];
+    int nmodels = run7point(ms1, ms2, F);
+    if (nmodels <= 0) continue;
+    for (int k = 0; k < nmodels; k++) {
+      for (int i = 0; i < count; i++) err[i] = epipolar_error(F + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
+      // std::sort(errf.ptr<int>(), ...): the float bit patterns are ordered as integers
+      std::vector<int32_t> bits(count);
+      memcpy(bits.data(), err.data(), sizeof(float) * count);
+      std::sort(bits.begin(), bits.end());
+      memcpy(err.data(), bits.data(), sizeof(float) * count);
+      double median = count % 2 != 0 ? err[count / 2] : (err[count / 2 - 1] + err[count / 2]) * 0.5;
+      if (median < min_median) {
+        min_median = median;
+        memcpy(best, F + 9 * k, sizeof(best));
+      }
+    }
+  }
+  if (min_median < 1.7976931348623157e308) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - model_points)) * std::sqrt(min_median);
+    sigma = std::max(sigma, 0.001);
+    int good = find_inliers(m1, m2, count, best, sigma, out_mask);  // the mask is copied out before `result` is formed
+    return good >= model_points;
+  }
+  for (int q = 0; q < count; q++) out_mask[q] = 1;  // no model at all: the reference would read an empty status vector
+  return false;
+}
+
 // RANSACPointSetRegistrator::run with FMEstimatorCallback, modelPoints 7, maxIters 1000 (ptsetreg.cpp)
 bool fundamental_ransac(const float *m1, const float *m2, int count, double threshold, double confidence, uint8_t *out_mask) {
   const int model_points = 7, max_iters = 1000;
-  if (count < 15) {  // OpenCV 3.0.0 uses LMedS below 15 points (fundam.cpp); not restated
+  if (count < 15) {
+    // findFundamentalMat (fundam.cpp, 3.0.0): "(method & ~3) == FM_RANSAC && npoints >= 15" else LMedS. The tracker only
+    // calls with >= 8 points (feature_tracker.cpp:92,196); fewer than 8 keeps everything (7 would run the plain solver).
+    if (count >= 8) return fundamental_lmeds(m1, m2, count, confidence, out_mask);
     for (int i = 0; i < count; i++) out_mask[i] = 1;
     return false;
   }

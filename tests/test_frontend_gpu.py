@@ -80,8 +80,18 @@ def test_fundamental_ransac_identical(stream):
     got, ref = fe.fundamental_ransac(cfg, p1, p2), H.oracle_ransac(cfg, p1, p2)
     assert np.array_equal(got, ref)
     assert ref.sum() < len(p1) and ref.sum() > len(p1) - 30
-    # fewer than 15 points: everything is kept (LMedS branch of OpenCV 3.0 not restated)
-    assert fe.fundamental_ransac(cfg, p1[:10], p2[:10]).all()
+    # 8..14 points: OpenCV 3.0.0 switches to LMedS (fundam.cpp); below 8 the tracker does not call at all
+    rejected = 0
+    for n in range(8, 15):
+        for off in (0, 20, 40):
+            q1, q2 = p1[off:off + n], p2[off:off + n].copy()
+            if off:
+                q2[n // 2] += np.float32(17.0)  # one gross outlier
+            got, ref = fe.fundamental_ransac(cfg, q1, q2), H.oracle_ransac(cfg, q1, q2)
+            assert np.array_equal(got, ref), (n, off)
+            rejected += int((ref == 0).sum())
+    assert rejected > 0
+    assert fe.fundamental_ransac(cfg, p1[:7], p2[:7]).all()
 
 
 def test_tracker_sequence_matches_oracle():

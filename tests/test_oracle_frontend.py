@@ -83,6 +83,28 @@ def test_ransac_rejects_injected_outliers_only():
     assert (m[good] == 0).sum() <= 2
 
 
+def test_lmeds_branch_below_15_points():
+    """8..14 correspondences take OpenCV 3.0.0's LMedS branch: a gross outlier goes, consistent points stay; below 8
+    points the tracker never calls findFundamentalMat and everything is kept."""
+    frames, _ = synth.make_image_stream(5, 2)
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    p1 = H.oracle_good_features(cfg, frames[0], None, 150)
+    p2, st, _ = H.oracle_klt(cfg, frames[0], frames[1], p1)
+    p1, p2 = p1[st > 0], p2[st > 0].copy()
+    for n in (8, 11, 14):
+        q1, q2 = p1[30:30 + n], p2[30:30 + n].copy()
+        clean = H.oracle_ransac(cfg, q1, q2)
+        # the cut is sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median error): on nearly noise-free tracks it is
+        # tight and drops consistent points too (that is what the 3.0.0 code does); the 7 sample points always survive
+        assert set(np.unique(clean)) <= {0, 1} and clean.sum() >= 7
+        q2[3] += np.float32([13.0, 19.0])
+        m = H.oracle_ransac(cfg, q1, q2)
+        # (with 8 points every 7-subset fits its own points exactly, outlier included: only the larger sets must drop it)
+        assert m.sum() >= 7 and (n < 14 or m[3] == 0)
+        assert np.array_equal(m, H.oracle_ransac(cfg, q1, q2))
+    assert H.oracle_ransac(cfg, p1[:7], p2[:7]).all()
+
+
 def test_tracker_bookkeeping():
     cfg = abi.default_config(max_corners=120, min_dist=25)
     frames, _ = synth.make_image_stream(11, 7)

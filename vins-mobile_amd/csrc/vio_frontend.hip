@@ -461,7 +461,7 @@ __device__ int run7point_dev(const float *ms1, const float *ms2, double *fmatrix
   return n;
 }
 
-__device__ __forceinline__ bool epipolar_inlier(const double *F, float x1f, float y1f, float x2f, float y2f, float t) {
+__device__ __forceinline__ float epipolar_error(const double *F, float x1f, float y1f, float x2f, float y2f) {
   double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f;
   double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
   double s2 = 1. / (a * a + b * b);
@@ -469,8 +469,10 @@ __device__ __forceinline__ bool epipolar_inlier(const double *F, float x1f, floa
   a = F[0] * x2 + F[3] * y2 + F[6], b = F[1] * x2 + F[4] * y2 + F[7], c = F[2] * x2 + F[5] * y2 + F[8];
   double s1 = 1. / (a * a + b * b);
   double d1 = x1 * a + y1 * b + c;
-  float e = (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
-  return e <= t;
+  return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+__device__ __forceinline__ bool epipolar_inlier(const double *F, float x1f, float y1f, float x2f, float y2f, float t) {
+  return epipolar_error(F, x1f, y1f, x2f, y2f) <= t;
 }
 
 __device__ bool have_collinear_dev(const float *p, int count) {
@@ -506,6 +508,7 @@ struct RansacShared {
   unsigned long long rng_state;
   int niters, max_good, best_h, best_k, iter, done, failed_first;
   double bestF[9];
+  double med[kHypBatch][3], min_median;  // LMedS (fewer than 15 correspondences)
 };
 
 // Block-cooperative RANSAC over `count` correspondences (m1, m2 in LDS or global). Writes mask[count] (1 = inlier).
@@ -515,14 +518,20 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
                                          double confidence, uint8_t *mask) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int model_points = 7, max_iters = 1000;
-  if (count < 15) {  // OpenCV 3.0.0 uses LMedS below 15 points: not restated, keep all
+  // findFundamentalMat (fundam.cpp, 3.0.0) runs RANSAC only from 15 points on, LMedS below; the tracker calls with
+  // >= 8 points. LMedS shares the subset stream and the 7-point solver: a fixed number of iterations (300 at
+  // confidence 0.99), the model with the smallest median error wins, inliers are cut at sigma^2 of that median.
+  const bool lmeds = count < 15;
+  if (count < 8) {
     for (int i = tid; i < count; i += nt) mask[i] = 1;
     __syncthreads();
     return;
   }
   if (tid == 0) {
     S.rng_state = 0xffffffffffffffffULL;
-    S.niters = max_iters, S.max_good = 0, S.best_h = -1, S.best_k = 0, S.iter = 0, S.done = 0, S.failed_first = 0;
+    S.niters = lmeds ? ransac_update_iters(confidence, 0.45, model_points, max_iters) : max_iters;
+    S.max_good = 0, S.best_h = -1, S.best_k = 0, S.iter = 0, S.done = 0, S.failed_first = 0;
+    S.min_median = 1.7976931348623157e308;
   }
   __syncthreads();
   const float t = thresh * thresh;
@@ -590,7 +599,22 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       S.good[tid][0] = S.good[tid][1] = S.good[tid][2] = 0;
     }
     __syncthreads();
-    // ---- phase 3: inlier counts for every (hypothesis, model)
+    // ---- phase 3: inlier counts for every (hypothesis, model) [RANSAC] / median error of every model [LMedS]
+    if (lmeds) {
+      for (int hk = tid; hk < kHypBatch * 3; hk += nt) {
+        const int h = hk / 3, k = hk - 3 * h;
+        if (k >= S.nmodels[h]) continue;
+        int bits[14];  // count <= 14; std::sort on the float bit patterns as ints (ptsetreg.cpp)
+        for (int i = 0; i < count; i++) {
+          const int b = __float_as_int(epipolar_error(S.F[h] + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]));
+          int j = i;
+          for (; j > 0 && bits[j - 1] > b; j--) bits[j] = bits[j - 1];
+          bits[j] = b;
+        }
+        S.med[h][k] = (count & 1) ? (double)__int_as_float(bits[count / 2])
+                                  : (double)(__int_as_float(bits[count / 2 - 1]) + __int_as_float(bits[count / 2])) * 0.5;
+      }
+    } else
     for (int item = tid; item < kHypBatch * 3 * count; item += nt) {
       int hk = item / count, i = item - hk * count;
       int h = hk / 3, k = hk - 3 * h;
@@ -608,6 +632,13 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
           break;
         }
         for (int k = 0; k < S.nmodels[h]; k++) {
+          if (lmeds) {
+            if (S.med[h][k] < S.min_median) {
+              S.min_median = S.med[h][k];
+              for (int q = 0; q < 9; q++) S.bestF[q] = S.F[h][9 * k + q];
+            }
+            continue;
+          }
           int good = S.good[h][k];
           if (good > max(S.max_good, model_points - 1)) {
             S.max_good = good;
@@ -623,7 +654,13 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     __syncthreads();
     if (S.done) break;
   }
-  if (S.max_good > 0 && !S.failed_first) {
+  if (lmeds && S.min_median < 1.7976931348623157e308 && !S.failed_first) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (count - model_points)) * sqrt(S.min_median);
+    sigma = fmax(sigma, 0.001);
+    const float ts = (float)(sigma * sigma);
+    for (int i = tid; i < count; i += nt)
+      mask[i] = epipolar_inlier(S.bestF, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1], ts) ? 1 : 0;
+  } else if (!lmeds && S.max_good > 0 && !S.failed_first) {
     for (int i = tid; i < count; i += nt)
       mask[i] = epipolar_inlier(S.bestF, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1], t) ? 1 : 0;
   } else {
