@@ -207,7 +207,9 @@ int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches);
  * 753-758). Enable before vio_backend_upload; read after a launch. Stage order:
  * setup_imu, setup_prior, eval_prior, eval_imu, eval_proj, scale, schur, rhs,
  * cholesky, tri_solve, quad_form, dogleg, cost_eval, new2old, marg_build,
- * marg_chol, total (shader-clock cycles, thread 0 of the window's workgroup).  */
+ * marg_chol, total (shader-clock cycles, thread 0 of the window's workgroup).
+ * Asking for more than VIO_N_STAGES entries also returns the finer sub-stage
+ * breakdown listed in csrc/solver_core.h (Stage enum) / vins-mobile_amd/abi.py. */
 #define VIO_N_STAGES 17
 int vio_backend_set_profile(vio_backend_t *be, int32_t enable);
 int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles, int32_t n_stages);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <limits>
 #include <vector>
 
 #include "batch.h"
@@ -24,11 +25,14 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   int rc = pack_window(hb, 0, *win);
   if (rc != VIO_OK) return rc;
   const BatchStrides &s = hb.s;
-  std::vector<double> scratch(s.scratch), hm(s.hm), out_pose(s.out_pose), out_sb(s.out_sb), out_feat(s.out_feat),
+  // every working buffer starts as NaN: a read of something the solver did not write itself poisons the result
+  // (device LDS / hipMalloc'd scratch hold whatever the previous kernel left there)
+  const double kNaN = std::numeric_limits<double>::quiet_NaN();
+  std::vector<double> scratch(s.scratch, kNaN), hm(s.hm, kNaN), out_pose(s.out_pose), out_sb(s.out_sb), out_feat(s.out_feat),
       raw_pose(s.out_pose), raw_sb(s.out_sb), raw_feat(s.out_feat), out_loop(7), stats_d(s.stats_d);
   std::vector<int> stats_i(s.stats_i);
   MargOut mo;
-  std::vector<double> m_scratch(marg_scratch_doubles(hb.d.Wcap)), m_x0(9 * kMaxPriorBlocks), m_J((size_t)hb.d.Ncap * hb.d.Ncap),
+  std::vector<double> m_scratch(marg_scratch_doubles(hb.d.Wcap), kNaN), m_x0(9 * kMaxPriorBlocks), m_J((size_t)hb.d.Ncap * hb.d.Ncap),
       m_r(hb.d.Ncap);
   std::vector<int> m_int(4 + 3 * kMaxPriorBlocks);
   BatchPtrs B;
@@ -48,7 +52,7 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
 
   WinView v = make_view(B, 0);
   size_t bytes = carve_work<double *>(B.d, true, 64, nullptr, nullptr, nullptr, nullptr);
-  std::vector<double> lds(bytes / sizeof(double) + 2);
+  std::vector<double> lds(bytes / sizeof(double) + 2, kNaN);
   WorkT<double *> w;
   Ctx cx;
   cx.tid = 0, cx.nt = 1, cx.prof = nullptr;
@@ -62,7 +66,7 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   size_t core = carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, 0) / sizeof(double);
   const size_t avail = std::max<size_t>(20480, core + 512 * kMargSlot + 64);
   size_t mbytes = carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, avail);
-  std::vector<double> mlds(mbytes / sizeof(double) + 2);
+  std::vector<double> mlds(mbytes / sizeof(double) + 2, kNaN);
   MargWorkT<double *> mw;
   carve_marg(B.d, true, mlds.data(), nullptr, &mw, avail);
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);

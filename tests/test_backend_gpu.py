@@ -4,6 +4,7 @@ Bars: north_star asks for poses and inverse depths within 1e-4 relative of the r
 fixtures ARE that path's outputs (tests/golden/make_golden.py); the HIP path is held to 1e-6 against them and against
 the CPU oracle on freshly seeded windows."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -127,3 +128,15 @@ def test_error_codes(solver_cache):
     arr2 = (abi.VioWindow * 1)()
     big.fill_struct(arr2[0])
     assert lib.vio_backend_solve_windows(solver._h, arr2, 1, 0, None) == abi.VIO_ECAP  # W=10 into a W=4 context
+
+
+def test_poisoned_device_buffers():
+    """VIO_AMD_POISON=1 fills the whole LDS of every CU and every device scratch / output buffer with NaN patterns before
+    each launch: anything the kernel reads without having written it (LDS and hipMalloc'd scratch keep whatever the
+    previous kernel left) turns the solve into NaNs instead of passing by luck. Own process: the switch is read once."""
+    import subprocess, sys
+    env = dict(os.environ, VIO_AMD_POISON="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "not poisoned and not error_codes", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

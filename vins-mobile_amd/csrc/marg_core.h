@@ -220,7 +220,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     }
     VIO_SYNC();
   }
-  stamp(cx, ST_X8);
+  stamp(cx, ST_M_PRIOR);
   if (flag == 0) {
     // ---- IMUFactor(pre_integrations[1]) on (pose0, sb0, pose1, sb1) ------------------------------------
     if (cx.tid == 0)
@@ -255,7 +255,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       for (int k = 0; k < 15; k++) s += v.imu_J[k * 30 + a] * v.imu_Mr[k];
       VIO_ATOMIC_ADD(m.bm + ca, s);
     }
-    stamp(cx, ST_X9);
+    stamp(cx, ST_M_IMU);
     // ---- projections hosted at frame 0: blocks (pose0, pose_t, extrinsic, feature), Cauchy-corrected
     //      (ResidualBlockInfo::Evaluate, marginalization_factor.cpp:45-76, rho'' < 0 branch).
     //      Same scheme as the solver: rows staged in (0,t)-bucket order, one Gram product per bucket on the matrix
@@ -304,7 +304,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
           v.WT[(6 * t + c) * v.Fpad + f] = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
       }
       VIO_SYNC();
-      stamp(cx, ST_X10);
+      stamp(cx, ST_M_FACT);
       // one element of the three Gram matrices of bucket (0, t)
       auto flush1 = [&](int t, int row, int col, double val) {  // G1^T G1
         const int c0p = m.col_pose[0], ctp = m.col_pose[t];
@@ -373,7 +373,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
         }
       }
 #endif
-      stamp(cx, ST_X11);
+      stamp(cx, ST_M_GRAM);
       // per-feature sums: host coupling, extrinsic coupling, H_ff, g_f
       VIO_PARFOR(f, F) {
         double w0[6] = {0, 0, 0, 0, 0, 0}, wx[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;

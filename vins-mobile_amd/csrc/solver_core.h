@@ -78,9 +78,14 @@ constexpr int kStatsInts = 4 + kMaxTrace;         // iterations, termination, n_
 enum Stage {
   ST_SETUP_IMU = 0, ST_SETUP_PRIOR, ST_EVAL_PRIOR, ST_EVAL_IMU, ST_EVAL_PROJ, ST_SCALE, ST_SCHUR, ST_RHS, ST_CHOL,
   ST_TRISOLVE, ST_QUADFORM, ST_DOGLEG, ST_COST_EVAL, ST_NEW2OLD, ST_MARG_BUILD, ST_MARG_CHOL, ST_TOTAL,
-  ST_P_ZERO, ST_P_FACT, ST_P_GRAM, ST_P_FEAT, ST_C_POTRF, ST_C_TRSM,
-  ST_X0, ST_X1, ST_X2, ST_X3, ST_X4, ST_X5, ST_X6, ST_X7, ST_X8, ST_X9, ST_X10, ST_X11,  // scratch stages for ad-hoc profiling
-  ST_COUNT = 36
+  // finer attribution (sub-stages; their cycles are NOT included in the stages above)
+  ST_P_ZERO, ST_P_FACT, ST_P_GRAM, ST_P_FEAT,      // projection factors: zeroing, evaluation+staging, Gram, per-feature
+  ST_C_POTRF, ST_C_TRSM,                           // Cholesky: first diagonal block, panel
+  ST_IMU_RAW,                                      // raw IMU residual/Jacobian (one thread per factor)
+  ST_C_WAIT, ST_Q_W, ST_BACKSOLVE, ST_C_AHEAD,     // trailing-update wait, W part of quad_form, back-substitution, wave-0 look-ahead
+  ST_TR_VEC,                                       // trust-region vector phase before the linear solve
+  ST_M_PRIOR, ST_M_IMU, ST_M_FACT, ST_M_GRAM,      // marginalization: prior/setup, IMU factor, factor staging, Gram
+  ST_COUNT = 34                                    // (last slot = time of the previous stamp)
 };
 
 struct Ctx {
@@ -1146,7 +1151,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
                  sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
   }
   VIO_SYNC();
-  if (jac) stamp(cx, ST_X0);
+  if (jac) stamp(cx, ST_IMU_RAW);
   VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
     int f = q / 15, r = q % 15;
     const double *info = v.imu_info + f * 225 + r * 15;
@@ -1266,7 +1271,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 template <class WK>
 VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu) {
   const int np = v.np, F = v.F;
-  stamp(cx, ST_X6);
+  stamp(cx, ST_TR_VEC);
   // Ceres solves (S H S + mu D^2) y = S g with the Jacobi scaling S and D^2 = clamp(diag(S H S)). The same system in
   // unscaled unknowns z = S y is (H + mu C) z = g with C = D^2 / S^2 (diagonal): no scaling pass over the matrix or
   // over the landmark coupling W is needed, and y = z / s at the end. (Cholesky is invariant under this diagonal
@@ -1411,7 +1416,8 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
     int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
     double x[kWStrip], s = 0;
-    const int nb = f1 - f0 > 0 ? f1 - f0 : 0;  // <= kWStrip by the choice of nch
+    const int nb = f1 - f0;  // <= kWStrip by the choice of nch
+    if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
     wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
 #pragma unroll
     for (int j = 0; j < kWStrip; j++) s += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
@@ -1478,7 +1484,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
         bool good = potrf15_inv_wave(Dn, Ln, true, w.ldinv + (k + 1) * kBS, lane);
         if (!good && lane == 0) w.flag[1] = 1;
       }
-      stamp(cx, ST_X5);
+      stamp(cx, ST_C_AHEAD);
     } else {
       const int stride = nw - 1;
       for (int pr = wave; pr < npairs; pr += 2 * stride) {
@@ -1496,7 +1502,7 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
       }
     }
     VIO_SYNC();
-    stamp(cx, ST_X2);
+    stamp(cx, ST_C_WAIT);
   }
   return w.flag[1] == 0;
 }
@@ -1662,7 +1668,7 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
     }
     VIO_ATOMIC_ADD(w.tf + f, s);
   }
-  stamp(cx, ST_X3);
+  stamp(cx, ST_Q_W);
   const int nblocks = v.nblk * (v.nblk + 1) / 2;
   VIO_PARFOR(q, nblocks * kBS) {  // (L^T v)_j += sum_r L_(bi,bj)[r][c] v[15 bi + r]
     const int blk = q / kBS, c = q - blk * kBS;
@@ -1811,7 +1817,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         stamp(cx, ST_CHOL);
         if (ok) {
           cholesky_backsolve(cx, v, w, w.t1);  // y_p
-          stamp(cx, ST_X4);
+          stamp(cx, ST_BACKSOLVE);
           // back-substitute features: z_f = (g_f - w_f^T z_p) / E_f ; y = z / s ; GN = -d * y
           double bad = 0;
           VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p from the (feature, part) items

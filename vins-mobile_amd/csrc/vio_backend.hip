@@ -60,6 +60,15 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 }
 
+// Debug aid (VIO_AMD_POISON=1): every launch is preceded by NaN patterns in the whole LDS of every CU and in all device
+// scratch / output buffers, so that a read of something the kernel did not write itself cannot go unnoticed.
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int n_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double poison_smem[];
+  for (int i = threadIdx.x; i < n_doubles; i += blockDim.x) poison_smem[i] = __longlong_as_double(0x7ff8dead0000beefLL);
+  __syncthreads();
+  if (poison_smem[(threadIdx.x * 7) % n_doubles] == 1.0) poison_smem[0] = 2.0;  // keep the stores alive
+}
+
 #define HIP_OK(expr)                                                                       \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
@@ -330,6 +339,15 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
     }
   }
   auto &ev = be->events[be->events_used++];
+  static const bool poison = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
+  if (poison) {
+    HIP_OK(hipMemsetAsync(be->d_scratch.p, 0xff, be->d_scratch.n * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(be->d_hm.p, 0xff, be->d_hm.n * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(be->d_out_pose.p, 0xff, be->d_out_pose.n * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(be->d_stats_d.p, 0xff, be->d_stats_d.n * sizeof(double), st));
+    HIP_OK(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), kLdsLimit, st, (int)(kLdsLimit / sizeof(double)));
+  }
   HIP_OK(hipEventRecord(ev.first, st));
   if (be->lds_matrix) {
     HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
