@@ -168,6 +168,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   ldsd xpose = take(7 * (size_t)(d.Pcap + 1)), xsb = take(9 * (size_t)d.Pcap), xfeat = take(F);
   ldsd ex = take(8);
   ldsd red = take(6 * ((size_t)nthreads / 64) + 2);
+  ldsd lprof = take(ST_COUNT);
   if (state_end_doubles) *state_end_doubles = o;
   ldsd hm = nullptr;
   if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
@@ -193,7 +194,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
     w->ppd = ppd;
     w->rot = rot;
   }
-  if (cx) cx->red = red;
+  if (cx) cx->red = red, cx->lprof = reinterpret_cast<VIO_AS3 long long *>(lprof);
   return o * sizeof(double);
 }
 

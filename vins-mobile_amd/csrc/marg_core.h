@@ -528,9 +528,6 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   if (cx.tid == 0) out.n[0] = n, out.n[1] = nblocks, out.n[2] = mdrop, out.n[3] = pos;
   VIO_SYNC();
   stamp(cx, ST_MARG_CHOL);
-#ifndef VIO_EMUL
-  if (cx.prof && cx.tid == 0) cx.prof[ST_TOTAL] += cx.prof[ST_COUNT - 1];
-#endif
 }
 
 inline void unpack_prior(const MargOut &mo, VioPrior &p) {

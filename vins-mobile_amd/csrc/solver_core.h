@@ -93,15 +93,16 @@ struct Ctx {
   ldsd red;           // LDS scratch for block reductions: two halves of [3 nt/64]
   mutable int red_phase = 0;  // which half the next reduction writes (uniform across the block)
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
+  VIO_AS3 long long *lprof;  // the same counters while the kernel runs (LDS); copied to prof at the end
 };
 
 // Charges the cycles since the previous stamp to `stage` (thread 0 only; call between barriers).
 VIO_DEV void stamp(const Ctx &cx, int stage) {
 #ifndef VIO_EMUL
-  if (cx.prof && cx.tid == 0) {
+  if (cx.prof && cx.tid == 0) {  // accumulators live in LDS (a global read-modify-write per stamp costs ~3k cycles)
     long long t = clock64();
-    cx.prof[stage] += t - cx.prof[ST_COUNT - 1];
-    cx.prof[ST_COUNT - 1] = t;
+    cx.lprof[stage] += t - cx.lprof[ST_COUNT - 1];
+    cx.lprof[ST_COUNT - 1] = t;
   }
 #else
   (void)cx, (void)stage;
@@ -2021,9 +2022,9 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   VIO_SYNC();
 #ifndef VIO_EMUL
   if (cx.prof && cx.tid == 0) {
-    for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = 0;
-    cx.prof[ST_COUNT - 1] = clock64();
-    cx.prof[ST_TOTAL] = -cx.prof[ST_COUNT - 1];
+    for (int q = 0; q < ST_COUNT; q++) cx.lprof[q] = 0;
+    cx.lprof[ST_COUNT - 1] = clock64();
+    cx.lprof[ST_TOTAL] = -cx.lprof[ST_COUNT - 1];
   }
 #endif
   VIO_PARFOR(q, v.nslots) v.sfact[q] = -1;

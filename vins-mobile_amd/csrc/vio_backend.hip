@@ -58,6 +58,10 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   carve_marg(B.d, LDS_MATRIX, lds + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
   __syncthreads();
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
+  if (cx.prof && cx.tid == 0) {  // stage counters: LDS -> global
+    cx.lprof[ST_TOTAL] += clock64();
+    for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = cx.lprof[q];
+  }
 }
 
 // Debug aid (VIO_AMD_POISON=1): every launch is preceded by NaN patterns in the whole LDS of every CU and in all device
