@@ -217,10 +217,11 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     // stage I on [ipx-1, ipx+23) x [ipy-1, ipy+23) (BORDER_REFLECT_101), then its Scharr derivatives on
     // [ipx, ipx+22) x [ipy, ipy+22): zero outside the image (copyMakeBorder BORDER_CONSTANT of derivI)
     wave_lds_fence();  // previous level's readers are done
-    for (int e = lane; e < kIP * kIP; e += 64) {
-      int ly = e / kIP, lx = e - ly * kIP;
-      int y = reflect101(ipy - 1 + ly, rows), x = reflect101(ipx - 1 + lx, cols);
-      L.I[ly][lx] = I[(size_t)y * cols + x];
+    {  // 32 lanes per row (24 used), two rows per trip: the column index is reflected once per lane
+      const int lx = lane & 31;
+      const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
+      if (lx < kIP)
+        for (int ly = lane >> 5; ly < kIP; ly += 2) L.I[ly][lx] = I[(size_t)reflect101(ipy - 1 + ly, rows) * cols + x];
     }
     wave_lds_fence();
     for (int e = lane; e < kDP * kDP; e += 64) {
@@ -272,11 +273,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     auto stage_j = [&](int iqx, int iqy) {
       jox = iqx - kJMargin, joy = iqy - kJMargin;
       wave_lds_fence();
-      for (int e = lane; e < kJP * kJP; e += 64) {
-        int ly = e / kJP, lx = e - ly * kJP;
-        int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
-        int x = reflect101(min(max(jox + lx, -cols + 1), 2 * cols - 2), cols);
-        L.J[ly][lx] = (uint16_t)J[(size_t)y * cols + x];
+      {  // 32 lanes per row (28 used), two rows per trip
+        const int lx = lane & 31;
+        const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
+        if (lx < kJP)
+          for (int ly = lane >> 5; ly < kJP; ly += 2) {
+            const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
+            L.J[ly][lx] = (uint16_t)J[(size_t)y * cols + x];
+          }
       }
       wave_lds_fence();
       j_staged = true;
