@@ -78,7 +78,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: same code path for every world size
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
