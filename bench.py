@@ -156,7 +156,7 @@ def main():
             "dtype": "f64 (solve) / u8+i32+f32 (KLT)", "data": "synthetic",
             "config": {"workload": "configs[1]: 640x480 stream, 150 feats, window=10, ~%d projection factors; every frame "
                                    "published: KLT track + F-RANSAC + detect + 10-iteration window solve + marginalization" % M,
-                       "sequences_per_gpu": S, "gn_iterations": iters, "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms}},
+                       "sequences_per_gpu": S, "preprocessing": "none (the app's CLAHE pre-step is outside readImage)", "gn_iterations": iters, "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms}},
             "roofline": {"kernel": "vio_window_kernel (solve + new2old + marginalization, one workgroup per window)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS,
