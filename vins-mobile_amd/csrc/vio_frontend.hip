@@ -154,13 +154,16 @@ constexpr int kIP = kWin + 3;              // 24: window + 1 (bilinear) + 2 (Sch
 constexpr int kDP = kWin + 1;              // 22: derivative positions
 constexpr int kJMargin = 3;
 constexpr int kJP = kWin + 1 + 2 * kJMargin;  // 28
-constexpr int kJS = kJP + 2;                  // row stride of the staged J region (16-bit elements)
+constexpr int kJS = kJP + 1;                  // row stride of the staged J region (dwords; odd: rows start on different banks)
+constexpr int kIS = kIP + 1;                  // row stride of the staged I patch (dwords)
+// Every staged pixel is ONE ALIGNED DWORD holding the pair (v[x] | v[x+1] << 16): sub-dword and unaligned LDS accesses
+// crawl on this hardware (the byte-array version of this kernel spent 40 % of its wave cycles in LDS issue stalls).
+// A pair is also exactly one v_dot2_u32_u16 operand, so a bilinear sample is two reads and two dot instructions
+// (weights < 2^15, products < 2^22).
 struct LkWaveLds {
-  uint8_t I[kIP][kIP];
+  uint32_t I[kIP][kIS];
   short2 dI[kDP][kDP];
-  // 16 bits per pixel: a 32-bit LDS read at a pixel yields (J[x], J[x+1]) as the two halves of one v_dot2_u32_u16
-  // operand, so a bilinear sample is two reads and two dot instructions (weights < 2^15, products < 2^22)
-  uint16_t J[kJP][kJS];
+  uint32_t J[kJP][kJS];
 };
 typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 
@@ -217,11 +220,15 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     // stage I on [ipx-1, ipx+23) x [ipy-1, ipy+23) (BORDER_REFLECT_101), then its Scharr derivatives on
     // [ipx, ipx+22) x [ipy, ipy+22): zero outside the image (copyMakeBorder BORDER_CONSTANT of derivI)
     wave_lds_fence();  // previous level's readers are done
-    {  // 32 lanes per row (24 used), two rows per trip: the column index is reflected once per lane
+    {  // 32 lanes per row (24 used), two rows per trip: the column index is reflected once per lane; the right-hand
+       // neighbour of every pixel comes from the next lane (DPP wave_shl) so that a pair can be stored as one dword
       const int lx = lane & 31;
       const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
-      if (lx < kIP)
-        for (int ly = lane >> 5; ly < kIP; ly += 2) L.I[ly][lx] = I[(size_t)reflect101(ipy - 1 + ly, rows) * cols + x];
+      for (int ly = lane >> 5; ly < kIP; ly += 2) {
+        const int v = I[(size_t)reflect101(ipy - 1 + ly, rows) * cols + x];
+        const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
+        if (lx < kIP) L.I[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
+      }
     }
     wave_lds_fence();
     for (int e = lane; e < kDP * kDP; e += 64) {
@@ -230,9 +237,11 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       short2 d = make_short2(0, 0);
       if (X >= 0 && X < cols && Y >= 0 && Y < rows) {
         // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
-        int p00 = L.I[ly][lx], p01 = L.I[ly][lx + 1], p02 = L.I[ly][lx + 2];
-        int p10 = L.I[ly + 1][lx], p12 = L.I[ly + 1][lx + 2];
-        int p20 = L.I[ly + 2][lx], p21 = L.I[ly + 2][lx + 1], p22 = L.I[ly + 2][lx + 2];
+        const uint32_t a0 = L.I[ly][lx], a1 = L.I[ly][lx + 1], b0 = L.I[ly + 1][lx], b1 = L.I[ly + 1][lx + 1],
+                       c0 = L.I[ly + 2][lx], c1 = L.I[ly + 2][lx + 1];
+        int p00 = a0 & 0xffff, p01 = a0 >> 16, p02 = a1 >> 16;
+        int p10 = b0 & 0xffff, p12 = b1 >> 16;
+        int p20 = c0 & 0xffff, p21 = c0 >> 16, p22 = c1 >> 16;
         d.x = (short)(3 * (p02 - p00) + 10 * (p12 - p10) + 3 * (p22 - p20));
         d.y = (short)(3 * (p20 - p00) + 10 * (p21 - p01) + 3 * (p22 - p02));
       }
@@ -248,7 +257,8 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       Iv[q] = Ix[q] = Iy[q] = 0;
       if (e < kWin * kWin) {
         int y = e / kWin, x = e - y * kWin;
-        int ival = descale(L.I[y + 1][x + 1] * iw00 + L.I[y + 1][x + 2] * iw01 + L.I[y + 2][x + 1] * iw10 + L.I[y + 2][x + 2] * iw11,
+        const uint32_t it = L.I[y + 1][x + 1], ib = L.I[y + 2][x + 1];  // (I[x+1], I[x+2]) of the two rows
+        int ival = descale((int)((it & 0xffff) * iw00 + (it >> 16) * iw01 + (ib & 0xffff) * iw10 + (ib >> 16) * iw11),
                            kWBits - 5);
         short2 d00 = L.dI[y][x], d01 = L.dI[y][x + 1], d10 = L.dI[y + 1][x], d11 = L.dI[y + 1][x + 1];
         int ixval = descale(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, kWBits);
@@ -273,23 +283,25 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     auto stage_j = [&](int iqx, int iqy) {
       jox = iqx - kJMargin, joy = iqy - kJMargin;
       wave_lds_fence();
-      {  // 32 lanes per row (28 used), two rows per trip
+      {  // 32 lanes per row (28 used), two rows per trip; pairs (J[x] | J[x+1] << 16) like the template patch
         const int lx = lane & 31;
         const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
-        if (lx < kJP)
-          for (int ly = lane >> 5; ly < kJP; ly += 2) {
-            const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
-            L.J[ly][lx] = (uint16_t)J[(size_t)y * cols + x];
-          }
+        for (int ly = lane >> 5; ly < kJP; ly += 2) {
+          const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
+          const int v = J[(size_t)y * cols + x];
+          const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
+          if (lx < kJP) L.J[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
+        }
       }
       wave_lds_fence();
       j_staged = true;
     };
-    const uint16_t *Jl = &L.J[0][0];
+    const uint32_t *Jl = &L.J[0][0];
     auto sample_j = [&](int base, int q, lk_us2 wtop, lk_us2 wbot) {  // bilinear J at this lane's q-th window pixel
       lk_us2 top, bot;
-      __builtin_memcpy(&top, Jl + base + joff[q], 4);
-      __builtin_memcpy(&bot, Jl + base + joff[q] + kJS, 4);
+      const uint32_t t32 = Jl[base + joff[q]], b32 = Jl[base + joff[q] + kJS];
+      __builtin_memcpy(&top, &t32, 4);
+      __builtin_memcpy(&bot, &b32, 4);
       const unsigned acc = __builtin_amdgcn_udot2(top, wtop, __builtin_amdgcn_udot2(bot, wbot, 0u, false), false);
       return descale((int)acc, kWBits - 5);
     };
