@@ -64,7 +64,7 @@ constexpr int kPdW = 64, kPdH = 8;
 __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *src_base, uint8_t *dst_base, size_t seq_stride,
                                                        int srows, int scols, int drows, int dcols) {
   constexpr int SW = 2 * kPdW + 4, SH = 2 * kPdH + 4;
-  __shared__ uint8_t patch[SH][SW + 4];
+  __shared__ int patch[SH][SW + 1];  // one dword per pixel: sub-dword LDS accesses are slow on this hardware
   __shared__ int hsum[SH][kPdW + 1];
   const uint8_t *src = src_base + (size_t)blockIdx.z * seq_stride;
   uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *src_base, 
   __syncthreads();
   for (int e = tid; e < SH * kPdW; e += 256) {
     int ly = e / kPdW, lx = e - ly * kPdW;
-    const uint8_t *r = &patch[ly][2 * lx];
+    const int *r = &patch[ly][2 * lx];
     hsum[ly][lx] = r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4];
   }
   __syncthreads();
@@ -530,8 +530,9 @@ struct RansacShared {
 // Block-cooperative RANSAC over `count` correspondences (m1, m2 in LDS or global). Writes mask[count] (1 = inlier).
 // Exactly reproduces the sequential loop of RANSACPointSetRegistrator::run: subsets are drawn in order from one RNG
 // stream; hypotheses are evaluated a batch at a time and then scanned in order with the adaptive iteration bound.
+template <class MaskT>
 __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const float *m2, int count, float thresh,
-                                         double confidence, uint8_t *mask) {
+                                         double confidence, MaskT *mask) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int model_points = 7, max_iters = 1000;
   // findFundamentalMat (fundam.cpp, 3.0.0) runs RANSAC only from 15 points on, LMedS below; the tracker calls with
@@ -707,7 +708,7 @@ struct TrackerArrays {
 struct TrackShared {
   float pre[kMaxCap][2], cur[kMaxCap][2], forw[kMaxCap][2];
   int ids[kMaxCap], cnt[kMaxCap];
-  uint8_t keep[kMaxCap];
+  int keep[kMaxCap];  // (dword flags: sub-dword LDS accesses are slow)
   int pos[kMaxCap];
   float t_pre[kMaxCap][2], t_cur[kMaxCap][2], t_forw[kMaxCap][2];
   int t_ids[kMaxCap], t_cnt[kMaxCap];
@@ -715,7 +716,6 @@ struct TrackShared {
   int order[kMaxCap];
   int ixy[kMaxCap][2];
   unsigned long long inside[kMaxCap][kMaxCap / 64];
-  uint8_t kept[kMaxCap];
 };
 
 __device__ void compact_block(TrackShared &T) {
