@@ -905,31 +905,38 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   __shared__ unsigned long long s_mask[kDetWaves][kDetR];
   __shared__ unsigned long long s_cand[kCandLds];
   __shared__ unsigned smax;
-  __shared__ int s_ncand, s_base;
+  __shared__ int s_ncand, s_base, s_ndisc;
+  __shared__ int2 s_disc[kMaxCap];
   const int seq = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint8_t *img = img_base + (size_t)seq * img_stride;
   const int XB = blockIdx.x * (kDetWaves * kDetW), Y0 = blockIdx.y * kDetR;
   const int X0 = XB + wave * kDetW;  // first output column of this wave; lane l <-> extended column X0 - 2 + l
-  if (tid == 0) smax = 0, s_ncand = 0;
+  if (tid == 0) smax = 0, s_ncand = 0, s_ndisc = 0;
   if (tid < kDetWaves * kDetR) s_mask[tid / kDetR][tid % kDetR] = 0ull;
   __syncthreads();
   if (!IMG_MASK) {
     // disc rows that cross this workgroup's strip -> bits of the (wave, row) words
-    const int nk = n_kept[seq], span = 2 * radius + 1;
-    for (int k = 0; k < nk; k++) {
+    // (1) every thread tests one kept feature against the strip, the few that touch it are listed in LDS;
+    // (2) one item per (listed disc, strip row, wave) ORs the lanes the disc covers on that row.
+    const int nk = n_kept[seq];
+    for (int k = tid; k < nk; k += 256) {
       const int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
-      if (cy + radius < Y0 || cy - radius >= Y0 + kDetR || cx + radius < XB - 2 || cx - radius >= XB + kDetWaves * kDetW + 2)
-        continue;  // uniform across the workgroup
-      for (int it = tid; it < span * kDetWaves; it += 256) {
-        const int dyi = it % span, wv = it / span;
-        const int r = cy + dyi - radius - Y0;
-        if (r < 0 || r >= kDetR) continue;
-        const int h = hw[dyi];
-        const int l0 = max(cx - h - (XB + wv * kDetW - 2), 0), l1 = min(cx + h - (XB + wv * kDetW - 2), 63);
-        if (l0 > l1) continue;
-        const unsigned long long bits = (l1 - l0 == 63 ? ~0ull : ((1ull << (l1 - l0 + 1)) - 1ull)) << l0;
-        atomicOr(&s_mask[wv][r], bits);
+      if (cy + radius >= Y0 && cy - radius < Y0 + kDetR && cx + radius >= XB - 2 && cx - radius < XB + kDetWaves * kDetW + 2) {
+        const int slot = atomicAdd(&s_ndisc, 1);
+        s_disc[slot] = make_int2(cx, cy);  // (at most cap entries: every feature at most once)
       }
+    }
+    __syncthreads();
+    const int nd = s_ndisc;
+    for (int it = tid; it < nd * kDetR * kDetWaves; it += 256) {
+      const int wv = it % kDetWaves, r = (it / kDetWaves) % kDetR, dsc = it / (kDetWaves * kDetR);
+      const int cx = s_disc[dsc].x, dy = Y0 + r - s_disc[dsc].y;
+      if (dy < -radius || dy > radius) continue;
+      const int h = hw[radius + dy];
+      const int l0 = max(cx - h - (XB + wv * kDetW - 2), 0), l1 = min(cx + h - (XB + wv * kDetW - 2), 63);
+      if (l0 > l1) continue;
+      const unsigned long long bits = (l1 - l0 == 63 ? ~0ull : ((1ull << (l1 - l0 + 1)) - 1ull)) << l0;
+      atomicOr(&s_mask[wv][r], bits);
     }
     __syncthreads();
   }
