@@ -518,6 +518,7 @@ struct RansacShared {
   double F[kHypBatch][27];
   int nmodels[kHypBatch];
   int good[kHypBatch][3];
+  int idx[kHypBatch][7];  // drawn point indices of the batch
   int valid[kHypBatch];  // subset found
   int coll[kHypBatch];   // speculative subset failed checkSubset
   unsigned long long rng_before[kHypBatch];
@@ -581,12 +582,38 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       return (i == model_points && iters < max_attempts) ? 1 : 0;
     };
     if (tid == 0) {
+      // the serial part is the RNG stream only: indices go to LDS, the points are gathered by all threads afterwards.
+      // x % count without an integer division: q = umulhi(x, floor((2^32 - 1) / count)) underestimates the quotient
+      // by at most 2.
+      const unsigned ucount = (unsigned)count, magic = 0xffffffffu / ucount;
       unsigned long long st = S.rng_state;
       for (int h = 0; h < kHypBatch; h++) {
         S.rng_before[h] = st;
-        S.valid[h] = draw(st, h, false);
+        int idx[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          for (;;) {
+            st = (unsigned long long)(unsigned)st * 4164903690U + (unsigned)(st >> 32);
+            const unsigned x = (unsigned)st;
+            unsigned r = x - __umulhi(x, magic) * ucount;
+            r = r >= ucount ? r - ucount : r;
+            r = r >= ucount ? r - ucount : r;
+            bool dup = false;
+#pragma unroll
+            for (int j = 0; j < i; j++) dup |= (int)r == idx[j];
+            if (!dup) { idx[i] = (int)r; break; }
+          }
+          S.idx[h][i] = idx[i];
+        }
+        S.valid[h] = 1;  // (count >= 8 distinct points exist: the attempt cap of getSubset cannot trigger without checks)
       }
       S.rng_state = st;
+    }
+    __syncthreads();
+    for (int it = tid; it < kHypBatch * 7; it += nt) {
+      const int h = it / 7, i = it - 7 * h, id = S.idx[h][i];
+      S.ms1[h][2 * i] = m1[2 * id], S.ms1[h][2 * i + 1] = m1[2 * id + 1];
+      S.ms2[h][2 * i] = m2[2 * id], S.ms2[h][2 * i + 1] = m2[2 * id + 1];
     }
     __syncthreads();
     if (tid < kHypBatch) S.coll[tid] = (have_collinear_dev(S.ms1[tid], 7) || have_collinear_dev(S.ms2[tid], 7)) ? 1 : 0;
