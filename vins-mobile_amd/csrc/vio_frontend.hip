@@ -1215,6 +1215,10 @@ struct vio_frontend {
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
+  // host-buffer path (vio_frontend_read_images): device staging for the frames, pinned memory for the observations
+  uint8_t *d_stage = nullptr;
+  VioObs *p_obs = nullptr;
+  int *p_nobs = nullptr;
   // host staging
   std::vector<VioObs> h_obs;
   std::vector<int> h_nobs;
@@ -1382,6 +1386,8 @@ void vio_frontend_destroy(vio_frontend_t *fe) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto &e : fe->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
+  if (fe->d_stage) (void)hipFree(fe->d_stage);
+  if (fe->p_obs) (void)hipHostFree(fe->p_obs);
   if (fe->stream) (void)hipStreamDestroy(fe->stream);
   delete fe;
 }
@@ -1447,24 +1453,29 @@ int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t ro
   if (!fe || !gray || !n_obs || (publish && !out_obs)) return VIO_EINVAL;
   if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
   const size_t px = (size_t)rows * cols, S = fe->n_seq;
-  // stage through the eig buffer's tail? no: use a dedicated transient allocation (this path is not the throughput path)
-  uint8_t *d = nullptr;
-  if (dev_alloc(&d, S * px) != VIO_OK) return VIO_ENOMEM;
-  hipError_t e = hipMemcpy2D(d, cols, gray, stride, cols, S * rows, hipMemcpyHostToDevice);
-  int rc = e == hipSuccess ? fe_step(fe, d, publish, fe->stream) : VIO_ENODEV;
-  if (rc == VIO_OK && hipStreamSynchronize(fe->stream) != hipSuccess) rc = VIO_ENODEV;
-  (void)hipFree(d);
-  if (rc != VIO_OK) return rc;
-  for (size_t s = 0; s < S; s++) n_obs[s] = 0;
-  if (publish) {
-    fe->h_obs.resize(S * fe->cap), fe->h_nobs.resize(S);
-    HIP_OK(hipMemcpy(fe->h_obs.data(), fe->obs, sizeof(VioObs) * S * fe->cap, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(fe->h_nobs.data(), fe->n_obs, sizeof(int) * S, hipMemcpyDeviceToHost));
-    for (size_t s = 0; s < S; s++) {
-      n_obs[s] = fe->h_nobs[s];
-      memcpy(out_obs + s * fe->cap, fe->h_obs.data() + s * fe->cap, sizeof(VioObs) * fe->h_nobs[s]);
-    }
+  // host frames land in a device staging buffer kept for the life of the context; observations come back through
+  // pinned host memory (no allocation, no pageable bounce on the return path)
+  if (!fe->d_stage && dev_alloc(&fe->d_stage, S * px) != VIO_OK) return VIO_ENOMEM;
+  if (!fe->p_obs) {
+    if (hipHostMalloc((void **)&fe->p_obs, sizeof(VioObs) * S * fe->cap + sizeof(int) * S, hipHostMallocDefault) != hipSuccess)
+      return VIO_ENOMEM;
+    fe->p_nobs = reinterpret_cast<int *>(fe->p_obs + S * fe->cap);
   }
+  hipStream_t st = fe->stream;
+  HIP_OK(hipMemcpy2DAsync(fe->d_stage, cols, gray, stride, cols, S * rows, hipMemcpyHostToDevice, st));
+  int rc = fe_step(fe, fe->d_stage, publish, st);
+  if (rc != VIO_OK) return rc;
+  if (publish) {
+    HIP_OK(hipMemcpyAsync(fe->p_obs, fe->obs, sizeof(VioObs) * S * fe->cap, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(fe->p_nobs, fe->n_obs, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  }
+  HIP_OK(hipStreamSynchronize(st));
+  for (size_t s = 0; s < S; s++) n_obs[s] = 0;
+  if (publish)
+    for (size_t s = 0; s < S; s++) {
+      n_obs[s] = fe->p_nobs[s];
+      memcpy(out_obs + s * fe->cap, fe->p_obs + s * fe->cap, sizeof(VioObs) * fe->p_nobs[s]);
+    }
   return VIO_OK;
 }
 
