@@ -683,73 +683,6 @@ VIO_DEV void sqrt_rsqrt(double x, double &d, double &inv) {
   d = s, inv = y;
 }
 
-// C(15x15) -= A(15x15) B(15x15)^T with four MFMAs (blocks padded to 16 with zeros on the fly).
-template <class MP>
-VIO_DEV void mfma_block_update(MP C, MP A, MP B, int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    int kk = 4 * s + kq;
-    bool ok = (i < kBS) && (kk < kBS);
-    int idx = ok ? i * kBS + kk : 0;
-    double a = A[idx], b = B[idx];
-    a = ok ? a : 0.0, b = ok ? b : 0.0;
-    acc = mfma_f64(a, b, acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    int row = kq + 4 * r;
-    if (row < kBS && i < kBS) C[row * kBS + i] -= acc[r];
-  }
-}
-
-// Cholesky of one 15x15 diagonal block by ONE wave: lane r keeps row r in registers, pivots travel through
-// v_readlane. Writes L (lower) back and 1/L_cc to ldinv_k. Returns false if a pivot is <= 0.
-template <class MP>
-VIO_DEV bool potrf15_wave(MP D, ldsd ldinv_k, int lane) {
-  double a[kBS];
-#pragma unroll
-  for (int c = 0; c < kBS; c++) a[c] = (lane < kBS && c <= lane) ? D[(lane < kBS ? lane : 0) * kBS + c] : 0.0;
-  bool good = true;
-#pragma unroll
-  for (int c = 0; c < kBS; c++) {
-    double x = lane_bcast(a[c], c);
-    good = good && (x > 0.0);
-    double d, inv;
-    sqrt_rsqrt(x, d, inv);
-    a[c] = (lane == c) ? d : a[c] * inv;
-    if (lane == c) ldinv_k[c] = inv;
-#pragma unroll
-    for (int j = c + 1; j < kBS; j++) {
-      double ljc = lane_bcast(a[c], j);
-      a[j] = fma(-a[c], ljc, a[j]);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < kBS; c++)
-    if (lane < kBS && c <= lane) D[lane * kBS + c] = a[c];
-  return good;
-}
-
-// x <- L_kk^-T x for one diagonal block by one wave: lane c keeps column c of L.
-template <class MP>
-VIO_DEV void trsv15T_wave(MP D, cldsd ldinv_k, ldsd x, int lane) {
-  double col[kBS];
-  const int lc = lane < kBS ? lane : 0;
-#pragma unroll
-  for (int r = 0; r < kBS; r++) col[r] = (lane < kBS && r >= lane) ? D[r * kBS + lc] : 0.0;
-  double acc = lane < kBS ? x[lc] : 0.0;
-  const double di = lane < kBS ? ldinv_k[lc] : 0.0;
-#pragma unroll
-  for (int r = kBS - 1; r >= 0; r--) {
-    double xr = lane_bcast(acc * di, r);  // x_r is final once every x_{r'>r} has been subtracted
-    if (lane == r) acc = xr;              // keep the solved value
-    else acc = fma(-col[r], xr, acc);     // lanes c < r: y_c -= L[r][c] x_r  (col[r] = 0 for lanes >= r)
-  }
-  if (lane < kBS) x[lane] = acc;
-}
-
 // Operand fetch for C -= A B^T on 15x15 row-major blocks: lane l supplies X[l&15][4s + (l>>4)] (zero-padded to 16).
 template <class MP>
 VIO_DEV void load_operand15(MP X, int lane, double out[4]) {
