@@ -183,6 +183,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   ldsd flag = take(2);
   ldsd ppd = take(36 * (size_t)(d.Pcap + 1));
   ldsd rot = take(9 * (size_t)(d.Pcap + 2));
+  ldsd fh = take((F + 1) / 2 + 1);
   if (w) {
     w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
@@ -193,6 +194,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
     w->prcol = reinterpret_cast<ldsi>(prcol), w->flag = reinterpret_cast<ldsi>(flag);
     w->ppd = ppd;
     w->rot = rot;
+    w->fh = reinterpret_cast<ldsi>(fh);
   }
   if (cx) cx->red = red, cx->lprof = reinterpret_cast<VIO_AS3 long long *>(lprof);
   return o * sizeof(double);

@@ -171,6 +171,7 @@ struct WorkT {
   ldsd prdx, prr;           // prior dx / residual: prior_n each
   ldsi prcol;               // prior column -> reduced parameter (-1 constant): prior_n
   ldsi flag;                // [4] block-uniform flags
+  ldsi fh;                  // F: host frame of every feature (-1: it has no factor)
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
   ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
 };
@@ -852,10 +853,11 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   auto G = w.Hm;
   const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
   const int CH = (nmat / kSlotStride) & ~1;
-  // per-feature sums of this thread's feature (valid when F <= nt: feature f <-> thread f), carried across chunks
-  double fwh[6] = {0, 0, 0, 0, 0, 0}, fe = 0, fgf = 0;
-  int fh = -1;
-  const bool one_thread_per_feature = v.F <= (int)cx.nt;
+  // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
+  // are gathered with LDS atomics by the factor threads themselves. The six components of w_h use six F-vectors that
+  // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
+  // scratch of the previous linear solve are all recomputed before their next use): see evaluate().
+  ldsd whv[6] = {w.cfeat, w.stf, w.gnf, w.tf, w.ef, w.einv};
   for (int c0 = 0; c0 < v.nslots; c0 += CH) {
     stamp(cx, ST_P_ZERO);
     const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
@@ -878,12 +880,17 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
       }
       // target-frame coupling w_t = Jj^T Jl: one writer per (feature, frame)
+      const double s2 = sr * sr;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
-        double val = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
+        double val = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * s2;
         v.WT[(6 * t + c) * v.Fpad + f] = val;
         v.WTf[f * v.n6cap + 6 * t + c] = val;
       }
+      VIO_ATOMIC_ADD(w.hff + f, (Jl[0] * Jl[0] + Jl[1] * Jl[1]) * s2);
+      VIO_ATOMIC_ADD(w.gf + f, (Jl[0] * r[0] + Jl[1] * r[1]) * s2);
+#pragma unroll
+      for (int c = 0; c < 6; c++) VIO_ATOMIC_ADD(whv[c] + f, (Ji[c] * Jl[0] + Ji[6 + c] * Jl[1]) * s2);
     }
     VIO_SYNC();
     stamp(cx, ST_P_FACT);
@@ -948,53 +955,17 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
 #endif
     VIO_SYNC();
     stamp(cx, ST_P_GRAM);
-    // per-feature sums over the feature's factors staged in this chunk: w_h += Ji^T Jl, H_ff += Jl^T Jl, g_f += Jl^T r
-    VIO_PARFOR(f, v.F) {
-      double wh[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;
-      int h = -1;
-      for (int k = v.fstart[f]; k < v.fstart[f + 1]; k++) {
-        const int slot = v.fslot[k] - c0;
-        if (slot < 0 || slot >= CH) continue;
-        h = v.fhost[k];
-        auto g = G + slot * kSlotStride;
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-          double jl = g[rr * kRowLen + 13];
-#pragma unroll
-          for (int c = 0; c < 6; c++) wh[c] += g[rr * kRowLen + c] * jl;
-          e += jl * jl, gf += jl * g[rr * kRowLen + 12];
-        }
-      }
-      if (one_thread_per_feature) {
-        if (h >= 0) {
-          fh = h, fe += e, fgf += gf;
-#pragma unroll
-          for (int c = 0; c < 6; c++) fwh[c] += wh[c];
-        }
-      } else if (h >= 0) {  // more features than threads: accumulate through memory (entries were zeroed)
-        w.hff[f] += e, w.gf[f] += gf;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          double val = wh[c];
-          v.WT[(6 * h + c) * v.Fpad + f] += val;
-          v.WTf[f * v.n6cap + 6 * h + c] += val;
-        }
-      }
-    }
-    VIO_SYNC();
     stamp(cx, ST_P_FEAT);
   }
-  if (one_thread_per_feature && (int)cx.tid < v.F) {
-    const int f = cx.tid;
-    w.hff[f] = fe, w.gf[f] = fgf;
-    if (fh >= 0) {
-#pragma unroll
+  // host-frame coupling of every feature: LDS sums -> both layouts of W
+  VIO_PARFOR(f, v.F) {
+    const int h = w.fh[f];
+    if (h >= 0)
       for (int c = 0; c < 6; c++) {
-        double val = fwh[c];
-        v.WT[(6 * fh + c) * v.Fpad + f] = val;
-        v.WTf[f * v.n6cap + 6 * fh + c] = val;
+        const double val = whv[c][f];
+        v.WT[(size_t)(6 * h + c) * v.Fpad + f] = val;
+        v.WTf[(size_t)f * v.n6cap + 6 * h + c] = val;
       }
-    }
   }
   return cost;
 }
@@ -1015,8 +986,11 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
   if (jac) {
     const int nF = v.P + v.has_loop;
     VIO_PARFOR(q, np) w.gp[q] = 0.0;
-    VIO_PARFOR(q, v.F) w.gf[q] = 0.0, w.hff[q] = 0.0;
-    if (!have_scale || v.F > (int)cx.nt) {
+    VIO_PARFOR(q, v.F) {
+      w.gf[q] = 0.0, w.hff[q] = 0.0;
+      w.cfeat[q] = w.stf[q] = w.gnf[q] = w.tf[q] = w.ef[q] = w.einv[q] = 0.0;  // w_h accumulators (projections_jac)
+    }
+    if (!have_scale) {
       // the (feature, frame) entries every evaluation writes are the same; they are all assigned (not accumulated)
       // when each feature has its own thread, so zeroing is needed once (first evaluation of the solve)
       VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
@@ -1963,6 +1937,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   VIO_PARFOR(q, v.nslots) v.sfact[q] = -1;
   VIO_SYNC();
   VIO_PARFOR(k, v.M) v.sfact[v.fslot[k]] = k;
+  VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
   setup_imu_info(cx, v, w.Hm);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, v, w);
