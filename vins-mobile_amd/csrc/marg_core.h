@@ -202,18 +202,12 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       else if (kind == 1) prior_block_dx(9, xsb + 9 * idx, x0, m.prdx + o);
       else prior_block_dx(7, ex, x0, m.prdx + o);
     }
+    VIO_PARFOR(i, pn) m.prr[i] = v.pr_r[i];
     VIO_SYNC();
-    VIO_PARFOR(i, pn) {
-      double s = v.pr_r[i];
-      for (int j = 0; j < pn; j++) s += v.prJT[j * pn + i] * m.prdx[j];
-      m.prr[i] = s;
-    }
+    dense_matvec_cols(cx, v.prJT, pn, m.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(m.prr + i, sacc); });
     VIO_SYNC();
-    VIO_PARFOR(a, pn) {
-      double g = 0;
-      for (int k = 0; k < pn; k++) g += v.pr_J[k * pn + a] * m.prr[k];
-      m.bm[m.pcol[a]] = g;
-    }
+    // (bm was zeroed above and every prior column owns its dense column)
+    dense_matvec_cols(cx, v.pr_J, pn, m.prr, [&](int a, double g) { VIO_ATOMIC_ADD(m.bm + m.pcol[a], g); });
     VIO_PARFOR(q, pn * pn) {
       int a = q / pn, b = q % pn;
       m.Am[m.pcol[a] * ld + m.pcol[b]] = v.prH0[q];

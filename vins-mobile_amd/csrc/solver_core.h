@@ -279,6 +279,28 @@ VIO_DEV void wt_parts(int nt, int F, int n6, int &nparts, int &per) {
   per = (n6 + nparts - 1) / nparts;
 }
 
+// y[c] += sum_k M[k][c] x[k] for a dense n x n matrix in global memory (the prior's J0 / J0^T): (column, part) items with
+// neighbouring lanes on neighbouring columns (coalesced), a strip of k fetched at once, partial sums through add(c, s).
+template <class XP, class ADD>
+VIO_DEV void dense_matvec_cols(const Ctx &cx, const double *M, int n, XP x, ADD add) {
+  int nparts = (int)cx.nt / (n > 0 ? n : 1);
+  const int need = (n + 4 * kWStrip - 1) / (4 * kWStrip);
+  nparts = nparts < need ? need : (nparts > 8 ? 8 : nparts);
+  const int per = (n + nparts - 1) / nparts;
+  VIO_PARFOR(q, n * nparts) {
+    const int part = q / n, c = q - part * n;
+    const int k0 = part * per, k1 = k0 + per < n ? k0 + per : n;
+    double xs[kWStrip], s = 0;
+    for (int b0 = k0; b0 < k1; b0 += kWStrip) {
+      const int nb = k1 - b0 < kWStrip ? k1 - b0 : kWStrip;
+      wt_strip_load(M + (size_t)b0 * n + c, (size_t)n, nb, xs);
+#pragma unroll
+      for (int j = 0; j < kWStrip; j++) s += (j < nb ? xs[j] : 0.0) * x[b0 + (j < nb ? j : 0)];
+    }
+    if (k1 > k0) add(c, s);
+  }
+}
+
 // ProjectionFactor::Evaluate (projection_facor.cpp:16-99) in local coordinates. Jex optional.
 template <class PA, class PE>
 VIO_DEV void projection_eval(double s_info, PA pose_i, PA pose_j, PE ex, double inv_dep, const double *pts_i,
@@ -644,15 +666,26 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
     else if (kind == 1)
       for (int k = 0; k < 9; k++) w.prcol[o + k] = off_sb(idx) + k;
   }
+  // J0 goes through the (still unused) matrix buffer when it fits: n^2 serial dot products over global memory cost a
+  // ~3k-cycle round trip per handful of terms, over LDS a few cycles
+  const bool stage = (size_t)n * n <= (size_t)v.nblk * (v.nblk + 1) / 2 * kBB;
+  auto Js = w.Hm;
   VIO_PARFOR(q, n * n) {
     int r = q / n, c = q % n;
-    v.prJT[c * n + r] = v.pr_J[q];
+    const double x = v.pr_J[q];
+    v.prJT[c * n + r] = x;
+    if (stage) Js[q] = x;
   }
   VIO_SYNC();
   VIO_PARFOR(q, n * n) {
     int a = q / n, b = q % n;
     double s = 0;
-    for (int k = 0; k < n; k++) s += v.pr_J[k * n + a] * v.pr_J[k * n + b];
+    if (stage) {
+#pragma unroll 5
+      for (int k = 0; k < n; k++) s += Js[k * n + a] * Js[k * n + b];
+    } else {
+      for (int k = 0; k < n; k++) s += v.pr_J[k * n + a] * v.pr_J[k * n + b];
+    }
     v.prH0[q] = s;
   }
   VIO_SYNC();
@@ -1014,25 +1047,18 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
       else prior_block_dx(7, w.ex, x0, w.prdx + o);
     }
+    VIO_PARFOR(i, n) w.prr[i] = v.pr_r[i];
     VIO_SYNC();
-    VIO_PARFOR(i, n) {
-      double s = v.pr_r[i];
-      for (int j = 0; j < n; j++) s += v.prJT[j * n + i] * w.prdx[j];
-      w.prr[i] = s;
-      cost += 0.5 * s * s;
-    }
+    dense_matvec_cols(cx, v.prJT, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });
   }
   VIO_SYNC();  // Hm zeroed, prr ready
+  if (n > 0) VIO_PARFOR(i, n) cost += 0.5 * w.prr[i] * w.prr[i];
   if (jac) {
     if (n > 0) {
-      VIO_PARFOR(a, n) {
-        int pa = w.prcol[a];
-        if (pa >= 0) {
-          double g = 0;
-          for (int k = 0; k < n; k++) g += v.pr_J[k * n + a] * w.prr[k];
-          w.gp[pa] += g;  // unique writer per parameter in this phase
-        }
-      }
+      dense_matvec_cols(cx, v.pr_J, n, w.prr, [&](int a, double g) {
+        const int pa = w.prcol[a];
+        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + pa, g);
+      });
       VIO_PARFOR(q, n * n) {
         int a = q / n, b = q - a * n;
         int pa = w.prcol[a], pb = w.prcol[b];
