@@ -276,6 +276,51 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
 int vio_fundamental_ransac(const VioConfig *cfg, const float *pts1, const float *pts2,
                            int32_t n, uint8_t *inlier_mask);
 
+/* ------------------------------------------------------------------------- */
+/* Window bookkeeping around the solve (host side): FeatureManager            */
+/* (VINS_ios/feature_manager.hpp:71-103). It decides which landmarks and      */
+/* observations become factors of a VioWindow; the window size is a run-time  */
+/* parameter (global_param.hpp:28 fixes WINDOW_SIZE = 10).                    */
+typedef struct vio_features vio_features_t;
+
+typedef struct VioFeatureInfo { /* FeaturePerId (feature_manager.hpp:47-69), list order */
+  int32_t id, start_frame, n_obs, used_num;
+  int32_t solve_flag;            /* 0 not solved yet, 1 ok, 2 negative depth (setDepth) */
+  int32_t is_outlier, fixed;
+  double estimated_depth;        /* -1: not triangulated yet */
+} VioFeatureInfo;
+
+int vio_features_create(int32_t window_size, vio_features_t **out);
+void vio_features_destroy(vio_features_t *fm);
+int vio_features_clear(vio_features_t *fm);                       /* clearState  feature_manager.cpp:315 */
+/* addFeatureCheckParallax feature_manager.cpp:103-155. obs = image_msg of one
+ * published frame (unique ids; taken in ascending id like the std::map).
+ * enough_parallax = its return value (true -> MARGIN_OLD, VINS.cpp:397-400).  */
+int vio_features_add_check_parallax(vio_features_t *fm, int32_t frame_count, const VioObs *obs, int32_t n_obs,
+                                    int32_t *enough_parallax, int32_t *parallax_num, int32_t *last_track_num);
+int vio_features_count(vio_features_t *fm, int32_t *n);           /* getFeatureCount :284 */
+int vio_features_get_depth_vector(vio_features_t *fm, double *inv_depth, int32_t cap, int32_t *n); /* :270 */
+int vio_features_set_depth(vio_features_t *fm, const double *inv_depth, int32_t n);                /* :300 */
+int vio_features_clear_depth(vio_features_t *fm, const double *inv_depth, int32_t n);              /* :176 */
+/* triangulate :189-248. Ps [W+1][3], Rs [W+1][9] row-major (body -> world),
+ * tic [3], ric [9] row-major (camera -> body).                               */
+int vio_features_triangulate(vio_features_t *fm, const double *Ps, const double *Rs, const double tic[3],
+                             const double ric[9]);
+int vio_features_remove_failures(vio_features_t *fm);             /* :259 */
+int vio_features_remove_back(vio_features_t *fm);                 /* :320 */
+int vio_features_remove_back_shift_depth(vio_features_t *fm, const double marg_R[9], const double marg_P[3],
+                                         const double new_R[9], const double new_P[3]);            /* :250 */
+int vio_features_remove_front(vio_features_t *fm, int32_t frame_count);                             /* :343 */
+/* The factor enumeration of solve_ceres (VINS.cpp:528-567): fills the factor
+ * arrays a VioWindow points to, landmark index = row of the depth vector.     */
+int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t *host, int32_t *target,
+                                int32_t *feature, double *pts_i /* [cap][3] */, double *pts_j /* [cap][3] */,
+                                int32_t *n_factors, int32_t *n_features);
+/* Introspection: per-landmark records (and, optionally, all observation points
+ * [sum n_obs][3]) in list order.                                             */
+int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
+                      int32_t cap_points, int32_t *n_points);
+
 const char *vio_version(void);
 
 #ifdef __cplusplus

@@ -111,6 +111,12 @@ class VioObs(C.Structure):
     _fields_ = [("id", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
 
 
+class VioFeatureInfo(C.Structure):
+    _fields_ = [("id", C.c_int32), ("start_frame", C.c_int32), ("n_obs", C.c_int32), ("used_num", C.c_int32),
+                ("solve_flag", C.c_int32), ("is_outlier", C.c_int32), ("fixed", C.c_int32),
+                ("estimated_depth", C.c_double)]
+
+
 def prior_capacity(W):
     return 6 * (W + 1) + 9 * (W + 1) + 6
 
@@ -390,6 +396,23 @@ def load_product():
     lib.vio_klt_track.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, fp, u8p, fp]
     lib.vio_good_features.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, _ip]
     lib.vio_fundamental_ransac.argtypes = [cfgp, fp, fp, C.c_int32, u8p]
+    obsp, infop = C.POINTER(VioObs), C.POINTER(VioFeatureInfo)
+    lib.vio_features_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    lib.vio_features_destroy.argtypes = [vp]
+    lib.vio_features_destroy.restype = None
+    lib.vio_features_clear.argtypes = [vp]
+    lib.vio_features_add_check_parallax.argtypes = [vp, C.c_int32, obsp, C.c_int32, _ip, _ip, _ip]
+    lib.vio_features_count.argtypes = [vp, _ip]
+    lib.vio_features_get_depth_vector.argtypes = [vp, _dp, C.c_int32, _ip]
+    lib.vio_features_set_depth.argtypes = [vp, _dp, C.c_int32]
+    lib.vio_features_clear_depth.argtypes = [vp, _dp, C.c_int32]
+    lib.vio_features_triangulate.argtypes = [vp, _dp, _dp, _dp, _dp]
+    lib.vio_features_remove_failures.argtypes = [vp]
+    lib.vio_features_remove_back.argtypes = [vp]
+    lib.vio_features_remove_back_shift_depth.argtypes = [vp, _dp, _dp, _dp, _dp]
+    lib.vio_features_remove_front.argtypes = [vp, C.c_int32]
+    lib.vio_features_export_factors.argtypes = [vp, C.c_int32, _ip, _ip, _ip, _dp, _dp, _ip, _ip]
+    lib.vio_features_dump.argtypes = [vp, infop, C.c_int32, _ip, _dp, C.c_int32, _ip]
     lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
     lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib
