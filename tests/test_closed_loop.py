@@ -1,0 +1,62 @@
+"""Closed loop over the rows built so far (tools/replay_synthetic.py): IMU pre-integration and state propagation,
+keyframe selection, triangulation, factor export, window solve + new2old + marginalization, prior hand-over, both
+slide modes — on a synthetic 3D sequence with known ground truth. The window solve is the product (GPU test) or the
+CPU oracle (CPU test, and the checker of the GPU run); everything else is the product's host code in both."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import abi, pkg
+
+sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+import replay_synthetic as RS  # noqa: E402
+
+
+def oracle_loop(cfg, seed, init_noise=1.0):
+    osolve, _ = H.oracle_backend()
+
+    def solve(w):
+        ref, st = H.solve_with(osolve, cfg, w)
+        w.pose[:], w.speed_bias[:], w.inv_depth[:] = ref.pose, ref.speed_bias, ref.inv_depth
+        w.next_prior = ref.next_prior
+        return st
+
+    pre = lambda *a: pkg.backend.preintegrate(cfg, *a)  # product host code (vio_preintegrate)
+    return RS.ClosedLoop(cfg, solve, pre, seed=seed, init_noise=init_noise)
+
+
+def test_closed_loop_with_oracle_solver_tracks_ground_truth():
+    cfg = abi.default_config()
+    loop = oracle_loop(cfg, seed=3)
+    for _ in range(45):
+        loop.step()
+    e = loop.errors()
+    assert len(e) == 45 - cfg.window_size
+    assert np.sqrt((e ** 2).mean()) < 0.06 and e.max() < 0.15, (e.max(), e[-1])
+    modes = [h[3]["iterations"] for h in loop.history]
+    assert min(modes) >= 2
+    assert loop.prior is not None and loop.prior.n >= 60          # a marginalization prior is carried along
+    assert 100 <= loop.fm.count() <= 400
+    loop.close()
+
+
+@pytest.mark.gpu
+def test_closed_loop_product_solver_matches_oracle_loop():
+    cfg = abi.default_config()
+    solver = pkg.backend.WindowSolver(cfg, max_batch=1)
+    pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
+    prod = RS.ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=5, init_noise=1.0)
+    ref = oracle_loop(cfg, seed=5)
+    for _ in range(70):
+        prod.step(), ref.step()
+    ep, er = prod.errors(), ref.errors()
+    assert np.sqrt((ep ** 2).mean()) < 0.06 and ep.max() < 0.15, (ep.max(), ep[-1])
+    # the two loops see the same data and make the same decisions; their trajectories stay together
+    dp = np.array([a[1] - b[1] for a, b in zip(prod.history, ref.history)])
+    assert np.abs(dp).max() < 1e-5, np.abs(dp).max()
+    assert [h[3]["iterations"] for h in prod.history] == [h[3]["iterations"] for h in ref.history]
+    assert prod.prior.n == ref.prior.n
+    prod.close(), ref.close(), solver.close()
