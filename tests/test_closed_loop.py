@@ -60,3 +60,22 @@ def test_closed_loop_product_solver_matches_oracle_loop():
     assert [h[3]["iterations"] for h in prod.history] == [h[3]["iterations"] for h in ref.history]
     assert prod.prior.n == ref.prior.n
     prod.close(), ref.close(), solver.close()
+
+
+@pytest.mark.gpu
+def test_closed_loop_from_rendered_frames_through_both_halves():
+    """Frames of a textured plane rendered along the trajectory -> KLT front-end (readImage) -> landmark store ->
+    window solve: the whole hot path in its natural loop, against the ground truth."""
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    solver = pkg.backend.WindowSolver(cfg, max_batch=1)
+    tracker = pkg.frontend.FeatureTracker(cfg, n_seq=1)
+    pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
+    loop = RS.ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=7, init_noise=1.0, tracker=tracker)
+    for _ in range(50):
+        loop.step()
+    e = loop.errors()
+    tracked = [h[4] for h in loop.history]
+    assert min(tracked) > 80, min(tracked)                       # the tracker keeps most of its 150 features frame to frame
+    assert np.sqrt((e ** 2).mean()) < 0.08 and e.max() < 0.2, (np.sqrt((e ** 2).mean()), e.max())
+    assert loop.prior is not None and loop.fm.count() >= 100
+    loop.close(), tracker.close(), solver.close()

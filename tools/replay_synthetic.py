@@ -93,13 +93,41 @@ class SyntheticWorld:
         return ids, xyz
 
 
-class ClosedLoop:
-    """The estimator loop. solve(window) -> stats solves one abi.Window in place (product WindowSolver or an oracle)."""
+class ImageWorld(SyntheticWorld):
+    """The same trajectory and IMU, but the camera films a textured plane: frames are rendered by intersecting every
+    pixel's ray with the plane z = z0, and the observations come from the KLT front-end run on those frames."""
 
-    def __init__(self, cfg, solve, preintegrate, seed=1, init_noise=0.0):
+    def __init__(self, cfg, seed, z0=-6.0, px_per_m=77.0, **kw):
+        super().__init__(cfg, seed, n_landmarks=1, **kw)
+        self.z0, self.s = z0, px_per_m
+        self.tex_half = 9.0  # metres covered by the texture around the origin
+        n = int(2 * self.tex_half * px_per_m)
+        self.tex = synth.make_texture(self.rng, n, n)
+        rows, cols = cfg.image_rows, cfg.image_cols
+        v, u = np.mgrid[0:rows, 0:cols].astype(np.float64)
+        self.rays = np.stack([(u - cfg.cx) / cfg.fx, (v - cfg.cy) / cfg.fy, np.ones_like(u)], axis=-1)
+
+    def render(self, k):
+        P, R, _ = self.truth(k)
+        Rc, Pc = R @ self.ric, P + R @ self.tic
+        d = self.rays @ Rc.T
+        lam = (self.z0 - Pc[2]) / d[..., 2]
+        X, Y = Pc[0] + lam * d[..., 0], Pc[1] + lam * d[..., 1]
+        img = synth._bilinear(self.tex, (X + self.tex_half) * self.s, (Y + self.tex_half) * self.s)
+        img = img + self.rng.normal(0, 1.0, img.shape)
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+class ClosedLoop:
+    """The estimator loop. solve(window) -> stats solves one abi.Window in place (product WindowSolver or an oracle).
+    With `tracker` (a frontend.FeatureTracker for one sequence) the observations are what the KLT front-end publishes
+    on frames rendered by an ImageWorld; without, they are noisy projections of a landmark cloud."""
+
+    def __init__(self, cfg, solve, preintegrate, seed=1, init_noise=0.0, tracker=None):
         self.cfg, self.solve, self.pre = cfg, solve, preintegrate
         self.W = cfg.window_size
-        self.world = SyntheticWorld(cfg, seed)
+        self.tracker = tracker
+        self.world = ImageWorld(cfg, seed) if tracker is not None else SyntheticWorld(cfg, seed)
         self.fm = window.FeatureManager(self.W)
         self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs = [], [], [], [], []
         self.pre_arr, self.pre_samples = [], []   # per interval (i-1, i): packed pre-integration and its raw samples
@@ -152,7 +180,10 @@ class ClosedLoop:
             if k == 0:
                 self.Bas.append(world.ba + self.rng.normal(0, 0.01 * n, 3)), self.Bgs.append(world.bg + self.rng.normal(0, 0.001 * n, 3))
         self.Ps.append(P), self.Rs.append(R), self.Vs.append(V)
-        ids, xyz = world.observe(k)
+        if self.tracker is not None:
+            ids, xyz = self.tracker.read_images(world.render(k)[None], True)[0]  # readImage, every frame published
+        else:
+            ids, xyz = world.observe(k)
         enough, _, ltn = self.fm.add_check_parallax(self.frame_count, ids, xyz)
         self.k += 1
         if self.frame_count < W:
@@ -215,12 +246,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--images", action="store_true", help="render frames of a textured plane and run the KLT front-end on them")
     args = ap.parse_args()
     import torch  # noqa: F401  (HIP runtime first)
     cfg = abi.default_config()
     solver = pkg.backend.WindowSolver(cfg, max_batch=1)
     pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
-    loop = ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=args.seed, init_noise=1.0)
+    tracker = pkg.frontend.FeatureTracker(cfg, n_seq=1) if args.images else None
+    loop = ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=args.seed, init_noise=1.0, tracker=tracker)
     for _ in range(args.frames):
         loop.step()
     e = loop.errors()
