@@ -321,6 +321,17 @@ int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
                       int32_t cap_points, int32_t *n_points);
 
+/* failureDetection VINS.cpp:214-265 on the newest frame after a solve (the
+ * failure_hand switch of the UI stays with the caller). reasons: bit mask.    */
+#define VIO_FAIL_FEW_FEATURES 1   /* f_manager.last_track_num < 4              */
+#define VIO_FAIL_GYR_BIAS 2       /* |Bgs[W]| > 1                              */
+#define VIO_FAIL_TRANSLATION 4    /* |Ps[W] - last_P| > 1                      */
+#define VIO_FAIL_Z_TRANSLATION 8  /* |Ps[W].z - last_P.z| > 0.5                */
+#define VIO_FAIL_ROTATION 16      /* angle(Rs[W]^T last_R) > 40 "degrees"      */
+int vio_failure_detection(int32_t last_track_num, const double Bg_newest[3], const double P_newest[3],
+                          const double R_newest[9], const double last_P[3], const double last_R[9],
+                          int32_t *reasons);
+
 const char *vio_version(void);
 
 #ifdef __cplusplus

@@ -258,3 +258,20 @@ def test_error_codes_and_window_size():
     with pytest.raises(RuntimeError):
         fm.set_depth([0.2, 0.3])  # more depths than windowed landmarks
     fm.close()
+
+
+def test_failure_detection_thresholds():
+    """failureDetection (VINS.cpp:214-265) restated (VINS.cpp needs OpenCV headers: no reference build for this one):
+    every threshold from both sides, including the reference's 3.14 in the degree conversion."""
+    fd = pkg.window.failure_detection
+    I = np.eye(3)
+    z = np.zeros(3)
+    assert fd(50, z, z, I, z, I) == 0
+    assert fd(3, z, z, I, z, I) == 1 and fd(4, z, z, I, z, I) == 0
+    assert fd(50, [0.6, 0.6, 0.6], z, I, z, I) == 2 and fd(50, [0.57, 0.57, 0.57], z, I, z, I) == 0
+    assert fd(50, z, [0.8, 0.7, 0.0], I, z, I) == 4 and fd(50, z, [0.7, 0.7, 0.0], I, z, I) == 0
+    assert fd(50, z, [0, 0, 0.6], I, z, I) == 8 and fd(50, z, [0, 0, -0.4], I, z, I) == 0
+    assert fd(50, z, [0.9, 0, 0.6], I, z, I) == 4 | 8
+    for deg, want in ((39.0, 0), (39.97, 0), (39.99, 16), (41.0, 16), (170.0, 16)):   # 40 "degrees" with pi = 3.14 is 39.98 true degrees
+        assert fd(50, z, z, rot(np.radians(deg), 0, 0), z, I) == want, deg
+    assert fd(50, z, z, rot(0, 0, np.radians(179.0)), z, rot(0.3, 0.1, 0)) == 16  # trace <= 0 branch of the conversion

@@ -413,6 +413,7 @@ def load_product():
     lib.vio_features_remove_front.argtypes = [vp, C.c_int32]
     lib.vio_features_export_factors.argtypes = [vp, C.c_int32, _ip, _ip, _ip, _dp, _dp, _ip, _ip]
     lib.vio_features_dump.argtypes = [vp, infop, C.c_int32, _ip, _dp, C.c_int32, _ip]
+    lib.vio_failure_detection.argtypes = [C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
     lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
     lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib

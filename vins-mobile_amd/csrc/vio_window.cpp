@@ -345,6 +345,26 @@ int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t
   return VIO_OK;
 }
 
+// failureDetection (VINS.cpp:214-265): the checks on the newest frame after a solve. Returns a bit mask (0 = healthy).
+int vio_failure_detection(int32_t last_track_num, const double Bg_newest[3], const double P_newest[3],
+                          const double R_newest[9], const double last_P[3], const double last_R[9], int32_t *reasons) {
+  if (!Bg_newest || !P_newest || !R_newest || !last_P || !last_R || !reasons) return VIO_EINVAL;
+  int r = 0;
+  if (last_track_num < 4) r |= VIO_FAIL_FEW_FEATURES;
+  if (sqrt(Bg_newest[0] * Bg_newest[0] + Bg_newest[1] * Bg_newest[1] + Bg_newest[2] * Bg_newest[2]) > 1) r |= VIO_FAIL_GYR_BIAS;
+  const double d[3] = {P_newest[0] - last_P[0], P_newest[1] - last_P[1], P_newest[2] - last_P[2]};
+  if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > 1) r |= VIO_FAIL_TRANSLATION;
+  if (fabs(P_newest[2] - last_P[2]) > 0.5) r |= VIO_FAIL_Z_TRANSLATION;
+  double RT[9], dR[9];
+  mat3T(R_newest, RT);
+  mat3mul(RT, last_R, dR);  // tmp_R^T last_R
+  const Quat dq = RtoQ(dR);  // Eigen's matrix -> quaternion (w may come out negative on the trace <= 0 branch)
+  const double delta_angle = acos(dq.w) * 2.0 / 3.14 * 180.0;  // (3.14, as written in the reference)
+  if (delta_angle > 40) r |= VIO_FAIL_ROTATION;
+  *reasons = r;
+  return VIO_OK;
+}
+
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points, int32_t cap_points,
                       int32_t *n_points) {
   if (!fm || !n || (cap > 0 && !info)) return VIO_EINVAL;

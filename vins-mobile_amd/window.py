@@ -103,3 +103,14 @@ class FeatureManager:
         rec = np.array([(f.id, f.start_frame, f.n_obs, f.used_num, f.solve_flag, f.is_outlier, f.fixed, f.estimated_depth)
                         for f in info[:n.value]], dtype=np.float64).reshape(-1, 8)
         return rec, pts[:npts.value].copy()
+
+
+def failure_detection(last_track_num, Bg, P, R, last_P, last_R, lib=None):
+    """failureDetection (VINS.cpp:214-265) -> bit mask of VIO_FAIL_* reasons (0 = healthy)."""
+    lib = lib or abi.load_product()
+    a = [_d(x).ravel() for x in (Bg, P, R, last_P, last_R)]
+    out = C.c_int32()
+    rc = lib.vio_failure_detection(int(last_track_num), *[x.ctypes.data_as(_dp) for x in a], C.byref(out))
+    if rc != 0:
+        raise RuntimeError("vio_failure_detection failed: %d" % rc)
+    return out.value
