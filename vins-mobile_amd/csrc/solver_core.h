@@ -1232,6 +1232,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   VIO_SYNC();
   stamp(cx, ST_SCALE);
   const int n6 = v.npose6;
+  bool rhs_done = false;
 #ifdef VIO_EMUL
   for (int a = 0; a < n6; a++)
     for (int b = 0; b <= a; b++) {
@@ -1249,6 +1250,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     const int li = lane & 15, kq = lane >> 4;
     const int ksteps = (F + 3) / 4;
     constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
+    rhs_done = false;
     if (T <= kT) {
       // K-split: every wave owns a slice of the features and forms ALL lower tiles from it. A and B operands are the
       // same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one latency) feeding
@@ -1256,15 +1258,18 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
       const int ksw = (ksteps + nw - 1) / nw;
       const int s_begin = wave * ksw, s_end = s_begin + ksw < ksteps ? s_begin + ksw : ksteps;
       v4d acc[kT * (kT + 1) / 2];
+      double rp[kT];  // the same fetch also yields this slice's part of rhs_p -= W (g_f / E_f)
 #pragma unroll
       for (int q = 0; q < kT * (kT + 1) / 2; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < kT; t++) rp[t] = 0.0;
       for (int s0 = s_begin; s0 < s_end; s0 += 5) {
-        double wv[5][kT], ev[5];
+        double wv[5][kT], ev[5], gv[5];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
           const int f = 4 * (s0 + j) + kq;
           const int fc = (s0 + j < s_end && f < F) ? f : 0;
-          ev[j] = w.einv[fc];
+          ev[j] = w.einv[fc], gv[j] = w.tf[fc];
 #pragma unroll
           for (int t = 0; t < kT; t++) {
             const int col = 16 * t + li;
@@ -1277,7 +1282,10 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
           const int f = 4 * (s0 + j) + kq;
           const bool vf = s0 + j < s_end && f < F;
 #pragma unroll
-          for (int t = 0; t < kT; t++) wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
+          for (int t = 0; t < kT; t++) {
+            wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
+            rp[t] = fma(wv[j][t], gv[j], rp[t]);
+          }
 #pragma unroll
           for (int ti = 0; ti < kT; ti++) {
             const double a = wv[j][ti] * ev[j];
@@ -1300,6 +1308,12 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
             }
           }
         }
+#pragma unroll
+      for (int t = 0; t < kT; t++) {
+        const int a = 16 * t + li;
+        if (a < n6 && rp[t] != 0.0) VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -rp[t]);
+      }
+      rhs_done = true;
     } else
     for (int p = wave; p < npairs; p += nw) {
       int ti = 0;
@@ -1344,7 +1358,9 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   }
 #endif
   stamp(cx, ST_SCHUR);
-  // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets
+  // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets (already folded into the
+  // K-split Schur product above when that form ran)
+  if (!rhs_done) {
   const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
   VIO_PARFOR(q, n6 * nch) {
     int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
@@ -1356,6 +1372,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 #pragma unroll
     for (int j = 0; j < kWStrip; j++) s += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
     VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -s);
+  }
   }
   VIO_SYNC();
   stamp(cx, ST_RHS);
