@@ -186,3 +186,11 @@ class OracleTracker:
 
     def close(self):
         self.lib.oracle_tracker_destroy(self.h)
+
+
+ODD_SHAPES = [  # (W, features, with_loop, seed): odd sizes around every chunk / strip / tile boundary of the kernel source
+    (10, 1, 0, 1), (10, 5, 0, 2), (10, 7, 0, 3), (10, 8, 0, 4), (10, 23, 0, 5), (10, 25, 0, 6), (10, 97, 0, 7),
+    (10, 170, 0, 8), (10, 260, 0, 9), (6, 40, 0, 10), (3, 12, 0, 11), (10, 60, 6, 12), (5, 30, 4, 13), (13, 120, 0, 14),
+]
+
+

@@ -140,3 +140,27 @@ def test_poisoned_device_buffers():
                         "not poisoned and not error_codes", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("W,F,loop,seed", H.ODD_SHAPES)
+def test_odd_shapes_match_oracle(W, F, loop, seed):
+    """Awkward window sizes (1..260 landmarks, W = 3..13, loop pose) through the device kernel against the CPU oracle; the
+    poisoned-buffer run below repeats them with NaN-filled LDS and scratch."""
+    cfg = abi.default_config(window_size=W)
+    osolve, opre = H.oracle_backend()
+    w = synth.make_window(cfg, lambda *a: abi.preintegrate_with(opre, cfg, *a), seed=900 + seed, n_features=F, W=W,
+                          with_loop=loop)
+    solver = pkg.backend.WindowSolver(cfg, max_batch=1)
+    got = w.copy()
+    gs = solver.solve([got])[0]
+    solver.close()
+    ref, rs = H.solve_with(osolve, cfg, w)
+    assert np.isfinite(got.pose).all() and np.isfinite(got.inv_depth).all()
+    assert gs["iterations"] == rs["iterations"] and list(gs["it_flags"]) == list(rs["it_flags"])
+    assert H.pose_relerr(got.pose, ref.pose) < TOL and H.relerr(got.inv_depth, ref.inv_depth) < TOL
+    assert got.next_prior.n == ref.next_prior.n
+    if ref.next_prior.n > 0:
+        Hr, br, _ = ref.next_prior.canonical()
+        Hg, bg, _ = got.next_prior.canonical()
+        assert np.abs(Hg - Hr).max() <= TOL_PRIOR * np.abs(Hr).max() + 1e-6
+        assert np.abs(bg - br).max() <= TOL_PRIOR * np.abs(br).max() + 1e-6
