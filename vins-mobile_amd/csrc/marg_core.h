@@ -49,6 +49,20 @@ struct MargWorkT {
   int stage_slots;
 };
 
+// int pointer in the address space of a double pointer type (LDS or global)
+template <class P>
+struct IntPtrOf;
+template <>
+struct IntPtrOf<double *> {
+  typedef int *type;
+};
+#ifndef VIO_EMUL
+template <>
+struct IntPtrOf<ldsd> {
+  typedef ldsi type;
+};
+#endif
+
 constexpr int kMargRowX = 6;                                   // extrinsic Jacobian row
 constexpr int kMargSlot = kSlotStride + 2 * kMargRowX + 1;     // [Ji Jj r Jl] x2 + pad, [Jex] x2 + pad = 42
 
@@ -482,20 +496,44 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   VIO_SYNC();
   // Right-looking, ONE barrier per column: column j stays unscaled in place while the trailing update uses
   // A_ij A_kj / piv; the scaling L_ij = A_ij / sqrt(piv) happens once at the end. A cut pivot zeroes its column.
+  // The lower-triangle entries (i, k) are listed once, columns from last to first, in the staging area the build phase
+  // no longer needs: the entries step j touches (k > j) are a PREFIX of that list, so every lane has an element and no
+  // index arithmetic beyond one table read.
+  auto tab = reinterpret_cast<typename IntPtrOf<decltype(m.stage)>::type>(m.stage);
+  const bool use_tab = (size_t)m.stage_slots * kMargSlot * 2 >= (size_t)pos * (pos - 1) / 2 + 2;
+  if (use_tab) {
+    VIO_PARFOR(k, pos) {
+      if (k < 1) continue;
+      const int off = (pos - 1 - k) * (pos - k) / 2;
+      for (int i = k; i < pos; i++) tab[off + i - k] = (i << 16) | k;
+    }
+    VIO_SYNC();
+  }
   for (int j = 0; j < pos; j++) {
     const double piv = m.Am[j * ld + j];
     const bool skip = !(piv > m.tol[j]);
     const double ip = skip ? 0.0 : 1.0 / piv;
     const double bj = m.bm[j];
     const int rem = pos - j - 1;
-    const int rl = cx.nt >= 32 ? 32 : (int)cx.nt, nrow = (int)cx.nt / rl;  // 32 lanes walk one row
-    const int lane_k = (int)cx.tid % rl;
-    for (int i = j + 1 + (int)cx.tid / rl; i < pos; i += nrow) {
-      const double lij = m.Am[i * ld + j] * ip;
-      for (int k = j + 1 + lane_k; k <= i; k += rl) m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
-      if (lane_k == 0) m.bm[i] -= lij * bj;
+    if (use_tab) {
+      VIO_PARFOR(q, rem * (rem + 1) / 2) {
+        const int ik = tab[q], i = ik >> 16, k = ik & 0xffff;
+        const double lij = m.Am[i * ld + j] * ip;
+        m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
+      }
+      VIO_PARFOR(q, rem) {
+        const int i = j + 1 + q;
+        m.bm[i] -= m.Am[i * ld + j] * ip * bj;
+      }
+    } else {
+      const int rl = cx.nt >= 32 ? 32 : (int)cx.nt, nrow = (int)cx.nt / rl;  // 32 lanes walk one row
+      const int lane_k = (int)cx.tid % rl;
+      for (int i = j + 1 + (int)cx.tid / rl; i < pos; i += nrow) {
+        const double lij = m.Am[i * ld + j] * ip;
+        for (int k = j + 1 + lane_k; k <= i; k += rl) m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
+        if (lane_k == 0) m.bm[i] -= lij * bj;
+      }
     }
-    (void)rem;
     VIO_SYNC();
   }
   // pass 1: 1/sqrt(piv) per column into tol (no longer needed as a threshold), pass 2: scale
