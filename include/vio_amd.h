@@ -316,6 +316,15 @@ int vio_features_remove_front(vio_features_t *fm, int32_t frame_count);         
 int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t *host, int32_t *target,
                                 int32_t *feature, double *pts_i /* [cap][3] */, double *pts_j /* [cap][3] */,
                                 int32_t *n_factors, int32_t *n_features);
+/* As above plus the relocalization factors of solve_ceres (VINS.cpp:597-631): landmarks
+ * observed in window frame `loop_frame` whose id appears in loop_ids (ascending,
+ * RetriveData::features_ids) get one more factor with target W+1 (the loop pose)
+ * and pts_j = (loop_xy, 1) (RetriveData::measurements); it closes the landmark's
+ * group of factors. loop_frame = -1: no loop.                                  */
+int vio_features_export_factors_loop(vio_features_t *fm, int32_t cap_factors, int32_t loop_frame,
+                                     const int32_t *loop_ids, const double *loop_xy /* [n_loop][2] */, int32_t n_loop,
+                                     int32_t *host, int32_t *target, int32_t *feature, double *pts_i, double *pts_j,
+                                     int32_t *n_factors, int32_t *n_features, int32_t *n_loop_factors /* may be NULL */);
 /* Introspection: per-landmark records (and, optionally, all observation points
  * [sum n_obs][3]) in list order.                                             */
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
@@ -331,6 +340,80 @@ int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int
 int vio_failure_detection(int32_t last_track_num, const double Bg_newest[3], const double P_newest[3],
                           const double R_newest[9], const double last_P[3], const double last_R[9],
                           int32_t *reasons);
+
+/* ------------------------------------------------------------------------- */
+/* Estimator: class VINS after initialisation (VINS.hpp:47-200), host side, for
+ * n_seq independent sequences whose window solves share ONE device launch.
+ * processIMU VINS.cpp:333-375, processImage :377-478, old2new/new2old :89-212,
+ * the relocalization bookkeeping :571-637,664-680, failureDetection :214-265,
+ * slideWindow :1149-1273, clearState :36-81. solveInitial (:833-1145) is not
+ * part of it: the caller hands the window states over instead
+ * (vio_estimator_set_initial_state) and the branches after it are the
+ * reference's (first solve, final_cost > 200 -> back to INITIAL).              */
+typedef struct vio_estimator vio_estimator_t;
+
+#define VIO_SOLVER_INITIAL 0      /* VINS::SolverFlag (VINS.hpp:60-64) */
+#define VIO_SOLVER_NON_LINEAR 1
+
+#define VIO_FRAME_SKIPPED 0      /* sequence not active in this call                               */
+#define VIO_FRAME_FILLING 1      /* window not full yet: frame_count++            VINS.cpp:448-452 */
+#define VIO_FRAME_WAIT_INIT 2    /* window full, no initial state: slid, no solve VINS.cpp:443-446 */
+#define VIO_FRAME_INIT_FAILED 3  /* first solve ended with final_cost > 200       VINS.cpp:415-424 */
+#define VIO_FRAME_SOLVED 4       /* solve_ceres + slideWindow                                      */
+#define VIO_FRAME_FAILURE 5      /* failureDetection fired: state cleared         VINS.cpp:462-467 */
+#define VIO_FRAME_RESET 6        /* track_num < 20 with a full INITIAL window     VINS.cpp:408-412 */
+#define VIO_FRAME_ERROR 7        /* capacity / argument error for this sequence, see .error        */
+
+typedef struct VioFrameResult {
+  int32_t action;               /* VIO_FRAME_*                                   */
+  int32_t error;                /* VIO_E* when action == VIO_FRAME_ERROR          */
+  int32_t marginalization_flag; /* VIO_MARGIN_OLD = the frame is a keyframe       */
+  int32_t failure_reasons;      /* VIO_FAIL_* mask                                */
+  int32_t track_num;            /* f_manager.last_track_num                       */
+  int32_t n_features, n_factors, n_loop_factors;
+  VioSolveStats stats;          /* valid when a solve ran                         */
+} VioFrameResult;
+
+typedef struct VioEstimatorStatus {
+  int32_t frame_count, solver_flag, marginalization_flag, failure_occur;
+  int32_t prior_rows;           /* rows of last_marginalization_info (0: none)    */
+  double final_cost;
+  double r_drift[9], t_drift[3];                 /* VINS.hpp r_drift / t_drift    */
+  double relative_t[3], relative_q[4], relative_yaw, loop_pose[7]; /* front_pose  */
+} VioEstimatorStatus;
+
+/* tic [3], ric [9] row-major: the camera-to-body extrinsic (TIC_*, RIC_*).     */
+int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3], const double ric[9],
+                         vio_estimator_t **out);
+void vio_estimator_destroy(vio_estimator_t *est);
+int vio_estimator_clear(vio_estimator_t *est, int32_t seq);                       /* clearState */
+int vio_estimator_process_imu(vio_estimator_t *est, int32_t seq, double dt, const double acc[3],
+                              const double gyr[3]);                                /* processIMU */
+/* The states solveInitial would leave for the W+1 frames with these headers
+ * (Ps [W+1][3], Rs [W+1][9], Vs, Bas, Bgs [W+1][3]); consumed by the next
+ * process_image that finds the window full with exactly these headers.        */
+int vio_estimator_set_initial_state(vio_estimator_t *est, int32_t seq, const double *headers, const double *Ps,
+                                    const double *Rs, const double *Vs, const double *Bas, const double *Bgs);
+/* retrive_pose_data = ... (ViewController.mm:964): the old keyframe matched to the
+ * window frame with this header; ids ascending; n = 0 withdraws it.            */
+int vio_estimator_set_relocalization(vio_estimator_t *est, int32_t seq, double header, const double P_old[3],
+                                     const double Q_old[4] /* x y z w */, const int32_t *ids,
+                                     const double *xy /* [n][2] */, int32_t n);
+/* processImage of one published frame for every active sequence (active NULL =
+ * all). obs of sequence q starts at obs + q*obs_stride and has n_obs[q] entries.
+ * The window solves of all sequences go to the device in one launch.          */
+int vio_estimator_process_images(vio_estimator_t *est, const VioObs *obs, const int32_t *n_obs, int32_t obs_stride,
+                                 const double *headers, const uint8_t *active, VioFrameResult *results /* [n_seq] */);
+int vio_estimator_process_image(vio_estimator_t *est, int32_t seq, const VioObs *obs, int32_t n_obs, double header,
+                                VioFrameResult *result);
+int vio_estimator_get_status(vio_estimator_t *est, int32_t seq, VioEstimatorStatus *st);
+/* Ps/Rs/Vs/Bas/Bgs/Headers of the window (any pointer may be NULL).            */
+int vio_estimator_get_window(vio_estimator_t *est, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas,
+                             double *Bgs, double *headers);
+/* update_loop_correction VINS.cpp:302-331: r_drift * Ps + t_drift, r_drift * Rs. */
+int vio_estimator_get_corrected_window(vio_estimator_t *est, int32_t seq, double *correct_Ps, double *correct_Rs);
+/* The sequence's landmark store (owned by the estimator), for introspection.   */
+int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 
 const char *vio_version(void);
 

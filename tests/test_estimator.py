@@ -1,0 +1,312 @@
+"""The native estimator (vio_estimator_*, csrc/vio_estimator.cpp = class VINS after initialisation: processIMU,
+processImage, the host half of solve_ceres, failureDetection, slideWindow, clearState; VINS_ios/VINS.cpp:36-478,
+1149-1273).
+
+CPU: the parts that never reach the solver (IMU propagation, window filling, the INITIAL-phase slides, resets) against
+numpy restatements and the stand-alone landmark store. GPU: the full loop against the python restatement of the same
+loop (tools/replay_synthetic.py::ClosedLoop) running the CPU ORACLE solver, plus batching, failure recovery and the
+relocalization (loop) bookkeeping."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import abi, pkg, synth
+
+sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+import replay_synthetic as RS  # noqa: E402
+from test_closed_loop import oracle_loop  # noqa: E402
+
+TIC = np.array([0.0, 0.065, 0.0])
+RIC = np.diag([1.0, -1.0, -1.0])
+
+
+def obs_grid(n, shift=0.0, first_id=0):
+    ids = list(range(first_id, first_id + n))
+    xyz = [[-0.4 + 0.8 * (i % 12) / 11 + shift, -0.3 + 0.6 * (i // 12) / 11, 1.0] for i in range(n)]
+    return ids, xyz
+
+
+def test_process_imu_propagates_like_the_reference_formula():
+    cfg = abi.default_config()
+    est = pkg.estimator.Estimator(cfg, TIC, RIC)
+    rng = np.random.default_rng(0)
+    est.process_imu(0.01, [0.1, 0.2, 9.7], [0.01, -0.02, 0.03])     # first sample: only acc_0 / gyr_0
+    assert est.process_image(*obs_grid(60), 1.0).action == abi.VIO_FRAME_FILLING
+    a0, w0 = np.array([0.1, 0.2, 9.7]), np.array([0.01, -0.02, 0.03])
+    P, R, V, g = np.zeros(3), np.eye(3), np.zeros(3), np.array([0, 0, cfg.gravity])
+    dts, accs, gyrs = [], [], []
+    for _ in range(25):
+        dt = rng.uniform(0.005, 0.02)
+        a1, w1 = rng.normal(0, 1, 3) + [0, 0, 9.8], rng.normal(0, 0.5, 3)
+        est.process_imu(dt, a1, w1)
+        ua0 = R @ a0 - g                                              # VINS.cpp:360-369
+        R = R @ synth.quat_to_rot(np.array([*(0.5 * (w0 + w1) * dt / 2), 1.0]), normalize=False)
+        ua = 0.5 * (ua0 + R @ a1 - g)
+        P, V = P + dt * V + 0.5 * dt * dt * ua, V + dt * ua
+        a0, w0 = a1, w1
+        dts.append(dt), accs.append(a1), gyrs.append(w1)
+    w = est.window()
+    assert np.abs(w["Ps"][1] - P).max() < 1e-12 and np.abs(w["Vs"][1] - V).max() < 1e-12
+    assert np.abs(w["Rs"][1] - R).max() < 1e-12
+    assert np.abs(w["Ps"][0]).max() == 0 and est.status().frame_count == 1
+    est.close()
+
+
+def test_window_fills_then_slides_while_waiting_for_the_initial_state():
+    cfg = abi.default_config(window_size=5)
+    W = cfg.window_size
+    est = pkg.estimator.Estimator(cfg, TIC, RIC)
+    fm = pkg.window.FeatureManager(W)                 # the stand-alone store driven the way processImage drives it
+    actions, fc = [], 0
+    for k in range(W + 4):
+        est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0.1])
+        ids, xyz = obs_grid(80, shift=0.03 * k)       # large parallax: every frame is a keyframe
+        res = est.process_image(ids, xyz, 10.0 + k)
+        actions.append(res.action)
+        enough, _, _ = fm.add_check_parallax(fc, ids, xyz)
+        assert res.marginalization_flag == (abi.VIO_MARGIN_OLD if enough else abi.VIO_MARGIN_SECOND_NEW)
+        if fc < W:
+            fc += 1
+        elif enough:
+            fm.remove_back()                          # INITIAL phase: no depth shift (VINS.cpp:1255-1271)
+        else:
+            fm.remove_front(fc)
+    assert actions == [abi.VIO_FRAME_FILLING] * W + [abi.VIO_FRAME_WAIT_INIT] * 4
+    st = est.status()
+    assert st.frame_count == W and st.solver_flag == abi.VIO_SOLVER_INITIAL and st.prior_rows == 0
+    hdr = est.window()["headers"]
+    assert list(hdr[:W]) == [10.0 + k for k in range(4, W + 4)]      # four slides dropped the four oldest frames
+    a, b = est.features().dump(), fm.dump()
+    assert a[0].shape == b[0].shape and len(a[0]) > 50 and np.array_equal(a[0][:, :3], b[0][:, :3])   # id, start, n_obs
+    assert np.array_equal(a[1], b[1])
+    est.close(), fm.close()
+
+
+def test_reset_when_the_full_initial_window_tracks_too_little():
+    cfg = abi.default_config(window_size=4)
+    est = pkg.estimator.Estimator(cfg, TIC, RIC)
+    for k in range(4):
+        est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0])
+        assert est.process_image(*obs_grid(50, shift=0.02 * k), float(k)).action == abi.VIO_FRAME_FILLING
+    res = est.process_image(*obs_grid(50, first_id=1000), 4.0)        # nothing tracked: track_num < 20
+    assert res.action == abi.VIO_FRAME_RESET and res.track_num == 0
+    st = est.status()
+    assert st.frame_count == 0 and est.features().count() == 0
+    assert np.abs(est.window()["Ps"]).max() == 0
+    est.close()
+
+
+def test_argument_errors():
+    cfg = abi.default_config()
+    lib = abi.load_product()
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.vio_estimator_create(C.byref(cfg), 0, None, None, C.byref(h)) == abi.VIO_EINVAL
+    est = pkg.estimator.Estimator(cfg, TIC, RIC, n_seq=2)
+    assert lib.vio_estimator_clear(est._h, 2) == abi.VIO_EINVAL
+    res = abi.VioFrameResult()
+    assert lib.vio_estimator_process_image(est._h, 5, None, 0, 0.0, C.byref(res)) == abi.VIO_EINVAL
+    est.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_estimator_matches_the_python_loop_with_the_oracle_solver():
+    cfg = abi.default_config()
+    prod = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    ref = oracle_loop(cfg, seed=5)
+    for _ in range(60):
+        prod.step(), ref.step()
+    assert len(prod.history) == len(ref.history) == 60 - cfg.window_size
+    dp = np.array([a[1] - b[1] for a, b in zip(prod.history, ref.history)])
+    assert np.abs(dp).max() < 1e-5, np.abs(dp).max()
+    assert [h[3].stats.iterations for h in prod.history] == [h[3]["iterations"] for h in ref.history]
+    e = prod.errors()
+    assert np.sqrt((e ** 2).mean()) < 0.06 and e.max() < 0.15
+    st = prod.est.status()
+    assert st.solver_flag == abi.VIO_SOLVER_NON_LINEAR and st.prior_rows == ref.prior.n
+    assert prod.est.features().count() == ref.fm.count()
+    prod.close(), ref.close()
+
+
+@pytest.mark.gpu
+def test_batched_sequences_equal_single_sequences():
+    """Three sequences in one estimator (their window solves share a launch, they reach the solve phase on different
+    frames) give what three single-sequence estimators give."""
+    cfg = abi.default_config(window_size=6)
+    W = cfg.window_size
+    worlds = [RS.SyntheticWorld(cfg, 20 + q) for q in range(3)]
+    singles = [RS.EstimatorLoop(cfg, seed=20 + q, init_noise=1.0) for q in range(3)]
+    for s in singles:
+        for _ in range(24):
+            s.step()
+    est = pkg.estimator.Estimator(cfg, worlds[0].tic, worlds[0].ric, n_seq=3)
+    feeders = [RS.EstimatorLoop(cfg, seed=20 + q, init_noise=1.0, world=worlds[q]) for q in range(3)]
+    start = [0, 3, 5]                                   # sequence q starts `start[q]` calls late
+    got = [[] for _ in range(3)]
+    for call in range(24 + max(start)):
+        obs, hdr, act = [], [], []
+        for q in range(3):
+            k = call - start[q]
+            f = feeders[q]
+            if k < 0 or k >= 24:
+                obs.append(([], [])), hdr.append(0.0), act.append(0)
+                continue
+            f.est.close()
+            f.est = _SeqView(est, q)                    # the feeder's IMU / init calls go to sequence q of the shared estimator
+            obs.append(f.feed_until_image()), hdr.append(worlds[q].time(k)), act.append(1)
+        res = est.process_images(obs, hdr, act)
+        for q in range(3):
+            if res[q].action == abi.VIO_FRAME_SOLVED:
+                got[q].append(est.window(q)["Ps"][W].copy())
+    for q in range(3):
+        want = np.array([h[1] for h in singles[q].history])
+        assert len(got[q]) == len(want) and np.abs(np.array(got[q]) - want).max() < 1e-6   # (LDS atomics: sums are not bit-reproducible)
+    est.close()
+    for s in singles:
+        s.close()
+
+
+class _SeqView:
+    """Routes a feeder's single-sequence calls to sequence q of a shared estimator."""
+
+    def __init__(self, est, q):
+        self.est, self.q = est, q
+
+    def process_imu(self, dt, a, w):
+        self.est.process_imu(dt, a, w, seq=self.q)
+
+    def set_initial_state(self, *a):
+        self.est.set_initial_state(*a, seq=self.q)
+
+    def close(self):
+        pass
+
+
+@pytest.mark.gpu
+def test_failure_detection_clears_and_the_next_window_continues_the_track():
+    cfg = abi.default_config(window_size=6)
+    W = cfg.window_size
+    loop = RS.EstimatorLoop(cfg, seed=9, init_noise=1.0)
+    for _ in range(20):
+        loop.step()
+    last = loop.est.window()
+    assert loop.history[-1][3].action == abi.VIO_FRAME_SOLVED
+    # a frame that tracks nothing: f_manager.last_track_num < 4 -> failure -> clearState (VINS.cpp:216-220, 462-467)
+    k = loop.k
+    for a, w in loop.world.imu_interval(k):
+        loop.est.process_imu(loop.world.dt, a, w)
+    res = loop.est.process_image(*obs_grid(60, first_id=10 ** 6), loop.world.time(k))
+    assert res.action == abi.VIO_FRAME_FAILURE and res.failure_reasons & abi.VIO_FAIL_FEW_FEATURES
+    st = loop.est.status()
+    assert st.failure_occur == 1 and st.frame_count == 0 and st.solver_flag == abi.VIO_SOLVER_INITIAL and st.prior_rows == 0
+    # refill a window and hand over initial states in ANOTHER gauge (rotated about z, shifted): new2old must anchor the
+    # first solved window where the failed one stood (last_P_old / yaw of last_R_old), VINS.cpp:139-144
+    yaw = synth.rotvec_to_rot(np.array([0, 0, 0.7]))
+    shift = np.array([3.0, -2.0, 0.0])
+    world = loop.world
+    init = []
+    loop.world.tracked.clear()
+    for j in range(W + 1):
+        kk = k + 1 + j
+        for a, w in world.imu_interval(kk):
+            loop.est.process_imu(world.dt, a, w)
+        P, R, V = world.truth(kk)
+        init.append((world.time(kk), yaw @ P + shift, yaw @ R, yaw @ V))
+        if j == W:
+            loop.est.set_initial_state([i[0] for i in init], [i[1] for i in init], [i[2] for i in init], [i[3] for i in init],
+                                       [world.ba] * (W + 1), [world.bg] * (W + 1))
+        res = loop.est.process_image(*world.observe(kk), world.time(kk))
+    assert res.action == abi.VIO_FRAME_SOLVED
+    st = loop.est.status()
+    assert st.failure_occur == 0 and st.solver_flag == abi.VIO_SOLVER_NON_LINEAR
+    # the oldest frame of the solved window sat at last_P_old (it left with the slide; the frame after it is one
+    # frame of motion away) and the yaw gauge is the old one: the window is back in the ORIGINAL frame, not the rotated one
+    w = loop.est.window()
+    P_true = np.array([world.truth(k + 2 + j)[0] for j in range(W)])
+    d = w["Ps"][:W] - P_true
+    assert np.abs(d - d.mean(0)).max() < 0.2            # same orientation gauge as before the failure (no 0.7 rad yaw)
+    assert np.linalg.norm(w["Ps"][0] - last["Ps"][0]) < 2.0
+    loop.close()
+
+
+@pytest.mark.gpu
+def test_relocalization_adds_loop_factors_and_reports_the_drift():
+    cfg = abi.default_config()
+    W = cfg.window_size
+    loop = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    for _ in range(25):
+        loop.step()
+    assert loop.history and loop.history[-1][0] == 24
+    est, world = loop.est, loop.world
+    win = est.window()
+    i = 4                                               # the window frame the loop detector matched
+    info, pts = est.features().dump()
+    # the old keyframe saw the landmarks of frame i from the (true) pose of frame i, but its own map places that pose
+    # 1.5 m away: the drift the relocalization has to report
+    k_i = int(round((win["headers"][i] - world.time(0)) / world.frame_dt))
+    assert abs(world.time(k_i) - win["headers"][i]) < 1e-9
+    ids, xy, off = [], [], 0
+    for fid, start, n_obs in info[:, :3].astype(int):
+        if start <= i <= start + n_obs - 1 and n_obs >= 2 and start < W - 2:
+            p = pts[off + (i - start)]
+            ids.append(fid), xy.append([p[0], p[1]])
+        off += n_obs
+    assert len(ids) > 30
+    P_i, R_i = win["Ps"][i], win["Rs"][i]
+    drift = np.array([1.5, -0.5, 0.0])
+    est.set_relocalization(win["headers"][i], P_i + drift, synth.rot_to_quat(R_i), ids, xy)
+    res = loop.step()
+    assert res.action == abi.VIO_FRAME_SOLVED and res.n_loop_factors == len(ids)
+    st = est.status()
+    assert np.abs(np.array(st.r_drift).reshape(3, 3) - np.eye(3)).max() < 2e-2
+    assert np.abs(np.array(st.t_drift) - drift).max() < 0.1, st.t_drift[:]
+    assert np.abs(np.array(st.relative_t)).max() < 0.1 and abs(st.relative_yaw) < 1.0   # loop pose ~ frame i itself
+    cP, cR = est.corrected_window()
+    w2 = est.window()
+    assert np.abs(cP - (w2["Ps"] @ np.array(st.r_drift).reshape(3, 3).T + np.array(st.t_drift))).max() < 1e-12
+    # the constraint stays while its frame is in the window, then drops out
+    n_loop = []
+    for _ in range(80):
+        n_loop.append(loop.step().n_loop_factors)
+        if n_loop[-1] == 0:
+            break
+    assert n_loop[0] > 0 and n_loop[-1] == 0 and all(a >= b for a, b in zip(n_loop, n_loop[1:]))
+    assert est.window()["headers"][0] > win["headers"][i]          # ... which happened because its frame left the window
+    loop.close()
+
+
+@pytest.mark.gpu
+def test_bad_initial_state_fails_the_cost_check_and_returns_to_initial():
+    """The branch after solveInitial: a first solve that ends above final_cost 200 drops the prior and goes back to
+    INITIAL (VINS.cpp:415-424); a good hand-over afterwards succeeds."""
+    cfg = abi.default_config(window_size=6)
+    W = cfg.window_size
+    loop = RS.EstimatorLoop(cfg, seed=13, init_noise=0.0)
+    world, est = loop.world, loop.est
+    for k in range(W + 1):
+        ids, xyz = loop.feed_until_image()
+        if k == W:   # overwrite the pending hand-over with garbage: identity attitudes on a straight line
+            P = W + 1
+            est.set_initial_state([world.time(j) for j in range(P)], [[0.3 * j, 0, 0] for j in range(P)], [np.eye(3)] * P,
+                                  [[3.0, 0, 0]] * P, [[0, 0, 0]] * P, [[0, 0, 0]] * P)
+        res = est.process_image(ids, xyz, world.time(k))
+    assert res.action == abi.VIO_FRAME_INIT_FAILED and res.stats.final_cost > 200
+    st = est.status()
+    assert st.solver_flag == abi.VIO_SOLVER_INITIAL and st.prior_rows == 0 and st.frame_count == W
+    # next frame: the window holds frames 1..W+1 (or 0..W-1,W+1 after a non-keyframe slide); hand over the truth
+    k = loop.k
+    ids, xyz = loop.feed_until_image()
+    hdr = est.window()["headers"].copy()
+    hdr[W] = world.time(k)
+    ks = [int(round((h - world.time(0)) / world.frame_dt)) for h in hdr]
+    tr = [world.truth(j) for j in ks]
+    est.set_initial_state(hdr, [t[0] for t in tr], [t[1] for t in tr], [t[2] for t in tr], [world.ba] * (W + 1), [world.bg] * (W + 1))
+    res = est.process_image(ids, xyz, world.time(k))
+    assert res.action == abi.VIO_FRAME_SOLVED and res.stats.final_cost < 200
+    assert est.status().solver_flag == abi.VIO_SOLVER_NON_LINEAR
+    assert np.abs(est.window()["Ps"][W] - world.truth(k)[0]).max() < 0.1
+    loop.close()

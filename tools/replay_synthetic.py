@@ -151,7 +151,7 @@ class ClosedLoop:
         for a1, w1 in samples:
             un_acc_0 = R @ (acc0 - ba) - g
             un_gyr = 0.5 * (gyr0 + w1) - bg
-            R = R @ synth.rotvec_to_rot(un_gyr * dt)
+            R = R @ synth.quat_to_rot(np.array([*(un_gyr * dt / 2), 1.0]), normalize=False)  # Utility::deltaQ, unnormalized
             un_acc_1 = R @ (a1 - ba) - g
             un_acc = 0.5 * (un_acc_0 + un_acc_1)
             P = P + dt * V + 0.5 * dt * dt * un_acc
@@ -211,13 +211,13 @@ class ClosedLoop:
             self.Ps[i], self.Rs[i] = w.pose[i, :3].copy(), synth.quat_to_rot(w.pose[i, 3:])
             self.Vs[i], self.Bas[i], self.Bgs[i] = w.speed_bias[i, :3].copy(), w.speed_bias[i, 3:6].copy(), w.speed_bias[i, 6:].copy()
         fm.set_depth(w.inv_depth)
-        fm.remove_failures()
         if w.next_prior.n > 0:   # n == -1: MARGIN_SECOND_NEW left the old prior untouched (VINS.cpp:778-779)
             self.prior = w.next_prior.copy()
         if enough:               # slideWindowOld (VINS.cpp:1253-1273)
             R0, P0 = self.Rs[0] @ world.ric, self.Ps[0] + self.Rs[0] @ world.tic
-            for lst in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs, self.pre_arr, self.pre_samples):
+            for lst in (self.Ps, self.Rs, self.Vs, self.pre_arr, self.pre_samples):
                 lst.pop(0)
+            self.Bas.pop(), self.Bgs.pop()  # the reference's loop does not rotate Bas / Bgs (VINS.cpp:1160-1176), restated as is
             fm.remove_back_shift_depth(R0, P0, self.Rs[0] @ world.ric, self.Ps[0] + self.Rs[0] @ world.tic)
         else:                    # slideWindowNew (VINS.cpp:1204-1251): frame W-1 leaves, its IMU samples join the last interval
             (imu0, s_a), (_, s_b) = self.pre_samples[W - 2], self.pre_samples[W - 1]
@@ -229,6 +229,7 @@ class ClosedLoop:
             for lst in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
                 lst.pop(W - 1)
             fm.remove_front(self.frame_count)
+        fm.remove_failures()     # after the slide (VINS.cpp:469-470)
         return stats
 
     def errors(self):
@@ -242,8 +243,71 @@ class ClosedLoop:
         self.fm.close()
 
 
+class EstimatorLoop:
+    """The same replay through the native estimator (vio_estimator_*, csrc/vio_estimator.cpp): this class only feeds IMU
+    samples and image_msg lists and, once, the initial window (in place of solveInitial)."""
+
+    def __init__(self, cfg, seed=1, init_noise=0.0, tracker=None, n_seq=1, world=None):
+        self.cfg, self.W = cfg, cfg.window_size
+        self.tracker = tracker
+        self.world = world or (ImageWorld(cfg, seed) if tracker is not None else SyntheticWorld(cfg, seed))
+        self.est = pkg.estimator.Estimator(cfg, self.world.tic, self.world.ric, n_seq=n_seq)
+        self.k = 0
+        self.init_noise = init_noise
+        self.rng = np.random.default_rng(seed + 99)
+        self.init = []
+        self.history = []   # (frame k, estimated position of the newest frame, true position, VioFrameResult)
+
+    def feed_until_image(self):
+        """IMU samples up to frame k, the initial window when it is due; returns image_msg of frame k as (ids, xyz)."""
+        world, W, k, est = self.world, self.W, self.k, self.est
+        if k == 0:
+            a, w = world.imu(world.time(0))
+            est.process_imu(world.dt, a, w)
+        else:
+            for a, w in world.imu_interval(k):
+                est.process_imu(world.dt, a, w)
+        if k <= W:
+            Pt, Rt, Vt = world.truth(k)
+            n = self.init_noise
+            P = Pt + self.rng.normal(0, 0.01 * n, 3)
+            R = Rt @ synth.rotvec_to_rot(self.rng.normal(0, 0.005 * n, 3))
+            V = Vt + self.rng.normal(0, 0.02 * n, 3)
+            if k == 0:
+                self.ba0, self.bg0 = world.ba + self.rng.normal(0, 0.01 * n, 3), world.bg + self.rng.normal(0, 0.001 * n, 3)
+            self.init.append((world.time(k), P, R, V))
+            if k == W:
+                est.set_initial_state([i[0] for i in self.init], [i[1] for i in self.init], [i[2] for i in self.init],
+                                      [i[3] for i in self.init], [self.ba0] * (W + 1), [self.bg0] * (W + 1))
+        if self.tracker is not None:
+            ids, xyz = self.tracker.read_images(world.render(k)[None], True)[0]
+        else:
+            ids, xyz = world.observe(k)
+        self.k += 1
+        return ids, xyz
+
+    def step(self):
+        k, W, world, est = self.k, self.W, self.world, self.est
+        ids, xyz = self.feed_until_image()
+        res = est.process_image(ids, xyz, world.time(k))
+        if res.action == abi.VIO_FRAME_SOLVED:
+            self.history.append((k, est.window()["Ps"][W].copy(), world.truth(k)[0], res))
+        return res
+
+    def errors(self):
+        est = np.array([h[1] for h in self.history])
+        tru = np.array([h[2] for h in self.history])
+        d = est - tru
+        d = d - d[0]
+        return np.sqrt((d ** 2).sum(1))
+
+    def close(self):
+        self.est.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--python-loop", action="store_true", help="window bookkeeping in this file instead of the native estimator")
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--images", action="store_true", help="render frames of a textured plane and run the KLT front-end on them")
@@ -253,11 +317,14 @@ def main():
     solver = pkg.backend.WindowSolver(cfg, max_batch=1)
     pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
     tracker = pkg.frontend.FeatureTracker(cfg, n_seq=1) if args.images else None
-    loop = ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=args.seed, init_noise=1.0, tracker=tracker)
+    if args.python_loop:
+        loop = ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=args.seed, init_noise=1.0, tracker=tracker)
+    else:
+        loop = EstimatorLoop(cfg, seed=args.seed, init_noise=1.0, tracker=tracker)
     for _ in range(args.frames):
         loop.step()
     e = loop.errors()
-    flags = [h[3]["iterations"] for h in loop.history]
+    flags = [h[3]["iterations"] if args.python_loop else h[3].stats.iterations for h in loop.history]
     print("frames %d, solves %d, position error of the newest frame: rms %.4f m, max %.4f m, final %.4f m; mean iterations %.1f"
           % (args.frames, len(e), np.sqrt((e ** 2).mean()), e.max(), e[-1], np.mean(flags)))
     loop.close()

@@ -111,6 +111,25 @@ class VioObs(C.Structure):
     _fields_ = [("id", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
 
 
+class VioFrameResult(C.Structure):
+    _fields_ = [("action", C.c_int32), ("error", C.c_int32), ("marginalization_flag", C.c_int32),
+                ("failure_reasons", C.c_int32), ("track_num", C.c_int32), ("n_features", C.c_int32),
+                ("n_factors", C.c_int32), ("n_loop_factors", C.c_int32), ("stats", VioSolveStats)]
+
+
+class VioEstimatorStatus(C.Structure):
+    _fields_ = [("frame_count", C.c_int32), ("solver_flag", C.c_int32), ("marginalization_flag", C.c_int32),
+                ("failure_occur", C.c_int32), ("prior_rows", C.c_int32), ("final_cost", C.c_double),
+                ("r_drift", C.c_double * 9), ("t_drift", C.c_double * 3), ("relative_t", C.c_double * 3),
+                ("relative_q", C.c_double * 4), ("relative_yaw", C.c_double), ("loop_pose", C.c_double * 7)]
+
+
+VIO_SOLVER_INITIAL, VIO_SOLVER_NON_LINEAR = 0, 1
+VIO_FAIL_FEW_FEATURES, VIO_FAIL_GYR_BIAS, VIO_FAIL_TRANSLATION, VIO_FAIL_Z_TRANSLATION, VIO_FAIL_ROTATION = 1, 2, 4, 8, 16
+(VIO_FRAME_SKIPPED, VIO_FRAME_FILLING, VIO_FRAME_WAIT_INIT, VIO_FRAME_INIT_FAILED, VIO_FRAME_SOLVED, VIO_FRAME_FAILURE,
+ VIO_FRAME_RESET, VIO_FRAME_ERROR) = range(8)
+
+
 class VioFeatureInfo(C.Structure):
     _fields_ = [("id", C.c_int32), ("start_frame", C.c_int32), ("n_obs", C.c_int32), ("used_num", C.c_int32),
                 ("solve_flag", C.c_int32), ("is_outlier", C.c_int32), ("fixed", C.c_int32),
@@ -414,6 +433,22 @@ def load_product():
     lib.vio_features_export_factors.argtypes = [vp, C.c_int32, _ip, _ip, _ip, _dp, _dp, _ip, _ip]
     lib.vio_features_dump.argtypes = [vp, infop, C.c_int32, _ip, _dp, C.c_int32, _ip]
     lib.vio_failure_detection.argtypes = [C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
+    lib.vio_features_export_factors_loop.argtypes = [vp, C.c_int32, C.c_int32, _ip, _dp, C.c_int32, _ip, _ip, _ip, _dp, _dp,
+                                                     _ip, _ip, _ip]
+    resp, stp = C.POINTER(VioFrameResult), C.POINTER(VioEstimatorStatus)
+    lib.vio_estimator_create.argtypes = [cfgp, C.c_int32, _dp, _dp, C.POINTER(vp)]
+    lib.vio_estimator_destroy.argtypes = [vp]
+    lib.vio_estimator_destroy.restype = None
+    lib.vio_estimator_clear.argtypes = [vp, C.c_int32]
+    lib.vio_estimator_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
+    lib.vio_estimator_set_initial_state.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.vio_estimator_set_relocalization.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp, _ip, _dp, C.c_int32]
+    lib.vio_estimator_process_images.argtypes = [vp, obsp, _ip, C.c_int32, _dp, u8p, resp]
+    lib.vio_estimator_process_image.argtypes = [vp, C.c_int32, obsp, C.c_int32, C.c_double, resp]
+    lib.vio_estimator_get_status.argtypes = [vp, C.c_int32, stp]
+    lib.vio_estimator_get_window.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.vio_estimator_get_corrected_window.argtypes = [vp, C.c_int32, _dp, _dp]
+    lib.vio_estimator_features.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
     lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib

@@ -1,0 +1,618 @@
+// vio_estimator.cpp — the estimator state machine around the device solve (host side), for n independent sequences.
+//
+// Reference: class VINS (VINS_ios/VINS.hpp:47-200): processIMU (VINS.cpp:333-375), processImage (:377-478), the host
+// half of solve_ceres (old2new :89-129, the factor list :528-637, the loop bookkeeping :664-680 and new2old :168-189),
+// failureDetection (:214-265), slideWindow / slideWindowOld / slideWindowNew (:1149-1273), clearState (:36-81).
+// One reference VINS object = one sequence here; the solve of ALL sequences that have a frame to solve goes to the
+// device in ONE launch of the window kernel (vio_backend_solve_windows), everything else is the same small host
+// bookkeeping the reference does on its "mainLoop" thread.
+//
+// What is NOT here: solveInitial (VINS.cpp:833-1145). Where the reference calls it, the estimator
+// takes the window states the caller handed over with vio_estimator_set_initial_state — same branch structure after it
+// (first solve, final_cost > 200 check, fall back to INITIAL).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "vio_amd.h"
+#include "vio_math.h"
+#include "vio_preint.h"
+
+using namespace vio;
+
+namespace {
+
+struct Relocalization {  // RetriveData (VINS.hpp:28-45), the fields the solve reads and writes
+  double header = -1;
+  double P_old[3] = {0, 0, 0};
+  Quat Q_old{0, 0, 0, 1};
+  std::vector<int32_t> ids;
+  std::vector<double> xy;
+  double loop_pose[7] = {0, 0, 0, 0, 0, 0, 1};
+  double relative_t[3] = {0, 0, 0};
+  Quat relative_q{0, 0, 0, 1};
+  double relative_yaw = 0;
+};
+
+struct PriorBuf {
+  VioPrior p;
+  std::vector<double> x0, J, r;
+  void init(int cap) {
+    x0.assign((size_t)VIO_MAX_PRIOR_BLOCKS * 9, 0.0), J.assign((size_t)cap * cap, 0.0), r.assign(cap, 0.0);
+    memset(&p, 0, sizeof(p));
+    p.block_x0 = x0.data(), p.linearized_jacobians = J.data(), p.linearized_residuals = r.data();
+  }
+};
+
+struct Sequence {
+  int frame_count = 0, solver_flag = VIO_SOLVER_INITIAL, marginalization_flag = VIO_MARGIN_OLD;
+  bool first_imu = false;
+  int failure_occur = 0;
+  double acc_0[3] = {0, 0, 0}, gyr_0[3] = {0, 0, 0};
+  std::vector<double> Ps, Rs, Vs, Bas, Bgs, Headers;  // [W+1] x {3, 9, 3, 3, 3, 1}
+  std::vector<host::Preint> pre;                      // pre_integrations[i]
+  std::vector<char> pre_valid;
+  std::vector<std::vector<double>> dt_buf, acc_buf, gyr_buf;
+  std::vector<double> lin_acc, lin_gyr;  // [W+1][3] IntegrationBase::linearized_acc / linearized_gyr (the first sample)
+  vio_features_t *fm = nullptr;
+  PriorBuf prior[2];
+  int cur_prior = 0;
+  bool has_prior = false;
+  double last_R[9], last_P[3], last_R_old[9], last_P_old[3];
+  double r_drift[9], t_drift[3];
+  Relocalization retrive, front;
+  bool loop_enable = false;
+  double final_cost = 0;
+  // initial window handed over in place of solveInitial
+  bool init_pending = false;
+  std::vector<double> init_headers, init_Ps, init_Rs, init_Vs, init_Bas, init_Bgs;
+  // scratch of the window being solved
+  std::vector<double> pose, sb, inv_depth, raw_pose, raw_sb, pts_i, pts_j;
+  std::vector<int32_t> f_host, f_target, f_feat;
+  std::vector<VioPreintegration> preint;
+  double ex_pose[7], loop_pose[7];
+  int loop_frame = -1, n_loop_factors = 0;
+  int last_track_num = 0;
+};
+
+const double kI3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+}  // namespace
+
+struct vio_estimator {
+  VioConfig cfg;
+  int W = 10, n_seq = 0;
+  double tic[3], ric[9];
+  std::vector<Sequence> seq;
+  vio_backend_t *be = nullptr;  // created at the first solve: IMU propagation and window filling need no device
+  std::vector<VioWindow> windows;
+  std::vector<VioSolveStats> stats;
+  std::vector<int> solving;  // sequences of the current launch
+};
+
+namespace {
+
+void clear_state(vio_estimator *e, Sequence &s) {  // VINS::clearState (VINS.cpp:36-81)
+  const int P = e->W + 1;
+  for (int i = 0; i < P; i++) {
+    memcpy(&s.Rs[9 * i], kI3, sizeof(kI3));
+    for (int k = 0; k < 3; k++) s.Ps[3 * i + k] = s.Vs[3 * i + k] = s.Bas[3 * i + k] = s.Bgs[3 * i + k] = 0;
+    s.pre_valid[i] = 0;
+    s.dt_buf[i].clear(), s.acc_buf[i].clear(), s.gyr_buf[i].clear();
+  }
+  s.frame_count = 0;
+  s.first_imu = false;
+  s.solver_flag = VIO_SOLVER_INITIAL;
+  s.has_prior = false;
+  s.init_pending = false;
+  vio_features_clear(s.fm);
+}
+
+void new_preintegration(vio_estimator *e, Sequence &s, int i) {
+  host::preint_init(s.pre[i], &e->cfg, s.acc_0, s.gyr_0, &s.Bas[3 * i], &s.Bgs[3 * i]);
+  memcpy(&s.lin_acc[3 * i], s.acc_0, 24), memcpy(&s.lin_gyr[3 * i], s.gyr_0, 24);
+  s.pre_valid[i] = 1;
+}
+
+// IntegrationBase::repropagate (integration_base.h:47-61): the same samples again from new linearization biases
+void repropagate(vio_estimator *e, Sequence &s, int i, const double ba[3], const double bg[3]) {
+  if (!s.pre_valid[i]) return;
+  host::preint_init(s.pre[i], &e->cfg, &s.lin_acc[3 * i], &s.lin_gyr[3 * i], ba, bg);
+  for (size_t k = 0; k < s.dt_buf[i].size(); k++)
+    host::propagate(s.pre[i], s.dt_buf[i][k], &s.acc_buf[i][3 * k], &s.gyr_buf[i][3 * k]);
+}
+
+// slideWindow (VINS.cpp:1149-1237) + slideWindowOld / slideWindowNew (:1239-1273)
+void slide_window(vio_estimator *e, Sequence &s) {
+  const int W = e->W;
+  if (s.frame_count != W) return;
+  if (s.marginalization_flag == VIO_MARGIN_OLD) {
+    double back_R0[9], back_P0[3];
+    memcpy(back_R0, &s.Rs[0], sizeof(back_R0)), memcpy(back_P0, &s.Ps[0], sizeof(back_P0));
+    for (int i = 0; i < W; i++) {
+      for (int k = 0; k < 9; k++) std::swap(s.Rs[9 * i + k], s.Rs[9 * (i + 1) + k]);
+      std::swap(s.pre[i], s.pre[i + 1]), std::swap(s.pre_valid[i], s.pre_valid[i + 1]);
+      s.dt_buf[i].swap(s.dt_buf[i + 1]), s.acc_buf[i].swap(s.acc_buf[i + 1]), s.gyr_buf[i].swap(s.gyr_buf[i + 1]);
+      for (int k = 0; k < 3; k++)
+        std::swap(s.lin_acc[3 * i + k], s.lin_acc[3 * (i + 1) + k]), std::swap(s.lin_gyr[3 * i + k], s.lin_gyr[3 * (i + 1) + k]);
+      s.Headers[i] = s.Headers[i + 1];
+      for (int k = 0; k < 3; k++)
+        std::swap(s.Ps[3 * i + k], s.Ps[3 * (i + 1) + k]), std::swap(s.Vs[3 * i + k], s.Vs[3 * (i + 1) + k]);
+    }
+    // (Bas / Bgs are not rotated by the reference's loop: only the newest slot is overwritten below — restated as is;
+    // the solve rewrites all of them from para_SpeedBias every frame)
+    s.Headers[W] = s.Headers[W - 1];
+    memcpy(&s.Rs[9 * W], &s.Rs[9 * (W - 1)], 72);
+    for (int k = 0; k < 3; k++) {
+      s.Ps[3 * W + k] = s.Ps[3 * (W - 1) + k], s.Vs[3 * W + k] = s.Vs[3 * (W - 1) + k];
+      s.Bas[3 * W + k] = s.Bas[3 * (W - 1) + k], s.Bgs[3 * W + k] = s.Bgs[3 * (W - 1) + k];
+    }
+    new_preintegration(e, s, W);
+    s.dt_buf[W].clear(), s.acc_buf[W].clear(), s.gyr_buf[W].clear();
+    // slideWindowOld: the landmarks hosted in the departed frame move to the next one
+    if (s.solver_flag == VIO_SOLVER_NON_LINEAR) {
+      double R0[9], R1[9], P0[3], P1[3], t[3];
+      mat3mul(back_R0, e->ric, R0), mat3mul(&s.Rs[0], e->ric, R1);
+      mat3vec(back_R0, e->tic, t);
+      for (int k = 0; k < 3; k++) P0[k] = back_P0[k] + t[k];
+      mat3vec(&s.Rs[0], e->tic, t);
+      for (int k = 0; k < 3; k++) P1[k] = s.Ps[k] + t[k];
+      vio_features_remove_back_shift_depth(s.fm, R0, P0, R1, P1);
+    } else {
+      vio_features_remove_back(s.fm);
+    }
+  } else {
+    // the second-newest frame leaves; its IMU samples extend the interval of the frame before it
+    const int fc = s.frame_count;
+    for (size_t i = 0; i < s.dt_buf[fc].size(); i++) {
+      const double dt = s.dt_buf[fc][i];
+      if (s.pre_valid[fc - 1]) host::propagate(s.pre[fc - 1], dt, &s.acc_buf[fc][3 * i], &s.gyr_buf[fc][3 * i]);
+      s.dt_buf[fc - 1].push_back(dt);
+      for (int k = 0; k < 3; k++)
+        s.acc_buf[fc - 1].push_back(s.acc_buf[fc][3 * i + k]), s.gyr_buf[fc - 1].push_back(s.gyr_buf[fc][3 * i + k]);
+    }
+    s.Headers[fc - 1] = s.Headers[fc];
+    memcpy(&s.Rs[9 * (fc - 1)], &s.Rs[9 * fc], 72);
+    for (int k = 0; k < 3; k++) {
+      s.Ps[3 * (fc - 1) + k] = s.Ps[3 * fc + k], s.Vs[3 * (fc - 1) + k] = s.Vs[3 * fc + k];
+      s.Bas[3 * (fc - 1) + k] = s.Bas[3 * fc + k], s.Bgs[3 * (fc - 1) + k] = s.Bgs[3 * fc + k];
+    }
+    new_preintegration(e, s, W);
+    s.dt_buf[W].clear(), s.acc_buf[W].clear(), s.gyr_buf[W].clear();
+    vio_features_remove_front(s.fm, s.frame_count);
+  }
+}
+
+// old2new + the factor list + the loop pose: everything solve_ceres hands to the solver (VINS.cpp:89-129, 505-637)
+int build_window(vio_estimator *e, Sequence &s, VioWindow *w) {
+  const int W = e->W, P = W + 1;
+  for (int i = 0; i < P; i++) {
+    const Quat q = RtoQ(&s.Rs[9 * i]);
+    double *p = &s.pose[7 * i], *b = &s.sb[9 * i];
+    p[0] = s.Ps[3 * i], p[1] = s.Ps[3 * i + 1], p[2] = s.Ps[3 * i + 2], p[3] = q.x, p[4] = q.y, p[5] = q.z, p[6] = q.w;
+    for (int k = 0; k < 3; k++) b[k] = s.Vs[3 * i + k], b[3 + k] = s.Bas[3 * i + k], b[6 + k] = s.Bgs[3 * i + k];
+  }
+  {
+    const Quat q = RtoQ(e->ric);
+    s.ex_pose[0] = e->tic[0], s.ex_pose[1] = e->tic[1], s.ex_pose[2] = e->tic[2];
+    s.ex_pose[3] = q.x, s.ex_pose[4] = q.y, s.ex_pose[5] = q.z, s.ex_pose[6] = q.w;
+  }
+  int nf = 0;
+  int rc = vio_features_get_depth_vector(s.fm, s.inv_depth.data(), e->cfg.max_features, &nf);
+  if (rc != VIO_OK) return rc;
+  // relocalization constraint: front_pose follows retrive_pose_data; it enters when its frame is still in the window
+  if (s.front.header != s.retrive.header) s.front = s.retrive;
+  s.loop_frame = -1;
+  if (!s.front.ids.empty() && s.front.header >= s.Headers[0])
+    for (int i = 0; i < W; i++)
+      if (s.front.header == s.Headers[i]) s.loop_frame = i;
+  int m = 0, nf2 = 0;
+  rc = vio_features_export_factors_loop(s.fm, e->cfg.max_factors, s.loop_frame, s.front.ids.data(), s.front.xy.data(),
+                                        (int)s.front.ids.size(), s.f_host.data(), s.f_target.data(), s.f_feat.data(),
+                                        s.pts_i.data(), s.pts_j.data(), &m, &nf2, &s.n_loop_factors);
+  if (rc != VIO_OK) return rc;
+  if (nf2 != nf) return VIO_ESTATE;
+  if (s.n_loop_factors > 0) s.loop_enable = true;
+  if (s.loop_frame >= 0 && s.n_loop_factors == 0) s.loop_frame = -1;  // a loop pose without factors is a free block
+  for (int i = 0; i < W; i++) {
+    if (!s.pre_valid[i + 1]) return VIO_ESTATE;
+    host::preint_export(s.pre[i + 1], &s.preint[i]);
+  }
+  memset(w, 0, sizeof(*w));
+  w->window_size = W, w->n_features = nf, w->n_factors = m, w->marginalization_flag = s.marginalization_flag;
+  w->pose = s.pose.data(), w->speed_bias = s.sb.data(), w->ex_pose = s.ex_pose, w->inv_depth = s.inv_depth.data();
+  w->factor_host = s.f_host.data(), w->factor_target = s.f_target.data(), w->factor_feature = s.f_feat.data();
+  w->factor_pts_i = s.pts_i.data(), w->factor_pts_j = s.pts_j.data();
+  w->preint = s.preint.data();
+  w->prior = s.has_prior ? &s.prior[s.cur_prior].p : nullptr;
+  w->loop_frame = s.loop_frame, w->loop_pose = s.loop_pose;
+  if (s.failure_occur) {  // new2old anchors the window where the failed one stood (VINS.cpp:139-144)
+    double ypr[3];
+    R2ypr(s.last_R_old, ypr);
+    w->use_origin_override = 1, w->origin_yaw_deg = ypr[0];
+    memcpy(w->origin_p, s.last_P_old, sizeof(w->origin_p));
+  }
+  w->raw_pose = s.raw_pose.data(), w->raw_speed_bias = s.raw_sb.data(), w->raw_inv_depth = nullptr;
+  w->next_prior = &s.prior[1 - s.cur_prior].p;
+  return VIO_OK;
+}
+
+double normalize_angle(double a) {  // Utility::normalizeAngle, degrees (utility.hpp:171-179)
+  const double two_pi = 2.0 * 180;
+  if (a > 0) return a - two_pi * floor((a + 180.0) / two_pi);
+  return a + two_pi * floor((-a + 180.0) / two_pi);
+}
+
+// double2vector of the solved window (the device already applied new2old to the para arrays), the loop bookkeeping
+// (VINS.cpp:664-680, 168-189) and the prior hand-over.
+void take_solution(vio_estimator *e, Sequence &s, const VioWindow &w, const VioSolveStats &st) {
+  const int W = e->W, P = W + 1;
+  s.final_cost = st.final_cost;
+  if (s.loop_frame >= 0) {
+    const int i = s.loop_frame;
+    const double *rp = &s.raw_pose[7 * i];
+    double Rs_i[9], Rs_loop[9], RlT[9], d[3], ypr_i[3], ypr_l[3];
+    qtoR(qnormalized(qfrom_pose(rp)), Rs_i);
+    qtoR(qnormalized(qfrom_pose(s.loop_pose)), Rs_loop);
+    mat3T(Rs_loop, RlT);
+    for (int k = 0; k < 3; k++) d[k] = rp[k] - s.loop_pose[k];
+    mat3vec(RlT, d, s.front.relative_t);
+    double Rrel[9];
+    mat3mul(RlT, Rs_i, Rrel);
+    s.front.relative_q = RtoQ(Rrel);
+    R2ypr(Rs_i, ypr_i), R2ypr(Rs_loop, ypr_l);
+    s.front.relative_yaw = normalize_angle(ypr_i[0] - ypr_l[0]);
+    memcpy(s.front.loop_pose, s.loop_pose, sizeof(s.loop_pose));
+  }
+  // the gauge the device applied: rot_diff and origin_P0 of new2old, needed once more for the loop pose
+  double origin_ypr[3], origin_P0[3], raw_ypr[3], R00[9], rot_diff[9];
+  if (s.failure_occur) {
+    R2ypr(s.last_R_old, origin_ypr), memcpy(origin_P0, s.last_P_old, 24);
+  } else {
+    R2ypr(&s.Rs[0], origin_ypr), memcpy(origin_P0, &s.Ps[0], 24);
+  }
+  qtoR(qfrom_pose(&s.raw_pose[0]), R00);
+  R2ypr(R00, raw_ypr);
+  const double yd[3] = {origin_ypr[0] - raw_ypr[0], 0, 0};
+  ypr2R(yd, rot_diff);
+  for (int i = 0; i < P; i++) {
+    const double *p = &s.pose[7 * i], *b = &s.sb[9 * i];
+    qtoR(qfrom_pose(p), &s.Rs[9 * i]);
+    for (int k = 0; k < 3; k++)
+      s.Ps[3 * i + k] = p[k], s.Vs[3 * i + k] = b[k], s.Bas[3 * i + k] = b[3 + k], s.Bgs[3 * i + k] = b[6 + k];
+  }
+  if (s.loop_enable) {  // drift of the window against the old keyframe (VINS.cpp:168-189)
+    s.loop_enable = false;
+    if (s.loop_frame >= 0) {
+      double Rl[9], Rloop[9], d[3], Pl[3], ypr_old[3], ypr_loop[3], Rold[9];
+      qtoR(qnormalized(qfrom_pose(s.loop_pose)), Rl);
+      mat3mul(rot_diff, Rl, Rloop);
+      for (int k = 0; k < 3; k++) d[k] = s.loop_pose[k] - s.raw_pose[k];
+      mat3vec(rot_diff, d, Pl);
+      for (int k = 0; k < 3; k++) Pl[k] += origin_P0[k];
+      qtoR(s.front.Q_old, Rold);
+      R2ypr(Rold, ypr_old), R2ypr(Rloop, ypr_loop);
+      const double dy[3] = {ypr_old[0] - ypr_loop[0], 0, 0};
+      ypr2R(dy, s.r_drift);
+      double t[3];
+      mat3vec(s.r_drift, Pl, t);
+      for (int k = 0; k < 3; k++) s.t_drift[k] = s.front.P_old[k] - t[k];
+    }
+  }
+  vio_features_set_depth(s.fm, s.inv_depth.data(), w.n_features);
+  // n == -1: MARGIN_SECOND_NEW without the second-newest pose in the old prior leaves it as it was (VINS.cpp:778-779)
+  if (w.next_prior && w.next_prior->n > 0) s.cur_prior = 1 - s.cur_prior, s.has_prior = true;
+}
+
+void remember_last(vio_estimator *e, Sequence &s) {  // VINS.cpp:431-434, 472-475
+  const int W = e->W;
+  memcpy(s.last_R, &s.Rs[9 * W], 72), memcpy(s.last_P, &s.Ps[3 * W], 24);
+  memcpy(s.last_R_old, &s.Rs[0], 72), memcpy(s.last_P_old, &s.Ps[0], 24);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3], const double ric[9],
+                         vio_estimator_t **out) {
+  if (!cfg || !out || n_seq < 1 || !tic || !ric || cfg->window_size < 3 || cfg->max_features < 1 || cfg->max_factors < 1)
+    return VIO_EINVAL;
+  vio_estimator *e = new (std::nothrow) vio_estimator();
+  if (!e) return VIO_ENOMEM;
+  e->cfg = *cfg, e->W = cfg->window_size, e->n_seq = n_seq;
+  memcpy(e->tic, tic, 24), memcpy(e->ric, ric, 72);
+  const int W = e->W, P = W + 1, cap = vio_prior_capacity(W);
+  e->seq.resize(n_seq);
+  for (Sequence &s : e->seq) {
+    s.Ps.assign(3 * P, 0), s.Rs.assign(9 * P, 0), s.Vs.assign(3 * P, 0), s.Bas.assign(3 * P, 0), s.Bgs.assign(3 * P, 0);
+    s.Headers.assign(P, 0);
+    s.pre.resize(P), s.pre_valid.assign(P, 0);
+    s.dt_buf.resize(P), s.acc_buf.resize(P), s.gyr_buf.resize(P);
+    s.lin_acc.assign(3 * P, 0), s.lin_gyr.assign(3 * P, 0);
+    if (vio_features_create(W, &s.fm) != VIO_OK) {
+      vio_estimator_destroy(e);
+      return VIO_ENOMEM;
+    }
+    s.prior[0].init(cap), s.prior[1].init(cap);
+    memcpy(s.last_R, kI3, 72), memcpy(s.last_R_old, kI3, 72), memcpy(s.r_drift, kI3, 72);
+    for (int k = 0; k < 3; k++) s.last_P[k] = s.last_P_old[k] = s.t_drift[k] = 0;
+    s.pose.assign(7 * P, 0), s.sb.assign(9 * P, 0), s.raw_pose.assign(7 * P, 0), s.raw_sb.assign(9 * P, 0);
+    s.inv_depth.assign(cfg->max_features, 0);
+    s.pts_i.assign((size_t)3 * cfg->max_factors, 0), s.pts_j.assign((size_t)3 * cfg->max_factors, 0);
+    s.f_host.assign(cfg->max_factors, 0), s.f_target.assign(cfg->max_factors, 0), s.f_feat.assign(cfg->max_factors, 0);
+    s.preint.resize(W);
+    clear_state(e, s);
+  }
+  e->windows.resize(n_seq), e->stats.resize(n_seq);
+  *out = e;
+  return VIO_OK;
+}
+
+void vio_estimator_destroy(vio_estimator_t *e) {
+  if (!e) return;
+  for (Sequence &s : e->seq)
+    if (s.fm) vio_features_destroy(s.fm);
+  if (e->be) vio_backend_destroy(e->be);
+  delete e;
+}
+
+int vio_estimator_clear(vio_estimator_t *e, int32_t seq) {
+  if (!e || seq < 0 || seq >= e->n_seq) return VIO_EINVAL;
+  clear_state(e, e->seq[seq]);
+  return VIO_OK;
+}
+
+// VINS::processIMU (VINS.cpp:333-375): extend the pre-integration of the interval that ends in the frame being filled
+// and propagate that frame's state with the midpoint rule.
+int vio_estimator_process_imu(vio_estimator_t *e, int32_t seq, double dt, const double acc[3], const double gyr[3]) {
+  if (!e || seq < 0 || seq >= e->n_seq || !acc || !gyr) return VIO_EINVAL;
+  Sequence &s = e->seq[seq];
+  if (!s.first_imu) {
+    s.first_imu = true;
+    memcpy(s.acc_0, acc, 24), memcpy(s.gyr_0, gyr, 24);
+  }
+  const int j = s.frame_count;
+  if (!s.pre_valid[j]) new_preintegration(e, s, j);
+  if (j != 0) {
+    host::propagate(s.pre[j], dt, acc, gyr);
+    s.dt_buf[j].push_back(dt);
+    for (int k = 0; k < 3; k++) s.acc_buf[j].push_back(acc[k]), s.gyr_buf[j].push_back(gyr[k]);
+    const double g[3] = {0, 0, e->cfg.gravity};
+    double *R = &s.Rs[9 * j], *Pj = &s.Ps[3 * j], *V = &s.Vs[3 * j];
+    const double *ba = &s.Bas[3 * j], *bg = &s.Bgs[3 * j];
+    double a0[3], ua0[3], w[3], a1[3], ua1[3];
+    for (int k = 0; k < 3; k++) a0[k] = s.acc_0[k] - ba[k], w[k] = 0.5 * (s.gyr_0[k] + gyr[k]) - bg[k];
+    mat3vec(R, a0, ua0);
+    // Rs[j] *= deltaQ(un_gyr * dt).toRotationMatrix()  (utility.hpp:22-34: a small-angle quaternion, NOT normalized)
+    double dR[9], Rn[9];
+    qtoR(Quat{w[0] * dt / 2, w[1] * dt / 2, w[2] * dt / 2, 1.0}, dR);
+    mat3mul(R, dR, Rn);
+    memcpy(R, Rn, 72);
+    for (int k = 0; k < 3; k++) a1[k] = acc[k] - ba[k];
+    mat3vec(R, a1, ua1);
+    for (int k = 0; k < 3; k++) {
+      const double ua = 0.5 * ((ua0[k] - g[k]) + (ua1[k] - g[k]));
+      Pj[k] += dt * V[k] + 0.5 * dt * dt * ua;
+      V[k] += dt * ua;
+    }
+  }
+  memcpy(s.acc_0, acc, 24), memcpy(s.gyr_0, gyr, 24);
+  return VIO_OK;
+}
+
+int vio_estimator_set_initial_state(vio_estimator_t *e, int32_t seq, const double *headers, const double *Ps,
+                                    const double *Rs, const double *Vs, const double *Bas, const double *Bgs) {
+  if (!e || seq < 0 || seq >= e->n_seq || !headers || !Ps || !Rs || !Vs || !Bas || !Bgs) return VIO_EINVAL;
+  Sequence &s = e->seq[seq];
+  if (s.solver_flag != VIO_SOLVER_INITIAL) return VIO_ESTATE;
+  const int P = e->W + 1;
+  s.init_headers.assign(headers, headers + P);
+  s.init_Ps.assign(Ps, Ps + 3 * P), s.init_Rs.assign(Rs, Rs + 9 * P), s.init_Vs.assign(Vs, Vs + 3 * P);
+  s.init_Bas.assign(Bas, Bas + 3 * P), s.init_Bgs.assign(Bgs, Bgs + 3 * P);
+  s.init_pending = true;
+  return VIO_OK;
+}
+
+int vio_estimator_set_relocalization(vio_estimator_t *e, int32_t seq, double header, const double P_old[3],
+                                     const double Q_old[4], const int32_t *ids, const double *xy, int32_t n) {
+  if (!e || seq < 0 || seq >= e->n_seq || n < 0 || (n > 0 && (!ids || !xy || !P_old || !Q_old))) return VIO_EINVAL;
+  Relocalization &r = e->seq[seq].retrive;
+  r = Relocalization();
+  r.header = header;
+  if (n > 0) {
+    memcpy(r.P_old, P_old, 24);
+    r.Q_old = Quat{Q_old[0], Q_old[1], Q_old[2], Q_old[3]};
+    r.ids.assign(ids, ids + n), r.xy.assign(xy, xy + 2 * n);
+  }
+  return VIO_OK;
+}
+
+// VINS::processImage for every active sequence (VINS.cpp:377-478); the solves of all of them are ONE device launch.
+int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const int32_t *n_obs, int32_t obs_stride,
+                                 const double *headers, const uint8_t *active, VioFrameResult *results) {
+  if (!e || !obs || !n_obs || !headers || !results || obs_stride < 0) return VIO_EINVAL;
+  const int W = e->W, P = W + 1;
+  e->solving.clear();
+  int first_error = VIO_OK;
+  for (int q = 0; q < e->n_seq; q++) {
+    VioFrameResult &res = results[q];
+    memset(&res, 0, sizeof(res));
+    res.action = VIO_FRAME_SKIPPED;
+    if (active && !active[q]) continue;
+    Sequence &s = e->seq[q];
+    int enough = 0, parallax_num = 0;
+    int rc = vio_features_add_check_parallax(s.fm, s.frame_count, obs + (size_t)q * obs_stride, n_obs[q], &enough,
+                                             &parallax_num, &s.last_track_num);
+    if (rc != VIO_OK) {
+      res.action = VIO_FRAME_ERROR, res.error = rc;
+      if (first_error == VIO_OK) first_error = rc;
+      continue;
+    }
+    s.marginalization_flag = enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW;
+    res.marginalization_flag = s.marginalization_flag;
+    res.track_num = s.last_track_num;
+    vio_features_count(s.fm, &res.n_features);
+    s.Headers[s.frame_count] = headers[q];
+    bool solve = false;
+    if (s.solver_flag == VIO_SOLVER_INITIAL) {
+      if (s.frame_count == W) {
+        if (s.last_track_num < 20) {
+          clear_state(e, s);
+          res.action = VIO_FRAME_RESET;
+          continue;
+        }
+        bool have_init = s.init_pending;
+        if (have_init)
+          for (int i = 0; i < P; i++) have_init = have_init && s.init_headers[i] == s.Headers[i];
+        if (have_init) {  // what solveInitial leaves behind: every state of the window (VINS.cpp:1081-1143)
+          s.Ps = s.init_Ps, s.Rs = s.init_Rs, s.Vs = s.init_Vs, s.Bas = s.init_Bas, s.Bgs = s.init_Bgs;
+          s.init_pending = false;
+          // visualInitialAlign re-integrates every interval from the biases it found (VINS.cpp:1057-1060, with ba = 0 there)
+          for (int i = 1; i < P; i++) repropagate(e, s, i, &s.Bas[3 * i], &s.Bgs[3 * i]);
+          // visualInitialAlign re-triangulates every landmark with the aligned poses (VINS.cpp:1094-1100)
+          int nfe = 0;
+          vio_features_count(s.fm, &nfe);
+          std::vector<double> minus1(nfe > 0 ? nfe : 1, -1.0);
+          vio_features_clear_depth(s.fm, minus1.data(), nfe);
+          vio_features_triangulate(s.fm, s.Ps.data(), s.Rs.data(), e->tic, e->ric);
+          solve = true;
+        } else {
+          slide_window(e, s);
+          res.action = VIO_FRAME_WAIT_INIT;
+        }
+      } else {
+        s.frame_count++;
+        res.action = VIO_FRAME_FILLING;
+      }
+    } else {
+      vio_features_triangulate(s.fm, s.Ps.data(), s.Rs.data(), e->tic, e->ric);
+      solve = true;
+    }
+    if (solve) {
+      rc = build_window(e, s, &e->windows[e->solving.size()]);
+      if (rc != VIO_OK) {
+        res.action = VIO_FRAME_ERROR, res.error = rc;
+        if (first_error == VIO_OK) first_error = rc;
+        continue;
+      }
+      e->solving.push_back(q);
+    }
+  }
+  const int n = (int)e->solving.size();
+  if (n > 0) {
+    if (!e->be) {
+      int rc = vio_backend_create(&e->cfg, e->n_seq, &e->be);
+      if (rc != VIO_OK) return rc;
+    }
+    int rc = vio_backend_solve_windows(e->be, e->windows.data(), n, 0, e->stats.data());
+    if (rc != VIO_OK) return rc;
+  }
+  for (int k = 0; k < n; k++) {
+    const int q = e->solving[k];
+    Sequence &s = e->seq[q];
+    VioFrameResult &res = results[q];
+    const VioWindow &w = e->windows[k];
+    res.stats = e->stats[k];
+    res.n_factors = w.n_factors, res.n_loop_factors = s.n_loop_factors, res.n_features = w.n_features;
+    take_solution(e, s, w, e->stats[k]);
+    if (s.solver_flag == VIO_SOLVER_INITIAL) {
+      if (s.final_cost > 200) {  // initialization failed, need reinitialize (VINS.cpp:415-424)
+        s.has_prior = false;
+        res.action = VIO_FRAME_INIT_FAILED;
+        slide_window(e, s);
+      } else {
+        s.failure_occur = 0;
+        s.solver_flag = VIO_SOLVER_NON_LINEAR;
+        slide_window(e, s);
+        vio_features_remove_failures(s.fm);
+        remember_last(e, s);
+        res.action = VIO_FRAME_SOLVED;
+      }
+    } else {
+      s.failure_occur = 0;
+      int reasons = 0;
+      vio_failure_detection(s.last_track_num, &s.Bgs[3 * W], &s.Ps[3 * W], &s.Rs[9 * W], s.last_P, s.last_R, &reasons);
+      if (reasons) {
+        s.failure_occur = 1;
+        clear_state(e, s);
+        res.action = VIO_FRAME_FAILURE, res.failure_reasons = reasons;
+        continue;
+      }
+      slide_window(e, s);
+      vio_features_remove_failures(s.fm);
+      remember_last(e, s);
+      res.action = VIO_FRAME_SOLVED;
+    }
+  }
+  return first_error;
+}
+
+int vio_estimator_process_image(vio_estimator_t *e, int32_t seq, const VioObs *obs, int32_t n_obs, double header,
+                                VioFrameResult *result) {
+  if (!e || seq < 0 || seq >= e->n_seq || !result || n_obs < 0 || (n_obs > 0 && !obs)) return VIO_EINVAL;
+  std::vector<uint8_t> active(e->n_seq, 0);
+  std::vector<int32_t> n(e->n_seq, 0);
+  std::vector<double> hdr(e->n_seq, 0);
+  std::vector<VioFrameResult> res(e->n_seq);
+  active[seq] = 1, n[seq] = n_obs, hdr[seq] = header;
+  // stride 0: every sequence would read the same list, only `seq` is active
+  static const VioObs none = {0, 0, 0, 0};
+  int rc = vio_estimator_process_images(e, n_obs > 0 ? obs : &none, n.data(), 0, hdr.data(), active.data(), res.data());
+  *result = res[seq];
+  return rc;
+}
+
+int vio_estimator_get_status(vio_estimator_t *e, int32_t seq, VioEstimatorStatus *st) {
+  if (!e || seq < 0 || seq >= e->n_seq || !st) return VIO_EINVAL;
+  const Sequence &s = e->seq[seq];
+  memset(st, 0, sizeof(*st));
+  st->frame_count = s.frame_count, st->solver_flag = s.solver_flag, st->marginalization_flag = s.marginalization_flag;
+  st->failure_occur = s.failure_occur, st->prior_rows = s.has_prior ? s.prior[s.cur_prior].p.n : 0;
+  st->final_cost = s.final_cost;
+  memcpy(st->r_drift, s.r_drift, 72), memcpy(st->t_drift, s.t_drift, 24);
+  memcpy(st->relative_t, s.front.relative_t, 24);
+  st->relative_q[0] = s.front.relative_q.x, st->relative_q[1] = s.front.relative_q.y;
+  st->relative_q[2] = s.front.relative_q.z, st->relative_q[3] = s.front.relative_q.w;
+  st->relative_yaw = s.front.relative_yaw;
+  memcpy(st->loop_pose, s.front.loop_pose, sizeof(st->loop_pose));
+  return VIO_OK;
+}
+
+int vio_estimator_get_window(vio_estimator_t *e, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs,
+                             double *headers) {
+  if (!e || seq < 0 || seq >= e->n_seq) return VIO_EINVAL;
+  const Sequence &s = e->seq[seq];
+  const int P = e->W + 1;
+  if (Ps) memcpy(Ps, s.Ps.data(), sizeof(double) * 3 * P);
+  if (Rs) memcpy(Rs, s.Rs.data(), sizeof(double) * 9 * P);
+  if (Vs) memcpy(Vs, s.Vs.data(), sizeof(double) * 3 * P);
+  if (Bas) memcpy(Bas, s.Bas.data(), sizeof(double) * 3 * P);
+  if (Bgs) memcpy(Bgs, s.Bgs.data(), sizeof(double) * 3 * P);
+  if (headers) memcpy(headers, s.Headers.data(), sizeof(double) * P);
+  return VIO_OK;
+}
+
+// update_loop_correction (VINS.cpp:302-331): the window poses with the loop drift applied.
+int vio_estimator_get_corrected_window(vio_estimator_t *e, int32_t seq, double *correct_Ps, double *correct_Rs) {
+  if (!e || seq < 0 || seq >= e->n_seq || !correct_Ps || !correct_Rs) return VIO_EINVAL;
+  const Sequence &s = e->seq[seq];
+  for (int i = 0; i <= e->W; i++) {
+    double t[3];
+    mat3vec(s.r_drift, &s.Ps[3 * i], t);
+    for (int k = 0; k < 3; k++) correct_Ps[3 * i + k] = t[k] + s.t_drift[k];
+    mat3mul(s.r_drift, &s.Rs[9 * i], &correct_Rs[9 * i]);
+  }
+  return VIO_OK;
+}
+
+int vio_estimator_features(vio_estimator_t *e, int32_t seq, vio_features_t **fm) {
+  if (!e || seq < 0 || seq >= e->n_seq || !fm) return VIO_EINVAL;
+  *fm = e->seq[seq].fm;
+  return VIO_OK;
+}
+
+}  // extern "C"

@@ -8,127 +8,17 @@
 
 #include "vio_amd.h"
 #include "vio_math.h"
+#include "vio_preint.h"
 
 using namespace vio;
-
-namespace {
-
-inline void put33(double *M, int ld, int r0, int c0, const double B[9], double s) {
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) M[(r0 + i) * ld + c0 + j] = s * B[i * 3 + j];
-}
-
-struct Preint {
-  double acc_0[3], gyr_0[3], ba[3], bg[3];
-  double sum_dt, dp[3], dv[3];
-  Quat dq;
-  double J[225], C[225], noise[18];
-};
-
-void propagate(Preint &ib, double dt, const double *acc_1, const double *gyr_1) {
-  // midpoint rule (integration_base.h:71-81)
-  double a0[3], a1[3], w[3];
-  for (int k = 0; k < 3; k++) {
-    a0[k] = ib.acc_0[k] - ib.ba[k];
-    a1[k] = acc_1[k] - ib.ba[k];
-    w[k] = 0.5 * (ib.gyr_0[k] + gyr_1[k]) - ib.bg[k];
-  }
-  double ua0[3], ua1[3];
-  qrot(ib.dq, a0, ua0);
-  Quat nq = qmul(ib.dq, Quat{w[0] * dt / 2, w[1] * dt / 2, w[2] * dt / 2, 1.0});
-  qrot(nq, a1, ua1);
-  double ua[3], np[3], nv[3];
-  for (int k = 0; k < 3; k++) {
-    ua[k] = 0.5 * (ua0[k] + ua1[k]);
-    np[k] = ib.dp[k] + ib.dv[k] * dt + 0.5 * ua[k] * dt * dt;
-    nv[k] = ib.dv[k] + ua[k] * dt;
-  }
-  // first-order error-state transition F (15x15) and noise input V (15x18) (integration_base.h:84-131)
-  double Wx[9], A0x[9], A1x[9], R0[9], R1[9], IW[9], R0A0[9], R1A1[9], R1A1IW[9], T[9];
-  const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  skew3(w, Wx), skew3(a0, A0x), skew3(a1, A1x);
-  qtoR(ib.dq, R0), qtoR(nq, R1);
-  for (int i = 0; i < 9; i++) IW[i] = I3[i] - Wx[i] * dt;
-  mat3mul(R0, A0x, R0A0), mat3mul(R1, A1x, R1A1), mat3mul(R1A1, IW, R1A1IW);
-  double F[225], V[270];
-  memset(F, 0, sizeof(F)), memset(V, 0, sizeof(V));
-  put33(F, 15, 0, 0, I3, 1.0);
-  for (int i = 0; i < 9; i++) T[i] = -0.25 * R0A0[i] * dt * dt + -0.25 * R1A1IW[i] * dt * dt;
-  put33(F, 15, 0, 3, T, 1.0);
-  put33(F, 15, 0, 6, I3, dt);
-  for (int i = 0; i < 9; i++) T[i] = -0.25 * (R0[i] + R1[i]) * dt * dt;
-  put33(F, 15, 0, 9, T, 1.0);
-  for (int i = 0; i < 9; i++) T[i] = -0.25 * R1A1[i] * dt * dt * -dt;
-  put33(F, 15, 0, 12, T, 1.0);
-  put33(F, 15, 3, 3, IW, 1.0);
-  put33(F, 15, 3, 12, I3, -1.0 * dt);
-  for (int i = 0; i < 9; i++) T[i] = -0.5 * R0A0[i] * dt + -0.5 * R1A1IW[i] * dt;
-  put33(F, 15, 6, 3, T, 1.0);
-  put33(F, 15, 6, 6, I3, 1.0);
-  for (int i = 0; i < 9; i++) T[i] = -0.5 * (R0[i] + R1[i]) * dt;
-  put33(F, 15, 6, 9, T, 1.0);
-  for (int i = 0; i < 9; i++) T[i] = -0.5 * R1A1[i] * dt * -dt;
-  put33(F, 15, 6, 12, T, 1.0);
-  put33(F, 15, 9, 9, I3, 1.0);
-  put33(F, 15, 12, 12, I3, 1.0);
-  put33(V, 18, 0, 0, R0, 0.25 * dt * dt);
-  for (int i = 0; i < 9; i++) T[i] = 0.25 * -R1A1[i] * dt * dt * 0.5 * dt;
-  put33(V, 18, 0, 3, T, 1.0);
-  put33(V, 18, 0, 9, T, 1.0);
-  put33(V, 18, 0, 6, R1, 0.25 * dt * dt);
-  put33(V, 18, 3, 3, I3, 0.5 * dt);
-  put33(V, 18, 3, 9, I3, 0.5 * dt);
-  put33(V, 18, 6, 0, R0, 0.5 * dt);
-  for (int i = 0; i < 9; i++) T[i] = 0.5 * -R1A1[i] * dt * 0.5 * dt;
-  put33(V, 18, 6, 3, T, 1.0);
-  put33(V, 18, 6, 9, T, 1.0);
-  put33(V, 18, 6, 6, R1, 0.5 * dt);
-  put33(V, 18, 9, 12, I3, dt);
-  put33(V, 18, 12, 15, I3, dt);
-  // jacobian = F jacobian ; covariance = F covariance F^T + V noise V^T  (:135-136)
-  double Jn[225], FC[225], Cn[225];
-  for (int i = 0; i < 15; i++)
-    for (int j = 0; j < 15; j++) {
-      double s = 0, t = 0;
-      for (int k = 0; k < 15; k++) s += F[i * 15 + k] * ib.J[k * 15 + j], t += F[i * 15 + k] * ib.C[k * 15 + j];
-      Jn[i * 15 + j] = s, FC[i * 15 + j] = t;
-    }
-  for (int i = 0; i < 15; i++)
-    for (int j = 0; j < 15; j++) {
-      double s = 0, t = 0;
-      for (int k = 0; k < 15; k++) s += FC[i * 15 + k] * F[j * 15 + k];
-      for (int k = 0; k < 18; k++) t += V[i * 18 + k] * ib.noise[k] * V[j * 18 + k];
-      Cn[i * 15 + j] = s + t;
-    }
-  memcpy(ib.J, Jn, sizeof(Jn)), memcpy(ib.C, Cn, sizeof(Cn));
-  for (int k = 0; k < 3; k++) ib.dp[k] = np[k], ib.dv[k] = nv[k];
-  ib.dq = qnormalized(nq);  // delta_q.normalize() (:164)
-  ib.sum_dt += dt;
-  memcpy(ib.acc_0, acc_1, 24), memcpy(ib.gyr_0, gyr_1, 24);
-}
-
-}  // namespace
 
 extern "C" int vio_preintegrate(const VioConfig *cfg, const double acc_0[3], const double gyr_0[3], const double ba[3],
                                 const double bg[3], int32_t n, const double *dt, const double *acc, const double *gyr,
                                 VioPreintegration *out) {
   if (!cfg || !acc_0 || !gyr_0 || !ba || !bg || n < 0 || !out || (n > 0 && (!dt || !acc || !gyr))) return VIO_EINVAL;
-  Preint ib;
-  memcpy(ib.acc_0, acc_0, 24), memcpy(ib.gyr_0, gyr_0, 24), memcpy(ib.ba, ba, 24), memcpy(ib.bg, bg, 24);
-  ib.sum_dt = 0;
-  for (int k = 0; k < 3; k++) ib.dp[k] = ib.dv[k] = 0;
-  ib.dq = Quat{0, 0, 0, 1};
-  for (int i = 0; i < 225; i++) ib.J[i] = (i % 16 == 0) ? 1.0 : 0.0, ib.C[i] = 0.0;
-  const double an = cfg->acc_n * cfg->acc_n, gn = cfg->gyr_n * cfg->gyr_n, aw = cfg->acc_w * cfg->acc_w,
-               gw = cfg->gyr_w * cfg->gyr_w;  // noise diagonal, integration_base.h:30-36
-  for (int k = 0; k < 3; k++)
-    ib.noise[k] = an, ib.noise[3 + k] = gn, ib.noise[6 + k] = an, ib.noise[9 + k] = gn, ib.noise[12 + k] = aw,
-    ib.noise[15 + k] = gw;
-  for (int i = 0; i < n; i++) propagate(ib, dt[i], acc + 3 * i, gyr + 3 * i);
-  out->sum_dt = ib.sum_dt;
-  for (int k = 0; k < 3; k++)
-    out->delta_p[k] = ib.dp[k], out->delta_v[k] = ib.dv[k], out->linearized_ba[k] = ib.ba[k], out->linearized_bg[k] = ib.bg[k];
-  out->delta_q[0] = ib.dq.x, out->delta_q[1] = ib.dq.y, out->delta_q[2] = ib.dq.z, out->delta_q[3] = ib.dq.w;
-  memcpy(out->jacobian, ib.J, sizeof(ib.J)), memcpy(out->covariance, ib.C, sizeof(ib.C));
+  host::Preint ib;
+  host::preint_init(ib, cfg, acc_0, gyr_0, ba, bg);
+  for (int i = 0; i < n; i++) host::propagate(ib, dt[i], acc + 3 * i, gyr + 3 * i);
+  host::preint_export(ib, out);
   return VIO_OK;
 }

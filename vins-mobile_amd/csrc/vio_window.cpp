@@ -320,12 +320,14 @@ int vio_features_remove_front(vio_features_t *fm, int32_t frame_count) {  // :34
 }
 
 // The factor enumeration of solve_ceres (VINS.cpp:528-567): landmark f of the depth vector, hosted at its start frame,
-// one factor per later observation. Fills the arrays a VioWindow points to.
-int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t *host, int32_t *target, int32_t *feature,
-                                double *pts_i, double *pts_j, int32_t *n_factors, int32_t *n_features) {
-  if (!fm || !n_factors || !n_features || (cap_factors > 0 && (!host || !target || !feature || !pts_i || !pts_j)))
-    return VIO_EINVAL;
-  int m = 0, fi = -1;
+// one factor per later observation. Fills the arrays a VioWindow points to. With a relocalization frame (loop_frame >= 0)
+// the landmarks seen in that frame and matched in the old keyframe get one more factor whose target is the loop pose
+// (index W+1), VINS.cpp:597-631; it closes the landmark's group (the device solve wants factors grouped by landmark, the
+// order inside a group is the reference's: window factors first).
+static int export_factors(vio_features_t *fm, int32_t cap_factors, int32_t loop_frame, const int32_t *loop_ids,
+                          const double *loop_xy, int32_t n_loop, int32_t *host, int32_t *target, int32_t *feature,
+                          double *pts_i, double *pts_j, int32_t *n_factors, int32_t *n_features, int32_t *n_loop_factors) {
+  int m = 0, fi = -1, r = 0, nl = 0;
   for (Feature &f : fm->feature) {
     f.used_num = (int)f.obs.size();
     if (!fm->solved_in_window(f)) continue;
@@ -340,9 +342,39 @@ int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t
       for (int k = 0; k < 3; k++) pts_i[3 * m + k] = f.obs[0].point[k], pts_j[3 * m + k] = o.point[k];
       m++;
     }
+    if (loop_frame >= 0 && f.start_frame <= loop_frame && f.end_frame() >= loop_frame) {
+      while (r < n_loop && loop_ids[r] < f.feature_id) r++;  // (the reference walks its id list without the bound)
+      if (r < n_loop && loop_ids[r] == f.feature_id) {
+        if (m >= cap_factors) return VIO_ECAP;
+        host[m] = imu_i, target[m] = fm->window_size + 1, feature[m] = fi;
+        for (int k = 0; k < 3; k++) pts_i[3 * m + k] = f.obs[0].point[k];
+        pts_j[3 * m] = loop_xy[2 * r], pts_j[3 * m + 1] = loop_xy[2 * r + 1], pts_j[3 * m + 2] = 1.0;
+        m++, r++, nl++;
+      }
+    }
   }
   *n_factors = m, *n_features = fi + 1;
+  if (n_loop_factors) *n_loop_factors = nl;
   return VIO_OK;
+}
+
+int vio_features_export_factors(vio_features_t *fm, int32_t cap_factors, int32_t *host, int32_t *target, int32_t *feature,
+                                double *pts_i, double *pts_j, int32_t *n_factors, int32_t *n_features) {
+  if (!fm || !n_factors || !n_features || (cap_factors > 0 && (!host || !target || !feature || !pts_i || !pts_j)))
+    return VIO_EINVAL;
+  return export_factors(fm, cap_factors, -1, nullptr, nullptr, 0, host, target, feature, pts_i, pts_j, n_factors, n_features,
+                        nullptr);
+}
+
+int vio_features_export_factors_loop(vio_features_t *fm, int32_t cap_factors, int32_t loop_frame, const int32_t *loop_ids,
+                                     const double *loop_xy, int32_t n_loop, int32_t *host, int32_t *target, int32_t *feature,
+                                     double *pts_i, double *pts_j, int32_t *n_factors, int32_t *n_features,
+                                     int32_t *n_loop_factors) {
+  if (!fm || !n_factors || !n_features || (cap_factors > 0 && (!host || !target || !feature || !pts_i || !pts_j)))
+    return VIO_EINVAL;
+  if (n_loop < 0 || (n_loop > 0 && (!loop_ids || !loop_xy)) || loop_frame >= fm->window_size) return VIO_EINVAL;
+  return export_factors(fm, cap_factors, loop_frame, loop_ids, loop_xy, n_loop, host, target, feature, pts_i, pts_j,
+                        n_factors, n_features, n_loop_factors);
 }
 
 // failureDetection (VINS.cpp:214-265): the checks on the newest frame after a solve. Returns a bit mask (0 = healthy).

@@ -1,0 +1,117 @@
+"""Host-side mirror of the estimator interface (class VINS, VINS_ios/VINS.hpp:47-200): thin ctypes wrappers over
+vio_estimator_* for tests, the replay tool and examples. No logic lives here."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Estimator:
+    """n_seq independent VINS objects whose window solves share one device launch."""
+
+    def __init__(self, cfg, tic, ric, n_seq=1, lib=None):
+        self.lib = lib or abi.load_product()
+        self.cfg, self.n_seq, self.W = cfg, n_seq, cfg.window_size
+        self._h = C.c_void_p()
+        tic, ric = _d(tic), _d(ric)
+        self._check(self.lib.vio_estimator_create(C.byref(cfg), n_seq, _p(tic), _p(ric), C.byref(self._h)), "create")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("vio_estimator_%s failed: %d" % (what, rc))
+
+    def close(self):
+        if self._h:
+            self.lib.vio_estimator_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def clear(self, seq=0):
+        self._check(self.lib.vio_estimator_clear(self._h, seq), "clear")
+
+    def process_imu(self, dt, acc, gyr, seq=0):
+        acc, gyr = _d(acc), _d(gyr)
+        self._check(self.lib.vio_estimator_process_imu(self._h, seq, float(dt), _p(acc), _p(gyr)), "process_imu")
+
+    def set_initial_state(self, headers, Ps, Rs, Vs, Bas, Bgs, seq=0):
+        a = [_d(x) for x in (headers, Ps, Rs, Vs, Bas, Bgs)]
+        P = self.W + 1
+        assert a[0].size == P and a[1].size == 3 * P and a[2].size == 9 * P
+        self._check(self.lib.vio_estimator_set_initial_state(self._h, seq, *[_p(x) for x in a]), "set_initial_state")
+
+    def set_relocalization(self, header, P_old, Q_old, ids, xy, seq=0):
+        ids = np.ascontiguousarray(ids, np.int32)
+        xy, P_old, Q_old = _d(xy), _d(P_old), _d(Q_old)
+        self._check(self.lib.vio_estimator_set_relocalization(self._h, seq, float(header), _p(P_old), _p(Q_old),
+                                                              ids.ctypes.data_as(_ip), _p(xy), len(ids)), "set_relocalization")
+
+    @staticmethod
+    def _pack_obs(ids, xyz, dst, off):
+        for i in range(len(ids)):
+            o = dst[off + i]
+            o.id, o.x, o.y, o.z = int(ids[i]), float(xyz[i][0]), float(xyz[i][1]), float(xyz[i][2])
+
+    def process_image(self, ids, xyz, header, seq=0):
+        n = len(ids)
+        obs = (abi.VioObs * max(n, 1))()
+        self._pack_obs(ids, xyz, obs, 0)
+        res = abi.VioFrameResult()
+        self._check(self.lib.vio_estimator_process_image(self._h, seq, obs, n, float(header), C.byref(res)), "process_image")
+        return res
+
+    def process_images(self, obs_per_seq, headers, active=None):
+        """obs_per_seq: list of (ids, xyz) per sequence; one launch solves every sequence that has a full window."""
+        stride = max(1, max(len(o[0]) for o in obs_per_seq))
+        obs = (abi.VioObs * (stride * self.n_seq))()
+        n = np.zeros(self.n_seq, np.int32)
+        for q, (ids, xyz) in enumerate(obs_per_seq):
+            self._pack_obs(ids, xyz, obs, q * stride)
+            n[q] = len(ids)
+        headers = _d(headers)
+        res = (abi.VioFrameResult * self.n_seq)()
+        act = None
+        if active is not None:
+            act = np.ascontiguousarray(active, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self.lib.vio_estimator_process_images(self._h, obs, n.ctypes.data_as(_ip), stride, _p(headers), act, res),
+                    "process_images")
+        return list(res)
+
+    def status(self, seq=0):
+        st = abi.VioEstimatorStatus()
+        self._check(self.lib.vio_estimator_get_status(self._h, seq, C.byref(st)), "get_status")
+        return st
+
+    def window(self, seq=0):
+        P = self.W + 1
+        Ps, Rs, Vs, Bas, Bgs, hdr = (np.zeros((P, 3)), np.zeros((P, 3, 3)), np.zeros((P, 3)), np.zeros((P, 3)),
+                                     np.zeros((P, 3)), np.zeros(P))
+        self._check(self.lib.vio_estimator_get_window(self._h, seq, _p(Ps), _p(Rs), _p(Vs), _p(Bas), _p(Bgs), _p(hdr)),
+                    "get_window")
+        return dict(Ps=Ps, Rs=Rs, Vs=Vs, Bas=Bas, Bgs=Bgs, headers=hdr)
+
+    def corrected_window(self, seq=0):
+        P = self.W + 1
+        Ps, Rs = np.zeros((P, 3)), np.zeros((P, 3, 3))
+        self._check(self.lib.vio_estimator_get_corrected_window(self._h, seq, _p(Ps), _p(Rs)), "get_corrected_window")
+        return Ps, Rs
+
+    def features(self, seq=0):
+        """A non-owning FeatureManager view of the sequence's landmark store."""
+        from . import window
+        h = C.c_void_p()
+        self._check(self.lib.vio_estimator_features(self._h, seq, C.byref(h)), "features")
+        fm = window.FeatureManager.__new__(window.FeatureManager)
+        fm.lib, fm.W, fm._h = self.lib, self.W, h
+        fm.close = lambda: None
+        return fm

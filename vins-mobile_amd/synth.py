@@ -22,8 +22,8 @@ def quat_mul(a, b):
                      aw * bw - ax * bx - ay * by - az * bz])
 
 
-def quat_to_rot(q):
-    x, y, z, w = q / np.linalg.norm(q)
+def quat_to_rot(q, normalize=True):
+    x, y, z, w = q / np.linalg.norm(q) if normalize else q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
