@@ -415,6 +415,56 @@ int vio_estimator_get_corrected_window(vio_estimator_t *est, int32_t seq, double
 /* The sequence's landmark store (owned by the estimator), for introspection.   */
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 
+/* ------------------------------------------------------------------------- */
+/* Replay I/O: the record / playback formats of the app and the IMU-image
+ * association of its estimator thread (host side; PNG through the image's zlib). */
+typedef struct VioImuMsg {     /* IMU_MSG ViewController.h:58-62 (56 bytes)      */
+  double header;
+  double acc[3];
+  double gyr[3];
+} VioImuMsg;
+
+typedef struct VioKeyframeData { /* KEYFRAME_DATA loop/keyfame_database.h:22-27  */
+  double header;
+  double translation[3];
+  double rotation[4];            /* Eigen::Quaterniond coefficient order x y z w */
+} VioKeyframeData;
+
+/* "IMU" file: back-to-back IMU_MSG, closed by a header == 0 record
+ * (ViewController.mm:1120-1150,1505-1511,1614-1622). cap = 0: count only.      */
+int vio_replay_read_imu(const char *path, VioImuMsg *out, int32_t cap, int32_t *n);
+int vio_replay_write_imu(const char *path, const VioImuMsg *msgs, int32_t n);
+/* "IMAGE_TIME/<index>": 8-byte timestamp; "IMAGE/<index>": PNG
+ * (ViewController.mm:1634-1708). read_image returns the gray frame the camera
+ * callback feeds the tracker before CLAHE: cv::cvtColor CV_RGBA2GRAY
+ * (ViewController.mm:432-433); cap = bytes available in gray (VIO_ECAP with
+ * rows/cols set when too small).                                               */
+int vio_replay_read_image_time(const char *dir, uint64_t index, double *header);
+int vio_replay_write_image_time(const char *dir, uint64_t index, double header);
+int vio_replay_read_image(const char *dir, uint64_t index, uint8_t *gray, int64_t cap, int32_t *rows, int32_t *cols);
+int vio_replay_decode_png_gray(const uint8_t *png, int64_t png_bytes, uint8_t *gray, int64_t cap, int32_t *rows,
+                               int32_t *cols);
+/* channels 1 (gray), 3 (RGB) or 4 (RGBA, what UIImagePNGRepresentation stores). */
+int vio_replay_write_image(const char *dir, uint64_t index, const uint8_t *pixels, int32_t rows, int32_t cols,
+                           int32_t channels);
+int vio_replay_rgba_to_gray(const uint8_t *rgba, int32_t rows, int32_t cols, int32_t stride, uint8_t *gray);
+/* Pose log: back-to-back KEYFRAME_DATA records.                                */
+int vio_replay_read_keyframes(const char *path, VioKeyframeData *out, int32_t cap, int32_t *n);
+int vio_replay_write_keyframes(const char *path, const VioKeyframeData *kf, int32_t n);
+
+/* getMeasurements + send_imu (ViewController.mm:603-682): queue IMU samples and
+ * published image_msg lists as they arrive; each call to _next hands out one
+ * (IMU batch with header <= image header, image) pair in the reference's order,
+ * with the dt send_imu would pass to processIMU. available = 0: wait for more.  */
+typedef struct vio_measurements vio_measurements_t;
+int vio_measurements_create(vio_measurements_t **out);
+void vio_measurements_destroy(vio_measurements_t *q);
+int vio_measurements_push_imu(vio_measurements_t *q, const VioImuMsg *msg);
+int vio_measurements_push_image(vio_measurements_t *q, double header, const VioObs *obs, int32_t n_obs);
+int vio_measurements_next(vio_measurements_t *q, VioImuMsg *imu, double *dt /* may be NULL */, int32_t cap_imu,
+                          int32_t *n_imu, double *header, VioObs *obs, int32_t cap_obs, int32_t *n_obs,
+                          int32_t *available);
+
 const char *vio_version(void);
 
 #ifdef __cplusplus

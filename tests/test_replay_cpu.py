@@ -1,0 +1,185 @@
+"""Replay I/O (csrc/vio_replay.cpp): the recording formats of the reference's record / playback mode
+(VINS_ios/ViewController.mm:1120-1150,1505-1511,1614-1708; IMU_MSG ViewController.h:58-62; KEYFRAME_DATA
+loop/keyfame_database.h:22-27) and getMeasurements / send_imu (ViewController.mm:603-682).
+
+Checked against independent implementations: PIL (libpng) for PNG in both directions, struct.pack for the binary
+records, and a line-by-line python restatement of the getMeasurements loop for the association."""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import abi, pkg
+
+PIL = pytest.importorskip("PIL.Image")
+R = pkg.replay
+
+
+def test_imu_file_is_the_raw_struct_stream_with_an_end_marker(tmp_path):
+    rng = np.random.default_rng(0)
+    hdr = 1000.0 + np.cumsum(rng.uniform(0.005, 0.015, 57))
+    acc, gyr = rng.normal(0, 3, (57, 3)), rng.normal(0, 1, (57, 3))
+    path = str(tmp_path / "IMU")
+    R.write_imu(path, hdr, acc, gyr)
+    raw = open(path, "rb").read()
+    assert len(raw) == 58 * 56                                     # sizeof(IMU_MSG) = 8 + 24 + 24, + the ending marker
+    want = b"".join(struct.pack("<7d", h, *a, *g) for h, a, g in zip(hdr, acc, gyr)) + struct.pack("<7d", *[0.0] * 7)
+    assert raw == want
+    h2, a2, g2 = R.read_imu(path)
+    assert np.array_equal(h2, hdr) and np.array_equal(a2, acc) and np.array_equal(g2, gyr)
+    # records after the marker are not played back (imuDataFinished, ViewController.mm:1127-1131); a truncated tail is ignored
+    open(path, "ab").write(struct.pack("<7d", 5.0, *[1.0] * 6) + b"\x01\x02\x03")
+    assert len(R.read_imu(path)[0]) == 57
+    assert abi.load_product().vio_replay_read_imu(b"/nonexistent/IMU", None, 0, abi.C.byref(abi.C.c_int32())) == abi.VIO_EINVAL
+
+
+def test_image_time_and_keyframe_records(tmp_path):
+    d = str(tmp_path)
+    R.write_image_time(d, 17, 12345.678)
+    assert open(os.path.join(d, "17"), "rb").read() == struct.pack("<d", 12345.678)
+    assert R.read_image_time(d, 17) == 12345.678 and R.read_image_time(d, 18) is None
+    rng = np.random.default_rng(1)
+    hdr, t, q = rng.uniform(0, 100, 9), rng.normal(0, 5, (9, 3)), rng.normal(0, 1, (9, 4))
+    path = str(tmp_path / "poses")
+    R.write_keyframes(path, hdr, t, q)
+    assert open(path, "rb").read() == b"".join(struct.pack("<8d", h, *a, *b) for h, a, b in zip(hdr, t, q))   # 64-byte records
+    h2, t2, q2 = R.read_keyframes(path)
+    assert np.array_equal(h2, hdr) and np.array_equal(t2, t) and np.array_equal(q2, q)
+
+
+def _gray_cv(rgb):
+    r, g, b = (rgb[..., k].astype(np.int64) for k in range(3))
+    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", ["L", "RGB", "RGBA", "LA", "P", "I;16", "1"])
+def test_png_decoding_matches_pil(mode, tmp_path):
+    rng = np.random.default_rng(5)
+    rows, cols = 67, 93
+    # smooth + noise so that libpng's adaptive filtering picks all five filter types
+    base = (np.add.outer(np.arange(rows) * 2.0, np.arange(cols) * 1.5)[..., None] + rng.normal(0, 12, (rows, cols, 4))) % 256
+    rgba = base.astype(np.uint8)
+    if mode == "L":
+        img, want = PIL.fromarray(rgba[..., 0], "L"), rgba[..., 0]
+    elif mode == "RGB":
+        img, want = PIL.fromarray(rgba[..., :3], "RGB"), _gray_cv(rgba)
+    elif mode == "RGBA":
+        img, want = PIL.fromarray(rgba, "RGBA"), _gray_cv(rgba)       # alpha ignored like CV_RGBA2GRAY
+    elif mode == "LA":
+        img, want = PIL.fromarray(rgba[..., :2], "LA"), rgba[..., 0]
+    elif mode == "P":
+        img = PIL.fromarray(rgba[..., :3], "RGB").quantize(64)
+        want = _gray_cv(np.asarray(img.convert("RGB")))
+    elif mode == "I;16":
+        v = (rgba[..., 0].astype(np.uint16) << 8) | rgba[..., 1]
+        img, want = PIL.fromarray(v, "I;16"), rgba[..., 0]
+    else:
+        bits = rgba[..., 0] > 127
+        img, want = PIL.fromarray(bits), (bits * 255).astype(np.uint8)
+    buf = io.BytesIO()
+    img.save(buf, format="PNG")
+    data = buf.getvalue()
+    got = R.decode_png_gray(data)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    (tmp_path / "3").write_bytes(data)
+    assert np.array_equal(R.read_image(str(tmp_path), 3), want)
+    assert R.read_image(str(tmp_path), 4) is None
+
+
+def test_png_filters_are_all_exercised_and_corruption_is_rejected():
+    rng = np.random.default_rng(6)
+    img = (np.add.outer(np.arange(80) * 3, np.arange(120) * 2)[..., None] + rng.integers(0, 9, (80, 120, 3))) % 256
+    buf = io.BytesIO()
+    PIL.fromarray(img.astype(np.uint8), "RGB").save(buf, format="PNG")
+    data = bytearray(buf.getvalue())
+    import zlib
+    # walk the chunks, inflate IDAT and list the filter bytes PIL chose
+    pos, idat = 8, b""
+    while pos < len(data):
+        ln = int.from_bytes(data[pos:pos + 4], "big")
+        if data[pos + 4:pos + 8] == b"IDAT":
+            idat += bytes(data[pos + 8:pos + 8 + ln])
+        pos += 12 + ln
+    raw = zlib.decompress(idat)
+    filters = {raw[(120 * 3 + 1) * y] for y in range(80)}
+    assert len(filters) >= 2, filters
+    assert np.array_equal(R.decode_png_gray(bytes(data)), _gray_cv(img.astype(np.uint8)))
+    data[len(data) // 2] ^= 0x55                                    # CRC mismatch
+    with pytest.raises(ValueError):
+        R.decode_png_gray(bytes(data))
+    with pytest.raises(ValueError):
+        R.decode_png_gray(b"not a png at all, just some bytes that are long enough to pass the size check")
+
+
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_written_png_is_read_back_by_pil(channels, tmp_path):
+    rng = np.random.default_rng(7)
+    px = rng.integers(0, 256, (48, 64) if channels == 1 else (48, 64, channels), dtype=np.uint8)
+    R.write_image(str(tmp_path), 0, px)
+    back = np.asarray(PIL.open(str(tmp_path / "0")))
+    assert np.array_equal(back, px)
+    want = px if channels == 1 else _gray_cv(px)
+    assert np.array_equal(R.read_image(str(tmp_path), 0), want)
+    if channels == 4:
+        assert np.array_equal(R.rgba_to_gray(px), want)
+
+
+def _get_measurements_reference_loop(imu_buf, img_buf):
+    """getMeasurements as written (ViewController.mm:603-638) on python lists used as queues."""
+    out = []
+    while True:
+        if not imu_buf or not img_buf:
+            return out
+        if not (imu_buf[-1][0] > img_buf[0][0]):
+            return out
+        if not (imu_buf[0][0] < img_buf[0][0]):
+            img_buf.pop(0)
+            continue
+        img = img_buf.pop(0)
+        imus = []
+        while imu_buf[0][0] <= img[0]:
+            imus.append(imu_buf.pop(0))
+        out.append((imus, img))
+
+
+def test_measurement_association_follows_getMeasurements():
+    rng = np.random.default_rng(8)
+    # images at ~10 Hz starting BEFORE the first IMU sample (the "throw img" branch), IMU at ~100 Hz with jitter,
+    # arrival order interleaved in bursts (the "wait for imu" branch)
+    t_imu = 5.0 + np.cumsum(rng.uniform(0.008, 0.012, 400))
+    t_img = 4.9 + 0.1 * np.arange(40) + rng.uniform(-0.003, 0.003, 40)
+    events = sorted([(t, "imu", i) for i, t in enumerate(t_imu)] + [(t + rng.uniform(0, 0.05), "img", i) for i, t in enumerate(t_img)])
+    q = R.Measurements()
+    imu_buf, img_buf, want, got = [], [], [], []
+    current_time = -1.0
+    for _, kind, i in events:
+        if kind == "imu":
+            a, g = rng.normal(0, 1, 3), rng.normal(0, 1, 3)
+            q.push_imu(t_imu[i], a, g)
+            imu_buf.append((t_imu[i], a, g))
+        else:
+            ids = list(range(i, i + 5))
+            xyz = rng.normal(0, 1, (5, 3)).tolist()
+            q.push_image(t_img[i], ids, xyz)
+            img_buf.append((t_img[i], ids, xyz))
+        for imus, img in _get_measurements_reference_loop(imu_buf, img_buf):
+            dts = []
+            for m in imus:                                           # send_imu (ViewController.mm:661-668)
+                if current_time < 0:
+                    current_time = m[0]
+                dts.append(m[0] - current_time)
+                current_time = m[0]
+            want.append(([m[0] for m in imus], dts, img[0], img[1]))
+        while True:
+            r = q.next()
+            if r is None:
+                break
+            got.append(([s[0] for s in r[0]], [s[1] for s in r[0]], r[1], r[2]))
+    assert len(want) > 30 and len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[2] == w[2] and g[3] == w[3]
+        assert np.allclose(g[1], w[1], atol=0, rtol=0)
+    assert got[0][1][0] == 0.0                                       # very first sample: dt = 0
+    q.close()

@@ -111,6 +111,14 @@ class VioObs(C.Structure):
     _fields_ = [("id", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
 
 
+class VioImuMsg(C.Structure):
+    _fields_ = [("header", C.c_double), ("acc", C.c_double * 3), ("gyr", C.c_double * 3)]
+
+
+class VioKeyframeData(C.Structure):
+    _fields_ = [("header", C.c_double), ("translation", C.c_double * 3), ("rotation", C.c_double * 4)]
+
+
 class VioFrameResult(C.Structure):
     _fields_ = [("action", C.c_int32), ("error", C.c_int32), ("marginalization_flag", C.c_int32),
                 ("failure_reasons", C.c_int32), ("track_num", C.c_int32), ("n_features", C.c_int32),
@@ -435,6 +443,23 @@ def load_product():
     lib.vio_failure_detection.argtypes = [C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
     lib.vio_features_export_factors_loop.argtypes = [vp, C.c_int32, C.c_int32, _ip, _dp, C.c_int32, _ip, _ip, _ip, _dp, _dp,
                                                      _ip, _ip, _ip]
+    imup, kfp, i64 = C.POINTER(VioImuMsg), C.POINTER(VioKeyframeData), C.c_int64
+    lib.vio_replay_read_imu.argtypes = [C.c_char_p, imup, C.c_int32, _ip]
+    lib.vio_replay_write_imu.argtypes = [C.c_char_p, imup, C.c_int32]
+    lib.vio_replay_read_image_time.argtypes = [C.c_char_p, C.c_uint64, _dp]
+    lib.vio_replay_write_image_time.argtypes = [C.c_char_p, C.c_uint64, C.c_double]
+    lib.vio_replay_read_image.argtypes = [C.c_char_p, C.c_uint64, u8p, i64, _ip, _ip]
+    lib.vio_replay_decode_png_gray.argtypes = [u8p, i64, u8p, i64, _ip, _ip]
+    lib.vio_replay_write_image.argtypes = [C.c_char_p, C.c_uint64, u8p, C.c_int32, C.c_int32, C.c_int32]
+    lib.vio_replay_rgba_to_gray.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, u8p]
+    lib.vio_replay_read_keyframes.argtypes = [C.c_char_p, kfp, C.c_int32, _ip]
+    lib.vio_replay_write_keyframes.argtypes = [C.c_char_p, kfp, C.c_int32]
+    lib.vio_measurements_create.argtypes = [C.POINTER(vp)]
+    lib.vio_measurements_destroy.argtypes = [vp]
+    lib.vio_measurements_destroy.restype = None
+    lib.vio_measurements_push_imu.argtypes = [vp, imup]
+    lib.vio_measurements_push_image.argtypes = [vp, C.c_double, obsp, C.c_int32]
+    lib.vio_measurements_next.argtypes = [vp, imup, _dp, C.c_int32, _ip, _dp, obsp, C.c_int32, _ip, _ip]
     resp, stp = C.POINTER(VioFrameResult), C.POINTER(VioEstimatorStatus)
     lib.vio_estimator_create.argtypes = [cfgp, C.c_int32, _dp, _dp, C.POINTER(vp)]
     lib.vio_estimator_destroy.argtypes = [vp]
