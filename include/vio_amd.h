@@ -257,6 +257,26 @@ int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t 
 int vio_frontend_sync(vio_frontend_t *fe);
 int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches);
 
+/* The image pre-step of the camera callback, batched on the device
+ * (ViewController.mm:432-437): cv::cvtColor(CV_RGBA2GRAY) then CLAHE with
+ * clipLimit 3 on the default 8x8 grid; its output is what readImage receives.
+ * channels = 4 (RGBA as UIImageToMat delivers it) or 1 (already gray).         */
+typedef struct vio_preprocess vio_preprocess_t;
+int vio_preprocess_create(int32_t max_frames, int32_t rows, int32_t cols, vio_preprocess_t **out);
+void vio_preprocess_destroy(vio_preprocess_t *p);
+int vio_preprocess_set_clahe(vio_preprocess_t *p, double clip_limit, int32_t tiles_x, int32_t tiles_y);
+/* Host buffers: pixels = n_frames images of rows*stride bytes back to back;
+ * equalized_out (and gray_out, may be NULL) = n_frames * rows * cols bytes.    */
+int vio_preprocess_run(vio_preprocess_t *p, const uint8_t *pixels, int32_t channels, int32_t n_frames, int32_t stride,
+                       uint8_t *gray_out, uint8_t *equalized_out);
+/* Resident form: device pointers, asynchronous on `stream` (a hipStream_t, NULL =
+ * the context's own); d_equalized is packed [n_frames][rows][cols], ready for
+ * vio_frontend_step_resident-style consumers.                                  */
+int vio_preprocess_run_resident(vio_preprocess_t *p, const void *d_pixels, int32_t channels, int32_t n_frames,
+                                int32_t stride, void *d_equalized, void *stream);
+int vio_preprocess_sync(vio_preprocess_t *p);
+int vio_preprocess_kernel_ms(vio_preprocess_t *p, double *ms_avg, int32_t *launches);
+
 /* Introspection of tracker state (cur_pts / ids / track_cnt,
  * feature_tracker.hpp:72-75) for parity tests.                               */
 int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts /* [cap][2] */,

@@ -839,3 +839,84 @@ int oracle_tracker_get_state(oracle_tracker_t *t, float *cur_pts, int32_t *ids, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The image pre-step of the camera callback: cv::cvtColor(CV_RGBA2GRAY) + cv::CLAHE(clipLimit 3, 8x8)
+// (VINS_ios/ViewController.mm:432-437). OpenCV is a third-party binary the reference links (opencv2.framework, 3.x), not
+// in /root/reference: this restates the PUBLISHED algorithm (imgproc color.cpp RGB2Gray<uchar>; imgproc clahe.cpp
+// CLAHE_CalcLut_Body / CLAHE_Interpolation_Body) with plain loops over whole images — parity unpinned (no OpenCV here).
+#include <vector>
+extern "C" int oracle_preprocess(const uint8_t *pixels, int32_t channels, int32_t rows, int32_t cols, int32_t stride,
+                                 double clip_limit, int32_t tiles_x, int32_t tiles_y, uint8_t *gray_out,
+                                 uint8_t *equalized_out) {
+  if (!pixels || !equalized_out || !(channels == 1 || channels == 4) || rows < 1 || cols < 1 || tiles_x < 1 || tiles_y < 1)
+    return VIO_EINVAL;
+  std::vector<uint8_t> gray((size_t)rows * cols);
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      const uint8_t *p = pixels + (size_t)y * stride + (size_t)channels * x;
+      gray[(size_t)y * cols + x] = channels == 1 ? p[0] : (uint8_t)((p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + (1 << 13)) >> 14);
+    }
+  if (gray_out) memcpy(gray_out, gray.data(), gray.size());
+  // the image the histograms are taken from: the source, or its reflect-101 extension to a multiple of the grid
+  int ext_r = rows, ext_c = cols;
+  if (cols % tiles_x != 0 || rows % tiles_y != 0) ext_c = cols + (tiles_x - cols % tiles_x), ext_r = rows + (tiles_y - rows % tiles_y);
+  std::vector<uint8_t> ext((size_t)ext_r * ext_c);
+  for (int y = 0; y < ext_r; y++)
+    for (int x = 0; x < ext_c; x++) {
+      const int sy = y < rows ? y : 2 * rows - 2 - y, sx = x < cols ? x : 2 * cols - 2 - x;
+      if (sy < 0 || sx < 0) return VIO_EINVAL;
+      ext[(size_t)y * ext_c + x] = gray[(size_t)sy * cols + sx];
+    }
+  const int tw = ext_c / tiles_x, th = ext_r / tiles_y, area = tw * th;
+  const float lut_scale = (float)(256 - 1) / area;
+  int clip = 0;
+  if (clip_limit > 0.0) {
+    clip = (int)(clip_limit * area / 256);
+    if (clip < 1) clip = 1;
+  }
+  std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+  for (int k = 0; k < tiles_x * tiles_y; k++) {
+    const int ty = k / tiles_x, tx = k % tiles_x;
+    int hist[256] = {0};
+    for (int y = 0; y < th; y++)
+      for (int x = 0; x < tw; x++) hist[ext[(size_t)(ty * th + y) * ext_c + tx * tw + x]]++;
+    if (clip > 0) {
+      int clipped = 0;
+      for (int i = 0; i < 256; i++)
+        if (hist[i] > clip) clipped += hist[i] - clip, hist[i] = clip;
+      const int batch = clipped / 256;
+      int residual = clipped - batch * 256;
+      for (int i = 0; i < 256; i++) hist[i] += batch;
+      if (residual != 0) {
+        const int step = 256 / residual > 1 ? 256 / residual : 1;
+        for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+      }
+    }
+    int sum = 0;
+    for (int i = 0; i < 256; i++) {
+      sum += hist[i];
+      long r = lrintf(sum * lut_scale);
+      lut[(size_t)k * 256 + i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+  }
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  for (int y = 0; y < rows; y++) {
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = ty1 < 0 ? 0 : ty1, ty2 = ty2 > tiles_y - 1 ? tiles_y - 1 : ty2;
+    const uint8_t *p1 = &lut[(size_t)ty1 * tiles_x * 256], *p2 = &lut[(size_t)ty2 * tiles_x * 256];
+    for (int x = 0; x < cols; x++) {
+      const float txf = x * inv_tw - 0.5f;
+      int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+      const float xa = txf - tx1, xa1 = 1.0f - xa;
+      tx1 = tx1 < 0 ? 0 : tx1, tx2 = tx2 > tiles_x - 1 ? tiles_x - 1 : tx2;
+      const int v = gray[(size_t)y * cols + x], i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+      const float res = (p1[i1] * xa1 + p1[i2] * xa) * ya1 + (p2[i1] * xa1 + p2[i2] * xa) * ya;
+      long r = lrintf(res);
+      equalized_out[(size_t)y * cols + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+  }
+  return VIO_OK;
+}

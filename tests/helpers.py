@@ -31,6 +31,8 @@ def oracle_lib():
         u8p, fp, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
         cfgp = C.POINTER(abi.VioConfig)
         lib.oracle_pyr_down.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, u8p]
+        lib.oracle_preprocess.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                          u8p, u8p]
         lib.oracle_klt_track.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, fp, u8p, fp]
         lib.oracle_min_eigen_map.argtypes = [u8p, C.c_int32, C.c_int32, C.c_int32, fp]
         lib.oracle_good_features.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, ip]
@@ -194,3 +196,17 @@ ODD_SHAPES = [  # (W, features, with_loop, seed): odd sizes around every chunk /
 ]
 
 
+
+
+def oracle_preprocess(frame, clip_limit=3.0, tiles_x=8, tiles_y=8):
+    """cvtColor + CLAHE of one frame ([rows, cols] gray or [rows, cols, 4] RGBA) by the CPU oracle -> (gray, equalized)."""
+    lib = oracle_lib()
+    frame = np.ascontiguousarray(frame, np.uint8)
+    ch = 4 if frame.ndim == 3 else 1
+    rows, cols = frame.shape[:2]
+    gray, eq = np.zeros((rows, cols), np.uint8), np.zeros((rows, cols), np.uint8)
+    u8p = C.POINTER(C.c_uint8)
+    rc = lib.oracle_preprocess(frame.ctypes.data_as(u8p), ch, rows, cols, cols * ch, float(clip_limit), tiles_x, tiles_y,
+                               gray.ctypes.data_as(u8p), eq.ctypes.data_as(u8p))
+    assert rc == 0, rc
+    return gray, eq

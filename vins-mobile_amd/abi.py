@@ -443,6 +443,14 @@ def load_product():
     lib.vio_failure_detection.argtypes = [C.c_int32, _dp, _dp, _dp, _dp, _dp, _ip]
     lib.vio_features_export_factors_loop.argtypes = [vp, C.c_int32, C.c_int32, _ip, _dp, C.c_int32, _ip, _ip, _ip, _dp, _dp,
                                                      _ip, _ip, _ip]
+    lib.vio_preprocess_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.vio_preprocess_destroy.argtypes = [vp]
+    lib.vio_preprocess_destroy.restype = None
+    lib.vio_preprocess_set_clahe.argtypes = [vp, C.c_double, C.c_int32, C.c_int32]
+    lib.vio_preprocess_run.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, u8p, u8p]
+    lib.vio_preprocess_run_resident.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    lib.vio_preprocess_sync.argtypes = [vp]
+    lib.vio_preprocess_kernel_ms.argtypes = [vp, _dp, _ip]
     imup, kfp, i64 = C.POINTER(VioImuMsg), C.POINTER(VioKeyframeData), C.c_int64
     lib.vio_replay_read_imu.argtypes = [C.c_char_p, imup, C.c_int32, _ip]
     lib.vio_replay_write_imu.argtypes = [C.c_char_p, imup, C.c_int32]

@@ -133,3 +133,56 @@ def fundamental_ransac(cfg, p1, p2):
     if rc != abi.VIO_OK:
         raise RuntimeError("vio_fundamental_ransac rc=%d" % rc)
     return m
+
+
+class Preprocessor:
+    """The image pre-step of the camera callback on the device (cvtColor RGBA2GRAY + CLAHE, ViewController.mm:432-437):
+    ctypes wrapper over vio_preprocess_*."""
+
+    def __init__(self, rows, cols, max_frames=1, lib=None):
+        self.lib = lib or abi.load_product()
+        self.rows, self.cols, self.max_frames = rows, cols, max_frames
+        self._h = C.c_void_p()
+        rc = self.lib.vio_preprocess_create(max_frames, rows, cols, C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("vio_preprocess_create failed: %d" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_preprocess_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_clahe(self, clip_limit=3.0, tiles_x=8, tiles_y=8):
+        rc = self.lib.vio_preprocess_set_clahe(self._h, float(clip_limit), tiles_x, tiles_y)
+        if rc != 0:
+            raise RuntimeError("vio_preprocess_set_clahe failed: %d" % rc)
+
+    def run(self, frames):
+        """frames: [n, rows, cols] gray or [n, rows, cols, 4] RGBA (uint8) -> (gray [n, rows, cols], equalized)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        ch = 4 if frames.ndim == 4 else 1
+        n = frames.shape[0]
+        assert frames.shape[1:3] == (self.rows, self.cols)
+        gray, eq = np.zeros((n, self.rows, self.cols), np.uint8), np.zeros((n, self.rows, self.cols), np.uint8)
+        u8p = C.POINTER(C.c_uint8)
+        rc = self.lib.vio_preprocess_run(self._h, frames.ctypes.data_as(u8p), ch, n, self.cols * ch, gray.ctypes.data_as(u8p),
+                                         eq.ctypes.data_as(u8p))
+        if rc != 0:
+            raise RuntimeError("vio_preprocess_run failed: %d" % rc)
+        return gray, eq
+
+    def run_resident(self, d_pixels, channels, n_frames, d_equalized, stream=None):
+        rc = self.lib.vio_preprocess_run_resident(self._h, C.c_void_p(d_pixels), channels, n_frames, self.cols * channels,
+                                                  C.c_void_p(d_equalized), C.c_void_p(stream or 0))
+        if rc != 0:
+            raise RuntimeError("vio_preprocess_run_resident failed: %d" % rc)
+
+    def sync(self):
+        rc = self.lib.vio_preprocess_sync(self._h)
+        if rc != 0:
+            raise RuntimeError("vio_preprocess_sync failed: %d" % rc)
+
+    def kernel_ms(self):
+        ms, n = C.c_double(), C.c_int32()
+        self.lib.vio_preprocess_kernel_ms(self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
