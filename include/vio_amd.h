@@ -432,6 +432,10 @@ int vio_estimator_get_window(vio_estimator_t *est, int32_t seq, double *Ps, doub
                              double *Bgs, double *headers);
 /* update_loop_correction VINS.cpp:302-331: r_drift * Ps + t_drift, r_drift * Rs. */
 int vio_estimator_get_corrected_window(vio_estimator_t *est, int32_t seq, double *correct_Ps, double *correct_Rs);
+/* Wall time (ms) of the last process_image(s) call by phase: bookkeeping before
+ * the solve, vio_backend_solve_windows (pack, upload, kernel, download), and
+ * the bookkeeping after it.                                                    */
+int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
 /* The sequence's landmark store (owned by the estimator), for introspection.   */
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 

@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
+#include <new>
 #include <vector>
 
 #include "solver_core.h"
@@ -201,14 +203,46 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
 }
 
 // ---- host-side staging ---------------------------------------------------------------------------------
+// Staging vectors live in page-locked memory in the device build (hipMemcpyAsync then runs at link speed and really is
+// asynchronous); the host emulation of the kernel (tests/emul, -DVIO_EMUL) uses plain vectors.
+#if defined(__HIPCC__) && !defined(VIO_EMUL)
+template <class T>
+struct PinnedAllocator {
+  typedef T value_type;
+  PinnedAllocator() = default;
+  template <class U>
+  PinnedAllocator(const PinnedAllocator<U> &) {}
+  T *allocate(size_t n) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t) { (void)hipHostFree(p); }
+  template <class U>
+  bool operator==(const PinnedAllocator<U> &) const { return true; }
+  template <class U>
+  bool operator!=(const PinnedAllocator<U> &) const { return false; }
+};
+template <class T>
+using HostVec = std::vector<T, PinnedAllocator<T>>;
+#else
+template <class T>
+using HostVec = std::vector<T>;
+#endif
+
 struct HostBatch {
   BatchDims d;
   BatchStrides s;
   int n = 0;
-  std::vector<int> hdr, fhost, ftarget, ffeat, pr_kind, pr_index, pr_offset, fslot, fstart, pair_h, pair_t, pair_s0, pair_s1;
-  std::vector<double> hdr_d, pose, sb, ex, feat, pts_i, pts_j, preint, pr_x0, pr_J, pr_r;
-  void resize(const BatchDims &dims, int n_) {
-    d = dims, s = make_strides(dims), n = n_;
+  bool sized = false;
+  HostVec<int> hdr, fhost, ftarget, ffeat, pr_kind, pr_index, pr_offset, fslot, fstart, pair_h, pair_t, pair_s0, pair_s1;
+  HostVec<double> hdr_d, pose, sb, ex, feat, pts_i, pts_j, preint, pr_x0, pr_J, pr_r;
+  // poison: fill every double with NaN first (VIO_AMD_POISON) so that a kernel reading staging padding is caught.
+  // Same shape as the previous batch: nothing is refilled, pack_window rewrites every field the kernel reads and the
+  // padding keeps finite values of earlier windows.
+  void resize(const BatchDims &dims, int n_, bool poison = false) {
+    if (sized && !poison && n == n_ && memcmp(&d, &dims, sizeof(BatchDims)) == 0) return;
+    d = dims, s = make_strides(dims), n = n_, sized = true;
     hdr.assign((size_t)n * kHdrInts, 0), hdr_d.assign((size_t)n * kHdrDoubles, 0.0);
     pose.assign(n * s.pose, 0.0), sb.assign(n * s.sb, 0.0), ex.assign(n * s.ex, 0.0), feat.assign(n * s.feat, 1.0);
     fhost.assign(n * s.fint, 0), ftarget.assign(n * s.fint, 0), ffeat.assign(n * s.fint, 0);
@@ -217,6 +251,13 @@ struct HostBatch {
     pts_i.assign(n * s.pts, 0.0), pts_j.assign(n * s.pts, 0.0), preint.assign(n * s.preint, 0.0);
     pr_kind.assign(n * s.pr_int, 0), pr_index.assign(n * s.pr_int, 0), pr_offset.assign(n * s.pr_int, 0);
     pr_x0.assign(n * s.pr_x0, 0.0), pr_J.assign(n * s.pr_J, 0.0), pr_r.assign(n * s.pr_r, 0.0);
+    if (poison) {
+      double nan;
+      const unsigned long long bits = 0x7ff8dead0000beefULL;
+      memcpy(&nan, &bits, sizeof(nan));
+      for (HostVec<double> *v : {&hdr_d, &pose, &sb, &ex, &feat, &pts_i, &pts_j, &preint, &pr_x0, &pr_J, &pr_r})
+        std::fill(v->begin(), v->end(), nan);
+    }
   }
 };
 

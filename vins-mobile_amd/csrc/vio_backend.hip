@@ -12,7 +12,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <chrono>
+
 #include "batch.h"
+#include "vio_pool.h"
 #include "marg_core.h"
 #include "vio_amd.h"
 
@@ -102,6 +105,14 @@ struct DevBuf {
 
 }  // namespace
 
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool host_timing() {
+  static const bool on = getenv("VIO_AMD_HOST_TIMING") && getenv("VIO_AMD_HOST_TIMING")[0] == '1';
+  return on;
+}
+
 struct vio_backend {
   VioConfig cfg;
   int max_batch = 0;
@@ -124,9 +135,9 @@ struct vio_backend {
       d_hm, d_out_pose, d_out_sb, d_out_feat, d_raw_pose, d_raw_sb, d_raw_feat, d_out_loop, d_stats_d, d_m_x0, d_m_J,
       d_m_r, d_m_scratch;
   // host copies of the outputs
-  std::vector<double> h_out_pose, h_out_sb, h_out_feat, h_raw_pose, h_raw_sb, h_raw_feat, h_out_loop, h_stats_d, h_m_x0,
+  HostVec<double> h_out_pose, h_out_sb, h_out_feat, h_raw_pose, h_raw_sb, h_raw_feat, h_out_loop, h_stats_d, h_m_x0,
       h_m_J, h_m_r;
-  std::vector<int> h_stats_i, h_m_ints;
+  HostVec<int> h_stats_i, h_m_ints;
 };
 
 extern "C" {
@@ -199,13 +210,32 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
       for (int k = 0; k < w.n_factors; k++)
         if (w.factor_target[k] == w.window_size + 1) any_loop = true;
   }
-  BatchDims d = make_dims(be->cfg, Wmax, Fmax, Mmax, any_loop);
-  d.Ncap = std::max(6 * Wmax + 15, Nmax);
-  be->hb.resize(d, n);
-  for (int b = 0; b < n; b++) {
-    int rc = pack_window(be->hb, b, windows[b]);
-    if (rc != VIO_OK) return rc;
+  // Capacities are sticky while the batch keeps its size: a batch that fits the previous layout reuses it (no
+  // re-staging of the padding, no device reallocation); otherwise they grow in steps.
+  BatchDims d;
+  const BatchDims &pd = be->hb.d;
+  if (be->hb.sized && n == be->hb.n && Wmax == pd.Wcap && Fmax <= pd.Fcap && Mmax <= pd.Mcap && Nmax <= pd.Ncap &&
+      (!any_loop || pd.nblk_cap == pd.Pcap + 1)) {
+    d = pd;
+  } else {
+    const int Fr = Fmax /* every landmark costs LDS: no rounding */, Mr = std::min(be->cfg.max_factors, (Mmax + 127) / 128 * 128);
+    d = make_dims(be->cfg, Wmax, Fr, Mr, any_loop);
+    d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
+  static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
+  const double t0 = now_ms();
+  try {
+    be->hb.resize(d, n, poison_staging);
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+  {
+    std::vector<int> rcs(n, VIO_OK);
+    vio::HostPool::get().parallel_for(n, [&](int b) { rcs[b] = pack_window(be->hb, b, windows[b]); });
+    for (int b = 0; b < n; b++)
+      if (rcs[b] != VIO_OK) return rcs[b];
+  }
+  const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
   // LDS or global matrix: both phases must fit the CU's 160 KB
   size_t state_end = 0;
@@ -297,6 +327,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   H2D(be->d_pr_r, be->hb.pr_r);
 #undef H2D
   HIP_OK(hipStreamSynchronize(st));
+  if (host_timing()) fprintf(stderr, "vio_backend_upload: pack %.2f ms, alloc+H2D %.2f ms (n=%d)\n", t1 - t0, now_ms() - t1, n);
 
   BatchPtrs &B = be->B;
   B.n = n, B.d = d, B.s = s;
@@ -410,11 +441,14 @@ int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles,
 int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats) {
   if (!be || !windows) return VIO_EINVAL;
   if (!be->uploaded || n != be->n) return VIO_ESTATE;
+  const double t0 = now_ms();
   HIP_OK(hipDeviceSynchronize());
-#define D2H(dst, src)                                                                              \
-  do {                                                                                             \
-    (dst).resize((src).n);                                                                         \
-    HIP_OK(hipMemcpy((dst).data(), (src).p, (src).n * sizeof((dst)[0]), hipMemcpyDeviceToHost));   \
+  const double t1 = now_ms();
+  hipStream_t st = be->stream;
+#define D2H(dst, src)                                                                                          \
+  do {                                                                                                         \
+    if ((dst).size() != (src).n) (dst).resize((src).n);                                                        \
+    HIP_OK(hipMemcpyAsync((dst).data(), (src).p, (src).n * sizeof((dst)[0]), hipMemcpyDeviceToHost, st));      \
   } while (0)
   D2H(be->h_out_pose, be->d_out_pose);
   D2H(be->h_out_sb, be->d_out_sb);
@@ -430,8 +464,10 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
   D2H(be->h_m_J, be->d_m_J);
   D2H(be->h_m_r, be->d_m_r);
 #undef D2H
+  HIP_OK(hipStreamSynchronize(st));
+  const double t2 = now_ms();
   const BatchStrides &s = be->hb.s;
-  for (int b = 0; b < n; b++) {
+  vio::HostPool::get().parallel_for(n, [&](int b) {
     unpack_window(s, b, be->h_out_pose.data(), be->h_out_sb.data(), be->h_out_feat.data(), be->h_raw_pose.data(),
                   be->h_raw_sb.data(), be->h_raw_feat.data(), be->h_out_loop.data(), be->h_stats_d.data(),
                   be->h_stats_i.data(), windows[b], stats ? stats + b : nullptr);
@@ -445,7 +481,9 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
       mo.scratch = nullptr, mo.ncap = be->B.d.Ncap;
       unpack_prior(mo, *windows[b].next_prior);
     }
-  }
+  });
+  if (host_timing())
+    fprintf(stderr, "vio_backend_download: wait for kernel %.2f ms, D2H %.2f ms, unpack %.2f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
   return VIO_OK;
 }
 

@@ -14,11 +14,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
 #include "vio_amd.h"
 #include "vio_math.h"
+#include "vio_pool.h"
 #include "vio_preint.h"
 
 using namespace vio;
@@ -91,6 +93,9 @@ struct vio_estimator {
   std::vector<VioWindow> windows;
   std::vector<VioSolveStats> stats;
   std::vector<int> solving;  // sequences of the current launch
+  std::vector<VioWindow> staged;   // per sequence, built in parallel, compacted into `windows`
+  std::vector<char> wants_solve;
+  double ms_pre = 0, ms_solve = 0, ms_post = 0;  // wall time of the last process_images call, by phase
 };
 
 namespace {
@@ -438,19 +443,23 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   const int W = e->W, P = W + 1;
   e->solving.clear();
   int first_error = VIO_OK;
-  for (int q = 0; q < e->n_seq; q++) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  // phase A, per sequence and independent of the others (spread over the host pool): landmark bookkeeping, the
+  // INITIAL / NON_LINEAR branch, triangulation, the window as solve_ceres hands it to the solver
+  e->staged.resize(e->n_seq);
+  e->wants_solve.assign(e->n_seq, 0);
+  HostPool::get().parallel_for(e->n_seq, [&](int q) {
     VioFrameResult &res = results[q];
     memset(&res, 0, sizeof(res));
     res.action = VIO_FRAME_SKIPPED;
-    if (active && !active[q]) continue;
+    if (active && !active[q]) return;
     Sequence &s = e->seq[q];
     int enough = 0, parallax_num = 0;
     int rc = vio_features_add_check_parallax(s.fm, s.frame_count, obs + (size_t)q * obs_stride, n_obs[q], &enough,
                                              &parallax_num, &s.last_track_num);
     if (rc != VIO_OK) {
       res.action = VIO_FRAME_ERROR, res.error = rc;
-      if (first_error == VIO_OK) first_error = rc;
-      continue;
+      return;
     }
     s.marginalization_flag = enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW;
     res.marginalization_flag = s.marginalization_flag;
@@ -463,7 +472,7 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
         if (s.last_track_num < 20) {
           clear_state(e, s);
           res.action = VIO_FRAME_RESET;
-          continue;
+          return;
         }
         bool have_init = s.init_pending;
         if (have_init)
@@ -493,16 +502,22 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
       solve = true;
     }
     if (solve) {
-      rc = build_window(e, s, &e->windows[e->solving.size()]);
+      rc = build_window(e, s, &e->staged[q]);
       if (rc != VIO_OK) {
         res.action = VIO_FRAME_ERROR, res.error = rc;
-        if (first_error == VIO_OK) first_error = rc;
-        continue;
+        return;
       }
-      e->solving.push_back(q);
+      e->wants_solve[q] = 1;
     }
+  });
+  for (int q = 0; q < e->n_seq; q++) {
+    if (results[q].action == VIO_FRAME_ERROR && first_error == VIO_OK) first_error = results[q].error;
+    if (!e->wants_solve[q]) continue;
+    e->windows[e->solving.size()] = e->staged[q];
+    e->solving.push_back(q);
   }
   const int n = (int)e->solving.size();
+  const auto t_pre = std::chrono::steady_clock::now();
   if (n > 0) {
     if (!e->be) {
       int rc = vio_backend_create(&e->cfg, e->n_seq, &e->be);
@@ -511,7 +526,9 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     int rc = vio_backend_solve_windows(e->be, e->windows.data(), n, 0, e->stats.data());
     if (rc != VIO_OK) return rc;
   }
-  for (int k = 0; k < n; k++) {
+  const auto t_solve = std::chrono::steady_clock::now();
+  // phase C, per solved sequence: double2vector, loop bookkeeping, failure detection, slide
+  HostPool::get().parallel_for(n, [&](int k) {
     const int q = e->solving[k];
     Sequence &s = e->seq[q];
     VioFrameResult &res = results[q];
@@ -540,15 +557,26 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
         s.failure_occur = 1;
         clear_state(e, s);
         res.action = VIO_FRAME_FAILURE, res.failure_reasons = reasons;
-        continue;
+        return;
       }
       slide_window(e, s);
       vio_features_remove_failures(s.fm);
       remember_last(e, s);
       res.action = VIO_FRAME_SOLVED;
     }
-  }
+  });
+  const auto t_end = std::chrono::steady_clock::now();
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  e->ms_pre = ms(t_begin, t_pre), e->ms_solve = ms(t_pre, t_solve), e->ms_post = ms(t_solve, t_end);
   return first_error;
+}
+
+int vio_estimator_get_timing(vio_estimator_t *e, double ms[3]) {
+  if (!e || !ms) return VIO_EINVAL;
+  ms[0] = e->ms_pre, ms[1] = e->ms_solve, ms[2] = e->ms_post;
+  return VIO_OK;
 }
 
 int vio_estimator_process_image(vio_estimator_t *e, int32_t seq, const VioObs *obs, int32_t n_obs, double header,

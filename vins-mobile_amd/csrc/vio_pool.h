@@ -1,0 +1,94 @@
+// vio_pool.h — a small persistent host thread pool for the per-sequence / per-window host work around a batched launch
+// (landmark bookkeeping, window packing, result unpacking). The reference runs ONE sequence on one thread
+// (ViewController.mm:688-724); a batch of hundreds of sequences per GPU needs the same work done for all of them
+// within the ~2 ms one launch takes, so it is spread over host cores. VIO_AMD_HOST_THREADS overrides the width
+// (1 = everything inline on the caller's thread).
+#pragma once
+#include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace vio {
+
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool pool;
+    return pool;
+  }
+  int width() const { return (int)workers_.size() + 1; }
+
+  // fn(i) for i in [0, n), dynamically distributed; returns when all are done. Not re-entrant.
+  void parallel_for(int n, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n < 4) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn, n_ = n, next_.store(0), pending_ = (int)workers_.size(), generation_++;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() {
+    int t = 0;
+    if (const char *e = getenv("VIO_AMD_HOST_THREADS")) t = atoi(e);
+    if (t <= 0) t = std::min(32, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    for (int i = 1; i < t; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread &w : workers_) w.join();
+  }
+  void drain() {
+    const int chunk = std::max(1, n_ / (8 * width()));
+    while (true) {
+      const int i0 = next_.fetch_add(chunk);
+      if (i0 >= n_) break;
+      for (int i = i0; i < std::min(n_, i0 + chunk); i++) (*fn_)(i);
+    }
+  }
+  void loop() {
+    unsigned seen = 0;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      drain();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0;
+  unsigned generation_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace vio
