@@ -409,6 +409,10 @@ void vio_estimator_destroy(vio_estimator_t *est);
 int vio_estimator_clear(vio_estimator_t *est, int32_t seq);                       /* clearState */
 int vio_estimator_process_imu(vio_estimator_t *est, int32_t seq, double dt, const double acc[3],
                               const double gyr[3]);                                /* processIMU */
+/* processIMU for all sequences in one call (spread over host threads): sequence q
+ * gets n_samples[q] <= stride samples dt[q*stride + i], acc/gyr[(q*stride + i)*3]. */
+int vio_estimator_process_imu_batch(vio_estimator_t *est, const int32_t *n_samples, int32_t stride, const double *dt,
+                                    const double *acc, const double *gyr);
 /* The states solveInitial would leave for the W+1 frames with these headers
  * (Ps [W+1][3], Rs [W+1][9], Vs, Bas, Bgs [W+1][3]); consumed by the next
  * process_image that finds the window full with exactly these headers.        */

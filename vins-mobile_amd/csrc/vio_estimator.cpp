@@ -409,6 +409,23 @@ int vio_estimator_process_imu(vio_estimator_t *e, int32_t seq, double dt, const 
   return VIO_OK;
 }
 
+// processIMU for every sequence at once: sequence q receives n_samples[q] samples dt/acc/gyr[q*stride ...], in order.
+// Sequences are independent, so they are spread over the host pool (one frame interval of 256 sequences is a few
+// thousand 15x15 covariance propagations).
+int vio_estimator_process_imu_batch(vio_estimator_t *e, const int32_t *n_samples, int32_t stride, const double *dt,
+                                    const double *acc, const double *gyr) {
+  if (!e || !n_samples || stride < 0 || !dt || !acc || !gyr) return VIO_EINVAL;
+  for (int q = 0; q < e->n_seq; q++)
+    if (n_samples[q] < 0 || n_samples[q] > stride) return VIO_EINVAL;
+  HostPool::get().parallel_for(e->n_seq, [&](int q) {
+    for (int i = 0; i < n_samples[q]; i++) {
+      const size_t k = (size_t)q * stride + i;
+      vio_estimator_process_imu(e, q, dt[k], acc + 3 * k, gyr + 3 * k);
+    }
+  });
+  return VIO_OK;
+}
+
 int vio_estimator_set_initial_state(vio_estimator_t *e, int32_t seq, const double *headers, const double *Ps,
                                     const double *Rs, const double *Vs, const double *Bas, const double *Bgs) {
   if (!e || seq < 0 || seq >= e->n_seq || !headers || !Ps || !Rs || !Vs || !Bas || !Bgs) return VIO_EINVAL;

@@ -44,6 +44,14 @@ class Estimator:
         acc, gyr = _d(acc), _d(gyr)
         self._check(self.lib.vio_estimator_process_imu(self._h, seq, float(dt), _p(acc), _p(gyr)), "process_imu")
 
+    def process_imu_batch(self, n_samples, dt, acc, gyr):
+        """dt [n_seq, stride], acc / gyr [n_seq, stride, 3]; sequence q consumes its first n_samples[q] entries."""
+        n = np.ascontiguousarray(n_samples, np.int32)
+        dt, acc, gyr = _d(dt), _d(acc), _d(gyr)
+        assert dt.shape[0] == self.n_seq and acc.shape == dt.shape + (3,) and gyr.shape == acc.shape
+        self._check(self.lib.vio_estimator_process_imu_batch(self._h, n.ctypes.data_as(_ip), dt.shape[1], _p(dt), _p(acc),
+                                                             _p(gyr)), "process_imu_batch")
+
     def set_initial_state(self, headers, Ps, Rs, Vs, Bas, Bgs, seq=0):
         a = [_d(x) for x in (headers, Ps, Rs, Vs, Bas, Bgs)]
         P = self.W + 1
