@@ -444,6 +444,25 @@ int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 
 /* ------------------------------------------------------------------------- */
+/* Initialisation pieces (host side, one-off): VINS::solveInitial VINS.cpp:833-1145.
+ * Exposed one by one so that each can be tested against its reference.         */
+typedef struct VioInitFrame {  /* ImageFrame initial_aligment.hpp:24-39            */
+  double header;
+  double R[9];                 /* body attitude in the SfM frame (Q[i] * ric^T)   */
+  double T[3];                 /* camera position in the SfM frame, unknown scale  */
+  int32_t is_key_frame;
+  int32_t n_samples;           /* IMU samples from the previous frame to this one  */
+  const double *dt, *acc, *gyr; /* [n_samples], [n_samples][3], [n_samples][3]      */
+  double acc_0[3], gyr_0[3];   /* the sample the interval starts from              */
+} VioInitFrame;
+/* VisualIMUAlignment initial_aligment.cpp:223-229 (solveGyroscopeBias, SolveScale,
+ * RefineGravity). Bgs [(W+1)][3] in/out (+= delta_bg); g [3] out; x out =
+ * [n_frames][3] body-frame velocities followed by the metric scale; ok = its
+ * return value.                                                                */
+int vio_visual_imu_alignment(const VioConfig *cfg, const double tic[3], const VioInitFrame *frames, int32_t n_frames,
+                             int32_t window_size, double *Bgs, double g[3], double *x, int32_t *ok);
+
+/* ------------------------------------------------------------------------- */
 /* Replay I/O: the record / playback formats of the app and the IMU-image
  * association of its estimator thread (host side; PNG through the image's zlib). */
 typedef struct VioImuMsg {     /* IMU_MSG ViewController.h:58-62 (56 bytes)      */

@@ -119,6 +119,12 @@ class VioKeyframeData(C.Structure):
     _fields_ = [("header", C.c_double), ("translation", C.c_double * 3), ("rotation", C.c_double * 4)]
 
 
+class VioInitFrame(C.Structure):
+    _fields_ = [("header", C.c_double), ("R", C.c_double * 9), ("T", C.c_double * 3), ("is_key_frame", C.c_int32),
+                ("n_samples", C.c_int32), ("dt", _dp), ("acc", _dp), ("gyr", _dp), ("acc_0", C.c_double * 3),
+                ("gyr_0", C.c_double * 3)]
+
+
 class VioFrameResult(C.Structure):
     _fields_ = [("action", C.c_int32), ("error", C.c_int32), ("marginalization_flag", C.c_int32),
                 ("failure_reasons", C.c_int32), ("track_num", C.c_int32), ("n_features", C.c_int32),
@@ -468,6 +474,7 @@ def load_product():
     lib.vio_measurements_push_imu.argtypes = [vp, imup]
     lib.vio_measurements_push_image.argtypes = [vp, C.c_double, obsp, C.c_int32]
     lib.vio_measurements_next.argtypes = [vp, imup, _dp, C.c_int32, _ip, _dp, obsp, C.c_int32, _ip, _ip]
+    lib.vio_visual_imu_alignment.argtypes = [cfgp, _dp, C.POINTER(VioInitFrame), C.c_int32, C.c_int32, _dp, _dp, _dp, _ip]
     resp, stp = C.POINTER(VioFrameResult), C.POINTER(VioEstimatorStatus)
     lib.vio_estimator_create.argtypes = [cfgp, C.c_int32, _dp, _dp, C.POINTER(vp)]
     lib.vio_estimator_destroy.argtypes = [vp]
