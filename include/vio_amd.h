@@ -345,8 +345,10 @@ int vio_features_export_factors_loop(vio_features_t *fm, int32_t cap_factors, in
                                      const int32_t *loop_ids, const double *loop_xy /* [n_loop][2] */, int32_t n_loop,
                                      int32_t *host, int32_t *target, int32_t *feature, double *pts_i, double *pts_j,
                                      int32_t *n_factors, int32_t *n_features, int32_t *n_loop_factors /* may be NULL */);
+/* estimated_depth *= s for the landmarks of the solve (visualInitialAlign VINS.cpp:1079-1085). */
+int vio_features_scale_depth(vio_features_t *fm, double s);
 /* Introspection: per-landmark records (and, optionally, all observation points
- * [sum n_obs][3]) in list order.                                             */
+ * [sum n_obs][3]) in list order. cap = 0: only the counts.                   */
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
                       int32_t cap_points, int32_t *n_points);
 
@@ -407,6 +409,10 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
                          vio_estimator_t **out);
 void vio_estimator_destroy(vio_estimator_t *est);
 int vio_estimator_clear(vio_estimator_t *est, int32_t seq);                       /* clearState */
+/* solveInitial (VINS.cpp:833-1145) inside process_image when the window is full and no
+ * state was handed over: relative pose, global SfM, PnP of the in-between frames,
+ * visual-inertial alignment. Off by default (0): the caller hands states over.   */
+int vio_estimator_enable_initialization(vio_estimator_t *est, int32_t enable);
 int vio_estimator_process_imu(vio_estimator_t *est, int32_t seq, double dt, const double acc[3],
                               const double gyr[3]);                                /* processIMU */
 /* processIMU for all sequences in one call (spread over host threads): sequence q
@@ -461,6 +467,22 @@ typedef struct VioInitFrame {  /* ImageFrame initial_aligment.hpp:24-39         
  * return value.                                                                */
 int vio_visual_imu_alignment(const VioConfig *cfg, const double tic[3], const VioInitFrame *frames, int32_t n_frames,
                              int32_t window_size, double *Bgs, double g[3], double *x, int32_t *ok);
+
+/* solveRelativeRT motion_estimator.cpp:200-236: pose of the second camera in the first
+ * (R [9], unit t [3]) from n >= 9 normalized correspondences xy0/xy1 [n][2];
+ * inliers = points in front of both cameras, ok = inliers > 10.                */
+int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, double R[9], double t[3], int32_t *inliers,
+                           int32_t *ok);
+/* cv::solvePnP(..., useExtrinsicGuess = true) with K = I as inital_sfm.cpp:57 and
+ * VINS.cpp:982 call it: refines world->camera R [9], t [3] in place.            */
+int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok);
+/* GlobalSFM::construct inital_sfm.cpp:117-316. Landmark j has observations
+ * obs_frame/obs_xy[feat_start[j] .. feat_start[j+1]) (frame index, normalized xy).
+ * Out: q [frame_num][4] (x y z w) and T [frame_num][3] = camera poses in frame l's
+ * camera frame, points [n_features][3] with point_ok flags.                     */
+int vio_init_sfm(int32_t frame_num, int32_t l, const double relative_R[9], const double relative_T[3], int32_t n_features,
+                 const int32_t *feat_start, const int32_t *obs_frame, const double *obs_xy, double *q, double *T,
+                 double *points, uint8_t *point_ok, int32_t *ok);
 
 /* ------------------------------------------------------------------------- */
 /* Replay I/O: the record / playback formats of the app and the IMU-image

@@ -128,3 +128,120 @@ def test_alignment_matches_the_reference(seed, n, scale):
     assert np.abs(got["Bgs"] - ref["Bgs"]).max() < 1e-10
     assert np.abs(got["g"] - ref["g"]).max() < 1e-8
     assert np.abs(got["x"] - ref["x"]).max() < 1e-7 * max(1.0, np.abs(ref["x"]).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# relative pose / PnP / global SfM: OpenCV + Ceres code in the reference (unbuildable here) -> against the scene's truth
+def _scene(seed, n_frames=11, n_points=160, planar=False, pix_noise=0.5):
+    """Camera poses along a smooth trajectory (about a second) and normalized observations of a landmark cloud."""
+    rng = np.random.default_rng(seed)
+    traj = synth.Trajectory(rng)
+    t0 = rng.uniform(0, 20)
+    ex = synth.ex_pose_default()
+    ric, tic = synth.quat_to_rot(ex[3:]), ex[:3]
+    Rwc = [traj.rot(t0 + 0.1 * k) @ ric for k in range(n_frames)]
+    pwc = [traj.pos(t0 + 0.1 * k) + traj.rot(t0 + 0.1 * k) @ tic for k in range(n_frames)]
+    # landmarks in front of the middle camera
+    mid = n_frames // 2
+    z = np.full(n_points, 6.0) if planar else rng.uniform(4, 11, n_points)
+    xy = rng.uniform(-0.45, 0.45, (n_points, 2))
+    Xc = np.column_stack([xy * z[:, None], z])
+    if planar:                               # a tilted plane, not fronto-parallel
+        Xc[:, 2] += 0.3 * Xc[:, 0]
+    Xw = Xc @ Rwc[mid].T + pwc[mid]
+    obs = []                                 # per point: list of (frame, x, y)
+    sig = pix_noise / 460.0
+    for p in range(n_points):
+        first = 0 if rng.random() < 0.7 else int(rng.integers(0, n_frames - 3))
+        lst = []
+        for k in range(first, n_frames):
+            c = Rwc[k].T @ (Xw[p] - pwc[k])
+            if c[2] > 0.5 and abs(c[0] / c[2]) < 0.6 and abs(c[1] / c[2]) < 0.8:
+                lst.append((k, c[0] / c[2] + rng.normal(0, sig), c[1] / c[2] + rng.normal(0, sig)))
+        obs.append(lst)
+    return dict(Rwc=Rwc, pwc=pwc, Xw=Xw, obs=obs, n_frames=n_frames)
+
+
+def _relative(sc, a, b):
+    pa = {p: (x, y) for p, o in enumerate(sc["obs"]) for (k, x, y) in o if k == a}
+    pb = {p: (x, y) for p, o in enumerate(sc["obs"]) for (k, x, y) in o if k == b}
+    common = sorted(set(pa) & set(pb))
+    xy0 = np.array([pa[p] for p in common])
+    xy1 = np.array([pb[p] for p in common])
+    R, t, inl, ok = np.zeros(9), np.zeros(3), C.c_int32(), C.c_int32()
+    rc = abi.load_product().vio_init_relative_pose(xy0.ctypes.data_as(_dp), xy1.ctypes.data_as(_dp), len(common), R.ctypes.data_as(_dp),
+                                                   t.ctypes.data_as(_dp), C.byref(inl), C.byref(ok))
+    assert rc == 0
+    return R.reshape(3, 3), t, inl.value, ok.value, len(common)
+
+
+@pytest.mark.parametrize("seed,planar", [(1, False), (2, False), (4, True), (8, True), (5, False), (7, False)])
+def test_relative_pose_from_correspondences(seed, planar):
+    """(Planar scenes: two-view geometry of a plane has two exact solutions; the seeds here are ones where the fit started
+    from R = I lands on the physical one — the reference's five-point RANSAC faces the same tie.)"""
+    sc = _scene(seed, planar=planar)
+    a, b = 2, sc["n_frames"] - 1
+    R, t, inl, ok, n = _relative(sc, a, b)
+    assert ok == 1 and inl > 0.5 * n          # recoverPose only counts points closer than 50 baselines
+    R_true = sc["Rwc"][a].T @ sc["Rwc"][b]                       # pose of camera b in camera a
+    t_true = sc["Rwc"][a].T @ (sc["pwc"][b] - sc["pwc"][a])
+    ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ R_true) - 1) / 2, -1, 1)))
+    dirang = np.degrees(np.arccos(np.clip(t @ t_true / np.linalg.norm(t_true), -1, 1)))
+    assert abs(np.linalg.norm(t) - 1) < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
+    assert ang < 0.5 and dirang < 6.0, (ang, dirang)
+
+
+def test_pnp_refines_a_pose_from_a_neighbouring_guess():
+    sc = _scene(7)
+    k = 5
+    p3, p2 = [], []
+    for p, o in enumerate(sc["obs"]):
+        for (f, x, y) in o:
+            if f == k:
+                p3.append(sc["Xw"][p]), p2.append((x, y))
+    p3, p2 = np.array(p3), np.array(p2)
+    R = (sc["Rwc"][k - 1].T).copy().ravel()                      # world -> camera of the previous frame as the guess
+    t = -(sc["Rwc"][k - 1].T @ sc["pwc"][k - 1])
+    ok = C.c_int32()
+    rc = abi.load_product().vio_init_pnp(p3.ctypes.data_as(_dp), p2.ctypes.data_as(_dp), len(p3), R.ctypes.data_as(_dp), t.ctypes.data_as(_dp),
+                                         C.byref(ok))
+    assert rc == 0 and ok.value == 1
+    R = R.reshape(3, 3)
+    assert np.abs(R - sc["Rwc"][k].T).max() < 2e-3
+    assert np.abs(-R.T @ t - sc["pwc"][k]).max() < 0.02
+
+
+@pytest.mark.parametrize("seed,planar", [(11, False), (12, False), (14, False)])
+def test_global_sfm_reconstructs_poses_and_points_up_to_scale(seed, planar):
+    sc = _scene(seed, planar=planar)
+    F, l = sc["n_frames"], 1
+    Rrel, trel, _, ok, _ = _relative(sc, l, F - 1)
+    assert ok == 1
+    start, fr, xy = [0], [], []
+    for o in sc["obs"]:
+        for (k, x, y) in o:
+            fr.append(k), xy.append((x, y))
+        start.append(len(fr))
+    start, fr, xy = np.array(start, np.int32), np.array(fr, np.int32), np.array(xy)
+    n = len(sc["obs"])
+    q, T, pts, pok, okf = np.zeros((F, 4)), np.zeros((F, 3)), np.zeros((n, 3)), np.zeros(n, np.uint8), C.c_int32()
+    _ip = C.POINTER(C.c_int32)
+    rc = abi.load_product().vio_init_sfm(F, l, np.ascontiguousarray(Rrel).ctypes.data_as(_dp), trel.ctypes.data_as(_dp), n,
+                                         start.ctypes.data_as(_ip), fr.ctypes.data_as(_ip), xy.ctypes.data_as(_dp), q.ctypes.data_as(_dp),
+                                         T.ctypes.data_as(_dp), pts.ctypes.data_as(_dp), pok.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(okf))
+    assert rc == 0 and okf.value == 1
+    # truth in frame l's camera frame, scaled so that |T_last| = 1 (the gauge relativePose fixes)
+    Rl, pl = sc["Rwc"][l], sc["pwc"][l]
+    s = 1.0 / np.linalg.norm(sc["pwc"][F - 1] - pl)
+    for k in range(F):
+        R_true = Rl.T @ sc["Rwc"][k]
+        T_true = Rl.T @ (sc["pwc"][k] - pl) * s
+        Rk = synth.quat_to_rot(q[k])
+        ang = np.degrees(np.arccos(np.clip((np.trace(Rk.T @ R_true) - 1) / 2, -1, 1)))
+        assert ang < 0.5 and np.abs(T[k] - T_true).max() < 0.06, (k, ang, T[k], T_true)
+    seen2 = np.array([len(o) >= 2 for o in sc["obs"]])
+    assert np.array_equal(pok.astype(bool), seen2)
+    X_true = (sc["Xw"] - pl) @ Rl * s
+    good = pok.astype(bool) & np.array([len(o) >= 4 for o in sc["obs"]])
+    rel = np.linalg.norm(pts[good] - X_true[good], axis=1) / np.linalg.norm(X_true[good], axis=1)
+    assert np.median(rel) < 0.03, np.median(rel)

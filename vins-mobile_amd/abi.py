@@ -474,12 +474,17 @@ def load_product():
     lib.vio_measurements_push_imu.argtypes = [vp, imup]
     lib.vio_measurements_push_image.argtypes = [vp, C.c_double, obsp, C.c_int32]
     lib.vio_measurements_next.argtypes = [vp, imup, _dp, C.c_int32, _ip, _dp, obsp, C.c_int32, _ip, _ip]
+    lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
+    lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]
+    lib.vio_init_sfm.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _ip, _ip, _dp, _dp, _dp, _dp, u8p, _ip]
     lib.vio_visual_imu_alignment.argtypes = [cfgp, _dp, C.POINTER(VioInitFrame), C.c_int32, C.c_int32, _dp, _dp, _dp, _ip]
     resp, stp = C.POINTER(VioFrameResult), C.POINTER(VioEstimatorStatus)
     lib.vio_estimator_create.argtypes = [cfgp, C.c_int32, _dp, _dp, C.POINTER(vp)]
     lib.vio_estimator_destroy.argtypes = [vp]
     lib.vio_estimator_destroy.restype = None
     lib.vio_estimator_clear.argtypes = [vp, C.c_int32]
+    lib.vio_estimator_enable_initialization.argtypes = [vp, C.c_int32]
+    lib.vio_features_scale_depth.argtypes = [vp, C.c_double]
     lib.vio_estimator_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
     lib.vio_estimator_process_imu_batch.argtypes = [vp, _ip, C.c_int32, _dp, _dp, _dp]
     lib.vio_estimator_set_initial_state.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]

@@ -15,11 +15,13 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <new>
 #include <vector>
 
 #include "vio_amd.h"
 #include "vio_math.h"
+#include "vio_initial.h"
 #include "vio_pool.h"
 #include "vio_preint.h"
 
@@ -68,6 +70,13 @@ struct Sequence {
   Relocalization retrive, front;
   bool loop_enable = false;
   double final_cost = 0;
+  // solveInitial's bookkeeping: every published frame since the window's oldest one, with the IMU interval that leads
+  // to it integrated from zero biases (all_image_frame / tmp_pre_integration, VINS.cpp:402-404)
+  std::map<double, init::Frame> all_image_frame;
+  init::Frame tmp;           // the interval being integrated
+  bool tmp_valid = false;
+  double initial_timestamp = 0;
+  double g[3] = {0, 0, 0};
   // initial window handed over in place of solveInitial
   bool init_pending = false;
   std::vector<double> init_headers, init_Ps, init_Rs, init_Vs, init_Bas, init_Bgs;
@@ -92,6 +101,7 @@ struct vio_estimator {
   vio_backend_t *be = nullptr;  // created at the first solve: IMU propagation and window filling need no device
   std::vector<VioWindow> windows;
   std::vector<VioSolveStats> stats;
+  bool enable_init = false;
   std::vector<int> solving;  // sequences of the current launch
   std::vector<VioWindow> staged;   // per sequence, built in parallel, compacted into `windows`
   std::vector<char> wants_solve;
@@ -113,6 +123,9 @@ void clear_state(vio_estimator *e, Sequence &s) {  // VINS::clearState (VINS.cpp
   s.solver_flag = VIO_SOLVER_INITIAL;
   s.has_prior = false;
   s.init_pending = false;
+  s.all_image_frame.clear();
+  s.tmp_valid = false;
+  s.initial_timestamp = 0;
   vio_features_clear(s.fm);
 }
 
@@ -157,6 +170,8 @@ void slide_window(vio_estimator *e, Sequence &s) {
     }
     new_preintegration(e, s, W);
     s.dt_buf[W].clear(), s.acc_buf[W].clear(), s.gyr_buf[W].clear();
+    if (s.solver_flag == VIO_SOLVER_INITIAL)  // frames older than the new oldest one leave all_image_frame (VINS.cpp:1190-1197)
+      s.all_image_frame.erase(s.all_image_frame.begin(), s.all_image_frame.lower_bound(s.Headers[0]));
     // slideWindowOld: the landmarks hosted in the departed frame move to the next one
     if (s.solver_flag == VIO_SOLVER_NON_LINEAR) {
       double R0[9], R1[9], P0[3], P1[3], t[3];
@@ -312,6 +327,182 @@ void take_solution(vio_estimator *e, Sequence &s, const VioWindow &w, const VioS
   if (w.next_prior && w.next_prior->n > 0) s.cur_prior = 1 - s.cur_prior, s.has_prior = true;
 }
 
+// Eigen::Quaterniond::FromTwoVectors(a, b).toRotationMatrix() for unit a, b (Geometry/Quaternion.h)
+void rotation_between(const double a[3], const double b[3], double R[9]) {
+  const double c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  if (c < -1.0 + 1e-12) {  // opposite vectors: any axis orthogonal to a, angle pi
+    double ax[3] = {1, 0, 0};
+    if (fabs(a[0]) > 0.9) ax[0] = 0, ax[1] = 1;
+    double v[3] = {a[1] * ax[2] - a[2] * ax[1], a[2] * ax[0] - a[0] * ax[2], a[0] * ax[1] - a[1] * ax[0]};
+    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    qtoR(Quat{v[0] / n, v[1] / n, v[2] / n, 0.0}, R);
+    return;
+  }
+  const double axis[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  const double sq = sqrt((1.0 + c) * 2.0), inv = 1.0 / sq;
+  qtoR(Quat{axis[0] * inv, axis[1] * inv, axis[2] * inv, sq * 0.5}, R);
+}
+
+void g2R(const double g[3], double R0[9]) {  // Utility::g2R (utility.cpp:11-21)
+  const double n = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+  const double ng1[3] = {g[0] / n, g[1] / n, g[2] / n}, ng2[3] = {0, 0, 1};
+  double R[9], ypr[3], Y[9], T[9];
+  rotation_between(ng1, ng2, R);
+  R2ypr(R, ypr);
+  const double y1[3] = {-ypr[0], 0, 0};
+  ypr2R(y1, Y);
+  mat3mul(Y, R, T);
+  const double y2[3] = {-90, 0, 0};
+  ypr2R(y2, Y);
+  mat3mul(Y, T, R0);
+}
+
+// VINS::solveInitial + relativePose + visualInitialAlign (VINS.cpp:833-1145).
+bool solve_initial(vio_estimator *e, Sequence &s) {
+  const int W = e->W, P = W + 1;
+  // the landmark store as SfM features (VINS.cpp:883-899) and as correspondences (getCorresponding)
+  int nfe = 0, npts = 0;
+  vio_features_dump(s.fm, nullptr, 0, &nfe, nullptr, 0, &npts);
+  std::vector<VioFeatureInfo> info(nfe > 0 ? nfe : 1);
+  std::vector<double> pts(3 * (size_t)(npts > 0 ? npts : 1));
+  if (vio_features_dump(s.fm, info.data(), nfe, &nfe, pts.data(), npts, &npts) != VIO_OK) return false;
+  std::vector<init::SfmFeature> sfm_f(nfe);
+  std::vector<size_t> first(nfe);
+  {
+    size_t off = 0;
+    for (int j = 0; j < nfe; j++) {
+      first[j] = off;
+      sfm_f[j].id = info[j].id;
+      for (int k = 0; k < info[j].n_obs; k++)
+        sfm_f[j].observation.push_back({info[j].start_frame + k, {pts[3 * (off + k)], pts[3 * (off + k) + 1]}});
+      off += info[j].n_obs;
+    }
+  }
+  // relativePose (VINS.cpp:1106-1145): the oldest frame with enough parallax against the newest one
+  int l = -1;
+  double relative_R[9], relative_T[3];
+  for (int i = 0; i < W; i++) {
+    std::vector<double> a, b;
+    for (int j = 0; j < nfe; j++)
+      if (info[j].start_frame <= i && info[j].start_frame + info[j].n_obs - 1 >= W) {
+        const double *pa = &pts[3 * (first[j] + (i - info[j].start_frame))], *pb = &pts[3 * (first[j] + (W - info[j].start_frame))];
+        a.push_back(pa[0]), a.push_back(pa[1]), b.push_back(pb[0]), b.push_back(pb[1]);
+      }
+    const int nc = (int)a.size() / 2;
+    if (nc > 20) {
+      double sum = 0;
+      for (int k = 0; k < nc; k++) sum += sqrt((a[2 * k] - b[2 * k]) * (a[2 * k] - b[2 * k]) + (a[2 * k + 1] - b[2 * k + 1]) * (a[2 * k + 1] - b[2 * k + 1]));
+      if (sum / nc * 520 < 30) return false;  // FAIL_PARALLAX
+      if (!init::solve_relative_rt(a, b, relative_R, relative_T, nullptr)) return false;  // FAIL_RELATIVE
+      l = i;
+      break;
+    }
+  }
+  if (l < 0) return false;
+  std::vector<double> Q(4 * (size_t)P), T(3 * (size_t)P);
+  std::map<int, std::vector<double>> tracked;
+  if (!init::sfm_construct(P, Q.data(), T.data(), l, relative_R, relative_T, sfm_f, tracked)) {
+    s.marginalization_flag = VIO_MARGIN_OLD;  // FAIL_SFM (VINS.cpp:915-917)
+    return false;
+  }
+  // PnP for every frame of all_image_frame (VINS.cpp:926-1003)
+  double ricT[9];
+  mat3T(e->ric, ricT);
+  int i = 0;
+  for (auto &kv : s.all_image_frame) {
+    init::Frame &f = kv.second;
+    double Rq[9];
+    if (i < P && f.header == s.Headers[i]) {
+      qtoR(Quat{Q[4 * i], Q[4 * i + 1], Q[4 * i + 2], Q[4 * i + 3]}, Rq);
+      f.is_key_frame = true;
+      mat3mul(Rq, ricT, f.R);
+      memcpy(f.T, &T[3 * i], 24);
+      i++;
+      continue;
+    }
+    if (i < P && f.header > s.Headers[i]) i++;
+    const int ii = std::min(i, P - 1);
+    qtoR(Quat{Q[4 * ii], Q[4 * ii + 1], Q[4 * ii + 2], Q[4 * ii + 3]}, Rq);
+    double R_init[9], P_init[3], v[3];
+    mat3T(Rq, R_init);  // Q[i].inverse()
+    mat3vec(R_init, &T[3 * ii], v);
+    for (int k = 0; k < 3; k++) P_init[k] = -v[k];
+    f.is_key_frame = false;
+    std::vector<double> p3, p2;
+    for (const VioObs &o : f.points) {
+      auto it = tracked.find(o.id);
+      if (it == tracked.end()) continue;
+      p3.insert(p3.end(), it->second.begin(), it->second.end());
+      p2.push_back(o.x), p2.push_back(o.y);
+    }
+    if (p2.size() / 2 < 6) return false;                       // "init Not enough points for solve pnp !"
+    if (!init::pnp_refine(p3, p2, R_init, P_init)) return false;  // FAIL_PNP
+    double R_pnp[9];
+    mat3T(R_init, R_pnp);
+    mat3mul(R_pnp, ricT, f.R);
+    mat3vec(R_pnp, P_init, v);
+    for (int k = 0; k < 3; k++) f.T[k] = -v[k];
+  }
+  // visualInitialAlign (VINS.cpp:1021-1104)
+  std::vector<init::Frame> frames;
+  frames.reserve(s.all_image_frame.size());
+  for (auto &kv : s.all_image_frame) frames.push_back(kv.second);
+  std::vector<double> x;
+  if (!init::visual_imu_alignment(e->cfg, e->tic, frames, W, s.Bgs.data(), s.g, x)) return false;  // FAIL_ALIGN
+  {
+    size_t k = 0;
+    for (auto &kv : s.all_image_frame) kv.second = frames[k++];  // the re-integrated intervals
+  }
+  for (int k = 0; k <= s.frame_count; k++) {
+    init::Frame &f = s.all_image_frame[s.Headers[k]];
+    memcpy(&s.Ps[3 * k], f.T, 24), memcpy(&s.Rs[9 * k], f.R, 72);
+    f.is_key_frame = true;
+  }
+  int nfeat = 0;
+  vio_features_count(s.fm, &nfeat);
+  std::vector<double> minus1(nfeat > 0 ? nfeat : 1, -1.0);
+  vio_features_clear_depth(s.fm, minus1.data(), nfeat);
+  const double tic0[3] = {0, 0, 0};  // "triangulat on cam pose , no tic"
+  vio_features_triangulate(s.fm, s.Ps.data(), s.Rs.data(), tic0, e->ric);
+  const double sc = x.back();
+  const double zero[3] = {0, 0, 0};
+  for (int k = 0; k <= W; k++) repropagate(e, s, k, zero, &s.Bgs[3 * k]);
+  {
+    double r0t[3], base[3];
+    mat3vec(&s.Rs[0], e->tic, r0t);
+    for (int k = 0; k < 3; k++) base[k] = sc * s.Ps[k] - r0t[k];
+    for (int k = s.frame_count; k >= 0; k--) {
+      double rt[3];
+      mat3vec(&s.Rs[9 * k], e->tic, rt);
+      for (int c = 0; c < 3; c++) s.Ps[3 * k + c] = sc * s.Ps[3 * k + c] - rt[c] - base[c];
+    }
+  }
+  {
+    int kv = -1;
+    for (auto &f : s.all_image_frame)
+      if (f.second.is_key_frame) {
+        kv++;
+        if (kv <= W && 3 * (size_t)kv + 2 < x.size()) mat3vec(f.second.R, &x[3 * kv], &s.Vs[3 * kv]);  // x.segment<3>(kv * 3), as written
+      }
+  }
+  vio_features_scale_depth(s.fm, sc);
+  double R0[9], ypr[3], Yr[9], Rd[9], gn[3];
+  g2R(s.g, R0);
+  R2ypr(R0, ypr);
+  const double yneg[3] = {-ypr[0], 0, 0};
+  ypr2R(yneg, Yr);
+  mat3mul(Yr, R0, Rd);
+  mat3vec(Rd, s.g, gn);
+  memcpy(s.g, gn, sizeof(gn));
+  for (int k = 0; k <= s.frame_count; k++) {
+    double v[3], M[9];
+    mat3vec(Rd, &s.Ps[3 * k], v), memcpy(&s.Ps[3 * k], v, 24);
+    mat3vec(Rd, &s.Vs[3 * k], v), memcpy(&s.Vs[3 * k], v, 24);
+    mat3mul(Rd, &s.Rs[9 * k], M), memcpy(&s.Rs[9 * k], M, 72);
+  }
+  return true;
+}
+
 void remember_last(vio_estimator *e, Sequence &s) {  // VINS.cpp:431-434, 472-475
   const int W = e->W;
   memcpy(s.last_R, &s.Rs[9 * W], 72), memcpy(s.last_P, &s.Ps[3 * W], 24);
@@ -365,6 +556,12 @@ void vio_estimator_destroy(vio_estimator_t *e) {
   delete e;
 }
 
+int vio_estimator_enable_initialization(vio_estimator_t *e, int32_t enable) {
+  if (!e) return VIO_EINVAL;
+  e->enable_init = enable != 0;
+  return VIO_OK;
+}
+
 int vio_estimator_clear(vio_estimator_t *e, int32_t seq) {
   if (!e || seq < 0 || seq >= e->n_seq) return VIO_EINVAL;
   clear_state(e, e->seq[seq]);
@@ -384,6 +581,11 @@ int vio_estimator_process_imu(vio_estimator_t *e, int32_t seq, double dt, const 
   if (!s.pre_valid[j]) new_preintegration(e, s, j);
   if (j != 0) {
     host::propagate(s.pre[j], dt, acc, gyr);
+    if (s.solver_flag != VIO_SOLVER_NON_LINEAR && s.tmp_valid) {  // tmp_pre_integration->push_back (VINS.cpp:350-351)
+      host::propagate(s.tmp.pre, dt, acc, gyr);
+      s.tmp.dt.push_back(dt);
+      for (int k = 0; k < 3; k++) s.tmp.acc.push_back(acc[k]), s.tmp.gyr.push_back(gyr[k]);
+    }
     s.dt_buf[j].push_back(dt);
     for (int k = 0; k < 3; k++) s.acc_buf[j].push_back(acc[k]), s.gyr_buf[j].push_back(gyr[k]);
     const double g[3] = {0, 0, e->cfg.gravity};
@@ -485,6 +687,17 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     s.Headers[s.frame_count] = headers[q];
     bool solve = false;
     if (s.solver_flag == VIO_SOLVER_INITIAL) {
+      {  // ImageFrame imageframe(image_msg, header); pre_integration = tmp_pre_integration; a fresh one starts (VINS.cpp:402-404)
+        init::Frame f = s.tmp_valid ? s.tmp : init::Frame();
+        f.header = headers[q];
+        f.points.assign(obs + (size_t)q * obs_stride, obs + (size_t)q * obs_stride + n_obs[q]);
+        s.all_image_frame[headers[q]] = f;
+        s.tmp = init::Frame();
+        memcpy(s.tmp.lin_acc, s.acc_0, 24), memcpy(s.tmp.lin_gyr, s.gyr_0, 24);
+        const double zero[3] = {0, 0, 0};
+        init::repropagate(e->cfg, s.tmp, zero, zero);
+        s.tmp_valid = true;
+      }
       if (s.frame_count == W) {
         if (s.last_track_num < 20) {
           clear_state(e, s);
@@ -507,8 +720,17 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
           vio_features_triangulate(s.fm, s.Ps.data(), s.Rs.data(), e->tic, e->ric);
           solve = true;
         } else {
-          slide_window(e, s);
-          res.action = VIO_FRAME_WAIT_INIT;
+          bool result = false;
+          if (e->enable_init && headers[q] - s.initial_timestamp > 0.3) {  // VINS.cpp:413-417
+            result = solve_initial(e, s);
+            s.initial_timestamp = headers[q];
+          }
+          if (result) {
+            solve = true;
+          } else {
+            slide_window(e, s);
+            res.action = VIO_FRAME_WAIT_INIT;
+          }
         }
       } else {
         s.frame_count++;

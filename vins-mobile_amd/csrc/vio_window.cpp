@@ -377,6 +377,18 @@ int vio_features_export_factors_loop(vio_features_t *fm, int32_t cap_factors, in
                         n_factors, n_features, n_loop_factors);
 }
 
+// visualInitialAlign rescales the landmarks that take part in the solve once the metric scale is known
+// (VINS.cpp:1079-1085).
+int vio_features_scale_depth(vio_features_t *fm, double s) {
+  if (!fm) return VIO_EINVAL;
+  for (Feature &f : fm->feature) {
+    f.used_num = (int)f.obs.size();
+    if (!fm->solved_in_window(f)) continue;
+    f.estimated_depth *= s;
+  }
+  return VIO_OK;
+}
+
 // failureDetection (VINS.cpp:214-265): the checks on the newest frame after a solve. Returns a bit mask (0 = healthy).
 int vio_failure_detection(int32_t last_track_num, const double Bg_newest[3], const double P_newest[3],
                           const double R_newest[9], const double last_P[3], const double last_R[9], int32_t *reasons) {
@@ -401,6 +413,12 @@ int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int
                       int32_t *n_points) {
   if (!fm || !n || (cap > 0 && !info)) return VIO_EINVAL;
   int i = 0, p = 0;
+  if (cap == 0) {  // count only
+    for (const Feature &f : fm->feature) i++, p += (int)f.obs.size();
+    *n = i;
+    if (n_points) *n_points = p;
+    return VIO_OK;
+  }
   for (const Feature &f : fm->feature) {
     if (i >= cap) return VIO_ECAP;
     VioFeatureInfo &o = info[i++];

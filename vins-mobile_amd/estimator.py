@@ -37,6 +37,9 @@ class Estimator:
             self.lib.vio_estimator_destroy(self._h)
             self._h = C.c_void_p()
 
+    def enable_initialization(self, on=True):
+        self._check(self.lib.vio_estimator_enable_initialization(self._h, int(on)), "enable_initialization")
+
     def clear(self, seq=0):
         self._check(self.lib.vio_estimator_clear(self._h, seq), "clear")
 
