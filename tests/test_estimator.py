@@ -331,3 +331,26 @@ def test_bad_initial_state_fails_the_cost_check_and_returns_to_initial():
     assert est.status().solver_flag == abi.VIO_SOLVER_NON_LINEAR
     assert np.abs(est.window()["Ps"][W] - world.truth(k)[0]).max() < 0.1
     loop.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 3, 4])
+def test_estimator_initialises_itself(seed):
+    """No hand-over: solveInitial inside the estimator (relative pose, global SfM + BA, PnP, visual-inertial alignment,
+    VINS.cpp:833-1104) starts the track at the first full window; positions compared after aligning the estimator's own
+    gravity-aligned frame (yaw, origin) with the scene's."""
+    cfg = abi.default_config()
+    W = cfg.window_size
+    loop = RS.EstimatorLoop(cfg, seed=seed, self_init=True)
+    acts = [loop.step().action for _ in range(60)]
+    assert acts[:W] == [abi.VIO_FRAME_FILLING] * W
+    assert acts[W:].count(abi.VIO_FRAME_SOLVED) >= 48 and abi.VIO_FRAME_FAILURE not in acts
+    e = loop.errors()
+    assert np.sqrt((e ** 2).mean()) < 0.1 and e.max() < 0.2, (np.sqrt((e ** 2).mean()), e.max())
+    w = loop.est.window()
+    k = loop.history[-1][0]
+    # metric scale and gravity direction came out right: speed and the vertical velocity component match the truth
+    v_true = loop.world.truth(k)[2]
+    assert abs(np.linalg.norm(w["Vs"][W]) - np.linalg.norm(v_true)) < 0.1 and abs(w["Vs"][W][2] - v_true[2]) < 0.1
+    assert np.abs(w["Bgs"][W] - loop.world.bg).max() < 5e-3
+    loop.close()

@@ -34,3 +34,16 @@ def test_vio_replay_tracks_a_recorded_sequence(tmp_path):
     assert r2.returncode == 0
     err2, _ = MR.score(out + "2", truth)
     assert len(err2) == 35 and err2.max() < 0.3
+    # without the INIT file the estimator initialises itself (relative pose, SfM + BA, visual-inertial alignment): its
+    # world frame is gravity-aligned with its own yaw and origin, so positions are compared after a yaw alignment
+    os.remove(os.path.join(rec, "INIT"))
+    r3 = subprocess.run([exe, rec, out + "3", "--max-corners", "150", "--min-dist", "20"], capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-2000:]
+    t3, P3, _ = H.pkg.replay.read_keyframes(out + "3")
+    assert len(t3) >= 33
+    idx = [int(np.argmin(np.abs(truth["t"] - h))) for h in t3]
+    a, b = P3 - P3[0], truth["P"][idx] - truth["P"][idx][0]
+    th = np.arctan2((a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]).sum(), (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]).sum())
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    e3 = np.sqrt(((a @ Rz.T - b) ** 2).sum(1))
+    assert np.sqrt((e3 ** 2).mean()) < 0.1 and e3.max() < 0.25, (np.sqrt((e3 ** 2).mean()), e3.max())

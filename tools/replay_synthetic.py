@@ -247,11 +247,14 @@ class EstimatorLoop:
     """The same replay through the native estimator (vio_estimator_*, csrc/vio_estimator.cpp): this class only feeds IMU
     samples and image_msg lists and, once, the initial window (in place of solveInitial)."""
 
-    def __init__(self, cfg, seed=1, init_noise=0.0, tracker=None, n_seq=1, world=None):
+    def __init__(self, cfg, seed=1, init_noise=0.0, tracker=None, n_seq=1, world=None, self_init=False):
         self.cfg, self.W = cfg, cfg.window_size
+        self.self_init = self_init   # True: the estimator's own solveInitial instead of handing the first window over
         self.tracker = tracker
         self.world = world or (ImageWorld(cfg, seed) if tracker is not None else SyntheticWorld(cfg, seed))
         self.est = pkg.estimator.Estimator(cfg, self.world.tic, self.world.ric, n_seq=n_seq)
+        if self_init:
+            self.est.enable_initialization(True)
         self.k = 0
         self.init_noise = init_noise
         self.rng = np.random.default_rng(seed + 99)
@@ -267,7 +270,7 @@ class EstimatorLoop:
         else:
             for a, w in world.imu_interval(k):
                 est.process_imu(world.dt, a, w)
-        if k <= W:
+        if k <= W and not self.self_init:
             Pt, Rt, Vt = world.truth(k)
             n = self.init_noise
             P = Pt + self.rng.normal(0, 0.01 * n, 3)
@@ -297,6 +300,15 @@ class EstimatorLoop:
     def errors(self):
         est = np.array([h[1] for h in self.history])
         tru = np.array([h[2] for h in self.history])
+        if self.self_init:
+            # the estimator chose its own world frame (gravity-aligned, yaw and origin arbitrary): align the first solved
+            # position and the yaw (horizontal Procrustes) before comparing
+            a, b = est - est[0], tru - tru[0]
+            num = (a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]).sum()
+            den = (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]).sum()
+            th = np.arctan2(num, den)
+            Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+            return np.sqrt(((a @ Rz.T - b) ** 2).sum(1))
         d = est - tru
         d = d - d[0]
         return np.sqrt((d ** 2).sum(1))
@@ -308,6 +320,7 @@ class EstimatorLoop:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--python-loop", action="store_true", help="window bookkeeping in this file instead of the native estimator")
+    ap.add_argument("--self-init", action="store_true", help="the estimator initialises itself (solveInitial) instead of taking the first window")
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--images", action="store_true", help="render frames of a textured plane and run the KLT front-end on them")
@@ -320,7 +333,7 @@ def main():
     if args.python_loop:
         loop = ClosedLoop(cfg, lambda w: solver.solve([w])[0], pre, seed=args.seed, init_noise=1.0, tracker=tracker)
     else:
-        loop = EstimatorLoop(cfg, seed=args.seed, init_noise=1.0, tracker=tracker)
+        loop = EstimatorLoop(cfg, seed=args.seed, init_noise=1.0, tracker=tracker, self_init=args.self_init)
     for _ in range(args.frames):
         loop.step()
     e = loop.errors()

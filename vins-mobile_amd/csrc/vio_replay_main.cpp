@@ -3,7 +3,8 @@
 //   <dir>/IMU              IMU_MSG stream                      (ViewController.mm:1120-1150, 1614-1622)
 //   <dir>/IMAGE/<i>        PNG frames, <dir>/IMAGE_TIME/<i>    (ViewController.mm:1634-1708)
 //   <dir>/INIT  (optional) window states in place of solveInitial: records of 22 doubles
-//                          {header, P[3], R[9] row-major, V[3], Ba[3], Bg[3]} (this tool's own format)
+//                          {header, P[3], R[9] row-major, V[3], Ba[3], Bg[3]} (this tool's own format); without it the
+//                          estimator initialises itself (relative pose, SfM, visual-inertial alignment)
 //   -> <out>               KEYFRAME_DATA per solved frame: header, position, attitude (x y z w) of the newest frame
 //
 // It strings the calls in the order the app's two threads make them: camera callback (cvtColor + CLAHE + readImage,
@@ -101,6 +102,7 @@ int main(int argc, char **argv) {
   vio_measurements_t *mq = nullptr;
   CHECK(vio_frontend_create(&cfg, 1, &fe));
   CHECK(vio_estimator_create(&cfg, 1, tic, ric, &est));
+  if (init.empty()) CHECK(vio_estimator_enable_initialization(est, 1));  // no INIT file: the estimator's own solveInitial
   CHECK(vio_measurements_create(&mq));
   if (clahe) CHECK(vio_preprocess_create(1, rows, cols, &pp));
 
