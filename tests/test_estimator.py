@@ -354,3 +354,26 @@ def test_estimator_initialises_itself(seed):
     assert abs(np.linalg.norm(w["Vs"][W]) - np.linalg.norm(v_true)) < 0.1 and abs(w["Vs"][W][2] - v_true[2]) < 0.1
     assert np.abs(w["Bgs"][W] - loop.world.bg).max() < 5e-3
     loop.close()
+
+
+@pytest.mark.gpu
+def test_two_estimators_driven_from_two_host_threads():
+    """The deployment DESIGN §5 recommends (one estimator's host phases overlap the other's kernel): contexts are
+    independent, the shared host pool serves one parallel region at a time and the other caller runs inline."""
+    import threading
+    cfg = abi.default_config()
+
+    def run(seed, out):
+        lp = RS.EstimatorLoop(cfg, seed=seed, init_noise=1.0)
+        for _ in range(40):
+            lp.step()
+        out[seed] = np.array([h[1] for h in lp.history])
+        lp.close()
+
+    ref, got = {}, {}
+    run(5, ref), run(6, ref)
+    ts = [threading.Thread(target=run, args=(s, got)) for s in (5, 6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for s in (5, 6):
+        assert got[s].shape == ref[s].shape and np.abs(got[s] - ref[s]).max() < 1e-6

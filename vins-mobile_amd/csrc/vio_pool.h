@@ -24,10 +24,12 @@ class HostPool {
   }
   int width() const { return (int)workers_.size() + 1; }
 
-  // fn(i) for i in [0, n), dynamically distributed; returns when all are done. Not re-entrant.
+  // fn(i) for i in [0, n), dynamically distributed; returns when all are done. One parallel region at a time: a caller
+  // that finds the pool busy (another host thread driving another context, or a nested call) runs its loop inline.
   void parallel_for(int n, const std::function<void(int)> &fn) {
     if (n <= 0) return;
-    if (workers_.empty() || n < 4) {
+    std::unique_lock<std::mutex> region(region_m_, std::try_to_lock);
+    if (workers_.empty() || n < 4 || !region.owns_lock()) {
       for (int i = 0; i < n; i++) fn(i);
       return;
     }
@@ -82,7 +84,7 @@ class HostPool {
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex m_;
+  std::mutex m_, region_m_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)> *fn_ = nullptr;
   std::atomic<int> next_{0};
