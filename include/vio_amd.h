@@ -450,6 +450,32 @@ int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 
 /* ------------------------------------------------------------------------- */
+/* Motion-only window of the front-end: vinsPnP (vins_pnp.hpp:45-91), the 30 Hz
+ * pose the tracker can compute between two back-end solves
+ * (FeatureTracker::solveVinsPnP feature_tracker.cpp:107-160, called from readImage
+ * :207; USE_PNP is off by default, ViewController.mm:144).                       */
+#define VIO_PNP_MAX_FRAMES 8   /* PNP_SIZE + 1 = 7 in the reference (global_param.hpp) */
+typedef struct VioPnpWindow {  /* vinsPnP::solve_ceres vins_pnp.cpp:264-341 after old2new() */
+  int32_t n_frames;            /* PNP_SIZE + 1                                         */
+  double *pose;                /* [n][7] para_Pose   in: initial, out: solved          */
+  double *speed;               /* [n][3] para_Speed                                    */
+  const double *bias;          /* [n][6] para_Bias (Ba, Bg): constant blocks           */
+  const uint8_t *fixed;        /* [n] find_solved: pose and speed constant (:279-284)  */
+  const double *ex_pose;       /* [7] para_Ex_Pose[0], constant                        */
+  const VioPreintegration *preint; /* [n-1]; preint[k] links frame k -> k+1            */
+  const int32_t *feat_start;   /* [n+1] frame k owns factors feat_start[k..k+1)        */
+  const double *observation;   /* [M][2] IMG_MSG_LOCAL::observation                    */
+  const double *position;      /* [M][3] IMG_MSG_LOCAL::position (fixed 3D point)      */
+  const int32_t *track_num;    /* [M]    IMG_MSG_LOCAL::track_num (weight / 10)        */
+} VioPnpWindow;
+typedef struct vio_pnp vio_pnp_t;
+int vio_pnp_create(const VioConfig *cfg, int32_t max_batch, vio_pnp_t **out);
+void vio_pnp_destroy(vio_pnp_t *p);
+/* n independent windows in one device launch (one workgroup each).              */
+int vio_pnp_solve_windows(vio_pnp_t *p, VioPnpWindow *windows, int32_t n, VioSolveStats *stats /* [n] or NULL */);
+int vio_pnp_kernel_ms(vio_pnp_t *p, double *ms_avg, int32_t *launches);
+
+/* ------------------------------------------------------------------------- */
 /* Initialisation pieces (host side, one-off): VINS::solveInitial VINS.cpp:833-1145.
  * Exposed one by one so that each can be tested against its reference.         */
 typedef struct VioInitFrame {  /* ImageFrame initial_aligment.hpp:24-39            */

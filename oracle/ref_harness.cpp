@@ -23,6 +23,8 @@
 
 #include "global_param.hpp"
 #include "imu_factor.h"
+#include "imu_factor_pnp.h"
+#include "perspective_factor.hpp"
 #include "integration_base.h"
 #include "marginalization_factor.hpp"
 #include "pose_local_parameterization.hpp"
@@ -408,4 +410,79 @@ int ref_solve_window(const VioConfig *cfg, VioWindow *w, VioSolveStats *stats) {
   return VIO_OK;
 }
 
+
+// vinsPnP::solve_ceres (vins_pnp.cpp:264-341) with the reference's own factor classes (IMUFactorPnP, PerspectiveFactor)
+// and the vendored Ceres; vins_pnp.cpp itself cannot be compiled here (vins_pnp.hpp pulls in an OpenCV header), so the
+// problem is assembled here line for line. The 0.01 s wall-clock limit is lifted (non-deterministic).
+int ref_pnp_solve(const VioConfig *cfg, VioPnpWindow *w, VioSolveStats *stats) {
+  const int n = w->n_frames;
+  PerspectiveFactor::sqrt_info = cfg->fx / 1.5 * Matrix2d::Identity();  // vinsPnP::setIMUModel
+  std::vector<double> pose(w->pose, w->pose + 7 * n), speed(w->speed, w->speed + 3 * n), bias(w->bias, w->bias + 6 * n);
+  double ex[7];
+  memcpy(ex, w->ex_pose, sizeof(ex));
+  ceres::Problem problem;
+  ceres::LossFunction *loss_function = new ceres::CauchyLoss(1.0);
+  for (int i = 0; i < n; i++) {
+    problem.AddParameterBlock(&pose[7 * i], SIZE_POSE, new PoseLocalParameterization());
+    problem.AddParameterBlock(&speed[3 * i], 3);
+    problem.AddParameterBlock(&bias[6 * i], 6);
+    if (w->fixed[i]) {
+      problem.SetParameterBlockConstant(&pose[7 * i]);
+      problem.SetParameterBlockConstant(&speed[3 * i]);
+    }
+    problem.SetParameterBlockConstant(&bias[6 * i]);
+  }
+  problem.AddParameterBlock(ex, SIZE_POSE, new PoseLocalParameterization());
+  problem.SetParameterBlockConstant(ex);
+  std::vector<IntegrationBase *> pre(n, nullptr);
+  for (int i = 0; i + 1 < n; i++) {
+    int j = i + 1;
+    pre[j] = make_integration(w->preint[i]);
+    problem.AddResidualBlock(new IMUFactorPnP(pre[j]), NULL, &pose[7 * i], &speed[3 * i], &bias[6 * i], &pose[7 * j], &speed[3 * j],
+                             &bias[6 * j]);
+  }
+  for (int i = 0; i < n; i++)
+    for (int m = w->feat_start[i]; m < w->feat_start[i + 1]; m++) {
+      PerspectiveFactor *f = new PerspectiveFactor(Vector2d(w->observation[2 * m], w->observation[2 * m + 1]),
+                                                   Vector3d(w->position[3 * m], w->position[3 * m + 1], w->position[3 * m + 2]),
+                                                   w->track_num[m]);
+      problem.AddResidualBlock(f, loss_function, &pose[7 * i], ex);
+    }
+  ceres::Solver::Options options;
+  options.linear_solver_type = ceres::DENSE_SCHUR;
+  options.num_threads = 1;
+  options.trust_region_strategy_type = ceres::DOGLEG;
+  options.use_explicit_schur_complement = true;
+  options.minimizer_progress_to_stdout = false;
+  options.max_num_iterations = 5;
+  options.max_solver_time_in_seconds = 1e9;
+  ceres::Solver::Summary summary;
+  ceres::Solve(options, &problem, &summary);
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->initial_cost = summary.initial_cost;
+    stats->final_cost = summary.final_cost;
+    stats->iterations = (int)summary.iterations.size();
+    stats->termination = summary.termination_type == ceres::CONVERGENCE ? 1 : summary.termination_type == ceres::NO_CONVERGENCE ? 0 : 2;
+    stats->num_successful_steps = summary.num_successful_steps;
+    stats->num_unsuccessful_steps = summary.num_unsuccessful_steps;
+    for (int i = 0; i < stats->iterations && i < VIO_MAX_TRACE; i++) {
+      const ceres::IterationSummary &it = summary.iterations[i];
+      stats->it_cost[i] = it.cost, stats->it_radius[i] = it.trust_region_radius, stats->it_step_norm[i] = it.step_norm;
+      stats->it_relative_decrease[i] = it.relative_decrease, stats->it_gradient_max_norm[i] = it.gradient_max_norm;
+      stats->it_flags[i] = (it.step_is_valid ? 1 : 0) | (it.step_is_successful ? 2 : 0);
+    }
+  }
+  // new2old (vins_pnp.cpp:137-172): normalized quaternions, no gauge change
+  for (int i = 0; i < n; i++) {
+    Quaterniond q = Quaterniond(pose[7 * i + 6], pose[7 * i + 3], pose[7 * i + 4], pose[7 * i + 5]).normalized();
+    // Rs[i] = q.toRotationMatrix(); old2new would turn it back into Quaterniond{Rs[i]}
+    Quaterniond q2{q.toRotationMatrix()};
+    w->pose[7 * i] = pose[7 * i], w->pose[7 * i + 1] = pose[7 * i + 1], w->pose[7 * i + 2] = pose[7 * i + 2];
+    w->pose[7 * i + 3] = q2.x(), w->pose[7 * i + 4] = q2.y(), w->pose[7 * i + 5] = q2.z(), w->pose[7 * i + 6] = q2.w();
+    for (int k = 0; k < 3; k++) w->speed[3 * i + k] = speed[3 * i + k];
+  }
+  for (IntegrationBase *p : pre) delete p;
+  return VIO_OK;
+}
 }  // extern "C"

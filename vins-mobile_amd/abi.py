@@ -119,6 +119,12 @@ class VioKeyframeData(C.Structure):
     _fields_ = [("header", C.c_double), ("translation", C.c_double * 3), ("rotation", C.c_double * 4)]
 
 
+class VioPnpWindow(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("pose", _dp), ("speed", _dp), ("bias", _dp), ("fixed", C.POINTER(C.c_uint8)),
+                ("ex_pose", _dp), ("preint", C.POINTER(VioPreintegration)), ("feat_start", _ip), ("observation", _dp),
+                ("position", _dp), ("track_num", _ip)]
+
+
 class VioInitFrame(C.Structure):
     _fields_ = [("header", C.c_double), ("R", C.c_double * 9), ("T", C.c_double * 3), ("is_key_frame", C.c_int32),
                 ("n_samples", C.c_int32), ("dt", _dp), ("acc", _dp), ("gyr", _dp), ("acc_0", C.c_double * 3),
@@ -474,6 +480,11 @@ def load_product():
     lib.vio_measurements_push_imu.argtypes = [vp, imup]
     lib.vio_measurements_push_image.argtypes = [vp, C.c_double, obsp, C.c_int32]
     lib.vio_measurements_next.argtypes = [vp, imup, _dp, C.c_int32, _ip, _dp, obsp, C.c_int32, _ip, _ip]
+    lib.vio_pnp_create.argtypes = [cfgp, C.c_int32, C.POINTER(vp)]
+    lib.vio_pnp_destroy.argtypes = [vp]
+    lib.vio_pnp_destroy.restype = None
+    lib.vio_pnp_solve_windows.argtypes = [vp, C.POINTER(VioPnpWindow), C.c_int32, C.POINTER(VioSolveStats)]
+    lib.vio_pnp_kernel_ms.argtypes = [vp, _dp, _ip]
     lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]
     lib.vio_init_sfm.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _ip, _ip, _dp, _dp, _dp, _dp, u8p, _ip]
