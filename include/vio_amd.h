@@ -475,6 +475,33 @@ void vio_pnp_destroy(vio_pnp_t *p);
 int vio_pnp_solve_windows(vio_pnp_t *p, VioPnpWindow *windows, int32_t n, VioSolveStats *stats /* [n] or NULL */);
 int vio_pnp_kernel_ms(vio_pnp_t *p, double *ms_avg, int32_t *launches);
 
+/* The vinsPnP object around that solve (vins_pnp.cpp:16-382), n_seq sequences sharing one launch; what
+ * FeatureTracker::solveVinsPnP drives inside readImage (feature_tracker.cpp:107-160).                   */
+typedef struct VioPnpFeature {  /* IMG_MSG_LOCAL vins_pnp.hpp:36-41; lists ascending in id */
+  int32_t id;
+  double observation[2];        /* ((forw_pts.x - PX) / fx, (forw_pts.y - PY) / fy) feature_tracker.cpp:131 */
+  double position[3];           /* the landmark as the back-end solved it (world frame)   */
+  int32_t track_num;
+} VioPnpFeature;
+typedef struct VioVinsResult {  /* VINS_RESULT vins_pnp.hpp:27-34: the newest back-end state */
+  double header;
+  double Ba[3], Bg[3], P[3], R[9], V[3];
+} VioVinsResult;
+typedef struct vio_pnp_tracker vio_pnp_tracker_t;
+int vio_pnp_tracker_create(const VioConfig *cfg, int32_t n_seq, int32_t pnp_size /* PNP_SIZE = 6 */, const double tic[3],
+                           const double ric[9], vio_pnp_tracker_t **out);
+void vio_pnp_tracker_destroy(vio_pnp_tracker_t *t);
+int vio_pnp_tracker_clear(vio_pnp_tracker_t *t, int32_t seq);                                       /* clearState */
+int vio_pnp_tracker_set_init(vio_pnp_tracker_t *t, int32_t seq, const VioVinsResult *r);           /* setInit    */
+int vio_pnp_tracker_process_imu(vio_pnp_tracker_t *t, int32_t seq, double dt, const double acc[3], const double gyr[3]);
+/* processImage(feature_msg, header, use_pnp) for every active sequence; P_out [n_seq][3] / R_out [n_seq][9] =
+ * Ps / Rs[PNP_SIZE - 1] as solveVinsPnP returns them; solved[q] = 1 when a solve ran for sequence q.       */
+int vio_pnp_tracker_process_images(vio_pnp_tracker_t *t, const VioPnpFeature *features, const int32_t *n_features,
+                                   int32_t stride, const double *headers, int32_t use_pnp, const uint8_t *active,
+                                   double *P_out, double *R_out, int32_t *solved);
+int vio_pnp_tracker_get_window(vio_pnp_tracker_t *t, int32_t seq, double *Ps, double *Rs, double *Vs, double *headers,
+                               uint8_t *find_solved, int32_t *frame_count);
+
 /* ------------------------------------------------------------------------- */
 /* Initialisation pieces (host side, one-off): VINS::solveInitial VINS.cpp:833-1145.
  * Exposed one by one so that each can be tested against its reference.         */

@@ -156,3 +156,95 @@ def test_device_kernel_full_batch_and_errors():
     with pytest.raises(RuntimeError):
         solver.solve([base.copy() for _ in range(257)])
     solver.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the vinsPnP object around the solve (vio_pnp_tracker_*)
+class _Scene:
+    """30 Hz camera, 120 Hz IMU, a landmark cloud with known positions: what the tracker + the back-end feed solveVinsPnP."""
+
+    def __init__(self, cfg, seed):
+        self.cfg, rng = cfg, np.random.default_rng(seed)
+        self.rng = rng
+        self.traj = synth.Trajectory(rng)
+        self.t0 = rng.uniform(0, 20)
+        ex = synth.ex_pose_default()
+        self.ric, self.tic = synth.quat_to_rot(ex[3:]), ex[:3]
+        self.g = np.array([0, 0, cfg.gravity])
+        self.ba, self.bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
+        self.fdt, self.per = 1.0 / 30, 4
+        self.lm = np.column_stack([rng.uniform(-9, 9, 3000), rng.uniform(-9, 9, 3000), rng.uniform(-11, -4, 3000)])
+
+    def t(self, k):
+        return self.t0 + k * self.fdt
+
+    def imu(self, t):
+        R = self.traj.rot(t)
+        return (R.T @ (self.traj.acc(t) + self.g) + self.ba + self.rng.normal(0, 0.02, 3),
+                self.traj.omega_body(t) + self.bg + self.rng.normal(0, 0.002, 3))
+
+    def imu_interval(self, k):
+        dt = self.fdt / self.per
+        return [(dt,) + self.imu(self.t(k - 1) + (s + 1) * dt) for s in range(self.per)]
+
+    def features(self, k, n=120):
+        P, R = self.traj.pos(self.t(k)), self.traj.rot(self.t(k))
+        Rc, Pc = R @ self.ric, P + R @ self.tic
+        pc = (self.lm - Pc) @ Rc
+        vis = np.flatnonzero((pc[:, 2] > 0.5) & (np.abs(pc[:, 0]) < 0.4 * pc[:, 2]) & (np.abs(pc[:, 1]) < 0.55 * pc[:, 2]))[:n]
+        return [(int(i), pc[i, :2] / pc[i, 2] + self.rng.normal(0, 0.5 / self.cfg.fx, 2), self.lm[i] + self.rng.normal(0, 0.01, 3),
+                 int(5 + i % 20)) for i in vis]
+
+
+def test_pnp_tracker_bookkeeping_without_a_solve():
+    """Window filling, updateFeatures, setInit, IMU propagation and the slide with use_pnp = false never reach the
+    device (feature_tracker.cpp:151 passes use_pnp through; the default is off)."""
+    cfg = abi.default_config()
+    sc = _Scene(cfg, 3)
+    tr = pkg.pnp.PnpTracker(cfg, sc.tic, sc.ric, pnp_size=6)
+    hdrs = []
+    for k in range(10):
+        for dt, a, w in ([(0.0,) + sc.imu(sc.t(0))] if k == 0 else sc.imu_interval(k)):
+            tr.process_imu(dt, a, w)
+        if k == 4:   # the back-end's result for frame 2 arrives: it becomes the constant of the window
+            P, R, V = sc.traj.pos(sc.t(2)), sc.traj.rot(sc.t(2)), sc.traj.vel(sc.t(2))
+            tr.set_init(sc.t(2), sc.ba, sc.bg, P, R, V)
+            w = tr.window()
+            assert list(w["find_solved"]) == [0, 0, 1, 0, 0, 0, 0] and np.array_equal(w["Ps"][2], P) and np.array_equal(w["Vs"][2], V)
+        _, _, solved = tr.process_images([sc.features(k)], [sc.t(k)], use_pnp=False)
+        assert solved[0] == 0
+        hdrs.append(sc.t(k))
+        w = tr.window()
+        assert w["frame_count"] == min(k + 1, 6)
+    w = tr.window()
+    assert list(w["headers"][:6]) == hdrs[4:10]                      # four slides: frames 4..9 remain (+ the copy in slot 6)
+    assert list(w["find_solved"]) == [0] * 7                         # frame 2 (the solved one) has left the window
+    assert np.array_equal(w["Ps"][6], w["Ps"][5]) and np.array_equal(w["Rs"][6], w["Rs"][5])   # the slide seeds the next frame
+    tr.close()
+
+
+@pytest.mark.gpu
+def test_pnp_tracker_follows_the_truth_between_backend_results():
+    """solveVinsPnP as readImage runs it: IMU samples since the last frame, the landmarks the back-end has solved with
+    their current observations, and every third frame the back-end's newest state (two frames late) through setInit."""
+    cfg = abi.default_config()
+    sc = _Scene(cfg, 4)
+    tr = pkg.pnp.PnpTracker(cfg, sc.tic, sc.ric, pnp_size=6)
+    errs, n_solved = [], 0
+    for k in range(60):
+        for dt, a, w in ([(0.0,) + sc.imu(sc.t(0))] if k == 0 else sc.imu_interval(k)):
+            tr.process_imu(dt, a, w)
+        if k >= 2 and k % 3 == 2:
+            j = k - 2
+            tr.set_init(sc.t(j), sc.ba, sc.bg, sc.traj.pos(sc.t(j)) + sc.rng.normal(0, 0.005, 3), sc.traj.rot(sc.t(j)),
+                        sc.traj.vel(sc.t(j)) + sc.rng.normal(0, 0.01, 3))
+        P, R, solved = tr.process_images([sc.features(k)], [sc.t(k)], use_pnp=True)
+        n_solved += int(solved[0])
+        if solved[0]:
+            # P / R = the second-newest slot after the slide = the frame just solved
+            errs.append(np.linalg.norm(P[0] - sc.traj.pos(sc.t(k))))
+            assert np.abs(R[0] - sc.traj.rot(sc.t(k))).max() < 0.01
+    assert n_solved == 60 - 6
+    errs = np.array(errs)
+    assert np.sqrt((errs ** 2).mean()) < 0.03 and errs.max() < 0.08, (np.sqrt((errs ** 2).mean()), errs.max())
+    tr.close()

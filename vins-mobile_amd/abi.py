@@ -119,6 +119,15 @@ class VioKeyframeData(C.Structure):
     _fields_ = [("header", C.c_double), ("translation", C.c_double * 3), ("rotation", C.c_double * 4)]
 
 
+class VioPnpFeature(C.Structure):
+    _fields_ = [("id", C.c_int32), ("observation", C.c_double * 2), ("position", C.c_double * 3), ("track_num", C.c_int32)]
+
+
+class VioVinsResult(C.Structure):
+    _fields_ = [("header", C.c_double), ("Ba", C.c_double * 3), ("Bg", C.c_double * 3), ("P", C.c_double * 3),
+                ("R", C.c_double * 9), ("V", C.c_double * 3)]
+
+
 class VioPnpWindow(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("pose", _dp), ("speed", _dp), ("bias", _dp), ("fixed", C.POINTER(C.c_uint8)),
                 ("ex_pose", _dp), ("preint", C.POINTER(VioPreintegration)), ("feat_start", _ip), ("observation", _dp),
@@ -485,6 +494,14 @@ def load_product():
     lib.vio_pnp_destroy.restype = None
     lib.vio_pnp_solve_windows.argtypes = [vp, C.POINTER(VioPnpWindow), C.c_int32, C.POINTER(VioSolveStats)]
     lib.vio_pnp_kernel_ms.argtypes = [vp, _dp, _ip]
+    lib.vio_pnp_tracker_create.argtypes = [cfgp, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(vp)]
+    lib.vio_pnp_tracker_destroy.argtypes = [vp]
+    lib.vio_pnp_tracker_destroy.restype = None
+    lib.vio_pnp_tracker_clear.argtypes = [vp, C.c_int32]
+    lib.vio_pnp_tracker_set_init.argtypes = [vp, C.c_int32, C.POINTER(VioVinsResult)]
+    lib.vio_pnp_tracker_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
+    lib.vio_pnp_tracker_process_images.argtypes = [vp, C.POINTER(VioPnpFeature), _ip, C.c_int32, _dp, C.c_int32, u8p, _dp, _dp, _ip]
+    lib.vio_pnp_tracker_get_window.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, u8p, _ip]
     lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip, _ip]
     lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]
     lib.vio_init_sfm.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _ip, _ip, _dp, _dp, _dp, _dp, u8p, _ip]

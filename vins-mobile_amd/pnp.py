@@ -83,3 +83,66 @@ class PnpSolver:
         ms, k = C.c_double(), C.c_int32()
         self.lib.vio_pnp_kernel_ms(self._h, C.byref(ms), C.byref(k))
         return ms.value, k.value
+
+
+class PnpTracker:
+    """class vinsPnP for n sequences (vio_pnp_tracker_*)."""
+
+    def __init__(self, cfg, tic, ric, n_seq=1, pnp_size=6, lib=None):
+        self.lib = lib or abi.load_product()
+        self.cfg, self.n_seq, self.size = cfg, n_seq, pnp_size
+        self._h = C.c_void_p()
+        tic, ric = np.ascontiguousarray(tic, np.float64), np.ascontiguousarray(ric, np.float64)
+        rc = self.lib.vio_pnp_tracker_create(C.byref(cfg), n_seq, pnp_size, tic.ctypes.data_as(_dp), ric.ctypes.data_as(_dp),
+                                             C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("vio_pnp_tracker_create failed: %d" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_pnp_tracker_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("vio_pnp_tracker_%s failed: %d" % (what, rc))
+
+    def set_init(self, header, Ba, Bg, P, R, V, seq=0):
+        r = abi.VioVinsResult()
+        r.header = float(header)
+        r.Ba[:], r.Bg[:], r.P[:], r.V[:] = list(Ba), list(Bg), list(P), list(V)
+        r.R[:] = list(np.asarray(R, np.float64).ravel())
+        self._check(self.lib.vio_pnp_tracker_set_init(self._h, seq, C.byref(r)), "set_init")
+
+    def process_imu(self, dt, acc, gyr, seq=0):
+        a, g = np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyr, np.float64)
+        self._check(self.lib.vio_pnp_tracker_process_imu(self._h, seq, float(dt), a.ctypes.data_as(_dp), g.ctypes.data_as(_dp)), "process_imu")
+
+    def process_images(self, features_per_seq, headers, use_pnp=True, active=None):
+        """features_per_seq: per sequence a list of (id, (x, y), (X, Y, Z), track_num), ascending id.
+        -> (P [n_seq, 3], R [n_seq, 3, 3], solved [n_seq])."""
+        stride = max(1, max(len(f) for f in features_per_seq))
+        arr = (abi.VioPnpFeature * (stride * self.n_seq))()
+        n = np.zeros(self.n_seq, np.int32)
+        for q, feats in enumerate(features_per_seq):
+            n[q] = len(feats)
+            for i, (fid, ob, pos, tn) in enumerate(feats):
+                f = arr[q * stride + i]
+                f.id, f.track_num = int(fid), int(tn)
+                f.observation[:] = [float(ob[0]), float(ob[1])]
+                f.position[:] = [float(v) for v in pos]
+        hdr = np.ascontiguousarray(headers, np.float64)
+        P, R, solved = np.zeros((self.n_seq, 3)), np.zeros((self.n_seq, 3, 3)), np.zeros(self.n_seq, np.int32)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self.lib.vio_pnp_tracker_process_images(self._h, arr, n.ctypes.data_as(_ip), stride, hdr.ctypes.data_as(_dp),
+                                                            int(use_pnp), act, P.ctypes.data_as(_dp), R.ctypes.data_as(_dp),
+                                                            solved.ctypes.data_as(_ip)), "process_images")
+        return P, R, solved
+
+    def window(self, seq=0):
+        n = self.size + 1
+        Ps, Rs, Vs, hdr, fs, fc = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3)), np.zeros(n), np.zeros(n, np.uint8), C.c_int32()
+        self._check(self.lib.vio_pnp_tracker_get_window(self._h, seq, Ps.ctypes.data_as(_dp), Rs.ctypes.data_as(_dp), Vs.ctypes.data_as(_dp),
+                                                        hdr.ctypes.data_as(_dp), fs.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(fc)),
+                    "get_window")
+        return dict(Ps=Ps, Rs=Rs, Vs=Vs, headers=hdr, find_solved=fs, frame_count=fc.value)
