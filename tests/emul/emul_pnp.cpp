@@ -23,7 +23,7 @@ extern "C" int emul_pnp_solve(const VioConfig *cfg, VioPnpWindow *win, VioSolveS
   v.preint = reinterpret_cast<const double *>(win->preint);
   v.obs = win->observation, v.pos = win->position, v.track = win->track_num;
   v.out_pose = out_pose.data(), v.out_speed = out_speed.data(), v.stats_d = sd.data(), v.stats_i = si.data();
-  v.U = U.data(), v.Jraw = Jraw.data();
+  v.Jraw = Jraw.data();
   v.s_info = cfg->fx / 1.5, v.gravity = cfg->gravity, v.cauchy_b = cfg->cauchy_a * cfg->cauchy_a;
   Ctx cx;
   cx.tid = 0, cx.nt = 1, cx.prof = nullptr, cx.lprof = nullptr;

@@ -37,7 +37,6 @@ struct View {  // one window, all pointers into global memory
   double *out_pose, *out_speed;
   double *stats_d;
   int *stats_i;
-  double *U;              // [n-1][225] whitening matrices (scratch)
   double *Jraw;           // [n-1][15*30] raw IMU Jacobians (scratch)
   double s_info, gravity, cauchy_b;
   int max_iter;
@@ -48,12 +47,16 @@ struct Work {
   P xp, xs, cp, cs;  // iterate and candidate: pose [n][7], speed [n][3]
   P H, Lf;           // normal matrix and its factor, dim x dim row-major (lower triangle valid)
   P g, sc, dg, gd, gn, step, t1, t2, del;
+  P Ul;  // [n-1][225] whitening matrices (upper triangular)
+  P Jw;  // [n-1][18][15] whitened IMU Jacobian columns of the current linearization (also setup scratch)
+  P rl;  // [n-1][15] whitened IMU residuals
   int dim;
   int off[kMaxFrames];  // first column of frame k, or -1 when the frame is constant
 };
 
 // ---- small dense helpers (one thread) -----------------------------------------------------------------------------------
-VIO_DEV bool chol15(double *A) {  // in place lower Cholesky of a 15x15 SPD matrix
+template <class PM>
+VIO_DEV bool chol15(PM A) {  // in place lower Cholesky of a 15x15 SPD matrix
   for (int j = 0; j < 15; j++) {
     double d = A[j * 15 + j];
     for (int k = 0; k < j; k++) d -= A[j * 15 + k] * A[j * 15 + k];
@@ -70,7 +73,8 @@ VIO_DEV bool chol15(double *A) {  // in place lower Cholesky of a 15x15 SPD matr
 }
 
 // sqrt_info = LLT(covariance^-1).matrixL().transpose() (imu_factor_pnp.h:72): U upper triangular with U^T U = cov^-1.
-VIO_DEV bool imu_sqrt_info(const double *cov, double *U /* 225 */, double *tmp /* 225 */) {
+template <class PM>
+VIO_DEV bool imu_sqrt_info(const double *cov, PM U /* 225 */, PM tmp /* 225 */) {
   // cov = C C^T  ->  cov^-1 = C^-T C^-1
   for (int i = 0; i < 225; i++) tmp[i] = cov[i];
   if (!chol15(tmp)) return false;
@@ -136,51 +140,57 @@ VIO_DEV double evaluate(const Ctx &cx, const View &v, Work<P> &w, P pose, P spee
     VIO_SYNC();
   }
   double part = 0;
-  // IMU factors: one lane each
+  // IMU factors. Phase 1, one lane per factor: raw residual / Jacobian (imu_factor_pnp.h:68-71), whitened residual.
   VIO_PARFOR(k, v.n - 1) {
     double sbi[9], sbj[9], pi7[7], pj7[7], res[15];
     for (int c = 0; c < 7; c++) pi7[c] = pose[7 * k + c], pj7[c] = pose[7 * (k + 1) + c];
     for (int c = 0; c < 3; c++) sbi[c] = speed[3 * k + c], sbj[c] = speed[3 * (k + 1) + c];
     for (int c = 0; c < 6; c++) sbi[3 + c] = v.bias[6 * k + c], sbj[3 + c] = v.bias[6 * (k + 1) + c];
-    double *Jraw = v.Jraw + (size_t)k * 450;
-    imu_eval_raw(v.gravity, v.preint + (size_t)k * kPreDoubles, pi7, sbi, pj7, sbj, res, want_lin ? Jraw : nullptr);
-    const double *U = v.U + (size_t)k * 225;
-    double r[15];
+    imu_eval_raw(v.gravity, v.preint + (size_t)k * kPreDoubles, pi7, sbi, pj7, sbj, res, want_lin ? v.Jraw + (size_t)k * 450 : nullptr);
     for (int a = 0; a < 15; a++) {
       double s = 0;
-      for (int b = a; b < 15; b++) s += U[a * 15 + b] * res[b];
-      r[a] = s;
+      for (int b = a; b < 15; b++) s += w.Ul[k * 225 + a * 15 + b] * res[b];
+      if (want_lin) w.rl[k * 15 + a] = s;
       part += 0.5 * s * s;
     }
-    if (want_lin) {
-      // the 18 free columns this factor can touch: pose_i, speed_i, pose_j, speed_j
-      int col[18], src[18], nc = 0;
-      if (w.off[k] >= 0) {
-        for (int c = 0; c < 6; c++) col[nc] = w.off[k] + c, src[nc] = c, nc++;
-        for (int c = 0; c < 3; c++) col[nc] = w.off[k] + 6 + c, src[nc] = 6 + c, nc++;
+  }
+  if (want_lin) {
+    VIO_SYNC();
+    // Phase 2, one lane per (factor, column): the whitened column. Columns of a factor in the order pose_i, speed_i,
+    // pose_j, speed_j; those of constant frames are skipped (col < 0).
+    auto column_of = [&](int k, int a, int *src) {
+      const int fr = a < 9 ? k : k + 1, c = a < 9 ? a : a - 9;
+      *src = (a < 9 ? 0 : 15) + (c < 6 ? c : c);  // pose 0..5, speed = first 3 of the speed-bias part (6..8)
+      return w.off[fr] < 0 ? -1 : w.off[fr] + c;
+    };
+    VIO_PARFOR(item, (v.n - 1) * 18) {
+      const int k = item / 18, a = item - k * 18;
+      int src;
+      if (column_of(k, a, &src) < 0) continue;
+      const double *Jraw = v.Jraw + (size_t)k * 450;
+      double ga = 0;
+      for (int i = 0; i < 15; i++) {
+        double s2 = 0;
+        for (int b = i; b < 15; b++) s2 += w.Ul[k * 225 + i * 15 + b] * Jraw[b * 30 + src];
+        w.Jw[(k * 18 + a) * 15 + i] = s2;
+        ga += s2 * w.rl[k * 15 + i];
       }
-      if (w.off[k + 1] >= 0) {
-        for (int c = 0; c < 6; c++) col[nc] = w.off[k + 1] + c, src[nc] = 15 + c, nc++;
-        for (int c = 0; c < 3; c++) col[nc] = w.off[k + 1] + 6 + c, src[nc] = 21 + c, nc++;
-      }
-      // whitened columns, one at a time against the ones already done (lower triangle of H)
-      double Jw[18][15];
-      for (int a = 0; a < nc; a++) {
-        for (int i = 0; i < 15; i++) {
-          double s = 0;
-          for (int b = i; b < 15; b++) s += U[i * 15 + b] * Jraw[b * 30 + src[a]];
-          Jw[a][i] = s;
-        }
-        double ga = 0;
-        for (int i = 0; i < 15; i++) ga += Jw[a][i] * r[i];
-        VIO_ATOMIC_ADD(&w.g[col[a]], ga);
-        for (int b = 0; b <= a; b++) {
-          double s = 0;
-          for (int i = 0; i < 15; i++) s += Jw[a][i] * Jw[b][i];
-          const int hi = col[a] > col[b] ? col[a] : col[b], lo = col[a] > col[b] ? col[b] : col[a];
-          VIO_ATOMIC_ADD(&w.H[hi * dim + lo], s);
-        }
-      }
+      VIO_ATOMIC_ADD(&w.g[column_of(k, a, &src)], ga);
+    }
+    VIO_SYNC();
+    // Phase 3, one lane per (factor, column pair): J^T J into the lower triangle of H.
+    VIO_PARFOR(item, (v.n - 1) * 171) {
+      const int k = item / 171, pr = item - k * 171;
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= pr) a++;
+      const int b = pr - a * (a + 1) / 2;
+      int sa, sb2;
+      const int ca = column_of(k, a, &sa), cb = column_of(k, b, &sb2);
+      if (ca < 0 || cb < 0) continue;
+      double s2 = 0;
+      for (int i = 0; i < 15; i++) s2 += w.Jw[(k * 18 + a) * 15 + i] * w.Jw[(k * 18 + b) * 15 + i];
+      const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca;
+      VIO_ATOMIC_ADD(&w.H[hi * dim + lo], s2);
     }
   }
   // perspective factors: all lanes; frame of factor m by a short search in feat_start
@@ -320,10 +330,8 @@ VIO_DEV void solve(const Ctx &cx, const View &v, Work<P> &w) {
   VIO_PARFOR(i, 7 * v.n) w.xp[i] = v.pose0[i];
   VIO_PARFOR(i, 3 * v.n) w.xs[i] = v.speed0[i];
   VIO_PARFOR(k, v.n - 1) {
-    double tmp[225], U[225];
-    if (!imu_sqrt_info(v.preint + (size_t)k * kPreDoubles + 17 + 225, U, tmp))
-      for (int i = 0; i < 225; i++) U[i] = (i % 16 == 0) ? 1.0 : 0.0;
-    for (int i = 0; i < 225; i++) v.U[(size_t)k * 225 + i] = U[i];
+    if (!imu_sqrt_info(v.preint + (size_t)k * kPreDoubles + 17 + 225, w.Ul + k * 225, w.Jw + k * 270))
+      for (int i = 0; i < 225; i++) w.Ul[k * 225 + i] = (i % 16 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 450; i++) v.Jraw[(size_t)k * 450 + i] = 0.0;
   }
   VIO_SYNC();
@@ -535,7 +543,9 @@ VIO_HD size_t carve(int n, int nthreads, P base, Work<P> *w, Ctx *cx) {
   P H = take(dim * dim), Lf = take(dim * dim);
   P g = take(dim), sc = take(dim), dg = take(dim), gd = take(dim), gn = take(dim), step = take(dim), t1 = take(dim), t2 = take(dim),
     del = take(dim);
+  P Ul = take(225 * (size_t)(n - 1)), Jw = take(270 * (size_t)(n - 1)), rl = take(15 * (size_t)(n - 1));
   if (w) {
+    w->Ul = Ul, w->Jw = Jw, w->rl = rl;
     w->xp = xp, w->xs = xs, w->cp = cp, w->cs = cs, w->H = H, w->Lf = Lf;
     w->g = g, w->sc = sc, w->dg = dg, w->gd = gd, w->gn = gn, w->step = step, w->t1 = t1, w->t2 = t2, w->del = del;
   }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void pnp_window_kernel(PnpBatch B) {
   v.track = B.track + (size_t)b * B.max_factors;
   v.out_pose = B.out_pose + (size_t)b * 7 * F, v.out_speed = B.out_speed + (size_t)b * 3 * F;
   v.stats_d = B.stats_d + (size_t)b * kStatsD, v.stats_i = B.stats_i + (size_t)b * kStatsI;
-  v.U = B.U + (size_t)b * (F - 1) * 225, v.Jraw = B.Jraw + (size_t)b * (F - 1) * 450;
+  v.Jraw = B.Jraw + (size_t)b * (F - 1) * 450;
   v.s_info = B.s_info, v.gravity = B.gravity, v.cauchy_b = B.cauchy_b;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.lprof = nullptr;
