@@ -524,8 +524,10 @@ int vio_visual_imu_alignment(const VioConfig *cfg, const double tic[3], const Vi
 /* solveRelativeRT motion_estimator.cpp:200-236: pose of the second camera in the first
  * (R [9], unit t [3]) from n >= 9 normalized correspondences xy0/xy1 [n][2];
  * inliers = points in front of both cameras, ok = inliers > 10.                */
-int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, double R[9], double t[3], int32_t *inliers,
-                           int32_t *ok);
+/* R_hint (may be NULL): roughly known rotation of the second camera in the first (e.g.
+ * gyroscope), used only to pick between the two exact solutions of a planar scene. */
+int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, const double *R_hint /* [9] or NULL */,
+                           double R[9], double t[3], int32_t *inliers, int32_t *ok);
 /* cv::solvePnP(..., useExtrinsicGuess = true) with K = I as inital_sfm.cpp:57 and
  * VINS.cpp:982 call it: refines world->camera R [9], t [3] in place.            */
 int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok);

@@ -162,14 +162,16 @@ def _scene(seed, n_frames=11, n_points=160, planar=False, pix_noise=0.5):
     return dict(Rwc=Rwc, pwc=pwc, Xw=Xw, obs=obs, n_frames=n_frames)
 
 
-def _relative(sc, a, b):
+def _relative(sc, a, b, hint=None):
     pa = {p: (x, y) for p, o in enumerate(sc["obs"]) for (k, x, y) in o if k == a}
     pb = {p: (x, y) for p, o in enumerate(sc["obs"]) for (k, x, y) in o if k == b}
     common = sorted(set(pa) & set(pb))
     xy0 = np.array([pa[p] for p in common])
     xy1 = np.array([pb[p] for p in common])
     R, t, inl, ok = np.zeros(9), np.zeros(3), C.c_int32(), C.c_int32()
-    rc = abi.load_product().vio_init_relative_pose(xy0.ctypes.data_as(_dp), xy1.ctypes.data_as(_dp), len(common), R.ctypes.data_as(_dp),
+    h = None if hint is None else np.ascontiguousarray(hint, np.float64)
+    rc = abi.load_product().vio_init_relative_pose(xy0.ctypes.data_as(_dp), xy1.ctypes.data_as(_dp), len(common),
+                                                   None if h is None else h.ctypes.data_as(_dp), R.ctypes.data_as(_dp),
                                                    t.ctypes.data_as(_dp), C.byref(inl), C.byref(ok))
     assert rc == 0
     return R.reshape(3, 3), t, inl.value, ok.value, len(common)
@@ -189,6 +191,22 @@ def test_relative_pose_from_correspondences(seed, planar):
     dirang = np.degrees(np.arccos(np.clip(t @ t_true / np.linalg.norm(t_true), -1, 1)))
     assert abs(np.linalg.norm(t) - 1) < 1e-9 and abs(np.linalg.det(R) - 1) < 1e-9
     assert ang < 0.5 and dirang < 6.0, (ang, dirang)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 6, 8, 9, 10])
+def test_planar_scenes_are_disambiguated_by_a_rotation_hint(seed):
+    """A plane has two exact two-view solutions; with the gyroscope's rotation (here the truth disturbed by 1.5 deg, the
+    size of an uncalibrated bias over a second) as a tie-breaker the physical one is chosen."""
+    sc = _scene(seed, planar=True)
+    a, b = 2, sc["n_frames"] - 1
+    R_true = sc["Rwc"][a].T @ sc["Rwc"][b]
+    t_true = sc["Rwc"][a].T @ (sc["pwc"][b] - sc["pwc"][a])
+    hint = R_true @ synth.rotvec_to_rot(np.random.default_rng(seed).normal(0, np.radians(1.5) / np.sqrt(3), 3))
+    R, t, inl, ok, n = _relative(sc, a, b, hint=hint)
+    assert ok == 1
+    ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ R_true) - 1) / 2, -1, 1)))
+    dirang = np.degrees(np.arccos(np.clip(t @ t_true / np.linalg.norm(t_true), -1, 1)))
+    assert ang < 0.6 and dirang < 6.0, (ang, dirang)
 
 
 def test_pnp_refines_a_pose_from_a_neighbouring_guess():

@@ -393,7 +393,15 @@ bool solve_initial(vio_estimator *e, Sequence &s) {
       double sum = 0;
       for (int k = 0; k < nc; k++) sum += sqrt((a[2 * k] - b[2 * k]) * (a[2 * k] - b[2 * k]) + (a[2 * k + 1] - b[2 * k + 1]) * (a[2 * k + 1] - b[2 * k + 1]));
       if (sum / nc * 520 < 30) return false;  // FAIL_PARALLAX
-      if (!init::solve_relative_rt(a, b, relative_R, relative_T, nullptr)) return false;  // FAIL_RELATIVE
+      // the gyroscope's rotation between frame i and the newest one, as a tie-breaker for planar scenes only: the product
+      // of the pre-integrated delta_q of the intervals in between (body frame), moved into the camera frame
+      Quat dq{0, 0, 0, 1};
+      for (int k = i + 1; k <= W; k++) dq = qmul(dq, s.pre[k].dq);
+      double Rb[9], Rt[9], hint[9], ricT[9];
+      qtoR(qnormalized(dq), Rb);
+      mat3T(e->ric, ricT);
+      mat3mul(ricT, Rb, Rt), mat3mul(Rt, e->ric, hint);
+      if (!init::solve_relative_rt(a, b, relative_R, relative_T, nullptr, hint)) return false;  // FAIL_RELATIVE
       l = i;
       break;
     }

@@ -260,12 +260,18 @@ double sampson_cost(const std::vector<double> &a, const std::vector<double> &b, 
 // the rotation between its frames is small), which also holds on planar scenes where a linear eight-point fit is
 // degenerate. recoverPose's part — choosing the sign of t by the points in front of both cameras (closer than 50) and
 // counting them — follows the published algorithm.
+//
+// One addition over the reference: a scene that is (nearly) a plane admits two exact two-view solutions, and nothing in
+// the correspondences tells them apart (OpenCV's sampler picks one by chance). When the caller knows roughly how the
+// camera rotated (R_hint: second camera in the first, e.g. from the gyroscope), the local minima whose cost is within a
+// factor of the best are compared against it and the closest rotation wins.
 bool solve_relative_rt(const std::vector<double> &xy0, const std::vector<double> &xy1, double Rout[9], double tout[3],
-                       int *inliers) {
+                       int *inliers, const double *R_hint) {
   const size_t n = xy0.size() / 2;
   if (inliers) *inliers = 0;
   if (n < 9 || xy1.size() != xy0.size()) return false;
   double best_cost = 1e300, bestR[9], bestt[3];
+  double cand_cost[6], candR[6][9], candt[6][3];
   const double dirs[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
   for (int start = 0; start < 6; start++) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {dirs[start][0], dirs[start][1], dirs[start][2]};
@@ -332,7 +338,19 @@ bool solve_relative_rt(const std::vector<double> &xy0, const std::vector<double>
       }
       if (!improved) break;
     }
+    cand_cost[start] = cost, memcpy(candR[start], R, sizeof(R)), memcpy(candt[start], t, sizeof(t));
     if (cost < best_cost) best_cost = cost, memcpy(bestR, R, sizeof(R)), memcpy(bestt, t, sizeof(t));
+  }
+  if (R_hint) {  // x2 ~ R x1 + t: R is the first camera seen from the second, the hint is the other way round
+    double best_angle = 1e300;
+    for (int c = 0; c < 6; c++) {
+      if (!(cand_cost[c] <= 3.0 * best_cost + 1e-12 * n)) continue;
+      double M[9];
+      mat3mul(candR[c], R_hint, M);  // R * R_hint = I when they agree
+      const double tr = std::min(3.0, std::max(-1.0, M[0] + M[4] + M[8]));
+      const double angle = acos((tr - 1.0) / 2.0);
+      if (angle < best_angle) best_angle = angle, memcpy(bestR, candR[c], sizeof(bestR)), memcpy(bestt, candt[c], sizeof(bestt));
+    }
   }
   // recoverPose: x2 ~ R x1 + t; the sign of t with more points in front of both cameras within distance 50
   int best_good = -1;
@@ -704,12 +722,12 @@ extern "C" int vio_visual_imu_alignment(const VioConfig *cfg, const double tic[3
   return VIO_OK;
 }
 
-extern "C" int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, double R[9], double t[3],
-                                      int32_t *inliers, int32_t *ok) {
+extern "C" int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, const double *R_hint, double R[9],
+                                      double t[3], int32_t *inliers, int32_t *ok) {
   if (!xy0 || !xy1 || n < 0 || !R || !t || !ok) return VIO_EINVAL;
   std::vector<double> a(xy0, xy0 + 2 * (size_t)n), b(xy1, xy1 + 2 * (size_t)n);
   int in = 0;
-  *ok = init::solve_relative_rt(a, b, R, t, &in) ? 1 : 0;
+  *ok = init::solve_relative_rt(a, b, R, t, &in, R_hint) ? 1 : 0;
   if (inliers) *inliers = in;
   return VIO_OK;
 }

@@ -35,7 +35,10 @@ struct SfmFeature {  // SFMFeature (inital_sfm.hpp:13-21)
 
 // MotionEstimator::solveRelativeRT (motion_estimator.cpp:200-236): rotation / unit translation of the second view expressed
 // in the first from >= 9 correspondences; false when fewer than 11 points end up in front of both cameras.
-bool solve_relative_rt(const std::vector<double> &xy0, const std::vector<double> &xy1, double R[9], double t[3], int *inliers);
+// R_hint (optional, 3x3): an approximate rotation of the second camera in the first, used only to choose between
+// equally good solutions (planar scenes).
+bool solve_relative_rt(const std::vector<double> &xy0, const std::vector<double> &xy1, double R[9], double t[3], int *inliers,
+                       const double *R_hint = nullptr);
 
 // GlobalSFM::construct (inital_sfm.cpp:117-316): q [frame_num][4] (x y z w), T [frame_num][3] = camera-to-frame-l poses.
 bool sfm_construct(int frame_num, double *q, double *T, int l, const double relative_R[9], const double relative_T[3],
