@@ -59,7 +59,7 @@ int paeth(int a, int b, int c) {
 
 // PNG (ISO/IEC 15948) -> 8-bit gray. Colour types 0/2/3/4/6, bit depth 8 or 16 (1/2/4 for gray and palette),
 // non-interlaced. Alpha is ignored like CV_RGBA2GRAY ignores it.
-int decode_png_gray(const std::vector<uint8_t> &file, uint8_t *gray, int64_t cap, int32_t *rows, int32_t *cols) {
+int decode_png_gray_impl(const std::vector<uint8_t> &file, uint8_t *gray, int64_t cap, int32_t *rows, int32_t *cols) {
   if (file.size() < 8 + 25 || memcmp(file.data(), kPngSig, 8) != 0) return VIO_EINVAL;
   size_t pos = 8;
   uint32_t width = 0, height = 0;
@@ -85,7 +85,9 @@ int decode_png_gray(const std::vector<uint8_t> &file, uint8_t *gray, int64_t cap
     }
     pos += 12 + (size_t)len;
   }
-  if (!have_ihdr || idat.empty() || width == 0 || height == 0 || width > 16384 || height > 16384) return VIO_EINVAL;
+  if (!have_ihdr || idat.empty() || width == 0 || height == 0 || width > 16384 || height > 16384 ||
+      (uint64_t)width * height > (1u << 26))  // 64 Mpixel: far beyond any camera frame, keeps the buffers bounded
+    return VIO_EINVAL;
   if (interlace != 0) return VIO_EINVAL;
   int channels;
   switch (ctype) {
@@ -150,6 +152,15 @@ int decode_png_gray(const std::vector<uint8_t> &file, uint8_t *gray, int64_t cap
     prev.swap(cur);
   }
   return VIO_OK;
+}
+
+// The C ABI never throws: allocation failures on hostile sizes come back as VIO_ENOMEM.
+int decode_png_gray(const std::vector<uint8_t> &file, uint8_t *gray, int64_t cap, int32_t *rows, int32_t *cols) {
+  try {
+    return decode_png_gray_impl(file, gray, cap, rows, cols);
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
 }
 
 void png_chunk(std::vector<uint8_t> &out, const char *type, const uint8_t *data, uint32_t len) {
