@@ -175,8 +175,8 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   ldsd hm = nullptr;
   if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
   ldsd cpose = take(7 * (size_t)(d.Pcap + 1)), csb = take(9 * (size_t)d.Pcap), cfeat = take(F);
-  ldsd gp = take(npc), gf = take(F), sp = take(npc), sf = take(F), dp = take(npc), df = take(F);
-  ldsd gdp = take(npc), gdf = take(F), gnp = take(npc), gnf = take(F), stp = take(npc), stf = take(F);
+  ldsd gp = take(npc), gf = take(F), sp = take(npc), sf = take(F), dp = take(npc);
+  ldsd gdp = take(npc), gnp = take(npc), gnf = take(F), stp = take(npc), stf = take(F);
   ldsd hdiag = take(npc), hff = take(F), ef = take(F), einv = take(F), ldinv = take(npc), t1 = take(npc),
          t2 = take(npc);
   ldsd blk = take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1);
@@ -189,7 +189,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   if (w) {
     w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
     w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
-    w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->df = df, w->gdp = gdp, w->gdf = gdf;
+    w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->gdp = gdp;
     w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef, w->einv = einv;
     w->blk_ij = reinterpret_cast<ldsi>(blk);
     w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;

@@ -158,8 +158,8 @@ struct WorkT {
   ldsd ex;                  // 7
   ldsd gp, gf;              // unscaled gradient J^T r: np, F
   ldsd sp, sf;              // Jacobi scaling
-  ldsd dp, df;              // dogleg diagonal
-  ldsd gdp, gdf;            // gradient in d-scaled space
+  ldsd dp;                  // dogleg diagonal (poses; landmarks: feat_d)
+  ldsd gdp;                 // gradient in d-scaled space (poses; landmarks: feat_gd)
   ldsd gnp, gnf;            // Gauss-Newton step in d-scaled space
   ldsd stp, stf;            // trust-region step (J_s coordinates), later delta
   ldsd hdiag, hff;          // diag(H_pp), H_ff (unscaled)
@@ -1202,6 +1202,19 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 // In place: Hm <- S Hm S + diag(Dp^2) on the pose side, then subtracts the landmark Schur term
 // sum_f ws_f ws_f^T / e_f (ws = WT scaled by sp, sf). Also builds rhs (-> w.t1) = sp gp - sum_f ws_f gs_f / e_f.
 // Returns false if some e_f <= 0.
+// Ceres' trust-region diagonal of a landmark, D_f = sqrt(clamp(diag(J_s^T J_s))) = sqrt(clamp(s_f^2 H_ff)), and the scaled
+// gradient in those units, g_f s_f / D_f (dogleg_strategy.cc:98-115). Both are functions of arrays that only change at a
+// new linearization, so they are recomputed where needed instead of living in LDS (16 bytes per landmark that decide
+// whether a window's matrix still fits next to its vectors).
+template <class WK>
+VIO_DEV double feat_d(const WK &w, int f) {
+  return sqrt(fmin(fmax(w.sf[f] * w.sf[f] * w.hff[f], 1e-6), 1e32));
+}
+template <class WK>
+VIO_DEV double feat_gd(const WK &w, int f) {
+  return w.sf[f] * w.gf[f] / feat_d(w, f);
+}
+
 template <class WK>
 VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu) {
   const int np = v.np, F = v.F;
@@ -1211,7 +1224,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   // over the landmark coupling W is needed, and y = z / s at the end. (Cholesky is invariant under this diagonal
   // congruence up to rounding; a non-positive pivot appears in both forms or in neither.)
   VIO_PARFOR(f, F) {
-    const double c = w.df[f] / w.sf[f];
+    const double c = feat_d(w, f) / w.sf[f];
     const double e = w.hff[f] + mu * c * c;  // E_f
     const double ei = 1.0 / e;
     w.ef[f] = e;
@@ -1744,11 +1757,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         part += g * g;
       }
       VIO_PARFOR(f, F) {
-        double c = w.sf[f] * w.sf[f] * w.hff[f];
-        double d = sqrt(fmin(fmax(c, 1e-6), 1e32));
-        w.df[f] = d;
-        double g = w.sf[f] * w.gf[f] / d;
-        w.gdf[f] = g;
+        const double g = feat_gd(w, f);
         part += g * g;
       }
       gd_sq = block_sum(cx, part);
@@ -1795,7 +1804,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
           VIO_SYNC();
           VIO_PARFOR(f, F) {
             double y = (w.tf[f] - w.gnf[f] / w.ef[f]) / w.sf[f];
-            w.gnf[f] = -w.df[f] * y;
+            w.gnf[f] = -feat_d(w, f) * y;
             if (!isfinite(y)) bad = 1;
           }
           VIO_PARFOR(i, np) {
@@ -1818,9 +1827,10 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
           part2 += mu_used * w.dp[i] * w.dp[i] * u * u;
         }
         VIO_PARFOR(f, F) {
-          double u = w.gdf[f] / w.df[f];
+          const double d = feat_d(w, f);
+          double u = w.sf[f] * w.gf[f] / d / d;
           w.stf[f] = u;
-          part2 += mu_used * w.df[f] * w.df[f] * u * u;
+          part2 += mu_used * d * d * u * u;
         }
         VIO_SYNC();
         double reg = block_sum(cx, part2);
@@ -1837,7 +1847,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       // ComputeTraditionalDoglegStep (dogleg_strategy.cc:199-255)
       double p1 = 0, p2 = 0;
       VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += w.gdp[i] * w.gnp[i];
-      VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += w.gdf[f] * w.gnf[f];
+      VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += feat_gd(w, f) * w.gnf[f];
       double pdummy = 0;
       block_sum3(cx, p1, p2, pdummy);
       double gnn2 = p1, gdot = p2;
@@ -1868,12 +1878,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         preg += mu_used * w.dp[i] * w.dp[i] * st * st;
       }
       VIO_PARFOR(f, F) {
-        double s = ca * w.gdf[f] + cb * w.gnf[f];
+        const double d = feat_d(w, f);
+        double s = ca * (w.sf[f] * w.gf[f] / d) + cb * w.gnf[f];
         pn += s * s;
-        double st = s / w.df[f];
+        double st = s / d;
         w.stf[f] = st;
         psg += st * w.sf[f] * w.gf[f];
-        preg += mu_used * w.df[f] * w.df[f] * st * st;
+        preg += mu_used * d * d * st * st;
       }
       VIO_SYNC();
       block_sum3(cx, pn, psg, preg);
