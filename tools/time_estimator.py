@@ -20,6 +20,23 @@ abi = pkg.abi
 def main():
     n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    n_est = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if n_est > 1:   # several estimator objects, one host thread each: their kernels overlap the others' host phases
+        import threading
+        t0 = time.perf_counter()
+        res = [None] * n_est
+        ths = [threading.Thread(target=lambda i=i: res.__setitem__(i, run(n_seq, n_frames, quiet=True))) for i in range(n_est)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        solves = sum(r[0] for r in res)
+        span = max(r[2] for r in res) - min(r[1] for r in res)
+        print("%d estimators x %d sequences on %d host threads: %d window solves in %.1f ms of solve phase -> %.0f solves/s aggregate"
+              % (n_est, n_seq, n_est, solves, span * 1e3, solves / span))
+        return
+    run(n_seq, n_frames)
+
+
+def run(n_seq, n_frames, quiet=False):
     n_worlds = min(n_seq, 8)     # distinct data sets, reused round-robin (python-side generation is the slow part)
     cfg = abi.default_config()
     W = cfg.window_size
@@ -40,6 +57,7 @@ def main():
     hdr = np.zeros(n_seq)
     res = (abi.VioFrameResult * n_seq)()
     t_img, t_imu, phases = [], [], []
+    t_first_solve = t_last = None
     for k in range(n_frames):
         ns = np.array([len(data[q % n_worlds][k][0]) for q in range(n_seq)], np.int32)
         st = int(ns.max())
@@ -73,6 +91,12 @@ def main():
         phases.append(ph)
         if k >= W:
             assert all(r.action == abi.VIO_FRAME_SOLVED for r in res), [r.action for r in res][:8]
+            if k == W + 2:
+                t_first_solve = time.perf_counter()
+            t_last = time.perf_counter()
+    if quiet:
+        est.close()
+        return n_seq * (n_frames - W - 3), t_first_solve, t_last
     solve = np.array(t_img[W + 2:]) * 1e3
     fill = np.array(t_img[1:W]) * 1e3
     print("n_seq %d: process_images with a solve: %.2f ms median (%.2f min) -> %.0f window solves/s end to end; filling phase %.2f ms"

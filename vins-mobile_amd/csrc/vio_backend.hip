@@ -122,6 +122,7 @@ struct vio_backend {
   // current batch
   int n = 0;
   bool uploaded = false;
+  hipStream_t last_stream = nullptr;  // where the last launch went: what sync / download wait for
   bool lds_matrix = true;
   bool profile = false;
   size_t lds_bytes = 0;
@@ -363,6 +364,7 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (!be) return VIO_EINVAL;
   if (!be->uploaded) return VIO_ESTATE;
   hipStream_t st = stream ? (hipStream_t)stream : be->stream;
+  be->last_stream = st;
   if (be->events_used == be->events.size()) {
     if (be->events.size() >= 4096) {  // recycle: fold what is pending into nothing (caller did not ask for it)
       be->events_used = 0;
@@ -442,7 +444,8 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
   if (!be || !windows) return VIO_EINVAL;
   if (!be->uploaded || n != be->n) return VIO_ESTATE;
   const double t0 = now_ms();
-  HIP_OK(hipDeviceSynchronize());
+  // only this context's launch: other contexts (other host threads) keep the device busy meanwhile
+  HIP_OK(hipStreamSynchronize(be->last_stream ? be->last_stream : be->stream));
   const double t1 = now_ms();
   hipStream_t st = be->stream;
 #define D2H(dst, src)                                                                                          \

@@ -25,11 +25,18 @@ class HostPool {
   int width() const { return (int)workers_.size() + 1; }
 
   // fn(i) for i in [0, n), dynamically distributed; returns when all are done. One parallel region at a time: a caller
-  // that finds the pool busy (another host thread driving another context, or a nested call) runs its loop inline.
+  // that finds the pool busy (another host thread driving another context) waits for its turn when the loop is long and
+  // runs it inline when it is short. fn must not call parallel_for itself.
   void parallel_for(int n, const std::function<void(int)> &fn) {
     if (n <= 0) return;
-    std::unique_lock<std::mutex> region(region_m_, std::try_to_lock);
-    if (workers_.empty() || n < 4 || !region.owns_lock()) {
+    if (workers_.empty() || n < 4) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    std::unique_lock<std::mutex> region(region_m_, std::defer_lock);
+    if (n >= 32) {
+      region.lock();
+    } else if (!region.try_lock()) {
       for (int i = 0; i < n; i++) fn(i);
       return;
     }
