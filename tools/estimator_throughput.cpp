@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -53,6 +54,8 @@ int main(int argc, char **argv) {
   const int W = cfg.window_size, stride = 160, imu_stride = 16;
   std::vector<double> t_begin(E), t_end(E);
   std::vector<long> solved(E, 0);
+  std::vector<std::array<double, 3>> phase(E, {0, 0, 0});
+  std::vector<int> frames_timed(E, 0);
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto run = [&](int e) {
     vio_estimator_t *est = nullptr;
@@ -84,8 +87,13 @@ int main(int argc, char **argv) {
       if (k == W + 2) t_begin[e] = now();
       vio_estimator_process_imu_batch(est, n_imu.data(), imu_stride, dt.data(), acc.data(), gyr.data());
       if (vio_estimator_process_images(est, obs.data(), n_obs.data(), stride, hdr.data(), nullptr, res.data()) != VIO_OK) break;
-      if (k >= W + 2)
+      if (k >= W + 2) {
         for (int q = 0; q < S; q++) solved[e] += res[q].action == VIO_FRAME_SOLVED;
+        double ms[3];
+        vio_estimator_get_timing(est, ms);
+        for (int i = 0; i < 3; i++) phase[e][i] += ms[i];
+        frames_timed[e]++;
+      }
     }
     t_end[e] = now();
     vio_estimator_destroy(est);
@@ -96,6 +104,9 @@ int main(int argc, char **argv) {
   double b = t_begin[0], en = t_end[0];
   long tot = 0;
   for (int e = 0; e < E; e++) b = std::min(b, t_begin[e]), en = std::max(en, t_end[e]), tot += solved[e];
+  for (int e = 0; e < E; e++)
+    printf("  estimator %d: mean ms per frame: before-solve %.2f, solve_windows %.2f, after-solve %.2f\n", e, phase[e][0] / frames_timed[e],
+           phase[e][1] / frames_timed[e], phase[e][2] / frames_timed[e]);
   printf("%d estimator(s) x %d sequences: %ld window solves in %.1f ms -> %.0f solves/s end to end (host buffers in, host states out)\n", E, S,
          tot, (en - b) * 1e3, tot / (en - b));
   return 0;

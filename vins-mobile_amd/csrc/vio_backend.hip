@@ -492,11 +492,16 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
 
 int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n, int32_t buf_num, VioSolveStats *stats) {
   (void)buf_num;  // wall-clock budget selector in the reference (VINS.cpp:648-653); no time limit here
+  const double t0 = now_ms();
   int rc = vio_backend_upload(be, windows, n);
   if (rc != VIO_OK) return rc;
+  const double t1 = now_ms();
   rc = vio_backend_launch(be, nullptr);
   if (rc != VIO_OK) return rc;
-  return vio_backend_download(be, windows, n, stats);
+  const double t2 = now_ms();
+  rc = vio_backend_download(be, windows, n, stats);
+  if (host_timing()) fprintf(stderr, "vio_backend_solve_windows: upload %.2f ms, launch call %.2f ms, download %.2f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
+  return rc;
 }
 
 }  // extern "C"
