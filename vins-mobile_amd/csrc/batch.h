@@ -25,6 +25,7 @@ constexpr int kMaxPriorBlocks = VIO_MAX_PRIOR_BLOCKS;
 
 struct BatchDims {
   int Wcap, Pcap, Fcap, Mcap, Ncap, Fpad, n6cap, nblk_cap, pair_cap;
+  int Flds;  // landmarks the LDS layout is carved for (<= Fcap, which sizes the global strides): every landmark costs LDS
   int max_iter;
   double s_info, gravity, cauchy_b;
 };
@@ -36,6 +37,7 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
   d.Wcap = Wcap, d.Pcap = Wcap + 1, d.Fcap = Fcap > 0 ? Fcap : 1, d.Mcap = Mcap > 0 ? Mcap : 1;
   d.Ncap = 15 * d.Pcap + 6;
   d.Fpad = (d.Fcap + 7) / 8 * 8;
+  d.Flds = d.Fcap;
   d.n6cap = 6 * (d.Pcap + 1);  // pose groups 0..P-1 plus one more: loop pose (solve) / extrinsic (marginalization)
   d.nblk_cap = d.Pcap + (any_loop ? 1 : 0);
   d.pair_cap = (d.Pcap + 1) * (d.Pcap + 2) / 2;  // distinct (host, target) pairs incl. the loop pose
@@ -160,7 +162,7 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
                          WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // padded pose-side length
-  const size_t F = d.Fcap;
+  const size_t F = d.Flds;
   auto take = [&](size_t n) {
     ldsd p = base + o;  // (a null base only measures; the pointers are then never used)
     o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
@@ -241,7 +243,12 @@ struct HostBatch {
   // Same shape as the previous batch: nothing is refilled, pack_window rewrites every field the kernel reads and the
   // padding keeps finite values of earlier windows.
   void resize(const BatchDims &dims, int n_, bool poison = false) {
-    if (sized && !poison && n == n_ && memcmp(&d, &dims, sizeof(BatchDims)) == 0) return;
+    BatchDims a = d, b = dims;
+    a.Flds = b.Flds = 0;  // the LDS carve size does not change the staging layout
+    if (sized && !poison && n == n_ && memcmp(&a, &b, sizeof(BatchDims)) == 0) {
+      d.Flds = dims.Flds;
+      return;
+    }
     d = dims, s = make_strides(dims), n = n_, sized = true;
     hdr.assign((size_t)n * kHdrInts, 0), hdr_d.assign((size_t)n * kHdrDoubles, 0.0);
     pose.assign(n * s.pose, 0.0), sb.assign(n * s.sb, 0.0), ex.assign(n * s.ex, 0.0), feat.assign(n * s.feat, 1.0);

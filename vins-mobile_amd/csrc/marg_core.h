@@ -84,7 +84,7 @@ VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, 
     o += (n + 1) & ~(size_t)1;
     return p;
   };
-  const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Fcap;
+  const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Flds;
   ldsd Am = lds_matrix ? take(pos * pos) : nullptr;
   ldsd bm = take(pos), tol = take(pos), hff = take(F), gf = take(F), einv = take(F);
   ldsd prdx = take(d.Ncap), prr = take(d.Ncap);

@@ -211,18 +211,21 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
       for (int k = 0; k < w.n_factors; k++)
         if (w.factor_target[k] == w.window_size + 1) any_loop = true;
   }
-  // Capacities are sticky while the batch keeps its size: a batch that fits the previous layout reuses it (no
-  // re-staging of the padding, no device reallocation); otherwise they grow in steps.
+  // Capacities (global strides, allocations) are sticky while the batch keeps its size and grow in generous steps: a
+  // batch that fits the previous layout re-stages and reallocates nothing (hipFree synchronizes the device and
+  // page-locked reallocation costs milliseconds, which stalls every other context on the GPU). The LDS layout is carved
+  // for the exact landmark maximum of THIS batch (d.Flds): every landmark costs LDS.
   BatchDims d;
   const BatchDims &pd = be->hb.d;
   if (be->hb.sized && n == be->hb.n && Wmax == pd.Wcap && Fmax <= pd.Fcap && Mmax <= pd.Mcap && Nmax <= pd.Ncap &&
       (!any_loop || pd.nblk_cap == pd.Pcap + 1)) {
     d = pd;
   } else {
-    const int Fr = Fmax /* every landmark costs LDS: no rounding */, Mr = std::min(be->cfg.max_factors, (Mmax + 127) / 128 * 128);
-    d = make_dims(be->cfg, Wmax, Fr, Mr, any_loop);
+    const int Fr = std::min(be->cfg.max_features, (Fmax + 63) / 64 * 64), Mr = std::min(be->cfg.max_factors, (Mmax + 511) / 512 * 512);
+    d = make_dims(be->cfg, Wmax, std::max(Fr, Fmax), std::max(Mr, Mmax), any_loop);
     d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
+  d.Flds = std::max(Fmax, 1);
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
   const double t0 = now_ms();
   try {
