@@ -50,6 +50,7 @@ struct Work {
   P Ul;  // [n-1][225] whitening matrices (upper triangular)
   P Jw;  // [n-1][18][15] whitened IMU Jacobian columns of the current linearization (also setup scratch)
   P rl;  // [n-1][15] whitened IMU residuals
+  VIO_AS3 int *tab;  // lower-triangle entry list of damped_solve, (i << 8) | k
   int dim;
   int off[kMaxFrames];  // first column of frame k, or -1 when the frame is constant
 };
@@ -232,7 +233,11 @@ VIO_DEV void scaled_Hv(const Ctx &cx, Work<P> &w, P vin, P y) {
   VIO_SYNC();
 }
 
-// Solves (S H S + diag(D^2)) y = S g by Cholesky; y into w.t1. Returns false when a pivot is not positive.
+// Solves (S H S + diag(D^2) mu) y = S g; y into w.t1. Returns false when a pivot is not positive (the condition under
+// which Ceres' dense Cholesky fails). Right-looking LDL^T with the column left unscaled (no square roots) and the
+// right-hand side carried as one more row, so the forward substitution is part of the elimination; the lower-triangle
+// entries (i, k) are listed once in w.tab, columns last to first: the entries step j updates (k > j) are a prefix of that
+// list and all lanes share them evenly. The back substitution runs column by column.
 template <class P>
 VIO_DEV bool damped_solve(const Ctx &cx, Work<P> &w, double mu) {
   const int dim = w.dim;
@@ -252,34 +257,26 @@ VIO_DEV bool damped_solve(const Ctx &cx, Work<P> &w, double mu) {
       ok = false;
       break;
     }
-    const double d = sqrt(piv);
-    VIO_SYNC();  // every lane has read the pivot
-    VIO_PARFOR(i, dim) {
-      if (i == j) w.Lf[j * dim + j] = d;
-      if (i > j) w.Lf[i * dim + j] /= d;
-    }
-    VIO_SYNC();
-    VIO_PARFOR(i, dim) {
-      if (i <= j) continue;
-      const double lij = w.Lf[i * dim + j];
-      for (int k = j + 1; k <= i; k++) w.Lf[i * dim + k] -= lij * w.Lf[k * dim + j];
+    const double ip = 1.0 / piv, bj = w.t1[j];
+    const int rem = dim - j;  // rows below j plus the rhs row
+    VIO_PARFOR(q, rem * (rem + 1) / 2 - 1) {
+      const int ik = w.tab[q], i = ik >> 8, k = ik & 0xff;
+      const double akj = w.Lf[k * dim + j] * ip;
+      if (i < dim) w.Lf[i * dim + k] -= w.Lf[i * dim + j] * akj;
+      else w.t1[k] -= bj * akj;
     }
     VIO_SYNC();
   }
   if (!ok) return false;
-  if (cx.tid == 0) {  // two triangular solves on 63 unknowns
-    for (int i = 0; i < dim; i++) {
-      double s = w.t1[i];
-      for (int k = 0; k < i; k++) s -= w.Lf[i * dim + k] * w.t1[k];
-      w.t1[i] = s / w.Lf[i * dim + i];
+  for (int j = dim - 1; j >= 0; j--) {  // x_j = b_j / piv_j, then b_i -= a_ji x_j for the rows above
+    const double xj = w.t1[j] / w.Lf[j * dim + j];
+    VIO_SYNC();
+    VIO_PARFOR(i, j + 1) {
+      if (i == j) w.t1[j] = xj;
+      else w.t1[i] -= w.Lf[j * dim + i] * xj;
     }
-    for (int i = dim - 1; i >= 0; i--) {
-      double s = w.t1[i];
-      for (int k = i + 1; k < dim; k++) s -= w.Lf[k * dim + i] * w.t1[k];
-      w.t1[i] = s / w.Lf[i * dim + i];
-    }
+    VIO_SYNC();
   }
-  VIO_SYNC();
   return true;
 }
 
@@ -327,6 +324,12 @@ VIO_DEV void solve(const Ctx &cx, const View &v, Work<P> &w) {
   int dim = 0;
   for (int k = 0; k < v.n; k++) w.off[k] = v.fixed[k] ? -1 : (dim += kDof) - kDof;
   w.dim = dim;
+  // entry list of damped_solve: column k = dim-1 .. 1, rows i = k .. dim (row dim = the right-hand side)
+  VIO_PARFOR(k, dim) {
+    if (k < 1) continue;
+    const int off = (dim - k) * (dim - k + 1) / 2 - 1;
+    for (int i = k; i <= dim; i++) w.tab[off + i - k] = (i << 8) | k;
+  }
   VIO_PARFOR(i, 7 * v.n) w.xp[i] = v.pose0[i];
   VIO_PARFOR(i, 3 * v.n) w.xs[i] = v.speed0[i];
   VIO_PARFOR(k, v.n - 1) {
@@ -544,8 +547,10 @@ VIO_HD size_t carve(int n, int nthreads, P base, Work<P> *w, Ctx *cx) {
   P g = take(dim), sc = take(dim), dg = take(dim), gd = take(dim), gn = take(dim), step = take(dim), t1 = take(dim), t2 = take(dim),
     del = take(dim);
   P Ul = take(225 * (size_t)(n - 1)), Jw = take(270 * (size_t)(n - 1)), rl = take(15 * (size_t)(n - 1));
+  P tab = take(((dim + 1) * (dim + 2) / 2 + 1) / 2 + 1);
   if (w) {
     w->Ul = Ul, w->Jw = Jw, w->rl = rl;
+    w->tab = reinterpret_cast<VIO_AS3 int *>(tab);
     w->xp = xp, w->xs = xs, w->cp = cp, w->cs = cs, w->H = H, w->Lf = Lf;
     w->g = g, w->sc = sc, w->dg = dg, w->gd = gd, w->gn = gn, w->step = step, w->t1 = t1, w->t2 = t2, w->del = del;
   }

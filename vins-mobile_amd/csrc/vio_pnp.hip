@@ -14,7 +14,7 @@ using namespace vio;
 
 namespace {
 
-constexpr int kThreads = 128;
+constexpr int kThreads = 256;
 constexpr int kStatsD = 4 + 5 * kMaxTrace, kStatsI = 4 + kMaxTrace;
 
 struct PnpBatch {  // device pointers, per-window strides in elements
