@@ -16,6 +16,11 @@ from . import abi
 _u8p, _fp, _ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
 
 
+_OBS_DTYPE = np.dtype({"names": ["id", "x", "y", "z"], "formats": ["<i4", "<f8", "<f8", "<f8"],
+                       "offsets": [0, 8, 16, 24], "itemsize": 32})
+assert C.sizeof(abi.VioObs) == 32
+
+
 class FeatureTracker:
     def __init__(self, cfg=None, n_seq=1):
         self.lib = abi.load_product()
@@ -48,17 +53,17 @@ class FeatureTracker:
         frames = np.ascontiguousarray(frames, np.uint8)
         assert frames.shape == (self.n_seq, self.cfg.image_rows, self.cfg.image_cols), frames.shape
         cap = self.cfg.max_corners
-        obs = (abi.VioObs * (self.n_seq * cap))()
+        obs = np.zeros(self.n_seq * cap, _OBS_DTYPE)      # VioObs records, read back without per-element ctypes access
         n_obs = np.zeros(self.n_seq, np.int32)
         self._check(self.lib.vio_frontend_read_images(self._h, frames.ctypes.data_as(_u8p), frames.shape[1], frames.shape[2],
-                                                      frames.shape[2], None, 1 if publish else 0, obs,
-                                                      n_obs.ctypes.data_as(_ip)), "read_images")
+                                                      frames.shape[2], None, 1 if publish else 0,
+                                                      C.cast(obs.ctypes.data, C.POINTER(abi.VioObs)), n_obs.ctypes.data_as(_ip)),
+                    "read_images")
+        obs = obs.reshape(self.n_seq, cap)
         out = []
         for s in range(self.n_seq):
-            n = int(n_obs[s])
-            ids = np.array([obs[s * cap + i].id for i in range(n)], np.int32)
-            xyz = np.array([[obs[s * cap + i].x, obs[s * cap + i].y, obs[s * cap + i].z] for i in range(n)]).reshape(n, 3)
-            out.append((ids, xyz))
+            o = obs[s, :int(n_obs[s])]
+            out.append((o["id"].copy(), np.stack([o["x"], o["y"], o["z"]], axis=1)))
         return out
 
     def state(self, seq=0):
