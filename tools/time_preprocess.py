@@ -21,3 +21,12 @@ for ch in (4,1):
     ms,k=pp.kernel_ms()
     by=(ch+3)*rows*cols*n
     print("channels %d: %d frames %.3f ms -> %.0f frames/s, %.0f GB/s algorithmic" % (ch, n, ms, n/ms*1e3, by/ms/1e6))
+# host-buffer entry point (pageable numpy in, pageable numpy out)
+import time
+for it in range(3):
+    pp.run(rgba)
+t0 = time.perf_counter()
+for it in range(5):
+    pp.run(rgba)
+dt = (time.perf_counter() - t0) / 5
+print("host path, %d RGBA frames (%d MB in, %d MB out): %.2f ms per call -> %.0f frames/s" % (n, rgba.nbytes >> 20, 2 * n * rows * cols >> 20, dt * 1e3, n / dt))
