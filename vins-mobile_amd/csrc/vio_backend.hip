@@ -221,7 +221,10 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
       (!any_loop || pd.nblk_cap == pd.Pcap + 1)) {
     d = pd;
   } else {
-    const int Fr = std::min(be->cfg.max_features, (Fmax + 63) / 64 * 64), Mr = std::min(be->cfg.max_factors, (Mmax + 511) / 512 * 512);
+    // 25 % headroom, then rounded: landmark and factor counts of a running batch drift by a few percent from frame to
+    // frame, and every growth is a round of page-locked and device reallocations (tens of milliseconds)
+    const int Fr = std::min(be->cfg.max_features, (Fmax + Fmax / 4 + 63) / 64 * 64),
+              Mr = std::min(be->cfg.max_factors, (Mmax + Mmax / 4 + 511) / 512 * 512);
     d = make_dims(be->cfg, Wmax, std::max(Fr, Fmax), std::max(Mr, Mmax), any_loop);
     d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
