@@ -74,3 +74,19 @@ def test_oracle_rejects_bad_indices():
     w.factor_feature[0] = w.n_features  # out of range
     st = abi.VioSolveStats()
     assert osolve(C.byref(cfg), C.byref(w.struct()), C.byref(st)) == abi.VIO_EINVAL
+
+
+def test_reference_build_passes_ceres_own_unit_tests():
+    """oracle/_ref is a build of the vendored Ceres made here from the reference tree; where that tree exists, a few of
+    Ceres' OWN unit tests — the components the back-end restates (corrector, loss functions, dogleg strategy,
+    trust-region minimizer, Schur eliminator / complement solver, residual blocks, parameter-block ordering)
+    — are compiled where they lie and run against the very objects libvio_ref.so is linked from."""
+    import os
+    import subprocess
+    if not os.path.isdir("/root/reference") or not os.path.isdir(os.path.join(H.ROOT, "oracle", "_ref", "obj")):
+        pytest.skip("needs /root/reference and the object files of oracle/_ref")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(H.ROOT, "oracle"), "ref-selftest"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "PASSED" in r.stdout and "FAILED" not in r.stdout
+    n = int(r.stdout.split("PASSED  ]")[1].split("tests")[0])
+    assert n >= 39, r.stdout[-500:]
