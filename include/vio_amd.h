@@ -499,6 +499,11 @@ int vio_pnp_tracker_process_imu(vio_pnp_tracker_t *t, int32_t seq, double dt, co
 int vio_pnp_tracker_process_images(vio_pnp_tracker_t *t, const VioPnpFeature *features, const int32_t *n_features,
                                    int32_t stride, const double *headers, int32_t use_pnp, const uint8_t *active,
                                    double *P_out, double *R_out, int32_t *solved);
+/* feature_msg of solveVinsPnP (feature_tracker.cpp:121-134): solved landmarks (id, position, track_num; ascending id)
+ * joined by id with the tracker's current ids / pixel positions (vio_frontend_get_state); observation =
+ * ((x - PX) / fx, (y - PY) / fy).                                                                            */
+int vio_pnp_match_features(const VioConfig *cfg, const int32_t *ids, const float *forw_pts /* [n_pts][2] */, int32_t n_pts,
+                           const VioPnpFeature *solved, int32_t n_solved, VioPnpFeature *out, int32_t cap, int32_t *n_out);
 int vio_pnp_tracker_get_window(vio_pnp_tracker_t *t, int32_t seq, double *Ps, double *Rs, double *Vs, double *headers,
                                uint8_t *find_solved, int32_t *frame_count);
 

@@ -248,3 +248,25 @@ def test_pnp_tracker_follows_the_truth_between_backend_results():
     errs = np.array(errs)
     assert np.sqrt((errs ** 2).mean()) < 0.03 and errs.max() < 0.08, (np.sqrt((errs ** 2).mean()), errs.max())
     tr.close()
+
+
+def test_solved_features_are_joined_with_the_tracker_points_by_id():
+    cfg = abi.default_config()
+    lib = abi.load_product()
+    ids = np.array([3, 4, 7, 9, 12, 15, 20], np.int32)                 # tracker: ascending ids
+    pts = np.array([[10 * i + 0.25, 20 * i + 0.5] for i in range(7)], np.float32)
+    solved = (abi.VioPnpFeature * 5)()
+    for k, (fid, tn) in enumerate([(1, 5), (4, 6), (9, 7), (13, 8), (20, 9)]):   # back-end: ascending ids, some lost by the tracker
+        solved[k].id, solved[k].track_num = fid, tn
+        solved[k].position[:] = [fid * 1.0, fid * 2.0, fid * 3.0]
+    out, n = (abi.VioPnpFeature * 8)(), C.c_int32()
+    rc = lib.vio_pnp_match_features(C.byref(cfg), ids.ctypes.data_as(C.POINTER(C.c_int32)), pts.ctypes.data_as(C.POINTER(C.c_float)), 7,
+                                    solved, 5, out, 8, C.byref(n))
+    assert rc == 0 and n.value == 3
+    assert [out[i].id for i in range(3)] == [4, 9, 20] and [out[i].track_num for i in range(3)] == [6, 7, 9]
+    for o, row in zip(out[:3], (1, 3, 6)):
+        assert abs(o.observation[0] - (float(pts[row, 0]) - cfg.cx) / cfg.fx) < 1e-15
+        assert abs(o.observation[1] - (float(pts[row, 1]) - cfg.cy) / cfg.fy) < 1e-15
+        assert list(o.position) == [o.id * 1.0, o.id * 2.0, o.id * 3.0]
+    assert lib.vio_pnp_match_features(C.byref(cfg), ids.ctypes.data_as(C.POINTER(C.c_int32)), pts.ctypes.data_as(C.POINTER(C.c_float)), 7,
+                                      solved, 5, out, 2, C.byref(n)) == abi.VIO_ECAP

@@ -501,6 +501,8 @@ def load_product():
     lib.vio_pnp_tracker_set_init.argtypes = [vp, C.c_int32, C.POINTER(VioVinsResult)]
     lib.vio_pnp_tracker_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
     lib.vio_pnp_tracker_process_images.argtypes = [vp, C.POINTER(VioPnpFeature), _ip, C.c_int32, _dp, C.c_int32, u8p, _dp, _dp, _ip]
+    lib.vio_pnp_match_features.argtypes = [cfgp, _ip, fp, C.c_int32, C.POINTER(VioPnpFeature), C.c_int32, C.POINTER(VioPnpFeature),
+                                           C.c_int32, _ip]
     lib.vio_pnp_tracker_get_window.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, u8p, _ip]
     lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _dp, _ip, _ip]
     lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]

@@ -268,6 +268,29 @@ int vio_pnp_tracker_process_images(vio_pnp_tracker_t *t, const VioPnpFeature *fe
   return VIO_OK;
 }
 
+// The join at the top of solveVinsPnP (feature_tracker.cpp:121-134): the landmarks the back-end has solved (ascending id)
+// against the tracker's current ids / points (ascending id too: ids grow with n_id and the vectors are only ever
+// compacted); a match takes the back-end's position and track count and the tracker's current normalized observation.
+int vio_pnp_match_features(const VioConfig *cfg, const int32_t *ids, const float *forw_pts, int32_t n_pts,
+                           const VioPnpFeature *solved, int32_t n_solved, VioPnpFeature *out, int32_t cap, int32_t *n_out) {
+  if (!cfg || !n_out || n_pts < 0 || n_solved < 0 || (n_pts > 0 && (!ids || !forw_pts)) || (n_solved > 0 && !solved) ||
+      (cap > 0 && !out))
+    return VIO_EINVAL;
+  int i = 0, m = 0;
+  for (int k = 0; k < n_solved; k++) {
+    while (i < n_pts && ids[i] < solved[k].id) i++;  // (the reference walks ids[] without the bound)
+    if (i < n_pts && ids[i] == solved[k].id) {
+      if (m >= cap) return VIO_ECAP;
+      out[m] = solved[k];
+      out[m].observation[0] = ((double)forw_pts[2 * i] - cfg->cx) / cfg->fx;
+      out[m].observation[1] = ((double)forw_pts[2 * i + 1] - cfg->cy) / cfg->fy;
+      m++;
+    }
+  }
+  *n_out = m;
+  return VIO_OK;
+}
+
 int vio_pnp_tracker_get_window(vio_pnp_tracker_t *t, int32_t seq, double *Ps, double *Rs, double *Vs, double *headers,
                                uint8_t *find_solved, int32_t *frame_count) {
   if (!t || seq < 0 || seq >= t->n_seq) return VIO_EINVAL;
