@@ -682,6 +682,10 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     if (active && !active[q]) return;
     Sequence &s = e->seq[q];
     int enough = 0, parallax_num = 0;
+    if (n_obs[q] < 0 || (obs_stride > 0 && n_obs[q] > obs_stride)) {
+      res.action = VIO_FRAME_ERROR, res.error = VIO_EINVAL;
+      return;
+    }
     int rc = vio_features_add_check_parallax(s.fm, s.frame_count, obs + (size_t)q * obs_stride, n_obs[q], &enough,
                                              &parallax_num, &s.last_track_num);
     if (rc != VIO_OK) {
