@@ -142,6 +142,24 @@ def test_poisoned_device_buffers():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_one_batch_split_over_both_kernel_variants(solver_cache):
+    """Windows that fit the CU's LDS and windows that do not (260 landmarks, a relocalization pose) in ONE batch: the
+    launch is split by variant, every window still matches the CPU oracle solved alone."""
+    cfg = abi.default_config()
+    osolve, opre = H.oracle_backend()
+    pre = lambda *a: abi.preintegrate_with(opre, cfg, *a)
+    shapes = [(150, 0), (260, 0), (40, 0), (150, 12), (200, 0), (255, 8), (7, 0), (236, 0)]
+    ws = [synth.make_window(cfg, pre, seed=700 + i, n_features=F, W=10, with_loop=loop) for i, (F, loop) in enumerate(shapes)]
+    solver = get_solver(solver_cache, cfg)
+    got = [w.copy() for w in ws]
+    stats = solver.solve(got)
+    for w, g, s in zip(ws, got, stats):
+        ref, rs = H.solve_with(osolve, cfg, w)
+        assert s["iterations"] == rs["iterations"] and list(s["it_flags"]) == list(rs["it_flags"])
+        assert H.pose_relerr(g.pose, ref.pose) < TOL and H.relerr(g.inv_depth, ref.inv_depth) < TOL
+        assert g.next_prior.n == ref.next_prior.n
+
+
 @pytest.mark.parametrize("W,F,loop,seed", H.ODD_SHAPES)
 def test_odd_shapes_match_oracle(W, F, loop, seed):
     """Awkward window sizes (1..260 landmarks, W = 3..13, loop pose) through the device kernel against the CPU oracle; the

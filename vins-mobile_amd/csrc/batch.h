@@ -98,6 +98,7 @@ struct BatchPtrs {
   const double *pr_x0, *pr_J, *pr_r;
   double *scratch;   // [n][s.scratch]
   double *hm;        // [n][s.hm] (only used when the matrix does not fit LDS)
+  const int *order;  // launch-local block index -> window (null: identity); a batch may be split into two launches
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop, *stats_d;
   int *stats_i;
 };

@@ -39,7 +39,7 @@ struct MargPtrs {
 template <bool LDS_MATRIX>
 __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = blockIdx.x;
+  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
   WinView v = make_view(B, b);
   typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
   ldsd lds = (ldsd)smem;
@@ -123,7 +123,14 @@ struct vio_backend {
   int n = 0;
   bool uploaded = false;
   hipStream_t last_stream = nullptr;  // where the last launch went: what sync / download wait for
-  bool lds_matrix = true;
+  bool lds_matrix = true;  // every window of the batch runs the LDS variant
+  // a batch is split by variant: windows whose matrix and vectors fit the CU's LDS, and the rest (relocalization pose,
+  // very many landmarks) with the matrix in global scratch
+  int n_lds = 0, n_glb = 0;
+  BatchDims d_lds, d_glb;
+  size_t lds_bytes_glb = 0;
+  DevBuf<int> d_order;
+  HostVec<int> h_order;
   bool profile = false;
   size_t lds_bytes = 0;
   DevBuf<long long> d_prof;
@@ -244,19 +251,49 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   }
   const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
-  // LDS or global matrix: both phases must fit the CU's 160 KB
-  size_t state_end = 0;
-  size_t bytes_solver = carve_work<ldsd>(d, true, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-  size_t bytes_marg = state_end * sizeof(double) + carve_marg<ldsd>(d, true, nullptr, nullptr, nullptr, 0);
-  // the marginalization phase additionally wants >= 64 staging slots behind its dense matrix
-  be->lds_matrix = std::max(bytes_solver, bytes_marg + 64 * kMargSlot * sizeof(double)) <= kLdsLimit;
-  if (!be->lds_matrix) {
-    bytes_solver = carve_work<double *>(d, false, kThreads, nullptr, nullptr, nullptr, nullptr, &state_end);
-    bytes_marg = state_end * sizeof(double) + carve_marg<double *>(d, false, nullptr, nullptr, nullptr, 0);
-    if (std::max(bytes_solver, bytes_marg) > kLdsLimit) return VIO_ECAP;
+  // LDS or global matrix, per window: both phases must fit the CU's 160 KB. Windows without a relocalization pose are
+  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum, no loop block row)
+  // fits runs the LDS variant in one launch, everything else the global-matrix variant in a second one.
+  auto fits_lds = [&](const BatchDims &dd) {
+    size_t se = 0;
+    const size_t bs = carve_work<ldsd>(dd, true, kThreads, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
+    // the marginalization phase additionally wants >= 64 staging slots behind its dense matrix
+    return std::max(bs, bm + 64 * kMargSlot * sizeof(double)) <= kLdsLimit;
+  };
+  std::vector<int> cand, order;
+  for (int b = 0; b < n; b++)
+    if (!be->hb.hdr[(size_t)b * kHdrInts + H_HAS_LOOP]) cand.push_back(b);
+  std::sort(cand.begin(), cand.end(), [&](int a, int b2) {
+    return be->hb.hdr[(size_t)a * kHdrInts + H_F] < be->hb.hdr[(size_t)b2 * kHdrInts + H_F];
+  });
+  BatchDims dl = d;
+  dl.nblk_cap = dl.Pcap;
+  int n_lds = (int)cand.size();
+  while (n_lds > 0) {
+    dl.Flds = std::max(1, be->hb.hdr[(size_t)cand[n_lds - 1] * kHdrInts + H_F]);
+    if (fits_lds(dl)) break;
+    n_lds--;
   }
-  // the marginalization phase stages Jacobian rows in whatever LDS is left: give the launch the whole CU budget
-  be->lds_bytes = be->lds_matrix ? kLdsLimit : std::max(bytes_solver, bytes_marg);
+  std::vector<char> in_lds(n, 0);
+  for (int i = 0; i < n_lds; i++) in_lds[cand[i]] = 1, order.push_back(cand[i]);
+  for (int b = 0; b < n; b++)
+    if (!in_lds[b]) order.push_back(b);
+  be->n_lds = n_lds, be->n_glb = n - n_lds, be->d_lds = dl, be->lds_matrix = be->n_glb == 0;
+  be->lds_bytes = kLdsLimit;  // the marginalization phase stages Jacobian rows in whatever LDS is left: whole CU budget
+  if (be->n_glb > 0) {
+    BatchDims dg = d;
+    int fg = 1;
+    for (int i = n_lds; i < n; i++) fg = std::max(fg, be->hb.hdr[(size_t)order[i] * kHdrInts + H_F]);
+    dg.Flds = fg;
+    size_t se = 0;
+    const size_t bs = carve_work<double *>(dg, false, kThreads, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
+    if (std::max(bs, bm) > kLdsLimit) return VIO_ECAP;
+    be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bm);
+  }
+  if (be->d_order.ensure(n) != VIO_OK) return VIO_ENOMEM;
+  be->h_order.assign(order.begin(), order.end());  // page-locked: goes up with the other staging copies below
 
   const size_t N = (size_t)n;
   const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
@@ -290,7 +327,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   ENSURE(be->d_pr_J, N * s.pr_J);
   ENSURE(be->d_pr_r, N * s.pr_r);
   ENSURE(be->d_scratch, N * s.scratch);
-  ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);
+  ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);  // (indexed by window: sized for the whole batch when any window needs it)
   ENSURE(be->d_out_pose, N * s.out_pose);
   ENSURE(be->d_out_sb, N * s.out_sb);
   ENSURE(be->d_out_feat, N * s.out_feat);
@@ -308,6 +345,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
 #undef ENSURE
   hipStream_t st = be->stream;
 #define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
+  H2D(be->d_order, be->h_order);
   H2D(be->d_hdr, be->hb.hdr);
   H2D(be->d_hdr_d, be->hb.hdr_d);
   H2D(be->d_pose, be->hb.pose);
@@ -346,7 +384,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   B.pts_i = be->d_pts_i.p, B.pts_j = be->d_pts_j.p, B.preint = be->d_preint.p;
   B.pr_kind = be->d_pr_kind.p, B.pr_index = be->d_pr_index.p, B.pr_offset = be->d_pr_offset.p;
   B.pr_x0 = be->d_pr_x0.p, B.pr_J = be->d_pr_J.p, B.pr_r = be->d_pr_r.p;
-  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p;
+  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
   B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
   B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
@@ -392,16 +430,21 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), kLdsLimit, st, (int)(kLdsLimit / sizeof(double)));
   }
   HIP_OK(hipEventRecord(ev.first, st));
-  if (be->lds_matrix) {
+  if (be->n_lds > 0) {
+    BatchPtrs Bl = be->B;
+    Bl.d = be->d_lds, Bl.order = be->d_order.p;
     HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)be->lds_bytes));
-    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP,
+    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n_lds), dim3(kThreads), be->lds_bytes, st, Bl, be->MP,
                        (int)(be->lds_bytes / sizeof(double)));
-  } else {
+  }
+  if (be->n_glb > 0) {
+    BatchPtrs Bg = be->B;
+    Bg.d = be->d_glb, Bg.order = be->d_order.p + be->n_lds;
     HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)be->lds_bytes));
-    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n), dim3(kThreads), be->lds_bytes, st, be->B, be->MP,
-                       (int)(be->lds_bytes / sizeof(double)));
+                               (int)be->lds_bytes_glb));
+    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n_glb), dim3(kThreads), be->lds_bytes_glb, st, Bg, be->MP,
+                       (int)(be->lds_bytes_glb / sizeof(double)));
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ev.second, st));
