@@ -183,3 +183,19 @@ def test_measurement_association_follows_getMeasurements():
         assert np.allclose(g[1], w[1], atol=0, rtol=0)
     assert got[0][1][0] == 0.0                                       # very first sample: dt = 0
     q.close()
+
+
+def test_file_readers_survive_mutated_input_under_sanitizers(tmp_path):
+    """tests/fuzz/fuzz_replay.cpp: 100k mutated PNGs (CRCs repaired so that the decoder body is reached) and garbage IMU
+    files through the readers compiled with AddressSanitizer + UndefinedBehaviorSanitizer."""
+    import subprocess
+    import helpers as H
+    exe = str(tmp_path / "fuzz_replay")
+    src = [os.path.join(H.ROOT, "tests", "fuzz", "fuzz_replay.cpp"), os.path.join(H.ROOT, "vins-mobile_amd", "csrc", "vio_replay.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I" + os.path.join(H.ROOT, "include")] + src + ["-lz", "-o", exe])
+    r = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "fuzz done" in r.stdout and "imu fuzz done" in r.stdout
+    decoded = int(r.stdout.split("fuzz done:")[1].split("decoded")[0])
+    assert decoded > 1000          # the mutations are not all rejected at the door
