@@ -373,6 +373,7 @@ bool solve_initial(vio_estimator *e, Sequence &s) {
     for (int j = 0; j < nfe; j++) {
       first[j] = off;
       sfm_f[j].id = info[j].id;
+      if (info[j].start_frame < 0 || info[j].start_frame + info[j].n_obs > P) return false;  // not a window's store
       for (int k = 0; k < info[j].n_obs; k++)
         sfm_f[j].observation.push_back({info[j].start_frame + k, {pts[3 * (off + k)], pts[3 * (off + k) + 1]}});
       off += info[j].n_obs;
@@ -772,10 +773,24 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   if (n > 0) {
     if (!e->be) {
       int rc = vio_backend_create(&e->cfg, e->n_seq, &e->be);
-      if (rc != VIO_OK) return rc;
+      if (rc != VIO_OK) {
+        for (int k = 0; k < n; k++) {
+          clear_state(e, e->seq[e->solving[k]]);
+          results[e->solving[k]].action = VIO_FRAME_ERROR, results[e->solving[k]].error = rc;
+        }
+        return rc;
+      }
     }
     int rc = vio_backend_solve_windows(e->be, e->windows.data(), n, 0, e->stats.data());
-    if (rc != VIO_OK) return rc;
+    if (rc != VIO_OK) {
+      // the frame is in the landmark stores but the windows did not slide: restart those sequences rather than carry an
+      // inconsistent window into the next call
+      for (int k = 0; k < n; k++) {
+        clear_state(e, e->seq[e->solving[k]]);
+        results[e->solving[k]].action = VIO_FRAME_ERROR, results[e->solving[k]].error = rc;
+      }
+      return rc;
+    }
   }
   const auto t_solve = std::chrono::steady_clock::now();
   // phase C, per solved sequence: double2vector, loop bookkeeping, failure detection, slide
