@@ -275,3 +275,23 @@ def test_failure_detection_thresholds():
     for deg, want in ((39.0, 0), (39.97, 0), (39.99, 16), (41.0, 16), (170.0, 16)):   # 40 "degrees" with pi = 3.14 is 39.98 true degrees
         assert fd(50, z, z, rot(np.radians(deg), 0, 0), z, I) == want, deg
     assert fd(50, z, z, rot(0, 0, np.radians(179.0)), z, rot(0.3, 0.1, 0)) == 16  # trace <= 0 branch of the conversion
+
+
+def test_call_order_errors_are_refused_before_anything_changes():
+    """A frame index outside the window, or a second message for a frame a landmark already has, would push
+    start_frame + observation indices past the window (every other call indexes Ps / Rs with them)."""
+    fm = pkg.window.FeatureManager(W)
+    ids = list(range(30))
+    xyz = [[0.01 * i, 0.02 * i, 1.0] for i in range(30)]
+    fm.add_check_parallax(0, ids, xyz)
+    fm.add_check_parallax(1, ids, xyz)
+    before = fm.dump()
+    with pytest.raises(RuntimeError):
+        fm.add_check_parallax(1, ids[:5], xyz[:5])        # frame 1 again
+    with pytest.raises(RuntimeError):
+        fm.add_check_parallax(W + 1, ids, xyz)            # beyond the window
+    after = fm.dump()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    fm.add_check_parallax(2, ids, xyz)                     # the regular next frame still goes in
+    assert fm.dump()[0][0, 2] == 3
+    fm.close()

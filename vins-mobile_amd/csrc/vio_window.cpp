@@ -115,6 +115,16 @@ int vio_features_add_check_parallax(vio_features_t *fm, int32_t frame_count, con
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return obs[a].id < obs[b].id; });
   for (int i = 1; i < n_obs; i++)
     if (obs[order[i]].id == obs[order[i - 1]].id) return VIO_EINVAL;  // a map has unique keys
+  // every index the other calls derive from a landmark (start_frame + observation number) must stay inside the window:
+  // a frame index outside [0, W] or a second message for a frame a landmark already has is a call-order error
+  if (frame_count < 0 || frame_count > fm->window_size) return VIO_EINVAL;
+  {
+    std::vector<int> ids(n_obs);
+    for (int i = 0; i < n_obs; i++) ids[i] = obs[order[i]].id;  // ascending
+    for (const Feature &x : fm->feature)
+      if (x.start_frame + (int)x.obs.size() > frame_count && std::binary_search(ids.begin(), ids.end(), x.feature_id))
+        return VIO_ESTATE;
+  }
   double parallax_sum = 0;
   int pnum = 0;
   fm->last_track_num = 0;
