@@ -19,3 +19,21 @@ def test_host_code_walk_is_clean_under_asan_ubsan(tmp_path):
     assert "host_sanity: done" in r.stdout and "sfm ok 1" in r.stdout
     reached = int(r.stdout.split("estimator walked,")[1].split("frames")[0])
     assert reached >= 1            # solveInitial ran to the end at least once (the solve itself is stubbed)
+
+
+def test_kernel_sources_are_clean_under_asan_ubsan(tmp_path):
+    """solver_core.h / marg_core.h / pnp_core.h compiled for the host (-DVIO_EMUL) WITH sanitizers and run over 26 + 7
+    windows (tests/fuzz/run_emul_sanitized.py): index arithmetic of the kernel source against the packed batch arrays."""
+    import sys
+    csrc = os.path.join(H.ROOT, "vins-mobile_amd", "csrc")
+    flags = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DVIO_EMUL", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=undefined", "-I" + os.path.join(H.ROOT, "include"), "-I" + csrc, "-shared"]
+    so_b, so_p = str(tmp_path / "emul_b.so"), str(tmp_path / "emul_p.so")
+    subprocess.check_call(flags + ["-o", so_b, os.path.join(H.ROOT, "tests", "emul", "emul_backend.cpp")])
+    subprocess.check_call(flags + ["-o", so_p, os.path.join(H.ROOT, "tests", "emul", "emul_pnp.cpp")])
+    pre = ":".join(subprocess.check_output(["g++", "-print-file-name=" + n], text=True).strip() for n in ("libasan.so", "libubsan.so"))
+    env = dict(os.environ, LD_PRELOAD=pre, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tests", "fuzz", "run_emul_sanitized.py"), so_b, so_p], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    assert "26 windows clean" in r.stdout and "7 windows clean" in r.stdout
