@@ -64,7 +64,8 @@ struct Scene {  // camera looking along +z of the body (ric = I), moving mostly 
     }                                                            \
   } while (0)
 
-int main() {
+int main(int argc, char **argv) {
+  const int NS = argc > 1 ? atoi(argv[1]) : 3;  // sequences in the estimator (>= 32 engages the host thread pool)
   VioConfig cfg;
   vio_config_default(&cfg);
   cfg.window_size = 6;
@@ -73,22 +74,25 @@ int main() {
   Scene sc;
   // ---- estimator: three sequences at different phases, own initialisation switched on for sequence 0's sake
   vio_estimator_t *est = nullptr;
-  REQUIRE(vio_estimator_create(&cfg, 3, tic, ric, &est) == VIO_OK);
+  REQUIRE(NS >= 3 && vio_estimator_create(&cfg, NS, tic, ric, &est) == VIO_OK);
   REQUIRE(vio_estimator_enable_initialization(est, 1) == VIO_OK);
-  std::vector<VioObs> obs(3 * 160);
-  std::vector<VioFrameResult> res(3);
+  std::vector<VioObs> obs((size_t)NS * 160);
+  std::vector<VioFrameResult> res(NS);
   int solve_attempts = 0;
   for (int k = 0; k < 40; k++) {
     const double t = 0.1 * k;
-    int32_t n_imu[3] = {10, 10, k % 2 ? 10 : 0};
-    std::vector<double> dt(3 * 10, 0.01), acc(3 * 30), gyr(3 * 30);
+    std::vector<int32_t> n_imu(NS);
+    for (int q = 0; q < NS; q++) n_imu[q] = q % 3 == 2 ? (k % 2 ? 10 : 0) : 10;
+    std::vector<double> dt((size_t)NS * 10, 0.01), acc((size_t)NS * 30), gyr((size_t)NS * 30);
     for (size_t i = 0; i < acc.size(); i++) acc[i] = (i % 3 == 2 ? 9.8 : 0.0) + 0.05 * nrand(), gyr[i] = 0.01 * nrand();
-    REQUIRE(vio_estimator_process_imu_batch(est, n_imu, 10, dt.data(), acc.data(), gyr.data()) == VIO_OK);
-    int32_t n_obs[3];
-    double hdr[3] = {t, t + 100, t + 200};
-    uint8_t active[3] = {1, (uint8_t)(k >= 5), (uint8_t)(k % 3 != 1)};
-    for (int q = 0; q < 3; q++) {
-      std::vector<VioObs> o = sc.observe(t + 0.03 * q, q == 2 && k > 20 ? 10 : 150);  // sequence 2 starves -> RESET branch
+    REQUIRE(vio_estimator_process_imu_batch(est, n_imu.data(), 10, dt.data(), acc.data(), gyr.data()) == VIO_OK);
+    std::vector<int32_t> n_obs(NS);
+    std::vector<double> hdr(NS);
+    std::vector<uint8_t> active(NS);
+    for (int q = 0; q < NS; q++) {
+      hdr[q] = t + 100 * (q % 3);
+      active[q] = q % 3 == 0 ? 1 : (q % 3 == 1 ? (uint8_t)(k >= 5) : (uint8_t)(k % 3 != 1));
+      std::vector<VioObs> o = sc.observe(t + 0.03 * (q % 3), q % 3 == 2 && k > 20 ? 10 : 150);  // every third sequence starves -> RESET branch
       n_obs[q] = (int32_t)o.size();
       memcpy(&obs[160 * q], o.data(), sizeof(VioObs) * o.size());
     }
@@ -99,7 +103,7 @@ int main() {
       REQUIRE(vio_estimator_get_window(est, 1, nullptr, nullptr, nullptr, nullptr, nullptr, headers) == VIO_OK);
       REQUIRE(vio_estimator_set_relocalization(est, 1, headers[2], P_old, Q_old, ids, xy, 4) == VIO_OK);
     }
-    const int rc = vio_estimator_process_images(est, obs.data(), n_obs, 160, hdr, active, res.data());
+    const int rc = vio_estimator_process_images(est, obs.data(), n_obs.data(), 160, hdr.data(), active.data(), res.data());
     if (rc == VIO_ENODEV) solve_attempts++;  // solveInitial went through and wanted the device: stubbed here
     else REQUIRE(rc == VIO_OK || rc == VIO_ESTATE);  // (sequence 2 is fed IMU irregularly: a window without an interval)
     VioEstimatorStatus stt;

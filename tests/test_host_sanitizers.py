@@ -7,18 +7,26 @@ import subprocess
 import helpers as H
 
 
-def test_host_code_walk_is_clean_under_asan_ubsan(tmp_path):
+def test_host_code_walk_is_clean_under_asan_ubsan_and_tsan(tmp_path):
     csrc = os.path.join(H.ROOT, "vins-mobile_amd", "csrc")
     exe = str(tmp_path / "host_sanity")
     src = [os.path.join(H.ROOT, "tests", "fuzz", "host_sanity.cpp")] + [os.path.join(csrc, f + ".cpp") for f in (
         "vio_window", "vio_initial", "vio_host", "vio_estimator", "vio_pnp_tracker", "vio_replay")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-I" + os.path.join(H.ROOT, "include"), "-I" + csrc] + src + ["-lz", "-lpthread", "-o", exe])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
-    assert "host_sanity: done" in r.stdout and "sfm ok 1" in r.stdout
-    reached = int(r.stdout.split("estimator walked,")[1].split("frames")[0])
-    assert reached >= 1            # solveInitial ran to the end at least once (the solve itself is stubbed)
+    for n_seq in ("3", "48"):      # 48 sequences engage the host thread pool
+        r = subprocess.run([exe, n_seq], capture_output=True, text=True, timeout=600, env=dict(os.environ, VIO_AMD_HOST_THREADS="8"))
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+        assert "host_sanity: done" in r.stdout and "sfm ok 1" in r.stdout
+        reached = int(r.stdout.split("estimator walked,")[1].split("frames")[0])
+        assert reached >= 1            # solveInitial ran to the end at least once (the solve itself is stubbed)
+    # the same walk under ThreadSanitizer: the per-sequence phases run on the pool's worker threads
+    tsan = str(tmp_path / "host_sanity_tsan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + os.path.join(H.ROOT, "include"), "-I" + csrc] + src +
+                          ["-lz", "-lpthread", "-o", tsan])
+    r = subprocess.run([tsan, "48"], capture_output=True, text=True, timeout=900, env=dict(os.environ, VIO_AMD_HOST_THREADS="8"))
+    assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout[-1000:] + r.stderr[-4000:]
+    assert "host_sanity: done" in r.stdout
 
 
 def test_kernel_sources_are_clean_under_asan_ubsan(tmp_path):
