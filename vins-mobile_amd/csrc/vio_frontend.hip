@@ -122,25 +122,6 @@ __device__ __forceinline__ double wave_sum_exact(int p) {
   return (double)shi * 65536.0 + (double)slo;
 }
 
-__device__ __forceinline__ void scharr_at(const uint8_t *im, int rows, int cols, int y, int x, int &dx, int &dy) {
-  if (x < 0 || x >= cols || y < 0 || y >= rows) {
-    dx = dy = 0;
-    return;
-  }
-  int ym = reflect101(y - 1, rows), yp = reflect101(y + 1, rows), xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
-  const uint8_t *r0 = im + (size_t)ym * cols, *r1 = im + (size_t)y * cols, *r2 = im + (size_t)yp * cols;
-  int p00 = r0[xm], p01 = r0[x], p02 = r0[xp], p10 = r1[xm], p12 = r1[xp], p20 = r2[xm], p21 = r2[x], p22 = r2[xp];
-  dx = 3 * (p02 - p00) + 10 * (p12 - p10) + 3 * (p22 - p20);
-  dy = 3 * (p20 - p00) + 10 * (p21 - p01) + 3 * (p22 - p02);
-}
-
-__device__ __forceinline__ int bilin_u8(const uint8_t *im, int rows, int cols, int Y, int X, int iw00, int iw01, int iw10,
-                                        int iw11) {
-  int y0 = reflect101(Y, rows), y1 = reflect101(Y + 1, rows), x0 = reflect101(X, cols), x1 = reflect101(X + 1, cols);
-  const uint8_t *r0 = im + (size_t)y0 * cols, *r1 = im + (size_t)y1 * cols;
-  return descale(r0[x0] * iw00 + r0[x1] * iw01 + r1[x0] * iw10 + r1[x1] * iw11, kWBits - 5);
-}
-
 __device__ __forceinline__ void lk_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11) {
   iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << kWBits));
   iw01 = __float2int_rn(a * (1.f - b) * (1 << kWBits));
@@ -1330,7 +1311,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
     ld.rows[l] = r, ld.cols[l] = c, ld.off[l] = off, off += (size_t)r * c, ld.levels = l + 1;
   }
   ld.pyr_bytes = (off + 255) & ~(size_t)255;
-  const size_t S = n_seq, px = (size_t)cfg->image_rows * cfg->image_cols, cap = fe->cap;
+  const size_t S = n_seq, cap = fe->cap;
   fe->nseg = (cfg->image_rows + kDetR - 1) / kDetR;
   fe->seg_cap = kDetR * cfg->image_cols / 4;  // a 3x3 local maximum can occupy at most one pixel in four
   int rc = VIO_OK;
