@@ -145,6 +145,7 @@ def test_resident_stepping_equals_read_images():
     (250, 333, 60, 12, 5),     # neither a multiple of the 32-row strips nor of the 60-column waves of detect_kernel
     (97, 61, 20, 8, 4),        # one partial strip row, one partial wave; 2 pyramid levels
     (720, 1280, 300, 30, 3),   # BASELINE configs[2] frame geometry and feature count
+    (1080, 1920, 500, 30, 3),  # BASELINE configs[4] frame geometry and feature count (close to the 512-feature capacity)
 ])
 def test_tracker_sequence_other_geometries(rows, cols, corners, min_dist, T):
     """Tracker state and published observations stay bit-identical to the oracle on frame sizes that leave partial
