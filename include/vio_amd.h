@@ -146,6 +146,15 @@ typedef struct VioWindow {
   double *raw_inv_depth;  /* [n_features] or NULL */
   VioPrior *next_prior;   /* caller-allocated buffers sized for
                              vio_prior_capacity(W); NULL to skip               */
+  /* Device-resident prior chain (vio_backend_reserve_priors). 0: the prior
+   * travels through host memory as described above. k >= 1: slot k-1 of the
+   * back-end's prior store. Then (a) a `prior` whose three data pointers are
+   * NULL names the prior the slot holds (n, n_blocks and the block_* arrays
+   * still come from the struct); a `prior` with data pointers is uploaded as
+   * usual; (b) the next prior is written into the slot instead of host
+   * memory: `next_prior` receives n, n_blocks and the block_* arrays only
+   * (its data pointers may be NULL), and the slot is advanced when n > 0.   */
+  int32_t resident_prior;
 } VioWindow;
 
 #define VIO_MAX_TRACE 64
@@ -190,6 +199,16 @@ int vio_preintegrate(const VioConfig *cfg, const double acc_0[3], const double g
  * results are deterministic).                                                */
 int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n,
                               int32_t buf_num, VioSolveStats *stats /* [n] or NULL */);
+
+/* Device-resident prior chain. The prior a window leaves behind (the output of
+ * marginalize(), VINS.cpp:697-831) is the next window's
+ * last_marginalization_info (VINS.cpp:523-528): a caller that chains windows
+ * frame after frame only needs its header on the host. This reserves
+ * `n_slots` slots of two banks each in device memory (2 x ~46 KB per slot at
+ * W=10); VioWindow.resident_prior selects a slot, see there. Reserving again
+ * forgets what the slots held. One slot belongs to one chain: two windows of
+ * one batch must not name the same slot (VIO_EINVAL).                        */
+int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots);
 
 /* Resident-batch API for throughput runs: pack + upload once, launch many
  * times from the same initial state, download when wanted. `stream` is a

@@ -36,7 +36,7 @@ extern "C" int emul_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
       m_r(hb.d.Ncap);
   std::vector<int> m_int(4 + 3 * kMaxPriorBlocks);
   BatchPtrs B;
-  B.n = 1, B.d = hb.d, B.s = s, B.order = nullptr;
+  B.n = 1, B.d = hb.d, B.s = s, B.order = nullptr, B.ptab = nullptr;
   B.hdr = hb.hdr.data(), B.hdr_d = hb.hdr_d.data();
   B.pose = hb.pose.data(), B.sb = hb.sb.data(), B.ex = hb.ex.data(), B.feat = hb.feat.data();
   B.fhost = hb.fhost.data(), B.ftarget = hb.ftarget.data(), B.ffeat = hb.ffeat.data();

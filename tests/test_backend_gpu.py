@@ -98,6 +98,48 @@ def test_prior_chain_on_device(solver_cache):
         prior_g, prior_o = wg.next_prior.copy(), ref.next_prior.copy()
 
 
+def test_prior_chain_resident_in_device_memory():
+    """vio_backend_reserve_priors: a chain whose priors never leave the device gives what the chain through host memory
+    gives. One batch carries both kinds; a SECOND_NEW step that leaves the prior alone (n = -1) keeps the slot."""
+    cfg = abi.default_config()
+    pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
+    solver = pkg.backend.WindowSolver(cfg, max_batch=4)
+    solver.reserve_priors(3)
+    flags = [abi.VIO_MARGIN_OLD, abi.VIO_MARGIN_OLD, abi.VIO_MARGIN_SECOND_NEW, abi.VIO_MARGIN_OLD, abi.VIO_MARGIN_OLD]
+    prior_h = prior_r = None
+    for k, flag in enumerate(flags):
+        w = synth.make_window(cfg, pre, seed=700 + k, traj_seed=78, frame_offset=k)
+        w.marginalization_flag = flag
+        wh, wr = w.copy(), w.copy()
+        wh.prior, wr.prior = prior_h, prior_r
+        wr.resident_prior = 2 + 1  # slot 2
+        stats = solver.solve([wh, wr])
+        assert stats[0]["iterations"] == stats[1]["iterations"]
+        assert np.abs(wh.pose - wr.pose).max() < 1e-9 and np.abs(wh.inv_depth - wr.inv_depth).max() < 1e-9
+        nh, nr = wh.next_prior.c, wr.next_prior.c
+        assert nh.n == nr.n and nh.n_blocks == nr.n_blocks
+        assert list(nh.block_index[: nh.n_blocks]) == list(nr.block_index[: nr.n_blocks])
+        assert list(nh.block_offset[: nh.n_blocks]) == list(nr.block_offset[: nr.n_blocks])
+        if flag == abi.VIO_MARGIN_SECOND_NEW and nh.n < 0:
+            continue  # both chains keep their prior
+        assert nh.n > 0
+        assert not wr.next_prior.J.any()  # the data stayed on the device
+        prior_h, prior_r = wh.next_prior.copy(), wr.next_prior.header_only()
+    # errors: a slot out of range, a slot named twice, a header-only prior without a slot
+    w = synth.make_window(cfg, pre, seed=1, traj_seed=78)
+    a, b = w.copy(), w.copy()
+    a.resident_prior = 4
+    with pytest.raises(RuntimeError):
+        solver.solve([a])
+    a.resident_prior = b.resident_prior = 1
+    with pytest.raises(RuntimeError):
+        solver.solve([a, b])
+    a.resident_prior, a.prior = 0, prior_r
+    with pytest.raises(RuntimeError):
+        solver.solve([a])
+    solver.close()
+
+
 def test_determinism_and_resident_api(solver_cache):
     cfg, w, d = H.load_golden_window("win_c2_easy")
     solver = get_solver(solver_cache, cfg)

@@ -135,7 +135,11 @@ def test_argument_errors():
 
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-def test_estimator_matches_the_python_loop_with_the_oracle_solver():
+@pytest.mark.parametrize("host_priors", [False, True])
+def test_estimator_matches_the_python_loop_with_the_oracle_solver(host_priors, monkeypatch):
+    """host_priors False: the marginalization priors stay in the back-end's device store from frame to frame (the
+    default); True: VIO_AMD_HOST_PRIORS=1, they travel through host memory. The oracle loop always carries its own."""
+    monkeypatch.setenv("VIO_AMD_HOST_PRIORS", "1" if host_priors else "0")
     cfg = abi.default_config()
     prod = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
     ref = oracle_loop(cfg, seed=5)

@@ -91,6 +91,7 @@ class VioWindow(C.Structure):
         ("origin_p", C.c_double * 3),
         ("raw_pose", _dp), ("raw_speed_bias", _dp), ("raw_inv_depth", _dp),
         ("next_prior", C.POINTER(VioPrior)),
+        ("resident_prior", C.c_int32),
     ]
 
 
@@ -238,6 +239,12 @@ class Prior:
             p.c.block_offset[b] = self.c.block_offset[b]
         return p
 
+    def header_only(self):
+        """A copy whose data pointers are NULL: names the prior a device-resident slot holds (vio_amd.h)."""
+        p = self.copy()
+        p.c.block_x0 = p.c.linearized_jacobians = p.c.linearized_residuals = _dp()
+        return p
+
     def to_npz_dict(self, prefix):
         n, nb = self.c.n, self.c.n_blocks
         return {
@@ -289,6 +296,7 @@ class Window:
         self.use_origin_override = 0
         self.origin_yaw_deg = 0.0
         self.origin_p = np.zeros(3)
+        self.resident_prior = 0  # k >= 1: slot k-1 of the back-end's device-resident prior store
         self.raw_pose = np.zeros((P, 7))
         self.raw_speed_bias = np.zeros((P, 9))
         self.raw_inv_depth = np.zeros(len(self.inv_depth))
@@ -334,6 +342,7 @@ class Window:
         c.raw_pose, c.raw_speed_bias = _ptr(self.raw_pose), _ptr(self.raw_speed_bias)
         c.raw_inv_depth = _ptr(self.raw_inv_depth)
         c.next_prior = C.pointer(self.next_prior.c)
+        c.resident_prior = self.resident_prior
         return c
 
     def struct(self):
@@ -422,6 +431,7 @@ def load_product():
                                      C.POINTER(VioPreintegration)]
     lib.vio_backend_solve_windows.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.c_int32,
                                               C.POINTER(VioSolveStats)]
+    lib.vio_backend_reserve_priors.argtypes = [vp, C.c_int32]
     lib.vio_backend_upload.argtypes = [vp, C.POINTER(VioWindow), C.c_int32]
     lib.vio_backend_launch.argtypes = [vp, vp]
     lib.vio_backend_sync.argtypes = [vp]

@@ -54,6 +54,10 @@ class WindowSolver:
         self._check(self.lib.vio_backend_solve_windows(self._h, arr, len(windows), buf_num, stats), "solve_windows")
         return [abi.stats_to_dict(s) for s in stats]
 
+    def reserve_priors(self, n_slots):
+        """Device-resident prior chain: Window.resident_prior = k selects slot k-1 (vio_amd.h)."""
+        self._check(self.lib.vio_backend_reserve_priors(self._h, n_slots), "reserve_priors")
+
     # resident-batch API (throughput runs)
     def upload(self, windows):
         self._structs = self._array(windows)

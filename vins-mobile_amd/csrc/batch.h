@@ -83,6 +83,14 @@ inline BatchStrides make_strides(const BatchDims &d) {
   return s;
 }
 
+// Device-resident prior chain: where window b reads its prior data from (null J: the strided pr_* arrays) and where it
+// writes the next one (null mJ: the strided MargPtrs arrays).
+struct PriorTab {
+  const double *x0, *J, *r;
+  double *mx0, *mJ, *mr;
+  int ncap;  // capacity of mJ (ncap x ncap) and mr
+};
+
 // Base pointers (device or host, depending on who fills it).
 struct BatchPtrs {
   int n;
@@ -96,6 +104,7 @@ struct BatchPtrs {
   const double *pts_i, *pts_j, *preint;
   const int *pr_kind, *pr_index, *pr_offset;
   const double *pr_x0, *pr_J, *pr_r;
+  const PriorTab *ptab;  // [n] or null
   double *scratch;   // [n][s.scratch]
   double *hm;        // [n][s.hm] (only used when the matrix does not fit LDS)
   const int *order;  // launch-local block index -> window (null: identity); a batch may be split into two launches
@@ -127,6 +136,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.pr_kind = B.pr_kind + b * B.s.pr_int, v.pr_index = B.pr_index + b * B.s.pr_int;
   v.pr_offset = B.pr_offset + b * B.s.pr_int;
   v.pr_x0 = B.pr_x0 + b * B.s.pr_x0, v.pr_J = B.pr_J + b * B.s.pr_J, v.pr_r = B.pr_r + b * B.s.pr_r;
+  if (B.ptab && B.ptab[b].J) v.pr_x0 = B.ptab[b].x0, v.pr_J = B.ptab[b].J, v.pr_r = B.ptab[b].r;
   v.use_origin = h[H_USE_ORIGIN];
   v.origin_yaw = hd[0], v.origin_p[0] = hd[1], v.origin_p[1] = hd[2], v.origin_p[2] = hd[3];
   double *sc = B.scratch + b * B.s.scratch;
@@ -270,7 +280,8 @@ struct HostBatch {
 };
 
 // Validates one window against the capacities and writes it into slot b. Returns VIO_OK / VIO_EINVAL / VIO_ECAP.
-inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
+// store_ok: the window names a valid slot of a reserved prior store, so a prior without data pointers is acceptable.
+inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok = false) {
   const BatchDims &d = hb.d;
   const BatchStrides &s = hb.s;
   const int W = w.window_size, P = W + 1, F = w.n_features, M = w.n_factors;
@@ -338,7 +349,8 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
   if (w.prior && w.prior->n > 0) {
     const VioPrior *p = w.prior;
     if (p->n > d.Ncap || p->n_blocks > kMaxPriorBlocks) return VIO_ECAP;
-    if (!p->block_x0 || !p->linearized_jacobians || !p->linearized_residuals) return VIO_EINVAL;
+    const bool in_store = !p->block_x0 && !p->linearized_jacobians && !p->linearized_residuals;
+    if (in_store ? !store_ok : (!p->block_x0 || !p->linearized_jacobians || !p->linearized_residuals)) return VIO_EINVAL;
     for (int k = 0; k < p->n_blocks; k++) {
       int kind = p->block_kind[k], idx = p->block_index[k], o = p->block_offset[k];
       int ls = kind == VIO_BLOCK_SPEEDBIAS ? 9 : 6;
@@ -346,9 +358,11 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w) {
       hb.pr_kind[b * s.pr_int + k] = kind, hb.pr_index[b * s.pr_int + k] = idx, hb.pr_offset[b * s.pr_int + k] = o;
     }
     h[H_PRIOR_N] = p->n, h[H_PRIOR_NB] = p->n_blocks;
-    memcpy(&hb.pr_x0[b * s.pr_x0], p->block_x0, sizeof(double) * 9 * p->n_blocks);
-    memcpy(&hb.pr_J[b * s.pr_J], p->linearized_jacobians, sizeof(double) * p->n * p->n);
-    memcpy(&hb.pr_r[b * s.pr_r], p->linearized_residuals, sizeof(double) * p->n);
+    if (!in_store) {
+      memcpy(&hb.pr_x0[b * s.pr_x0], p->block_x0, sizeof(double) * 9 * p->n_blocks);
+      memcpy(&hb.pr_J[b * s.pr_J], p->linearized_jacobians, sizeof(double) * p->n * p->n);
+      memcpy(&hb.pr_r[b * s.pr_r], p->linearized_residuals, sizeof(double) * p->n);
+    }
   }
   return VIO_OK;
 }

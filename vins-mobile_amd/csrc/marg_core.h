@@ -562,7 +562,8 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   stamp(cx, ST_MARG_CHOL);
 }
 
-inline void unpack_prior(const MargOut &mo, VioPrior &p) {
+// data = false: header only (the data stays in the device-resident store; mo.x0 / J / r are not read).
+inline void unpack_prior(const MargOut &mo, VioPrior &p, bool data = true) {
   p.n = mo.n[0];
   p.n_blocks = mo.n[1];
   if (p.n <= 0) {
@@ -571,6 +572,7 @@ inline void unpack_prior(const MargOut &mo, VioPrior &p) {
   }
   for (int b = 0; b < p.n_blocks; b++)
     p.block_kind[b] = mo.kind[b], p.block_index[b] = mo.index[b], p.block_offset[b] = mo.offset[b];
+  if (!data) return;
   memcpy(p.block_x0, mo.x0, sizeof(double) * 9 * p.n_blocks);
   memcpy(p.linearized_jacobians, mo.J, sizeof(double) * p.n * p.n);
   memcpy(p.linearized_residuals, mo.r, sizeof(double) * p.n);

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
   mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
   mo.ncap = B.d.Ncap;
+  if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
   MargWorkT<MatP> mw;
   carve_marg(B.d, LDS_MATRIX, lds + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
   __syncthreads();
@@ -142,6 +143,15 @@ struct vio_backend {
   DevBuf<double> d_hdr_d, d_pose, d_sb, d_ex, d_feat, d_pts_i, d_pts_j, d_preint, d_pr_x0, d_pr_J, d_pr_r, d_scratch,
       d_hm, d_out_pose, d_out_sb, d_out_feat, d_raw_pose, d_raw_sb, d_raw_feat, d_out_loop, d_stats_d, d_m_x0, d_m_J,
       d_m_r, d_m_scratch;
+  // device-resident prior chain (vio_backend_reserve_priors): st_n slots x 2 banks; st_bank[k] = the bank slot k's
+  // current prior lives in; the kernel writes the next one into the other bank
+  int st_n = 0, st_ncap = 0;
+  DevBuf<double> d_st_x0[2], d_st_J[2], d_st_r[2];
+  std::vector<unsigned char> st_bank;
+  std::vector<int> slot_of;  // [n] slot of window b in this upload or -1
+  DevBuf<PriorTab> d_ptab;
+  HostVec<PriorTab> h_ptab;
+  bool host_prior_in = true, host_prior_out = true, slots_advanced = false;  // any window of this upload moves prior data through the host
   // host copies of the outputs
   HostVec<double> h_out_pose, h_out_sb, h_out_feat, h_raw_pose, h_raw_sb, h_raw_feat, h_out_loop, h_stats_d, h_m_x0,
       h_m_J, h_m_r;
@@ -197,13 +207,52 @@ void vio_backend_destroy(vio_backend_t *be) {
                           &be->d_m_scratch};
   for (auto *b : db) b->release();
   be->d_prof.release();
+  for (int k = 0; k < 2; k++) be->d_st_x0[k].release(), be->d_st_J[k].release(), be->d_st_r[k].release();
+  be->d_ptab.release();
   (void)hipStreamDestroy(be->stream);
   delete be;
+}
+
+int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
+  if (!be || n_slots < 0) return VIO_EINVAL;
+  HIP_OK(hipStreamSynchronize(be->last_stream ? be->last_stream : be->stream));
+  be->uploaded = false;
+  be->st_n = 0;
+  const int ncap = 6 * be->cfg.window_size + 15;  // what marginalize() can leave behind: W poses, one speed-bias, the extrinsic
+  for (int k = 0; k < 2; k++) {
+    int rc = be->d_st_x0[k].ensure((size_t)n_slots * 9 * kMaxPriorBlocks);
+    if (rc == VIO_OK) rc = be->d_st_J[k].ensure((size_t)n_slots * ncap * ncap);
+    if (rc == VIO_OK) rc = be->d_st_r[k].ensure((size_t)n_slots * ncap);
+    if (rc != VIO_OK) return rc;
+  }
+  be->st_n = n_slots, be->st_ncap = ncap;
+  be->st_bank.assign(n_slots, 0);
+  return VIO_OK;
 }
 
 int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   if (!be || !windows || n < 1) return VIO_EINVAL;
   if (n > be->max_batch) return VIO_ECAP;
+  // device-resident prior chain: which windows name a slot, and whether any prior data crosses the host at all
+  be->slot_of.assign(n, -1);
+  be->host_prior_in = false, be->host_prior_out = false;
+  bool any_slot = false;
+  {
+    std::vector<char> taken(be->st_n, 0);
+    for (int b = 0; b < n; b++) {
+      const VioWindow &w = windows[b];
+      if (w.resident_prior < 0 || w.resident_prior > be->st_n) return VIO_EINVAL;
+      const int slot = w.resident_prior - 1;
+      if (slot >= 0) {
+        if (taken[slot]) return VIO_EINVAL;
+        taken[slot] = 1, any_slot = true;
+        if (w.prior && w.prior->n > be->st_ncap) return VIO_ECAP;
+      }
+      be->slot_of[b] = slot;
+      if (w.prior && w.prior->n > 0 && w.prior->linearized_jacobians) be->host_prior_in = true;
+      if (w.next_prior && slot < 0) be->host_prior_out = true;
+    }
+  }
   int Wmax = 1, Fmax = 1, Mmax = 1, Nmax = 0;
   bool any_loop = false;
   for (int b = 0; b < n; b++) {
@@ -245,7 +294,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   }
   {
     std::vector<int> rcs(n, VIO_OK);
-    vio::HostPool::get().parallel_for(n, [&](int b) { rcs[b] = pack_window(be->hb, b, windows[b]); });
+    vio::HostPool::get().parallel_for(n, [&](int b) { rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0); });
     for (int b = 0; b < n; b++)
       if (rcs[b] != VIO_OK) return rcs[b];
   }
@@ -367,9 +416,30 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   H2D(be->d_pr_kind, be->hb.pr_kind);
   H2D(be->d_pr_index, be->hb.pr_index);
   H2D(be->d_pr_offset, be->hb.pr_offset);
-  H2D(be->d_pr_x0, be->hb.pr_x0);
-  H2D(be->d_pr_J, be->hb.pr_J);
-  H2D(be->d_pr_r, be->hb.pr_r);
+  if (be->host_prior_in) {  // (the bulk of the upload: ~45 KB per window at W=10)
+    H2D(be->d_pr_x0, be->hb.pr_x0);
+    H2D(be->d_pr_J, be->hb.pr_J);
+    H2D(be->d_pr_r, be->hb.pr_r);
+  }
+  if (any_slot) {
+    if (be->d_ptab.ensure(n) != VIO_OK) return VIO_ENOMEM;
+    be->h_ptab.resize(n);
+    const size_t sx = 9 * kMaxPriorBlocks, sJ = (size_t)be->st_ncap * be->st_ncap, sr = be->st_ncap;
+    for (int b = 0; b < n; b++) {
+      PriorTab t = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      const int k = be->slot_of[b];
+      if (k >= 0) {
+        const int cur = be->st_bank[k], nxt = 1 - cur;
+        const VioPrior *p = windows[b].prior;
+        if (p && p->n > 0 && !p->linearized_jacobians)
+          t.x0 = be->d_st_x0[cur].p + k * sx, t.J = be->d_st_J[cur].p + k * sJ, t.r = be->d_st_r[cur].p + k * sr;
+        t.mx0 = be->d_st_x0[nxt].p + k * sx, t.mJ = be->d_st_J[nxt].p + k * sJ, t.mr = be->d_st_r[nxt].p + k * sr;
+        t.ncap = std::min(be->st_ncap, d.Ncap);
+      }
+      be->h_ptab[b] = t;
+    }
+    H2D(be->d_ptab, be->h_ptab);
+  }
 #undef H2D
   HIP_OK(hipStreamSynchronize(st));
   if (host_timing()) fprintf(stderr, "vio_backend_upload: pack %.2f ms, alloc+H2D %.2f ms (n=%d)\n", t1 - t0, now_ms() - t1, n);
@@ -384,6 +454,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   B.pts_i = be->d_pts_i.p, B.pts_j = be->d_pts_j.p, B.preint = be->d_preint.p;
   B.pr_kind = be->d_pr_kind.p, B.pr_index = be->d_pr_index.p, B.pr_offset = be->d_pr_offset.p;
   B.pr_x0 = be->d_pr_x0.p, B.pr_J = be->d_pr_J.p, B.pr_r = be->d_pr_r.p;
+  B.ptab = any_slot ? be->d_ptab.p : nullptr;
   B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
   B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
@@ -400,7 +471,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
     MP.prof = be->d_prof.p;
   }
   be->n = n;
-  be->uploaded = true;
+  be->uploaded = true, be->slots_advanced = false;
   return VIO_OK;
 }
 
@@ -512,9 +583,11 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
   D2H(be->h_stats_d, be->d_stats_d);
   D2H(be->h_stats_i, be->d_stats_i);
   D2H(be->h_m_ints, be->d_m_ints);
-  D2H(be->h_m_x0, be->d_m_x0);
-  D2H(be->h_m_J, be->d_m_J);
-  D2H(be->h_m_r, be->d_m_r);
+  if (be->host_prior_out) {
+    D2H(be->h_m_x0, be->d_m_x0);
+    D2H(be->h_m_J, be->d_m_J);
+    D2H(be->h_m_r, be->d_m_r);
+  }
 #undef D2H
   HIP_OK(hipStreamSynchronize(st));
   const double t2 = now_ms();
@@ -527,13 +600,23 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
       MargOut mo;
       int *mi = be->h_m_ints.data() + (size_t)b * be->MP.s_ints;
       mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
-      mo.x0 = be->h_m_x0.data() + (size_t)b * be->MP.s_x0;
-      mo.J = be->h_m_J.data() + (size_t)b * be->MP.s_J;
-      mo.r = be->h_m_r.data() + (size_t)b * be->MP.s_r;
+      mo.x0 = nullptr, mo.J = nullptr, mo.r = nullptr;
       mo.scratch = nullptr, mo.ncap = be->B.d.Ncap;
-      unpack_prior(mo, *windows[b].next_prior);
+      const int k = be->slot_of[b];
+      if (k < 0) mo.x0 = be->h_m_x0.data() + (size_t)b * be->MP.s_x0, mo.J = be->h_m_J.data() + (size_t)b * be->MP.s_J,
+                 mo.r = be->h_m_r.data() + (size_t)b * be->MP.s_r;
+      unpack_prior(mo, *windows[b].next_prior, k < 0);
     }
   });
+  // advance the slots whose window produced a new prior; once per upload (a second download of the same launch, or a
+  // re-launch of the same upload, reads and writes the same banks again)
+  if (!be->slots_advanced) {
+    for (int b = 0; b < n; b++) {
+      const int k = be->slot_of[b];
+      if (k >= 0 && be->h_m_ints[(size_t)b * be->MP.s_ints] > 0) be->st_bank[k] ^= 1;
+    }
+    be->slots_advanced = true;
+  }
   if (host_timing())
     fprintf(stderr, "vio_backend_download: wait for kernel %.2f ms, D2H %.2f ms, unpack %.2f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
   return VIO_OK;

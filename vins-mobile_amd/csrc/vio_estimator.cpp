@@ -44,14 +44,17 @@ struct Relocalization {  // RetriveData (VINS.hpp:28-45), the fields the solve r
 struct PriorBuf {
   VioPrior p;
   std::vector<double> x0, J, r;
-  void init(int cap) {
-    x0.assign((size_t)VIO_MAX_PRIOR_BLOCKS * 9, 0.0), J.assign((size_t)cap * cap, 0.0), r.assign(cap, 0.0);
+  // resident: only the header lives here, the data stays in the back-end's device store (vio_backend_reserve_priors)
+  void init(int cap, bool resident) {
     memset(&p, 0, sizeof(p));
+    if (resident) return;
+    x0.assign((size_t)VIO_MAX_PRIOR_BLOCKS * 9, 0.0), J.assign((size_t)cap * cap, 0.0), r.assign(cap, 0.0);
     p.block_x0 = x0.data(), p.linearized_jacobians = J.data(), p.linearized_residuals = r.data();
   }
 };
 
 struct Sequence {
+  int index = 0;  // position in the estimator = slot of the device-resident prior store
   int frame_count = 0, solver_flag = VIO_SOLVER_INITIAL, marginalization_flag = VIO_MARGIN_OLD;
   bool first_imu = false;
   int failure_occur = 0;
@@ -102,6 +105,9 @@ struct vio_estimator {
   std::vector<VioWindow> windows;
   std::vector<VioSolveStats> stats;
   bool enable_init = false;
+  // the marginalization prior of every sequence stays in device memory between launches; only its header comes back
+  // (VIO_AMD_HOST_PRIORS=1: carry it through host memory instead, ~45 KB per sequence and direction)
+  bool resident_priors = !(getenv("VIO_AMD_HOST_PRIORS") && getenv("VIO_AMD_HOST_PRIORS")[0] == '1');
   std::vector<int> solving;  // sequences of the current launch
   std::vector<VioWindow> staged;   // per sequence, built in parallel, compacted into `windows`
   std::vector<char> wants_solve;
@@ -257,6 +263,7 @@ int build_window(vio_estimator *e, Sequence &s, VioWindow *w) {
   }
   w->raw_pose = s.raw_pose.data(), w->raw_speed_bias = s.raw_sb.data(), w->raw_inv_depth = nullptr;
   w->next_prior = &s.prior[1 - s.cur_prior].p;
+  w->resident_prior = e->resident_priors ? s.index + 1 : 0;
   return VIO_OK;
 }
 
@@ -542,7 +549,8 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
       vio_estimator_destroy(e);
       return VIO_ENOMEM;
     }
-    s.prior[0].init(cap), s.prior[1].init(cap);
+    s.index = (int)(&s - e->seq.data());
+    s.prior[0].init(cap, e->resident_priors), s.prior[1].init(cap, e->resident_priors);
     memcpy(s.last_R, kI3, 72), memcpy(s.last_R_old, kI3, 72), memcpy(s.r_drift, kI3, 72);
     for (int k = 0; k < 3; k++) s.last_P[k] = s.last_P_old[k] = s.t_drift[k] = 0;
     s.pose.assign(7 * P, 0), s.sb.assign(9 * P, 0), s.raw_pose.assign(7 * P, 0), s.raw_sb.assign(9 * P, 0);
@@ -773,6 +781,7 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   if (n > 0) {
     if (!e->be) {
       int rc = vio_backend_create(&e->cfg, e->n_seq, &e->be);
+      if (rc == VIO_OK && e->resident_priors) rc = vio_backend_reserve_priors(e->be, e->n_seq);
       if (rc != VIO_OK) {
         for (int k = 0; k < n; k++) {
           clear_state(e, e->seq[e->solving[k]]);
