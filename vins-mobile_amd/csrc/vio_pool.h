@@ -2,7 +2,10 @@
 // (landmark bookkeeping, window packing, result unpacking). The reference runs ONE sequence on one thread
 // (ViewController.mm:688-724); a batch of hundreds of sequences per GPU needs the same work done for all of them
 // within the ~2 ms one launch takes, so it is spread over host cores. VIO_AMD_HOST_THREADS overrides the width
-// (1 = everything inline on the caller's thread).
+// (1 = everything inline on the caller's thread). A pool runs one parallel region at a time; host threads that drive
+// different contexts (several estimator objects sharing a GPU) are spread over two pools on hosts with >= 128
+// hardware threads, so that the host phases of one overlap those of another as well as its kernels
+// (VIO_AMD_HOST_POOLS overrides the count, at most 4).
 #pragma once
 #include <stdlib.h>
 
@@ -18,9 +21,11 @@ namespace vio {
 
 class HostPool {
  public:
-  static HostPool &get() {
-    static HostPool pool;
-    return pool;
+  static HostPool &get() {  // the calling thread's pool: assigned round-robin at its first call
+    static Pools pools;
+    static std::atomic<unsigned> next_caller{0};
+    thread_local const unsigned mine = next_caller.fetch_add(1);
+    return pools.p[mine % pools.n];
   }
   int width() const { return (int)workers_.size() + 1; }
 
@@ -52,6 +57,18 @@ class HostPool {
   }
 
  private:
+  struct Pools {
+    int n = 1;
+    HostPool *p = nullptr;
+    Pools() {
+      const int hw = (int)std::thread::hardware_concurrency();
+      if (const char *e = getenv("VIO_AMD_HOST_POOLS")) n = atoi(e);
+      else n = hw >= 128 ? 2 : 1;
+      n = std::min(4, std::max(1, n));
+      p = new HostPool[n];
+    }
+    ~Pools() { delete[] p; }
+  };
   HostPool() {
     int t = 0;
     if (const char *e = getenv("VIO_AMD_HOST_THREADS")) t = atoi(e);
