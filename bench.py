@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
 # Memory-side traffic of vio_window_kernel per window from the PMC passes of this very workload
-# (profiles/r01_h_pmc_hbm.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, 256 windows per launch):
+# (profiles/r01_i_pmc_hbm.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, 256 windows per launch):
 # FETCH_SIZE 1004820 KB (doubled: gfx950 reports half the bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 952949 KB.
 # bench.py cannot collect counters itself; the figure is only attached when the profiled configuration is the one run.
-PMC_TRAFFIC_BYTES_PER_WINDOW = (2 * 1004819.7 + 952949.3) * 1024.0 / 256.0
+PMC_TRAFFIC_BYTES_PER_WINDOW = (2 * 1007830.6 + 953780.0) * 1024.0 / 256.0
 PMC_TRAFFIC_CONFIG = (10, 150)  # (window size, features) the passes were taken on
 # The same passes for the front-end kernels of one publish step of 256 sequences (sum over copy_frames, 3 x pyr_down,
 # lk_track, track_update, detect, corner_select): FETCH_SIZE 523110 KB (doubled) + WRITE_SIZE 272870 KB.
@@ -169,14 +169,14 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES_PER_WINDOW * S if (cfg.window_size, 150) == PMC_TRAFFIC_CONFIG else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_h_pmc_hbm.txt)"},
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_i_pmc_hbm.txt)"},
             "roofline_frontend": {"kernel": "front-end step (copy + pyr_down x3 + lk_track + track_update + detect + corner_select)",
                                   "bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": PMC_FE_TRAFFIC_BYTES_PER_SEQUENCE * S
                                   if (rows, cols, cfg.max_corners, args.publish_every) == (640, 480, 150, 1) else None,
                                   "traffic_unit": "bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, "
-                                                  "profiles/r01_h_pmc_hbm.txt)"},
+                                                  "profiles/r01_i_pmc_hbm.txt)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, abi, uniq_frames[0], uniq_w)
