@@ -115,7 +115,8 @@ def test_prior_chain_resident_in_device_memory():
         wr.resident_prior = 2 + 1  # slot 2
         stats = solver.solve([wh, wr])
         assert stats[0]["iterations"] == stats[1]["iterations"]
-        assert np.abs(wh.pose - wr.pose).max() < 1e-9 and np.abs(wh.inv_depth - wr.inv_depth).max() < 1e-9
+        # (the two chains run in different workgroups: LDS atomics sum in a different order, the chains drift apart by rounding)
+        assert np.abs(wh.pose - wr.pose).max() < 1e-7 and np.abs(wh.inv_depth - wr.inv_depth).max() < 1e-7
         nh, nr = wh.next_prior.c, wr.next_prior.c
         assert nh.n == nr.n and nh.n_blocks == nr.n_blocks
         assert list(nh.block_index[: nh.n_blocks]) == list(nr.block_index[: nr.n_blocks])
@@ -170,6 +171,9 @@ def test_error_codes(solver_cache):
     arr2 = (abi.VioWindow * 1)()
     big.fill_struct(arr2[0])
     assert lib.vio_backend_solve_windows(solver._h, arr2, 1, 0, None) == abi.VIO_ECAP  # W=10 into a W=4 context
+    # a failed upload leaves nothing behind that could be launched or downloaded
+    assert lib.vio_backend_launch(solver._h, None) == abi.VIO_ESTATE
+    assert lib.vio_backend_download(solver._h, arr2, 1, None) == abi.VIO_ESTATE
 
 
 def test_poisoned_device_buffers():

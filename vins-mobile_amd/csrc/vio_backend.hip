@@ -233,6 +233,7 @@ int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
 int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   if (!be || !windows || n < 1) return VIO_EINVAL;
   if (n > be->max_batch) return VIO_ECAP;
+  be->uploaded = false;  // a failed upload leaves nothing to launch or download
   // device-resident prior chain: which windows name a slot, and whether any prior data crosses the host at all
   be->slot_of.assign(n, -1);
   be->host_prior_in = false, be->host_prior_out = false;
