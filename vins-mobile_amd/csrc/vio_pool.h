@@ -5,8 +5,13 @@
 // (1 = everything inline on the caller's thread). A pool runs one parallel region at a time; host threads that drive
 // different contexts (several estimator objects sharing a GPU) are spread over two pools on hosts with >= 128
 // hardware threads, so that the host phases of one overlap those of another as well as its kernels
-// (VIO_AMD_HOST_POOLS overrides the count, at most 4).
+// (VIO_AMD_HOST_POOLS overrides the count, at most 4). On a multi-socket host the workers of pool i stay on NUMA node
+// i mod nodes (the staging buffers a context fills and the landmark stores it walks then live next to the threads that
+// touch them; VIO_AMD_HOST_NUMA=0 leaves the workers unbound).
 #pragma once
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -57,6 +62,33 @@ class HostPool {
   }
 
  private:
+  // CPUs of NUMA node `node` that this process may run on; false when there is no such node or none is allowed
+  static bool node_cpus(int node, cpu_set_t *out) {
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    CPU_ZERO(out);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) {
+      fclose(f);
+      return false;
+    }
+    int a = 0, n_set = 0;
+    while (fscanf(f, "%d", &a) == 1) {  // "0-63,128-191"
+      int b = a, c = fgetc(f);
+      if (c == '-' && fscanf(f, "%d", &b) == 1) c = fgetc(f);
+      for (int i = a; i <= b && i < CPU_SETSIZE; i++)
+        if (i >= 0 && CPU_ISSET(i, &allowed)) {
+          CPU_SET(i, out);
+          n_set++;
+        }
+      if (c != ',') break;
+    }
+    fclose(f);
+    return n_set > 0;
+  }
   struct Pools {
     int n = 1;
     HostPool *p = nullptr;
@@ -66,14 +98,26 @@ class HostPool {
       else n = hw >= 128 ? 2 : 1;
       n = std::min(4, std::max(1, n));
       p = new HostPool[n];
+      const char *numa = getenv("VIO_AMD_HOST_NUMA");
+      cpu_set_t set;
+      int nodes = 0;
+      while (nodes < 16 && node_cpus(nodes, &set)) nodes++;
+      for (int i = 0; i < n; i++) {
+        const bool bind = nodes > 1 && !(numa && numa[0] == '0') && node_cpus(i % nodes, &set);
+        p[i].start(bind ? &set : nullptr);
+      }
     }
     ~Pools() { delete[] p; }
   };
-  HostPool() {
+  HostPool() {}
+  void start(const cpu_set_t *cpus) {
     int t = 0;
     if (const char *e = getenv("VIO_AMD_HOST_THREADS")) t = atoi(e);
     if (t <= 0) t = std::min(32, std::max(1, (int)std::thread::hardware_concurrency() / 2));
-    for (int i = 1; i < t; i++) workers_.emplace_back([this] { loop(); });
+    for (int i = 1; i < t; i++) {
+      workers_.emplace_back([this] { loop(); });
+      if (cpus) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(*cpus), cpus);  // best effort
+    }
   }
   ~HostPool() {
     {
