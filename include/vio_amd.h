@@ -16,7 +16,16 @@
  *   - all matrices are row-major; quaternions are stored x y z w exactly like
  *     para_Pose (VINS.cpp:93-101);
  *   - the product path needs a gfx950 device: there is no CPU fallback inside
- *     this library (the CPU restatement lives in oracle/ and is test-only).
+ *     this library (the CPU restatement lives in oracle/ and is test-only);
+ *   - DEVICE BINDING: a context lives on the HIP device that is current on the
+ *     creating thread at *_create (hipSetDevice(k) before the call; default 0).
+ *     Every later call on the context may come from ANY host thread — the
+ *     reference calls readImage on the camera-callback thread and solve_ceres
+ *     on the mainLoop thread (ViewController.mm:458 vs :688-724) — the entry
+ *     point switches the calling thread to the context's device for the call
+ *     and restores the thread's previous device on return. One process per GPU
+ *     or one context per GPU in one process both work; vio_*_get_device reports
+ *     the binding.
  */
 #ifndef VIO_AMD_H
 #define VIO_AMD_H
@@ -184,6 +193,8 @@ typedef struct vio_backend vio_backend_t;
 
 /* max_batch = number of independent windows one launch may carry.            */
 int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **out);
+/* HIP device ordinal the context was created on (see DEVICE BINDING above). */
+int vio_backend_get_device(const vio_backend_t *be, int32_t *device);
 void vio_backend_destroy(vio_backend_t *be);
 
 /* IntegrationBase(acc_0, gyr_0, ba, bg) followed by n push_back(dt, acc, gyr)
@@ -251,6 +262,7 @@ typedef struct VioTrackViz { /* good_pts / track_len (UI only), optional */
 
 /* n_seq independent trackers (sequences) share one context and one launch.   */
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out);
+int vio_frontend_get_device(const vio_frontend_t *fe, int32_t *device);
 void vio_frontend_destroy(vio_frontend_t *fe);
 
 /* readImage for sequence `seq` (feature_tracker.cpp:162-310). `publish` is the

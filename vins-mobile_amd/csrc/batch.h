@@ -77,7 +77,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
   s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
   s.scratch = (o + 7) / 8 * 8;
-  s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB;
+  s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB + 16;  // (+16: operand fetches of the padded 16th row read past a block)
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
   s.stats_d = kStatsDoubles, s.stats_i = kStatsInts;
   return s;

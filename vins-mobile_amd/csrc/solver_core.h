@@ -730,37 +730,6 @@ VIO_DEV void load_operand15(MP X, int lane, double out[4]) {
   }
 }
 
-// Two independent block updates C0 -= A0 B0^T, C1 -= A1 B1^T by one wave: the two MFMA chains interleave and every
-// operand load is in flight before the first matrix instruction issues.
-template <class MP>
-VIO_DEV void mfma_block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool second, int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-  double a0[4], b0[4], a1[4], b1[4];
-  load_operand15(A0, lane, a0), load_operand15(B0, lane, b0);
-  load_operand15(A1, lane, a1), load_operand15(B1, lane, b1);
-  v4d acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = kq + 4 * r;
-    const bool ok = row < kBS && i < kBS;
-    const int idx = ok ? row * kBS + i : 0;
-    acc0[r] = C0[idx], acc1[r] = C1[idx];
-  }
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    acc0 = mfma_f64(-a0[s], b0[s], acc0);
-    acc1 = mfma_f64(-a1[s], b1[s], acc1);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = kq + 4 * r;
-    if (row < kBS && i < kBS) {
-      C0[row * kBS + i] = acc0[r];
-      if (second) C1[row * kBS + i] = acc1[r];
-    }
-  }
-}
-
 // Cholesky of one 15x15 diagonal block AND the inverse of its factor by one wave, entirely on the matrix cores.
 // The block lives in the f64 accumulator layout (lane (kq, n), element r <-> D[kq + 4r][n]) as a full symmetric matrix;
 // pivot c: row c of D sits in the 16 lanes kq == (c & 3), element c >> 2, which is exactly where the A and the B operand
@@ -824,27 +793,120 @@ VIO_DEV bool potrf15_inv_wave(MP D, MP Lprev, bool with_update, ldsd ldinv_k, in
   return minpiv > 0.0;
 }
 
-// TRSM on the matrix cores: A_ik <- A_ik L_kk^-T with the inverse left behind by potrf15_inv_wave.
+// ---- block operations of the reduced-system Cholesky, second generation -------------------------------------------
+// What the first version cost (s_memtime stamps, tools/microbench/chol_bench.hip): an f64 MFMA holds its SIMD's VALU for
+// 64 cycles (no co-issue, not even from the other wave of the SIMD), every compiler-inserted hazard wait state is 4
+// cycles, and the predicated operand fetches (index clamp + two v_cndmask per value) were as long as the eight matrix
+// instructions of a block update (520 of 1650 cycles; stores 240). Here the per-lane offsets are wave constants and the
+// fetches are plain ds_read_b64 with immediate offsets.
+struct LaneMap {
+  int op;      // operand fetch base: X[i][kq] = i * 15 + kq (k-step s adds 4 s)
+  int acc;     // accumulator base:   C[kq][i] = kq * 15 + i (element r adds 60 r)
+  bool i_ok;   // i < 15: this lane's accumulator column / operand row exists
+  bool k3_ok;  // kq < 3: k index 12 + kq of the last k-step exists (k = 15 is padding)
+};
+VIO_DEV LaneMap lane_map(int lane) {
+  LaneMap m;
+  const int i = lane & 15, kq = lane >> 4;
+  m.op = i * kBS + kq, m.acc = kq * kBS + i, m.i_ok = i < kBS, m.k3_ok = kq < 3;
+  return m;
+}
+// A / B operand of C -= A B^T: the lane supplies X[i][4 s + kq]. Lanes i == 15 read up to 16 doubles past the block
+// (finite or not, their products land in output row / column 15, which is never stored); only the k = 15 padding has
+// to be a true zero on both operands.
 template <class MP>
-VIO_DEV void trsm15_mfma(MP Aik, MP Dkk, cldsd ldinv_k, int lane) {
+VIO_DEV void load_op(MP X, const LaneMap &m, double out[4]) {
+  auto p = X + m.op;
+  out[0] = p[0], out[1] = p[4], out[2] = p[8];
+  const double x3 = p[12];
+  out[3] = m.k3_ok ? x3 : 0.0;
+}
+template <class MP>
+VIO_DEV v4d load_acc(MP C, const LaneMap &m) {
+  auto p = C + m.acc;
+  v4d a;
+  a[0] = p[0], a[1] = p[60], a[2] = p[120], a[3] = p[180];  // (row 15 / column 15 garbage is never stored)
+  return a;
+}
+template <class MP>
+VIO_DEV void store_acc(MP C, const LaneMap &m, v4d a) {
+  auto p = C + m.acc;
+  if (m.i_ok) {
+    p[0] = a[0], p[60] = a[1], p[120] = a[2];
+    if (m.k3_ok) p[180] = a[3];
+  }
+}
+// two independent block updates C -= A B^T by one wave (interleaved MFMA chains)
+template <class MP>
+VIO_DEV void block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool second, const LaneMap &m) {
+  double a0[4], b0[4], a1[4], b1[4];
+  load_op(A0, m, a0), load_op(B0, m, b0), load_op(A1, m, a1), load_op(B1, m, b1);
+  v4d acc0 = load_acc(C0, m), acc1 = load_acc(C1, m);
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) {
+    acc0 = mfma_f64(-a0[s4], b0[s4], acc0);
+    acc1 = mfma_f64(-a1[s4], b1[s4], acc1);
+  }
+  store_acc(C0, m, acc0);
+  if (second) store_acc(C1, m, acc1);
+}
+// A_ik <- A_ik L_kk^-T with the inverse potrf15_inv_wave leaves behind (strict lower part of L^-1 transposed above the
+// diagonal of the block, 1 / L_cc in ldinv_k)
+template <class MP>
+VIO_DEV void block_trsm(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   double a[4];
-  load_operand15(Aik, lane, a);
+  load_op(Aik, m, a);
+  auto q = Dkk + m.acc;  // Dkk[kq + 4 s][n] = Linv[n][kq + 4 s] for kq + 4 s < n
+  const double dg = ldinv_k[m.i_ok ? n : 0];
+  double b[4];
+  b[0] = q[0], b[1] = q[60], b[2] = q[120], b[3] = q[180];
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int kk = 4 * s + kq;
-    const bool lower = n < kBS && kk < n;
-    const double off = Dkk[lower ? kk * kBS + n : 0];
-    const double dg = ldinv_k[n < kBS ? n : 0];
-    const double b = lower ? off : ((n < kBS && kk == n) ? dg : 0.0);  // Linv[n][kk]
-    acc = mfma_f64(a[s], b, acc);
+  for (int s4 = 0; s4 < 4; s4++) {
+    const int kk = 4 * s4 + kq;
+    const double bb = (m.i_ok && kk < n) ? b[s4] : ((m.i_ok && kk == n) ? dg : 0.0);
+    acc = mfma_f64(a[s4], bb, acc);
   }
+  store_acc(Aik, m, acc);
+}
+// Sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane of the quad gets the total.
+VIO_DEV double quad_sum_f64(double v) {
+  v += dpp_move_f64<0xB1, 0xf>(v);
+  v += dpp_move_f64<0x4E, 0xf>(v);
+  return v;
+}
+// rhs_i -= L_ik y_k for one block by one wave: lane = 4 r + p, row r, the four lanes of a quad split the 15 terms.
+template <class MP>
+VIO_DEV void block_rhs_update(MP Lik, ldsd rhs_i, cldsd yk, int lane) {
+  const int r = lane >> 2, p = lane & 3;
+  const bool ok = r < kBS;
+  auto Lr = Lik + (ok ? r : 0) * kBS + p;
+  double s = Lr[0] * yk[p];
+  s = fma(Lr[4], yk[p + 4], s);
+  s = fma(Lr[8], yk[p + 8], s);
+  const double l3 = Lr[12], y3 = yk[p + 12];  // p == 3: one past the row / segment (in bounds), masked
+  s = fma(p < 3 ? l3 : 0.0, p < 3 ? y3 : 0.0, s);
+  s = quad_sum_f64(s);
+  if (ok && p == 0) rhs_i[r] -= s;
+}
+// y_k = L_kk^-1 rhs_k with the stored inverse, in place, by one wave: lane = 4 n + p.
+template <class MP>
+VIO_DEV void block_forward_diag(MP Dkk, cldsd ldinv_k, ldsd rhs_k, int lane) {
+  const int n = lane >> 2, p = lane & 3;
+  const bool ok = n < kBS;
+  const int nn = ok ? n : 0;
+  double s = (p == 0) ? ldinv_k[nn] * rhs_k[nn] : 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = kq + 4 * r;
-    if (row < kBS && n < kBS) Aik[row * kBS + n] = acc[r];
+  for (int t4 = 0; t4 < 4; t4++) {
+    const int kk = p + 4 * t4;           // Linv[n][kk], kk < n, sits at Dkk[kk][n]
+    const bool in = ok && kk < n;
+    const double lv = Dkk[(in ? kk : 0) * kBS + nn], xv = rhs_k[in ? kk : 0];
+    s = fma(in ? lv : 0.0, xv, s);
   }
+  s = quad_sum_f64(s);
+  __builtin_amdgcn_wave_barrier();       // every load of the wave precedes the stores (compiler-level ordering)
+  if (ok && p == 0) rhs_k[n] = s;
 }
 #endif  // !VIO_EMUL
 
@@ -1404,7 +1466,9 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 template <class WK>
 VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
   const int nb = v.nblk;
-  const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+  // the wave index as a scalar: block loops and addresses then run on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane(cx.tid >> 6), nw = cx.nt >> 6, lane = cx.tid & 63;
+  const LaneMap m = lane_map(lane);
   if (wave == 0) {
     bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
     if (!good && lane == 0) w.flag[1] = 1;
@@ -1415,32 +1479,13 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
     if (w.flag[1]) return false;
     auto D = w.Hm + blk_off(k, k);
     const int ntb = nb - k - 1;
-    // ---- panel: L_ik = A_ik L_kk^-T (one wave per block), y_k = L_kk^-1 rhs_k (15 lanes of the last wave)
-    for (int bi = wave; bi < ntb; bi += nw) trsm15_mfma(w.Hm + blk_off(k + 1 + bi, k), D, w.ldinv + k * kBS, lane);
-    if (wave == nw - 1) {
-      const int nn = lane < kBS ? lane : 0;
-      double sacc = w.ldinv[k * kBS + nn] * rhs[k * kBS + nn];
-#pragma unroll
-      for (int kk = 0; kk < kBS - 1; kk++) {  // unrolled and predicated: the 28 LDS loads are all in flight at once
-        const bool in = kk < nn;
-        const double lv = D[(in ? kk : 0) * kBS + nn], xv = rhs[k * kBS + (in ? kk : 0)];
-        sacc = fma(in ? lv : 0.0, xv, sacc);
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < kBS) rhs[k * kBS + lane] = sacc;  // (all loads of the wave precede this store)
-    }
+    // ---- panel: L_ik = A_ik L_kk^-T (one wave per block), y_k = L_kk^-1 rhs_k (the last wave, which has the fewest blocks)
+    for (int bi = wave; bi < ntb; bi += nw) block_trsm(w.Hm + blk_off(k + 1 + bi, k), D, w.ldinv + k * kBS, m, lane);
+    if (wave == nw - 1) block_forward_diag(D, w.ldinv + k * kBS, rhs + k * kBS, lane);
     VIO_SYNC();
     stamp(cx, ST_C_TRSM);
     // ---- trailing update with look-ahead: wave 0 updates the next diagonal block and factors it at once while the
-    // other waves update the remaining blocks (two at a time each)
-    for (int q = cx.nt - 1 - cx.tid; q < ntb * kBS; q += cx.nt) {  // rhs_i -= L_ik y_k (upper waves)
-      int i = k + 1 + q / kBS, r = q % kBS;
-      auto Lr = w.Hm + blk_off(i, k) + r * kBS;
-      double sacc = 0;
-#pragma unroll
-      for (int m = 0; m < kBS; m++) sacc = fma(Lr[m], rhs[k * kBS + m], sacc);
-      rhs[i * kBS + r] -= sacc;
-    }
+    // other waves update the remaining blocks (two at a time each) and the right-hand side
     const int npairs = ntb * (ntb + 1) / 2;
     if (wave == 0) {
       if (ntb > 0) {
@@ -1451,18 +1496,16 @@ VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
       stamp(cx, ST_C_AHEAD);
     } else {
       const int stride = nw - 1;
+      for (int bi = wave - 1; bi < ntb; bi += stride)  // rhs_i -= L_ik y_k
+        block_rhs_update(w.Hm + blk_off(k + 1 + bi, k), rhs + (k + 1 + bi) * kBS, rhs + k * kBS, lane);
+      // pair p of the trailing lower triangle (p = 0 is the look-ahead block): the same enumeration as the block table
       for (int pr = wave; pr < npairs; pr += 2 * stride) {
         const int pr1 = pr + stride;
         const bool second = pr1 < npairs;
-        const int q1 = second ? pr1 : pr;
-        int li = 0, lj, mi = 0, mj;
-        while ((li + 1) * (li + 2) / 2 <= pr) li++;
-        lj = pr - li * (li + 1) / 2;
-        while ((mi + 1) * (mi + 2) / 2 <= q1) mi++;
-        mj = q1 - mi * (mi + 1) / 2;
-        const int i0 = k + 1 + li, j0 = k + 1 + lj, i1 = k + 1 + mi, j1 = k + 1 + mj;
-        mfma_block_update2(w.Hm + blk_off(i0, j0), w.Hm + blk_off(i0, k), w.Hm + blk_off(j0, k),
-                           w.Hm + blk_off(i1, j1), w.Hm + blk_off(i1, k), w.Hm + blk_off(j1, k), second, lane);
+        const int ij0 = w.blk_ij[pr], ij1 = w.blk_ij[second ? pr1 : pr];
+        const int i0 = k + 1 + (ij0 >> 8), j0 = k + 1 + (ij0 & 255), i1 = k + 1 + (ij1 >> 8), j1 = k + 1 + (ij1 & 255);
+        block_update2(w.Hm + blk_off(i0, j0), w.Hm + blk_off(i0, k), w.Hm + blk_off(j0, k),
+                      w.Hm + blk_off(i1, j1), w.Hm + blk_off(i1, k), w.Hm + blk_off(j1, k), second, m);
       }
     }
     VIO_SYNC();

@@ -16,6 +16,7 @@
 
 #include "batch.h"
 #include "vio_pool.h"
+#include "vio_device.h"
 #include "marg_core.h"
 #include "vio_amd.h"
 
@@ -116,6 +117,7 @@ static bool host_timing() {
 
 struct vio_backend {
   VioConfig cfg;
+  int device = -1;  // HIP device the context lives on (current device at create)
   int max_batch = 0;
   hipStream_t stream = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -181,9 +183,19 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
     fprintf(stderr, "vio_amd: no HIP device visible; the back-end has no CPU fallback\n");
     return VIO_ENODEV;
   }
-  vio_backend *be = new vio_backend();
+  vio_backend *be = new (std::nothrow) vio_backend();
+  if (!be) return VIO_ENOMEM;
   be->cfg = *cfg;
   be->max_batch = max_batch;
+  be->device = vio::current_device();
+  // the dynamic-LDS ceiling is a property of the FUNCTION, not of a launch: raised once to the CU's whole LDS for both
+  // variants (several contexts on several host threads launch these kernels; a per-launch value could be lowered by
+  // another thread between this thread's set and its launch)
+  if (hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+    delete be;
+    return VIO_ENODEV;
+  }
   if (hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking) != hipSuccess) {
     delete be;
     return VIO_ENODEV;
@@ -192,8 +204,15 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
   return VIO_OK;
 }
 
+int vio_backend_get_device(const vio_backend_t *be, int32_t *device) {
+  if (!be || !device) return VIO_EINVAL;
+  *device = be->device;
+  return VIO_OK;
+}
+
 void vio_backend_destroy(vio_backend_t *be) {
   if (!be) return;
+  vio::DeviceScope scope(be->device);
   (void)hipStreamSynchronize(be->stream);
   for (auto &e : be->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   DevBuf<int> *ib[] = {&be->d_hdr, &be->d_fhost, &be->d_ftarget, &be->d_ffeat, &be->d_pr_kind, &be->d_pr_index,
@@ -215,6 +234,7 @@ void vio_backend_destroy(vio_backend_t *be) {
 
 int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
   if (!be || n_slots < 0) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(be);
   HIP_OK(hipStreamSynchronize(be->last_stream ? be->last_stream : be->stream));
   be->uploaded = false;
   be->st_n = 0;
@@ -230,10 +250,24 @@ int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
   return VIO_OK;
 }
 
+static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int32_t n);
+
 int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   if (!be || !windows || n < 1) return VIO_EINVAL;
   if (n > be->max_batch) return VIO_ECAP;
+  VIO_ON_DEVICE_OF(be);
   be->uploaded = false;  // a failed upload leaves nothing to launch or download
+  try {  // page-locked staging vectors and the per-window packers allocate: no exception crosses the ABI
+    return backend_upload_impl(be, windows, n);
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+}
+
+static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int32_t n) {
+  // an earlier launch may still be reading the device inputs this upload overwrites (it may have gone to a caller's
+  // stream): wait for it first
+  if (be->last_stream && be->last_stream != be->stream) HIP_OK(hipStreamSynchronize(be->last_stream));
   // device-resident prior chain: which windows name a slot, and whether any prior data crosses the host at all
   be->slot_of.assign(n, -1);
   be->host_prior_in = false, be->host_prior_out = false;
@@ -288,14 +322,16 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
   d.Flds = std::max(Fmax, 1);
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
   const double t0 = now_ms();
-  try {
-    be->hb.resize(d, n, poison_staging);
-  } catch (const std::bad_alloc &) {
-    return VIO_ENOMEM;
-  }
+  be->hb.resize(d, n, poison_staging);
   {
     std::vector<int> rcs(n, VIO_OK);
-    vio::HostPool::get().parallel_for(n, [&](int b) { rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0); });
+    vio::HostPool::get().parallel_for(n, [&](int b) {
+      try {
+        rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0);
+      } catch (const std::bad_alloc &) {  // (worker thread: must not unwind out of the pool)
+        rcs[b] = VIO_ENOMEM;
+      }
+    });
     for (int b = 0; b < n; b++)
       if (rcs[b] != VIO_OK) return rcs[b];
   }
@@ -479,6 +515,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
 int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (!be) return VIO_EINVAL;
   if (!be->uploaded) return VIO_ESTATE;
+  VIO_ON_DEVICE_OF(be);
   hipStream_t st = stream ? (hipStream_t)stream : be->stream;
   be->last_stream = st;
   if (be->events_used == be->events.size()) {
@@ -505,16 +542,12 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)be->lds_bytes));
     hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n_lds), dim3(kThreads), be->lds_bytes, st, Bl, be->MP,
                        (int)(be->lds_bytes / sizeof(double)));
   }
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
     Bg.d = be->d_glb, Bg.order = be->d_order.p + be->n_lds;
-    HIP_OK(hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)be->lds_bytes_glb));
     hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n_glb), dim3(kThreads), be->lds_bytes_glb, st, Bg, be->MP,
                        (int)(be->lds_bytes_glb / sizeof(double)));
   }
@@ -525,12 +558,14 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
 
 int vio_backend_sync(vio_backend_t *be) {
   if (!be) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(be);
   HIP_OK(hipDeviceSynchronize());
   return VIO_OK;
 }
 
 int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches) {
   if (!be || !ms_avg || !launches) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(be);
   HIP_OK(hipDeviceSynchronize());
   double sum = 0;
   for (size_t i = 0; i < be->events_used; i++) {
@@ -554,6 +589,7 @@ int vio_backend_set_profile(vio_backend_t *be, int32_t enable) {
 int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles, int32_t n_stages) {
   if (!be || !cycles || n_stages < 1) return VIO_EINVAL;
   if (!be->uploaded || !be->profile || window < 0 || window >= be->n) return VIO_ESTATE;
+  VIO_ON_DEVICE_OF(be);
   HIP_OK(hipDeviceSynchronize());
   long long tmp[ST_COUNT];
   HIP_OK(hipMemcpy(tmp, be->d_prof.p + (size_t)window * ST_COUNT, sizeof(tmp), hipMemcpyDeviceToHost));
@@ -561,9 +597,20 @@ int vio_backend_stage_cycles(vio_backend_t *be, int32_t window, int64_t *cycles,
   return VIO_OK;
 }
 
+static int backend_download_impl(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats);
+
 int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats) {
   if (!be || !windows) return VIO_EINVAL;
   if (!be->uploaded || n != be->n) return VIO_ESTATE;
+  VIO_ON_DEVICE_OF(be);
+  try {  // the page-locked host copies are (re)sized here
+    return backend_download_impl(be, windows, n, stats);
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+}
+
+static int backend_download_impl(vio_backend_t *be, VioWindow *windows, int32_t n, VioSolveStats *stats) {
   const double t0 = now_ms();
   // only this context's launch: other contexts (other host threads) keep the device busy meanwhile
   HIP_OK(hipStreamSynchronize(be->last_stream ? be->last_stream : be->stream));

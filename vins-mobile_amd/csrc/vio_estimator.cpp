@@ -698,6 +698,9 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     int rc = vio_features_add_check_parallax(s.fm, s.frame_count, obs + (size_t)q * obs_stride, n_obs[q], &enough,
                                              &parallax_num, &s.last_track_num);
     if (rc != VIO_OK) {
+      // the landmark store may hold part of this frame while the window did not advance: every later frame would be
+      // refused as out of order (VIO_ESTATE). Restart the sequence, as after a device error.
+      clear_state(e, s);
       res.action = VIO_FRAME_ERROR, res.error = rc;
       return;
     }
@@ -764,6 +767,10 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     if (solve) {
       rc = build_window(e, s, &e->staged[q]);
       if (rc != VIO_OK) {
+        // (typically VIO_ECAP: more landmarks / factors than cfg.max_features / max_factors.) The frame's observations
+        // are in the landmark store but the window will not slide: without a restart add_check_parallax refuses every
+        // following frame and the sequence stays stuck until the caller clears it.
+        clear_state(e, s);
         res.action = VIO_FRAME_ERROR, res.error = rc;
         return;
       }

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "vio_amd.h"
+#include "vio_device.h"
 #include "vio_pool.h"
 
 namespace {
@@ -1037,6 +1038,7 @@ struct SelectParams {
 };
 
 constexpr int kSelThreads = 512;
+constexpr int kSelMaxSeg = 256;  // strips of kDetR rows: images up to 8192 rows
 constexpr int kSelLds = 8192;  // candidate keys kept in LDS (64 KB); larger lists are processed in place in HBM
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -1060,6 +1062,7 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
   __shared__ unsigned long long keys[kSelLds];
   __shared__ unsigned long long red[kSelThreads / 64];
   __shared__ int s_n, s_cnt;
+  __shared__ int s_off[kSelMaxSeg + 1];
   const int seq = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   unsigned long long *cand = cand_base + (size_t)seq * nseg * seg_cap;  // nseg segments of seg_cap keys
   const size_t base = (size_t)seq * P.cap;
@@ -1071,21 +1074,39 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
   const float thr = mb ? (float)((double)from_ordered_bits(mb) * quality) : 3.4e38f;
   if (tid == 0) s_n = n, s_cnt = 0;
   __syncthreads();
-  // threshold(eig, maxVal * qualityLevel, THRESH_TOZERO): keep v > thr. Unused tail slots of every segment are
-  // zeroed so that the in-place (HBM) path can scan the whole nseg * seg_cap range.
-  const int total = nseg * seg_cap;
-  for (int i = tid; i < total; i += nt) {
-    int g = i / seg_cap, j = i - g * seg_cap;
-    int cnt = min(n_cand[(size_t)seq * nseg + g], seg_cap);
-    unsigned long long k = j < cnt ? cand[i] : 0;
+  // threshold(eig, maxVal * qualityLevel, THRESH_TOZERO): keep v > thr. Only the slots the detector really filled are
+  // visited (prefix of the per-segment counts), survivors go to LDS and NOTHING is written back to the candidate list:
+  // the first version zeroed every rejected and unused slot in HBM (0.6 MB per sequence and publish frame, twice the
+  // frame itself) although only the rare in-place path below reads the list again.
+  if (tid == 0) {
+    int o = 0;
+    for (int g = 0; g < nseg; g++) s_off[g] = o, o += min(n_cand[(size_t)seq * nseg + g], seg_cap);
+    s_off[nseg] = o;
+  }
+  __syncthreads();
+  const int real = s_off[nseg];
+  for (int i = tid; i < real; i += nt) {
+    int g = 0;
+    while (s_off[g + 1] <= i) g++;
+    const unsigned long long k = cand[(size_t)g * seg_cap + (i - s_off[g])];
     if (k && __uint_as_float((unsigned)(k >> 32)) > thr) {
       int slot = atomicAdd(&s_cnt, 1);
       if (slot < kSelLds) keys[slot] = k;
-    } else {
-      cand[i] = 0;
     }
   }
   __syncthreads();
+  const int total = nseg * seg_cap;
+  if (s_cnt > kSelLds) {
+    // more survivors than LDS holds: the greedy selection runs in place over the whole nseg * seg_cap range, so
+    // rejected candidates and the unused tail of every segment are zeroed now
+    for (int i = tid; i < total; i += nt) {
+      int g = i / seg_cap, j = i - g * seg_cap;
+      const bool used = j < s_off[g + 1] - s_off[g];
+      const unsigned long long k = used ? cand[i] : 0;
+      if (!(k && __uint_as_float((unsigned)(k >> 32)) > thr)) cand[i] = 0;
+    }
+    __syncthreads();
+  }
   // this kernel is the only consumer of the per-segment counters: leave them zeroed for the next detection pass
   for (int g = tid; g < nseg; g += nt) n_cand[(size_t)seq * nseg + g] = 0, max_bits[(size_t)seq * nseg + g] = 0;
   const bool in_lds = s_cnt <= kSelLds;
@@ -1172,6 +1193,7 @@ int dev_alloc(T **p, size_t count) {
 }  // namespace
 
 struct vio_frontend {
+  int device = -1;  // HIP device the context lives on (current device at create)
   VioConfig cfg;
   int n_seq = 0, cap = 0;
   LevelDims ld;
@@ -1300,6 +1322,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
     return VIO_ENODEV;
   }
   vio_frontend *fe = new vio_frontend();
+  fe->device = vio::current_device();
   fe->cfg = *cfg, fe->n_seq = n_seq, fe->cap = cfg->max_corners;
   // buildOpticalFlowPyramid: levels stop when one would not hold the window
   LevelDims &ld = fe->ld;
@@ -1313,6 +1336,10 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   ld.pyr_bytes = (off + 255) & ~(size_t)255;
   const size_t S = n_seq, cap = fe->cap;
   fe->nseg = (cfg->image_rows + kDetR - 1) / kDetR;
+  if (fe->nseg > kSelMaxSeg) {
+    delete fe;
+    return VIO_ECAP;
+  }
   fe->seg_cap = kDetR * cfg->image_cols / 4;  // a 3x3 local maximum can occupy at most one pixel in four
   int rc = VIO_OK;
   if (hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking) != hipSuccess) rc = VIO_ENODEV;
@@ -1360,8 +1387,15 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   return VIO_OK;
 }
 
+int vio_frontend_get_device(const vio_frontend_t *fe, int32_t *device) {
+  if (!fe || !device) return VIO_EINVAL;
+  *device = fe->device;
+  return VIO_OK;
+}
+
 void vio_frontend_destroy(vio_frontend_t *fe) {
   if (!fe) return;
+  vio::DeviceScope scope(fe->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {fe->pyr[0], fe->pyr[1], fe->mask, fe->max_bits, fe->cand, fe->n_cand, fe->cur_pts, fe->pre_pts,
                   fe->forw_pts, fe->lk_err, fe->ids, fe->track_cnt, fe->n_pts, fe->n_forw, fe->n_id, fe->kept_xy, fe->n_kept,
@@ -1380,6 +1414,7 @@ int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t 
                                int32_t stride) {
   if (!fe || !gray || n_frames < 1) return VIO_EINVAL;
   if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
   const size_t px = (size_t)rows * cols, total = (size_t)n_frames * fe->n_seq;
   if (fe->frames) (void)hipFree(fe->frames), fe->frames = nullptr;
   if (dev_alloc(&fe->frames, total * px) != VIO_OK) return VIO_ENOMEM;
@@ -1391,6 +1426,7 @@ int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t 
 int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t publish, void *stream) {
   if (!fe) return VIO_EINVAL;
   if (!fe->frames || frame_index < 0 || frame_index >= fe->n_frames) return VIO_ESTATE;
+  VIO_ON_DEVICE_OF(fe);
   hipStream_t st = stream ? (hipStream_t)stream : fe->stream;
   if (fe->events_used == fe->events.size()) {
     if (fe->events.size() >= 4096) fe->events_used = 0;
@@ -1412,12 +1448,14 @@ int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t 
 
 int vio_frontend_sync(vio_frontend_t *fe) {
   if (!fe) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   return VIO_OK;
 }
 
 int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches) {
   if (!fe || !ms_avg || !launches) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   double sum = 0;
   for (size_t i = 0; i < fe->events_used; i++) {
@@ -1436,6 +1474,7 @@ int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t ro
   (void)headers;  // the reference only forwards the header to the (default-off) vinsPnP branch
   if (!fe || !gray || !n_obs || (publish && !out_obs)) return VIO_EINVAL;
   if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
   const size_t px = (size_t)rows * cols, S = fe->n_seq;
   // host frames land in a device staging buffer kept for the life of the context; observations come back through
   // pinned host memory (no allocation, no pageable bounce on the return path)
@@ -1491,6 +1530,7 @@ int vio_frontend_read_image(vio_frontend_t *fe, int32_t seq, const uint8_t *gray
 int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int32_t *ids, int32_t *track_cnt, int32_t cap,
                            int32_t *n) {
   if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   int m = 0;
   HIP_OK(hipMemcpy(&m, fe->n_pts + seq, sizeof(int), hipMemcpyDeviceToHost));

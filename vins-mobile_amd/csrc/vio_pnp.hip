@@ -9,6 +9,7 @@
 
 #include "pnp_core.h"
 #include "vio_amd.h"
+#include "vio_device.h"
 
 using namespace vio;
 
@@ -70,6 +71,7 @@ struct Dev {
 }  // namespace
 
 struct vio_pnp {
+  int device = -1;  // HIP device the context lives on (current device at create)
   VioConfig cfg;
   int max_batch = 0;
   hipStream_t stream = nullptr;
@@ -90,6 +92,7 @@ int vio_pnp_create(const VioConfig *cfg, int32_t max_batch, vio_pnp_t **out) {
     return VIO_ENODEV;
   }
   vio_pnp *p = new (std::nothrow) vio_pnp();
+  if (p) p->device = vio::current_device();
   if (!p) return VIO_ENOMEM;
   p->cfg = *cfg, p->max_batch = max_batch;
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
@@ -103,6 +106,7 @@ int vio_pnp_create(const VioConfig *cfg, int32_t max_batch, vio_pnp_t **out) {
 
 void vio_pnp_destroy(vio_pnp_t *p) {
   if (!p) return;
+  vio::DeviceScope scope(p->device);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -112,6 +116,7 @@ void vio_pnp_destroy(vio_pnp_t *p) {
 int vio_pnp_solve_windows(vio_pnp_t *p, VioPnpWindow *windows, int32_t n, VioSolveStats *stats) {
   if (!p || !windows || n < 1) return VIO_EINVAL;
   if (n > p->max_batch) return VIO_ECAP;
+  VIO_ON_DEVICE_OF(p);
   int F = 2, Mmax = 1;
   for (int b = 0; b < n; b++) {
     const VioPnpWindow &w = windows[b];
@@ -214,6 +219,7 @@ int vio_pnp_solve_windows(vio_pnp_t *p, VioPnpWindow *windows, int32_t n, VioSol
 
 int vio_pnp_kernel_ms(vio_pnp_t *p, double *ms_avg, int32_t *launches) {
   if (!p || !ms_avg || !launches) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(p);
   *launches = p->launches, *ms_avg = p->launches ? p->ms_sum / p->launches : 0.0;
   p->ms_sum = 0, p->launches = 0;
   return VIO_OK;

@@ -28,6 +28,7 @@
 #include <algorithm>
 
 #include "vio_amd.h"
+#include "vio_device.h"
 #include "vio_pool.h"
 
 namespace {
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void clahe_apply_kernel(const uint8_t *__
 }  // namespace
 
 struct vio_preprocess {
+  int device = -1;  // HIP device the context lives on (current device at create)
   int max_frames = 0, rows = 0, cols = 0;
   double clip_limit = 3.0;  // clahe->setClipLimit(3) ViewController.mm:436
   int tiles_x = 8, tiles_y = 8;  // cv::createCLAHE() default tileGridSize
@@ -251,6 +253,7 @@ int vio_preprocess_create(int32_t max_frames, int32_t rows, int32_t cols, vio_pr
     return VIO_ENODEV;
   }
   vio_preprocess *p = new (std::nothrow) vio_preprocess();
+  if (p) p->device = vio::current_device();
   if (!p) return VIO_ENOMEM;
   p->max_frames = max_frames, p->rows = rows, p->cols = cols;
   const size_t px = (size_t)rows * cols;
@@ -274,6 +277,7 @@ int vio_preprocess_create(int32_t max_frames, int32_t rows, int32_t cols, vio_pr
 
 void vio_preprocess_destroy(vio_preprocess_t *p) {
   if (!p) return;
+  vio::DeviceScope scope(p->device);
   if (p->d_src) (void)hipFree(p->d_src);
   if (p->d_gray) (void)hipFree(p->d_gray);
   if (p->d_out) (void)hipFree(p->d_out);
@@ -302,6 +306,7 @@ int vio_preprocess_run(vio_preprocess_t *p, const uint8_t *pixels, int32_t chann
   if (!p || !pixels || !equalized_out || !(channels == 1 || channels == 4) || n_frames < 1 || stride < channels * p->cols)
     return VIO_EINVAL;
   if (n_frames > p->max_frames) return VIO_ECAP;
+  VIO_ON_DEVICE_OF(p);
   const size_t px = (size_t)p->rows * p->cols, row_bytes = (size_t)channels * p->cols, fb = row_bytes * p->rows;
   hipStream_t st = p->stream;
   // caller memory is pageable: gather into / scatter from page-locked staging with the host pool, a few frames per chunk,
@@ -342,6 +347,7 @@ int vio_preprocess_run_resident(vio_preprocess_t *p, const void *d_pixels, int32
     return VIO_EINVAL;
   if (n_frames > p->max_frames) return VIO_ECAP;
   if (channels == 4 && ((reinterpret_cast<uintptr_t>(d_pixels) | (uintptr_t)stride) & 3)) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(p);
   hipStream_t st = stream ? (hipStream_t)stream : p->stream;
   return launch(p, (const uint8_t *)d_pixels, channels, n_frames, (size_t)stride * p->rows, stride, (uint8_t *)d_equalized,
                 (size_t)p->rows * p->cols, p->cols, st);
@@ -349,6 +355,7 @@ int vio_preprocess_run_resident(vio_preprocess_t *p, const void *d_pixels, int32
 
 int vio_preprocess_sync(vio_preprocess_t *p) {
   if (!p) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(p);
   if (hipEventSynchronize(p->ev1) != hipSuccess || hipGetLastError() != hipSuccess) return VIO_ENODEV;
   account(p);
   return VIO_OK;
@@ -356,6 +363,7 @@ int vio_preprocess_sync(vio_preprocess_t *p) {
 
 int vio_preprocess_kernel_ms(vio_preprocess_t *p, double *ms_avg, int32_t *launches) {
   if (!p || !ms_avg || !launches) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(p);
   *launches = p->launches;
   *ms_avg = p->launches ? p->ms_sum / p->launches : 0.0;
   p->ms_sum = 0, p->launches = 0;

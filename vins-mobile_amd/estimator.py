@@ -94,9 +94,15 @@ class Estimator:
         act = None
         if active is not None:
             act = np.ascontiguousarray(active, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8))
-        self._check(self.lib.vio_estimator_process_images(self._h, obs, n.ctypes.data_as(_ip), stride, _p(headers), act, res),
-                    "process_images")
-        return list(res)
+        rc = self.lib.vio_estimator_process_images(self._h, obs, n.ctypes.data_as(_ip), stride, _p(headers), act, res)
+        out = list(res)
+        # A non-zero code with per-sequence VIO_FRAME_ERROR results is the FIRST failing sequence's code: every other
+        # sequence was processed, solved and slid, so the results are returned (state and caller stay in step) and the code
+        # is kept in last_error. Only a failure before any processing (bad arguments) raises.
+        self.last_error = rc
+        if rc != 0 and not any(r.action == abi.VIO_FRAME_ERROR for r in out):
+            self._check(rc, "process_images")
+        return out
 
     def status(self, seq=0):
         st = abi.VioEstimatorStatus()
