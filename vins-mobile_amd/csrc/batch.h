@@ -168,9 +168,21 @@ struct MatPick<ldsd> {
 };
 #endif
 
+// Everything carve_work lays out, returned BY VALUE: the kernel must not take the address of its WorkT / Ctx objects.
+// (A null test of a pointer to a private-memory object is not folded by LLVM -- in the private address space 0 is a
+// valid address -- and one such compare is enough to keep the whole struct out of registers: the first version of the
+// kernel read every w.field and cx.field back from scratch memory, ~1100 scratch_load sites.)
 template <class MP>
-VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global,
-                         WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
+struct Carved {
+  WorkT<MP> w;
+  ldsd red;
+  VIO_AS3 long long *lprof;
+  size_t bytes, state_end_doubles;
+};
+
+template <class MP>
+VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global) {
+  Carved<MP> c;
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // padded pose-side length
   const size_t F = d.Flds;
@@ -179,40 +191,41 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
     o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
     return p;
   };
+  WorkT<MP> &w = c.w;
   // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
-  ldsd xpose = take(7 * (size_t)(d.Pcap + 1)), xsb = take(9 * (size_t)d.Pcap), xfeat = take(F);
-  ldsd ex = take(8);
-  ldsd red = take(6 * ((size_t)nthreads / 64) + 2);
-  ldsd lprof = take(ST_COUNT);
-  if (state_end_doubles) *state_end_doubles = o;
+  w.xpose = take(7 * (size_t)(d.Pcap + 1)), w.xsb = take(9 * (size_t)d.Pcap), w.xfeat = take(F);
+  w.ex = take(8);
+  c.red = take(6 * ((size_t)nthreads / 64) + 2);
+  c.lprof = reinterpret_cast<VIO_AS3 long long *>(take(ST_COUNT));
+  c.state_end_doubles = o;
   ldsd hm = nullptr;
   if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
-  ldsd cpose = take(7 * (size_t)(d.Pcap + 1)), csb = take(9 * (size_t)d.Pcap), cfeat = take(F);
-  ldsd gp = take(npc), gf = take(F), sp = take(npc), sf = take(F), dp = take(npc);
-  ldsd gdp = take(npc), gnp = take(npc), gnf = take(F), stp = take(npc), stf = take(F);
-  ldsd hdiag = take(npc), hff = take(F), ef = take(F), einv = take(F), ldinv = take(npc), t1 = take(npc),
-         t2 = take(npc);
-  ldsd blk = take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1);
-  ldsd tf = take(F), prdx = take(d.Ncap), prr = take(d.Ncap);
-  ldsd prcol = take(((size_t)d.Ncap + 1) / 2 + 1);
-  ldsd flag = take(2);
-  ldsd ppd = take(36 * (size_t)(d.Pcap + 1));
-  ldsd rot = take(9 * (size_t)(d.Pcap + 2));
-  ldsd fh = take((F + 1) / 2 + 1);
-  if (w) {
-    w->Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
-    w->xpose = xpose, w->xsb = xsb, w->xfeat = xfeat, w->cpose = cpose, w->csb = csb, w->cfeat = cfeat, w->ex = ex;
-    w->gp = gp, w->gf = gf, w->sp = sp, w->sf = sf, w->dp = dp, w->gdp = gdp;
-    w->gnp = gnp, w->gnf = gnf, w->stp = stp, w->stf = stf, w->hdiag = hdiag, w->hff = hff, w->ef = ef, w->einv = einv;
-    w->blk_ij = reinterpret_cast<ldsi>(blk);
-    w->ldinv = ldinv, w->t1 = t1, w->t2 = t2, w->tf = tf, w->prdx = prdx, w->prr = prr;
-    w->prcol = reinterpret_cast<ldsi>(prcol), w->flag = reinterpret_cast<ldsi>(flag);
-    w->ppd = ppd;
-    w->rot = rot;
-    w->fh = reinterpret_cast<ldsi>(fh);
-  }
-  if (cx) cx->red = red, cx->lprof = reinterpret_cast<VIO_AS3 long long *>(lprof);
-  return o * sizeof(double);
+  w.Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
+  w.cpose = take(7 * (size_t)(d.Pcap + 1)), w.csb = take(9 * (size_t)d.Pcap), w.cfeat = take(F);
+  w.gp = take(npc), w.gf = take(F), w.sp = take(npc), w.sf = take(F), w.dp = take(npc);
+  w.gdp = take(npc), w.gnp = take(npc), w.gnf = take(F), w.stp = take(npc), w.stf = take(F);
+  w.hdiag = take(npc), w.hff = take(F), w.ef = take(F), w.einv = take(F), w.ldinv = take(npc), w.t1 = take(npc);
+  w.t2 = take(npc);
+  w.blk_ij = reinterpret_cast<ldsi>(take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1));
+  w.tf = take(F), w.prdx = take(d.Ncap), w.prr = take(d.Ncap);
+  w.prcol = reinterpret_cast<ldsi>(take(((size_t)d.Ncap + 1) / 2 + 1));
+  w.flag = reinterpret_cast<ldsi>(take(2));
+  w.ppd = take(36 * (size_t)(d.Pcap + 1));
+  w.rot = take(9 * (size_t)(d.Pcap + 2));
+  w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
+  c.bytes = o * sizeof(double);
+  return c;
+}
+
+// Pointer form for host code (sizing: all outputs optional). Returns the number of bytes used.
+template <class MP>
+VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global,
+                         WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
+  const Carved<MP> c = carve_all<MP>(d, lds_matrix, nthreads, base, hm_global);
+  if (w) *w = c.w;
+  if (cx) cx->red = c.red, cx->lprof = c.lprof;
+  if (state_end_doubles) *state_end_doubles = c.state_end_doubles;
+  return c.bytes;
 }
 
 // ---- host-side staging ---------------------------------------------------------------------------------

@@ -75,9 +75,16 @@ VIO_HD size_t marg_scratch_doubles(const int Wcap) {
 
 // LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
 // is preserved; everything behind it is re-used. Returns bytes used (base may be null to just measure).
+// By value (the kernel must not take the address of its MargWorkT, see carve_all in batch.h).
+template <class MP>
+struct CarvedMarg {
+  MargWorkT<MP> m;
+  size_t bytes;
+};
 template <class MP, class Dims>
-VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, double *am_global, MargWorkT<MP> *m,
-                         size_t avail_doubles = 0) {
+VIO_HD CarvedMarg<MP> carve_marg_all(const Dims &d, bool lds_matrix, ldsd base_after_state, double *am_global,
+                                     size_t avail_doubles = 0) {
+  CarvedMarg<MP> c;
   size_t o = 0;
   auto take = [&](size_t n) {
     ldsd p = base_after_state + o;
@@ -86,8 +93,9 @@ VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, 
   };
   const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Flds;
   ldsd Am = lds_matrix ? take(pos * pos) : nullptr;
-  ldsd bm = take(pos), tol = take(pos), hff = take(F), gf = take(F), einv = take(F);
-  ldsd prdx = take(d.Ncap), prr = take(d.Ncap);
+  MargWorkT<MP> &m = c.m;
+  m.bm = take(pos), m.tol = take(pos), m.hff = take(F), m.gf = take(F), m.einv = take(F);
+  m.prdx = take(d.Ncap), m.prr = take(d.Ncap);
   ldsd ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
   // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows;
   // in the global-matrix variant the staging area follows the matrix in the scratch buffer
@@ -101,15 +109,21 @@ VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, 
     stage_slots = 512;
     stage_global = am_global ? am_global + pos * pos + 8 : nullptr;
   }
-  if (m) {
-    m->stage = MatPick<MP>::get(lds_matrix, stage, stage_global), m->stage_slots = (int)stage_slots;
-    m->Am = MatPick<MP>::get(lds_matrix, Am, am_global), m->ld = (int)pos, m->bm = bm, m->tol = tol;
-    m->hff = hff, m->gf = gf, m->einv = einv, m->prdx = prdx, m->prr = prr;
-    ldsi ip = reinterpret_cast<ldsi>(ints);
-    m->col_pose = ip, m->col_sb = ip + d.Pcap + 1, m->col_ex = m->col_sb + d.Pcap;
-    m->pcol = m->col_ex + 1, m->meta = m->pcol + d.Ncap;
-  }
-  return o * sizeof(double);
+  m.stage = MatPick<MP>::get(lds_matrix, stage, stage_global), m.stage_slots = (int)stage_slots;
+  m.Am = MatPick<MP>::get(lds_matrix, Am, am_global), m.ld = (int)pos;
+  ldsi ip = reinterpret_cast<ldsi>(ints);
+  m.col_pose = ip, m.col_sb = ip + d.Pcap + 1, m.col_ex = m.col_sb + d.Pcap;
+  m.pcol = m.col_ex + 1, m.meta = m.pcol + d.Ncap;
+  c.bytes = o * sizeof(double);
+  return c;
+}
+// Pointer form for host code. Returns bytes used (base may be null to just measure).
+template <class MP, class Dims>
+VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, double *am_global, MargWorkT<MP> *m,
+                         size_t avail_doubles = 0) {
+  const CarvedMarg<MP> c = carve_marg_all<MP>(d, lds_matrix, base_after_state, am_global, avail_doubles);
+  if (m) *m = c.m;
+  return c.bytes;
 }
 
 template <class MW>

@@ -40,7 +40,15 @@
 #define VIO_SYNC() __syncthreads()
 #define VIO_ATOMIC_ADD(p, v) ::vio::atomic_add((p), (v))
 #endif
-#define VIO_PARFOR(i, n) for (int i = (int)cx.tid; i < (int)(n); i += (int)cx.nt)
+// The thread index every phase starts from passes through an empty asm: LLVM otherwise hoists the per-lane address
+// arithmetic of ALL phases out of the trust-region loop (loop-invariant), keeps hundreds of values alive across the whole
+// kernel and spills them to scratch -- a scratch_load (L2 latency) where two integer instructions would do.
+#ifdef VIO_EMUL
+#define VIO_TID(cx) ((int)(cx).tid)
+#else
+#define VIO_TID(cx) ::vio::opaque_tid((int)(cx).tid)
+#endif
+#define VIO_PARFOR(i, n) for (int i = VIO_TID(cx); i < (int)(n); i += (int)cx.nt)
 
 // LDS pointers carry their address space in the type: generic pointers make hipcc emit flat_load/flat_store for every
 // LDS access (no ds_read/ds_write at all in the first version of this kernel), which is several times slower.
@@ -51,6 +59,13 @@
 #endif
 
 namespace vio {
+
+#ifndef VIO_EMUL
+__device__ __forceinline__ int opaque_tid(int t) {
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#endif
 
 typedef VIO_AS3 double *ldsd;
 typedef const VIO_AS3 double *cldsd;
@@ -590,7 +605,7 @@ template <class MP>
 VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
   const int W = v.W;
   VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
-  const int j = cx.tid & 31, slot = cx.tid >> 5, nslots = cx.nt >> 5;
+  const int tid_ = VIO_TID(cx), j = tid_ & 31, slot = tid_ >> 5, nslots = cx.nt >> 5;
   for (int f0 = 0; f0 < W; f0 += nslots) {
     const int f = f0 + slot;
     const bool act = f < W && j < 30;
@@ -1004,7 +1019,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     }
 #else
     {
-      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+      const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
       const int li = lane & 15, kq = lane >> 4;
       // bucket descriptors of this wave's rounds, one round per lane (a dependent global load per round otherwise)
       const int pl = wave + lane * nw;
@@ -1165,7 +1180,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     // The f64 accumulator layout of T (lane l, element r <-> T[(l>>4)+4r][l&15]) IS the B-operand layout of k-step r,
     // so T never leaves the registers.
     {
-      const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+      const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
       const int n = lane & 15, kq = lane >> 4;
       for (int f = wave; f < v.W; f += nw) {
         const double *info = v.imu_info + f * 225, *Jr = v.imu_J + f * 450, *rr = v.imu_r + f * 15;
@@ -1321,7 +1336,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   {
     // Landmark Schur complement as a GEMM on the matrix cores: C(n6 x n6, lower tiles) = (Ws E^-1) Ws^T, K = F.
     const int T = (n6 + 15) / 16, npairs = T * (T + 1) / 2;
-    const int wave = cx.tid >> 6, lane = cx.tid & 63, nw = cx.nt >> 6;
+    const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int ksteps = (F + 3) / 4;
     constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
@@ -1467,7 +1482,7 @@ template <class WK>
 VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
   const int nb = v.nblk;
   // the wave index as a scalar: block loops and addresses then run on the scalar unit
-  const int wave = __builtin_amdgcn_readfirstlane(cx.tid >> 6), nw = cx.nt >> 6, lane = cx.tid & 63;
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
   const LaneMap m = lane_map(lane);
   if (wave == 0) {
     bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
@@ -1610,7 +1625,7 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) 
     }
   }
 #else
-  const int wave = cx.tid >> 6, lane = cx.tid & 63;
+  const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63;
   auto solve_diag = [&](int k) {  // x_k <- L_kk^-T x_k, lanes 0..14 of the calling wave
     auto D = w.Hm + blk_off(k, k);
     const int c = lane < kBS ? lane : 0;
@@ -1641,7 +1656,7 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       solve_diag(k - 1);
     } else {
-      for (int q = (int)cx.tid - 64; q < (k - 1) * kBS; q += (int)cx.nt - 64) apply(k, q / kBS, q % kBS);
+      for (int q = tid_ - 64; q < (k - 1) * kBS; q += (int)cx.nt - 64) apply(k, q / kBS, q % kBS);
     }
     VIO_SYNC();
   }

@@ -44,12 +44,14 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   WinView v = make_view(B, b);
   typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
   ldsd lds = (ldsd)smem;
-  WorkT<MatP> w;
+  // (by value: neither struct ever has its address taken, so both live in registers)
+  const Carved<MatP> cw = carve_all<MatP>(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm);
+  WorkT<MatP> w = cw.w;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
-  size_t state_end = 0;
-  carve_work(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, &w, &cx, &state_end);
+  cx.red = cw.red, cx.lprof = cw.lprof;
+  const size_t state_end = cw.state_end_doubles;
   solve_window(cx, v, w);
 
   MargOut mo;
@@ -59,8 +61,7 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
   mo.ncap = B.d.Ncap;
   if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
-  MargWorkT<MatP> mw;
-  carve_marg(B.d, LDS_MATRIX, lds + state_end, mo.scratch, &mw, (size_t)lds_doubles - state_end);
+  MargWorkT<MatP> mw = carve_marg_all<MatP>(B.d, LDS_MATRIX, lds + state_end, mo.scratch, (size_t)lds_doubles - state_end).m;
   __syncthreads();
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
   if (cx.prof && cx.tid == 0) {  // stage counters: LDS -> global
