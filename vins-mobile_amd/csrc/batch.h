@@ -19,7 +19,7 @@
 namespace vio {
 
 constexpr int kHdrInts = 12;
-enum { H_W = 0, H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_PRIOR_N, H_PRIOR_NB, H_USE_ORIGIN, H_NPAIRS, H_NSLOTS };
+enum { H_W = 0, H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_PRIOR_N, H_PRIOR_NB, H_USE_ORIGIN, H_NPAIRS, H_NSLOTS, H_NREV };
 constexpr int kHdrDoubles = 4;
 constexpr int kMaxPriorBlocks = VIO_MAX_PRIOR_BLOCKS;
 
@@ -130,7 +130,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.fslot = B.fslot + b * B.s.fint, v.fstart = B.fstart + b * B.s.fstart;
   v.pair_h = B.pair_h + b * B.s.pair, v.pair_t = B.pair_t + b * B.s.pair;
   v.pair_s0 = B.pair_s0 + b * B.s.pair, v.pair_s1 = B.pair_s1 + b * B.s.pair;
-  v.npairs = h[H_NPAIRS], v.nslots = h[H_NSLOTS], v.n6cap = B.d.n6cap;
+  v.npairs = h[H_NPAIRS], v.nslots = h[H_NSLOTS], v.n6cap = B.d.n6cap, v.nrev = h[H_NREV];
   v.pts_i = B.pts_i + b * B.s.pts, v.pts_j = B.pts_j + b * B.s.pts;
   v.preint = B.preint + b * B.s.preint;
   v.pr_kind = B.pr_kind + b * B.s.pr_int, v.pr_index = B.pr_index + b * B.s.pr_int;
@@ -303,12 +303,13 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
   if ((F > 0 && !w.inv_depth) || (M > 0 && (!w.factor_host || !w.factor_target || !w.factor_feature ||
                                             !w.factor_pts_i || !w.factor_pts_j)))
     return VIO_EINVAL;
-  int has_loop = 0;
+  int has_loop = 0, nrev = 0;
   for (int k = 0; k < M; k++) {
     int h = w.factor_host[k], t = w.factor_target[k], f = w.factor_feature[k];
     if (f < 0 || f >= F || h < 0 || h >= P || t < 0 || t > P || t == h) return VIO_EINVAL;
     if (k > 0 && f < w.factor_feature[k - 1]) return VIO_EINVAL;  // factors come grouped by ascending feature
     if (t == P) has_loop = 1;
+    if (t < h) nrev++;
   }
   {
     // Device-side accumulation layout: factors bucketed by (host, target) pair, each bucket starting on an even slot
@@ -342,7 +343,7 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
   if (has_loop && (w.loop_frame < 0 || w.loop_frame >= W)) return VIO_EINVAL;
   int *h = &hb.hdr[(size_t)b * kHdrInts];
   h[H_W] = W, h[H_F] = F, h[H_M] = M, h[H_HAS_LOOP] = has_loop, h[H_LOOP_FRAME] = w.loop_frame;
-  h[H_MARG] = w.marginalization_flag, h[H_USE_ORIGIN] = w.use_origin_override;
+  h[H_MARG] = w.marginalization_flag, h[H_USE_ORIGIN] = w.use_origin_override, h[H_NREV] = nrev;
   double *hd = &hb.hdr_d[(size_t)b * kHdrDoubles];
   hd[0] = w.origin_yaw_deg, hd[1] = w.origin_p[0], hd[2] = w.origin_p[1], hd[3] = w.origin_p[2];
   memcpy(&hb.pose[b * s.pose], w.pose, sizeof(double) * 7 * P);

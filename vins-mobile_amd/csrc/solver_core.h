@@ -137,6 +137,7 @@ struct WinView {
   const int *fstart;                    // [F+1] factor range of every feature
   const int *pair_h, *pair_t, *pair_s0, *pair_s1;  // [npairs] bucket -> frames and slot range
   int npairs, nslots, n6cap;
+  int nrev;      // number of factors whose target frame precedes their host (never produced by the reference's factor list)
   const double *pts_i, *pts_j;
   const double *preint;
   const int *pr_kind, *pr_index, *pr_offset;
@@ -401,7 +402,8 @@ VIO_DEV void projection_eval_rot(double s_info, PR Ri_, PA pose_i, PR Rj_, PA po
   for (int k = 0; k < 9; k++) Ri[k] = Ri_[k], Rj[k] = Rj_[k], ric[k] = ric_[k];
   const double tic[3] = {ex[0], ex[1], ex[2]};
   const double pi3[3] = {pts_i[0], pts_i[1], pts_i[2]};
-  const double pc_i[3] = {pi3[0] / inv_dep, pi3[1] / inv_dep, pi3[2] / inv_dep};
+  const double dep_i = rcp_f(inv_dep);
+  const double pc_i[3] = {pi3[0] * dep_i, pi3[1] * dep_i, pi3[2] * dep_i};
   double p_imu_i[3], p_w[3], p_imu_j[3], p_c_j[3], d[3], e[3];
   for (int a = 0; a < 3; a++) p_imu_i[a] = ric[3 * a] * pc_i[0] + ric[3 * a + 1] * pc_i[1] + ric[3 * a + 2] * pc_i[2] + tic[a];
   for (int a = 0; a < 3; a++) p_w[a] = Ri[3 * a] * p_imu_i[0] + Ri[3 * a + 1] * p_imu_i[1] + Ri[3 * a + 2] * p_imu_i[2] + pose_i[a];
@@ -409,12 +411,12 @@ VIO_DEV void projection_eval_rot(double s_info, PR Ri_, PA pose_i, PR Rj_, PA po
   for (int a = 0; a < 3; a++) p_imu_j[a] = Rj[a] * d[0] + Rj[3 + a] * d[1] + Rj[6 + a] * d[2];  // R_j^T d
   for (int a = 0; a < 3; a++) e[a] = p_imu_j[a] - tic[a];
   for (int a = 0; a < 3; a++) p_c_j[a] = ric[a] * e[0] + ric[3 + a] * e[1] + ric[6 + a] * e[2];  // r_ic^T e
-  const double dep_j = p_c_j[2];
-  r[0] = s_info * (p_c_j[0] / dep_j - pts_j[0]);
-  r[1] = s_info * (p_c_j[1] / dep_j - pts_j[1]);
+  const double idep_j = rcp_f(p_c_j[2]);
+  r[0] = s_info * (p_c_j[0] * idep_j - pts_j[0]);
+  r[1] = s_info * (p_c_j[1] * idep_j - pts_j[1]);
   if (!jac) return;
   // reduce (2x3, projection_facor.cpp:46-50) has the sparsity [s/z 0 -s x/z^2 ; 0 s/z -s y/z^2]
-  const double rz = s_info * (1. / dep_j), rx = s_info * (-p_c_j[0] / (dep_j * dep_j)), ry = s_info * (-p_c_j[1] / (dep_j * dep_j));
+  const double rz = s_info * idep_j, rx = -(rz * p_c_j[0]) * idep_j, ry = -(rz * p_c_j[1]) * idep_j;
   double A[9];  // r_ic^T R_j^T
   for (int a = 0; a < 3; a++)
     for (int b = 0; b < 3; b++) A[3 * a + b] = ric[a] * Rj[3 * b] + ric[3 + a] * Rj[3 * b + 1] + ric[6 + a] * Rj[3 * b + 2];
@@ -439,7 +441,7 @@ VIO_DEV void projection_eval_rot(double s_info, PR Ri_, PA pose_i, PR Rj_, PA po
     Jj[i * 6 + 3] = t[1] * p_imu_j[2] - t[2] * p_imu_j[1];
     Jj[i * 6 + 4] = t[2] * p_imu_j[0] - t[0] * p_imu_j[2];
     Jj[i * 6 + 5] = t[0] * p_imu_j[1] - t[1] * p_imu_j[0];
-    Jl[i] = (RC[3 * i] * pi3[0] + RC[3 * i + 1] * pi3[1] + RC[3 * i + 2] * pi3[2]) * -1.0 / (inv_dep * inv_dep);
+    Jl[i] = -(RC[3 * i] * pi3[0] + RC[3 * i + 1] * pi3[1] + RC[3 * i + 2] * pi3[2]) * (dep_i * dep_i);
   }
 }
 
@@ -933,14 +935,21 @@ constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 
 
 // One element D[row][col] of a (host,target) bucket's Gram matrix G^T G, G = [Ji(6) | Jj(6) | r | Jl | 0 0] per row:
 // host-host, target-target and target-host 6x6 blocks go to the pose-pose accumulator PP, row 12 is J^T r.
+// pp_mode: how the target-host block reaches PP. A (host, target) bucket belongs to ONE wave and, unless the window also
+// holds the reversed pair, is the only contributor of its off-diagonal block: 1 = plain store (the bucket's first chunk:
+// nothing has to be zeroed beforehand), 2 = plain read-modify-write (a bucket continued from the previous chunk, same
+// wave), 0 = atomic add into a zeroed PP (windows with reversed pairs; an L2 atomic round trip per element).
 template <class WK>
-VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col, double val) {
+VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col, double val, int pp_mode) {
   if (row < 6) {
     if (col <= row) VIO_ATOMIC_ADD(w.ppd + h * 36 + row * 6 + col, val);
   } else if (row < 12) {
     if (col < 6) {
-      if (t > h) VIO_ATOMIC_ADD(v.PP + (t * (t + 1) / 2 + h) * 36 + (row - 6) * 6 + col, val);
-      else VIO_ATOMIC_ADD(v.PP + (h * (h + 1) / 2 + t) * 36 + col * 6 + (row - 6), val);
+      double *dst = t > h ? v.PP + (t * (t + 1) / 2 + h) * 36 + (row - 6) * 6 + col
+                          : v.PP + (h * (h + 1) / 2 + t) * 36 + col * 6 + (row - 6);
+      if (pp_mode == 1) *dst = val;
+      else if (pp_mode == 2) *dst += val;
+      else VIO_ATOMIC_ADD(dst, val);
     } else if (col < 12 && col <= row) {
       VIO_ATOMIC_ADD(w.ppd + t * 36 + (row - 6) * 6 + (col - 6), val);
     }
@@ -981,7 +990,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       double sq = r[0] * r[0] + r[1] * r[1];
       double sum = 1.0 + sq * cc;
       cost += 0.5 * bb * log(sum);
-      double sr = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));  // Corrector: rho'' < 0 => scale by sqrt(rho')
+      double sr = rsqrt_f(sum);  // Corrector: rho'' < 0 => scale by sqrt(rho') = 1 / sqrt(1 + s / b)   (sum >= 1)
       auto g = G + slot * kSlotStride;
 #pragma unroll
       for (int rr = 0; rr < 2; rr++) {
@@ -1014,13 +1023,34 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
           for (int sl = s_lo; sl < s_hi; sl++)
             for (int rr = 0; rr < 2; rr++)
               d += G[(sl - c0) * kSlotStride + rr * kRowLen + row] * G[(sl - c0) * kSlotStride + rr * kRowLen + col];
-          gram_flush(v, w, v.pair_h[p], v.pair_t[p], row, col, d);
+          gram_flush(v, w, v.pair_h[p], v.pair_t[p], row, col, d, v.nrev ? 0 : (v.pair_s0[p] >= c0 ? 1 : 2));
         }
     }
 #else
     {
-      const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
+      const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
       const int li = lane & 15, kq = lane >> 4;
+      // Where this lane's four accumulator elements (rows kq + 4 r4, column li of G^T G) go is a property of the lane,
+      // not of the bucket: one LDS target  base + (h or t) * mul  (diagonal pose blocks in ppd, J^T r in gp) or one
+      // entry of the bucket's off-diagonal block in PP. Worked out once, a flush is 4 LDS atomics + 4 stores under
+      // two predicates each instead of a dozen divergent branches per element.
+      ldsd f_base[4];
+      int f_mul[4], f_goff[4];
+      bool f_t[4], f_lds[4], f_glb[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int row = kq + 4 * r4, col = li;
+        f_lds[r4] = false, f_glb[r4] = false, f_t[r4] = false, f_mul[r4] = 36, f_goff[r4] = 0, f_base[r4] = w.ppd;
+        if (row < 6) {
+          if (col <= row) f_lds[r4] = true, f_base[r4] = w.ppd + row * 6 + col;
+        } else if (row < 12) {
+          if (col < 6) f_glb[r4] = true, f_goff[r4] = (row - 6) * 6 + col;
+          else if (col < 12 && col <= row) f_lds[r4] = true, f_t[r4] = true, f_base[r4] = w.ppd + (row - 6) * 6 + (col - 6);
+        } else if (row == 12) {
+          if (col < 6) f_lds[r4] = true, f_mul[r4] = kBS, f_base[r4] = w.gp + col;
+          else if (col < 12) f_lds[r4] = true, f_t[r4] = true, f_mul[r4] = kBS, f_base[r4] = w.gp + col - 6;
+        }
+      }
       // bucket descriptors of this wave's rounds, one round per lane (a dependent global load per round otherwise)
       const int pl = wave + lane * nw;
       const bool pv = pl < v.npairs;
@@ -1058,8 +1088,19 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         }
         acc += acc2;
         const int h = b_ht >> 16, t = b_ht & 0xffff;
+        if (v.nrev) {  // (windows with reversed (host, target) pairs: general element-wise path)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) gram_flush(v, w, h, t, kq + 4 * r4, li, acc[r4]);
+          for (int r4 = 0; r4 < 4; r4++) gram_flush(v, w, h, t, kq + 4 * r4, li, acc[r4], 0);
+        } else {
+          // the bucket's off-diagonal block (t > h): first chunk of the bucket stores, a continued bucket adds
+          double *ppb = v.PP + (t * (t + 1) / 2 + h) * 36;
+          const bool first = b_s0 >= c0;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; r4++) {
+            if (f_lds[r4]) VIO_ATOMIC_ADD(f_base[r4] + (f_t[r4] ? t : h) * f_mul[r4], acc[r4]);
+            if (f_glb[r4]) ppb[f_goff[r4]] = first ? acc[r4] : ppb[f_goff[r4]] + acc[r4];
+          }
+        }
       }
     }
 #endif
@@ -1106,7 +1147,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
       VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
     }
-    VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;
+    if (v.nrev) VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
     VIO_PARFOR(q, nF * 36) w.ppd[q] = 0.0;
     VIO_SYNC();
     cost += projections_jac(cx, v, w, pose, feat, have_scale);
@@ -1143,15 +1184,27 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       }
       VIO_SYNC();
     }
-    // pose-pose blocks of the projection factors
+    // pose-pose blocks of the projection factors: diagonal blocks from LDS, one off-diagonal block per bucket
     const int nF = v.P + v.has_loop;
-    VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) {
-      int blk = q / 36, e = q - blk * 36, r = e / 6, c = e - r * 6;
-      int a = 0;
-      while ((a + 1) * (a + 2) / 2 <= blk) a++;
-      int b = blk - a * (a + 1) / 2;
-      if (a != b) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
-      else if (r >= c) *mat_at(w.Hm, kBS * a + r, kBS * a + c) += w.ppd[a * 36 + e];
+    VIO_PARFOR(q, nF * 36) {
+      const int a = q / 36, e = q - a * 36, r = e / 6, c = e - r * 6;
+      if (r >= c) *mat_at(w.Hm, kBS * a + r, kBS * a + c) += w.ppd[q];
+    }
+    if (v.nrev) {
+      VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) {
+        int blk = q / 36, e = q - blk * 36, r = e / 6, c = e - r * 6;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= blk) a++;
+        int b = blk - a * (a + 1) / 2;
+        if (a != b) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
+      }
+    } else {
+      VIO_PARFOR(q, v.npairs * 36) {  // (blocks without a bucket were never written and are not read)
+        const int pq = q / 36, e = q - pq * 36, r = e / 6, c = e - r * 6;
+        const int h = v.pair_h[pq], t = v.pair_t[pq];
+        const int a = t > h ? t : h, b = t > h ? h : t;
+        *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[(a * (a + 1) / 2 + b) * 36 + e];
+      }
     }
     VIO_SYNC();
   }
@@ -1284,12 +1337,16 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 // new linearization, so they are recomputed where needed instead of living in LDS (16 bytes per landmark that decide
 // whether a window's matrix still fits next to its vectors).
 template <class WK>
+VIO_DEV double feat_d2(const WK &w, int f) {  // D_f^2 (clamped: always in [1e-6, 1e32])
+  return fmin(fmax(w.sf[f] * w.sf[f] * w.hff[f], 1e-6), 1e32);
+}
+template <class WK>
 VIO_DEV double feat_d(const WK &w, int f) {
-  return sqrt(fmin(fmax(w.sf[f] * w.sf[f] * w.hff[f], 1e-6), 1e32));
+  return sqrt_f(feat_d2(w, f));
 }
 template <class WK>
 VIO_DEV double feat_gd(const WK &w, int f) {
-  return w.sf[f] * w.gf[f] / feat_d(w, f);
+  return w.sf[f] * w.gf[f] * rsqrt_f(feat_d2(w, f));
 }
 
 template <class WK>
@@ -1301,9 +1358,9 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   // over the landmark coupling W is needed, and y = z / s at the end. (Cholesky is invariant under this diagonal
   // congruence up to rounding; a non-positive pivot appears in both forms or in neither.)
   VIO_PARFOR(f, F) {
-    const double c = feat_d(w, f) / w.sf[f];
-    const double e = w.hff[f] + mu * c * c;  // E_f
-    const double ei = 1.0 / e;
+    const double isf = rcp_f(w.sf[f]);
+    const double e = w.hff[f] + mu * (feat_d2(w, f) * isf * isf);  // E_f = H_ff + mu (D_f / s_f)^2
+    const double ei = rcp_f(e);
     w.ef[f] = e;
     w.einv[f] = ei;
     w.tf[f] = w.gf[f] * ei;  // g_f / E_f
@@ -1311,7 +1368,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   }
   VIO_PARFOR(i, v.nblk * kBS) {
     if (i < np) {
-      const double c = w.dp[i] / w.sp[i];
+      const double c = w.dp[i] * rcp_f(w.sp[i]);
       *mat_at(w.Hm, i, i) += mu * c * c;
       w.t1[i] = w.gp[i];
     } else {
@@ -1708,7 +1765,7 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
   VIO_SYNC();
   double acc = 0;
   VIO_PARFOR(f, F) {
-    double u = w.sf[f] * vf[f] + w.tf[f] / w.ef[f];
+    double u = w.sf[f] * vf[f] + w.tf[f] * w.einv[f];
     acc += w.ef[f] * u * u;
   }
   VIO_PARFOR(j, np) acc += w.t1[j] * w.t1[j];
@@ -1782,8 +1839,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
 
   double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, false);
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
-  VIO_PARFOR(i, np) w.sp[i] = 1.0 / (1.0 + sqrt(w.hdiag[i]));  // Jacobi scaling, :239-254
-  VIO_PARFOR(f, F) w.sf[f] = 1.0 / (1.0 + sqrt(w.hff[f]));
+  VIO_PARFOR(i, np) w.sp[i] = rcp_f(1.0 + sqrt_f(w.hdiag[i]));  // Jacobi scaling, :239-254
+  VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f]));
   VIO_SYNC();
   double gmax = grad_max_norm();
   double radius = 1e4, mu = 1e-8;
@@ -1807,10 +1864,10 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       reuse = true;
       double part = 0;
       VIO_PARFOR(i, np) {
-        double c = w.sp[i] * w.sp[i] * w.hdiag[i];
-        double d = sqrt(fmin(fmax(c, 1e-6), 1e32));
+        double c = fmin(fmax(w.sp[i] * w.sp[i] * w.hdiag[i], 1e-6), 1e32);
+        double d = sqrt_f(c);
         w.dp[i] = d;
-        double g = w.sp[i] * w.gp[i] / d;
+        double g = w.sp[i] * w.gp[i] * rsqrt_f(c);
         w.gdp[i] = g;
         part += g * g;
       }
@@ -1861,12 +1918,12 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
           }
           VIO_SYNC();
           VIO_PARFOR(f, F) {
-            double y = (w.tf[f] - w.gnf[f] / w.ef[f]) / w.sf[f];
+            double y = (w.tf[f] - w.gnf[f] * w.einv[f]) * rcp_f(w.sf[f]);
             w.gnf[f] = -feat_d(w, f) * y;
             if (!isfinite(y)) bad = 1;
           }
           VIO_PARFOR(i, np) {
-            double y = w.t1[i] / w.sp[i];
+            double y = w.t1[i] * rcp_f(w.sp[i]);
             w.gnp[i] = -w.dp[i] * y;
             if (!isfinite(y)) bad = 1;
           }
@@ -1880,15 +1937,15 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         // Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192)
         double part2 = 0;
         VIO_PARFOR(i, np) {
-          double u = w.gdp[i] / w.dp[i];
+          double u = w.gdp[i] * rcp_f(w.dp[i]);
           w.t2[i] = u;
           part2 += mu_used * w.dp[i] * w.dp[i] * u * u;
         }
         VIO_PARFOR(f, F) {
-          const double d = feat_d(w, f);
-          double u = w.sf[f] * w.gf[f] / d / d;
+          const double d2 = feat_d2(w, f);
+          double u = w.sf[f] * w.gf[f] * rcp_f(d2);
           w.stf[f] = u;
-          part2 += mu_used * d * d * u * u;
+          part2 += mu_used * d2 * u * u;
         }
         VIO_SYNC();
         double reg = block_sum(cx, part2);
@@ -1930,19 +1987,19 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       VIO_PARFOR(i, np) {
         double s = ca * w.gdp[i] + cb * w.gnp[i];
         pn += s * s;
-        double st = s / w.dp[i];
+        double st = s * rcp_f(w.dp[i]);
         w.stp[i] = st;
         psg += st * w.sp[i] * w.gp[i];
         preg += mu_used * w.dp[i] * w.dp[i] * st * st;
       }
       VIO_PARFOR(f, F) {
-        const double d = feat_d(w, f);
-        double s = ca * (w.sf[f] * w.gf[f] / d) + cb * w.gnf[f];
+        const double d2 = feat_d2(w, f), id = rsqrt_f(d2);
+        double s = ca * (w.sf[f] * w.gf[f] * id) + cb * w.gnf[f];
         pn += s * s;
-        double st = s / d;
+        double st = s * id;
         w.stf[f] = st;
         psg += st * w.sf[f] * w.gf[f];
-        preg += mu_used * d * d * st * st;
+        preg += mu_used * d2 * st * st;
       }
       VIO_SYNC();
       block_sum3(cx, pn, psg, preg);

@@ -15,6 +15,47 @@
 
 namespace vio {
 
+// Reciprocal, square root and reciprocal square root for the solver kernels. On the device an IEEE f64 division costs
+// ~85 cycles of dependent latency and sqrt ~120 (div_scale / div_fmas / div_fixup sequences); the hardware seeds
+// (v_rcp_f64, v_rsq_f64: ~26 bits) with two Newton steps cost ~50 and are good to an ulp or two, which is far inside
+// the solver's 1e-6 bar. No special-case handling beyond what is noted: callers pass finite, non-zero (rcp) or
+// positive (rsqrt) arguments; sqrt_f maps 0 to 0. Host builds (and the host emulation of the kernels) use the exact
+// operations.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VIO_EMUL)
+#define VIO_FAST_F64 1
+#endif
+VIO_HD double rcp_f(double x) {
+#ifdef VIO_FAST_F64
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+VIO_HD double rsqrt_f(double x) {
+#ifdef VIO_FAST_F64
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+VIO_HD double sqrt_f(double x) {
+#ifdef VIO_FAST_F64
+  const double y = rsqrt_f(x);
+  double s = x * y;
+  s = fma(0.5 * y, fma(-s, s, x), s);
+  return x == 0.0 ? 0.0 : s;  // (negative / NaN arguments keep the NaN)
+#else
+  return sqrt(x);
+#endif
+}
+
 struct Quat {
   double x, y, z, w;
 };
@@ -25,11 +66,21 @@ VIO_HD Quat qmul(const Quat &a, const Quat &b) {
 }
 VIO_HD Quat qinv(const Quat &q) {  // conjugate / squaredNorm
   double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+#ifdef VIO_FAST_F64
+  const double in = rcp_f(n2);
+  return Quat{-q.x * in, -q.y * in, -q.z * in, q.w * in};
+#else
   return Quat{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
+#endif
 }
 VIO_HD Quat qnormalized(const Quat &q) {
+#ifdef VIO_FAST_F64
+  const double in = rsqrt_f(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  return Quat{q.x * in, q.y * in, q.z * in, q.w * in};
+#else
   double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   return Quat{q.x / n, q.y / n, q.z / n, q.w / n};
+#endif
 }
 VIO_HD void qrot(const Quat &q, const double v[3], double out[3]) {
   double ux = 2 * (q.y * v[2] - q.z * v[1]), uy = 2 * (q.z * v[0] - q.x * v[2]), uz = 2 * (q.x * v[1] - q.y * v[0]);
