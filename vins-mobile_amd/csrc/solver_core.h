@@ -1852,7 +1852,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   double min_rec = x_cost;
   record(0, x_cost, radius, 0, 0, gmax, true, true);
   if (cx.tid == 0) sd[0] = x_cost;
-  double gd_sq = 0, mu_used = mu;
+  double gd_sq = 0, mu_used = mu, qf_cauchy = 0;
 
   while (true) {
     if (it >= v.max_iter) break;
@@ -1950,9 +1950,9 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         VIO_SYNC();
         double reg = block_sum(cx, part2);
         stamp(cx, ST_DOGLEG);
-        double qf = quad_form(cx, v, w, w.t2, w.stf);
+        qf_cauchy = quad_form(cx, v, w, w.t2, w.stf);
         stamp(cx, ST_QUADFORM);
-        alpha = gd_sq / (qf - reg);
+        alpha = gd_sq / (qf_cauchy - reg);
       }
     }
     (void)have_factor;
@@ -2005,10 +2005,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       block_sum3(cx, pn, psg, preg);
       double n2 = pn, sg = psg, reg = preg;
       if (need_norm) dogleg_step_norm = sqrt(n2);
-      // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416)
+      // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416). The dogleg step is a
+      // combination  v = ca a - cb y  of the Cauchy direction a = D^-2 S g and the Gauss-Newton solution y of
+      // M y = S g, M = S H S + mu D^2, so its quadratic form needs no third pass over the factor and the landmark
+      // coupling:  v^T M v = ca^2 a^T M a - 2 ca cb a^T (S g) + cb^2 y^T (S g), with a^T M a the Cauchy form above,
+      // a^T S g = |g_d|^2 and y^T S g = -g_d . gn, all reduced already. (Exact up to the residual of the linear solve.)
       stamp(cx, ST_DOGLEG);
-      double shs = quad_form(cx, v, w, w.stp, w.stf) - reg;
-      stamp(cx, ST_QUADFORM);
+      double shs = ca * ca * qf_cauchy - 2.0 * ca * cb * gd_sq - cb * cb * gdot - reg;
       model_cost_change = -sg - 0.5 * shs;
       step_valid = model_cost_change > 0.0;
     }
