@@ -4,13 +4,19 @@
 One step = one camera frame for every resident sequence through the whole hot path:
     FeatureTracker::readImage  (pyramid, pyramidal LK, F-RANSAC, setMask, Shi-Tomasi detection)   [publish frame]
     VINS::solve_ceres          (10-iteration dogleg solve, new2old, marginalization)
-Workload = BASELINE.json configs[1]: 640x480 frames, up to 150 features, window 10, ~800 projection factors.
-Every frame is published (the conservative reading of "KLT + window solve" per frame; the reference publishes every
-3rd frame). Inputs (frames, windows) are resident in HBM before the timed region; sequences are independent, so N
-GPUs run N x the sequences with no data-path collective (weak scaling).
+Workload = BASELINE.json configs[1]: 640x480 frames, up to 150 features, window 10, ~800 projection factors, and — as
+every steady-state solve_ceres call has (VINS.cpp:508-513) — the marginalization prior left by the preceding MARGIN_OLD
+solve. Every frame is published (the conservative reading of "KLT + window solve" per frame; the reference publishes
+every 3rd frame). Inputs (frames, windows) are resident in HBM before the timed region; sequences are independent, so
+N GPUs run N x the sequences with no data-path collective (weak scaling).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Besides the contract line's `roofline` and `cpu_baseline`, rank 0 at N = 1 adds secondary measurements (bounded, ~1.5
+minutes in total; `--quick` skips them): `cpu_baseline_all_cores` (one sequence per host core), `end_to_end` (the
+estimator path: host observations in, host states out), `ate` (closed-loop position error against the truth and against
+the CPU path on the same data) and `large_windows` (kernel time of configs[2] and configs[4]).
 """
 import argparse
 import ctypes as C
@@ -18,6 +24,7 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,26 +34,18 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
-# Memory-side traffic of vio_window_kernel per window from the PMC passes of this very workload
-# (profiles/r01_i_pmc_hbm.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, 256 windows per launch):
-# FETCH_SIZE 1004820 KB (doubled: gfx950 reports half the bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 952949 KB.
-# bench.py cannot collect counters itself; the figure is only attached when the profiled configuration is the one run.
-PMC_TRAFFIC_BYTES_PER_WINDOW = (2 * 1007830.6 + 953780.0) * 1024.0 / 256.0
-PMC_TRAFFIC_CONFIG = (10, 150)  # (window size, features) the passes were taken on
-# The same passes for the front-end kernels of one publish step of 256 sequences (sum over copy_frames, 3 x pyr_down,
-# lk_track, track_update, detect, corner_select): FETCH_SIZE 523110 KB (doubled) + WRITE_SIZE 272870 KB.
-PMC_FE_TRAFFIC_BYTES_PER_SEQUENCE = (2 * 523110.0 + 272870.0) * 1024.0 / 256.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
 
 
-def algorithmic_flops_per_solve(W, M, n_prior, iters):
+def algorithmic_flops_per_solve(W, M, n_prior, iters, n_features=150):
     """per GN iteration J^T J of projection / IMU / prior blocks, landmark Schur outer products,
     reduced Cholesky and factor evaluation; times the iterations actually run."""
     P = W + 1
     proj = M * 2 * 13 * 13 * 2
     imu = W * 15 * 30 * 30 * 2
     prior = 2.0 * n_prior ** 3 if n_prior else 0.0
-    kf = max(2.0, M / 150.0 + 1.0)
-    schur = 150 * (6 * kf) ** 2 * 2
+    kf = max(2.0, M / float(n_features) + 1.0)
+    schur = n_features * (6 * kf) ** 2 * 2
     chol = (15 * P) ** 3 / 3.0
     evalf = M * 500 + W * 3000
     return iters * (proj + imu + prior + schur + chol + evalf)
@@ -61,6 +60,39 @@ def algorithmic_bytes_per_tracked_frame(rows, cols, n_feats, levels=4, mean_iter
     return b
 
 
+def pmc_traffic(kernel_key, workload_key):
+    """HBM bytes per launch from the tracked PMC summary (FETCH_SIZE x correction + WRITE_SIZE), or None when the file
+    is absent or was taken on another workload."""
+    try:
+        d = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    k = d.get(kernel_key)
+    if not k or d.get("workload") != workload_key:
+        return None, None
+    return k.get("bytes_per_launch"), "profiles/%s: %s" % (os.path.basename(PMC_FILE), d.get("method", ""))
+
+
+def steady_state_windows(cfg, pkg, pre, seeds, n_features=150, with_loop=0, imu_per_frame=10):
+    """configs[1] windows as solve_ceres sees them in steady state: window A of a sequence is solved with MARGIN_OLD on
+    the device and the prior it leaves is carried by window B, one frame later on the same trajectory (how
+    tests/golden/make_golden.py builds win_chain_b_prior; SURVEY §8d C5 'a prior produced by a preceding MARGIN_OLD step')."""
+    synth, backend = pkg.synth, pkg.backend
+    first = [synth.make_window(cfg, pre, seed=1000 + s, traj_seed=s, frame_offset=0, n_features=n_features,
+                               imu_per_frame=imu_per_frame) for s in seeds]
+    solver = backend.WindowSolver(cfg, max_batch=len(first))
+    solver.solve(first)
+    solver.close()
+    out = []
+    for s, a in zip(seeds, first):
+        b = synth.make_window(cfg, pre, seed=2000 + s, traj_seed=s, frame_offset=1, n_features=n_features,
+                              imu_per_frame=imu_per_frame, with_loop=with_loop)
+        assert a.next_prior.n > 0
+        b.prior = a.next_prior.copy()
+        out.append(b)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sequences", type=int, default=256, help="independent sequences resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="contract line only (no secondary measurements)")
+    ap.add_argument("--no-prior", action="store_true", help="aid: first-solve windows without a marginalization prior")
     ap.add_argument("--streams", type=int, choices=[1, 2], default=1,
                     help="1: tracker and solver kernels in order on one HIP stream; 2: each on its own stream")
     ap.add_argument("--publish-every", type=int, default=1,
@@ -82,7 +116,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)   # the contexts below bind to this device (vio_amd.h, DEVICE BINDING)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: same code path for every world size
         import torch.distributed as dist_mod
@@ -104,8 +138,13 @@ def main():
                    for u in range(n_unique)]
     frames = np.stack([np.stack([uniq_frames[s % n_unique][f] for s in range(S)]) for f in range(T)])
     pre = lambda *a: backend.preintegrate(cfg, *a)
-    uniq_w = [synth.make_window(cfg, pre, seed=pkg.multi.seed_of_sequence(my_ids[u]), n_features=150) for u in range(8)]
+    seeds = [pkg.multi.seed_of_sequence(my_ids[u]) for u in range(8)]
+    if args.no_prior:
+        uniq_w = [synth.make_window(cfg, pre, seed=s, n_features=150) for s in seeds]
+    else:
+        uniq_w = steady_state_windows(cfg, pkg, pre, seeds)
     windows = [uniq_w[s % len(uniq_w)].copy() for s in range(S)]
+    n_prior = int(np.mean([w.prior.n if w.prior is not None else 0 for w in uniq_w]))
 
     fe = frontend.FeatureTracker(cfg, n_seq=S)
     fe.upload_frames(frames)
@@ -148,96 +187,264 @@ def main():
     stats = be.download(windows)
     iters = float(np.mean([s["iterations"] - 1 for s in stats]))
     M = float(np.mean([w.n_factors for w in windows]))
+    fe.close(), be.close()
 
     if rank == 0:
         frames_total = S * world * args.steps
         value = frames_total / dt
-        flops = algorithmic_flops_per_solve(cfg.window_size, M, 0, iters) * S
+        flops = algorithmic_flops_per_solve(cfg.window_size, M, n_prior, iters) * S
         achieved = flops / (be_ms * 1e-3) / 1e12
         fe_bytes = algorithmic_bytes_per_tracked_frame(rows, cols, 150) * S
+        wkey = "configs[1] x %d sequences, prior %d" % (S, n_prior)
+        be_traffic, be_src = pmc_traffic("vio_window_kernel", wkey)
+        fe_traffic, fe_src = pmc_traffic("frontend_step", wkey)
         out = {
             "metric": "VIO frames/sec (KLT+window solve), 640x480/150 feats/W=10" +
                       ("" if args.only == "both" else " [PARTIAL: %s only, not the metric]" % args.only),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (solve) / u8+i32+f32 (KLT)", "data": "synthetic",
-            "config": {"workload": "configs[1]: 640x480 stream, 150 feats, window=10, ~%d projection factors; every frame "
-                                   "published: KLT track + F-RANSAC + detect + 10-iteration window solve + marginalization" % M,
-                       "sequences_per_gpu": S, "publish_every": args.publish_every,
-                       "preprocessing": "none (the app's CLAHE pre-step is outside readImage)", "gn_iterations": iters, "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms}},
+            "config": {"workload": "configs[1]: 640x480 stream, 150 feats, window=10, ~%d projection factors, marginalization "
+                                   "prior of %d rows from the preceding MARGIN_OLD solve; every frame published: KLT track + "
+                                   "F-RANSAC + detect + 10-iteration window solve + marginalization" % (M, n_prior),
+                       "sequences_per_gpu": S, "publish_every": args.publish_every, "prior_rows": n_prior,
+                       "preprocessing": "none (the app's CLAHE pre-step is outside readImage)", "gn_iterations": iters,
+                       "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms}},
             "roofline": {"kernel": "vio_window_kernel (solve + new2old + marginalization, one workgroup per window)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_WINDOW * S if (cfg.window_size, 150) == PMC_TRAFFIC_CONFIG else None,
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_i_pmc_hbm.txt)"},
-            "roofline_frontend": {"kernel": "front-end step (copy + pyr_down x3 + lk_track + track_update + detect + corner_select)",
+                         "flops_per_solve": flops / S, "traffic": be_traffic,
+                         "traffic_unit": "bytes per launch; " + (be_src or "no PMC summary for this workload under profiles/")},
+            "roofline_frontend": {"kernel": "front-end step (pyr_down x3 + lk_track + track_update + detect + corner_select)",
                                   "bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": PMC_FE_TRAFFIC_BYTES_PER_SEQUENCE * S
-                                  if (rows, cols, cfg.max_corners, args.publish_every) == (640, 480, 150, 1) else None,
-                                  "traffic_unit": "bytes per step (PMC FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, "
-                                                  "profiles/r01_i_pmc_hbm.txt)"},
+                                  "traffic": fe_traffic,
+                                  "traffic_unit": "bytes per step; " + (fe_src or "no PMC summary for this workload under profiles/")},
         }
+        extras = world == 1 and args.only == "both" and not args.quick
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, abi, uniq_frames[0], uniq_w)
+            base = CpuBaseline(cfg, abi, uniq_frames, uniq_w)
+            out["cpu_baseline"] = base.one_core(seconds=5.0)
+            if extras:
+                out["cpu_baseline_all_cores"] = base.all_cores(seconds=6.0)
+        if extras:
+            out["end_to_end"] = guarded(lambda: end_to_end(S))
+            out["ate"] = guarded(lambda: closed_loop_ate(cfg, pkg))
+            out["large_windows"] = guarded(lambda: large_windows(pkg))
         print(json.dumps(out))
-    fe.close(), be.close()
     if dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, abi, stream, uniq_windows):
-    """The same per-frame work on ONE host core (the reference runs Ceres with num_threads = 1, VINS.cpp:642):
-    front-end = CPU restatement (OpenCV is not available anywhere: 'port'); window solve = the real reference
-    (vendored Ceres 1.12 + VINS factors, oracle/_ref) when its prebuilt library travelled here, else the restatement."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers as H
-    trk = H.OracleTracker(cfg)
-    t_fe, n_fe = 0.0, 0
-    order = [0, 1, 2, 3, 2, 1]
-    trk.read_image(stream[0], True)
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 6.0:
-        trk.read_image(stream[order[(n_fe + 1) % len(order)]], True)
-        n_fe += 1
-    t_fe = (time.perf_counter() - t0) / n_fe
-    trk.close()
-    ref = H.ref_lib_or_none()
-    kind = "reference" if ref is not None else "port"
-    solve = abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(devnull, 1)  # the reference printf()s from marginalization
+def guarded(fn):
     try:
-        n_s, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 6.0:
-            w = uniq_windows[n_s % len(uniq_windows)].copy()
+        return fn()
+    except Exception as e:  # a secondary measurement must not take the contract line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+# ---- CPU path timed beside it: one thread per sequence like the reference (num_threads = 1, VINS.cpp:642) --
+class CpuBaseline:
+    """front-end = the CPU restatement (OpenCV is not available anywhere: 'port'); window solve = the real reference
+    (vendored Ceres 1.12 + VINS factors, oracle/_ref) when its prebuilt library travelled here, else the restatement."""
+
+    def __init__(self, cfg, abi, streams, uniq_windows):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers as H
+        self.H, self.cfg, self.abi, self.streams, self.windows = H, cfg, abi, streams, uniq_windows
+        ref = H.ref_lib_or_none()
+        self.kind = "reference" if ref is not None else "port"
+        self.solve = abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
+
+    def _worker(self, idx, seconds, out):
+        H, abi = self.H, self.abi
+        trk = H.OracleTracker(self.cfg)
+        stream = self.streams[idx % len(self.streams)]
+        order = [0, 1, 2, 3, 2, 1]
+        trk.read_image(stream[0], True)
+        n, t_fe, t_so = 0, 0.0, 0.0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            t0 = time.perf_counter()
+            trk.read_image(stream[order[(n + 1) % len(order)]], True)
+            t1 = time.perf_counter()
+            w = self.windows[(idx + n) % len(self.windows)].copy()
             st = abi.VioSolveStats()
-            solve(C.byref(cfg), C.byref(w.struct()), C.byref(st))
-            n_s += 1
-        t_solve = (time.perf_counter() - t0) / n_s
-    finally:
-        C.CDLL(None).fflush(None)  # the reference's printf()s sit in C stdio's buffer: drain them into /dev/null too
-        os.dup2(saved, 1)
-        os.close(devnull)
-    return {"value": 1.0 / (t_fe + t_solve), "unit": "frames/s", "cores": 1,
-            "kind": "port", "solve_kind": kind,
-            "sample": "%d published frames through the KLT restatement (%.1f ms each) + %d window solves incl. "
-                      "marginalization through %s (%.1f ms each), one thread, %s" % (
-                          n_fe, t_fe * 1e3, n_s, "vendored Ceres 1.12 + VINS factors" if ref is not None else
-                          "the C++ restatement", t_solve * 1e3, cpu_model()),
-            "frontend_ms": t_fe * 1e3, "solve_ms": t_solve * 1e3}
+            self.solve(C.byref(self.cfg), C.byref(w.struct()), C.byref(st))
+            t2 = time.perf_counter()
+            t_fe += t1 - t0
+            t_so += t2 - t1
+            n += 1
+        trk.close()
+        out[idx] = (n, t_fe, t_so)
+
+    def _run(self, threads, seconds):
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(devnull, 1)  # the reference printf()s from marginalization
+        out = [None] * threads
+        try:
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=self._worker, args=(i, seconds, out)) for i in range(threads)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            wall = time.perf_counter() - t0
+        finally:
+            C.CDLL(None).fflush(None)  # the reference's printf()s sit in C stdio's buffer: drain them into /dev/null too
+            os.dup2(saved, 1)
+            os.close(devnull)
+        return out, wall
+
+    def one_core(self, seconds):
+        out, _ = self._run(1, seconds)
+        n, t_fe, t_so = out[0]
+        return {"value": n / (t_fe + t_so), "unit": "frames/s", "cores": 1, "kind": "port", "solve_kind": self.kind,
+                "sample": "%d published frames through the KLT restatement (%.1f ms each) + %d steady-state window solves incl. "
+                          "prior and marginalization through %s (%.1f ms each), one thread, %s" % (
+                              n, t_fe / n * 1e3, n, "vendored Ceres 1.12 + VINS factors" if self.kind == "reference" else
+                              "the C++ restatement", t_so / n * 1e3, cpu_model()),
+                "frontend_ms": t_fe / n * 1e3, "solve_ms": t_so / n * 1e3}
+
+    def all_cores(self, seconds):
+        cores = usable_cores()
+        out, wall = self._run(cores, seconds)
+        n = sum(o[0] for o in out)
+        return {"value": n / wall, "unit": "frames/s", "cores": cores, "kind": "port", "solve_kind": self.kind,
+                "sample": "%d threads (one sequence each: KLT restatement frame + window solve through %s), %d frames in %.1f s; "
+                          "%s" % (cores, "vendored Ceres" if self.kind == "reference" else "the C++ restatement", n, wall, cpu_model()),
+                "per_thread_frames_per_s": n / wall / cores}
+
+
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # container CPU quota (cgroup v2): "max 100000" or "<quota> <period>"
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                return line.split(":", 1)[1].strip() + " (%d cores visible)" % os.cpu_count()
+                return line.split(":", 1)[1].strip() + " (%d cores visible, %d usable)" % (os.cpu_count(), usable_cores())
     except OSError:
         pass
     return "unknown CPU"
+
+
+# ---- secondary measurements ------------------------------------------------------------------------------------
+def end_to_end(n_seq):
+    """The estimator path (csrc/vio_estimator.cpp): per frame, host observations + IMU in, host states out — landmark
+    bookkeeping, window assembly, packing, H2D, ONE window-kernel launch for all sequences, D2H, slides."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import time_estimator as TE
+    n_frames = 24
+    solves, _, _, lib_s = TE.run(n_seq, n_frames, quiet=True)
+    return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
+            "frames_timed": solves // n_seq, "path": "vio_estimator_process_imu_batch + vio_estimator_process_images, one estimator "
+            "object on one host thread, host buffers in / host states out, priors resident on the device; time inside the two "
+            "library calls (closed-loop windows: ~190 landmarks, ~1400 factors, prior)",
+            "ms_per_frame_of_all_sequences": lib_s / (solves // n_seq) * 1e3}
+
+
+def se3_align_rmse(est, ref):
+    """RMSE of positions after the best rigid alignment (Kabsch, no scale): ATE."""
+    est, ref = np.asarray(est), np.asarray(ref)
+    ce, cr = est.mean(0), ref.mean(0)
+    Hm = (est - ce).T @ (ref - cr)
+    U, _, Vt = np.linalg.svd(Hm)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    d = (est - ce) @ R.T - (ref - cr)
+    return float(np.sqrt((d ** 2).sum(1).mean()))
+
+
+def closed_loop_ate(cfg, pkg, n_frames=70):
+    """The same synthetic sequence (truth known) through the closed loop twice: window solves on the device, and through
+    the CPU path (reference build when present, else the restatement); everything else identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import replay_synthetic as RS
+    c = pkg.abi.default_config()
+    pre = lambda *a: pkg.backend.preintegrate(c, *a)
+    solver = pkg.backend.WindowSolver(c, max_batch=1)
+    ref = H.ref_lib_or_none()
+    cpu_solve = pkg.abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
+
+    def cpu(w):
+        ref_w, st = H.solve_with(cpu_solve, c, w)
+        w.pose[:], w.speed_bias[:], w.inv_depth[:] = ref_w.pose, ref_w.speed_bias, ref_w.inv_depth
+        w.next_prior = ref_w.next_prior
+        return st
+
+    res = {}
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(devnull, 1)
+    try:
+        loops = {"gpu": RS.ClosedLoop(c, lambda w: solver.solve([w])[0], pre, seed=3, init_noise=1.0),
+                 "cpu": RS.ClosedLoop(c, cpu, pre, seed=3, init_noise=1.0)}
+        for name, lp in loops.items():
+            for _ in range(n_frames):
+                lp.step()
+            res[name] = (np.array([h[1] for h in lp.history]), np.array([h[2] for h in lp.history]))
+            lp.close()
+    finally:
+        C.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(devnull)
+    solver.close()
+    g, truth = res["gpu"]
+    cpos, _ = res["cpu"]
+    return {"unit": "m", "frames": n_frames, "solves": int(len(g)),
+            "ate_gpu_vs_truth": se3_align_rmse(g, truth), "ate_cpu_vs_truth": se3_align_rmse(cpos, truth),
+            "rmse_gpu_vs_cpu": float(np.sqrt(((g - cpos) ** 2).sum(1).mean())),
+            "cpu_path": "vendored Ceres 1.12 + VINS factors" if ref is not None else "C++ restatement",
+            "note": "synthetic landmark cloud, 0.5 px observation noise, noisy biased IMU; newest-frame positions of every solve"}
+
+
+def large_windows(pkg, batch=64):
+    """configs[2] (W=20, 300 feats, 200 Hz IMU) and configs[4] (W=30, 500 feats, prior + loop constraint): the reduced
+    system no longer fits a CU's LDS, vio_window_kernel<false> keeps it in global memory. Solver kernel only."""
+    abi, synth, backend = pkg.abi, pkg.synth, pkg.backend
+    out = {}
+    specs = [("configs[2]", dict(window_size=20, fx=1053.2, fy=1053.4, cx=640.0, cy=360.0), 300, 20, False),
+             ("configs[4]", dict(window_size=30, fx=1579.8, fy=1580.0, cx=960.0, cy=540.0), 500, 10, True)]
+    for name, kw, nf, ipf, full in specs:
+        cfg = abi.default_config(**kw)
+        pre = lambda *a, cfg=cfg: backend.preintegrate(cfg, *a)
+        if full:
+            uniq = steady_state_windows(cfg, pkg, pre, [7, 8], n_features=nf, with_loop=40, imu_per_frame=ipf)
+        else:
+            uniq = [synth.make_window(cfg, pre, seed=20 + s, n_features=nf, imu_per_frame=ipf) for s in range(2)]
+        ws = [uniq[i % len(uniq)].copy() for i in range(batch)]
+        solver = backend.WindowSolver(cfg, max_batch=batch)
+        solver.upload(ws)
+        solver.launch()
+        solver.sync()
+        solver.kernel_ms()
+        for _ in range(3):
+            solver.launch()
+        solver.sync()
+        ms, _ = solver.kernel_ms()
+        st = solver.download(ws)
+        solver.close()
+        iters = float(np.mean([s["iterations"] - 1 for s in st]))
+        M = float(np.mean([w.n_factors for w in ws]))
+        n_prior = int(np.mean([w.prior.n if w.prior is not None else 0 for w in uniq]))
+        flops = algorithmic_flops_per_solve(cfg.window_size, M, n_prior, iters, nf) * batch
+        out[name] = {"window": cfg.window_size, "features": nf, "factors": M, "prior_rows": n_prior, "loop_factors": 40 if full else 0,
+                     "batch": batch, "kernel_ms": ms, "ms_per_solve_at_batch": ms / batch, "solves_per_s": batch / (ms * 1e-3),
+                     "gn_iterations": iters, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+                     "frac_of_fp64_peak": flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+    return out
 
 
 if __name__ == "__main__":

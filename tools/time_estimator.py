@@ -30,6 +30,7 @@ def main():
         [t.join() for t in ths]
         solves = sum(r[0] for r in res)
         span = max(r[2] for r in res) - min(r[1] for r in res)
+        print("   (library time per estimator: %s s)" % ", ".join("%.3f" % r[3] for r in res))
         print("%d estimators x %d sequences on %d host threads: %d window solves in %.1f ms of solve phase -> %.0f solves/s aggregate"
               % (n_est, n_seq, n_est, solves, span * 1e3, solves / span))
         return
@@ -96,7 +97,8 @@ def run(n_seq, n_frames, quiet=False):
             t_last = time.perf_counter()
     if quiet:
         est.close()
-        return n_seq * (n_frames - W - 3), t_first_solve, t_last
+        lib_s = float(np.sum(t_img[W + 3:]) + np.sum(t_imu[W + 3:]))   # library time only (the python marshalling between calls is not the product)
+        return n_seq * (n_frames - W - 3), t_first_solve, t_last, lib_s
     solve = np.array(t_img[W + 2:]) * 1e3
     fill = np.array(t_img[1:W]) * 1e3
     print("n_seq %d: process_images with a solve: %.2f ms median (%.2f min) -> %.0f window solves/s end to end; filling phase %.2f ms"
