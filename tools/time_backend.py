@@ -14,10 +14,16 @@ abi, synth, backend = pkg.abi, pkg.synth, pkg.backend
 
 
 def main():
-    batches = [int(x) for x in sys.argv[1:]] or [1, 64, 256, 512, 1024]
+    args = [a for a in sys.argv[1:] if a != "--no-prior"]
+    batches = [int(x) for x in args] or [1, 64, 256, 512, 1024]
     cfg = abi.default_config()
     pre = lambda *a: backend.preintegrate(cfg, *a)
-    uniq = [synth.make_window(cfg, pre, seed=42 + i) for i in range(16)]
+    if "--no-prior" in sys.argv:
+        uniq = [synth.make_window(cfg, pre, seed=42 + i) for i in range(16)]
+    else:  # steady-state windows: the prior of the preceding MARGIN_OLD solve rides along (bench.py's workload)
+        sys.path.insert(0, ROOT)
+        import bench
+        uniq = bench.steady_state_windows(cfg, pkg, pre, [42 + i for i in range(8)])
     solver = backend.WindowSolver(cfg, max_batch=max(batches))
     solver.set_profile(True)
     ws = [uniq[0].copy()]

@@ -70,7 +70,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_M = o, o += (size_t)d.Wcap * 450;
   s.s_r = o, o += (size_t)d.Wcap * 15;
   s.s_Mr = o, o += (size_t)d.Wcap * 15;
-  s.s_prJT = o, o += (size_t)d.Ncap * d.Ncap;
+  s.s_prJT = o, o += (size_t)d.Ncap;  // b0 = J0^T r0
   s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
   s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
@@ -141,7 +141,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.origin_yaw = hd[0], v.origin_p[0] = hd[1], v.origin_p[1] = hd[2], v.origin_p[2] = hd[3];
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
-  v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prJT = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
+  v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
   v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;

@@ -230,16 +230,20 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       else if (kind == 1) prior_block_dx(9, xsb + 9 * idx, x0, m.prdx + o);
       else prior_block_dx(7, ex, x0, m.prdx + o);
     }
-    VIO_PARFOR(i, pn) m.prr[i] = v.pr_r[i];
+    // J^T r = b0 + H0 dx and J^T J = H0 (setup_prior in solver_core.h keeps both for the whole launch)
+    VIO_PARFOR(i, pn) m.prr[i] = v.prb0[i];
     VIO_SYNC();
-    dense_matvec_cols(cx, v.prJT, pn, m.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(m.prr + i, sacc); });
+    dense_matvec_cols(cx, v.prH0, pn, m.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(m.prr + i, sacc); });
+    {
+      const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
+      for (int a = tid_ >> 6; a < pn; a += nwv) {
+        const int ca = m.pcol[a];
+        for (int b = lane; b < pn; b += 64) m.Am[ca * ld + m.pcol[b]] = v.prH0[a * pn + b];
+      }
+    }
     VIO_SYNC();
     // (bm was zeroed above and every prior column owns its dense column)
-    dense_matvec_cols(cx, v.pr_J, pn, m.prr, [&](int a, double g) { VIO_ATOMIC_ADD(m.bm + m.pcol[a], g); });
-    VIO_PARFOR(q, pn * pn) {
-      int a = q / pn, b = q % pn;
-      m.Am[m.pcol[a] * ld + m.pcol[b]] = v.prH0[q];
-    }
+    VIO_PARFOR(a, pn) m.bm[m.pcol[a]] += m.prr[a];
     VIO_SYNC();
   }
   stamp(cx, ST_M_PRIOR);

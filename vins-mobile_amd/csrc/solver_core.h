@@ -151,7 +151,7 @@ struct WinView {
   double *imu_M;     // [W][15*30]
   double *imu_r;     // [W][15]
   double *imu_Mr;    // [W][15]
-  double *prJT;      // [n*n]  J0 transposed
+  double *prb0;      // [n]    b0 = J0^T r0
   double *prH0;      // [n*n]  J0^T J0
   double *WT;        // [npose6][Fpad]  H_pf transposed: row = 6*frame + c, col = feature
   double *WTf;       // [F][n6cap]      the same, feature-major (operand layout of the Schur GEMM)
@@ -669,7 +669,11 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
 }
 #endif
 
-// Prior constants: column map, J0^T (for coalesced mat-vecs) and H0 = J0^T J0.
+// Prior constants. MarginalizationFactor evaluates r = r0 + J0 dx with a constant J0 (marginalization_factor.cpp:
+// 336-384); everything the solver takes from it is a function of  H0 = J0^T J0  and  b0 = J0^T r0:
+//     J^T r = b0 + H0 dx,    cost = |r0|^2 / 2 + b0 . dx + dx . (H0 dx) / 2,    J^T J = H0,
+// so one symmetric mat-vec per evaluation serves the cost-only and the Jacobian evaluations alike (the first version
+// did r0 + J0 dx and J0^T r: two passes over two copies of J0). Here: the column map, H0 and b0, once per solve.
 template <class WK>
 VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
   const int n = v.prior_n;
@@ -683,27 +687,36 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
     else if (kind == 1)
       for (int k = 0; k < 9; k++) w.prcol[o + k] = off_sb(idx) + k;
   }
-  // J0 goes through the (still unused) matrix buffer when it fits: n^2 serial dot products over global memory cost a
-  // ~3k-cycle round trip per handful of terms, over LDS a few cycles
+  // J0 goes through the (still unused) matrix buffer when it fits: the n^2 dot products then read LDS
   const bool stage = (size_t)n * n <= (size_t)v.nblk * (v.nblk + 1) / 2 * kBB;
   auto Js = w.Hm;
-  VIO_PARFOR(q, n * n) {
-    int r = q / n, c = q % n;
-    const double x = v.pr_J[q];
-    v.prJT[c * n + r] = x;
-    if (stage) Js[q] = x;
+  if (stage) {
+    VIO_PARFOR(q, n * n) Js[q] = v.pr_J[q];
+    VIO_SYNC();
   }
-  VIO_SYNC();
-  VIO_PARFOR(q, n * n) {
-    int a = q / n, b = q % n;
+  // rows of the symmetric H0 by wave, columns by lane: no integer division per element
+  {
+    const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
+    for (int a = tid_ >> 6; a < n; a += nwv)
+      for (int b = lane; b < n; b += 64) {
+        double s = 0;
+        if (stage) {
+#pragma unroll 5
+          for (int k = 0; k < n; k++) s = fma(Js[k * n + a], Js[k * n + b], s);
+        } else {
+          for (int k = 0; k < n; k++) s = fma(v.pr_J[k * n + a], v.pr_J[k * n + b], s);
+        }
+        v.prH0[a * n + b] = s;
+      }
+  }
+  VIO_PARFOR(a, n) {
     double s = 0;
     if (stage) {
-#pragma unroll 5
-      for (int k = 0; k < n; k++) s += Js[k * n + a] * Js[k * n + b];
+      for (int k = 0; k < n; k++) s = fma(Js[k * n + a], v.pr_r[k], s);
     } else {
-      for (int k = 0; k < n; k++) s += v.pr_J[k * n + a] * v.pr_J[k * n + b];
+      for (int k = 0; k < n; k++) s = fma(v.pr_J[k * n + a], v.pr_r[k], s);
     }
-    v.prH0[q] = s;
+    v.prb0[a] = s;
   }
   VIO_SYNC();
 }
@@ -1165,22 +1178,48 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
       else prior_block_dx(7, w.ex, x0, w.prdx + o);
     }
-    VIO_PARFOR(i, n) w.prr[i] = v.pr_r[i];
+    VIO_PARFOR(i, n) w.prr[i] = v.prb0[i];
     VIO_SYNC();
-    dense_matvec_cols(cx, v.prJT, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });
+    dense_matvec_cols(cx, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
   }
   VIO_SYNC();  // Hm zeroed, prr ready
-  if (n > 0) VIO_PARFOR(i, n) cost += 0.5 * w.prr[i] * w.prr[i];
+  if (n > 0) VIO_PARFOR(i, n) {
+    const double r0 = v.pr_r[i], b0 = v.prb0[i];
+    cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
+  }
   if (jac) {
     if (n > 0) {
-      dense_matvec_cols(cx, v.pr_J, n, w.prr, [&](int a, double g) {
+      VIO_PARFOR(a, n) {
         const int pa = w.prcol[a];
-        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + pa, g);
-      });
-      VIO_PARFOR(q, n * n) {
-        int a = q / n, b = q - a * n;
-        int pa = w.prcol[a], pb = w.prcol[b];
-        if (pa >= 0 && pb >= 0 && pa >= pb) *mat_at(w.Hm, pa, pb) = v.prH0[q];
+        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + pa, w.prr[a]);
+      }
+      // H0 -> the reduced matrix: rows by wave, columns by lane, eight rows' loads in flight before the first store
+      // (one dependent global load per row otherwise: the phase is nothing but L2 latency)
+      const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
+      constexpr int kU = 8;
+      for (int b0 = 0; b0 < n; b0 += 64) {
+        const int b = b0 + lane;
+        const bool bok = b < n;
+        const int pb = w.prcol[bok ? b : 0];
+        for (int a0 = tid_ >> 6; a0 < n; a0 += nwv * kU) {
+          double x[kU];
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int a = a0 + u * nwv;
+            x[u] = v.prH0[(a < n && bok) ? a * n + b : 0];
+          }
+#ifndef VIO_EMUL
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int a = a0 + u * nwv;
+            if (a < n && bok) {
+              const int pa = w.prcol[a];
+              if (pa >= 0 && pb >= 0 && pa >= pb) *mat_at(w.Hm, pa, pb) = x[u];
+            }
+          }
+        }
       }
       VIO_SYNC();
     }
