@@ -787,12 +787,14 @@ VIO_DEV bool potrf15_inv_wave(MP D, MP Lprev, bool with_update, ldsd ldinv_k, in
     for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
   }
   // values this lane will store: pivot c = kq + 4 j lands in element j (L[n][c] for n >= c, Linv[c][n] for n < c)
-  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0, minpiv = 1.0;
+  // Everything in this loop is on the critical path of the solve and nothing in a wave overlaps its own matrix
+  // instructions (an f64 MFMA holds the SIMD for 64 cycles), so the loop carries no bookkeeping: a pivot <= 0 shows up
+  // as a NaN / inf reciprocal root and is tested once at the end.
+  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
   double dcc = lane_bcast(A[0], 0);
 #pragma unroll
   for (int c = 0; c < kBS; c++) {
-    minpiv = fmin(minpiv, dcc > 0.0 ? dcc : -1.0);  // (a NaN pivot also lands on -1)
-    // 1 / sqrt(dcc): hardware seed (~single precision) + two Newton steps
+    // 1 / sqrt(dcc): hardware seed + two Newton steps
     double y = __builtin_amdgcn_rsq(dcc);
     const double h = 0.5 * dcc;
     y = y * fma(-h * y, y, 1.5);
@@ -820,7 +822,9 @@ VIO_DEV bool potrf15_inv_wave(MP D, MP Lprev, bool with_update, ldsd ldinv_k, in
     }
     if (kq == 0) ldinv_k[n] = myinv;
   }
-  return minpiv > 0.0;
+  // rsq of a pivot <= 0 (or NaN) is NaN / inf, and every later pivot inherits it
+  const bool bad = n < kBS && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
+  return __builtin_amdgcn_ballot_w64(bad) == 0;
 }
 
 // ---- block operations of the reduced-system Cholesky, second generation -------------------------------------------
