@@ -432,6 +432,8 @@ def load_product():
     lib.vio_backend_solve_windows.argtypes = [vp, C.POINTER(VioWindow), C.c_int32, C.c_int32,
                                               C.POINTER(VioSolveStats)]
     lib.vio_backend_reserve_priors.argtypes = [vp, C.c_int32]
+    lib.vio_backend_get_device.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.vio_frontend_get_device.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.vio_backend_upload.argtypes = [vp, C.POINTER(VioWindow), C.c_int32]
     lib.vio_backend_launch.argtypes = [vp, vp]
     lib.vio_backend_sync.argtypes = [vp]

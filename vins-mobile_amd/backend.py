@@ -54,6 +54,12 @@ class WindowSolver:
         self._check(self.lib.vio_backend_solve_windows(self._h, arr, len(windows), buf_num, stats), "solve_windows")
         return [abi.stats_to_dict(s) for s in stats]
 
+    def device(self):
+        """HIP device ordinal the context is bound to (the device current on the creating thread)."""
+        d = C.c_int32(-1)
+        self._check(self.lib.vio_backend_get_device(self._h, C.byref(d)), "get_device")
+        return d.value
+
     def reserve_priors(self, n_slots):
         """Device-resident prior chain: Window.resident_prior = k selects slot k-1 (vio_amd.h)."""
         self._check(self.lib.vio_backend_reserve_priors(self._h, n_slots), "reserve_priors")
