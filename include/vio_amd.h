@@ -328,6 +328,43 @@ int vio_fundamental_ransac(const VioConfig *cfg, const float *pts1, const float 
                            int32_t n, uint8_t *inlier_mask);
 
 /* ------------------------------------------------------------------------- */
+/* Loop-closure producer, descriptor side:
+ *   KeyFrame::searchByDes               loop/keyframe.cpp:161-187
+ *   KeyFrame::HammingDis                loop/keyframe.cpp:368-373
+ *   KeyFrame::rejectWithF               loop/keyframe.cpp:35-58
+ *   KeyFrame::findConnectionWithOldFrame loop/keyframe.cpp:267-273
+ * A BRIEF descriptor (BRIEF::bitset, 256 bits) is four uint64_t words, word 0 =
+ * bits 0..63. The matcher context is bound to a device like every other
+ * context.                                                                     */
+typedef struct vio_matcher vio_matcher_t;
+int vio_matcher_create(vio_matcher_t **out);
+void vio_matcher_destroy(vio_matcher_t *m);
+/* searchByDes for n_pairs (current keyframe, old keyframe) pairs in one launch.
+ * cur_desc holds the pairs' window descriptors back to back (sum n_cur x 4
+ * words), old_desc the old keyframes' descriptors (sum n_old x 4, at most 65535
+ * per keyframe). Per query, in the order of cur_desc: best_index = index into
+ * that pair's old list of the smallest Hamming distance (first one on ties, as
+ * the reference's `dis < bestDist` scan), best_dist = that distance;
+ * best_index = -1 / best_dist = 256 when nothing is closer than 256 bits
+ * (empty old list).                                                            */
+int vio_matcher_search_by_des(vio_matcher_t *m, int32_t n_pairs, const int32_t *n_cur,
+                              const int32_t *n_old, const uint64_t *cur_desc,
+                              const uint64_t *old_desc, int32_t *best_index,
+                              int32_t *best_dist);
+/* findConnectionWithOldFrame: searchByDes, matched_old_pts[i] = keypoint of the
+ * best old descriptor (pixels), then, from 8 matches on, rejectWithF =
+ * findFundamentalMat(cur_pts, matched_old_pts, FM_RANSAC, 2.0, 0.99) ->
+ * status[i] (1 = kept), matched_old_norm = (pt - (cx, cy)) / (fx, fy)
+ * (optional). Fewer than 8 matches keep everything.                            */
+int vio_loop_find_connection(vio_matcher_t *m, const VioConfig *cfg, int32_t n_cur,
+                             const uint64_t *cur_desc, const float *cur_pts /* [n_cur][2] */,
+                             int32_t n_old, const uint64_t *old_desc,
+                             const float *old_pts /* [n_old][2] */,
+                             float *matched_old_pts /* [n_cur][2] */,
+                             float *matched_old_norm /* [n_cur][2] or NULL */,
+                             uint8_t *status /* [n_cur] */, int32_t *n_inliers);
+
+/* ------------------------------------------------------------------------- */
 /* Window bookkeeping around the solve (host side): FeatureManager            */
 /* (VINS_ios/feature_manager.hpp:71-103). It decides which landmarks and      */
 /* observations become factors of a VioWindow; the window size is a run-time  */

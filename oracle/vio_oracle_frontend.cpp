@@ -920,3 +920,63 @@ extern "C" int oracle_preprocess(const uint8_t *pixels, int32_t channels, int32_
   }
   return VIO_OK;
 }
+
+// ---- loop-closure producer, descriptor side (test infrastructure like everything in oracle/) ----------------------
+// KeyFrame::HammingDis (VINS_ios/loop/keyframe.cpp:368-373): popcount of the xor of two 256-bit strings.
+static int hamming256(const uint64_t *a, const uint64_t *b) {
+  int d = 0;
+  for (int w = 0; w < 4; w++) {
+    uint64_t x = a[w] ^ b[w];
+    while (x) d++, x &= x - 1;
+  }
+  return d;
+}
+
+extern "C" int oracle_search_by_des(const uint64_t *cur_desc, int32_t n_cur, const uint64_t *old_desc, int32_t n_old,
+                                    int32_t *best_index, int32_t *best_dist) {
+  // keyframe.cpp:167-187: for every window descriptor the first old descriptor of minimum distance
+  for (int i = 0; i < n_cur; i++) {
+    int bestDist = 256, bestIndex = -1;
+    for (int j = 0; j < n_old; j++) {
+      int dis = hamming256(cur_desc + 4 * (size_t)i, old_desc + 4 * (size_t)j);
+      if (dis < bestDist) bestDist = dis, bestIndex = j;
+    }
+    best_index[i] = bestDist < 256 ? bestIndex : -1;
+    best_dist[i] = bestDist;
+  }
+  return 0;
+}
+
+extern "C" int oracle_loop_find_connection(const VioConfig *cfg, int32_t n_cur, const uint64_t *cur_desc, const float *cur_pts,
+                                           int32_t n_old, const uint64_t *old_desc, const float *old_pts,
+                                           float *matched_old_pts, float *matched_old_norm, uint8_t *status,
+                                           int32_t *n_inliers) {
+  *n_inliers = 0;
+  if (n_cur == 0) return 0;
+  std::vector<int32_t> idx(n_cur), dist(n_cur);
+  oracle_search_by_des(cur_desc, n_cur, old_desc, n_old, idx.data(), dist.data());
+  for (int i = 0; i < n_cur; i++) {
+    if (idx[i] < 0) {
+      for (int k = 0; k < n_cur; k++) status[k] = 0;
+      return 0;
+    }
+    matched_old_pts[2 * i] = old_pts[2 * idx[i]], matched_old_pts[2 * i + 1] = old_pts[2 * idx[i] + 1];
+  }
+  if (n_cur >= 8) {  // rejectWithF, keyframe.cpp:35-58
+    if (matched_old_norm)
+      for (int i = 0; i < n_cur; i++) {
+        matched_old_norm[2 * i] = (float)((matched_old_pts[2 * i] - (float)cfg->cx) / (float)cfg->fx);
+        matched_old_norm[2 * i + 1] = (float)((matched_old_pts[2 * i + 1] - (float)cfg->cy) / (float)cfg->fy);
+      }
+    VioConfig c = *cfg;
+    c.f_threshold = 2.0, c.f_confidence = 0.99;
+    int rc = oracle_fundamental_ransac(&c, cur_pts, matched_old_pts, n_cur, status);
+    if (rc != 0) return rc;
+  } else {
+    for (int i = 0; i < n_cur; i++) status[i] = 1;
+  }
+  int k = 0;
+  for (int i = 0; i < n_cur; i++) k += status[i] ? 1 : 0;
+  *n_inliers = k;
+  return 0;
+}

@@ -1,0 +1,67 @@
+"""Host-side mirror of the loop-closure producer's descriptor side: KeyFrame::searchByDes / findConnectionWithOldFrame
+(VINS_ios/loop/keyframe.cpp:161-187, 267-273). Plumbing over csrc/vio_loop.hip for tests; no compute here."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+_u64p, _i32p, _fp, _u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+
+def bind(lib, prefix="vio"):
+    if prefix == "vio":
+        lib.vio_matcher_create.argtypes = [C.POINTER(C.c_void_p)]
+        lib.vio_matcher_destroy.argtypes = [C.c_void_p]
+        lib.vio_matcher_search_by_des.argtypes = [C.c_void_p, C.c_int32, _i32p, _i32p, _u64p, _u64p, _i32p, _i32p]
+        lib.vio_loop_find_connection.argtypes = [C.c_void_p, C.POINTER(abi.VioConfig), C.c_int32, _u64p, _fp, C.c_int32, _u64p,
+                                                 _fp, _fp, _fp, _u8p, _i32p]
+    return lib
+
+
+class Matcher:
+    def __init__(self):
+        self.lib = bind(abi.load_product())
+        self._h = C.c_void_p()
+        rc = self.lib.vio_matcher_create(C.byref(self._h))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_matcher_create failed rc=%d (a gfx950 device is required)" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def search_by_des(self, cur_list, old_list):
+        """cur_list / old_list: per pair uint64 arrays [n][4]. Returns per pair (best_index, best_dist)."""
+        n_cur = np.array([len(c) for c in cur_list], np.int32)
+        n_old = np.array([len(o) for o in old_list], np.int32)
+        cur = np.ascontiguousarray(np.concatenate([np.asarray(c, np.uint64).reshape(-1, 4) for c in cur_list] + [np.zeros((0, 4), np.uint64)]))
+        old = np.ascontiguousarray(np.concatenate([np.asarray(o, np.uint64).reshape(-1, 4) for o in old_list] + [np.zeros((0, 4), np.uint64)]))
+        idx = np.zeros(max(1, int(n_cur.sum())), np.int32)
+        dist = np.zeros_like(idx)
+        rc = self.lib.vio_matcher_search_by_des(self._h, len(cur_list), n_cur.ctypes.data_as(_i32p), n_old.ctypes.data_as(_i32p),
+                                                cur.ctypes.data_as(_u64p), old.ctypes.data_as(_u64p), idx.ctypes.data_as(_i32p),
+                                                dist.ctypes.data_as(_i32p))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_matcher_search_by_des failed rc=%d" % rc)
+        out, o = [], 0
+        for n in n_cur:
+            out.append((idx[o:o + n].copy(), dist[o:o + n].copy()))
+            o += n
+        return out
+
+    def find_connection(self, cfg, cur_desc, cur_pts, old_desc, old_pts):
+        cur_desc = np.ascontiguousarray(cur_desc, np.uint64).reshape(-1, 4)
+        old_desc = np.ascontiguousarray(old_desc, np.uint64).reshape(-1, 4)
+        cur_pts = np.ascontiguousarray(cur_pts, np.float32).reshape(-1, 2)
+        old_pts = np.ascontiguousarray(old_pts, np.float32).reshape(-1, 2)
+        n = len(cur_desc)
+        mo, mn = np.zeros((max(n, 1), 2), np.float32), np.zeros((max(n, 1), 2), np.float32)
+        status, k = np.zeros(max(n, 1), np.uint8), C.c_int32()
+        rc = self.lib.vio_loop_find_connection(self._h, C.byref(cfg), n, cur_desc.ctypes.data_as(_u64p), cur_pts.ctypes.data_as(_fp),
+                                               len(old_desc), old_desc.ctypes.data_as(_u64p), old_pts.ctypes.data_as(_fp),
+                                               mo.ctypes.data_as(_fp), mn.ctypes.data_as(_fp), status.ctypes.data_as(_u8p), C.byref(k))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_loop_find_connection failed rc=%d" % rc)
+        return mo[:n], mn[:n], status[:n], k.value
