@@ -313,6 +313,20 @@ int vio_preprocess_kernel_ms(vio_preprocess_t *p, double *ms_avg, int32_t *launc
 int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts /* [cap][2] */,
                            int32_t *ids, int32_t *track_cnt, int32_t cap, int32_t *n);
 
+/* The tracker's public fields (feature_tracker.hpp:68-80: pre_pts / cur_pts /
+ * forw_pts, ids, track_cnt) of one sequence in and out, and the steps of readImage
+ * between the LK call and goodFeaturesToTrack on their own
+ * (feature_tracker.cpp:183-205 status && inBorder, reduceVector, F-RANSAC; on
+ * publish frames also :235-255 rejectWithF, track_cnt++ and :50-87 setMask), for
+ * every sequence of the context. After the update forw_pts / ids / track_cnt
+ * hold what the step kept (in setMask's order on publish frames).               */
+int vio_frontend_set_tracks(vio_frontend_t *fe, int32_t seq, int32_t n, const float *pre_pts,
+                            const float *cur_pts, const float *forw_pts, const int32_t *ids,
+                            const int32_t *track_cnt, const uint8_t *lk_status);
+int vio_frontend_update_tracks(vio_frontend_t *fe, int32_t publish);
+int vio_frontend_get_tracks(vio_frontend_t *fe, int32_t seq, float *forw_pts, int32_t *ids,
+                            int32_t *track_cnt, int32_t cap, int32_t *n);
+
 /* Stand-alone operators of the front-end (each is one reference call site),
  * exposed so they can be parity-tested in isolation:
  *   calcOpticalFlowPyrLK  feature_tracker.cpp:181

@@ -683,6 +683,63 @@ bool in_border(const VioConfig &cfg, float x, float y) {  // feature_tracker.cpp
 
 }  // namespace
 
+// The steps of readImage between the LK call and goodFeaturesToTrack (feature_tracker.cpp:183-205, and on publish
+// frames :235-255 with setMask :50-87): status && inBorder, reduceVector, F-RANSAC on (cur, forw), rejectWithF on
+// (pre, forw), track_cnt++, setMask. `mask` is filled on publish frames. Also the body of the isolated operator tests
+// (oracle_tracker_update_tracks).
+static void tracker_update_tracks(oracle_tracker_t *t, std::vector<uint8_t> &status, bool publish, int rows, int cols,
+                                  std::vector<uint8_t> &mask) {
+  const VioConfig &cfg = t->cfg;
+  if (!t->cur_pts.empty()) {
+    int n = (int)t->cur_pts.size() / 2;
+    for (int i = 0; i < n; i++)
+      if (status[i] && !in_border(cfg, t->forw_pts[2 * i], t->forw_pts[2 * i + 1])) status[i] = 0;
+    reduce_vec(t->pre_pts, status, 2), reduce_vec(t->cur_pts, status, 2), reduce_vec(t->forw_pts, status, 2);
+    reduce_vec(t->ids, status, 1), reduce_vec(t->track_cnt, status, 1);
+    if (t->forw_pts.size() / 2 >= 8) {
+      int m = (int)t->forw_pts.size() / 2;
+      std::vector<uint8_t> st(m);
+      fundamental_ransac(t->cur_pts.data(), t->forw_pts.data(), m, cfg.f_threshold, cfg.f_confidence, st.data());
+      reduce_vec(t->cur_pts, st, 2), reduce_vec(t->pre_pts, st, 2), reduce_vec(t->forw_pts, st, 2);
+      reduce_vec(t->ids, st, 1), reduce_vec(t->track_cnt, st, 1);
+    }
+  }
+  if (!publish) return;
+  // rejectWithF over the publish baseline (feature_tracker.cpp:89-103)
+  if (t->forw_pts.size() / 2 >= 8) {
+    int m = (int)t->forw_pts.size() / 2;
+    std::vector<uint8_t> st(m);
+    fundamental_ransac(t->pre_pts.data(), t->forw_pts.data(), m, cfg.f_threshold, cfg.f_confidence, st.data());
+    reduce_vec(t->pre_pts, st, 2), reduce_vec(t->cur_pts, st, 2), reduce_vec(t->forw_pts, st, 2);
+    reduce_vec(t->ids, st, 1), reduce_vec(t->track_cnt, st, 1);
+  }
+  for (auto &c : t->track_cnt) c++;
+  // setMask (feature_tracker.cpp:50-87)
+  mask.assign((size_t)rows * cols, 255);
+  int n = (int)t->ids.size();
+  std::vector<int> order(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t->track_cnt[a] > t->track_cnt[b]; });
+  std::vector<float> kp;
+  std::vector<int> kid, kcnt;
+  const int r = cfg.min_dist;
+  for (int i : order) {
+    float x = t->forw_pts[2 * i], y = t->forw_pts[2 * i + 1];
+    int ix = cv_round(x), iy = cv_round(y);  // mask.at<uchar>(Point2f) rounds
+    if (mask[(size_t)iy * cols + ix] == 255) {
+      kp.push_back(x), kp.push_back(y), kid.push_back(t->ids[i]), kcnt.push_back(t->track_cnt[i]);
+      for (int dy = -r; dy <= r; dy++) {  // cv::circle(mask, pt, MIN_DIST, 0, -1); center = Point(Point2f) rounds
+        int yy = iy + dy;
+        if (yy < 0 || yy >= rows) continue;
+        int h = t->hw[r + dy];
+        for (int xx = std::max(0, ix - h); xx <= std::min(cols - 1, ix + h); xx++) mask[(size_t)yy * cols + xx] = 0;
+      }
+    }
+  }
+  t->forw_pts = kp, t->ids = kid, t->track_cnt = kcnt;
+}
+
+
 extern "C" {
 
 void oracle_set_lk_accum_mode(int mode) { g_lk_accum_mode = mode; }
@@ -747,57 +804,19 @@ int oracle_tracker_read_image(oracle_tracker_t *t, const uint8_t *gray, int32_t 
   if (!t->have_img) t->pre = t->cur = t->forw = img, t->have_img = true;
   else t->forw = img;
   t->forw_pts.clear();
+  std::vector<uint8_t> mask;
   if (!t->cur_pts.empty()) {
     int n = (int)t->cur_pts.size() / 2;
     std::vector<uint8_t> status(n);
     std::vector<float> err(n);
     t->forw_pts.resize(2 * n);
     klt_track(&cfg, t->cur, t->forw, t->cur_pts.data(), n, t->forw_pts.data(), status.data(), err.data());
-    for (int i = 0; i < n; i++)
-      if (status[i] && !in_border(cfg, t->forw_pts[2 * i], t->forw_pts[2 * i + 1])) status[i] = 0;
-    reduce_vec(t->pre_pts, status, 2), reduce_vec(t->cur_pts, status, 2), reduce_vec(t->forw_pts, status, 2);
-    reduce_vec(t->ids, status, 1), reduce_vec(t->track_cnt, status, 1);
-    if (t->forw_pts.size() / 2 >= 8) {
-      int m = (int)t->forw_pts.size() / 2;
-      std::vector<uint8_t> st(m);
-      fundamental_ransac(t->cur_pts.data(), t->forw_pts.data(), m, cfg.f_threshold, cfg.f_confidence, st.data());
-      reduce_vec(t->cur_pts, st, 2), reduce_vec(t->pre_pts, st, 2), reduce_vec(t->forw_pts, st, 2);
-      reduce_vec(t->ids, st, 1), reduce_vec(t->track_cnt, st, 1);
-    }
+    tracker_update_tracks(t, status, publish != 0, rows, cols, mask);
+  } else if (publish) {
+    std::vector<uint8_t> none;
+    tracker_update_tracks(t, none, true, rows, cols, mask);
   }
   if (publish) {
-    // rejectWithF over the publish baseline (feature_tracker.cpp:89-103)
-    if (t->forw_pts.size() / 2 >= 8) {
-      int m = (int)t->forw_pts.size() / 2;
-      std::vector<uint8_t> st(m);
-      fundamental_ransac(t->pre_pts.data(), t->forw_pts.data(), m, cfg.f_threshold, cfg.f_confidence, st.data());
-      reduce_vec(t->pre_pts, st, 2), reduce_vec(t->cur_pts, st, 2), reduce_vec(t->forw_pts, st, 2);
-      reduce_vec(t->ids, st, 1), reduce_vec(t->track_cnt, st, 1);
-    }
-    for (auto &c : t->track_cnt) c++;
-    // setMask (feature_tracker.cpp:50-87)
-    std::vector<uint8_t> mask((size_t)rows * cols, 255);
-    int n = (int)t->ids.size();
-    std::vector<int> order(n);
-    for (int i = 0; i < n; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t->track_cnt[a] > t->track_cnt[b]; });
-    std::vector<float> kp;
-    std::vector<int> kid, kcnt;
-    const int r = cfg.min_dist;
-    for (int i : order) {
-      float x = t->forw_pts[2 * i], y = t->forw_pts[2 * i + 1];
-      int ix = cv_round(x), iy = cv_round(y);  // mask.at<uchar>(Point2f) rounds
-      if (mask[(size_t)iy * cols + ix] == 255) {
-        kp.push_back(x), kp.push_back(y), kid.push_back(t->ids[i]), kcnt.push_back(t->track_cnt[i]);
-        for (int dy = -r; dy <= r; dy++) {  // cv::circle(mask, pt, MIN_DIST, 0, -1); center = Point(Point2f) rounds
-          int yy = iy + dy;
-          if (yy < 0 || yy >= rows) continue;
-          int h = t->hw[r + dy];
-          for (int xx = std::max(0, ix - h); xx <= std::min(cols - 1, ix + h); xx++) mask[(size_t)yy * cols + xx] = 0;
-        }
-      }
-    }
-    t->forw_pts = kp, t->ids = kid, t->track_cnt = kcnt;
     int n_max = cfg.max_corners - (int)t->ids.size();
     std::vector<float> npts;
     if (n_max > 0) {
@@ -834,6 +853,29 @@ int oracle_tracker_get_state(oracle_tracker_t *t, float *cur_pts, int32_t *ids, 
   *n = m;
   if (m > cap) return VIO_ECAP;
   memcpy(cur_pts, t->cur_pts.data(), sizeof(float) * 2 * m);
+  memcpy(ids, t->ids.data(), sizeof(int) * m), memcpy(track_cnt, t->track_cnt.data(), sizeof(int) * m);
+  return VIO_OK;
+}
+
+// Public fields of the tracker (feature_tracker.hpp:68-80) in / out, and the update step on its own: the isolated
+// operator tests of rejectWithF (F6) and setMask (F7).
+int oracle_tracker_set_tracks(oracle_tracker_t *t, int32_t n, const float *pre_pts, const float *cur_pts, const float *forw_pts,
+                              const int32_t *ids, const int32_t *track_cnt) {
+  t->pre_pts.assign(pre_pts, pre_pts + 2 * n), t->cur_pts.assign(cur_pts, cur_pts + 2 * n);
+  t->forw_pts.assign(forw_pts, forw_pts + 2 * n);
+  t->ids.assign(ids, ids + n), t->track_cnt.assign(track_cnt, track_cnt + n);
+  return VIO_OK;
+}
+int oracle_tracker_update_tracks(oracle_tracker_t *t, const uint8_t *lk_status, int32_t publish) {
+  std::vector<uint8_t> status(lk_status, lk_status + t->cur_pts.size() / 2), mask;
+  tracker_update_tracks(t, status, publish != 0, t->cfg.image_rows, t->cfg.image_cols, mask);
+  return VIO_OK;
+}
+int oracle_tracker_get_tracks(oracle_tracker_t *t, float *forw_pts, int32_t *ids, int32_t *track_cnt, int32_t cap, int32_t *n) {
+  int m = (int)t->ids.size();
+  *n = m;
+  if (m > cap) return VIO_ECAP;
+  memcpy(forw_pts, t->forw_pts.data(), sizeof(float) * 2 * m);
   memcpy(ids, t->ids.data(), sizeof(int) * m), memcpy(track_cnt, t->track_cnt.data(), sizeof(int) * m);
   return VIO_OK;
 }

@@ -1258,6 +1258,23 @@ __global__ __launch_bounds__(256) void copy_frames_kernel(const uint8_t *src, si
   }
 }
 
+// feature_tracker.cpp:183-205 (+ :235-255, :50-87 on publish frames) for every sequence: one workgroup each
+int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
+  TrackerArrays A;
+  A.cap = fe->cap, A.rows = fe->cfg.image_rows, A.cols = fe->cfg.image_cols;
+  A.cur_pts = fe->cur_pts, A.pre_pts = fe->pre_pts, A.forw_pts = fe->forw_pts, A.ids = fe->ids, A.track_cnt = fe->track_cnt;
+  A.n_pts = fe->n_pts, A.n_forw = fe->n_forw, A.n_id = fe->n_id, A.lk_status = fe->lk_status, A.kept_xy = fe->kept_xy;
+  A.n_kept = fe->n_kept, A.hw = fe->hw, A.radius = fe->cfg.min_dist, A.f_thresh = (float)fe->cfg.f_threshold;
+  A.f_conf = fe->cfg.f_confidence;
+  const size_t shm = ((sizeof(TrackShared) + 15) & ~(size_t)15) + sizeof(RansacShared);
+  if (!fe->attr_set) {
+    HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    fe->attr_set = true;
+  }
+  hipLaunchKernelGGL(track_update_kernel, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
+  return VIO_OK;
+}
+
 int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on device */, int publish, hipStream_t st) {
   const int S = fe->n_seq, rows = fe->cfg.image_rows, cols = fe->cfg.image_cols, cap = fe->cap;
   const size_t img_bytes = (size_t)rows * cols;
@@ -1289,18 +1306,8 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     hipLaunchKernelGGL(lk_track_kernel, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
                        fe->forw_pts, fe->lk_status, fe->lk_err);
   }
-  TrackerArrays A;
-  A.cap = cap, A.rows = rows, A.cols = cols;
-  A.cur_pts = fe->cur_pts, A.pre_pts = fe->pre_pts, A.forw_pts = fe->forw_pts, A.ids = fe->ids, A.track_cnt = fe->track_cnt;
-  A.n_pts = fe->n_pts, A.n_forw = fe->n_forw, A.n_id = fe->n_id, A.lk_status = fe->lk_status, A.kept_xy = fe->kept_xy;
-  A.n_kept = fe->n_kept, A.hw = fe->hw, A.radius = fe->cfg.min_dist, A.f_thresh = (float)fe->cfg.f_threshold;
-  A.f_conf = fe->cfg.f_confidence;
-  const size_t shm = ((sizeof(TrackShared) + 15) & ~(size_t)15) + sizeof(RansacShared);
-  if (!fe->attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    fe->attr_set = true;
-  }
-  hipLaunchKernelGGL(track_update_kernel, dim3(S), dim3(256), shm, st, A, publish);
+  int rcu = launch_track_update(fe, publish, st);
+  if (rcu != VIO_OK) return rcu;
   if (publish) {
     dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
     hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
@@ -1550,6 +1557,55 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int3
   const size_t base = (size_t)seq * fe->cap;
   if (m > 0) {
     HIP_OK(hipMemcpy(cur_pts, fe->cur_pts + base * 2, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ids, fe->ids + base, sizeof(int) * m, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(track_cnt, fe->track_cnt + base, sizeof(int) * m, hipMemcpyDeviceToHost));
+  }
+  return VIO_OK;
+}
+
+// ---- the tracker's public fields in / out and the update step on its own (isolated tests of F3/F4/F6/F7) ---------------
+int vio_frontend_set_tracks(vio_frontend_t *fe, int32_t seq, int32_t n, const float *pre_pts, const float *cur_pts,
+                            const float *forw_pts, const int32_t *ids, const int32_t *track_cnt, const uint8_t *lk_status) {
+  if (!fe || seq < 0 || seq >= fe->n_seq || n < 0 || (n > 0 && (!pre_pts || !cur_pts || !forw_pts || !ids || !track_cnt || !lk_status)))
+    return VIO_EINVAL;
+  if (n > fe->cap) return VIO_ECAP;
+  VIO_ON_DEVICE_OF(fe);
+  HIP_OK(hipDeviceSynchronize());
+  const size_t base = (size_t)seq * fe->cap;
+  if (n > 0) {
+    HIP_OK(hipMemcpy(fe->pre_pts + base * 2, pre_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fe->cur_pts + base * 2, cur_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fe->forw_pts + base * 2, forw_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fe->ids + base, ids, sizeof(int) * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fe->track_cnt + base, track_cnt, sizeof(int) * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(fe->lk_status + base, lk_status, n, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipMemcpy(fe->n_pts + seq, &n, sizeof(int), hipMemcpyHostToDevice));
+  return VIO_OK;
+}
+
+int vio_frontend_update_tracks(vio_frontend_t *fe, int32_t publish) {
+  if (!fe) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
+  int rc = launch_track_update(fe, publish, fe->stream);
+  if (rc != VIO_OK) return rc;
+  HIP_OK(hipStreamSynchronize(fe->stream));
+  HIP_OK(hipGetLastError());
+  return VIO_OK;
+}
+
+int vio_frontend_get_tracks(vio_frontend_t *fe, int32_t seq, float *forw_pts, int32_t *ids, int32_t *track_cnt, int32_t cap,
+                            int32_t *n) {
+  if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
+  HIP_OK(hipDeviceSynchronize());
+  int m = 0;
+  HIP_OK(hipMemcpy(&m, fe->n_forw + seq, sizeof(int), hipMemcpyDeviceToHost));
+  *n = m;
+  if (m > cap) return VIO_ECAP;
+  const size_t base = (size_t)seq * fe->cap;
+  if (m > 0) {
+    HIP_OK(hipMemcpy(forw_pts, fe->forw_pts + base * 2, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(ids, fe->ids + base, sizeof(int) * m, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(track_cnt, fe->track_cnt + base, sizeof(int) * m, hipMemcpyDeviceToHost));
   }
