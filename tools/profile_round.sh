@@ -1,14 +1,33 @@
+# Round profiling on the GPU box (gpurun): kernel trace, HBM counters (+ calibration), SQ counters, stage cycles.
+# usage: gpurun -- 'bash tools/profile_round.sh r02_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -x
 export TMPDIR=/tmp
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_i
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+BENCH="python $R/bench.py --quick --no-cpu-baseline"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_i/kt -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_i/bench_kt.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_i/fetch -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_i/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_i/write -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_i/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -- $BENCH --steps 20 --warmup 3 > $O/bench_kt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -- $BENCH --steps 6 --warmup 2 > $O/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -- $BENCH --steps 6 --warmup 2 > $O/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch -- $R/tools/microbench/bin/pmc_calib > $O/calib_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/calib_write -- $R/tools/microbench/bin/pmc_calib > $O/calib_write.log 2>&1
+# SQ passes on the window kernel alone (counters that fit one pass each)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq1 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/sq2 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d $O/sq3 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq3.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM -d $O/sq4 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq4.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_FLAT -d $O/sq5 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq5.log 2>&1
 cd $R
-find gpurun_out/prof_i -name "*.db" | head
-python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/prof_i/bench.json 2> gpurun_out/prof_i/bench.err
-python tools/time_backend.py 1 256 > gpurun_out/prof_i/stage_cycles.txt 2>&1
-python tools/time_preprocess.py > gpurun_out/prof_i/preprocess.txt 2>&1
-python tools/time_estimator.py 256 30 > gpurun_out/prof_i/estimator.txt 2>&1
+db() { find $O/$1 -name "*.db" | head -1; }
+python tools/rocpd_summary.py $(db kt) $O/kernel_trace.txt > /dev/null
+python tools/rocpd_pmc_summary.py $(db fetch) $(db write) > $O/pmc_hbm.txt 2>&1
+python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_calib.txt 2>&1
+for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
+python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 256 sequences, prior 75" \
+  --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
+python tools/time_backend.py 1 256 > $O/stage_cycles.txt 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5
+ls -la $O
