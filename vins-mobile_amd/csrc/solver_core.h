@@ -153,8 +153,8 @@ struct WinView {
   double *imu_Mr;    // [W][15]
   double *prb0;      // [n]    b0 = J0^T r0
   double *prH0;      // [n*n]  J0^T J0
-  double *WT;        // [npose6][Fpad]  H_pf transposed: row = 6*frame + c, col = feature
-  double *WTf;       // [F][n6cap]      the same, feature-major (operand layout of the Schur GEMM)
+  double *WT;        // [npose6][Fpad]  pose-major landmark coupling: the marginalization phase only (marg_core.h)
+  double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
   // outputs
@@ -1020,7 +1020,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         double val = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * s2;
-        v.WT[(6 * t + c) * v.Fpad + f] = val;
         v.WTf[f * v.n6cap + 6 * t + c] = val;
       }
       VIO_ATOMIC_ADD(w.hff + f, (Jl[0] * Jl[0] + Jl[1] * Jl[1]) * s2);
@@ -1131,7 +1130,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     if (h >= 0)
       for (int c = 0; c < 6; c++) {
         const double val = whv[c][f];
-        v.WT[(size_t)(6 * h + c) * v.Fpad + f] = val;
         v.WTf[(size_t)f * v.n6cap + 6 * h + c] = val;
       }
   }
@@ -1161,7 +1159,6 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     if (!have_scale) {
       // the (feature, frame) entries every evaluation writes are the same; they are all assigned (not accumulated)
       // when each feature has its own thread, so zeroing is needed once (first evaluation of the solve)
-      VIO_PARFOR(q, v.npose6 * v.Fpad) v.WT[q] = 0.0;
       VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
     }
     if (v.nrev) VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
@@ -1427,9 +1424,8 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
   for (int a = 0; a < n6; a++)
     for (int b = 0; b <= a; b++) {
       int i = kBS * (a / 6) + a % 6, j = kBS * (b / 6) + b % 6;
-      const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
       double s = 0;
-      for (int f = 0; f < F; f++) s += wa[f] * w.einv[f] * wb[f];
+      for (int f = 0; f < F; f++) s += v.WTf[(size_t)f * v.n6cap + a] * w.einv[f] * v.WTf[(size_t)f * v.n6cap + b];
       *mat_at(w.Hm, i, j) -= s;
     }
 #else
@@ -1781,7 +1777,7 @@ VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd
     double x[kWStrip], s = 0;
     for (int b0 = a0; b0 < a1; b0 += kWStrip) {
       const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
-      wt_strip_load(v.WT + (size_t)b0 * v.Fpad + f, v.Fpad, nb, x);
+      wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, x);  // the lane's own contiguous strip of the feature-major W
 #pragma unroll
       for (int j = 0; j < kWStrip; j++) {
         const int a = b0 + (j < nb ? j : 0), i = kBS * (a / 6) + a % 6;
@@ -1949,7 +1945,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
               double x[kWStrip], s = 0;
               for (int b0 = a0; b0 < a1; b0 += kWStrip) {
                 const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
-                wt_strip_load(v.WT + (size_t)b0 * v.Fpad + f, v.Fpad, nb, x);
+                wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, x);  // the lane's own contiguous strip of the feature-major W
 #pragma unroll
                 for (int j = 0; j < kWStrip; j++) {
                   const int a = b0 + (j < nb ? j : 0);
