@@ -1722,37 +1722,51 @@ VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) 
   }
 #else
   const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63;
-  auto solve_diag = [&](int k) {  // x_k <- L_kk^-T x_k, lanes 0..14 of the calling wave
+  // The chain (apply block k to segment k-1, solve segment k-1) is the critical path: 11 steps one after the other on
+  // wave 0. Both of its 15-term dot products are split over the four lanes of a quad (lane = 4 c + p) and summed on the
+  // DPP network, so a step is two LDS round trips and a handful of FMAs instead of two 15-deep dependent chains.
+  const int qc = lane >> 2, qp = lane & 3;
+  const bool qok = qc < kBS;
+  const int qcc = qok ? qc : 0;
+  auto solve_diag = [&](int k) {  // x_k <- L_kk^-T x_k: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
     auto D = w.Hm + blk_off(k, k);
-    const int c = lane < kBS ? lane : 0;
-    double sacc = w.ldinv[k * kBS + c] * x[k * kBS + c];
+    double sacc = qp == 0 ? w.ldinv[k * kBS + qcc] * x[k * kBS + qcc] : 0.0;
 #pragma unroll
-    for (int r = 1; r < kBS; r++) {
-      const int rr = c + r < kBS ? c + r : c;
-      const double lv = D[c * kBS + rr], xv = x[k * kBS + rr];
-      sacc = fma(c + r < kBS ? lv : 0.0, xv, sacc);
+    for (int t4 = 0; t4 < 4; t4++) {
+      const int r = qcc + 1 + qp + 4 * t4;
+      const bool in = qok && r < kBS;
+      const double lv = D[qcc * kBS + (in ? r : qcc)], xv = x[k * kBS + (in ? r : qcc)];
+      sacc = fma(in ? lv : 0.0, xv, sacc);
     }
+    sacc = quad_sum_f64(sacc);
     __builtin_amdgcn_wave_barrier();
-    if (lane < kBS) x[k * kBS + c] = sacc;
+    if (qok && qp == 0) x[k * kBS + qc] = sacc;
   };
-  auto apply = [&](int k, int j, int c) {  // y_j[c] -= (L_kj^T x_k)[c]
+  auto apply_quad = [&](int k, int j) {  // y_j[c] -= (L_kj^T x_k)[c], c = lane >> 2
     auto Lkj = w.Hm + blk_off(k, j);
-    double sacc = 0;
+    double sacc = 0.0;
 #pragma unroll
-    for (int m = 0; m < kBS; m++) sacc = fma(Lkj[m * kBS + c], x[k * kBS + m], sacc);
-    x[j * kBS + c] -= sacc;
+    for (int t4 = 0; t4 < 4; t4++) {
+      const int m = qp + 4 * t4;
+      const bool in = m < kBS;
+      const double lv = Lkj[(in ? m : 0) * kBS + qcc], xv = x[k * kBS + (in ? m : 0)];
+      sacc = fma(in ? lv : 0.0, xv, sacc);
+    }
+    sacc = quad_sum_f64(sacc);
+    if (qok && qp == 0) x[j * kBS + qc] -= sacc;
   };
   if (wave == 0) solve_diag(nb - 1);
   VIO_SYNC();
   for (int k = nb - 1; k >= 1; k--) {
     if (wave == 0) {
-      if (lane < kBS) apply(k, k - 1, lane);
+      apply_quad(k, k - 1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       solve_diag(k - 1);
     } else {
-      for (int q = tid_ - 64; q < (k - 1) * kBS; q += (int)cx.nt - 64) apply(k, q / kBS, q % kBS);
+      const int nwv = (int)cx.nt >> 6;
+      for (int j = wave - 1; j < k - 1; j += nwv - 1) apply_quad(k, j);  // one block per wave at a time
     }
     VIO_SYNC();
   }
