@@ -235,10 +235,10 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     VIO_SYNC();
     dense_matvec_cols(cx, v.prH0, pn, m.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(m.prr + i, sacc); });
     {
-      const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
-      for (int a = tid_ >> 6; a < pn; a += nwv) {
+      const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
+      for (int a = tid_ / kLanes; a < pn; a += nwv) {
         const int ca = m.pcol[a];
-        for (int b = lane; b < pn; b += 64) m.Am[ca * ld + m.pcol[b]] = v.prH0[a * pn + b];
+        for (int b = lane; b < pn; b += kLanes) m.Am[ca * ld + m.pcol[b]] = v.prH0[a * pn + b];
       }
     }
     VIO_SYNC();

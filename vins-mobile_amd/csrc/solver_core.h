@@ -696,9 +696,9 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
   }
   // rows of the symmetric H0 by wave, columns by lane: no integer division per element
   {
-    const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
-    for (int a = tid_ >> 6; a < n; a += nwv)
-      for (int b = lane; b < n; b += 64) {
+    const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
+    for (int a = tid_ / kLanes; a < n; a += nwv)
+      for (int b = lane; b < n; b += kLanes) {
         double s = 0;
         if (stage) {
 #pragma unroll 5
@@ -1136,9 +1136,13 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   return cost;
 }
 
+// keep_aux (cost-only evaluation of a candidate): also leave the raw IMU Jacobians behind; reuse_aux (the Jacobian
+// evaluation at a point whose cost-only evaluation just ran, i.e. an accepted step): the prior's dx and J^T r (prdx, prr)
+// and the raw IMU residuals / Jacobians (imu_r, imu_J) of that evaluation are still valid and are not formed again --
+// two serial few-thread phases and a mat-vec less per accepted iteration.
 template <class WK>
 VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, cldsd sb,
-                        cldsd feat, bool jac, bool have_scale = false) {
+                        cldsd feat, bool jac, bool have_scale = false, bool reuse_aux = false, bool keep_aux = false) {
   const int np = v.np;
   double cost = 0.0;  // per-thread partial, reduced at the end
   VIO_PARFOR(i, v.P + v.has_loop + 1) {  // rotation matrices for the projection factors (consumed after a barrier)
@@ -1171,7 +1175,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
   }
   // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
   const int n = v.prior_n;
-  if (n > 0) {
+  if (n > 0 && !reuse_aux) {
     VIO_PARFOR(b, v.prior_nb) {
       int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
       const double *x0 = v.pr_x0 + 9 * b;
@@ -1196,13 +1200,13 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       }
       // H0 -> the reduced matrix: rows by wave, columns by lane, eight rows' loads in flight before the first store
       // (one dependent global load per row otherwise: the phase is nothing but L2 latency)
-      const int tid_ = VIO_TID(cx), lane = tid_ & 63, nwv = (int)cx.nt >> 6;
+      const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
       constexpr int kU = 8;
-      for (int b0 = 0; b0 < n; b0 += 64) {
+      for (int b0 = 0; b0 < n; b0 += kLanes) {
         const int b = b0 + lane;
         const bool bok = b < n;
         const int pb = w.prcol[bok ? b : 0];
-        for (int a0 = tid_ >> 6; a0 < n; a0 += nwv * kU) {
+        for (int a0 = tid_ / kLanes; a0 < n; a0 += nwv * kU) {
           double x[kU];
 #pragma unroll
           for (int u = 0; u < kU; u++) {
@@ -1250,11 +1254,13 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
   }
   stamp(cx, jac ? ST_EVAL_PRIOR : ST_COST_EVAL);
   // ---- IMU factors -------------------------------------------------------------------------------
-  VIO_PARFOR(f, v.W) {
-    imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
-                 sb + 9 * (f + 1), v.imu_r + f * 15, jac ? v.imu_J + f * 450 : nullptr);
+  if (!reuse_aux) {
+    VIO_PARFOR(f, v.W) {
+      imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
+                   sb + 9 * (f + 1), v.imu_r + f * 15, (jac || keep_aux) ? v.imu_J + f * 450 : nullptr);
+    }
+    VIO_SYNC();
   }
-  VIO_SYNC();
   if (jac) stamp(cx, ST_IMU_RAW);
   VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
     int f = q / 15, r = q % 15;
@@ -2086,7 +2092,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     VIO_SYNC();
     apply_plus(cx, v, w, w.t2, w.tf);
     stamp(cx, ST_DOGLEG);
-    double cand_cost = evaluate(cx, v, w, w.cpose, w.csb, w.cfeat, false);
+    double cand_cost = evaluate(cx, v, w, w.cpose, w.csb, w.cfeat, false, false, false, true);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     double step_norm, dummy;
     state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
@@ -2102,7 +2108,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       VIO_PARFOR(q, F) w.xfeat[q] = w.cfeat[q];
       VIO_SYNC();
       state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
-      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true, /*reuse_aux=*/true);  // (x is the candidate just evaluated)
       gmax = grad_max_norm();
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
