@@ -152,6 +152,8 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   return v;
 }
 
+constexpr size_t kLdsBytes = 160 * 1024;  // LDS of one CU (gfx950), the budget of one window
+
 // ---- LDS working set ------------------------------------------------------------------------------------
 // Carves `base` (LDS, 16-byte aligned) into the Work arrays for capacities d. When lds_matrix is false the matrix
 // lives in global memory (hm_global). Returns the number of bytes used.
@@ -213,6 +215,14 @@ VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, l
   w.ppd = take(36 * (size_t)(d.Pcap + 1));
   w.rot = take(9 * (size_t)(d.Pcap + 2));
   w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
+  // global-matrix variant: what is left of the CU's LDS holds the current block column of L during the factorization
+  // (solver_core.h cholesky_blocks_panel); without room for it the operands come from global memory
+  w.panel = nullptr, w.ctr = nullptr;
+  const size_t panel_doubles = (size_t)(d.nblk_cap > 1 ? d.nblk_cap - 1 : 1) * kBB + 16;
+  if (!lds_matrix && (o + panel_doubles + (size_t)d.nblk_cap / 2 + 4) * sizeof(double) <= kLdsBytes) {
+    w.panel = take(panel_doubles);
+    w.ctr = reinterpret_cast<ldsi>(take((size_t)d.nblk_cap / 2 + 1));
+  }
   c.bytes = o * sizeof(double);
   return c;
 }

@@ -181,6 +181,8 @@ struct WorkT {
   ldsd hdiag, hff;          // diag(H_pp), H_ff (unscaled)
   ldsd ef, einv;            // e_f = sf^2 hff + mu df^2 and its reciprocal
   ldsi blk_ij;              // block index -> (bi << 8) | bj
+  ldsd panel;               // global-matrix variant: LDS copy of the current block column of L (nblk - 1 blocks), or null
+  ldsi ctr;                 // global-matrix variant: [nblk] work counters of the trailing updates
   ldsd ldinv;               // 1 / L_ii
   ldsd t1, t2;              // np temporaries
   ldsd tf;                  // F temporary
@@ -767,8 +769,8 @@ VIO_DEV void load_operand15(MP X, int lane, double out[4]) {
 // ET (initially I) receives the same eliminations, ET -= l e^T with e = ET[c][:] / L_cc, which leaves e = row c of
 // L^-1. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
 // triangle (D[n][c] = Linv[c][n], n < c), 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
-template <class MP>
-VIO_DEV bool potrf15_inv_wave(MP D, MP Lprev, bool with_update, ldsd ldinv_k, int lane) {
+template <class MP, class LP>
+VIO_DEV bool potrf15_inv_wave(MP D, LP Lprev, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
 #pragma unroll
@@ -884,10 +886,33 @@ VIO_DEV void block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool second
   store_acc(C0, m, acc0);
   if (second) store_acc(C1, m, acc1);
 }
+// 2 x 2 blocks of the trailing matrix by one wave: C_ab -= A_a B_b^T with the four operands fetched once (panel blocks
+// in LDS) and the four accumulators read-modify-written in global memory. `diag`: the tile sits on the diagonal (B_b is
+// A_b), block (0,1) is above it and skipped; has1: block row / column 1 exists; skip00: block (0,0) belongs to the
+// look-ahead wave.
+template <class MP, class OP>
+VIO_DEV void block_update_2x2(MP C00, MP C10, MP C11, MP C01, OP A0, OP A1, OP B0, OP B1, bool diag, bool has_a1, bool has_b1,
+                              bool skip00, const LaneMap &m) {
+  double a0[4], a1[4], b0[4], b1[4];
+  load_op(A0, m, a0), load_op(A1, m, a1), load_op(B0, m, b0), load_op(B1, m, b1);
+  const bool do01 = !diag && has_b1, do10 = has_a1, do11 = has_a1 && has_b1;
+  v4d c00 = load_acc(C00, m), c10 = load_acc(C10, m), c11 = load_acc(C11, m), c01 = load_acc(C01, m);
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) {
+    c00 = mfma_f64(-a0[s4], b0[s4], c00);
+    c10 = mfma_f64(-a1[s4], b0[s4], c10);
+    c11 = mfma_f64(-a1[s4], b1[s4], c11);
+    c01 = mfma_f64(-a0[s4], b1[s4], c01);
+  }
+  if (!skip00) store_acc(C00, m, c00);
+  if (do10) store_acc(C10, m, c10);
+  if (do11) store_acc(C11, m, c11);
+  if (do01) store_acc(C01, m, c01);
+}
 // A_ik <- A_ik L_kk^-T with the inverse potrf15_inv_wave leaves behind (strict lower part of L^-1 transposed above the
 // diagonal of the block, 1 / L_cc in ldinv_k)
 template <class MP>
-VIO_DEV void block_trsm(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
+VIO_DEV v4d block_trsm_acc(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   double a[4];
   load_op(Aik, m, a);
@@ -902,7 +927,11 @@ VIO_DEV void block_trsm(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lan
     const double bb = (m.i_ok && kk < n) ? b[s4] : ((m.i_ok && kk == n) ? dg : 0.0);
     acc = mfma_f64(a[s4], bb, acc);
   }
-  store_acc(Aik, m, acc);
+  return acc;
+}
+template <class MP>
+VIO_DEV void block_trsm(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
+  store_acc(Aik, m, block_trsm_acc(Aik, Dkk, ldinv_k, m, lane));
 }
 // Sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane of the quad gets the total.
 VIO_DEV double quad_sum_f64(double v) {
@@ -1580,6 +1609,71 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 // (The VIO_EMUL build runs the textbook scalar version of the same factorization.)
 // false when a pivot is <= 0 (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
 #ifndef VIO_EMUL
+// The same factorization for a matrix that lives in global memory (windows whose reduced system does not fit the LDS).
+// There the trailing update is bound by the CU's vector-memory path, not by the matrix cores: per block product the
+// plain version moves two operand blocks (16 partially filled cache lines per fetch) and the accumulator both ways. Here
+//   * TRSM leaves the block column k of L in LDS as well (w.panel), every operand of step k is a ds_read;
+//   * a wave updates 2 x 2 blocks per visit: 4 LDS operand fetches for 4 products, 16 back-to-back MFMA;
+//   * tiles are handed out through an LDS counter, so the look-ahead wave joins once the next diagonal block is done.
+template <class WK>
+VIO_DEV bool cholesky_blocks_panel(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
+  const int nb = v.nblk;
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const LaneMap m = lane_map(lane);
+  if (wave == 0) {
+    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
+    if (!good && lane == 0) w.flag[1] = 1;
+  }
+  VIO_PARFOR(q, nb) w.ctr[q] = 0;
+  VIO_SYNC();
+  stamp(cx, ST_C_POTRF);
+  for (int k = 0; k < nb; k++) {
+    if (w.flag[1]) return false;
+    auto D = w.Hm + blk_off(k, k);
+    const int ntb = nb - k - 1;
+    for (int bi = wave; bi < ntb; bi += nw) {
+      auto Aik = w.Hm + blk_off(k + 1 + bi, k);
+      const v4d l = block_trsm_acc(Aik, D, w.ldinv + k * kBS, m, lane);
+      store_acc(Aik, m, l);
+      store_acc(w.panel + bi * kBB, m, l);
+    }
+    if (wave == nw - 1) block_forward_diag(D, w.ldinv + k * kBS, rhs + k * kBS, lane);
+    VIO_SYNC();
+    stamp(cx, ST_C_TRSM);
+    if (wave == 0) {
+      if (ntb > 0) {
+        bool good = potrf15_inv_wave(w.Hm + blk_off(k + 1, k + 1), w.panel, true, w.ldinv + (k + 1) * kBS, lane);
+        if (!good && lane == 0) w.flag[1] = 1;
+      }
+      stamp(cx, ST_C_AHEAD);
+    } else {
+      for (int bi = wave - 1; bi < ntb; bi += nw - 1)  // rhs_i -= L_ik y_k
+        block_rhs_update(w.panel + bi * kBB, rhs + (k + 1 + bi) * kBS, rhs + k * kBS, lane);
+    }
+    // 2 x 2 tiles of the trailing lower triangle: tile row I >= tile column J over nt2 = ceil(ntb / 2)
+    const int nt2 = (ntb + 1) >> 1, ntiles = nt2 * (nt2 + 1) / 2;
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(w.ctr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= ntiles) break;
+      const int ij = w.blk_ij[t], I = ij >> 8, J = ij & 255;  // (the block table enumerates a lower triangle row by row)
+      const int i0 = 2 * I, j0 = 2 * J;
+      const bool has_a1 = i0 + 1 < ntb, has_b1 = j0 + 1 < ntb, diag = I == J;
+      const int i1 = has_a1 ? i0 + 1 : i0, j1 = has_b1 ? j0 + 1 : j0;
+      const int gi0 = k + 1 + i0, gi1 = k + 1 + i1, gj0 = k + 1 + j0, gj1 = k + 1 + j1;
+      block_update_2x2(w.Hm + blk_off(gi0, gj0), w.Hm + blk_off(gi1, gj0), w.Hm + blk_off(gi1, gj1),
+                       w.Hm + (diag ? blk_off(gi0, gj0) : blk_off(gi0, gj1)), w.panel + i0 * kBB, w.panel + i1 * kBB,
+                       w.panel + j0 * kBB, w.panel + j1 * kBB, diag, has_a1, has_b1, /*skip00=*/t == 0, m);
+    }
+    VIO_SYNC();
+    stamp(cx, ST_C_WAIT);
+  }
+  return w.flag[1] == 0;
+}
+#endif
+
+#ifndef VIO_EMUL
 template <class WK>
 VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
   const int nb = v.nblk;
@@ -1947,7 +2041,14 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
         VIO_SYNC();
         bool ok = build_reduced_system(cx, v, w, mu);
-        if (ok) ok = cholesky_blocks(cx, v, w, w.t1);
+        if (ok) {
+#ifndef VIO_EMUL
+          if constexpr (std::is_same<decltype(w.Hm), double *>::value)
+            ok = w.panel ? cholesky_blocks_panel(cx, v, w, w.t1) : cholesky_blocks(cx, v, w, w.t1);
+          else
+#endif
+            ok = cholesky_blocks(cx, v, w, w.t1);
+        }
         stamp(cx, ST_CHOL);
         if (ok) {
           cholesky_backsolve(cx, v, w, w.t1);  // y_p

@@ -25,7 +25,7 @@ using namespace vio;
 namespace {
 
 constexpr int kThreads = 512;
-constexpr size_t kLdsLimit = 160 * 1024;
+constexpr size_t kLdsLimit = vio::kLdsBytes;
 
 struct MargPtrs {
   int *ints;        // [n][4 + 3 * kMaxPriorBlocks]
