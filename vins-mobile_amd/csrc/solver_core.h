@@ -671,6 +671,14 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
 }
 #endif
 
+#ifndef VIO_EMUL
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C. Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives
+// D[(l>>4) + 4 r][l&15] in element r (the f64 C/D map differs from the f32 one, cdna_hip_programming.md §3).
+VIO_DEV v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+#endif
+
 // Prior constants. MarginalizationFactor evaluates r = r0 + J0 dx with a constant J0 (marginalization_factor.cpp:
 // 336-384); everything the solver takes from it is a function of  H0 = J0^T J0  and  b0 = J0^T r0:
 //     J^T r = b0 + H0 dx,    cost = |r0|^2 / 2 + b0 . dx + dx . (H0 dx) / 2,    J^T J = H0,
@@ -696,9 +704,57 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
     VIO_PARFOR(q, n * n) Js[q] = v.pr_J[q];
     VIO_SYNC();
   }
+#ifndef VIO_EMUL
+  // H0 = J0^T J0 on the matrix cores: one 16 x 16 tile of the lower triangle per wave visit (mirrored on store), the
+  // k loop in chunks of 8 steps whose 16 operand fetches (4 row segments of 128 B each) are issued together
+  {
+    const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+    const int li = lane & 15, kq = lane >> 4;
+    const int nt16 = (n + 15) >> 4, ntiles = nt16 * (nt16 + 1) / 2, ksteps = (n + 3) >> 2;
+    for (int t = wave; t < ntiles; t += nw) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+      const int tj = t - ti * (ti + 1) / 2;
+      const int ca = 16 * ti + li, cb = 16 * tj + li;
+      const bool va = ca < n, vb = cb < n;
+      const int oa = va ? ca : 0, ob = vb ? cb : 0;
+      v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      constexpr int kChunk = 8;
+      for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
+        double av[kChunk], bv[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+          const int k = 4 * (s0 + j) + kq, kc = k < n ? k : 0;
+          if (stage) av[j] = Js[kc * n + oa], bv[j] = Js[kc * n + ob];
+          else av[j] = v.pr_J[kc * n + oa], bv[j] = v.pr_J[kc * n + ob];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) {
+          const bool vk = 4 * (s0 + j) + kq < n;
+          av[j] = (va && vk) ? av[j] : 0.0, bv[j] = (vb && vk) ? bv[j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; j += 2) acc0 = mfma_f64(av[j], bv[j], acc0), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
+      }
+      acc0 += acc1;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {  // element r: row 16 ti + kq + 4 r, column 16 tj + li
+        const int a = 16 * ti + kq + 4 * r, b = cb;
+        if (a < n && b < n) {
+          v.prH0[a * n + b] = acc0[r];
+          if (ti != tj) v.prH0[b * n + a] = acc0[r];
+        }
+      }
+    }
+  }
+  if (false) {
+    const int tid_ = 0, kLanes = 1, lane = 0, nwv = 1;
+#else
   // rows of the symmetric H0 by wave, columns by lane: no integer division per element
   {
     const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
+#endif
     for (int a = tid_ / kLanes; a < n; a += nwv)
       for (int b = lane; b < n; b += kLanes) {
         double s = 0;
@@ -725,11 +781,6 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
 
 // ---- wave-level device helpers (matrix cores, v_readlane) ------------------------------------------
 #ifndef VIO_EMUL
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-// v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C. Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives
-// D[(l>>4) + 4 r][l&15] in element r (the f64 C/D map differs from the f32 one, cdna_hip_programming.md §3).
-VIO_DEV v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // Value of x held by `lane` (compile-time constant) broadcast to the whole wave through SGPRs.
 VIO_DEV double lane_bcast(double x, int lane) {
