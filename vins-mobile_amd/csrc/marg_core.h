@@ -38,6 +38,7 @@ struct MargWorkT {
   int ld;
   ldsd bm;       // pos
   ldsd tol;      // pos
+  ldsd ldinv;    // pos: 1 / L_jj (0 for a cut pivot)
   ldsd hff, gf, einv;  // F
   ldsd prdx, prr;      // prior_n
   ldsi col_pose;  // [P+1]: first dense column of pose i (-1: not involved); entry P unused
@@ -94,7 +95,8 @@ VIO_HD CarvedMarg<MP> carve_marg_all(const Dims &d, bool lds_matrix, ldsd base_a
   const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Flds;
   ldsd Am = lds_matrix ? take(pos * pos) : nullptr;
   MargWorkT<MP> &m = c.m;
-  m.bm = take(pos), m.tol = take(pos), m.hff = take(F), m.gf = take(F), m.einv = take(F);
+  m.bm = take(pos + 16), m.tol = take(pos + 16), m.ldinv = take(pos + 16);  // (+16: whole 16-wide tiles)
+  m.hff = take(F), m.gf = take(F), m.einv = take(F);
   m.prdx = take(d.Ncap), m.prr = take(d.Ncap);
   ldsd ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
   // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows;
@@ -125,6 +127,191 @@ VIO_HD size_t carve_marg(const Dims &d, bool lds_matrix, ldsd base_after_state, 
   if (m) *m = c.m;
   return c.bytes;
 }
+
+#ifndef VIO_EMUL
+// ---- tiled factorization of the dense marginalization matrix on the matrix cores ----------------------------------
+// 16 x 16 tiles of the row-major pos x pos matrix (leading dimension ld), the structure of cholesky_blocks
+// (solver_core.h): one wave factors the diagonal tile and produces its inverse, TRSM and the trailing update are MFMA
+// products, wave 0 looks ahead. Differences: a pivot <= tol is CUT (its column of L, its row of L^-1 and its entry of
+// the carried right-hand side become 0 -- the pseudo-inverse of the reference), and the last tile may be partial.
+// Per-lane offsets: operand X[i][kq + 4 s] at i * ld + kq + 4 s, accumulator C[kq + 4 r][i] at (kq + 4 r) * ld + i.
+template <class MP>
+VIO_DEV void dtile_load_op(MP X, int op, double out[4]) {
+  out[0] = X[op], out[1] = X[op + 4], out[2] = X[op + 8], out[3] = X[op + 12];
+}
+template <class MP>
+VIO_DEV v4d dtile_load_acc(MP C, int acc, int ld) {
+  v4d a;
+  a[0] = C[acc], a[1] = C[acc + 4 * ld], a[2] = C[acc + 8 * ld], a[3] = C[acc + 12 * ld];
+  return a;
+}
+template <class MP>
+VIO_DEV void dtile_store_acc(MP C, int acc, int ld, v4d a, int kq, int rows, bool col_ok = true) {  // rows: valid rows of the tile
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    if (col_ok && kq + 4 * r < rows) C[acc + 4 * r * ld] = a[r];
+}
+
+// Diagonal tile: L (lower, with diagonal) in place, the strict lower part of L^-1 transposed above the diagonal,
+// 1 / L_cc (0: cut) in ldinv_k. nvalid: rows / columns of the tile inside the matrix; tolv: lane n holds tol of column n.
+template <class MP, class LP>
+VIO_DEV void potrf16_cut_wave(MP D, LP Lprev, int ld, int nvalid, bool with_update, double tolv, ldsd ldinv_k, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  v4d A, E;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int mm = kq + 4 * r;
+    const bool ok = mm < nvalid && n < nvalid;
+    const int hi = mm > n ? mm : n, lo = mm > n ? n : mm;
+    const double x = D[ok ? hi * ld + lo : 0];
+    A[r] = ok ? x : 0.0;
+    E[r] = (mm == n) ? 1.0 : 0.0;
+  }
+  if (with_update) {  // look-ahead: D -= Lprev Lprev^T (the panel tile left of D)
+    double l[4];
+    dtile_load_op(Lprev, (n < nvalid ? n : 0) * ld + kq, l);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const double ls = n < nvalid ? l[s] : 0.0;
+      A = mfma_f64(-ls, ls, A);
+    }
+  }
+  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
+  double dcc = lane_bcast(A[0], 0);
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const double tol_c = lane_bcast(tolv, c);
+    double y = __builtin_amdgcn_rsq(dcc);
+    const double h = 0.5 * dcc;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    y = (dcc > tol_c) ? y : 0.0;  // cut pivot (also NaN): the direction carries no information
+    const bool sel = kq == (c & 3);
+    const double a = sel ? A[c >> 2] * y : 0.0;  // L[n][c]
+    const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
+    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+    myinv = (n == c) ? y : myinv;
+    if (c + 1 < 16) {
+      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
+      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
+      dcc = fma(-lnext, lnext, dold);
+    }
+    A = mfma_f64(-a, a, A);
+    E = mfma_f64(-a, e, E);
+  }
+  if (n < nvalid) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = kq + 4 * j;
+      if (c < nvalid) D[n * ld + c] = keep[j];
+    }
+    if (kq == 0) ldinv_k[n] = myinv;
+  }
+}
+
+// A_ik <- A_ik L_kk^-T (rows: valid rows of the tile)
+template <class MP>
+VIO_DEV void dtile_trsm(MP Aik, MP Dkk, cldsd ldinv_k, int ld, int rows, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  double a[4];
+  dtile_load_op(Aik, n * ld + kq, a);
+  const v4d b = dtile_load_acc(Dkk, kq * ld + n, ld);  // Dkk[kq + 4 s][n] = Linv[n][kq + 4 s] for kq + 4 s < n
+  const double dg = ldinv_k[n];
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) {
+    const int kk = 4 * s4 + kq;
+    const double bb = kk < n ? b[s4] : (kk == n ? dg : 0.0);
+    acc = mfma_f64(a[s4], bb, acc);
+  }
+  dtile_store_acc(Aik, kq * ld + n, ld, acc, kq, rows);
+}
+// y_k = L_kk^-1 b_k in place by 16 lanes of one wave
+template <class MP>
+VIO_DEV void dtile_forward_diag(MP Dkk, cldsd ldinv_k, ldsd bk, int ld, int nvalid, int lane) {
+  const int c = lane & 15;
+  double s = ldinv_k[c] * bk[c];
+#pragma unroll
+  for (int n = 0; n < 15; n++) {
+    const double x = Dkk[n * ld + c], bn = bk[n];
+    s = fma(n < c ? x : 0.0, n < c ? bn : 0.0, s);
+  }
+  if (lane < 16 && c < nvalid) bk[c] = s;
+}
+// b_i -= L_ik y_k: lane = 4 r + p, the four lanes of a quad split the 16 terms
+template <class MP>
+VIO_DEV void dtile_rhs_update(MP Lik, ldsd bi, cldsd yk, int ld, int rows, int lane) {
+  const int r = lane >> 2, p = lane & 3;
+  auto Lr = Lik + r * ld + p;
+  double s = Lr[0] * yk[p];
+  s = fma(Lr[4], yk[p + 4], s);
+  s = fma(Lr[8], yk[p + 8], s);
+  s = fma(Lr[12], yk[p + 12], s);
+  s = quad_sum_f64(s);
+  if (p == 0 && r < rows) bi[r] -= s;
+}
+// two independent tile updates C -= A B^T by one wave
+template <class MP>
+VIO_DEV void dtile_update2(MP C0, MP A0, MP B0, int rows0, int cols0, MP C1, MP A1, MP B1, int rows1, int cols1, int ld, int lane) {
+  const int n = lane & 15, kq = lane >> 4, op = n * ld + kq, acc = kq * ld + n;
+  double a0[4], b0[4], a1[4], b1[4];
+  dtile_load_op(A0, op, a0), dtile_load_op(B0, op, b0), dtile_load_op(A1, op, a1), dtile_load_op(B1, op, b1);
+  v4d c0 = dtile_load_acc(C0, acc, ld), c1 = dtile_load_acc(C1, acc, ld);
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) {
+    c0 = mfma_f64(-a0[s4], b0[s4], c0);
+    c1 = mfma_f64(-a1[s4], b1[s4], c1);
+  }
+  // (a partial last tile: with ld == pos its columns past the matrix ARE the next row's first entries)
+  dtile_store_acc(C0, acc, ld, c0, kq, rows0, n < cols0);
+  dtile_store_acc(C1, acc, ld, c1, kq, rows1, n < cols1);  // (rows1 = 0: no second tile)
+}
+
+// In place: the lower triangle of Am becomes L (cut columns zero), m.bm becomes L^-1 b. m.tol holds the cut thresholds.
+template <class MW>
+VIO_DEV void marg_cholesky_tiles(const Ctx &cx, MW &m, int pos) {
+  const int ld = m.ld, nt = (pos + 15) >> 4;
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  auto tile = [&](int ti, int tj) { return m.Am + (16 * ti) * ld + 16 * tj; };
+  auto rows_of = [&](int ti) { return pos - 16 * ti < 16 ? pos - 16 * ti : 16; };
+  auto tol_of = [&](int ti) {
+    const int j = 16 * ti + (lane & 15);
+    const double t = m.tol[j];  // (padded: readable past pos)
+    return j < pos ? t : 1.0;
+  };
+  if (wave == 0) potrf16_cut_wave(tile(0, 0), tile(0, 0), ld, rows_of(0), false, tol_of(0), m.ldinv, lane);
+  VIO_SYNC();
+  for (int k = 0; k < nt; k++) {
+    const int ntb = nt - k - 1;
+    for (int bi = wave; bi < ntb; bi += nw) dtile_trsm(tile(k + 1 + bi, k), tile(k, k), m.ldinv + 16 * k, ld, rows_of(k + 1 + bi), lane);
+    if (wave == nw - 1) dtile_forward_diag(tile(k, k), m.ldinv + 16 * k, m.bm + 16 * k, ld, rows_of(k), lane);
+    VIO_SYNC();
+    if (wave == 0) {
+      if (ntb > 0) potrf16_cut_wave(tile(k + 1, k + 1), tile(k + 1, k), ld, rows_of(k + 1), true, tol_of(k + 1), m.ldinv + 16 * (k + 1), lane);
+    } else {
+      const int stride = nw - 1;
+      for (int bi = wave - 1; bi < ntb; bi += stride)
+        dtile_rhs_update(tile(k + 1 + bi, k), m.bm + 16 * (k + 1 + bi), m.bm + 16 * k, ld, rows_of(k + 1 + bi), lane);
+      const int npairs = ntb * (ntb + 1) / 2;  // pair 0 = the look-ahead tile
+      auto pair_ij = [&](int p, int &ti, int &tj) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= p) a++;
+        ti = a, tj = p - a * (a + 1) / 2;
+      };
+      for (int pr = wave; pr < npairs; pr += 2 * stride) {
+        const int pr1 = pr + stride;
+        const bool second = pr1 < npairs;
+        int i0, j0, i1, j1;
+        pair_ij(pr, i0, j0), pair_ij(second ? pr1 : pr, i1, j1);
+        i0 += k + 1, j0 += k + 1, i1 += k + 1, j1 += k + 1;
+        dtile_update2(tile(i0, j0), tile(i0, k), tile(j0, k), rows_of(i0), rows_of(j0), tile(i1, j1), tile(i1, k), tile(j1, k),
+                      second ? rows_of(i1) : 0, rows_of(j1), ld, lane);
+      }
+    }
+    VIO_SYNC();
+  }
+}
+#endif
 
 template <class MW>
 VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpose, cldsd xsb, cldsd xfeat, cldsd ex,
@@ -517,6 +704,9 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   // The lower-triangle entries (i, k) are listed once, columns from last to first, in the staging area the build phase
   // no longer needs: the entries step j touches (k > j) are a PREFIX of that list, so every lane has an element and no
   // index arithmetic beyond one table read.
+#ifndef VIO_EMUL
+  marg_cholesky_tiles(cx, m, pos);
+#else
   auto tab = reinterpret_cast<typename IntPtrOf<decltype(m.stage)>::type>(m.stage);
   const bool use_tab = (size_t)m.stage_slots * kMargSlot * 2 >= (size_t)pos * (pos - 1) / 2 + 2;
   if (use_tab) {
@@ -569,6 +759,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   }
   VIO_PARFOR(j, pos) m.bm[j] *= m.tol[j];
   VIO_SYNC();
+#endif
   // ---- outputs: J0 = L'^T (upper triangular), r0 = y' ---------------------------------------------------
   VIO_PARFOR(q, n * n) {
     int r = q / n, c = q % n;
