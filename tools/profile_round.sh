@@ -28,6 +28,7 @@ for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep 
 python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 256 sequences, prior 75" \
   --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
 python tools/time_backend.py 1 256 > $O/stage_cycles.txt 2>&1
+python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5
 ls -la $O
