@@ -127,6 +127,7 @@ struct vio_backend {
   int n = 0;
   bool uploaded = false;
   hipStream_t last_stream = nullptr;  // where the last launch went: what sync / download wait for
+  hipEvent_t upload_done = nullptr;   // recorded behind the upload's copies on `stream`: launches on another stream wait for it
   bool lds_matrix = true;  // every window of the batch runs the LDS variant
   // a batch is split by variant: windows whose matrix and vectors fit the CU's LDS, and the rest (relocalization pose,
   // very many landmarks) with the matrix in global scratch
@@ -141,9 +142,9 @@ struct vio_backend {
   HostBatch hb;
   BatchPtrs B;
   MargPtrs MP;
-  DevBuf<int> d_hdr, d_fhost, d_ftarget, d_ffeat, d_pr_kind, d_pr_index, d_pr_offset, d_stats_i, d_m_ints, d_fslot,
-      d_fstart, d_pair_h, d_pair_t, d_pair_s0, d_pair_s1;
-  DevBuf<double> d_hdr_d, d_pose, d_sb, d_ex, d_feat, d_pts_i, d_pts_j, d_preint, d_pr_x0, d_pr_J, d_pr_r, d_scratch,
+  DevBuf<unsigned char> d_in;  // every input array, laid out like the host staging arena (HostBatch::off)
+  DevBuf<int> d_stats_i, d_m_ints;
+  DevBuf<double> d_scratch,
       d_hm, d_out_pose, d_out_sb, d_out_feat, d_raw_pose, d_raw_sb, d_raw_feat, d_out_loop, d_stats_d, d_m_x0, d_m_J,
       d_m_r, d_m_scratch;
   // device-resident prior chain (vio_backend_reserve_priors): st_n slots x 2 banks; st_bank[k] = the bank slot k's
@@ -216,12 +217,9 @@ void vio_backend_destroy(vio_backend_t *be) {
   vio::DeviceScope scope(be->device);
   (void)hipStreamSynchronize(be->stream);
   for (auto &e : be->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
-  DevBuf<int> *ib[] = {&be->d_hdr, &be->d_fhost, &be->d_ftarget, &be->d_ffeat, &be->d_pr_kind, &be->d_pr_index,
-                       &be->d_pr_offset, &be->d_stats_i, &be->d_m_ints, &be->d_fslot, &be->d_fstart, &be->d_pair_h,
-                       &be->d_pair_t, &be->d_pair_s0, &be->d_pair_s1};
-  for (auto *b : ib) b->release();
-  DevBuf<double> *db[] = {&be->d_hdr_d, &be->d_pose, &be->d_sb, &be->d_ex, &be->d_feat, &be->d_pts_i, &be->d_pts_j,
-                          &be->d_preint, &be->d_pr_x0, &be->d_pr_J, &be->d_pr_r, &be->d_scratch, &be->d_hm,
+  if (be->upload_done) (void)hipEventDestroy(be->upload_done);
+  be->d_in.release(), be->d_stats_i.release(), be->d_m_ints.release();
+  DevBuf<double> *db[] = {&be->d_scratch, &be->d_hm,
                           &be->d_out_pose, &be->d_out_sb, &be->d_out_feat, &be->d_raw_pose, &be->d_raw_sb,
                           &be->d_raw_feat, &be->d_out_loop, &be->d_stats_d, &be->d_m_x0, &be->d_m_J, &be->d_m_r,
                           &be->d_m_scratch};
@@ -313,15 +311,17 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
       (!any_loop || pd.nblk_cap == pd.Pcap + 1)) {
     d = pd;
   } else {
-    // 25 % headroom, then rounded: landmark and factor counts of a running batch drift by a few percent from frame to
+    // headroom (25 % landmarks, 12.5 % factors: every factor slot is ~60 bytes of upload per window), then rounded: landmark and factor counts of a running batch drift by a few percent from frame to
     // frame, and every growth is a round of page-locked and device reallocations (tens of milliseconds)
     const int Fr = std::min(be->cfg.max_features, (Fmax + Fmax / 4 + 63) / 64 * 64),
-              Mr = std::min(be->cfg.max_factors, (Mmax + Mmax / 4 + 511) / 512 * 512);
+              Mr = std::min(be->cfg.max_factors, (Mmax + Mmax / 8 + 127) / 128 * 128);
     d = make_dims(be->cfg, Wmax, std::max(Fr, Fmax), std::max(Mr, Mmax), any_loop);
     d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
   d.Flds = std::max(Fmax, 1);
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
+  // the previous upload's copy may still be reading the staging arena (uploads do not wait for their own transfer)
+  HIP_OK(hipStreamSynchronize(be->stream));
   const double t0 = now_ms();
   be->hb.resize(d, n, poison_staging);
   {
@@ -389,30 +389,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     int rc_ = (buf).ensure(count);         \
     if (rc_ != VIO_OK) return rc_;         \
   } while (0)
-  ENSURE(be->d_hdr, N * kHdrInts);
-  ENSURE(be->d_hdr_d, N * kHdrDoubles);
-  ENSURE(be->d_pose, N * s.pose);
-  ENSURE(be->d_sb, N * s.sb);
-  ENSURE(be->d_ex, N * s.ex);
-  ENSURE(be->d_feat, N * s.feat);
-  ENSURE(be->d_fhost, N * s.fint);
-  ENSURE(be->d_ftarget, N * s.fint);
-  ENSURE(be->d_ffeat, N * s.fint);
-  ENSURE(be->d_fslot, N * s.fint);
-  ENSURE(be->d_fstart, N * s.fstart);
-  ENSURE(be->d_pair_h, N * s.pair);
-  ENSURE(be->d_pair_t, N * s.pair);
-  ENSURE(be->d_pair_s0, N * s.pair);
-  ENSURE(be->d_pair_s1, N * s.pair);
-  ENSURE(be->d_pts_i, N * s.pts);
-  ENSURE(be->d_pts_j, N * s.pts);
-  ENSURE(be->d_preint, N * s.preint);
-  ENSURE(be->d_pr_kind, N * s.pr_int);
-  ENSURE(be->d_pr_index, N * s.pr_int);
-  ENSURE(be->d_pr_offset, N * s.pr_int);
-  ENSURE(be->d_pr_x0, N * s.pr_x0);
-  ENSURE(be->d_pr_J, N * s.pr_J);
-  ENSURE(be->d_pr_r, N * s.pr_r);
+  ENSURE(be->d_in, be->hb.total_bytes);
   ENSURE(be->d_scratch, N * s.scratch);
   ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);  // (indexed by window: sized for the whole batch when any window needs it)
   ENSURE(be->d_out_pose, N * s.out_pose);
@@ -433,32 +410,10 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   hipStream_t st = be->stream;
 #define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
   H2D(be->d_order, be->h_order);
-  H2D(be->d_hdr, be->hb.hdr);
-  H2D(be->d_hdr_d, be->hb.hdr_d);
-  H2D(be->d_pose, be->hb.pose);
-  H2D(be->d_sb, be->hb.sb);
-  H2D(be->d_ex, be->hb.ex);
-  H2D(be->d_feat, be->hb.feat);
-  H2D(be->d_fhost, be->hb.fhost);
-  H2D(be->d_ftarget, be->hb.ftarget);
-  H2D(be->d_ffeat, be->hb.ffeat);
-  H2D(be->d_fslot, be->hb.fslot);
-  H2D(be->d_fstart, be->hb.fstart);
-  H2D(be->d_pair_h, be->hb.pair_h);
-  H2D(be->d_pair_t, be->hb.pair_t);
-  H2D(be->d_pair_s0, be->hb.pair_s0);
-  H2D(be->d_pair_s1, be->hb.pair_s1);
-  H2D(be->d_pts_i, be->hb.pts_i);
-  H2D(be->d_pts_j, be->hb.pts_j);
-  H2D(be->d_preint, be->hb.preint);
-  H2D(be->d_pr_kind, be->hb.pr_kind);
-  H2D(be->d_pr_index, be->hb.pr_index);
-  H2D(be->d_pr_offset, be->hb.pr_offset);
-  if (be->host_prior_in) {  // (the bulk of the upload: ~45 KB per window at W=10)
-    H2D(be->d_pr_x0, be->hb.pr_x0);
-    H2D(be->d_pr_J, be->hb.pr_J);
-    H2D(be->d_pr_r, be->hb.pr_r);
-  }
+  // one copy for every input array; the prior data ([in_bytes, total_bytes): the bulk, ~45 KB per window at W=10) only
+  // when some prior of this upload travels through the host
+  HIP_OK(hipMemcpyAsync(be->d_in.p, be->hb.arena.data(), be->host_prior_in ? be->hb.total_bytes : be->hb.in_bytes,
+                        hipMemcpyHostToDevice, st));
   if (any_slot) {
     if (be->d_ptab.ensure(n) != VIO_OK) return VIO_ENOMEM;
     be->h_ptab.resize(n);
@@ -479,19 +434,25 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     H2D(be->d_ptab, be->h_ptab);
   }
 #undef H2D
-  HIP_OK(hipStreamSynchronize(st));
-  if (host_timing()) fprintf(stderr, "vio_backend_upload: pack %.2f ms, alloc+H2D %.2f ms (n=%d)\n", t1 - t0, now_ms() - t1, n);
+  if (!be->upload_done) HIP_OK(hipEventCreateWithFlags(&be->upload_done, hipEventDisableTiming));
+  HIP_OK(hipEventRecord(be->upload_done, st));
+  // (no wait here: the launch follows on the same stream, and the staging arena is not touched again before the wait at
+  // the top of the next upload)
+  if (host_timing()) fprintf(stderr, "vio_backend_upload: pack %.2f ms, alloc+H2D calls %.2f ms (n=%d)\n", t1 - t0, now_ms() - t1, n);
 
   BatchPtrs &B = be->B;
   B.n = n, B.d = d, B.s = s;
-  B.hdr = be->d_hdr.p, B.hdr_d = be->d_hdr_d.p;
-  B.pose = be->d_pose.p, B.sb = be->d_sb.p, B.ex = be->d_ex.p, B.feat = be->d_feat.p;
-  B.fhost = be->d_fhost.p, B.ftarget = be->d_ftarget.p, B.ffeat = be->d_ffeat.p;
-  B.fslot = be->d_fslot.p, B.fstart = be->d_fstart.p;
-  B.pair_h = be->d_pair_h.p, B.pair_t = be->d_pair_t.p, B.pair_s0 = be->d_pair_s0.p, B.pair_s1 = be->d_pair_s1.p;
-  B.pts_i = be->d_pts_i.p, B.pts_j = be->d_pts_j.p, B.preint = be->d_preint.p;
-  B.pr_kind = be->d_pr_kind.p, B.pr_index = be->d_pr_index.p, B.pr_offset = be->d_pr_offset.p;
-  B.pr_x0 = be->d_pr_x0.p, B.pr_J = be->d_pr_J.p, B.pr_r = be->d_pr_r.p;
+  {
+    const size_t *o = be->hb.off;
+    unsigned char *base = be->d_in.p;
+    auto ip = [&](int k) { return reinterpret_cast<int *>(base + o[k]); };
+    auto dp = [&](int k) { return reinterpret_cast<double *>(base + o[k]); };
+    B.hdr = ip(0), B.fhost = ip(1), B.ftarget = ip(2), B.ffeat = ip(3), B.fslot = ip(4), B.fstart = ip(5);
+    B.pair_h = ip(6), B.pair_t = ip(7), B.pair_s0 = ip(8), B.pair_s1 = ip(9);
+    B.pr_kind = ip(10), B.pr_index = ip(11), B.pr_offset = ip(12);
+    B.hdr_d = dp(13), B.pose = dp(14), B.sb = dp(15), B.ex = dp(16), B.feat = dp(17), B.pts_i = dp(18), B.pts_j = dp(19);
+    B.preint = dp(20), B.pr_x0 = dp(21), B.pr_J = dp(22), B.pr_r = dp(23);
+  }
   B.ptab = any_slot ? be->d_ptab.p : nullptr;
   B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
@@ -518,6 +479,7 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (!be->uploaded) return VIO_ESTATE;
   VIO_ON_DEVICE_OF(be);
   hipStream_t st = stream ? (hipStream_t)stream : be->stream;
+  if (st != be->stream && be->upload_done) HIP_OK(hipStreamWaitEvent(st, be->upload_done, 0));
   be->last_stream = st;
   if (be->events_used == be->events.size()) {
     if (be->events.size() >= 4096) {  // recycle: fold what is pending into nothing (caller did not ask for it)

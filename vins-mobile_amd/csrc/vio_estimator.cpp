@@ -101,7 +101,13 @@ struct vio_estimator {
   int W = 10, n_seq = 0;
   double tic[3], ric[9];
   std::vector<Sequence> seq;
-  vio_backend_t *be = nullptr;  // created at the first solve: IMU propagation and window filling need no device
+  // Created at the first solve: IMU propagation and window filling need no device. The sequences are split into
+  // n_groups contiguous groups with one back-end context (own stream, own resident batch, own prior store) each: while
+  // the kernel of group g runs, the host packs group g + 1 and unpacks group g - 1. The window kernel occupies one CU
+  // per window, so n_groups launches of n_seq / n_groups windows run side by side on the device.
+  static constexpr int kMaxGroups = 8;
+  vio_backend_t *be[kMaxGroups] = {nullptr};
+  int n_groups = 1, group_size = 1;
   std::vector<VioWindow> windows;
   std::vector<VioSolveStats> stats;
   bool enable_init = false;
@@ -263,7 +269,7 @@ int build_window(vio_estimator *e, Sequence &s, VioWindow *w) {
   }
   w->raw_pose = s.raw_pose.data(), w->raw_speed_bias = s.raw_sb.data(), w->raw_inv_depth = nullptr;
   w->next_prior = &s.prior[1 - s.cur_prior].p;
-  w->resident_prior = e->resident_priors ? s.index + 1 : 0;
+  w->resident_prior = e->resident_priors ? s.index % e->group_size + 1 : 0;  // slot in the store of the sequence's group
   return VIO_OK;
 }
 
@@ -536,6 +542,13 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
   vio_estimator *e = new (std::nothrow) vio_estimator();
   if (!e) return VIO_ENOMEM;
   e->cfg = *cfg, e->W = cfg->window_size, e->n_seq = n_seq;
+  {  // VIO_AMD_EST_GROUPS overrides the number of solve groups (1 = one launch for all sequences)
+    int ng = n_seq >= 128 ? 4 : (n_seq >= 32 ? 2 : 1);
+    if (const char *env = getenv("VIO_AMD_EST_GROUPS")) ng = atoi(env);
+    ng = std::max(1, std::min(std::min(ng, (int)vio_estimator::kMaxGroups), n_seq));
+    e->group_size = (n_seq + ng - 1) / ng;
+    e->n_groups = (n_seq + e->group_size - 1) / e->group_size;
+  }
   memcpy(e->tic, tic, 24), memcpy(e->ric, ric, 72);
   const int W = e->W, P = W + 1, cap = vio_prior_capacity(W);
   e->seq.resize(n_seq);
@@ -569,7 +582,8 @@ void vio_estimator_destroy(vio_estimator_t *e) {
   if (!e) return;
   for (Sequence &s : e->seq)
     if (s.fm) vio_features_destroy(s.fm);
-  if (e->be) vio_backend_destroy(e->be);
+  for (int g = 0; g < vio_estimator::kMaxGroups; g++)
+    if (e->be[g]) vio_backend_destroy(e->be[g]);
   delete e;
 }
 
@@ -786,19 +800,7 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   const int n = (int)e->solving.size();
   const auto t_pre = std::chrono::steady_clock::now();
   if (n > 0) {
-    if (!e->be) {
-      int rc = vio_backend_create(&e->cfg, e->n_seq, &e->be);
-      if (rc == VIO_OK && e->resident_priors) rc = vio_backend_reserve_priors(e->be, e->n_seq);
-      if (rc != VIO_OK) {
-        for (int k = 0; k < n; k++) {
-          clear_state(e, e->seq[e->solving[k]]);
-          results[e->solving[k]].action = VIO_FRAME_ERROR, results[e->solving[k]].error = rc;
-        }
-        return rc;
-      }
-    }
-    int rc = vio_backend_solve_windows(e->be, e->windows.data(), n, 0, e->stats.data());
-    if (rc != VIO_OK) {
+    auto fail_all = [&](int rc) {
       // the frame is in the landmark stores but the windows did not slide: restart those sequences rather than carry an
       // inconsistent window into the next call
       for (int k = 0; k < n; k++) {
@@ -806,7 +808,36 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
         results[e->solving[k]].action = VIO_FRAME_ERROR, results[e->solving[k]].error = rc;
       }
       return rc;
+    };
+    // e->solving is ordered by sequence, so every group is a contiguous run [g0[g], g0[g + 1]) of e->windows
+    int g0[vio_estimator::kMaxGroups + 1];
+    {
+      int k = 0;
+      for (int g = 0; g <= e->n_groups; g++) {
+        while (k < n && e->solving[k] < g * e->group_size) k++;
+        g0[g] = g == e->n_groups ? n : k;
+      }
     }
+    for (int g = 0; g < e->n_groups; g++) {
+      if (g0[g + 1] == g0[g] || e->be[g]) continue;
+      int rc = vio_backend_create(&e->cfg, e->group_size, &e->be[g]);
+      if (rc == VIO_OK && e->resident_priors) rc = vio_backend_reserve_priors(e->be[g], e->group_size);
+      if (rc != VIO_OK) return fail_all(rc);
+    }
+    int rc = VIO_OK;
+    for (int g = 0; g < e->n_groups && rc == VIO_OK; g++) {  // pack + H2D + launch, group after group (no device wait)
+      const int ng = g0[g + 1] - g0[g];
+      if (ng == 0) continue;
+      rc = vio_backend_upload(e->be[g], e->windows.data() + g0[g], ng);
+      if (rc == VIO_OK) rc = vio_backend_launch(e->be[g], nullptr);
+    }
+    for (int g = 0; g < e->n_groups; g++) {  // (every launched group is waited for, also after an error)
+      const int ng = g0[g + 1] - g0[g];
+      if (ng == 0 || !e->be[g]) continue;
+      int rd = vio_backend_download(e->be[g], e->windows.data() + g0[g], ng, e->stats.data() + g0[g]);
+      if (rc == VIO_OK) rc = rd;
+    }
+    if (rc != VIO_OK) return fail_all(rc);
   }
   const auto t_solve = std::chrono::steady_clock::now();
   // phase C, per solved sequence: double2vector, loop bookkeeping, failure detection, slide
