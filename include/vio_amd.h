@@ -378,6 +378,61 @@ int vio_loop_find_connection(vio_matcher_t *m, const VioConfig *cfg, int32_t n_c
                              float *matched_old_norm /* [n_cur][2] or NULL */,
                              uint8_t *status /* [n_cur] */, int32_t *n_inliers);
 
+/* 4-DoF loop pose graph: KeyFrameDatabase::optimize4DoFLoopPoseGraph
+ * (VINS_ios/loop/keyfame_database.cpp:140-353). Per keyframe the unknowns are
+ * yaw (degrees, AngleLocalParameterization) and translation; pitch and roll of
+ * the odometry pose are kept. Edges: FourDOFError (keyfame_database.h:271-313)
+ * under HuberLoss(1.0) to up to five preceding kept keyframes (:232-262), and
+ * FourDOFWeightError (:315-366, weight 10, no loss) for every loop (:264-285).
+ * Solver: Ceres trust region, Levenberg-Marquardt, max_num_iterations = 5
+ * (:154-159; DENSE_SCHUR there is an exact linear solve).
+ *
+ * The graph is given in resample-index order: node k = k-th keyframe from
+ * earliest_loop_index on. `skip[k]` = need_resample (:176-198): the keyframe
+ * keeps its parameter blocks but gets no edge, so it is not part of the solve
+ * and is moved by the drift of the last kept keyframe afterwards (:316-319).   */
+typedef struct VioPoseGraph {
+  int32_t n_nodes;
+  double *t;            /* [n][3] in: origin translation; out: optimized (kept nodes) */
+  double *ypr;          /* [n][3] in: R2ypr(origin rotation), degrees; out: [k][0] = optimized yaw */
+  int32_t fixed_node;   /* SetParameterBlockConstant: the earliest_loop_index keyframe (:224-228) */
+  int32_t n_edges;
+  const int32_t *edge_i;   /* first pair of parameter blocks: the earlier / connected keyframe */
+  const int32_t *edge_j;   /* second pair: the keyframe the edge was created for */
+  const uint8_t *edge_kind; /* 0: sequential (Huber), 1: loop (weighted, no loss) */
+  const double *edge_meas; /* [n_edges][6]: t_x, t_y, t_z, relative_yaw, pitch_i, roll_i */
+} VioPoseGraph;
+
+/* Keyframe list as optimize4DoFLoopPoseGraph walks it (from earliest_loop_index to cur_index). */
+typedef struct VioPoseGraphKeyframe {
+  double origin_t[3], origin_r[9]; /* getOriginPose (VIO odometry) */
+  double t[3], r[9];               /* getPose (current, drift-corrected) — read by the resampling only */
+  int32_t global_index;
+  int32_t has_loop, is_looped;
+  int32_t loop_index;              /* global_index of the matched old keyframe (has_loop) */
+  double loop_info[8];             /* relative_t (0..2), relative_q (3..6), relative_yaw (7) */
+} VioPoseGraphKeyframe;
+
+typedef struct vio_posegraph vio_posegraph_t;
+/* max_nodes / max_edges bound one graph; n_graphs = graphs one call may carry (one workgroup each). */
+int vio_posegraph_create(int32_t max_nodes, int32_t max_edges, int32_t n_graphs, vio_posegraph_t **out);
+int vio_posegraph_get_device(const vio_posegraph_t *pg, int32_t *device);
+void vio_posegraph_destroy(vio_posegraph_t *pg);
+/* The ceres::Solve of :287: n graphs in one launch; t / ypr are updated in place, stats[g] carries the trace. */
+int vio_posegraph_optimize(vio_posegraph_t *pg, VioPoseGraph *graphs, int32_t n, int32_t max_iterations,
+                           VioSolveStats *stats);
+/* Host side of :166-285: resampling flags and the edge list from a keyframe list (kf[0] = earliest_loop_index,
+ * kf[n_kf-1] = cur_index). Arrays are caller-owned: t/ypr [n_kf][3], skip [n_kf], edges up to cap_edges.
+ * total_length, max_frame_num, list_size: the database's fields (keyfame_database.cpp:16-17,34,185).          */
+int vio_posegraph_build(const VioPoseGraphKeyframe *kf, int32_t n_kf, double total_length, int32_t max_frame_num,
+                        int32_t list_size, double *t, double *ypr, uint8_t *skip, int32_t cap_edges,
+                        int32_t *edge_i, int32_t *edge_j, uint8_t *edge_kind, double *edge_meas, int32_t *n_edges);
+/* Host side of :303-339: poses after the solve (kept keyframes take the optimized pose, skipped ones the drift of
+ * the last kept one) and the drift of the current keyframe (yaw_drift, r_drift, t_drift).                      */
+int vio_posegraph_apply(const VioPoseGraphKeyframe *kf, int32_t n_kf, const double *t, const double *ypr,
+                        const uint8_t *skip, double *out_t /* [n_kf][3] */, double *out_r /* [n_kf][9] */,
+                        double *yaw_drift, double *r_drift /* [9] */, double *t_drift /* [3] */);
+
 /* ------------------------------------------------------------------------- */
 /* Window bookkeeping around the solve (host side): FeatureManager            */
 /* (VINS_ios/feature_manager.hpp:71-103). It decides which landmarks and      */

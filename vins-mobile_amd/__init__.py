@@ -3,4 +3,4 @@
 The directory name is not a Python identifier; import it with
 ``importlib.import_module("vins-mobile_amd")`` (see ``__graft_entry__.py``).
 """
-from . import abi, backend, estimator, frontend, loop, multi, pnp, replay, synth, window  # noqa: F401
+from . import abi, backend, estimator, frontend, loop, multi, pnp, posegraph, replay, synth, window  # noqa: F401

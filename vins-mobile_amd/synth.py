@@ -272,3 +272,50 @@ def make_image_stream(seed, n_frames, rows=640, cols=480, max_shift=2.5, noise=1
         img = _bilinear(tex, u, v) + rng.normal(0, noise, (rows, cols))
         frames[f] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
     return frames, affines
+
+
+# ---- loop pose graph (keyfame_database.cpp:140-353) ------------------------------------------------------
+def _ypr_to_R(ypr_deg):
+    y, p, r = np.deg2rad(ypr_deg)
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    return Rz @ Ry @ Rx
+
+
+def make_loop_keyframes(n=60, seed=0, n_loops=6, laps=1.15, radius=8.0, yaw_drift_deg=0.25, pos_drift=0.03, first_index=0):
+    """A keyframe list as optimize4DoFLoopPoseGraph sees it: a (more than once around) circle walked by a drifting
+    odometry; the last `n_loops` keyframes revisit the start and carry a loop to an early keyframe. Returns
+    (keyframes as dicts for posegraph.keyframes_struct, total_length, true translations)."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0, 2 * np.pi * laps, n)
+    true_t = np.stack([radius * np.cos(ang), radius * np.sin(ang), 0.3 * np.sin(3 * ang)], 1)
+    true_ypr = np.stack([np.rad2deg(ang) + 90.0, 4.0 * np.sin(2 * ang), 3.0 * np.cos(ang)], 1)
+    true_ypr[:, 0] = (true_ypr[:, 0] + 180.0) % 360.0 - 180.0
+    true_R = [_ypr_to_R(a) for a in true_ypr]
+    # odometry: relative motions with a yaw bias and translation noise, chained from the true first pose
+    R, t = [true_R[0]], [true_t[0]]
+    for k in range(1, n):
+        dR = true_R[k - 1].T @ true_R[k]
+        dt = true_R[k - 1].T @ (true_t[k] - true_t[k - 1])
+        dR = _ypr_to_R([yaw_drift_deg * (1 + 0.3 * rng.standard_normal()), 0, 0]) @ dR
+        dt = dt + pos_drift * rng.standard_normal(3)
+        t.append(t[-1] + R[-1] @ dt)
+        R.append(R[-1] @ dR)
+    kfs = []
+    for k in range(n):
+        kfs.append({"origin_t": t[k], "origin_r": R[k], "t": t[k], "r": R[k], "global_index": first_index + k, "has_loop": 0,
+                    "is_looped": 0, "loop_index": -1, "loop_info": np.zeros(8)})
+    total_length = float(np.sum(np.linalg.norm(np.diff(np.array(t), axis=0), axis=1)))
+    lap_len = int(round(n / laps))
+    for k in range(n - n_loops, n):
+        old = max(0, k - lap_len)
+        rel_t = true_R[old].T @ (true_t[k] - true_t[old]) + 0.01 * rng.standard_normal(3)
+        rel_yaw = true_ypr[k, 0] - true_ypr[old, 0] + 0.05 * rng.standard_normal()
+        rel_yaw = (rel_yaw + 180.0) % 360.0 - 180.0
+        kfs[k]["has_loop"], kfs[k]["loop_index"] = 1, first_index + old
+        kfs[old]["is_looped"] = 1
+        info = np.zeros(8)
+        info[0:3], info[3], info[7] = rel_t, 1.0, rel_yaw
+        kfs[k]["loop_info"] = info
+    return kfs, total_length, true_t
