@@ -16,6 +16,9 @@ int vio_backend_create(const VioConfig *, int32_t, vio_backend_t **) { return VI
 void vio_backend_destroy(vio_backend_t *) {}
 int vio_backend_reserve_priors(vio_backend_t *, int32_t) { return VIO_ENODEV; }
 int vio_backend_solve_windows(vio_backend_t *, VioWindow *, int32_t, int32_t, VioSolveStats *) { return VIO_ENODEV; }
+int vio_backend_upload(vio_backend_t *, const VioWindow *, int32_t) { return VIO_ENODEV; }
+int vio_backend_launch(vio_backend_t *, void *) { return VIO_ENODEV; }
+int vio_backend_download(vio_backend_t *, VioWindow *, int32_t, VioSolveStats *) { return VIO_ENODEV; }
 int vio_pnp_create(const VioConfig *, int32_t, vio_pnp_t **) { return VIO_ENODEV; }
 void vio_pnp_destroy(vio_pnp_t *) {}
 int vio_pnp_solve_windows(vio_pnp_t *, VioPnpWindow *, int32_t, VioSolveStats *) { return VIO_ENODEV; }
