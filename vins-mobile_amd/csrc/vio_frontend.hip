@@ -34,6 +34,10 @@ constexpr int kMaxLevels = 4;   // level 0..3
 constexpr int kMaxCap = 512;    // max tracked features per sequence supported by the per-sequence kernels
 constexpr int kWin = 21;        // LK window (the kernel is specialised for 21x21; cfg->lk_win must match)
 constexpr int kWBits = 14;
+#ifndef VIO_LK_FPW
+#define VIO_LK_FPW 1
+#endif
+constexpr int kLkFpw = VIO_LK_FPW;  // features per wave of lk_track_kernel (1 or 2)
 
 #define HIP_OK(expr)                                                                       \
   do {                                                                                     \
@@ -143,10 +147,16 @@ constexpr int kIS = kIP + 1;                  // row stride of the staged I patc
 // crawl on this hardware (the byte-array version of this kernel spent 40 % of its wave cycles in LDS issue stalls).
 // A pair is also exactly one v_dot2_u32_u16 operand, so a bilinear sample is two reads and two dot instructions
 // (weights < 2^15, products < 2^22).
+// The template patch and its derivatives are consumed (into registers) before the first J region of a level is staged,
+// so the two share their LDS: 4.3 KB per feature instead of 7.6 KB.
 struct LkWaveLds {
-  uint32_t I[kIP][kIS];
-  short2 dI[kDP][kDP];
-  uint32_t J[kJP][kJS];
+  union {
+    struct {
+      uint32_t I[kIP][kIS];
+      short2 dI[kDP][kDP];
+    };
+    uint32_t J[kJP][kJS];
+  };
 };
 typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 
@@ -156,26 +166,57 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave per feature. prev/next pyramids: per sequence `pyr_bytes` apart. pts arrays: [seq][cap][2].
-__global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, const uint8_t *next_pyr, LkParams P,
+// Sums over the lanes of one feature. FPW = 1: the whole wave (wave_sum_i32). FPW = 2: each half of the wave is a feature;
+// the row-level DPP steps never leave a row of 16 lanes and row_bcast:15 only feeds rows 1 and 3, so the two halves do
+// not mix: the totals land in lanes 31 and 63.
+template <int FPW>
+__device__ __forceinline__ int feat_sum_i32(int v, int sub) {
+  if (FPW == 1) return wave_sum_i32(v);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+  return sub ? hi : lo;
+}
+template <int FPW>
+__device__ __forceinline__ double feat_sum_exact(int p, int sub) {
+  int lo = p & 0xffff, hi = p >> 16;
+  int slo = feat_sum_i32<FPW>(lo, sub), shi = feat_sum_i32<FPW>(hi, sub);
+  return (double)shi * 65536.0 + (double)slo;
+}
+
+// FPW features per wave (64 / FPW lanes each). prev/next pyramids: per sequence `pyr_bytes` apart. pts arrays:
+// [seq][cap][2]. Two features per wave share every wave-uniform instruction (the reductions, the 2x2 solve, the
+// convergence tests, the bilinear weights): the kernel is VALU-issue-bound and those are half of an LK iteration.
+// Occupancy: the kernel is latency-bound on its dependent chains (LDS round trips, DPP reductions), not on VALU issue —
+// two features per wave (FPW = 2: half the wave-uniform instructions per feature, but 154 VGPRs = 3 waves per SIMD) is
+// SLOWER (1.36 vs 1.28 ms per front-end step), more resident waves are faster: with the LDS per feature down to 4.3 KB the
+// register count is what limits residency, so the kernel is compiled for 6 waves per SIMD (80 VGPRs, no spills; 95 -> 5
+// waves before): front-end step 1.28 -> 1.17 ms. (8 waves per SIMD = 64 VGPRs spills 17 registers and gains another 0.5 %.)
+template <int FPW>
+__global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const uint8_t *prev_pyr, const uint8_t *next_pyr, LkParams P,
                                                        const int *n_pts, const float *prev_pts, float *next_pts,
                                                        uint8_t *status, float *err) {
-  __shared__ LkWaveLds lds_all[4];
+  constexpr int LPF = 64 / FPW;  // lanes per feature
+  __shared__ LkWaveLds lds_all[4 * FPW];
   const int seq = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int pt = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
+  const int sub = wlane / LPF, lane = wlane & (LPF - 1);  // feature within the wave, lane within the feature
+  const int pt = (blockIdx.x * (blockDim.x >> 6) + wave) * FPW + sub;
   if (pt >= n_pts[seq]) return;
-  LkWaveLds &L = lds_all[wave];
+  LkWaveLds &L = lds_all[wave * FPW + sub];
   const uint8_t *pp = prev_pyr + (size_t)seq * P.ld.pyr_bytes, *np = next_pyr + (size_t)seq * P.ld.pyr_bytes;
   const size_t pidx = ((size_t)seq * P.cap + pt) * 2;
   const float ptx = prev_pts[pidx], pty = prev_pts[pidx + 1];
   const float half = (kWin - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
-  const int NPX = (kWin * kWin + 63) / 64;  // 7 window pixels per lane
+  constexpr int NPX = (kWin * kWin + LPF - 1) / LPF;  // window pixels per lane: 7 (14 with two features per wave)
   int joff[NPX];  // this lane's window pixels as element offsets into the staged J region
 #pragma unroll
   for (int q = 0; q < NPX; q++) {
-    const int e = min(lane + 64 * q, kWin * kWin - 1);
+    const int e = min(lane + LPF * q, kWin * kWin - 1);
     joff[q] = (e / kWin) * kJS + (e % kWin);
   }
   bool st = true;
@@ -207,14 +248,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
        // neighbour of every pixel comes from the next lane (DPP wave_shl) so that a pair can be stored as one dword
       const int lx = lane & 31;
       const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
-      for (int ly = lane >> 5; ly < kIP; ly += 2) {
+      for (int ly = lane >> 5; ly < kIP; ly += LPF / 32) {
         const int v = I[(size_t)reflect101(ipy - 1 + ly, rows) * cols + x];
         const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
         if (lx < kIP) L.I[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
       }
     }
     wave_lds_fence();
-    for (int e = lane; e < kDP * kDP; e += 64) {
+    for (int e = lane; e < kDP * kDP; e += LPF) {
       int ly = e / kDP, lx = e - ly * kDP;
       int Y = ipy + ly, X = ipx + lx;
       short2 d = make_short2(0, 0);
@@ -233,10 +274,10 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
     wave_lds_fence();
     // template patch + derivatives for this lane's window pixels, kept in registers across the iterations
     short Iv[NPX], Ix[NPX], Iy[NPX];
-    int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: 7 products of |v| <= 4080^2 fit 32 bits
+      int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: <= 14 products of |v| <= 4080^2 fit 32 bits
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
-      int e = lane + 64 * q;
+      int e = lane + LPF * q;
       Iv[q] = Ix[q] = Iy[q] = 0;
       if (e < kWin * kWin) {
         int y = e / kWin, x = e - y * kWin;
@@ -250,7 +291,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
         p11 += ixval * ixval, p12 += ixval * iyval, p22 += iyval * iyval;
       }
     }
-    const double s11 = wave_sum_exact(p11), s12 = wave_sum_exact(p12), s22 = wave_sum_exact(p22);  // exact integer sums
+    const double s11 = feat_sum_exact<FPW>(p11, sub), s12 = feat_sum_exact<FPW>(p12, sub), s22 = feat_sum_exact<FPW>(p22, sub);  // exact integer sums
     float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * kWin * kWin);
@@ -269,7 +310,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       {  // 32 lanes per row (28 used), two rows per trip; pairs (J[x] | J[x+1] << 16) like the template patch
         const int lx = lane & 31;
         const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
-        for (int ly = lane >> 5; ly < kJP; ly += 2) {
+        for (int ly = lane >> 5; ly < kJP; ly += LPF / 32) {
           const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
           const int v = J[(size_t)y * cols + x];
           const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
@@ -297,17 +338,17 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       if (!j_staged || iqx < jox || iqx > jox + 2 * kJMargin || iqy < joy || iqy > joy + 2 * kJMargin) stage_j(iqx, iqy);
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
-      int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, 7 pixels per lane: fits 32 bits
+      int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, <= 14 pixels per lane: 9.3e8 fits 32 bits
       const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
       const int jbase = (iqy - joy) * kJS + (iqx - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        if (lane + 64 * q < kWin * kWin) {
+        if (lane + LPF * q < kWin * kWin) {
           int diff = sample_j(jbase, q, wtop, wbot) - Iv[q];
           pb1 += diff * Ix[q], pb2 += diff * Iy[q];
         }
       }
-      const double sb1 = wave_sum_exact(pb1), sb2 = wave_sum_exact(pb2);
+      const double sb1 = feat_sum_exact<FPW>(pb1, sub), sb2 = feat_sum_exact<FPW>(pb2, sub);
       float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
       qx += ddx, qy += ddy;
@@ -334,9 +375,9 @@ __global__ __launch_bounds__(256) void lk_track_kernel(const uint8_t *prev_pyr, 
       const int jbase = (iey - joy) * kJS + (iex - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        if (lane + 64 * q < kWin * kWin) pe += abs(sample_j(jbase, q, wtop, wbot) - Iv[q]);
+        if (lane + LPF * q < kWin * kWin) pe += abs(sample_j(jbase, q, wtop, wbot) - Iv[q]);
       }
-      const int se = wave_sum_i32(pe);  // <= 441 * 16320 < 2^23
+      const int se = feat_sum_i32<FPW>(pe, sub);  // <= 441 * 16320 < 2^23
       er = (float)se * 1.f / (32 * kWin * kWin);
     }
   }
@@ -1302,8 +1343,8 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     P.max_count = std::min(std::max(fe->cfg.lk_max_iters, 0), 100);
     double eps = std::min(std::max(fe->cfg.lk_eps, 0.), 10.);
     P.epsilon_sq = eps * eps, P.epsilon_sq_f = (float)(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
-    dim3 grd((cap + 3) / 4, S);
-    hipLaunchKernelGGL(lk_track_kernel, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
+    dim3 grd((cap + 4 * kLkFpw - 1) / (4 * kLkFpw), S);
+    hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
                        fe->forw_pts, fe->lk_status, fe->lk_err);
   }
   int rcu = launch_track_update(fe, publish, st);
@@ -1650,7 +1691,7 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
   P.ld = fe->ld, P.cap = fe->cap, P.max_count = std::min(std::max(c.lk_max_iters, 0), 100);
   double eps = std::min(std::max(c.lk_eps, 0.), 10.);
   P.epsilon_sq = eps * eps, P.epsilon_sq_f = (float)(eps * eps), P.min_eig = (float)c.lk_min_eig;
-  hipLaunchKernelGGL(lk_track_kernel, dim3((fe->cap + 3) / 4, 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
+  hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
                      fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);
   if (hipMemcpy(next_pts, fe->forw_pts, sizeof(float) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return fail(VIO_ENODEV);
