@@ -439,76 +439,120 @@ struct SevenPointWork {
   int colperm[10];
 };
 
-__device__ __forceinline__ int run7point_dev(const float *ms1, const float *ms2, double *fmatrix, SevenPointWork &wk) {
+// The 7-point solve by the 16 lanes of one DPP row (lane l of the group). One thread alone spends ~130 k cycles in it: the
+// elimination is ~1300 DEPENDENT LDS accesses (dynamic indexing keeps the system out of registers), and the whole RANSAC
+// call waits for it. Here the pivot search (4 candidates per lane, then a 4-step butterfly on (|value|, position) keys
+// with the serial scan's tie rule: first position wins), the swaps, the pivot-row division and the elimination (54
+// elements, every lane reads its factors and pivot-row entries before anyone writes) run across the lanes; every element
+// sees exactly the operations of the serial restatement (oracle run7point), so the result is bit-identical. The cubic and the model assembly
+// (~300 flops) stay on lane 0. Returns the number of models on every lane of the group.
+__device__ __forceinline__ int run7point_group(const float *ms1, const float *ms2, double *fmatrix, SevenPointWork &wk, int l) {
   double *a = wk.a, *f1 = wk.f1, *f2 = wk.f2;
   int *colperm = wk.colperm;
-  double c[4], r[3];
-  for (int i = 0; i < 7; i++) {
-    double x0 = ms1[2 * i], y0 = ms1[2 * i + 1], x1 = ms2[2 * i], y1 = ms2[2 * i + 1];
-    double *row = a + i * 9;
+  auto group_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  if (l < 7) {
+    double x0 = ms1[2 * l], y0 = ms1[2 * l + 1], x1 = ms2[2 * l], y1 = ms2[2 * l + 1];
+    double *row = a + l * 9;
     row[0] = x1 * x0, row[1] = x1 * y0, row[2] = x1, row[3] = y1 * x0, row[4] = y1 * y0, row[5] = y1, row[6] = x0,
     row[7] = y0, row[8] = 1;
   }
-  // null space by Gauss-Jordan with complete pivoting (same elimination order as the CPU restatement)
-  for (int j = 0; j < 9; j++) colperm[j] = j;
+  if (l < 9) colperm[l] = l;
+  group_sync();
   for (int k = 0; k < 7; k++) {
-    int pr = k, pc = k;
+    // pivot: largest |a[i][j]| over i >= k, j >= k, the first one in row-major order among equals
     double best = -1;
-    for (int i = k; i < 7; i++)
-      for (int j = k; j < 9; j++)
-        if (fabs(a[i * 9 + j]) > best) best = fabs(a[i * 9 + j]), pr = i, pc = j;
-    if (pr != k)
-      for (int j = 0; j < 9; j++) {
-        double t = a[k * 9 + j];
-        a[k * 9 + j] = a[pr * 9 + j], a[pr * 9 + j] = t;
+    int bpos = k * 9 + k;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int e = l + 16 * q, i = e / 9, j = e - 9 * i;
+      if (e < 63 && i >= k && j >= k) {
+        const double v = fabs(a[e]);
+        if (v > best) best = v, bpos = e;
       }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      const double ob = __shfl_xor(best, m, 16);
+      const int op = __shfl_xor(bpos, m, 16);
+      if (ob > best || (ob == best && op < bpos)) best = ob, bpos = op;
+    }
+    const int pr = bpos / 9, pc = bpos - 9 * pr;
+    if (pr != k && l < 9) {
+      const double t = a[k * 9 + l];
+      a[k * 9 + l] = a[pr * 9 + l], a[pr * 9 + l] = t;
+    }
+    group_sync();
     if (pc != k) {
-      for (int i = 0; i < 7; i++) {
-        double t = a[i * 9 + k];
-        a[i * 9 + k] = a[i * 9 + pc], a[i * 9 + pc] = t;
+      if (l < 7) {
+        const double t = a[l * 9 + k];
+        a[l * 9 + k] = a[l * 9 + pc], a[l * 9 + pc] = t;
       }
-      int t = colperm[k];
-      colperm[k] = colperm[pc], colperm[pc] = t;
+      if (l == 15) {
+        const int t = colperm[k];
+        colperm[k] = colperm[pc], colperm[pc] = t;
+      }
     }
-    double d = a[k * 9 + k];
+    group_sync();
+    const double d = a[k * 9 + k];
+    group_sync();
     if (d == 0.0) continue;
-    for (int j = 0; j < 9; j++) a[k * 9 + j] /= d;
-    for (int i = 0; i < 7; i++)
-      if (i != k) {
-        double f = a[i * 9 + k];
-        if (f != 0.0)
-          for (int j = 0; j < 9; j++) a[i * 9 + j] -= f * a[k * 9 + j];
-      }
+    if (l < 9) a[k * 9 + l] /= d;
+    group_sync();
+    double fv[4], pv[4], av[4];
+    int ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // element q of this lane: rows i != k in order, 9 columns each
+      const int e = l + 16 * q, ii = e / 9, j = e - 9 * ii, i = ii < k ? ii : ii + 1;
+      const bool on = e < 54;
+      ev[q] = on ? i * 9 + j : -1;
+      fv[q] = on ? a[i * 9 + k] : 0.0, pv[q] = on ? a[k * 9 + j] : 0.0, av[q] = on ? a[i * 9 + j] : 0.0;
+    }
+    group_sync();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (ev[q] >= 0 && fv[q] != 0.0) a[ev[q]] = av[q] - fv[q] * pv[q];
+    group_sync();
   }
-  for (int q = 0; q < 2; q++) {
-    double *out = q == 0 ? f1 : f2;
-    for (int j = 0; j < 9; j++) {
-      double vj = j < 7 ? -a[j * 9 + 7 + q] : (j - 7 == q ? 1.0 : 0.0);
-      out[colperm[j]] = vj;
+  if (l < 9) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      double *out = q == 0 ? f1 : f2;
+      const double vj = l < 7 ? -a[l * 9 + 7 + q] : (l - 7 == q ? 1.0 : 0.0);
+      out[colperm[l]] = vj;
     }
   }
-  for (int i = 0; i < 9; i++) f1[i] -= f2[i];
-  double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
-  c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
-  c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
-         f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
-         f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
-         f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
-  t0 = f1[4] * f1[8] - f1[5] * f1[7], t1 = f1[3] * f1[8] - f1[5] * f1[6], t2 = f1[3] * f1[7] - f1[4] * f1[6];
-  c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
-         f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
-         f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
-         f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
-  c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
-  int n = solve_cubic_dev(c, r);
-  if (n < 1 || n > 3) return n;
-  for (int k = 0; k < n; k++, fmatrix += 9) {
-    double lambda = r[k], mu = 1., s = f1[8] * r[k] + f2[8];
-    if (fabs(s) > 2.220446049250313e-16) mu = 1. / s, lambda *= mu, fmatrix[8] = 1.;
-    else fmatrix[8] = 0.;
-    for (int i = 0; i < 8; i++) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+  group_sync();
+  if (l < 9) f1[l] -= f2[l];
+  group_sync();
+  int n = 0;
+  if (l == 0) {
+    double c[4], r[3];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7], t1 = f1[3] * f1[8] - f1[5] * f1[6], t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    n = solve_cubic_dev(c, r);
+    if (n >= 1 && n <= 3)
+      for (int k = 0; k < n; k++, fmatrix += 9) {
+        double lambda = r[k], mu = 1., s = f1[8] * r[k] + f2[8];
+        if (fabs(s) > 2.220446049250313e-16) mu = 1. / s, lambda *= mu, fmatrix[8] = 1.;
+        else fmatrix[8] = 0.;
+        for (int i = 0; i < 8; i++) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+      }
   }
-  return n;
+  return __shfl(n, 0, 16);
 }
 
 __device__ __forceinline__ float epipolar_error(const double *F, float x1f, float y1f, float x2f, float y2f) {
@@ -670,12 +714,14 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       }
     }
     __syncthreads();
-    // ---- phase 2: 7-point models, one thread per hypothesis
-    if (tid < kHypBatch) {
+    // ---- phase 2: 7-point models, 16 lanes per hypothesis
+    for (int h = tid >> 4; h < kHypBatch; h += nt >> 4) {
       int n = 0;
-      if (S.valid[tid]) n = run7point_dev(S.ms1[tid], S.ms2[tid], S.F[tid], S.work[tid]);
-      S.nmodels[tid] = n < 0 ? 0 : n;
-      S.good[tid][0] = S.good[tid][1] = S.good[tid][2] = 0;
+      if (S.valid[h]) n = run7point_group(S.ms1[h], S.ms2[h], S.F[h], S.work[h], tid & 15);
+      if ((tid & 15) == 0) {
+        S.nmodels[h] = n < 0 ? 0 : n;
+        S.good[h][0] = S.good[h][1] = S.good[h][2] = 0;
+      }
     }
     __syncthreads();
     // ---- phase 3: inlier counts for every (hypothesis, model) [RANSAC] / median error of every model [LMedS]
