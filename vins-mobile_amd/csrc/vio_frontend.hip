@@ -34,6 +34,7 @@ constexpr int kMaxLevels = 4;   // level 0..3
 constexpr int kMaxCap = 512;    // max tracked features per sequence supported by the per-sequence kernels
 constexpr int kWin = 21;        // LK window (the kernel is specialised for 21x21; cfg->lk_win must match)
 constexpr int kWBits = 14;
+constexpr int kMaxRadius = 128;  // largest MIN_DIST (setMask circle radius) the tracker's LDS tables are sized for
 #ifndef VIO_LK_FPW
 #define VIO_LK_FPW 1
 #endif
@@ -824,6 +825,7 @@ struct TrackShared {
   int order[kMaxCap];
   int ixy[kMaxCap][2];
   unsigned long long inside[kMaxCap][kMaxCap / 64];
+  int hw[2 * kMaxRadius + 1];  // half-widths of the filled circle (setMask), staged from global memory
 };
 
 __device__ void compact_block(TrackShared &T) {
@@ -901,42 +903,53 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
     }
     const int words = (n + 63) / 64;
     __syncthreads();
-    // inside[i][w] bit j: pixel of i lies in the filled circle painted at j (i, j in ORIGINAL indices)
-    for (int item = tid; item < n * words; item += nt) {
-      int i = item / words, w = item - i * words;
-      unsigned long long bits = 0;
-      for (int b = 0; b < 64; b++) {
-        int j = w * 64 + b;
-        if (j >= n) break;
-        int dy = T.ixy[i][1] - T.ixy[j][1], dx = T.ixy[i][0] - T.ixy[j][0];
-        if (dy >= -A.radius && dy <= A.radius) {
-          int h = A.hw[A.radius + dy];
-          if (dx >= -h && dx <= h) bits |= 1ULL << b;
+    // inside[i][w] bit j: pixel of i lies in the filled circle painted at j (i, j in ORIGINAL indices). One word per wave
+    // instruction: the wave takes (i, w), lane b tests j = 64 w + b, the ballot IS the word. (The per-thread loop over
+    // 64 j with the half-width table read from global memory inside it was 57 k cycles; the table now sits in LDS.)
+    for (int q = tid; q < 2 * A.radius + 1; q += nt) T.hw[q] = A.hw[q];
+    __syncthreads();
+    {
+      const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+      for (int item = wave; item < n * words; item += nwv) {
+        const int i = item / words, w = item - i * words, j = w * 64 + lane;
+        bool in = false;
+        if (j < n) {
+          const int dy = T.ixy[i][1] - T.ixy[j][1], dx = T.ixy[i][0] - T.ixy[j][0];
+          if (dy >= -A.radius && dy <= A.radius) {
+            const int h = T.hw[A.radius + dy];
+            in = dx >= -h && dx <= h;
+          }
+        }
+        const unsigned long long bits = __builtin_amdgcn_ballot_w64(in);
+        if (lane == 0) T.inside[i][w] = bits;
+      }
+    }
+    __syncthreads();
+    // greedy in sorted order (:73-83): a feature is kept unless it lies in the circle of an earlier kept one. One wave:
+    // lane w owns word w of the kept set in a register, the hit test is a ballot; the index list and the bit rows do not
+    // depend on the decisions, so the compiler is free to fetch them ahead. Kept features get their output position
+    // (forw_pts.push_back order) on the way. (One thread with the kept set in a dynamically indexed array: 105 k cycles.)
+    if (tid < 64) {
+      const int lane = tid;
+      unsigned long long mine = 0;  // word `lane` of the kept set
+      int c = 0;
+      for (int r0 = 0; r0 < n; r0 += 64) {
+        const int my_i = r0 + lane < n ? T.order[r0 + lane] : 0;
+        const int cnt = n - r0 < 64 ? n - r0 : 64;
+        for (int q = 0; q < cnt; q++) {
+          const int i = __builtin_amdgcn_readlane(my_i, q);
+          const unsigned long long row = lane < words ? T.inside[i][lane] : 0ull;
+          const bool hit = __builtin_amdgcn_ballot_w64((row & mine) != 0) != 0;
+          if (!hit) {
+            if (lane == (i >> 6)) mine |= 1ULL << (i & 63);
+            if (lane == 0) T.keep[i] = 1, T.pos[i] = c;
+            c++;
+          } else if (lane == 0) {
+            T.keep[i] = 0;
+          }
         }
       }
-      T.inside[i][w] = bits;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long keptmask[kMaxCap / 64];
-      for (int w = 0; w < words; w++) keptmask[w] = 0;
-      for (int r = 0; r < n; r++) {
-        int i = T.order[r];
-        bool hit = false;
-        for (int w = 0; w < words; w++) hit |= (T.inside[i][w] & keptmask[w]) != 0;
-        T.keep[i] = hit ? 0 : 1;
-        if (!hit) keptmask[i >> 6] |= 1ULL << (i & 63);
-      }
-    }
-    __syncthreads();
-    // the kept features are re-emitted in sorted order (forw_pts.push_back in the loop :73-83)
-    if (tid == 0) {
-      int c = 0;
-      for (int r = 0; r < n; r++) {
-        int i = T.order[r];
-        if (T.keep[i]) T.pos[i] = c++;
-      }
-      T.n = c;
+      if (lane == 0) T.n = c;
     }
     __syncthreads();
     for (int i = tid; i < n; i += nt)
@@ -1419,7 +1432,7 @@ extern "C" {
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out) {
   if (!cfg || !out || n_seq < 1) return VIO_EINVAL;
   if (cfg->lk_win != kWin || cfg->lk_levels < 0 || cfg->lk_levels >= kMaxLevels || cfg->max_corners < 1 ||
-      cfg->max_corners > kMaxCap || cfg->image_rows < 32 || cfg->image_cols < 32 || cfg->min_dist < 0)
+      cfg->max_corners > kMaxCap || cfg->image_rows < 32 || cfg->image_cols < 32 || cfg->min_dist < 0 || cfg->min_dist > kMaxRadius)
     return VIO_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
