@@ -163,6 +163,31 @@ def test_device_closes_the_loop_end_to_end(optimizer):
 
 
 @pytest.mark.gpu
+def test_device_large_graph_matches_the_restatement():
+    """500 keyframes (2000 unknowns, 125 tile columns, 40 long loop rows) and 700 keyframes (the LDS limit is ~730)."""
+    plib = product_host()
+    ofn = pg.bind_checker(H.oracle_lib(), "oracle")
+    for n, loops in ((500, 40), (700, 25)):
+        kfs, total, truth = synth.make_loop_keyframes(n, 5, n_loops=loops, radius=30.0)
+        g, skip = pg.build_with(plib, "vio", kfs, total, max_frame_num=1000)
+        opt = pg.PoseGraphOptimizer(max_nodes=n, max_edges=len(g.edge_i), n_graphs=2)
+        try:
+            a, b, o = g.copy(), g.copy(), g.copy()
+            sa, sb = opt.optimize([a, b])
+            so = pg.optimize_with(ofn, o)
+        finally:
+            opt.close()
+        assert sa["iterations"] == so["iterations"] and list(sa["it_flags"]) == list(so["it_flags"])
+        assert np.allclose(np.asarray(sa["it_cost"])[:so["iterations"]], np.asarray(so["it_cost"])[:so["iterations"]], rtol=1e-8)
+        assert np.abs(a.t - o.t).max() < TOL_GPU * np.abs(o.t).max()
+        assert np.abs((a.ypr[:, 0] - o.ypr[:, 0] + 180.0) % 360.0 - 180.0).max() < TOL_GPU * 180.0
+        assert np.abs(a.t - b.t).max() < 1e-8
+        assert np.linalg.norm(a.t - truth, axis=1).max() < 0.9 * np.linalg.norm(g.t - truth, axis=1).max()
+    with pytest.raises(RuntimeError):
+        pg.PoseGraphOptimizer(max_nodes=900, max_edges=100, n_graphs=1)  # seven N-vectors no longer fit the LDS: VIO_ECAP
+
+
+@pytest.mark.gpu
 def test_device_capacity_and_argument_errors(optimizer):
     d = np.load(GOLD)
     g, _ = load_case(d, "lap200")
