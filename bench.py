@@ -16,7 +16,8 @@ N GPUs run N x the sequences with no data-path collective (weak scaling).
 Besides the contract line's `roofline` and `cpu_baseline`, rank 0 at N = 1 adds secondary measurements (bounded, ~1.5
 minutes in total; `--quick` skips them): `cpu_baseline_all_cores` (one sequence per host core), `end_to_end` (the
 estimator path: host observations in, host states out), `ate` (closed-loop position error against the truth and against
-the CPU path on the same data) and `large_windows` (kernel time of configs[2] and configs[4]).
+the CPU path on the same data), `large_windows` (kernel time of configs[2] and configs[4]) and `loop_closure` (pose graph
+solve and descriptor matching).
 """
 import argparse
 import ctypes as C
@@ -231,6 +232,7 @@ def main():
             out["end_to_end"] = guarded(lambda: end_to_end(S))
             out["ate"] = guarded(lambda: closed_loop_ate(cfg, pkg))
             out["large_windows"] = guarded(lambda: large_windows(pkg))
+            out["loop_closure"] = guarded(lambda: loop_closure(pkg))
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
@@ -347,7 +349,8 @@ def end_to_end(n_seq):
     solves, _, _, lib_s = TE.run(n_seq, n_frames, quiet=True)
     return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
             "frames_timed": solves // n_seq, "path": "vio_estimator_process_imu_batch + vio_estimator_process_images, one estimator "
-            "object on one host thread, host buffers in / host states out, priors resident on the device; time inside the two "
+            "object on one host thread (it solves its sequences in 2 groups on their own streams so that packing overlaps the "
+            "kernels), host buffers in / host states out, priors resident on the device; time inside the two "
             "library calls (closed-loop windows: ~190 landmarks, ~1400 factors, prior)",
             "ms_per_frame_of_all_sequences": lib_s / (solves // n_seq) * 1e3}
 
@@ -444,6 +447,54 @@ def large_windows(pkg, batch=64):
                      "batch": batch, "kernel_ms": ms, "ms_per_solve_at_batch": ms / batch, "solves_per_s": batch / (ms * 1e-3),
                      "gn_iterations": iters, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
                      "frac_of_fp64_peak": flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+    return out
+
+
+def loop_closure(pkg, n_graphs=256):
+    """descriptor matching (searchByDes) and the 4-DoF pose graph solve, many sequences per launch; the
+    CPU side is the reference's own functors under the vendored Ceres when oracle/_ref travelled, else the restatement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    pg, synth = pkg.posegraph, pkg.synth
+    out = {}
+    # ---- pose graph: 100 keyframes, 10 loop edges (a loop closed after ~100 keyframes of the 10 Hz keyframe stream)
+    plib = pg.bind_host(pkg.abi.load_product(), "vio")
+    kfs, total, _ = synth.make_loop_keyframes(100, 3, n_loops=10)
+    g0, _ = pg.build_with(plib, "vio", kfs, total)
+    opt = pg.PoseGraphOptimizer(max_nodes=100, max_edges=len(g0.edge_i), n_graphs=n_graphs)
+    try:
+        opt.optimize([g0.copy() for _ in range(n_graphs)])
+        gs = [g0.copy() for _ in range(n_graphs)]
+        t0 = time.perf_counter()
+        st = opt.optimize(gs)
+        dt = time.perf_counter() - t0
+    finally:
+        opt.close()
+    ref = H.ref_lib_or_none()
+    have_ref = ref is not None and hasattr(ref, "ref_posegraph_optimize")
+    cfn = pg.bind_checker(ref, "ref") if have_ref else pg.bind_checker(H.oracle_lib(), "oracle")
+    c = g0.copy()
+    t0 = time.perf_counter()
+    pg.optimize_with(cfn, c)
+    dc = time.perf_counter() - t0
+    out["pose_graph"] = {"keyframes": 100, "edges": int(len(g0.edge_i)), "graphs_per_launch": n_graphs, "iterations": st[0]["iterations"] - 1,
+                         "ms_per_call_host_to_host": dt * 1e3, "graphs_per_s": n_graphs / dt,
+                         "cpu_ms_per_graph": dc * 1e3, "cpu_kind": "reference (vendored Ceres DENSE_SCHUR + the reference's functors)" if have_ref else "port",
+                         "max_abs_dt_vs_cpu_m": float(np.abs(gs[0].t - c.t).max())}
+    # ---- searchByDes: 256 keyframe pairs, 150 window descriptors against 500 old descriptors each
+    rng = np.random.default_rng(0)
+    m = pkg.loop.Matcher()
+    try:
+        cur = [rng.integers(0, 2 ** 63, (150, 4), dtype=np.int64).astype(np.uint64) for _ in range(n_graphs)]
+        old = [rng.integers(0, 2 ** 63, (500, 4), dtype=np.int64).astype(np.uint64) for _ in range(n_graphs)]
+        m.search_by_des(cur, old)
+        t0 = time.perf_counter()
+        m.search_by_des(cur, old)
+        dm = time.perf_counter() - t0
+    finally:
+        m.close()
+    out["search_by_des"] = {"pairs_per_launch": n_graphs, "queries": 150, "candidates": 500, "ms_per_call_host_to_host": dm * 1e3,
+                            "descriptor_comparisons_per_s": n_graphs * 150 * 500 / dm}
     return out
 
 
