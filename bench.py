@@ -493,6 +493,22 @@ def loop_closure(pkg, n_graphs=256):
         dm = time.perf_counter() - t0
     finally:
         m.close()
+    # ---- keyframe descriptor extraction: 64 keyframes of 640x480, 150 window points each (FAST + blur + BRIEF)
+    pat = np.load(os.path.join(ROOT, "tests", "golden", "brief_pattern.npz"))
+    nkf = 64
+    frames = np.stack([np.ascontiguousarray(synth.make_texture(np.random.default_rng(100 + s), 480, 640), np.uint8) for s in range(4)])
+    frames = np.ascontiguousarray(frames[np.arange(nkf) % 4])
+    wpts = [rng.uniform(30, [610, 450], (150, 2)).astype(np.float32) for _ in range(nkf)]
+    ex = pkg.loop.BriefExtractor(480, 640, (pat["x1"], pat["y1"], pat["x2"], pat["y2"]), max_frames=nkf, max_keypoints=8192)
+    try:
+        ex.extract(frames, wpts, allow_cut=True)
+        t0 = time.perf_counter()
+        res = ex.extract(frames, wpts, allow_cut=True)
+        de = time.perf_counter() - t0
+    finally:
+        ex.close()
+    out["brief_extract"] = {"keyframes_per_call": nkf, "image": "640x480", "fast_corners_per_frame": float(np.mean([r[2] for r in res])),
+                            "window_points": 150, "ms_per_call_host_to_host": de * 1e3, "keyframes_per_s": nkf / de}
     out["search_by_des"] = {"pairs_per_launch": n_graphs, "queries": 150, "candidates": 500, "ms_per_call_host_to_host": dm * 1e3,
                             "descriptor_comparisons_per_s": n_graphs * 150 * 500 / dm}
     return out

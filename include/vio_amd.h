@@ -378,6 +378,30 @@ int vio_loop_find_connection(vio_matcher_t *m, const VioConfig *cfg, int32_t n_c
                              float *matched_old_norm /* [n_cur][2] or NULL */,
                              uint8_t *status /* [n_cur] */, int32_t *n_inliers);
 
+/* Keyframe descriptor extraction: BriefExtractor::operator() (loop/keyframe.cpp:395-409) =
+ * cv::FAST(im, keys, 20, true); keys += window_pts; DVision::BRIEF::compute
+ * (ThirdParty/DVision/BRIEF.cpp:40-105: GaussianBlur 9x9 sigma 2, then n_bits
+ * intensity tests im(pt + (x1,y1)) < im(pt + (x2,y2)) per keypoint, a test with
+ * an end outside the image leaves its bit 0). The pattern is the app's
+ * Resources/brief_pattern.yml (BriefExtractor::BriefExtractor, :375-393).
+ * A batch of keyframes per call. keypoints[f] = the FAST corners in cv::FAST's
+ * order (at most max_keypoints - n_window[f] are kept: VIO_ECAP says some were
+ * cut) followed by the frame's window points; descriptors [f][k][4] words, bit
+ * i of a descriptor = bit (i & 63) of word i >> 6 (vio_matcher_* layout).      */
+typedef struct vio_brief vio_brief_t;
+int vio_brief_load_pattern(const char *yml_path, int32_t *x1, int32_t *y1, int32_t *x2, int32_t *y2, int32_t cap,
+                           int32_t *n);
+int vio_brief_create(int32_t rows, int32_t cols, int32_t max_frames, int32_t max_keypoints, const int32_t *x1,
+                     const int32_t *y1, const int32_t *x2, const int32_t *y2, int32_t n_bits, vio_brief_t **out);
+int vio_brief_get_device(const vio_brief_t *b, int32_t *device);
+void vio_brief_destroy(vio_brief_t *b);
+int vio_brief_extract(vio_brief_t *b, const uint8_t *gray /* [n_frames][rows*cols] */, int32_t n_frames,
+                      const float *window_pts /* [n_frames][window_stride][2] */, const int32_t *n_window,
+                      int32_t window_stride, int32_t fast_threshold,
+                      float *keypoints /* [n_frames][max_keypoints][2] */,
+                      uint64_t *descriptors /* [n_frames][max_keypoints][4] */, int32_t *n_fast,
+                      int32_t *n_keypoints);
+
 /* 4-DoF loop pose graph: KeyFrameDatabase::optimize4DoFLoopPoseGraph
  * (VINS_ios/loop/keyfame_database.cpp:140-353). Per keyframe the unknowns are
  * yaw (degrees, AngleLocalParameterization) and translation; pitch and roll of

@@ -65,3 +65,64 @@ class Matcher:
         if rc != abi.VIO_OK:
             raise RuntimeError("vio_loop_find_connection failed rc=%d" % rc)
         return mo[:n], mn[:n], status[:n], k.value
+
+
+# ---- keyframe descriptor extraction: BriefExtractor::operator() (loop/keyframe.cpp:375-409) -----------------------------
+def bind_brief(lib):
+    lib.vio_brief_load_pattern.argtypes = [C.c_char_p, _i32p, _i32p, _i32p, _i32p, C.c_int32, _i32p]
+    lib.vio_brief_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.vio_brief_destroy.argtypes = [C.c_void_p]
+    lib.vio_brief_get_device.argtypes = [C.c_void_p, _i32p]
+    lib.vio_brief_extract.argtypes = [C.c_void_p, _u8p, C.c_int32, _fp, _i32p, C.c_int32, C.c_int32, _fp, _u64p, _i32p, _i32p]
+    return lib
+
+
+def load_pattern(path, cap=256):
+    """-> (x1, y1, x2, y2) int32 arrays from an OpenCV FileStorage YAML file (Resources/brief_pattern.yml). Host code only."""
+    lib = bind_brief(abi.load_product())
+    arr = [np.zeros(cap, np.int32) for _ in range(4)]
+    n = C.c_int32(0)
+    rc = lib.vio_brief_load_pattern(str(path).encode(), *[a.ctypes.data_as(_i32p) for a in arr], cap, C.byref(n))
+    if rc != abi.VIO_OK:
+        raise RuntimeError("vio_brief_load_pattern failed rc=%d" % rc)
+    return tuple(a[:n.value].copy() for a in arr)
+
+
+class BriefExtractor:
+    """FAST corners + window points -> BRIEF descriptors for a batch of keyframes (csrc/vio_brief.hip)."""
+
+    def __init__(self, rows, cols, pattern, max_frames=1, max_keypoints=4096):
+        self.lib = bind_brief(abi.load_product())
+        self.rows, self.cols, self.max_frames, self.cap = rows, cols, max_frames, max_keypoints
+        pat = [np.ascontiguousarray(p, np.int32) for p in pattern]
+        self._h = C.c_void_p()
+        rc = self.lib.vio_brief_create(rows, cols, max_frames, max_keypoints, *[p.ctypes.data_as(_i32p) for p in pat], len(pat[0]),
+                                       C.byref(self._h))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_brief_create failed rc=%d (a gfx950 device is required)" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_brief_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def extract(self, frames, window_pts, fast_threshold=20, allow_cut=False):
+        """frames: [n][rows][cols] uint8; window_pts: per frame float arrays [k][2]. Returns per frame
+        (keypoints [m][2], descriptors [m][4] uint64, n_fast)."""
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, self.rows, self.cols)
+        n = len(frames)
+        nw = np.array([len(w) for w in window_pts], np.int32)
+        stride = max(1, int(nw.max()) if n else 1)
+        wp = np.zeros((n, stride, 2), np.float32)
+        for f, w in enumerate(window_pts):
+            if len(w):
+                wp[f, :len(w)] = np.asarray(w, np.float32).reshape(-1, 2)
+        kp = np.zeros((n, self.cap, 2), np.float32)
+        desc = np.zeros((n, self.cap, 4), np.uint64)
+        nf, nk = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        rc = self.lib.vio_brief_extract(self._h, frames.ctypes.data_as(_u8p), n, wp.ctypes.data_as(_fp), nw.ctypes.data_as(_i32p), stride,
+                                        fast_threshold, kp.ctypes.data_as(_fp), desc.ctypes.data_as(_u64p), nf.ctypes.data_as(_i32p),
+                                        nk.ctypes.data_as(_i32p))
+        if rc != abi.VIO_OK and not (allow_cut and rc == abi.VIO_ECAP):
+            raise RuntimeError("vio_brief_extract failed rc=%d" % rc)
+        return [(kp[f, :nk[f]].copy(), desc[f, :nk[f]].copy(), int(nf[f])) for f in range(n)]
