@@ -114,3 +114,39 @@ def test_two_contexts_two_threads_concurrently():
             for g, s in zip(ws, sts):
                 H.check_solution(g, s, d, tol=1e-6)
     [s.close() for s in solvers]
+
+
+def test_loop_closure_contexts_created_on_one_thread_run_on_another():
+    """The pose-graph, descriptor-extraction and matcher contexts carry the same device binding."""
+    import os
+    import torch
+    torch.cuda.set_device(torch.cuda.device_count() - 1)
+    pg, loop, synth = pkg.posegraph, pkg.loop, pkg.synth
+    d = np.load(os.path.join(H.ROOT, "tests", "golden", "posegraph.npz"))
+    g0 = pg.Graph.from_npz_dict(d, "lap80_in_")
+    pat = np.load(os.path.join(H.ROOT, "tests", "golden", "brief_pattern.npz"))
+    opt = pg.PoseGraphOptimizer(max_nodes=128, max_edges=1024, n_graphs=2)
+    ex = loop.BriefExtractor(120, 160, (pat["x1"], pat["y1"], pat["x2"], pat["y2"]), max_frames=1, max_keypoints=4096)
+    m = loop.Matcher()
+    img = np.ascontiguousarray(synth.make_texture(np.random.default_rng(1), 120, 160), np.uint8)
+    pts = np.random.default_rng(2).uniform(20, [140, 100], (50, 2)).astype(np.float32)
+    try:
+        assert opt.device() == torch.cuda.device_count() - 1
+        here = g0.copy()
+        opt.optimize([here])
+        kp_here, desc_here, _ = ex.extract(img[None], [pts])[0]
+
+        def other_thread():
+            g = g0.copy()
+            st = opt.optimize([g])[0]
+            kp, desc, _ = ex.extract(img[None], [pts])[0]
+            idx, dist = m.search_by_des([desc[-50:]], [desc_here[-50:]])[0]
+            return g, st, kp, desc, idx, dist
+
+        g, st, kp, desc, idx, dist = _run_in_thread(other_thread)
+    finally:
+        opt.close(), ex.close(), m.close()
+    assert st["iterations"] == int(d["lap80_ref_iterations"])
+    assert np.abs(g.t - here.t).max() < 1e-9
+    assert np.array_equal(kp, kp_here) and np.array_equal(desc, desc_here)
+    assert np.array_equal(idx, np.arange(50)) and np.all(dist == 0)
