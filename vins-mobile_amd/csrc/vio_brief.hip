@@ -142,13 +142,14 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t *img, uin
 }
 
 constexpr int kColThreads = 1024;
+constexpr int kBriefMaxCols = 2048;  // widest image (the per-row corner lists of the collector live in LDS)
 // One workgroup per frame. Rows are taken 16 at a time (one per wave); a wave compacts the kept corners of its row into
 // its LDS list (ballot + popcount: column order), then the 16 lists are copied out behind each other: the emission order
 // of cv::FAST (row by row, columns ascending). n_fast counts every corner, stored are at most cap - n_window.
 __global__ __launch_bounds__(kColThreads) void fast_collect_kernel(const uint8_t *score, int rows, int cols, const float *window_pts,
                                                                    const int *n_window, int window_stride, int cap, float *keypoints,
                                                                    int *n_fast, int *n_keypoints) {
-  constexpr int kWaves = kColThreads / 64, kRowCap = 2048;
+  constexpr int kWaves = kColThreads / 64, kRowCap = kBriefMaxCols / 2;  // 3x3 non-maxima: at most every other pixel of a row
   __shared__ unsigned short s_cols[kWaves][kRowCap];
   __shared__ int s_cnt[kWaves];
   const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -292,7 +293,7 @@ int vio_brief_load_pattern(const char *yml_path, int32_t *x1, int32_t *y1, int32
 
 int vio_brief_create(int32_t rows, int32_t cols, int32_t max_frames, int32_t max_keypoints, const int32_t *x1, const int32_t *y1,
                      const int32_t *x2, const int32_t *y2, int32_t n_bits, vio_brief_t **out) {
-  if (!out || rows < 7 || cols < 7 || cols > 65535 || max_frames < 1 || max_keypoints < 1 || !x1 || !y1 || !x2 || !y2 || n_bits < 1 ||
+  if (!out || rows < 7 || cols < 7 || cols > kBriefMaxCols || max_frames < 1 || max_keypoints < 1 || !x1 || !y1 || !x2 || !y2 || n_bits < 1 ||
       n_bits > 256)
     return VIO_EINVAL;
   int ndev = 0;
