@@ -188,6 +188,44 @@ def test_device_large_graph_matches_the_restatement():
 
 
 @pytest.mark.gpu
+def test_device_properties_gauge_invariance_and_fixed_point(optimizer):
+    """Size-independent properties (no oracle involved). (1) The residuals only see relative poses in the frame of the
+    earlier keyframe: moving the whole graph by a yaw and a translation about the vertical axis moves the optimum with it
+    (pitch / roll are per-edge constants, untouched by a yaw). (2) A consistent graph — every edge equal to what its two
+    keyframes say — is a fixed point: zero cost, no step taken."""
+    plib = product_host()
+    kfs, total, _ = synth.make_loop_keyframes(140, 31, n_loops=12, yaw_drift_deg=0.5)
+    g, _ = pg.build_with(plib, "vio", kfs, total)
+    yaw0, shift = 73.0, np.array([5.0, -3.0, 1.5])
+    c, s_ = np.cos(np.deg2rad(yaw0)), np.sin(np.deg2rad(yaw0))
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+    moved = g.copy()
+    moved.t = g.t @ Rz.T + shift
+    moved.ypr = g.ypr.copy()
+    moved.ypr[:, 0] = (g.ypr[:, 0] + yaw0 + 180.0) % 360.0 - 180.0
+    a, b = g.copy(), moved.copy()
+    sa, sb = optimizer.optimize([a, b])
+    assert sa["iterations"] == sb["iterations"] and list(sa["it_flags"]) == list(sb["it_flags"])
+    n = sa["iterations"]
+    assert np.allclose(np.asarray(sa["it_cost"])[:n], np.asarray(sb["it_cost"])[:n], rtol=1e-7)
+    assert np.abs(a.t @ Rz.T + shift - b.t).max() < 1e-6 * np.abs(b.t).max()
+    assert np.abs((a.ypr[:, 0] + yaw0 - b.ypr[:, 0] + 180.0) % 360.0 - 180.0).max() < 1e-6
+    # (2) make every measurement consistent with the optimized poses of `a`, then optimize again from there
+    fixed = a.copy()
+    R = [synth._ypr_to_R(y) for y in fixed.ypr]
+    for e in range(len(fixed.edge_i)):
+        i, j = fixed.edge_i[e], fixed.edge_j[e]
+        Ri = synth._ypr_to_R([fixed.ypr[i, 0], fixed.edge_meas[e, 4], fixed.edge_meas[e, 5]])
+        fixed.edge_meas[e, 0:3] = Ri.T @ (fixed.t[j] - fixed.t[i])
+        fixed.edge_meas[e, 3] = (fixed.ypr[j, 0] - fixed.ypr[i, 0] + 180.0) % 360.0 - 180.0
+    before = fixed.copy()
+    st = optimizer.optimize([fixed])[0]
+    assert st["initial_cost"] < 1e-18 and st["termination"] == 1 and st["iterations"] == 1
+    assert np.array_equal(fixed.t, before.t) and np.array_equal(fixed.ypr, before.ypr)
+    del R
+
+
+@pytest.mark.gpu
 def test_device_capacity_and_argument_errors(optimizer):
     d = np.load(GOLD)
     g, _ = load_case(d, "lap200")
