@@ -442,7 +442,8 @@ typedef struct vio_posegraph vio_posegraph_t;
 int vio_posegraph_create(int32_t max_nodes, int32_t max_edges, int32_t n_graphs, vio_posegraph_t **out);
 int vio_posegraph_get_device(const vio_posegraph_t *pg, int32_t *device);
 void vio_posegraph_destroy(vio_posegraph_t *pg);
-/* The ceres::Solve of :287: n graphs in one launch; t / ypr are updated in place, stats[g] carries the trace. */
+/* The ceres::Solve of :287: n graphs in one launch; t / ypr are updated in place, stats[g] carries the trace.
+ * max_iterations is 5 in the reference (:159); values above VIO_MAX_TRACE - 1 are clamped to it.               */
 int vio_posegraph_optimize(vio_posegraph_t *pg, VioPoseGraph *graphs, int32_t n, int32_t max_iterations,
                            VioSolveStats *stats);
 /* Host side of :166-285: resampling flags and the edge list from a keyframe list (kf[0] = earliest_loop_index,
