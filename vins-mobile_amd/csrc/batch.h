@@ -163,7 +163,7 @@ template <>
 struct MatPick<double *> {
   static VIO_HD double *get(bool lds_matrix, ldsd l, double *g) { return lds_matrix ? (double *)l : g; }
 };
-#ifndef VIO_EMUL
+#ifndef VIO_HOST_BUILD
 template <>
 struct MatPick<ldsd> {
   static VIO_HD ldsd get(bool, ldsd l, double *) { return l; }

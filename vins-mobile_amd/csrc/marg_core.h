@@ -57,7 +57,7 @@ template <>
 struct IntPtrOf<double *> {
   typedef int *type;
 };
-#ifndef VIO_EMUL
+#ifndef VIO_HOST_BUILD
 template <>
 struct IntPtrOf<ldsd> {
   typedef ldsi type;
@@ -236,6 +236,7 @@ VIO_DEV void dtile_forward_diag(MP Dkk, cldsd ldinv_k, ldsd bk, int ld, int nval
     const double x = Dkk[n * ld + c], bn = bk[n];
     s = fma(n < c ? x : 0.0, n < c ? bn : 0.0, s);
   }
+  __builtin_amdgcn_wave_barrier();  // every load of the wave precedes the stores (compiler-level ordering)
   if (lane < 16 && c < nvalid) bk[c] = s;
 }
 // b_i -= L_ik y_k: lane = 4 r + p, the four lanes of a quad split the 16 terms

@@ -31,19 +31,31 @@
 
 #include "vio_math.h"
 
-#ifdef VIO_EMUL
+// Three builds of this file:
+//   hipcc (product)   the gfx950 kernel body;
+//   -DVIO_EMUL        tests only: ONE emulated thread, no barriers, scalar stand-ins for the wave-level sections;
+//   -DVIO_SIMT        tests only: the DEVICE sections themselves on the host, every work-item a fiber and every
+//                     wave-level instruction (v_mfma, v_readlane, DPP, ballot, s_barrier) evaluated with the hardware's
+//                     lane semantics by tests/emul/simt.h (included by the test harness before this file).
+#if defined(VIO_EMUL) || defined(VIO_SIMT)
+#define VIO_HOST_BUILD 1
+#endif
+#ifdef VIO_HOST_BUILD
 #define VIO_DEV inline
-#define VIO_SYNC() ((void)0)
 #define VIO_ATOMIC_ADD(p, v) ::vio::atomic_add((p), (v))
 #else
 #define VIO_DEV __device__ __forceinline__
-#define VIO_SYNC() __syncthreads()
 #define VIO_ATOMIC_ADD(p, v) ::vio::atomic_add((p), (v))
+#endif
+#if defined(VIO_EMUL)
+#define VIO_SYNC() ((void)0)
+#else
+#define VIO_SYNC() __syncthreads()
 #endif
 // The thread index every phase starts from passes through an empty asm: LLVM otherwise hoists the per-lane address
 // arithmetic of ALL phases out of the trust-region loop (loop-invariant), keeps hundreds of values alive across the whole
 // kernel and spills them to scratch -- a scratch_load (L2 latency) where two integer instructions would do.
-#ifdef VIO_EMUL
+#ifdef VIO_HOST_BUILD
 #define VIO_TID(cx) ((int)(cx).tid)
 #else
 #define VIO_TID(cx) ::vio::opaque_tid((int)(cx).tid)
@@ -52,7 +64,7 @@
 
 // LDS pointers carry their address space in the type: generic pointers make hipcc emit flat_load/flat_store for every
 // LDS access (no ds_read/ds_write at all in the first version of this kernel), which is several times slower.
-#ifdef VIO_EMUL
+#ifdef VIO_HOST_BUILD
 #define VIO_AS3
 #else
 #define VIO_AS3 __attribute__((address_space(3)))
@@ -60,7 +72,7 @@
 
 namespace vio {
 
-#ifndef VIO_EMUL
+#ifndef VIO_HOST_BUILD
 __device__ __forceinline__ int opaque_tid(int t) {
   asm volatile("" : "+v"(t));
   return t;
@@ -71,7 +83,7 @@ typedef VIO_AS3 double *ldsd;
 typedef const VIO_AS3 double *cldsd;
 typedef VIO_AS3 int *ldsi;
 
-#ifdef VIO_EMUL
+#ifdef VIO_HOST_BUILD
 inline void atomic_add(double *p, double v) { *p += v; }
 #else
 __device__ __forceinline__ void atomic_add(ldsd p, double v) {
@@ -672,7 +684,11 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
 #endif
 
 #ifndef VIO_EMUL
+#ifdef VIO_SIMT
+typedef ::simt::v4d v4d;
+#else
 typedef double v4d __attribute__((ext_vector_type(4)));
+#endif
 
 // v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C. Lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it receives
 // D[(l>>4) + 4 r][l&15] in element r (the f64 C/D map differs from the f32 one, cdna_hip_programming.md §3).
