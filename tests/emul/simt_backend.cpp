@@ -56,11 +56,12 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     const size_t bm = se * sizeof(double) + carve_marg<double *>(B.d, lds_matrix, nullptr, nullptr, nullptr, 0);
     return std::max(bs, bm + (lds_matrix ? 64 * kMargSlot * sizeof(double) : 0));
   };
-  bool lds_matrix = !any_loop && lds_need(true) <= kLdsBytes;
+  bool lds_matrix = pose_jp(B.d) <= 16 * kPanelTiles && lds_need(true) <= kLdsBytes;
   if (variant == 1 && !lds_matrix) return VIO_ECAP;
   if (variant == 0) lds_matrix = false;
   if (!lds_matrix && lds_need(false) > kLdsBytes) return VIO_ECAP;
-  const size_t lds_bytes = lds_matrix ? kLdsBytes : lds_need(false);
+  // (the launcher gives an LDS-variant workgroup half a CU whenever its layout fits there: two windows per CU)
+  const size_t lds_bytes = lds_matrix ? (lds_need(true) <= kLdsBytes / 2 ? kLdsBytes / 2 : kLdsBytes) : lds_need(false);
   const size_t lds_doubles = lds_bytes / sizeof(double);
   std::vector<double> lds(lds_doubles + 2, kNaN);
 
@@ -77,7 +78,8 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr;
     cx.red = cw.red, cx.lprof = cw.lprof;
     const size_t state_end = cw.state_end_doubles;
-    solve_window(cx, v, w);
+    if (lds_matrix) solve_window<true>(cx, v, w);
+    else solve_window<false>(cx, v, w);
     MargWorkT<double *> mw = carve_marg_all<double *>(B.d, lds_matrix, lds.data() + state_end, mo.scratch, lds_doubles - state_end).m;
     __syncthreads();
     marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);

@@ -3,8 +3,9 @@
 v_readlane, DPP moves, ballot and s_barrier evaluated with the hardware's lane semantics), through the same pack / view
 / carve / unpack code and the same kernel body as the device path, against the reference's golden outputs.
 
-The -DVIO_EMUL build (test_emul_backend.py) only walks scalar stand-ins of those sections. Lanes run in three different
-orders between rendezvous points: a missing barrier or an undeclared reliance on lockstep execution changes the result.
+(The scalar one-thread emulation of rounds 1-2 only walked stand-ins of those sections; it is gone.) Lanes run in three
+different orders between rendezvous points: a missing barrier or an undeclared reliance on lockstep execution changes
+the result.
 Test-only build (tests/emul/); the product library has no CPU path."""
 import ctypes as C
 import glob

@@ -7,6 +7,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -48,13 +49,18 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
   return d;
 }
 
+// Pose matrix of the reduced system: 6 (P + loop pose) unknowns + the carried right-hand side row; leading dimension of
+// the speed-bias x pose rows (whole tiles).
+inline int pose_rows(const BatchDims &d) { return 6 * d.nblk_cap + 1; }
+inline int pose_jp(const BatchDims &d) { return (pose_rows(d) + 15) / 16 * 16; }
+
 // Element counts per window of every array (strides).
 struct BatchStrides {
   size_t pose, sb, ex, feat, fint, pts, preint, pr_int, pr_x0, pr_J, pr_r, fstart, pair;
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -76,8 +82,9 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
   s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
+  s.s_Asp = o, o += (size_t)d.Pcap * kSB * pose_jp(d);
   s.scratch = (o + 7) / 8 * 8;
-  s.hm = (size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB + 16;  // (+16: operand fetches of the padded 16th row read past a block)
+  s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
   s.stats_d = kStatsDoubles, s.stats_i = kStatsInts;
   return s;
@@ -124,6 +131,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.max_iter = B.d.max_iter;
   v.Fpad = B.d.Fpad;
   v.npose6 = 6 * (v.P + (v.has_loop ? 1 : 0));
+  v.n6 = v.npose6, v.nrows = v.n6 + 1, v.nT = (v.nrows + 15) >> 4, v.jp = (6 * B.d.nblk_cap + 1 + 15) / 16 * 16;
   v.s_info = B.d.s_info, v.gravity = B.d.gravity, v.cauchy_b = B.d.cauchy_b;
   v.pose0 = B.pose + b * B.s.pose, v.sb0 = B.sb + b * B.s.sb, v.ex = B.ex + b * B.s.ex, v.feat0 = B.feat + b * B.s.feat;
   v.fhost = B.fhost + b * B.s.fint, v.ftarget = B.ftarget + b * B.s.fint, v.ffeat = B.ffeat + b * B.s.fint;
@@ -142,7 +150,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
-  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP;
+  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Asp = sc + B.s.s_Asp, v.Vsave = nullptr;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
@@ -186,7 +194,7 @@ template <class MP>
 VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global) {
   Carved<MP> c;
   size_t o = 0;
-  const size_t npc = (size_t)d.nblk_cap * kBS;  // padded pose-side length
+  const size_t npc = (size_t)d.nblk_cap * kBS;  // pose-side vector length (frame-major; the loop pose uses 6 of its 15)
   const size_t F = d.Flds;
   auto take = [&](size_t n) {
     ldsd p = base + o;  // (a null base only measures; the pointers are then never used)
@@ -200,29 +208,36 @@ VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, l
   c.red = take(6 * ((size_t)nthreads / 64) + 2);
   c.lprof = reinterpret_cast<VIO_AS3 long long *>(take(ST_COUNT));
   c.state_end_doubles = o;
-  ldsd hm = nullptr;
-  if (lds_matrix) hm = take((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 * kBB);
-  w.Hm = MatPick<MP>::get(lds_matrix, hm, hm_global);
+  // the reduced matrix: pose matrix (LDS or global) and the speed-bias band (always LDS), contiguous when both are in
+  // LDS so that the Jacobian rows of the projection factors can be staged across them
+  const size_t napp = tri_doubles(6 * (size_t)d.nblk_cap + 1);
+  const size_t o_mat = o;
+  ldsd app = nullptr;
+  if (lds_matrix) app = take(napp);
+  w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
+  w.Dss = take(2 * (size_t)d.Pcap * kSS + 16), w.Css = w.Dss + (size_t)d.Pcap * kSS;
+  w.nstage = lds_matrix ? (int)(o - o_mat) : (int)napp;
   w.cpose = take(7 * (size_t)(d.Pcap + 1)), w.csb = take(9 * (size_t)d.Pcap), w.cfeat = take(F);
   w.gp = take(npc), w.gf = take(F), w.sp = take(npc), w.sf = take(F), w.dp = take(npc);
-  w.gdp = take(npc), w.gnp = take(npc), w.gnf = take(F), w.stp = take(npc), w.stf = take(F);
-  w.hdiag = take(npc), w.hff = take(F), w.ef = take(F), w.einv = take(F), w.ldinv = take(npc), w.t1 = take(npc);
-  w.t2 = take(npc);
-  w.blk_ij = reinterpret_cast<ldsi>(take(((size_t)d.nblk_cap * (d.nblk_cap + 1) / 2 + 1) / 2 + 1));
+  w.gnp = take(npc), w.gnf = take(F), w.stf = take(F);
+  w.hff = take(F), w.ef = take(F), w.einv = take(F);
+  const size_t jp = (6 * (size_t)d.nblk_cap + 1 + 15) / 16 * 16;
+  w.ldinv = take((size_t)d.Pcap * kSB + jp);
+  // stp, t1, t2 are dead while the Jacobians are evaluated: the diagonal pose blocks of the projection Gram products
+  // (ppd, 36 per frame <= 3 x 15 per frame) accumulate in their place
+  const size_t npe = (npc + 1) & ~(size_t)1, nppd = 36 * (size_t)(d.Pcap + 1);
+  w.stp = take(npc), w.t1 = take(npc), w.t2 = take(nppd > 3 * npe ? nppd - 2 * npe : npc);
+  w.ppd = w.stp;
+  w.xt = take(jp);
   w.tf = take(F), w.prdx = take(d.Ncap), w.prr = take(d.Ncap);
   w.prcol = reinterpret_cast<ldsi>(take(((size_t)d.Ncap + 1) / 2 + 1));
+  w.sbr = reinterpret_cast<ldsi>(take((size_t)d.Pcap + 1));
   w.flag = reinterpret_cast<ldsi>(take(2));
-  w.ppd = take(36 * (size_t)(d.Pcap + 1));
   w.rot = take(9 * (size_t)(d.Pcap + 2));
   w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
-  // global-matrix variant: what is left of the CU's LDS holds the current block column of L during the factorization
-  // (solver_core.h cholesky_blocks_panel); without room for it the operands come from global memory
-  w.panel = nullptr, w.ctr = nullptr;
-  const size_t panel_doubles = (size_t)(d.nblk_cap > 1 ? d.nblk_cap - 1 : 1) * kBB + 16;
-  if (!lds_matrix && (o + panel_doubles + (size_t)d.nblk_cap / 2 + 4) * sizeof(double) <= kLdsBytes) {
-    w.panel = take(panel_doubles);
-    w.ctr = reinterpret_cast<ldsi>(take((size_t)d.nblk_cap / 2 + 1));
-  }
+  // pose matrices of more than kPanelTiles tile rows: the fill tiles of the band go through LDS
+  w.vbuf = nullptr;
+  if (!lds_matrix || jp > 16 * (size_t)kPanelTiles) w.vbuf = take((jp / 16) * 192);
   c.bytes = o * sizeof(double);
   return c;
 }
@@ -417,6 +432,13 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
       if (kind < 0 || kind > 2 || idx < 0 || idx >= P || o < 0 || o + ls > p->n) return VIO_EINVAL;
       hb.pr_kind[b * s.pr_int + k] = kind, hb.pr_index[b * s.pr_int + k] = idx, hb.pr_offset[b * s.pr_int + k] = o;
     }
+    // the reduced system stores speed-bias blocks as a block-tridiagonal band (solver_core.h): a prior that couples
+    // speed-bias blocks more than one frame apart has no slot there (no prior made by marginalize() does: it keeps one)
+    for (int k = 0; k < p->n_blocks; k++)
+      for (int k2 = 0; k2 < k; k2++)
+        if (p->block_kind[k] == VIO_BLOCK_SPEEDBIAS && p->block_kind[k2] == VIO_BLOCK_SPEEDBIAS &&
+            std::abs(p->block_index[k] - p->block_index[k2]) > 1)
+          return VIO_EINVAL;
     h[H_PRIOR_N] = p->n, h[H_PRIOR_NB] = p->n_blocks;
     if (!in_store) {
       memcpy(&hb.pr_x0[b * s.pr_x0], p->block_x0, sizeof(double) * 9 * p->n_blocks);

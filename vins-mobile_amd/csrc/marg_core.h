@@ -34,8 +34,8 @@ struct MargOut {
 
 template <class MP>
 struct MargWorkT {
-  MP Am;         // pos x pos row-major, leading dimension ld (LDS when it fits, else global)
-  int ld;
+  MP Am;         // pos x pos, lower triangle by 16-row tiles (tri_at, solver_core.h); LDS when it fits, else global
+  int ld;        // capacity: largest pos the buffer holds
   ldsd bm;       // pos
   ldsd tol;      // pos
   ldsd ldinv;    // pos: 1 / L_jj (0 for a cut pivot)
@@ -71,7 +71,7 @@ VIO_HD constexpr int kMargMaxPos(int W) { return 15 + 6 * W + 15; }
 
 VIO_HD size_t marg_scratch_doubles(const int Wcap) {
   size_t p = (size_t)kMargMaxPos(Wcap);
-  return p * p + 8 + 512 * 64;  // dense matrix + Jacobian-row staging (global-matrix variant)
+  return tri_doubles((int)p) + 8 + 512 * 64;  // packed matrix + Jacobian-row staging (global-matrix variant)
 }
 
 // LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
@@ -93,7 +93,8 @@ VIO_HD CarvedMarg<MP> carve_marg_all(const Dims &d, bool lds_matrix, ldsd base_a
     return p;
   };
   const size_t pos = (size_t)kMargMaxPos(d.Wcap), F = d.Flds;
-  ldsd Am = lds_matrix ? take(pos * pos) : nullptr;
+  const size_t nam = tri_doubles((int)pos);
+  ldsd Am = lds_matrix ? take(nam) : nullptr;
   MargWorkT<MP> &m = c.m;
   m.bm = take(pos + 16), m.tol = take(pos + 16), m.ldinv = take(pos + 16);  // (+16: whole 16-wide tiles)
   m.hff = take(F), m.gf = take(F), m.einv = take(F);
@@ -109,7 +110,7 @@ VIO_HD CarvedMarg<MP> carve_marg_all(const Dims &d, bool lds_matrix, ldsd base_a
     stage = take(stage_slots * kMargSlot);
   } else {
     stage_slots = 512;
-    stage_global = am_global ? am_global + pos * pos + 8 : nullptr;
+    stage_global = am_global ? am_global + nam + 8 : nullptr;
   }
   m.stage = MatPick<MP>::get(lds_matrix, stage, stage_global), m.stage_slots = (int)stage_slots;
   m.Am = MatPick<MP>::get(lds_matrix, Am, am_global), m.ld = (int)pos;
@@ -268,45 +269,67 @@ VIO_DEV void dtile_update2(MP C0, MP A0, MP B0, int rows0, int cols0, MP C1, MP 
   dtile_store_acc(C1, acc, ld, c1, kq, rows1, n < cols1);  // (rows1 = 0: no second tile)
 }
 
+// forward substitution pieces on the packed layout (tile rows past `rows` do not exist in memory)
+template <class MP>
+VIO_DEV void mtile_forward_diag(MP Dkk, cldsd ldinv_k, ldsd bk, int ld, int nvalid, int lane) {
+  const int c = lane & 15;
+  const bool cok = c < nvalid;
+  double s = cok ? ldinv_k[c] * bk[c] : 0.0;
+#pragma unroll
+  for (int n = 0; n < 15; n++) {
+    const bool in = cok && n < c;  // Linv[c][n] sits above the diagonal at Dkk[n][c]
+    const double x = Dkk[(in ? n : 0) * ld + (in ? c : 0)], bn = bk[in ? n : 0];
+    s = fma(in ? x : 0.0, bn, s);
+  }
+  __builtin_amdgcn_wave_barrier();  // every load of the wave precedes the stores (compiler-level ordering)
+  if (lane < 16 && cok) bk[c] = s;
+}
+template <class MP>
+VIO_DEV void mtile_rhs_update(MP Lik, ldsd bi, cldsd yk, int ld, int rows, int lane) {
+  const int r = lane >> 2, p = lane & 3;
+  const bool ok = r < rows;
+  auto Lr = Lik + (ok ? r : 0) * ld + p;
+  double s = Lr[0] * yk[p];
+  s = fma(Lr[4], yk[p + 4], s);
+  s = fma(Lr[8], yk[p + 8], s);
+  s = fma(Lr[12], yk[p + 12], s);
+  s = quad_sum_f64(s);
+  if (p == 0 && ok) bi[r] -= s;
+}
+
 // In place: the lower triangle of Am becomes L (cut columns zero), m.bm becomes L^-1 b. m.tol holds the cut thresholds.
 template <class MW>
 VIO_DEV void marg_cholesky_tiles(const Ctx &cx, MW &m, int pos) {
-  const int ld = m.ld, nt = (pos + 15) >> 4;
+  const int nt = (pos + 15) >> 4;
   const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
-  auto tile = [&](int ti, int tj) { return m.Am + (16 * ti) * ld + 16 * tj; };
+  const int li = lane & 15, kq = lane >> 4;
+  auto tile = [&](int ti, int tj) { return m.Am + tri_off(ti) + 16 * tj; };
   auto rows_of = [&](int ti) { return pos - 16 * ti < 16 ? pos - 16 * ti : 16; };
   auto tol_of = [&](int ti) {
     const int j = 16 * ti + (lane & 15);
     const double t = m.tol[j];  // (padded: readable past pos)
     return j < pos ? t : 1.0;
   };
-  if (wave == 0) potrf16_cut_wave(tile(0, 0), tile(0, 0), ld, rows_of(0), false, tol_of(0), m.ldinv, lane);
+  if (wave == 0) potrf16_cut_wave(tile(0, 0), tile(0, 0), tri_ld(0), rows_of(0), false, tol_of(0), m.ldinv, lane);
   VIO_SYNC();
   for (int k = 0; k < nt; k++) {
     const int ntb = nt - k - 1;
-    for (int bi = wave; bi < ntb; bi += nw) dtile_trsm(tile(k + 1 + bi, k), tile(k, k), m.ldinv + 16 * k, ld, rows_of(k + 1 + bi), lane);
-    if (wave == nw - 1) dtile_forward_diag(tile(k, k), m.ldinv + 16 * k, m.bm + 16 * k, ld, rows_of(k), lane);
+    for (int bi = wave; bi < ntb; bi += nw)
+      tile_trsm(tile(k + 1 + bi, k), tri_ld(k + 1 + bi), rows_of(k + 1 + bi), tile(k, k), tri_ld(k), m.ldinv + 16 * k, li, kq);
+    if (wave == nw - 1) mtile_forward_diag(tile(k, k), m.ldinv + 16 * k, m.bm + 16 * k, tri_ld(k), rows_of(k), lane);
     VIO_SYNC();
     if (wave == 0) {
-      if (ntb > 0) potrf16_cut_wave(tile(k + 1, k + 1), tile(k + 1, k), ld, rows_of(k + 1), true, tol_of(k + 1), m.ldinv + 16 * (k + 1), lane);
+      if (ntb > 0) potrf16_cut_wave(tile(k + 1, k + 1), tile(k + 1, k), tri_ld(k + 1), rows_of(k + 1), true, tol_of(k + 1), m.ldinv + 16 * (k + 1), lane);
     } else {
       const int stride = nw - 1;
       for (int bi = wave - 1; bi < ntb; bi += stride)
-        dtile_rhs_update(tile(k + 1 + bi, k), m.bm + 16 * (k + 1 + bi), m.bm + 16 * k, ld, rows_of(k + 1 + bi), lane);
+        mtile_rhs_update(tile(k + 1 + bi, k), m.bm + 16 * (k + 1 + bi), m.bm + 16 * k, tri_ld(k + 1 + bi), rows_of(k + 1 + bi), lane);
       const int npairs = ntb * (ntb + 1) / 2;  // pair 0 = the look-ahead tile
-      auto pair_ij = [&](int p, int &ti, int &tj) {
+      for (int pr = wave; pr < npairs; pr += stride) {
         int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= p) a++;
-        ti = a, tj = p - a * (a + 1) / 2;
-      };
-      for (int pr = wave; pr < npairs; pr += 2 * stride) {
-        const int pr1 = pr + stride;
-        const bool second = pr1 < npairs;
-        int i0, j0, i1, j1;
-        pair_ij(pr, i0, j0), pair_ij(second ? pr1 : pr, i1, j1);
-        i0 += k + 1, j0 += k + 1, i1 += k + 1, j1 += k + 1;
-        dtile_update2(tile(i0, j0), tile(i0, k), tile(j0, k), rows_of(i0), rows_of(j0), tile(i1, j1), tile(i1, k), tile(j1, k),
-                      second ? rows_of(i1) : 0, rows_of(j1), ld, lane);
+        while ((a + 1) * (a + 2) / 2 <= pr) a++;
+        const int i0 = k + 1 + a, j0 = k + 1 + pr - a * (a + 1) / 2;
+        tile_update(tile(i0, j0), tri_ld(i0), rows_of(i0), tile(i0, k), tile(j0, k), tri_ld(j0), rows_of(j0), li, kq);
       }
     }
     VIO_SYNC();
@@ -400,7 +423,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     if (cx.tid == 0) out.n[0] = -2, out.n[1] = 0, out.n[2] = mdrop, out.n[3] = pos;
     return;
   }
-  VIO_PARFOR(q, pos * ld) m.Am[q] = 0.0;
+  VIO_PARFOR(q, (int)tri_doubles(pos)) m.Am[q] = 0.0;
   VIO_PARFOR(q, pos) m.bm[q] = 0.0;
   VIO_PARFOR(f, F) m.hff[f] = 0.0, m.gf[f] = 0.0;
   const int n6 = 6 * (P + 1);  // WT row groups: poses 0..P-1 at 6 i, extrinsic at 6 P
@@ -426,7 +449,10 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
       for (int a = tid_ / kLanes; a < pn; a += nwv) {
         const int ca = m.pcol[a];
-        for (int b = lane; b < pn; b += kLanes) m.Am[ca * ld + m.pcol[b]] = v.prH0[a * pn + b];
+        for (int b = lane; b < pn; b += kLanes) {
+          const int cb = m.pcol[b];
+          if (ca >= cb) m.Am[tri_at(ca, cb)] = v.prH0[a * pn + b];
+        }
       }
     }
     VIO_SYNC();
@@ -461,7 +487,7 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       int cb = b < 6 ? m.col_pose[0] + b : b < 15 ? m.col_sb[0] + b - 6 : b < 21 ? m.col_pose[1] + b - 15 : m.col_sb[1] + b - 21;
       double s = 0;
       for (int k = 0; k < 15; k++) s += v.imu_J[k * 30 + a] * v.imu_M[k * 30 + b];
-      VIO_ATOMIC_ADD(m.Am + ca * ld + cb, s);
+      if (ca >= cb) VIO_ATOMIC_ADD(m.Am + tri_at(ca, cb), s);
     }
     VIO_PARFOR(a, 30) {
       int ca = a < 6 ? m.col_pose[0] + a : a < 15 ? m.col_sb[0] + a - 6 : a < 21 ? m.col_pose[1] + a - 15 : m.col_sb[1] + a - 21;
@@ -489,8 +515,8 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     const bool one_thread_per_feature = F <= (int)cx.nt;
     // dense-matrix add, lower triangle only
     auto add_lower = [&](int ra, int ca, double val) {
-      if (ra >= ca) VIO_ATOMIC_ADD(m.Am + ra * ld + ca, val);
-      else VIO_ATOMIC_ADD(m.Am + ca * ld + ra, val);
+      if (ra >= ca) VIO_ATOMIC_ADD(m.Am + tri_at(ra, ca), val);
+      else VIO_ATOMIC_ADD(m.Am + tri_at(ca, ra), val);
     };
     for (int c0 = 0; c0 < S0; c0 += CH) {
       VIO_PARFOR(k, v.M) {
@@ -523,10 +549,10 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       auto flush1 = [&](int t, int row, int col, double val) {  // G1^T G1
         const int c0p = m.col_pose[0], ctp = m.col_pose[t];
         if (row < 6) {
-          if (col <= row) VIO_ATOMIC_ADD(m.Am + (c0p + row) * ld + c0p + col, val);
+          if (col <= row) VIO_ATOMIC_ADD(m.Am + tri_at(c0p + row, c0p + col), val);
         } else if (row < 12) {
           if (col < 6) add_lower(ctp + row - 6, c0p + col, val);
-          else if (col < 12 && col <= row) VIO_ATOMIC_ADD(m.Am + (ctp + row - 6) * ld + ctp + col - 6, val);
+          else if (col < 12 && col <= row) VIO_ATOMIC_ADD(m.Am + tri_at(ctp + row - 6, ctp + col - 6), val);
         } else if (row == 12) {
           if (col < 6) VIO_ATOMIC_ADD(m.bm + c0p + col, val);
           else if (col < 12) VIO_ATOMIC_ADD(m.bm + ctp + col - 6, val);
@@ -540,28 +566,8 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
         else if (col == 12) VIO_ATOMIC_ADD(m.bm + cx0 + row, val);
       };
       auto flush3 = [&](int row, int col, double val) {  // Gx^T Gx
-        if (row < 6 && col <= row) VIO_ATOMIC_ADD(m.Am + (m.col_ex[0] + row) * ld + m.col_ex[0] + col, val);
+        if (row < 6 && col <= row) VIO_ATOMIC_ADD(m.Am + tri_at(m.col_ex[0] + row, m.col_ex[0] + col), val);
       };
-#ifdef VIO_EMUL
-      for (int p = 0; p < nb0; p++) {
-        if (v.pair_h[p] != 0 || v.pair_t[p] == P) continue;
-        int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
-        if (s_lo >= s_hi) continue;
-        const int t = v.pair_t[p];
-        for (int row = 0; row < 14; row++)
-          for (int col = 0; col < 14; col++) {
-            double d1 = 0, d2 = 0, d3 = 0;
-            for (int sl = s_lo; sl < s_hi; sl++)
-              for (int rr = 0; rr < 2; rr++) {
-                auto g = G + (sl - c0) * kMargSlot; auto gx = g + kSlotStride;
-                d1 += g[rr * kRowLen + row] * g[rr * kRowLen + col];
-                if (row < 6) d2 += gx[rr * kMargRowX + row] * g[rr * kRowLen + col];
-                if (row < 6 && col < 6) d3 += gx[rr * kMargRowX + row] * gx[rr * kMargRowX + col];
-              }
-            flush1(t, row, col, d1), flush2(t, row, col, d2), flush3(row, col, d3);
-          }
-      }
-#else
       {
         const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
         const int li = lane & 15, kq = lane >> 4;
@@ -586,7 +592,6 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
           }
         }
       }
-#endif
       stamp(cx, ST_M_GRAM);
       // per-feature sums: host coupling, extrinsic coupling, H_ff, g_f
       VIO_PARFOR(f, F) {
@@ -631,20 +636,6 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     VIO_SYNC();
     // pose-type groups: g in [0, P] -> (WT row base 6 g, dense column base)
     const int ng = P + 1;
-#ifdef VIO_EMUL
-    for (int a = 0; a < 6 * ng; a++)
-      for (int b = 0; b <= a; b++) {
-        int ga = a / 6, gb = b / 6;
-        int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
-        if (ca < 0 || cb < 0) continue;
-        const double *wa = v.WT + a * v.Fpad, *wb = v.WT + b * v.Fpad;
-        double sacc = 0;
-        for (int f = 0; f < F; f++) sacc += wa[f] * m.einv[f] * wb[f];
-        int ra = ca + a % 6, rb = cb + b % 6;
-        if (ra >= rb) m.Am[ra * ld + rb] -= sacc;
-        else m.Am[rb * ld + ra] -= sacc;
-      }
-#else
     {
       // (W E^-1) W^T over the pose-type index space as a GEMM on the matrix cores, like the solver's Schur term
       const int n6m = 6 * ng, T = (n6m + 15) / 16, npairs_t = T * (T + 1) / 2;
@@ -677,14 +668,13 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
             int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
             if (ca >= 0 && cb >= 0) {
               int rr = ca + arow % 6, cc2 = cb + bcol % 6;
-              if (rr >= cc2) m.Am[rr * ld + cc2] -= acc[r4];
-              else m.Am[cc2 * ld + rr] -= acc[r4];
+              if (rr >= cc2) m.Am[tri_at(rr, cc2)] -= acc[r4];
+              else m.Am[tri_at(cc2, rr)] -= acc[r4];
             }
           }
         }
       }
     }
-#endif
     VIO_PARFOR(a, 6 * ng) {
       int ga = a / 6;
       int ca = ga == P ? m.col_ex[0] : m.col_pose[ga];
@@ -698,73 +688,18 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   }
   stamp(cx, ST_MARG_BUILD);
   // ---- Cholesky with pivot cut, b carried along (forward substitution) --------------------------------
-  VIO_PARFOR(j, pos) m.tol[j] = fmax(1e-8, 1e-12 * m.Am[j * ld + j]);
+  VIO_PARFOR(j, pos) m.tol[j] = fmax(1e-8, 1e-12 * m.Am[tri_at(j, j)]);
   VIO_SYNC();
   // Right-looking, ONE barrier per column: column j stays unscaled in place while the trailing update uses
   // A_ij A_kj / piv; the scaling L_ij = A_ij / sqrt(piv) happens once at the end. A cut pivot zeroes its column.
   // The lower-triangle entries (i, k) are listed once, columns from last to first, in the staging area the build phase
   // no longer needs: the entries step j touches (k > j) are a PREFIX of that list, so every lane has an element and no
   // index arithmetic beyond one table read.
-#ifndef VIO_EMUL
   marg_cholesky_tiles(cx, m, pos);
-#else
-  auto tab = reinterpret_cast<typename IntPtrOf<decltype(m.stage)>::type>(m.stage);
-  const bool use_tab = (size_t)m.stage_slots * kMargSlot * 2 >= (size_t)pos * (pos - 1) / 2 + 2;
-  if (use_tab) {
-    VIO_PARFOR(k, pos) {
-      if (k < 1) continue;
-      const int off = (pos - 1 - k) * (pos - k) / 2;
-      for (int i = k; i < pos; i++) tab[off + i - k] = (i << 16) | k;
-    }
-    VIO_SYNC();
-  }
-  for (int j = 0; j < pos; j++) {
-    const double piv = m.Am[j * ld + j];
-    const bool skip = !(piv > m.tol[j]);
-    const double ip = skip ? 0.0 : 1.0 / piv;
-    const double bj = m.bm[j];
-    const int rem = pos - j - 1;
-    if (use_tab) {
-      VIO_PARFOR(q, rem * (rem + 1) / 2) {
-        const int ik = tab[q], i = ik >> 16, k = ik & 0xffff;
-        const double lij = m.Am[i * ld + j] * ip;
-        m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
-      }
-      VIO_PARFOR(q, rem) {
-        const int i = j + 1 + q;
-        m.bm[i] -= m.Am[i * ld + j] * ip * bj;
-      }
-    } else {
-      const int rl = cx.nt >= 32 ? 32 : (int)cx.nt, nrow = (int)cx.nt / rl;  // 32 lanes walk one row
-      const int lane_k = (int)cx.tid % rl;
-      for (int i = j + 1 + (int)cx.tid / rl; i < pos; i += nrow) {
-        const double lij = m.Am[i * ld + j] * ip;
-        for (int k = j + 1 + lane_k; k <= i; k += rl) m.Am[i * ld + k] -= lij * m.Am[k * ld + j];
-        if (lane_k == 0) m.bm[i] -= lij * bj;
-      }
-    }
-    VIO_SYNC();
-  }
-  // pass 1: 1/sqrt(piv) per column into tol (no longer needed as a threshold), pass 2: scale
-  VIO_PARFOR(j, pos) {
-    const double piv = m.Am[j * ld + j];
-    const bool skip = !(piv > m.tol[j]);
-    m.tol[j] = skip ? 0.0 : 1.0 / sqrt(piv);
-  }
-  VIO_SYNC();
-  VIO_PARFOR(q, pos * pos) {
-    int i = q / pos, j = q - i * pos;
-    if (j > i) continue;
-    const double inv = m.tol[j];
-    m.Am[i * ld + j] = (i == j) ? (inv > 0.0 ? sqrt(m.Am[i * ld + j]) : 0.0) : m.Am[i * ld + j] * inv;
-  }
-  VIO_PARFOR(j, pos) m.bm[j] *= m.tol[j];
-  VIO_SYNC();
-#endif
   // ---- outputs: J0 = L'^T (upper triangular), r0 = y' ---------------------------------------------------
   VIO_PARFOR(q, n * n) {
     int r = q / n, c = q % n;
-    out.J[q] = c >= r ? m.Am[(mdrop + c) * ld + mdrop + r] : 0.0;
+    out.J[q] = c >= r ? m.Am[tri_at(mdrop + c, mdrop + r)] : 0.0;
   }
   VIO_PARFOR(i, n) out.r[i] = m.bm[mdrop + i];
   if (cx.tid == 0) out.n[0] = n, out.n[1] = nblocks, out.n[2] = mdrop, out.n[3] = pos;

@@ -94,8 +94,9 @@ __device__ __forceinline__ void atomic_add(double *p, double v) {
 }
 #endif
 
-constexpr int kBS = 15;          // reduced-system block size: pose 6 + speed-bias 9
-constexpr int kBB = kBS * kBS;   // 225
+constexpr int kBS = 15;          // unknowns per frame in the pose-side vectors: pose 6 + speed-bias 9 (frame-major)
+constexpr int kSB = 9;           // speed-bias block
+constexpr int kSS = kSB * kSB;   // 81
 constexpr int kPreintDoubles = 467;
 constexpr int kMaxTrace = 64;
 constexpr int kStatsDoubles = 4 + 5 * kMaxTrace;  // initial, final, (it_cost, radius, step_norm, rel, gmax)[64]
@@ -165,56 +166,105 @@ struct WinView {
   double *imu_Mr;    // [W][15]
   double *prb0;      // [n]    b0 = J0^T r0
   double *prH0;      // [n*n]  J0^T J0
+  double *Asp;       // [P][9][jp]     speed-bias x pose coupling of the UNFACTORED reduced system (IMU factors, prior): row
+                     //                c of frame k holds A(s_k[c], pose index j); only [jlo_k, jhi_k) is ever written or read
+  int n6, nrows, nT, jp;  // pose unknowns 6 (P + has_loop); rows of the pose matrix (n6 + the carried right-hand side);
+                          // its 16-row tiles; leading dimension of Asp rows (16 nT)
   double *WT;        // [npose6][Fpad]  pose-major landmark coupling: the marginalization phase only (marg_core.h)
   double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
+  double *Vsave;     // unused by the solver (reserved)
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
   double *stats_d;
   int *stats_i;
 };
 
-// LDS (or emulated) working set; all arrays sized by the launcher from the dims. MP is the pointer type of the matrix
-// buffer: LDS when it fits (ldsd), else global (double *).
+// =====================================================================================================
+// Storage of the reduced system
+// =====================================================================================================
+// With the landmarks eliminated the unknowns are the poses (6 each, plus the relocalization pose) and one speed-bias
+// block (9) per frame. Pose x pose is dense (landmark Schur complement, prior), but a speed-bias block only couples to
+// its own and the neighbouring frame (IMU chain) and, for the one the prior keeps, to the prior's poses. The first two
+// versions of this kernel stored the reduced system as a dense 15(W+1) matrix: 118.8 KB of LDS at W = 10, one workgroup
+// per CU. Here the speed-bias blocks are ordered ahead of the poses and eliminated from the newest frame to the oldest
+// (Ceres itself moves speed-bias blocks into its e-set, CSI/reorder_program.cc:446-541): a block-tridiagonal band whose
+// fill into the pose columns is consumed as it is produced and never stored.
+//   App   pose x pose, nrows = n6 + 1: row n6 carries the right-hand side through the factorization (its row of L is the
+//         forward-substituted y_p). Lower triangle by 16-row tiles: tile row I = rows [16 I, 16 I + 16), 16 (I + 1) columns
+//         each, tile rows one after the other (21.9 KB at W = 10 instead of 34.8 KB for the square).
+//   Dss   [P][9][9]  diagonal speed-bias blocks (lower triangle read); factored: L below / on, L^-1 transposed above the
+//         diagonal, 1 / L_cc in ldinv
+//   Css   [P][9][9]  Css[k] = A(s_{k-1}, s_k), k >= 1; factored: E_k = L(s_{k-1}, s_k)
+//   Asp   (global, WinView) [P][9][jp]  A(s_k[c], pose index j) of the UNFACTORED system, columns [jlo_k, jhi_k) only
+// Pose index a = 6 frame + c; the pose-side VECTORS stay frame-major (15 frame + c, speed-bias at + 6).
+VIO_HD int tri_off(int I) { return 128 * I * (I + 1); }
+VIO_HD int tri_ld(int I) { return 16 * (I + 1); }
+VIO_HD int tri_at(int r, int c) {  // c < 16 ((r >> 4) + 1)
+  const int I = r >> 4;
+  return 128 * I * (I + 1) + (r & 15) * (16 * (I + 1)) + c;
+}
+VIO_HD size_t tri_doubles(int nrows) {
+  const int nT = (nrows + 15) >> 4;
+  return (size_t)128 * (nT - 1) * nT + (size_t)(nrows - 16 * (nT - 1)) * 16 * nT;
+}
+
+// LDS (or emulated) working set; all arrays sized by the launcher from the dims. MP is the pointer type of the pose
+// matrix: LDS when it fits (ldsd), else global (double *).
 template <class MP>
 struct WorkT {
   typedef MP mat_ptr;
-  MP Hm;          // block-lower matrix: nblk(nblk+1)/2 blocks of 225
+  MP App;         // pose x pose (+ the carried right-hand side row), tile-row packed lower triangle
+  int nstage;     // doubles behind App that are free whenever the reduced matrix is not assembled (Jacobian-row staging)
+  ldsd Dss, Css;  // speed-bias band: P blocks of 81 each, Css = Dss + 81 P (contiguous with App when App is in LDS)
   ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
   ldsd cpose, csb, cfeat;   // candidate
   ldsd ex;                  // 7
   ldsd gp, gf;              // unscaled gradient J^T r: np, F
   ldsd sp, sf;              // Jacobi scaling
-  ldsd dp;                  // dogleg diagonal (poses; landmarks: feat_d)
-  ldsd gdp;                 // gradient in d-scaled space (poses; landmarks: feat_gd)
+  ldsd dp;                  // dogleg diagonal (poses; landmarks: feat_d); the scaled gradient g s / d is recomputed
   ldsd gnp, gnf;            // Gauss-Newton step in d-scaled space
   ldsd stp, stf;            // trust-region step (J_s coordinates), later delta
-  ldsd hdiag, hff;          // diag(H_pp), H_ff (unscaled)
-  ldsd ef, einv;            // e_f = sf^2 hff + mu df^2 and its reciprocal
-  ldsi blk_ij;              // block index -> (bi << 8) | bj
-  ldsd panel;               // global-matrix variant: LDS copy of the current block column of L (nblk - 1 blocks), or null
-  ldsi ctr;                 // global-matrix variant: [nblk] work counters of the trailing updates
-  ldsd ldinv;               // 1 / L_ii
+  ldsd hff;                 // H_ff (unscaled)
+  ldsd ef, einv;            // landmark scratch / 1 / E_f
+  ldsd ldinv;               // 1 / L_cc: speed-bias blocks [9 P], then the pose matrix [16 nT]
   ldsd t1, t2;              // np temporaries
+  ldsd xt;                  // [16 nT] pose-index work vector of the back-substitution
   ldsd tf;                  // F temporary
   ldsd prdx, prr;           // prior dx / residual: prior_n each
-  ldsi prcol;               // prior column -> reduced parameter (-1 constant): prior_n
+  ldsi prcol;               // prior column -> (frame << 8 | component 0..14) of the reduced system (-1 constant): prior_n
+  ldsi sbr;                 // [2 P]: columns [jlo_k, jhi_k) of Asp row block k that the unfactored system can fill
   ldsi flag;                // [4] block-uniform flags
   ldsi fh;                  // F: host frame of every feature (-1: it has no factor)
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
   ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
+  ldsd vbuf;                // general panel path only: [nT][3][64] fill tiles V_k^T (else null)
 };
 
-
-VIO_DEV int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kBB; }
 VIO_DEV int off_pose(const WinView &v, int i) { return kBS * i; }  // loop pose: i == P -> 15 P
 VIO_DEV int off_sb(int i) { return kBS * i + 6; }
-// address of element (i, j) of the block-lower matrix, i >= j (diagonal blocks store the full 15x15)
-template <class MP>
-VIO_DEV MP mat_at(MP Hm, int i, int j) {
-  int bi = i / kBS, bj = j / kBS;
-  return Hm + blk_off(bi, bj) + (i - bi * kBS) * kBS + (j - bj * kBS);
+
+// Element of the UNFACTORED reduced system: row (frame fr, component cr in 0..14), column (fc, cc), row >= column in
+// frame-major order. add: accumulate atomically, else plain store. Speed-bias blocks more than one frame apart have no
+// slot (no factor of the reference couples them; pack_window refuses priors that would).
+template <class WK>
+VIO_DEV void red_put(const WinView &v, WK &w, int fr, int cr, int fc, int cc, double val, bool add) {
+  if (cr < 6 && cc < 6) {
+    auto p = w.App + tri_at(6 * fr + cr, 6 * fc + cc);
+    if (add) VIO_ATOMIC_ADD(p, val);
+    else *p = val;
+  } else if (cr >= 6 && cc >= 6) {
+    auto p = fr == fc ? w.Dss + fr * kSS + (cr - 6) * kSB + (cc - 6) : w.Css + fr * kSS + (cc - 6) * kSB + (cr - 6);
+    if (fr - fc > 1) return;
+    if (add) VIO_ATOMIC_ADD(p, val);
+    else *p = val;
+  } else {
+    double *p = cr >= 6 ? v.Asp + ((size_t)fr * kSB + (cr - 6)) * v.jp + 6 * fc + cc
+                        : v.Asp + ((size_t)fc * kSB + (cc - 6)) * v.jp + 6 * fr + cr;
+    if (add) VIO_ATOMIC_ADD(p, val);
+    else *p = val;
+  }
 }
 
 // ---- block reductions: every thread receives the same value ------------------------------------------------------
@@ -709,13 +759,13 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
   VIO_PARFOR(b, v.prior_nb) {
     int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
     if (kind == 0)
-      for (int k = 0; k < 6; k++) w.prcol[o + k] = off_pose(v, idx) + k;
+      for (int k = 0; k < 6; k++) w.prcol[o + k] = (idx << 8) | k;
     else if (kind == 1)
-      for (int k = 0; k < 9; k++) w.prcol[o + k] = off_sb(idx) + k;
+      for (int k = 0; k < 9; k++) w.prcol[o + k] = (idx << 8) | (6 + k);
   }
-  // J0 goes through the (still unused) matrix buffer when it fits: the n^2 dot products then read LDS
-  const bool stage = (size_t)n * n <= (size_t)v.nblk * (v.nblk + 1) / 2 * kBB;
-  auto Js = w.Hm;
+  // J0 goes through the (not yet assembled) matrix buffer when it fits: the n^2 dot products then read LDS
+  const bool stage = (size_t)n * n <= (size_t)w.nstage;
+  auto Js = w.App;
   if (stage) {
     VIO_PARFOR(q, n * n) Js[q] = v.pr_J[q];
     VIO_SYNC();
@@ -804,66 +854,75 @@ VIO_DEV double lane_bcast(double x, int lane) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
   return __hiloint2double(hi, lo);
 }
-
-// sqrt(x) and 1/sqrt(x) from v_rsq_f64 + Newton (the hardware seed carries ~single precision).
-VIO_DEV void sqrt_rsqrt(double x, double &d, double &inv) {
-  double y = __builtin_amdgcn_rsq(x);
-  double h = 0.5 * x;
-  y = y * fma(-h * y, y, 1.5);
-  y = y * fma(-h * y, y, 1.5);
-  double s = x * y;
-  s = fma(0.5 * y, fma(-s, s, x), s);
-  d = s, inv = y;
+// Sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane of the quad gets the total.
+VIO_DEV double quad_sum_f64(double v) {
+  v += dpp_move_f64<0xB1, 0xf>(v);
+  v += dpp_move_f64<0x4E, 0xf>(v);
+  return v;
 }
 
-// Operand fetch for C -= A B^T on 15x15 row-major blocks: lane l supplies X[l&15][4s + (l>>4)] (zero-padded to 16).
-template <class MP>
-VIO_DEV void load_operand15(MP X, int lane, double out[4]) {
-  const int i = lane & 15, kq = lane >> 4;
+// Layouts of v_mfma_f64_16x16x4 (lane l: li = l & 15, kq = l >> 4):
+//   operand layout of a tile X: k-step s takes X[li][4 s + kq] as A operand (rows of the product) and, for products
+//   with X^T on the right, as B operand;  accumulator layout: element r is [kq + 4 r][li].
+// The accumulator layout of a tile T is at the same time the B-operand layout of T over four k-steps (element r = k-step
+// r), so chains of products M1 (M2 T) never leave the registers.
+
+// ---- 9 x 9 speed-bias blocks (row-major, ld 9) in 16 x 16 register tiles --------------------------------------------
+// X[li][4 s + kq], zero outside the block (k-steps 0..2 cover k < 12)
+VIO_DEV void load_op9(cldsd X, int li, int kq, double out[3]) {
+  const bool iok = li < kSB;
+  cldsd p = X + (iok ? li : 0) * kSB + kq;
+  const double x0 = p[0], x1 = p[4], x2 = p[kq == 0 ? 8 : 0];
+  out[0] = iok ? x0 : 0.0, out[1] = iok ? x1 : 0.0, out[2] = (iok && kq == 0) ? x2 : 0.0;
+}
+// Linv[li][4 s + kq] of a factored diagonal block (potrf9_inv_wave): strict lower part of L^-1 transposed above the
+// diagonal (D[kk][n] = Linv[n][kk], kk < n), 1 / L_nn in ldinv_k. As A operand: Linv (.) ; as B operand: (.) L^-T.
+VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[3]) {
+  const bool iok = li < kSB;
+  const int n = iok ? li : 0;
+  const double dg = ldinv_k[n];
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 3; s++) {
     const int kk = 4 * s + kq;
-    const bool ok = (i < kBS) && (kk < kBS);
-    const double x = X[ok ? i * kBS + kk : 0];
-    out[s] = ok ? x : 0.0;
+    const bool in = iok && kk < n;
+    const double x = D[(in ? kk : 0) * kSB + n];
+    out[s] = in ? x : ((iok && kk == n) ? dg : 0.0);
   }
 }
 
-// Cholesky of one 15x15 diagonal block AND the inverse of its factor by one wave, entirely on the matrix cores.
-// The block lives in the f64 accumulator layout (lane (kq, n), element r <-> D[kq + 4r][n]) as a full symmetric matrix;
-// pivot c: row c of D sits in the 16 lanes kq == (c & 3), element c >> 2, which is exactly where the A and the B operand
-// of k-slot (c & 3) are fetched from, so the rank-1 update D -= l l^T is ONE v_mfma with a = b = l and no data movement.
-// ET (initially I) receives the same eliminations, ET -= l e^T with e = ET[c][:] / L_cc, which leaves e = row c of
-// L^-1. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
-// triangle (D[n][c] = Linv[c][n], n < c), 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
-template <class MP, class LP>
-VIO_DEV bool potrf15_inv_wave(MP D, LP Lprev, bool with_update, ldsd ldinv_k, int lane) {
+// Cholesky of one 9 x 9 diagonal block AND the inverse of its factor by one wave, entirely on the matrix cores.
+// The block lives in the f64 accumulator layout as a full symmetric matrix; pivot c: row c sits in the 16 lanes
+// kq == (c & 3), element c >> 2, which is exactly where the A and the B operand of k-slot (c & 3) are fetched from, so the
+// rank-1 update D -= l l^T is ONE v_mfma with a = b = l and no data movement. ET (initially I) receives the same
+// eliminations, ET -= l e^T with e = ET[c][:] / L_cc, which leaves e = row c of L^-1. with_update: D -= E E^T first
+// (E = the factored coupling block to the frame eliminated before, operand layout from LDS) -- the look-ahead of the
+// band. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
+// triangle, 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
+VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = kq + 4 * r;
-    const bool ok = m < kBS && n < kBS;
+    const bool ok = m < kSB && n < kSB;
     const int hi = m > n ? m : n, lo = m > n ? n : m;
-    const double x = D[ok ? hi * kBS + lo : 0];
+    const double x = D[ok ? hi * kSB + lo : 0];
     A[r] = ok ? x : 0.0;
     E[r] = (m == n) ? 1.0 : 0.0;
   }
-  if (with_update) {  // look-ahead: D -= Lprev Lprev^T (the panel block left of D) without a trip through LDS
-    double l[4];
-    load_operand15(Lprev, lane, l);
+  if (with_update) {
+    double l[3];
+    load_op9(Eprev, n, kq, l);
 #pragma unroll
-    for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
+    for (int s = 0; s < 3; s++) A = mfma_f64(-l[s], l[s], A);
   }
-  // values this lane will store: pivot c = kq + 4 j lands in element j (L[n][c] for n >= c, Linv[c][n] for n < c)
   // Everything in this loop is on the critical path of the solve and nothing in a wave overlaps its own matrix
   // instructions (an f64 MFMA holds the SIMD for 64 cycles), so the loop carries no bookkeeping: a pivot <= 0 shows up
   // as a NaN / inf reciprocal root and is tested once at the end.
-  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
+  double keep[3] = {0.0, 0.0, 0.0}, myinv = 0.0;
   double dcc = lane_bcast(A[0], 0);
 #pragma unroll
-  for (int c = 0; c < kBS; c++) {
-    // 1 / sqrt(dcc): hardware seed + two Newton steps
+  for (int c = 0; c < kSB; c++) {
     double y = __builtin_amdgcn_rsq(dcc);
     const double h = 0.5 * dcc;
     y = y * fma(-h * y, y, 1.5);
@@ -873,7 +932,7 @@ VIO_DEV bool potrf15_inv_wave(MP D, LP Lprev, bool with_update, ldsd ldinv_k, in
     const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
     keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
     myinv = (n == c) ? y : myinv;
-    if (c + 1 < kBS) {
+    if (c + 1 < kSB) {
       // the next pivot D[c+1][c+1] - l[c+1]^2 is formed ahead of the matrix instruction, so its rsqrt chain runs in
       // the shadow of the two v_mfma instead of behind them
       const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
@@ -883,166 +942,133 @@ VIO_DEV bool potrf15_inv_wave(MP D, LP Lprev, bool with_update, ldsd ldinv_k, in
     A = mfma_f64(-a, a, A);
     E = mfma_f64(-a, e, E);
   }
-  if (n < kBS) {
+  if (n < kSB) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 3; j++) {
       const int c = kq + 4 * j;
-      if (c < kBS) D[n * kBS + c] = keep[j];
+      if (c < kSB) D[n * kSB + c] = keep[j];
     }
     if (kq == 0) ldinv_k[n] = myinv;
   }
   // rsq of a pivot <= 0 (or NaN) is NaN / inf, and every later pivot inherits it
-  const bool bad = n < kBS && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
+  const bool bad = n < kSB && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
   return __builtin_amdgcn_ballot_w64(bad) == 0;
 }
 
-// ---- block operations of the reduced-system Cholesky, second generation -------------------------------------------
-// What the first version cost (s_memtime stamps, tools/microbench/chol_bench.hip): an f64 MFMA holds its SIMD's VALU for
-// 64 cycles (no co-issue, not even from the other wave of the SIMD), every compiler-inserted hazard wait state is 4
-// cycles, and the predicated operand fetches (index clamp + two v_cndmask per value) were as long as the eight matrix
-// instructions of a block update (520 of 1650 cycles; stores 240). Here the per-lane offsets are wave constants and the
-// fetches are plain ds_read_b64 with immediate offsets.
-struct LaneMap {
-  int op;      // operand fetch base: X[i][kq] = i * 15 + kq (k-step s adds 4 s)
-  int acc;     // accumulator base:   C[kq][i] = kq * 15 + i (element r adds 60 r)
-  bool i_ok;   // i < 15: this lane's accumulator column / operand row exists
-  bool k3_ok;  // kq < 3: k index 12 + kq of the last k-step exists (k = 15 is padding)
-};
-VIO_DEV LaneMap lane_map(int lane) {
-  LaneMap m;
-  const int i = lane & 15, kq = lane >> 4;
-  m.op = i * kBS + kq, m.acc = kq * kBS + i, m.i_ok = i < kBS, m.k3_ok = kq < 3;
-  return m;
-}
-// A / B operand of C -= A B^T: the lane supplies X[i][4 s + kq]. Lanes i == 15 read up to 16 doubles past the block
-// (finite or not, their products land in output row / column 15, which is never stored); only the k = 15 padding has
-// to be a true zero on both operands.
+// ---- 16 x 16 tiles of a row-major matrix (leading dimension per tile row) -------------------------------------------
+// operand X[li][kq + 4 s]; rows >= rows are zero (the lane reads row 0 instead)
 template <class MP>
-VIO_DEV void load_op(MP X, const LaneMap &m, double out[4]) {
-  auto p = X + m.op;
-  out[0] = p[0], out[1] = p[4], out[2] = p[8];
-  const double x3 = p[12];
-  out[3] = m.k3_ok ? x3 : 0.0;
+VIO_DEV void tile_load_op(MP X, int ld, int rows, int li, int kq, double out[4]) {
+  const bool ok = li < rows;
+  auto p = X + (ok ? li : 0) * ld + kq;
+  const double x0 = p[0], x1 = p[4], x2 = p[8], x3 = p[12];
+  out[0] = ok ? x0 : 0.0, out[1] = ok ? x1 : 0.0, out[2] = ok ? x2 : 0.0, out[3] = ok ? x3 : 0.0;
 }
 template <class MP>
-VIO_DEV v4d load_acc(MP C, const LaneMap &m) {
-  auto p = C + m.acc;
+VIO_DEV v4d tile_load_acc(MP C, int ld, int rows, int li, int kq) {
   v4d a;
-  a[0] = p[0], a[1] = p[60], a[2] = p[120], a[3] = p[180];  // (row 15 / column 15 garbage is never stored)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const bool ok = kq + 4 * r < rows;
+    const double x = C[(ok ? kq + 4 * r : 0) * ld + li];
+    a[r] = ok ? x : 0.0;
+  }
   return a;
 }
 template <class MP>
-VIO_DEV void store_acc(MP C, const LaneMap &m, v4d a) {
-  auto p = C + m.acc;
-  if (m.i_ok) {
-    p[0] = a[0], p[60] = a[1], p[120] = a[2];
-    if (m.k3_ok) p[180] = a[3];
-  }
-}
-// two independent block updates C -= A B^T by one wave (interleaved MFMA chains)
-template <class MP>
-VIO_DEV void block_update2(MP C0, MP A0, MP B0, MP C1, MP A1, MP B1, bool second, const LaneMap &m) {
-  double a0[4], b0[4], a1[4], b1[4];
-  load_op(A0, m, a0), load_op(B0, m, b0), load_op(A1, m, a1), load_op(B1, m, b1);
-  v4d acc0 = load_acc(C0, m), acc1 = load_acc(C1, m);
+VIO_DEV void tile_store_acc(MP C, int ld, int rows, int li, int kq, v4d a) {
 #pragma unroll
-  for (int s4 = 0; s4 < 4; s4++) {
-    acc0 = mfma_f64(-a0[s4], b0[s4], acc0);
-    acc1 = mfma_f64(-a1[s4], b1[s4], acc1);
-  }
-  store_acc(C0, m, acc0);
-  if (second) store_acc(C1, m, acc1);
+  for (int r = 0; r < 4; r++)
+    if (kq + 4 * r < rows) C[(kq + 4 * r) * ld + li] = a[r];
 }
-// 2 x 2 blocks of the trailing matrix by one wave: C_ab -= A_a B_b^T with the four operands fetched once (panel blocks
-// in LDS) and the four accumulators read-modify-written in global memory. `diag`: the tile sits on the diagonal (B_b is
-// A_b), block (0,1) is above it and skipped; has1: block row / column 1 exists; skip00: block (0,0) belongs to the
-// look-ahead wave.
-template <class MP, class OP>
-VIO_DEV void block_update_2x2(MP C00, MP C10, MP C11, MP C01, OP A0, OP A1, OP B0, OP B1, bool diag, bool has_a1, bool has_b1,
-                              bool skip00, const LaneMap &m) {
-  double a0[4], a1[4], b0[4], b1[4];
-  load_op(A0, m, a0), load_op(A1, m, a1), load_op(B0, m, b0), load_op(B1, m, b1);
-  const bool do01 = !diag && has_b1, do10 = has_a1, do11 = has_a1 && has_b1;
-  v4d c00 = load_acc(C00, m), c10 = load_acc(C10, m), c11 = load_acc(C11, m), c01 = load_acc(C01, m);
-#pragma unroll
-  for (int s4 = 0; s4 < 4; s4++) {
-    c00 = mfma_f64(-a0[s4], b0[s4], c00);
-    c10 = mfma_f64(-a1[s4], b0[s4], c10);
-    c11 = mfma_f64(-a1[s4], b1[s4], c11);
-    c01 = mfma_f64(-a0[s4], b1[s4], c01);
-  }
-  if (!skip00) store_acc(C00, m, c00);
-  if (do10) store_acc(C10, m, c10);
-  if (do11) store_acc(C11, m, c11);
-  if (do01) store_acc(C01, m, c01);
-}
-// A_ik <- A_ik L_kk^-T with the inverse potrf15_inv_wave leaves behind (strict lower part of L^-1 transposed above the
-// diagonal of the block, 1 / L_cc in ldinv_k)
+// Diagonal tile of the pose matrix: like potrf9_inv_wave on 16 x 16. nvalid rows / columns of the tile exist, the first
+// npiv of them are pivots; rows past npiv (the carried right-hand side) are eliminated along and end up as their row of L.
+// with_update: D -= Lprev Lprev^T first (the panel tile left of D, same tile row).
 template <class MP>
-VIO_DEV v4d block_trsm_acc(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
+VIO_DEV bool potrf16_wave(MP D, MP Lprev, int ld, int nvalid, int npiv, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
+  v4d A, E;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    const bool ok = m < nvalid && n < nvalid;
+    const int hi = m > n ? m : n, lo = m > n ? n : m;
+    const double x = D[ok ? hi * ld + lo : 0];
+    A[r] = ok ? x : 0.0;
+    E[r] = (m == n) ? 1.0 : 0.0;
+  }
+  if (with_update) {
+    double l[4];
+    tile_load_op(Lprev, ld, nvalid, n, kq, l);
+#pragma unroll
+    for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
+  }
+  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
+  double dcc = lane_bcast(A[0], 0);
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    if (c >= npiv) break;
+    double y = __builtin_amdgcn_rsq(dcc);
+    const double h = 0.5 * dcc;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    const bool sel = kq == (c & 3);
+    const double a = sel ? A[c >> 2] * y : 0.0;
+    const double e = sel ? E[c >> 2] * y : 0.0;
+    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+    myinv = (n == c) ? y : myinv;
+    if (c + 1 < 16) {
+      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
+      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
+      dcc = fma(-lnext, lnext, dold);
+    }
+    A = mfma_f64(-a, a, A);
+    E = mfma_f64(-a, e, E);
+  }
+  if (n < nvalid) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = kq + 4 * j;
+      if (c < npiv) D[n * ld + c] = keep[j];
+    }
+    if (kq == 0 && n < npiv) ldinv_k[n] = myinv;
+  }
+  const bool bad = n < npiv && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
+  return __builtin_amdgcn_ballot_w64(bad) == 0;
+}
+// A_ik <- A_ik L_kk^-T (panel tile below a factored FULL diagonal tile: 16 pivots)
+template <class MP>
+VIO_DEV void tile_trsm(MP Aik, int ld_i, int rows, MP Dkk, int ld_k, cldsd ldinv_k, int li, int kq) {
   double a[4];
-  load_op(Aik, m, a);
-  auto q = Dkk + m.acc;  // Dkk[kq + 4 s][n] = Linv[n][kq + 4 s] for kq + 4 s < n
-  const double dg = ldinv_k[m.i_ok ? n : 0];
-  double b[4];
-  b[0] = q[0], b[1] = q[60], b[2] = q[120], b[3] = q[180];
+  tile_load_op(Aik, ld_i, rows, li, kq, a);
+  const double dg = ldinv_k[li];
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s4 = 0; s4 < 4; s4++) {
-    const int kk = 4 * s4 + kq;
-    const double bb = (m.i_ok && kk < n) ? b[s4] : ((m.i_ok && kk == n) ? dg : 0.0);
-    acc = mfma_f64(a[s4], bb, acc);
+  for (int s = 0; s < 4; s++) {
+    const int kk = 4 * s + kq;  // B[kk][li] = Linv[li][kk]: above the diagonal of Dkk for kk < li
+    const double x = Dkk[kk * ld_k + li];
+    const double bb = kk < li ? x : (kk == li ? dg : 0.0);
+    acc = mfma_f64(a[s], bb, acc);
   }
-  return acc;
+  tile_store_acc(Aik, ld_i, rows, li, kq, acc);
 }
+// C_ij -= A_ik A_jk^T
 template <class MP>
-VIO_DEV void block_trsm(MP Aik, MP Dkk, cldsd ldinv_k, const LaneMap &m, int lane) {
-  store_acc(Aik, m, block_trsm_acc(Aik, Dkk, ldinv_k, m, lane));
-}
-// Sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane of the quad gets the total.
-VIO_DEV double quad_sum_f64(double v) {
-  v += dpp_move_f64<0xB1, 0xf>(v);
-  v += dpp_move_f64<0x4E, 0xf>(v);
-  return v;
-}
-// rhs_i -= L_ik y_k for one block by one wave: lane = 4 r + p, row r, the four lanes of a quad split the 15 terms.
-template <class MP>
-VIO_DEV void block_rhs_update(MP Lik, ldsd rhs_i, cldsd yk, int lane) {
-  const int r = lane >> 2, p = lane & 3;
-  const bool ok = r < kBS;
-  auto Lr = Lik + (ok ? r : 0) * kBS + p;
-  double s = Lr[0] * yk[p];
-  s = fma(Lr[4], yk[p + 4], s);
-  s = fma(Lr[8], yk[p + 8], s);
-  const double l3 = Lr[12], y3 = yk[p + 12];  // p == 3: one past the row / segment (in bounds), masked
-  s = fma(p < 3 ? l3 : 0.0, p < 3 ? y3 : 0.0, s);
-  s = quad_sum_f64(s);
-  if (ok && p == 0) rhs_i[r] -= s;
-}
-// y_k = L_kk^-1 rhs_k with the stored inverse, in place, by one wave: lane = 4 n + p.
-template <class MP>
-VIO_DEV void block_forward_diag(MP Dkk, cldsd ldinv_k, ldsd rhs_k, int lane) {
-  const int n = lane >> 2, p = lane & 3;
-  const bool ok = n < kBS;
-  const int nn = ok ? n : 0;
-  double s = (p == 0) ? ldinv_k[nn] * rhs_k[nn] : 0.0;
+VIO_DEV void tile_update(MP C, int ld_i, int rows_i, MP A, MP B, int ld_j, int rows_j, int li, int kq) {
+  double a[4], b[4];
+  tile_load_op(A, ld_i, rows_i, li, kq, a), tile_load_op(B, ld_j, rows_j, li, kq, b);
+  v4d acc = tile_load_acc(C, ld_i, rows_i, li, kq);
 #pragma unroll
-  for (int t4 = 0; t4 < 4; t4++) {
-    const int kk = p + 4 * t4;           // Linv[n][kk], kk < n, sits at Dkk[kk][n]
-    const bool in = ok && kk < n;
-    const double lv = Dkk[(in ? kk : 0) * kBS + nn], xv = rhs_k[in ? kk : 0];
-    s = fma(in ? lv : 0.0, xv, s);
-  }
-  s = quad_sum_f64(s);
-  __builtin_amdgcn_wave_barrier();       // every load of the wave precedes the stores (compiler-level ordering)
-  if (ok && p == 0) rhs_k[n] = s;
+  for (int s = 0; s < 4; s++) acc = mfma_f64(-a[s], b[s], acc);
+  tile_store_acc(C, ld_i, rows_i, li, kq, acc);
 }
 #endif  // !VIO_EMUL
 
+#ifndef VIO_EMUL  // (the host emulation build only takes the factor evaluations and reductions above: pnp_core.h)
 // =====================================================================================================
-// Evaluation: cost, and (jac) H -> w.Hm (lower blocks), WT / WTf, hff, gp, gf, hdiag
+// Evaluation: cost, and (jac) H -> App / Dss / Css / Asp (unfactored reduced system), WTf, hff, gp, gf, dp
 // =====================================================================================================
+constexpr int kPanelTiles = 5;   // pose matrices of up to 80 rows (W <= 12) keep the fill tiles of the band in registers
 constexpr int kRowLen = 14;      // staged Jacobian row: Ji(6) Jj(6) r Jl
 constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 1 pad (odd stride: conflict-free LDS writes)
 
@@ -1082,9 +1108,8 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
                                bool /*later_eval*/) {
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
-  auto G = w.Hm;
-  const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
-  const int CH = (nmat / kSlotStride) & ~1;
+  auto G = w.App;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
+  const int CH = (w.nstage / kSlotStride) & ~1;
   // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
   // are gathered with LDS atomics by the factor threads themselves. The six components of w_h use six F-vectors that
   // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
@@ -1125,20 +1150,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     }
     VIO_SYNC();
     stamp(cx, ST_P_FACT);
-#ifdef VIO_EMUL
-    for (int p = 0; p < v.npairs; p++) {
-      int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
-      if (s_lo >= s_hi) continue;
-      for (int row = 0; row < 13; row++)
-        for (int col = 0; col < 12; col++) {
-          double d = 0;
-          for (int sl = s_lo; sl < s_hi; sl++)
-            for (int rr = 0; rr < 2; rr++)
-              d += G[(sl - c0) * kSlotStride + rr * kRowLen + row] * G[(sl - c0) * kSlotStride + rr * kRowLen + col];
-          gram_flush(v, w, v.pair_h[p], v.pair_t[p], row, col, d, v.nrev ? 0 : (v.pair_s0[p] >= c0 ? 1 : 2));
-        }
-    }
-#else
     {
       const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
       const int li = lane & 15, kq = lane >> 4;
@@ -1215,7 +1226,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         }
       }
     }
-#endif
     VIO_SYNC();
     stamp(cx, ST_P_GRAM);
     stamp(cx, ST_P_FEAT);
@@ -1266,8 +1276,13 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     VIO_SYNC();
     cost += projections_jac(cx, v, w, pose, feat, have_scale);
     stamp(cx, ST_EVAL_PROJ);
-    const int nmat = v.nblk * (v.nblk + 1) / 2 * kBB;
-    VIO_PARFOR(q, nmat) w.Hm[q] = 0.0;
+    VIO_PARFOR(q, (int)tri_doubles(v.nrows)) w.App[q] = 0.0;
+    VIO_PARFOR(q, 2 * v.P * kSS) w.Dss[q] = 0.0;  // (Css follows Dss)
+    VIO_PARFOR(q, v.P * kSB) {  // the columns of Asp the unfactored system can fill
+      const int k = q / kSB, c = q - k * kSB;
+      double *row = v.Asp + ((size_t)k * kSB + c) * v.jp;
+      for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) row[j] = 0.0;
+    }
   }
   // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
   const int n = v.prior_n;
@@ -1292,7 +1307,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     if (n > 0) {
       VIO_PARFOR(a, n) {
         const int pa = w.prcol[a];
-        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + pa, w.prr[a]);
+        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[a]);
       }
       // H0 -> the reduced matrix: rows by wave, columns by lane, eight rows' loads in flight before the first store
       // (one dependent global load per row otherwise: the phase is nothing but L2 latency)
@@ -1317,7 +1332,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
             const int a = a0 + u * nwv;
             if (a < n && bok) {
               const int pa = w.prcol[a];
-              if (pa >= 0 && pb >= 0 && pa >= pb) *mat_at(w.Hm, pa, pb) = x[u];
+              if (pa >= 0 && pb >= 0 && pa >= pb) red_put(v, w, pa >> 8, pa & 255, pb >> 8, pb & 255, x[u], false);
             }
           }
         }
@@ -1328,7 +1343,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     const int nF = v.P + v.has_loop;
     VIO_PARFOR(q, nF * 36) {
       const int a = q / 36, e = q - a * 36, r = e / 6, c = e - r * 6;
-      if (r >= c) *mat_at(w.Hm, kBS * a + r, kBS * a + c) += w.ppd[q];
+      if (r >= c) w.App[tri_at(6 * a + r, 6 * a + c)] += w.ppd[q];
     }
     if (v.nrev) {
       VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) {
@@ -1336,14 +1351,14 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
         int a = 0;
         while ((a + 1) * (a + 2) / 2 <= blk) a++;
         int b = blk - a * (a + 1) / 2;
-        if (a != b) *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[q];
+        if (a != b) w.App[tri_at(6 * a + r, 6 * b + c)] += v.PP[q];
       }
     } else {
       VIO_PARFOR(q, v.npairs * 36) {  // (blocks without a bucket were never written and are not read)
         const int pq = q / 36, e = q - pq * 36, r = e / 6, c = e - r * 6;
         const int h = v.pair_h[pq], t = v.pair_t[pq];
         const int a = t > h ? t : h, b = t > h ? h : t;
-        *mat_at(w.Hm, kBS * a + r, kBS * b + c) += v.PP[(a * (a + 1) / 2 + b) * 36 + e];
+        w.App[tri_at(6 * a + r, 6 * b + c)] += v.PP[(a * (a + 1) / 2 + b) * 36 + e];
       }
     }
     VIO_SYNC();
@@ -1403,46 +1418,19 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
           const int row = kq + 4 * r4;  // within the tile
-          // tile (0,0): rows/cols 0..15
-          if (row >= n) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + row, 15 * f + n), G00[r4]);
+          // local index a in [0, 30): frame f components 0..14, then frame f + 1; tile (0,0): rows / cols 0..15
+          if (row >= n) red_put(v, w, f + (row >= 15), row >= 15 ? row - 15 : row, f + (n >= 15), n >= 15 ? n - 15 : n, G00[r4], true);
           // tiles (1,x): rows 16..31 -> 16..29 are Jacobian columns, 30 is the residual row
           const int R = 16 + row;
           if (R < 30) {
-            VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + R, 15 * f + n), G10[r4]);
-            if (n < 14 && R >= 16 + n) VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + R, 15 * f + 16 + n), G11[r4]);
+            red_put(v, w, f + 1, R - 15, f + (n >= 15), n >= 15 ? n - 15 : n, G10[r4], true);
+            if (n < 14 && R >= 16 + n) red_put(v, w, f + 1, R - 15, f + 1, n + 1, G11[r4], true);
           } else if (R == 30) {
             VIO_ATOMIC_ADD(w.gp + 15 * f + n, G10[r4]);
             if (n < 14) VIO_ATOMIC_ADD(w.gp + 15 * f + 16 + n, G11[r4]);
           }
         }
       }
-    }
-#else
-    VIO_PARFOR(q, v.W * 450) {  // M = info * Jraw
-      int f = q / 450, e = q % 450, r = e / 30, c = e % 30;
-      const double *info = v.imu_info + f * 225 + r * 15;
-      const double *Jr = v.imu_J + f * 450 + c;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += info[k] * Jr[k * 30];
-      v.imu_M[q] = s;
-    }
-    VIO_SYNC();
-    VIO_PARFOR(q, v.W * 465) {  // H[15f + a][15f + b] += sum_k Jraw[k][a] M[k][b], lower triangle of the 30x30
-      int f = q / 465, e = q - f * 465;
-      int a = 0;
-      while ((a + 1) * (a + 2) / 2 <= e) a++;
-      int b = e - a * (a + 1) / 2;
-      const double *Ja = v.imu_J + f * 450 + a, *Mb = v.imu_M + f * 450 + b;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mb[k * 30];
-      VIO_ATOMIC_ADD(mat_at(w.Hm, 15 * f + a, 15 * f + b), s);
-    }
-    VIO_PARFOR(q, v.W * 30) {
-      int f = q / 30, a = q % 30;
-      const double *Ja = v.imu_J + f * 450 + a, *Mr = v.imu_Mr + f * 15;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += Ja[k * 30] * Mr[k];
-      VIO_ATOMIC_ADD(w.gp + 15 * f + a, s);
     }
 #endif
     VIO_SYNC();
@@ -1460,7 +1448,15 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
   }
   double total = block_sum(cx, cost);  // contains barriers
   if (jac) {
-    VIO_PARFOR(i, np) w.hdiag[i] = *mat_at(w.Hm, i, i);
+    // diag(H) -> Jacobi scaling (fixed at the first evaluation, trust_region_minimizer.cc:239-254) and the trust-region
+    // diagonal D = sqrt(clamp(diag(J_s^T J_s))) of THIS linearization (dogleg_strategy.cc:98-115)
+    VIO_PARFOR(i, np) {
+      const int f = i / kBS, c = i - f * kBS;
+      const double h = c < 6 ? w.App[tri_at(6 * f + c, 6 * f + c)] : w.Dss[f * kSS + (c - 6) * (kSB + 1)];
+      if (!have_scale) w.sp[i] = rcp_f(1.0 + sqrt_f(h));
+      const double sc = w.sp[i];
+      w.dp[i] = sqrt_f(fmin(fmax(sc * sc * h, 1e-6), 1e32));
+    }
     VIO_SYNC();
   }
   stamp(cx, ST_COST_EVAL);
@@ -1491,6 +1487,83 @@ VIO_DEV double feat_gd(const WK &w, int f) {
   return w.sf[f] * w.gf[f] * rsqrt_f(feat_d2(w, f));
 }
 
+// pose-side scaled gradient g s / d (dogleg_strategy.cc:98-115), recomputed where it is used like feat_gd
+template <class WK>
+VIO_DEV double pose_gd(const WK &w, int i) {
+  return w.sp[i] * w.gp[i] * rcp_f(w.dp[i]);
+}
+
+// u^T H u for u = S a (a in Ceres' scaled coordinates: vp poses, vf landmarks) on the UNFACTORED system left behind by
+// evaluate(): u_p^T H_pp u_p + 2 u_f^T W^T u_p + sum_f H_ff u_f^2. This is |J_s a|^2 of the Cauchy-point formula
+// (dogleg_strategy.cc:172-192); the first two versions evaluated it after the factorization through L, which forced the
+// fill of the factor to be kept. Uses w.t1 (u_p, frame-major), w.xt (u_p by pose index) and w.tf as scratch.
+template <class WK>
+VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf) {
+  const int np = v.np, F = v.F, n6 = v.n6, P = v.P;
+  VIO_PARFOR(f, F) w.tf[f] = 0.0;
+  VIO_PARFOR(i, np) {
+    const int f = i / kBS, c = i - f * kBS;
+    const double u = w.sp[i] * vp[i];
+    w.t1[i] = u;
+    if (c < 6) w.xt[6 * f + c] = u;
+  }
+  VIO_SYNC();
+  int nparts, per;
+  wt_parts((int)cx.nt, F, n6, nparts, per);
+  VIO_PARFOR(q, F * nparts) {  // (W^T u_p)_f += sum_{a in part} W[f][a] u_p[a]
+    const int part = q / F, f = q - part * F;
+    const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
+    double x[kWStrip], sacc = 0;
+    for (int b0 = a0; b0 < a1; b0 += kWStrip) {
+      const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
+      wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, x);  // the lane's own contiguous strip of the feature-major W
+#pragma unroll
+      for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * w.xt[b0 + (j < nb ? j : 0)];
+    }
+    VIO_ATOMIC_ADD(w.tf + f, sacc);
+  }
+  stamp(cx, ST_Q_W);
+  double acc = 0;
+  // pose x pose (lower triangle, off-diagonal entries count twice): (row, quarter) items
+  VIO_PARFOR(q, 4 * n6) {
+    const int r = q >> 2, part = q & 3;
+    auto row = w.App + tri_at(r, 0);
+    double sacc = 0;
+    for (int c = part; c < r; c += 4) sacc = fma(row[c], w.xt[c], sacc);
+    sacc *= 2.0;
+    if (part == 0) sacc = fma(row[r], w.xt[r], sacc);
+    acc = fma(w.xt[r], sacc, acc);
+  }
+  // speed-bias band: D_k (lower triangle) and the coupling Css[k] = A(s_{k-1}, s_k)
+  VIO_PARFOR(q, P * kSB) {
+    const int k = q / kSB, r = q - k * kSB;
+    cldsd D = w.Dss + k * kSS + r * kSB;
+    const double ur = w.t1[kBS * k + 6 + r];
+    double sacc = 0;
+    for (int c = 0; c < r; c++) sacc = fma(D[c], w.t1[kBS * k + 6 + c], sacc);
+    sacc = 2.0 * sacc + D[r] * ur;
+    if (k >= 1) {  // row r of Css[k] belongs to s_{k-1}[r]
+      cldsd C = w.Css + k * kSS + r * kSB;
+      double s2 = 0;
+      for (int c = 0; c < kSB; c++) s2 = fma(C[c], w.t1[kBS * k + 6 + c], s2);
+      acc = fma(2.0 * w.t1[kBS * (k - 1) + 6 + r], s2, acc);
+    }
+    // speed-bias x pose (global, columns the unfactored system fills)
+    const double *A = v.Asp + ((size_t)k * kSB + r) * v.jp;
+    double s3 = 0;
+    for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) s3 = fma(A[j], w.xt[j], s3);
+    acc = fma(ur, sacc + 2.0 * s3, acc);
+  }
+  VIO_SYNC();  // tf complete
+  VIO_PARFOR(f, F) {
+    const double u = w.sf[f] * vf[f];
+    acc = fma(u, fma(w.hff[f], u, 2.0 * w.tf[f]), acc);
+  }
+  return block_sum(cx, acc);
+}
+
+// In place: (H + mu C) on the diagonals, then the landmark Schur term  App -= (W E^-1) W^T  and the right-hand side row
+// App[n6][:] = g_p - W (g_f / E_f). Returns false if some E_f <= 0.
 template <class WK>
 VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu) {
   const int np = v.np, F = v.F;
@@ -1503,46 +1576,35 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     const double isf = rcp_f(w.sf[f]);
     const double e = w.hff[f] + mu * (feat_d2(w, f) * isf * isf);  // E_f = H_ff + mu (D_f / s_f)^2
     const double ei = rcp_f(e);
-    w.ef[f] = e;
     w.einv[f] = ei;
     w.tf[f] = w.gf[f] * ei;  // g_f / E_f
     if (!(e > 0.0)) w.flag[0] = 1;
   }
-  VIO_PARFOR(i, v.nblk * kBS) {
-    if (i < np) {
-      const double c = w.dp[i] * rcp_f(w.sp[i]);
-      *mat_at(w.Hm, i, i) += mu * c * c;
-      w.t1[i] = w.gp[i];
+  VIO_PARFOR(i, np) {
+    const int f = i / kBS, c = i - f * kBS;
+    const double cc = w.dp[i] * rcp_f(w.sp[i]);
+    if (c < 6) {
+      w.App[tri_at(6 * f + c, 6 * f + c)] += mu * cc * cc;
+      w.App[tri_at(v.n6, 6 * f + c)] = w.gp[i];  // the carried right-hand side (speed-bias rows: taken from gp by the panel)
     } else {
-      *mat_at(w.Hm, i, i) = 1.0;  // padding of the last block (loop pose uses 6 of 15): rows/columns stay zero
-      w.t1[i] = 0.0;
+      w.Dss[f * kSS + (c - 6) * (kSB + 1)] += mu * cc * cc;
     }
   }
   VIO_SYNC();
   stamp(cx, ST_SCALE);
-  const int n6 = v.npose6;
-  bool rhs_done = false;
-#ifdef VIO_EMUL
-  for (int a = 0; a < n6; a++)
-    for (int b = 0; b <= a; b++) {
-      int i = kBS * (a / 6) + a % 6, j = kBS * (b / 6) + b % 6;
-      double s = 0;
-      for (int f = 0; f < F; f++) s += v.WTf[(size_t)f * v.n6cap + a] * w.einv[f] * v.WTf[(size_t)f * v.n6cap + b];
-      *mat_at(w.Hm, i, j) -= s;
-    }
-#else
+  const int n6 = v.n6;
   {
-    // Landmark Schur complement as a GEMM on the matrix cores: C(n6 x n6, lower tiles) = (Ws E^-1) Ws^T, K = F.
+    // Landmark Schur complement as a GEMM on the matrix cores: C(n6 x n6, lower tiles) = (W E^-1) W^T, K = F. Rows and
+    // columns are pose indices: the product tiles ARE the tiles of App.
     const int T = (n6 + 15) / 16, npairs = T * (T + 1) / 2;
     const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int ksteps = (F + 3) / 4;
     constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
-    rhs_done = false;
     if (T <= kT) {
       // K-split: every wave owns a slice of the features and forms ALL lower tiles from it. A and B operands are the
       // same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one latency) feeding
-      // 75 matrix instructions; the 8 partial results meet in the matrix through LDS atomics.
+      // 75 matrix instructions; the partial results of the waves meet in the matrix through LDS atomics.
       const int ksw = (ksteps + nw - 1) / nw;
       const int s_begin = wave * ksw, s_end = s_begin + ksw < ksteps ? s_begin + ksw : ksteps;
       v4d acc[kT * (kT + 1) / 2];
@@ -1590,406 +1652,460 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int arow = 16 * ti + kq + 4 * r;
-            if (arow < n6 && bcol < n6) {
-              const int i = kBS * (arow / 6) + arow % 6, j = kBS * (bcol / 6) + bcol % 6;
-              if (i >= j) VIO_ATOMIC_ADD(mat_at(w.Hm, i, j), -acc[ti * (ti + 1) / 2 + tj][r]);
-            }
+            if (arow < n6 && bcol <= arow) VIO_ATOMIC_ADD(w.App + tri_at(arow, bcol), -acc[ti * (ti + 1) / 2 + tj][r]);
           }
         }
 #pragma unroll
       for (int t = 0; t < kT; t++) {
         const int a = 16 * t + li;
-        if (a < n6 && rp[t] != 0.0) VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -rp[t]);
+        if (a < n6 && rp[t] != 0.0) VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -rp[t]);
       }
-      rhs_done = true;
-    } else
-    for (int p = wave; p < npairs; p += nw) {
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
-      const int tj = p - ti * (ti + 1) / 2;
-      const int ra = 16 * ti + li, rb = 16 * tj + li;
-      const bool va = ra < n6, vb = rb < n6;
-      const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
-      v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-      constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
-      for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
-        double av[kChunk], bv[kChunk], ev[kChunk];
+    } else {
+      for (int p = wave; p < npairs; p += nw) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
+        const int tj = p - ti * (ti + 1) / 2;
+        const int ra = 16 * ti + li, rb = 16 * tj + li;
+        const bool va = ra < n6, vb = rb < n6;
+        const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
+        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
+        for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
+          double av[kChunk], bv[kChunk], ev[kChunk];
 #pragma unroll
-        for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
-          const int f = 4 * (s0 + j) + kq;
-          const int fc = (f < F && s0 + j < ksteps) ? f : 0;
-          av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
+          for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
+            const int f = 4 * (s0 + j) + kq;
+            const int fc = (f < F && s0 + j < ksteps) ? f : 0;
+            av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) {
+            const int f = 4 * (s0 + j) + kq;
+            const bool vf = f < F && s0 + j < ksteps;
+            av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
         }
-#ifndef VIO_EMUL
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        acc += acc1;
+        const int bcol = 16 * tj + li;
 #pragma unroll
-        for (int j = 0; j < kChunk; j++) {
-          const int f = 4 * (s0 + j) + kq;
-          const bool vf = f < F && s0 + j < ksteps;
-          av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+        for (int r = 0; r < 4; r++) {  // (one wave per tile: plain read-modify-write)
+          const int arow = 16 * ti + kq + 4 * r;
+          if (arow < n6 && bcol <= arow) w.App[tri_at(arow, bcol)] -= acc[r];
         }
-#pragma unroll
-        for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
       }
-      acc += acc1;
-      const int bcol = 16 * tj + li;
+      stamp(cx, ST_SCHUR);
+      // rhs_p -= sum_f W_f (g_f / E_f): (row, feature-chunk) items
+      const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
+      VIO_PARFOR(q, n6 * nch) {
+        int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
+        int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
+        double x[kWStrip], sacc = 0;
+        const int nb = f1 - f0;  // <= kWStrip by the choice of nch
+        if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
+        wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int arow = 16 * ti + kq + 4 * r;
-        if (arow < n6 && bcol < n6) {
-          int i = kBS * (arow / 6) + arow % 6, j = kBS * (bcol / 6) + bcol % 6;
-          if (i >= j) *mat_at(w.Hm, i, j) -= acc[r];
-        }
+        for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
+        VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -sacc);
       }
     }
-  }
-#endif
-  stamp(cx, ST_SCHUR);
-  // rhs_p -= sum_f ws_f (gs_f / e_f): (row, feature-chunk) items, LDS atomics on 6 (P) targets (already folded into the
-  // K-split Schur product above when that form ran)
-  if (!rhs_done) {
-  const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
-  VIO_PARFOR(q, n6 * nch) {
-    int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
-    int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
-    double x[kWStrip], s = 0;
-    const int nb = f1 - f0;  // <= kWStrip by the choice of nch
-    if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
-    wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
-#pragma unroll
-    for (int j = 0; j < kWStrip; j++) s += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
-    VIO_ATOMIC_ADD(w.t1 + kBS * (a / 6) + a % 6, -s);
-  }
   }
   VIO_SYNC();
   stamp(cx, ST_RHS);
+  (void)np;
   return w.flag[0] == 0;
 }
 
-// Blocked right-looking Cholesky (block 15) of the block-lower matrix in place, with the right-hand side carried
-// along: on return the lower blocks hold L, ldinv = 1 / L_ii and rhs = L^-1 rhs (forward substitution).
-//   POTRF  one wave, block in the MFMA accumulator layout, one rank-1 v_mfma per pivot; also yields L_kk^-1
-//   TRSM   A_ik L_kk^-T as a matrix-core product, one block per wave (the rhs segment: 15 lanes)
-//   SYRK   trailing blocks A_ij -= L_ik L_jk^T on the matrix cores, two blocks per wave at a time; wave 0 looks
-//          ahead: it updates the next diagonal block first and factors it while the others finish the update
-// (The VIO_EMUL build runs the textbook scalar version of the same factorization.)
-// false when a pivot is <= 0 (Eigen LLT NumericalIssue, EIG/Eigen/src/Cholesky/LLT.h:300-312).
-#ifndef VIO_EMUL
-// The same factorization for a matrix that lives in global memory (windows whose reduced system does not fit the LDS).
-// There the trailing update is bound by the CU's vector-memory path, not by the matrix cores: per block product the
-// plain version moves two operand blocks (16 partially filled cache lines per fetch) and the accumulator both ways. Here
-//   * TRSM leaves the block column k of L in LDS as well (w.panel), every operand of step k is a ds_read;
-//   * a wave updates 2 x 2 blocks per visit: 4 LDS operand fetches for 4 products, 16 back-to-back MFMA;
-//   * tiles are handed out through an LDS counter, so the look-ahead wave joins once the next diagonal block is done.
-template <class WK>
-VIO_DEV bool cholesky_blocks_panel(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
-  const int nb = v.nblk;
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
-  const LaneMap m = lane_map(lane);
-  if (wave == 0) {
-    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
-    if (!good && lane == 0) w.flag[1] = 1;
-  }
-  VIO_PARFOR(q, nb) w.ctr[q] = 0;
-  VIO_SYNC();
-  stamp(cx, ST_C_POTRF);
-  for (int k = 0; k < nb; k++) {
-    if (w.flag[1]) return false;
-    auto D = w.Hm + blk_off(k, k);
-    const int ntb = nb - k - 1;
-    for (int bi = wave; bi < ntb; bi += nw) {
-      auto Aik = w.Hm + blk_off(k + 1 + bi, k);
-      const v4d l = block_trsm_acc(Aik, D, w.ldinv + k * kBS, m, lane);
-      store_acc(Aik, m, l);
-      store_acc(w.panel + bi * kBB, m, l);
-    }
-    if (wave == nw - 1) block_forward_diag(D, w.ldinv + k * kBS, rhs + k * kBS, lane);
-    VIO_SYNC();
-    stamp(cx, ST_C_TRSM);
-    if (wave == 0) {
-      if (ntb > 0) {
-        bool good = potrf15_inv_wave(w.Hm + blk_off(k + 1, k + 1), w.panel, true, w.ldinv + (k + 1) * kBS, lane);
-        if (!good && lane == 0) w.flag[1] = 1;
-      }
-      stamp(cx, ST_C_AHEAD);
-    } else {
-      for (int bi = wave - 1; bi < ntb; bi += nw - 1)  // rhs_i -= L_ik y_k
-        block_rhs_update(w.panel + bi * kBB, rhs + (k + 1 + bi) * kBS, rhs + k * kBS, lane);
-    }
-    // 2 x 2 tiles of the trailing lower triangle: tile row I >= tile column J over nt2 = ceil(ntb / 2)
-    const int nt2 = (ntb + 1) >> 1, ntiles = nt2 * (nt2 + 1) / 2;
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = __hip_atomic_fetch_add(w.ctr + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= ntiles) break;
-      const int ij = w.blk_ij[t], I = ij >> 8, J = ij & 255;  // (the block table enumerates a lower triangle row by row)
-      const int i0 = 2 * I, j0 = 2 * J;
-      const bool has_a1 = i0 + 1 < ntb, has_b1 = j0 + 1 < ntb, diag = I == J;
-      const int i1 = has_a1 ? i0 + 1 : i0, j1 = has_b1 ? j0 + 1 : j0;
-      const int gi0 = k + 1 + i0, gi1 = k + 1 + i1, gj0 = k + 1 + j0, gj1 = k + 1 + j1;
-      block_update_2x2(w.Hm + blk_off(gi0, gj0), w.Hm + blk_off(gi1, gj0), w.Hm + blk_off(gi1, gj1),
-                       w.Hm + (diag ? blk_off(gi0, gj0) : blk_off(gi0, gj1)), w.panel + i0 * kBB, w.panel + i1 * kBB,
-                       w.panel + j0 * kBB, w.panel + j1 * kBB, diag, has_a1, has_b1, /*skip00=*/t == 0, m);
-    }
-    VIO_SYNC();
-    stamp(cx, ST_C_WAIT);
-  }
-  return w.flag[1] == 0;
-}
-#endif
+// =====================================================================================================
+// Factorization of the reduced system
+// =====================================================================================================
+// Elimination order: speed-bias blocks s_W, s_{W-1}, ..., s_0, then the poses.
+//   band   (wave 0, a chain of 9-pivot steps)   L_k = chol(D_k - E_{k+1} E_{k+1}^T),  E_k = C_k L_k^-T
+//   panel  (the other waves, one step behind)   V_k^T = L_k^-1 (Asp_k - E_{k+1} V_{k+1}^T)   9 x (n6 + 1): the fill of
+//          the eliminated block into the pose columns and, in column n6, the forward-substituted right-hand side;
+//          App -= V_k V_k^T at once (which also carries App's right-hand side row along), then V_k is forgotten
+//   poses  tiled right-looking Cholesky of App (16 x 16 tiles, look-ahead on wave 0); the row n6 of L is y_p
+// Every product is a chain of v_mfma_f64_16x16x4 whose intermediate tiles stay in registers: the accumulator layout of
+// a tile is the B-operand layout of the next product (V_{k+1}^T -> E V^T, T -> L^-1 T) and V_k^T in accumulator layout
+// is V_k in operand layout for the rank-9 update of App.
 
-#ifndef VIO_EMUL
+// Band step k on one wave.
 template <class WK>
-VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
-  const int nb = v.nblk;
-  // the wave index as a scalar: block loops and addresses then run on the scalar unit
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
-  const LaneMap m = lane_map(lane);
-  if (wave == 0) {
-    bool good = potrf15_inv_wave(w.Hm + blk_off(0, 0), w.Hm, false, w.ldinv, lane);
-    if (!good && lane == 0) w.flag[1] = 1;
+VIO_DEV void band_step(const WinView &v, WK &w, int k, int fail_flag, int lane) {
+  const int li = lane & 15, kq = lane >> 4;
+  ldsd D = w.Dss + k * kSS;
+  ldsd ldk = w.ldinv + kSB * k;
+  const bool good = potrf9_inv_wave(D, w.Css + (k + 1 <= v.W ? k + 1 : k) * kSS, k < v.W, ldk, lane);
+  if (!good && lane == 0) w.flag[fail_flag] = 1;
+  if (k >= 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the factor just stored is read back in another lane mapping
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ldsd C = w.Css + k * kSS;
+    double a[3], b[3];
+    load_op9(C, li, kq, a), load_linv9(D, ldk, li, kq, b);
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 3; s++) acc = mfma_f64(a[s], b[s], acc);
+    __builtin_amdgcn_wave_barrier();  // (in place: every operand load of the wave precedes the stores)
+    if (li < kSB) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        if (kq + 4 * r < kSB) C[(kq + 4 * r) * kSB + li] = acc[r];
+    }
   }
-  VIO_SYNC();
-  stamp(cx, ST_C_POTRF);
-  for (int k = 0; k < nb; k++) {
-    if (w.flag[1]) return false;
-    auto D = w.Hm + blk_off(k, k);
-    const int ntb = nb - k - 1;
-    // ---- panel: L_ik = A_ik L_kk^-T (one wave per block), y_k = L_kk^-1 rhs_k (the last wave, which has the fewest blocks)
-    for (int bi = wave; bi < ntb; bi += nw) block_trsm(w.Hm + blk_off(k + 1 + bi, k), D, w.ldinv + k * kBS, m, lane);
-    if (wave == nw - 1) block_forward_diag(D, w.ldinv + k * kBS, rhs + k * kBS, lane);
-    VIO_SYNC();
-    stamp(cx, ST_C_TRSM);
-    // ---- trailing update with look-ahead: wave 0 updates the next diagonal block and factors it at once while the
-    // other waves update the remaining blocks (two at a time each) and the right-hand side
-    const int npairs = ntb * (ntb + 1) / 2;
+}
+
+// T = Asp_k^T tile t in accumulator layout: element r = A(s_k[kq + 4 r], pose index 16 t + li); column n6 = the
+// gradient of s_k (the right-hand side rides along as one more pose column)
+template <class WK>
+VIO_DEV v4d panel_load_tile(const WinView &v, WK &w, int k, int t, int li, int kq) {
+  const int j = 16 * t + li;
+  const bool inr = j >= w.sbr[2 * k] && j < w.sbr[2 * k + 1], isr = j == v.n6;
+  const double *A = v.Asp + (size_t)k * kSB * v.jp;
+  v4d T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int c = kq + 4 * r;
+    const bool ok = c < kSB;
+    const double x = A[(ok && inr) ? c * v.jp + j : 0];
+    const double g = w.gp[kBS * k + 6 + (ok ? c : 0)];
+    T[r] = ok ? (inr ? x : (isr ? g : 0.0)) : 0.0;
+  }
+  return T;
+}
+
+// Panel step k with the fill tiles in registers (every panel wave computes all of V_k: 6 matrix instructions per tile
+// cost less than a hand-over through LDS and its barrier), then this wave's share of the rank-9 update of App.
+template <int NT, class WK>
+VIO_DEV void panel_step_regs(const WinView &v, WK &w, int k, v4d (&V)[NT], int lane, int pw, int npw) {
+  const int li = lane & 15, kq = lane >> 4;
+  const int nT = v.nT;
+  v4d T[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    if (t < nT) T[t] = panel_load_tile(v, w, k, t, li, kq);
+  double e[3] = {0.0, 0.0, 0.0}, linv[3];
+  if (k < v.W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
+  load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    if (t >= nT) continue;
+    v4d Tt = T[t];
+    if (k < v.W) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t][s], Tt);
+    }
+    v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
+    V[t] = Vn;
+  }
+  int q = 0;
+#pragma unroll
+  for (int I = 0; I < NT; I++)
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      if (I < nT && q % npw == pw) {
+        auto C = w.App + tri_off(I) + 16 * J;
+        const int ld = tri_ld(I), rows = v.nrows - 16 * I;
+        v4d acc = tile_load_acc(C, ld, rows, li, kq);
+#pragma unroll
+        for (int s = 0; s < 3; s++) acc = mfma_f64(-V[I][s], V[J][s], acc);
+        tile_store_acc(C, ld, rows, li, kq, acc);
+      }
+      q++;
+    }
+}
+
+// Band + panel for pose matrices of up to NT tile rows. false: a pivot of the band was <= 0.
+template <int NT, class WK>
+VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int W = v.W;
+  v4d V[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) V[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int slot = 0; slot <= W + 1; slot++) {
+    const int kb = W - slot, kp = kb + 1, ff = 2 + (slot & 1);
     if (wave == 0) {
-      if (ntb > 0) {
-        auto Dn = w.Hm + blk_off(k + 1, k + 1), Ln = w.Hm + blk_off(k + 1, k);
-        bool good = potrf15_inv_wave(Dn, Ln, true, w.ldinv + (k + 1) * kBS, lane);
-        if (!good && lane == 0) w.flag[1] = 1;
-      }
+      if (kb >= 0) band_step(v, w, kb, ff, lane);
       stamp(cx, ST_C_AHEAD);
-    } else {
-      const int stride = nw - 1;
-      for (int bi = wave - 1; bi < ntb; bi += stride)  // rhs_i -= L_ik y_k
-        block_rhs_update(w.Hm + blk_off(k + 1 + bi, k), rhs + (k + 1 + bi) * kBS, rhs + k * kBS, lane);
-      // pair p of the trailing lower triangle (p = 0 is the look-ahead block): the same enumeration as the block table
-      for (int pr = wave; pr < npairs; pr += 2 * stride) {
-        const int pr1 = pr + stride;
-        const bool second = pr1 < npairs;
-        const int ij0 = w.blk_ij[pr], ij1 = w.blk_ij[second ? pr1 : pr];
-        const int i0 = k + 1 + (ij0 >> 8), j0 = k + 1 + (ij0 & 255), i1 = k + 1 + (ij1 >> 8), j1 = k + 1 + (ij1 & 255);
-        block_update2(w.Hm + blk_off(i0, j0), w.Hm + blk_off(i0, k), w.Hm + blk_off(j0, k),
-                      w.Hm + blk_off(i1, j1), w.Hm + blk_off(i1, k), w.Hm + blk_off(j1, k), second, m);
-      }
+    } else if (kp <= W) {
+      panel_step_regs<NT>(v, w, kp, V, lane, wave - 1, nw - 1);
     }
     VIO_SYNC();
     stamp(cx, ST_C_WAIT);
-  }
-  return w.flag[1] == 0;
-}
-#else
-template <class WK>
-VIO_DEV bool cholesky_blocks(const Ctx &cx, const WinView &v, WK &w, ldsd rhs) {
-  const int nb = v.nblk;
-  for (int k = 0; k < nb; k++) {
-    auto D = w.Hm + blk_off(k, k);
-    for (int c = 0; c < kBS; c++) {
-      double x = D[c * kBS + c];
-      for (int p = 0; p < c; p++) x -= D[c * kBS + p] * D[c * kBS + p];
-      if (!(x > 0.0)) return false;
-      x = sqrt(x);
-      D[c * kBS + c] = x;
-      w.ldinv[k * kBS + c] = 1.0 / x;
-      for (int i = c + 1; i < kBS; i++) {
-        double s = D[i * kBS + c];
-        for (int p = 0; p < c; p++) s -= D[i * kBS + p] * D[c * kBS + p];
-        D[i * kBS + c] = s / x;
-      }
-    }
-    stamp(cx, ST_C_POTRF);
-    // TRSM: x L_kk^T = a for every row below the diagonal block and for the rhs segment
-    const int nrows = (nb - k - 1) * kBS + 1;
-    auto trsm_row = [&](auto Ar) {
-      double x[kBS];
-#pragma unroll
-      for (int c = 0; c < kBS; c++) x[c] = Ar[c];
-#pragma unroll
-      for (int c = 0; c < kBS; c++) {
-        double s = x[c];
-#pragma unroll
-        for (int m = 0; m < c; m++) s = fma(-x[m], D[c * kBS + m], s);
-        x[c] = s * w.ldinv[k * kBS + c];
-      }
-#pragma unroll
-      for (int c = 0; c < kBS; c++) Ar[c] = x[c];
-    };
-    VIO_PARFOR(row, nrows) {
-      if (row < nrows - 1)
-        trsm_row(w.Hm + blk_off(k + 1 + row / kBS, k) + (row % kBS) * kBS);
-      else
-        trsm_row(rhs + k * kBS);
-    }
-    VIO_SYNC();
-    stamp(cx, ST_C_TRSM);
-    // trailing update
-    const int ntb = nb - k - 1;
-    VIO_PARFOR(q, ntb * kBS) {  // rhs_i -= L_ik y_k
-      int i = k + 1 + q / kBS, r = q % kBS;
-      auto Lr = w.Hm + blk_off(i, k) + r * kBS;
-      double s = 0;
-#pragma unroll
-      for (int m = 0; m < kBS; m++) s += Lr[m] * rhs[k * kBS + m];
-      rhs[i * kBS + r] -= s;
-    }
-    const int npairs = ntb * (ntb + 1) / 2;
-    for (int pr = 0; pr < npairs; pr++) {
-      int li = 0;
-      while ((li + 1) * (li + 2) / 2 <= pr) li++;
-      int lj = pr - li * (li + 1) / 2;
-      int i = k + 1 + li, j = k + 1 + lj;
-      for (int r = 0; r < kBS; r++)
-        for (int c = 0; c < kBS; c++) {
-          auto Li = w.Hm + blk_off(i, k) + r * kBS, *Lj = w.Hm + blk_off(j, k) + c * kBS;
-          double s = 0;
-          for (int m = 0; m < kBS; m++) s += Li[m] * Lj[m];
-          w.Hm[blk_off(i, j) + r * kBS + c] -= s;
-        }
-    }
-    VIO_SYNC();
+    // (the flag of this slot is not written again before every wave has passed the next barrier)
+    if (w.flag[ff]) return false;
   }
   return true;
 }
-#endif
 
-// x <- L^-T x (backward substitution; the forward half rode along with the factorization). One barrier per block
-// column: wave 0 applies step k to segment k-1 first and solves it at once with the stored inverse (above the diagonal
-// of the block, see potrf15_inv_wave) while the other waves apply step k to the segments before it.
+// The same with the fill tiles in LDS (w.vbuf: [nT][3][64], accumulator = operand layout, updated in place) for pose
+// matrices of any size: the tiles of a step are shared out over the waves, a barrier hands them over.
 template <class WK>
-VIO_DEV void cholesky_backsolve(const Ctx &cx, const WinView &v, WK &w, ldsd x) {
-  const int nb = v.nblk;
-#ifdef VIO_EMUL
-  for (int k = nb - 1; k >= 0; k--) {
-    auto D = w.Hm + blk_off(k, k);
-    for (int c = kBS - 1; c >= 0; c--) {
-      double s = x[k * kBS + c];
-      for (int r = c + 1; r < kBS; r++) s -= D[r * kBS + c] * x[k * kBS + r];
-      x[k * kBS + c] = s * w.ldinv[k * kBS + c];
+VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int W = v.W, nT = v.nT;
+  for (int k = W; k >= 0; k--) {
+    ldsd Vc = w.vbuf;  // V_{k+1}^T on entry, V_k^T behind the panel phase: element (t, s) of a lane is private to it
+    if (wave == 0) band_step(v, w, k, 2, lane);
+    VIO_SYNC();
+    stamp(cx, ST_C_AHEAD);
+    if (w.flag[2]) return false;
+    double e[3] = {0.0, 0.0, 0.0}, linv[3];
+    if (k < W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
+    load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
+    for (int t = wave; t < nT; t += nw) {
+      v4d Tt = panel_load_tile(v, w, k, t, li, kq);
+      if (k < W) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], Vc[(t * 3 + s) * 64 + lane], Tt);
+      }
+      v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
+#pragma unroll
+      for (int s = 0; s < 3; s++) Vc[(t * 3 + s) * 64 + lane] = Vn[s];
     }
-    for (int q = 0; q < k * kBS; q++) {  // y_j -= L_kj^T x_k for j < k
-      int j = q / kBS, c = q % kBS;
-      auto Lkj = w.Hm + blk_off(k, j);
-      double s = 0;
-      for (int m = 0; m < kBS; m++) s += Lkj[m * kBS + c] * x[k * kBS + m];
-      x[j * kBS + c] -= s;
+    VIO_SYNC();
+    stamp(cx, ST_C_TRSM);
+    const int ntiles = nT * (nT + 1) / 2;
+    for (int q = wave; q < ntiles; q += nw) {
+      int I = 0;
+      while ((I + 1) * (I + 2) / 2 <= q) I++;
+      const int J = q - I * (I + 1) / 2;
+      auto C = w.App + tri_off(I) + 16 * J;
+      const int ld = tri_ld(I), rows = v.nrows - 16 * I;
+      v4d acc = tile_load_acc(C, ld, rows, li, kq);
+#pragma unroll
+      for (int s = 0; s < 3; s++) acc = mfma_f64(-Vc[(I * 3 + s) * 64 + lane], Vc[(J * 3 + s) * 64 + lane], acc);
+      tile_store_acc(C, ld, rows, li, kq, acc);
     }
+    // (the next step's band work only touches Dss / Css; the barrier behind it orders this update before the next
+    // panel phase overwrites vbuf)
+    stamp(cx, ST_C_WAIT);
   }
-#else
-  const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63;
-  // The chain (apply block k to segment k-1, solve segment k-1) is the critical path: 11 steps one after the other on
-  // wave 0. Both of its 15-term dot products are split over the four lanes of a quad (lane = 4 c + p) and summed on the
-  // DPP network, so a step is two LDS round trips and a handful of FMAs instead of two 15-deep dependent chains.
-  const int qc = lane >> 2, qp = lane & 3;
-  const bool qok = qc < kBS;
-  const int qcc = qok ? qc : 0;
-  auto solve_diag = [&](int k) {  // x_k <- L_kk^-T x_k: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
-    auto D = w.Hm + blk_off(k, k);
-    double sacc = qp == 0 ? w.ldinv[k * kBS + qcc] * x[k * kBS + qcc] : 0.0;
+  VIO_SYNC();
+  return true;
+}
+
+// Tiled right-looking Cholesky of App with the right-hand side row carried along. false: a pivot was <= 0.
+template <class WK>
+VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int nT = v.nT, nrows = v.nrows, n6 = v.n6;
+  ldsd ldp = w.ldinv + kSB * v.P;
+  auto tile = [&](int I, int J) { return w.App + tri_off(I) + 16 * J; };
+  auto rows_of = [&](int I) { return nrows - 16 * I < 16 ? nrows - 16 * I : 16; };
+  auto piv_of = [&](int I) { return n6 - 16 * I < 16 ? (n6 - 16 * I > 0 ? n6 - 16 * I : 0) : 16; };
+  if (wave == 0) {
+    const bool good = potrf16_wave(tile(0, 0), tile(0, 0), tri_ld(0), rows_of(0), piv_of(0), false, ldp, lane);
+    if (!good && lane == 0) w.flag[1] = 1;
+  }
+  VIO_SYNC();
+  stamp(cx, ST_C_POTRF);
+  for (int K = 0; K < nT; K++) {
+    if (w.flag[1]) return false;
+    const int ntb = nT - K - 1;
+    for (int bi = wave; bi < ntb; bi += nw)
+      tile_trsm(tile(K + 1 + bi, K), tri_ld(K + 1 + bi), rows_of(K + 1 + bi), tile(K, K), tri_ld(K), ldp + 16 * K, li, kq);
+    VIO_SYNC();
+    stamp(cx, ST_C_TRSM);
+    // trailing update with look-ahead: wave 0 updates the next diagonal tile in registers and factors it at once while
+    // the other waves update the remaining tiles
+    if (wave == 0) {
+      if (ntb > 0) {
+        const bool good = potrf16_wave(tile(K + 1, K + 1), tile(K + 1, K), tri_ld(K + 1), rows_of(K + 1), piv_of(K + 1), true,
+                                       ldp + 16 * (K + 1), lane);
+        if (!good && lane == 0) w.flag[1] = 1;
+      }
+      stamp(cx, ST_C_AHEAD);
+    } else {
+      const int npairs = ntb * (ntb + 1) / 2;  // pair 0 = the look-ahead tile
+      for (int pr = wave; pr < npairs; pr += nw - 1) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= pr) a++;
+        const int I = K + 1 + a, J = K + 1 + pr - a * (a + 1) / 2;
+        tile_update(tile(I, J), tri_ld(I), rows_of(I), tile(I, K), tile(J, K), tri_ld(J), rows_of(J), li, kq);
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_C_WAIT);
+  }
+  return w.flag[1] == 0;
+}
+
+// z <- (H + mu C)^-1 g from the factorization: w.t1 receives z (frame-major). Poses: backward substitution through the
+// tiles of App (one barrier per tile column, wave 0 runs the chain); speed-bias: A_ss z_s = g_s - A_sp z_p with the
+// UNFACTORED coupling (the fill was never stored) through the band factor, forward (newest to oldest) and backward.
+// While wave 0 walks the band, the other waves accumulate w_f^T z_p of the landmark back-substitution into w.gnf.
+template <class WK>
+VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int nT = v.nT, n6 = v.n6, P = v.P, W = v.W, F = v.F;
+  cldsd ldp = w.ldinv + kSB * P;
+  ldsd x = w.xt;
+  auto tile = [&](int I, int J) { return w.App + tri_off(I) + 16 * J; };
+  auto piv_of = [&](int I) { return n6 - 16 * I < 16 ? n6 - 16 * I : 16; };
+  VIO_PARFOR(a, 16 * nT) x[a] = a < n6 ? w.App[tri_at(n6, a)] : 0.0;
+  VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p below
+  VIO_SYNC();
+  const int qc = lane >> 2, qp = lane & 3;  // lane = 4 c + p: the four lanes of a quad split a 16-term dot product
+  // x_K <- L_KK^-T x_K: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
+  auto solve_diag = [&](int K) {
+    auto D = tile(K, K);
+    const int ld = tri_ld(K), np_ = piv_of(K);
+    const bool ok = qc < np_;
+    const int c = ok ? qc : 0;
+    double sacc = qp == 0 ? ldp[16 * K + c] * x[16 * K + c] : 0.0;
 #pragma unroll
     for (int t4 = 0; t4 < 4; t4++) {
-      const int r = qcc + 1 + qp + 4 * t4;
-      const bool in = qok && r < kBS;
-      const double lv = D[qcc * kBS + (in ? r : qcc)], xv = x[k * kBS + (in ? r : qcc)];
+      const int r = c + 1 + qp + 4 * t4;
+      const bool in = ok && r < np_;
+      const double lv = D[c * ld + (in ? r : c)], xv = x[16 * K + (in ? r : c)];
       sacc = fma(in ? lv : 0.0, xv, sacc);
     }
     sacc = quad_sum_f64(sacc);
     __builtin_amdgcn_wave_barrier();
-    if (qok && qp == 0) x[k * kBS + qc] = sacc;
+    if (ok && qp == 0) x[16 * K + qc] = sacc;
   };
-  auto apply_quad = [&](int k, int j) {  // y_j[c] -= (L_kj^T x_k)[c], c = lane >> 2
-    auto Lkj = w.Hm + blk_off(k, j);
+  // x_J[c] -= (L_KJ^T x_K)[c], rows of tile (K, J) that are pivots
+  auto apply = [&](int K, int J) {
+    auto Lt = tile(K, J);
+    const int ld = tri_ld(K), np_ = piv_of(K);
     double sacc = 0.0;
 #pragma unroll
     for (int t4 = 0; t4 < 4; t4++) {
       const int m = qp + 4 * t4;
-      const bool in = m < kBS;
-      const double lv = Lkj[(in ? m : 0) * kBS + qcc], xv = x[k * kBS + (in ? m : 0)];
+      const bool in = m < np_;
+      const double lv = Lt[(in ? m : 0) * ld + qc], xv = x[16 * K + (in ? m : 0)];
       sacc = fma(in ? lv : 0.0, xv, sacc);
     }
     sacc = quad_sum_f64(sacc);
-    if (qok && qp == 0) x[j * kBS + qc] -= sacc;
+    if (qp == 0) x[16 * J + qc] -= sacc;
   };
-  if (wave == 0) solve_diag(nb - 1);
+  if (wave == 0) solve_diag(nT - 1);
   VIO_SYNC();
-  for (int k = nb - 1; k >= 1; k--) {
+  for (int K = nT - 1; K >= 1; K--) {
     if (wave == 0) {
-      apply_quad(k, k - 1);
+      apply(K, K - 1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      solve_diag(k - 1);
+      solve_diag(K - 1);
     } else {
-      const int nwv = (int)cx.nt >> 6;
-      for (int j = wave - 1; j < k - 1; j += nwv - 1) apply_quad(k, j);  // one block per wave at a time
+      for (int J = wave - 1; J < K - 1; J += nw - 1) apply(K, J);
     }
     VIO_SYNC();
   }
-#endif
-}
-
-// q(v) = v^T (S H S + mu D^2) v = (S v)^T (H + mu C) (S v) through the factorization of the unscaled system
-// (build_reduced_system): with u = S v, sum_f E_f (u_f + w_f^T u_p / E_f)^2 + |L^T u_p|^2.
-// Both mat-vecs are split into many short items that add into LDS accumulators: w.tf (F) and w.t1 (np) are free at
-// both call sites (the back-substitution has consumed them; the next build_reduced_system rewrites them).
-template <class WK>
-VIO_DEV double quad_form(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf) {
-  const int np = v.np, F = v.F, n6 = v.npose6;
-  VIO_PARFOR(f, F) w.tf[f] = 0.0;
-  VIO_PARFOR(j, v.nblk * kBS) w.t1[j] = 0.0;
+  // z_p -> t1 (pose components), t_s = g_s - A_sp z_p -> t1 (speed-bias components)
+  VIO_PARFOR(a, n6) w.t1[kBS * (a / 6) + a % 6] = x[a];
+  VIO_PARFOR(q, P * kSB) {
+    const int k = q / kSB, c = q - k * kSB;
+    const double *A = v.Asp + ((size_t)k * kSB + c) * v.jp;
+    double sacc = w.gp[kBS * k + 6 + c];
+    for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) sacc = fma(-A[j], x[j], sacc);
+    w.t1[kBS * k + 6 + c] = sacc;
+  }
   VIO_SYNC();
-  int nparts, per;
-  wt_parts((int)cx.nt, F, n6, nparts, per);
-  VIO_PARFOR(q, F * nparts) {  // u_f += sum_{a in part} WT[a][f] vp[a]
-    const int part = q / F, f = q - part * F;
-    const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
-    double x[kWStrip], s = 0;
-    for (int b0 = a0; b0 < a1; b0 += kWStrip) {
-      const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
-      wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, x);  // the lane's own contiguous strip of the feature-major W
+  stamp(cx, ST_BACKSOLVE);
+  if (wave == 0) {
+    // band: u_k = L_k^-1 (t_k - E_{k+1} u_{k+1}), k = W..0; then z_k = L_k^-T (u_k - E_k^T z_{k-1}), k = 0..W.
+    // lane = 4 n + p; the value of row n is complete in the four lanes of its quad
+    const bool ok = qc < kSB;
+    const int n = ok ? qc : 0;
+    for (int k = W; k >= 0; k--) {
+      ldsd tk = w.t1 + kBS * k + 6;
+      cldsd D = w.Dss + k * kSS;
+      double val = qp == 0 ? tk[n] : 0.0;
+      if (k < W) {
+        cldsd E = w.Css + (k + 1) * kSS + n * kSB, un = w.t1 + kBS * (k + 1) + 6;  // row n of E_{k+1}: s_k[n] x s_{k+1}
 #pragma unroll
-      for (int j = 0; j < kWStrip; j++) {
-        const int a = b0 + (j < nb ? j : 0), i = kBS * (a / 6) + a % 6;
-        s += (j < nb ? x[j] : 0.0) * (w.sp[i] * vp[i]);
+        for (int t4 = 0; t4 < 3; t4++) {
+          const int m = qp + 4 * t4;
+          const bool in = m < kSB;
+          val = fma(in ? -E[in ? m : 0] : 0.0, un[in ? m : 0], val);
+        }
       }
-    }
-    VIO_ATOMIC_ADD(w.tf + f, s);
-  }
-  stamp(cx, ST_Q_W);
-  const int nblocks = v.nblk * (v.nblk + 1) / 2;
-  VIO_PARFOR(q, nblocks * kBS) {  // (L^T v)_j += sum_r L_(bi,bj)[r][c] v[15 bi + r]
-    const int blk = q / kBS, c = q - blk * kBS;
-    const int bij = w.blk_ij[blk], bi = bij >> 8, bj = bij & 255;
-    auto B = w.Hm + (size_t)blk * kBB;
-    double s = 0;
+      val = quad_sum_f64(val);
+      __builtin_amdgcn_wave_barrier();
+      if (ok && qp == 0) tk[n] = val;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // u[n] = v[n] / L_nn + sum_{m < n} Linv[n][m] v[m], Linv[n][m] at D[m][n]
+      double u = qp == 0 ? w.ldinv[kSB * k + n] * tk[n] : 0.0;
 #pragma unroll
-    for (int r = 0; r < kBS; r++) {
-      const int i = bi * kBS + r;
-      // diagonal blocks keep L^-1 above the diagonal (cholesky_blocks): only r >= c belongs to L
-      if (i < np && (bi != bj || r >= c)) s += B[r * kBS + c] * (w.sp[i] * vp[i]);
+      for (int t4 = 0; t4 < 3; t4++) {
+        const int m = qp + 4 * t4;
+        const bool in = ok && m < n;
+        u = fma(in ? D[(in ? m : 0) * kSB + n] : 0.0, tk[in ? m : 0], u);
+      }
+      u = quad_sum_f64(u);
+      __builtin_amdgcn_wave_barrier();
+      if (ok && qp == 0) tk[n] = u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    VIO_ATOMIC_ADD(w.t1 + bj * kBS + c, s);
+    for (int k = 0; k <= W; k++) {
+      ldsd tk = w.t1 + kBS * k + 6;
+      cldsd D = w.Dss + k * kSS;
+      double val = qp == 0 ? tk[n] : 0.0;
+      if (k >= 1) {
+        cldsd E = w.Css + k * kSS, zp = w.t1 + kBS * (k - 1) + 6;  // (E_k^T z_{k-1})[n] = sum_m E_k[m][n] z_{k-1}[m]
+#pragma unroll
+        for (int t4 = 0; t4 < 3; t4++) {
+          const int m = qp + 4 * t4;
+          const bool in = m < kSB;
+          val = fma(in ? -E[(in ? m : 0) * kSB + n] : 0.0, zp[in ? m : 0], val);
+        }
+      }
+      val = quad_sum_f64(val);
+      __builtin_amdgcn_wave_barrier();
+      if (ok && qp == 0) tk[n] = val;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // z[n] = v[n] / L_nn + sum_{r > n} Linv[r][n] v[r], Linv[r][n] at D[n][r]
+      double z = qp == 0 ? w.ldinv[kSB * k + n] * tk[n] : 0.0;
+#pragma unroll
+      for (int t4 = 0; t4 < 3; t4++) {
+        const int r = n + 1 + qp + 4 * t4;
+        const bool in = ok && r < kSB;
+        z = fma(in ? D[n * kSB + (in ? r : n)] : 0.0, tk[in ? r : n], z);
+      }
+      z = quad_sum_f64(z);
+      __builtin_amdgcn_wave_barrier();
+      if (ok && qp == 0) tk[n] = z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else {
+    // landmark back-substitution, first half: w_f^T z_p over (feature, part) items by the waves that do not walk the band
+    int nparts, per;
+    wt_parts((int)cx.nt - 64, F, n6, nparts, per);
+    for (int q = tid_ - 64; q < F * nparts; q += (int)cx.nt - 64) {
+      const int part = q / F, f = q - part * F;
+      const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
+      double xs[kWStrip], sacc = 0;
+      for (int b0 = a0; b0 < a1; b0 += kWStrip) {
+        const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
+        wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, xs);  // the lane's own contiguous strip of the feature-major W
+#pragma unroll
+        for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? xs[j] : 0.0) * x[b0 + (j < nb ? j : 0)];
+      }
+      VIO_ATOMIC_ADD(w.gnf + f, sacc);
+    }
   }
   VIO_SYNC();
-  double acc = 0;
-  VIO_PARFOR(f, F) {
-    double u = w.sf[f] * vf[f] + w.tf[f] * w.einv[f];
-    acc += w.ef[f] * u * u;
-  }
-  VIO_PARFOR(j, np) acc += w.t1[j] * w.t1[j];
-  return block_sum(cx, acc);
 }
 
 // PoseLocalParameterization::Plus on all blocks: c = x [+] (delta_p, delta_f)
@@ -2033,7 +2149,8 @@ VIO_DEV void state_norms(const Ctx &cx, const WinView &v, cldsd apose, cldsd asb
 // =====================================================================================================
 // TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
 // =====================================================================================================
-template <class WK>
+// REGS: the pose matrix has at most kPanelTiles tile rows (the launcher's LDS variant): fill tiles in registers
+template <bool REGS, class WK>
 VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   const int np = v.np, F = v.F;
   double *sd = v.stats_d;
@@ -2059,8 +2176,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
 
   double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, false);
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
-  VIO_PARFOR(i, np) w.sp[i] = rcp_f(1.0 + sqrt_f(w.hdiag[i]));  // Jacobi scaling, :239-254
-  VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f]));
+  VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f]));  // Jacobi scaling, :239-254 (poses: at the end of evaluate)
   VIO_SYNC();
   double gmax = grad_max_norm();
   double radius = 1e4, mu = 1e-8;
@@ -2084,11 +2200,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       reuse = true;
       double part = 0;
       VIO_PARFOR(i, np) {
-        double c = fmin(fmax(w.sp[i] * w.sp[i] * w.hdiag[i], 1e-6), 1e32);
-        double d = sqrt_f(c);
-        w.dp[i] = d;
-        double g = w.sp[i] * w.gp[i] * rsqrt_f(c);
-        w.gdp[i] = g;
+        const double g = pose_gd(w, i);
         part += g * g;
       }
       VIO_PARFOR(f, F) {
@@ -2096,6 +2208,17 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         part += g * g;
       }
       gd_sq = block_sum(cx, part);
+      // Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192). |J_s a|^2 = u^T H u is taken from
+      // the unfactored system, i.e. before the linear solve consumes it (it does not depend on mu).
+      auto cauchy_direction = [&]() {  // a = D^-2 S g -> t2 (poses), stf (landmarks)
+        VIO_PARFOR(i, np) w.t2[i] = pose_gd(w, i) * rcp_f(w.dp[i]);
+        VIO_PARFOR(f, F) w.stf[f] = w.sf[f] * w.gf[f] * rcp_f(feat_d2(w, f));
+        VIO_SYNC();
+      };
+      cauchy_direction();
+      stamp(cx, ST_DOGLEG);
+      const double qf_h = quad_form_H(cx, v, w, w.t2, w.stf);
+      stamp(cx, ST_QUADFORM);
       // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
       solver_ok = false;
       bool first_try = true;
@@ -2103,47 +2226,22 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
           evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+          cauchy_direction();  // (stf doubles as an accumulator of the Jacobian evaluation)
         }
         first_try = false;
-        if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0;
+        if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;
         VIO_SYNC();
         bool ok = build_reduced_system(cx, v, w, mu);
         if (ok) {
-#ifndef VIO_EMUL
-          if constexpr (std::is_same<decltype(w.Hm), double *>::value)
-            ok = w.panel ? cholesky_blocks_panel(cx, v, w, w.t1) : cholesky_blocks(cx, v, w, w.t1);
-          else
-#endif
-            ok = cholesky_blocks(cx, v, w, w.t1);
+          if constexpr (REGS) ok = factor_band_regs<kPanelTiles>(cx, v, w);
+          else ok = factor_band_lds(cx, v, w);
         }
+        if (ok) ok = factor_poses(cx, v, w);
         stamp(cx, ST_CHOL);
         if (ok) {
-          cholesky_backsolve(cx, v, w, w.t1);  // y_p
-          stamp(cx, ST_BACKSOLVE);
+          backsolve(cx, v, w);  // z -> t1, w_f^T z_p -> gnf
           // back-substitute features: z_f = (g_f - w_f^T z_p) / E_f ; y = z / s ; GN = -d * y
           double bad = 0;
-          VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p from the (feature, part) items
-          VIO_SYNC();
-          {
-            int nparts, per;
-            wt_parts((int)cx.nt, F, v.npose6, nparts, per);
-            VIO_PARFOR(q, F * nparts) {
-              const int part = q / F, f = q - part * F;
-              const int a0 = part * per, a1 = a0 + per < v.npose6 ? a0 + per : v.npose6;
-              double x[kWStrip], s = 0;
-              for (int b0 = a0; b0 < a1; b0 += kWStrip) {
-                const int nb = a1 - b0 < kWStrip ? a1 - b0 : kWStrip;
-                wt_strip_load(v.WTf + (size_t)f * v.n6cap + b0, 1, nb, x);  // the lane's own contiguous strip of the feature-major W
-#pragma unroll
-                for (int j = 0; j < kWStrip; j++) {
-                  const int a = b0 + (j < nb ? j : 0);
-                  s += (j < nb ? x[j] : 0.0) * w.t1[kBS * (a / 6) + a % 6];
-                }
-              }
-              VIO_ATOMIC_ADD(w.gnf + f, s);
-            }
-          }
-          VIO_SYNC();
           VIO_PARFOR(f, F) {
             double y = (w.tf[f] - w.gnf[f] * w.einv[f]) * rcp_f(w.sf[f]);
             w.gnf[f] = -feat_d(w, f) * y;
@@ -2161,25 +2259,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         mu *= mu_inc;
       }
       if (solver_ok) {
-        // Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192)
-        double part2 = 0;
-        VIO_PARFOR(i, np) {
-          double u = w.gdp[i] * rcp_f(w.dp[i]);
-          w.t2[i] = u;
-          part2 += mu_used * w.dp[i] * w.dp[i] * u * u;
-        }
-        VIO_PARFOR(f, F) {
-          const double d2 = feat_d2(w, f);
-          double u = w.sf[f] * w.gf[f] * rcp_f(d2);
-          w.stf[f] = u;
-          part2 += mu_used * d2 * u * u;
-        }
-        VIO_SYNC();
-        double reg = block_sum(cx, part2);
+        double part2 = 0;  // mu |D a|^2 of the Cauchy direction a (t2, stf) for the mu the solve ended with
+        VIO_PARFOR(i, np) part2 += mu_used * w.dp[i] * w.dp[i] * w.t2[i] * w.t2[i];
+        VIO_PARFOR(f, F) part2 += mu_used * feat_d2(w, f) * w.stf[f] * w.stf[f];
+        const double reg = block_sum(cx, part2);
+        qf_cauchy = qf_h + reg;
+        alpha = gd_sq / qf_h;
         stamp(cx, ST_DOGLEG);
-        qf_cauchy = quad_form(cx, v, w, w.t2, w.stf);
-        stamp(cx, ST_QUADFORM);
-        alpha = gd_sq / (qf_cauchy - reg);
       }
     }
     (void)have_factor;
@@ -2188,7 +2274,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     if (solver_ok) {
       // ComputeTraditionalDoglegStep (dogleg_strategy.cc:199-255)
       double p1 = 0, p2 = 0;
-      VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += w.gdp[i] * w.gnp[i];
+      VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += pose_gd(w, i) * w.gnp[i];
       VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += feat_gd(w, f) * w.gnf[f];
       double pdummy = 0;
       block_sum3(cx, p1, p2, pdummy);
@@ -2212,7 +2298,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       }
       double pn = 0, psg = 0, preg = 0;
       VIO_PARFOR(i, np) {
-        double s = ca * w.gdp[i] + cb * w.gnp[i];
+        double s = ca * pose_gd(w, i) + cb * w.gnp[i];
         pn += s * s;
         double st = s * rcp_f(w.dp[i]);
         w.stp[i] = st;
@@ -2310,7 +2396,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
 // =====================================================================================================
 // Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs
 // =====================================================================================================
-template <class WK>
+template <bool REGS, class WK>
 VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   const int P = v.P, F = v.F;
   VIO_PARFOR(q, P * 7) w.xpose[q] = v.pose0[q];
@@ -2320,10 +2406,13 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   if (v.has_loop) VIO_PARFOR(q, 7) w.xpose[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
   VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
   if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
-  VIO_PARFOR(q, v.nblk * (v.nblk + 1) / 2) {
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= q) bi++;
-    w.blk_ij[q] = (bi << 8) | (q - bi * (bi + 1) / 2);
+  // columns of the speed-bias x pose coupling that the factors can fill: the IMU chain reaches the poses of the frame
+  // and of both neighbours, a speed-bias block kept by the prior reaches every pose the prior holds
+  VIO_PARFOR(k, P) {
+    int lo = 6 * (k > 0 ? k - 1 : 0), hi = 6 * (k + 2 < P ? k + 2 : P);
+    for (int b = 0; b < v.prior_nb; b++)
+      if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, hi = 6 * P;
+    w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = hi;
   }
   VIO_SYNC();
 #ifndef VIO_EMUL
@@ -2337,12 +2426,12 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   VIO_SYNC();
   VIO_PARFOR(k, v.M) v.sfact[v.fslot[k]] = k;
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
-  setup_imu_info(cx, v, w.Hm);
+  setup_imu_info(cx, v, w.App);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, v, w);
   stamp(cx, ST_SETUP_PRIOR);
 
-  minimize(cx, v, w);
+  minimize<REGS>(cx, v, w);
 
   VIO_PARFOR(q, P * 7) v.raw_pose[q] = w.xpose[q];
   VIO_PARFOR(q, P * 9) v.raw_sb[q] = w.xsb[q];
@@ -2387,5 +2476,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   VIO_SYNC();
   stamp(cx, ST_NEW2OLD);
 }
+
+#endif  // !VIO_EMUL
 
 }  // namespace vio

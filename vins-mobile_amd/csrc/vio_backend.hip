@@ -1,9 +1,11 @@
 // vio_backend.hip — gfx950 kernels and C ABI of the sliding-window back-end (include/vio_amd.h).
 //
-// One workgroup (512 threads = 8 wave64) owns one window for the whole of VINS::solve_ceres
-// (VINS_ios/VINS.cpp:480-831): solve, new2old, marginalization. The reduced 15(W+1) system lives in LDS
-// (119 KB of the CU's 160 KB at W = 10); the batch of independent sequences is the grid, so a launch of >= 256
-// windows fills the chip and each XCD's L2 only ever sees its own windows' scratch.
+// One workgroup owns one window for the whole of VINS::solve_ceres (VINS_ios/VINS.cpp:480-831): solve, new2old,
+// marginalization. At W <= 12 the reduced system (pose matrix 22 KB + speed-bias band 14 KB, solver_core.h) and every
+// vector of the solve fit in 80 KB of LDS: 256 threads (4 wave64) per window, TWO windows resident per CU, so that one
+// window's serial pivot chains run in the shadow of the other's parallel phases. The batch of independent sequences
+// is the grid: a launch of >= 512 windows fills the chip and each XCD's L2 only ever sees its own windows' scratch.
+// Larger windows keep the pose matrix in global scratch and take a CU each (512 threads).
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
@@ -24,8 +26,9 @@ using namespace vio;
 
 namespace {
 
-constexpr int kThreads = 512;
-constexpr size_t kLdsLimit = vio::kLdsBytes;
+constexpr int kThreadsLds = 256, kThreadsGlb = 512;
+constexpr size_t kLdsLimit = vio::kLdsBytes;      // one CU
+constexpr size_t kLdsHalf = vio::kLdsBytes / 2;   // two resident workgroups per CU
 
 struct MargPtrs {
   int *ints;        // [n][4 + 3 * kMaxPriorBlocks]
@@ -37,8 +40,10 @@ struct MargPtrs {
   long long *prof;  // [n][ST_COUNT] or null
 };
 
-template <bool LDS_MATRIX>
-__global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
+// NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
+// 512-thread workgroup per CU)
+template <bool LDS_MATRIX, int NT>
+__global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
   WinView v = make_view(B, b);
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void vio_window_kernel(BatchPtrs B, MargP
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
   cx.red = cw.red, cx.lprof = cw.lprof;
   const size_t state_end = cw.state_end_doubles;
-  solve_window(cx, v, w);
+  solve_window<LDS_MATRIX>(cx, v, w);
 
   MargOut mo;
   int *mi = MP.ints + (size_t)b * MP.s_ints;
@@ -138,6 +143,7 @@ struct vio_backend {
   HostVec<int> h_order;
   bool profile = false;
   size_t lds_bytes = 0;
+  int threads_lds = kThreadsLds;
   DevBuf<long long> d_prof;
   HostBatch hb;
   BatchPtrs B;
@@ -193,8 +199,9 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
   // the dynamic-LDS ceiling is a property of the FUNCTION, not of a launch: raised once to the CU's whole LDS for both
   // variants (several contexts on several host threads launch these kernels; a per-launch value could be lowered by
   // another thread between this thread's set and its launch)
-  if (hipFuncSetAttribute((const void *)vio_window_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+  if (hipFuncSetAttribute((const void *)vio_window_kernel<true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
     delete be;
     return VIO_ENODEV;
   }
@@ -338,24 +345,27 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   }
   const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
-  // LDS or global matrix, per window: both phases must fit the CU's 160 KB. Windows without a relocalization pose are
-  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum, no loop block row)
-  // fits runs the LDS variant in one launch, everything else the global-matrix variant in a second one.
-  auto fits_lds = [&](const BatchDims &dd) {
+  // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
+  // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
+  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
+  // variant in one launch -- with half a CU's LDS per workgroup whenever that is enough, so that two windows share a
+  // CU --, everything else the global-matrix variant in a second one.
+  static const int threads_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
+  be->threads_lds = threads_lds;
+  auto need_lds = [&](const BatchDims &dd) {
     size_t se = 0;
-    const size_t bs = carve_work<ldsd>(dd, true, kThreads, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
     const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
-    // the marginalization phase additionally wants >= 64 staging slots behind its dense matrix
-    return std::max(bs, bm + 64 * kMargSlot * sizeof(double)) <= kLdsLimit;
+    // the marginalization phase additionally wants >= 64 staging slots behind its matrix
+    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
   };
+  auto fits_lds = [&](const BatchDims &dd) { return pose_jp(dd) <= 16 * kPanelTiles && need_lds(dd) <= kLdsLimit; };
   std::vector<int> cand, order;
-  for (int b = 0; b < n; b++)
-    if (!be->hb.hdr[(size_t)b * kHdrInts + H_HAS_LOOP]) cand.push_back(b);
+  for (int b = 0; b < n; b++) cand.push_back(b);
   std::sort(cand.begin(), cand.end(), [&](int a, int b2) {
     return be->hb.hdr[(size_t)a * kHdrInts + H_F] < be->hb.hdr[(size_t)b2 * kHdrInts + H_F];
   });
   BatchDims dl = d;
-  dl.nblk_cap = dl.Pcap;
   int n_lds = (int)cand.size();
   while (n_lds > 0) {
     dl.Flds = std::max(1, be->hb.hdr[(size_t)cand[n_lds - 1] * kHdrInts + H_F]);
@@ -367,14 +377,17 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   for (int b = 0; b < n; b++)
     if (!in_lds[b]) order.push_back(b);
   be->n_lds = n_lds, be->n_glb = n - n_lds, be->d_lds = dl, be->lds_matrix = be->n_glb == 0;
-  be->lds_bytes = kLdsLimit;  // the marginalization phase stages Jacobian rows in whatever LDS is left: whole CU budget
+  // the marginalization phase stages Jacobian rows in whatever LDS is left: half a CU when the layout fits it (two
+  // workgroups per CU), else the whole CU
+  static const bool one_per_cu = getenv("VIO_AMD_WINDOW_ONE_PER_CU") && getenv("VIO_AMD_WINDOW_ONE_PER_CU")[0] == '1';
+  be->lds_bytes = (n_lds > 0 && need_lds(dl) <= kLdsHalf && !one_per_cu) ? kLdsHalf : kLdsLimit;
   if (be->n_glb > 0) {
     BatchDims dg = d;
     int fg = 1;
     for (int i = n_lds; i < n; i++) fg = std::max(fg, be->hb.hdr[(size_t)order[i] * kHdrInts + H_F]);
     dg.Flds = fg;
     size_t se = 0;
-    const size_t bs = carve_work<double *>(dg, false, kThreads, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
     const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
     if (std::max(bs, bm) > kLdsLimit) return VIO_ECAP;
     be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bm);
@@ -505,13 +518,17 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    hipLaunchKernelGGL(vio_window_kernel<true>, dim3(be->n_lds), dim3(kThreads), be->lds_bytes, st, Bl, be->MP,
-                       (int)(be->lds_bytes / sizeof(double)));
+    if (be->threads_lds == kThreadsLds)
+      hipLaunchKernelGGL((vio_window_kernel<true, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
+                         (int)(be->lds_bytes / sizeof(double)));
+    else
+      hipLaunchKernelGGL((vio_window_kernel<true, kThreadsGlb>), dim3(be->n_lds), dim3(kThreadsGlb), be->lds_bytes, st, Bl, be->MP,
+                         (int)(be->lds_bytes / sizeof(double)));
   }
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
     Bg.d = be->d_glb, Bg.order = be->d_order.p + be->n_lds;
-    hipLaunchKernelGGL(vio_window_kernel<false>, dim3(be->n_glb), dim3(kThreads), be->lds_bytes_glb, st, Bg, be->MP,
+    hipLaunchKernelGGL((vio_window_kernel<false, kThreadsGlb>), dim3(be->n_glb), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
                        (int)(be->lds_bytes_glb / sizeof(double)));
   }
   HIP_OK(hipGetLastError());
