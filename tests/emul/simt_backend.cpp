@@ -18,6 +18,7 @@ using namespace vio;
 // launcher would pick. Returns VIO_ECAP when the requested variant does not fit the CU's LDS.
 extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveStats *stats, int nthreads, int variant,
                                  int order) {
+  if (nthreads != 256 && nthreads != 512) return VIO_EINVAL;
   bool any_loop = false;
   for (int k = 0; k < win->n_factors; k++)
     if (win->factor_target[k] == win->window_size + 1) any_loop = true;
@@ -72,14 +73,16 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   // the body of vio_window_kernel (vio_backend.hip), one fiber per work-item
   simt::launch(nthreads, [&](int tid) {
     WinView v = make_view(B, 0);
-    const Carved<double *> cw = carve_all<double *>(B.d, lds_matrix, nthreads, lds.data(), hm.data());
+    const Carved<double *> cw = carve_all<double *>(B.d, lds_matrix, nthreads, lds.data(), hm.data(), v.AspG);
     WorkT<double *> w = cw.w;
     Ctx cx;
     cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr;
     cx.red = cw.red, cx.lprof = cw.lprof;
     const size_t state_end = cw.state_end_doubles;
-    if (lds_matrix) solve_window<true>(cx, v, w);
-    else solve_window<false>(cx, v, w);
+    if (lds_matrix && nthreads == 256) solve_window<true, 4>(cx, v, w);
+    else if (lds_matrix) solve_window<true, 8>(cx, v, w);
+    else if (nthreads == 256) solve_window<false, 4>(cx, v, w);
+    else solve_window<false, 8>(cx, v, w);
     MargWorkT<double *> mw = carve_marg_all<double *>(B.d, lds_matrix, lds.data() + state_end, mo.scratch, lds_doubles - state_end).m;
     __syncthreads();
     marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);

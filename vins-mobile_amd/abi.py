@@ -22,7 +22,7 @@ VIO_MARGIN_OLD, VIO_MARGIN_SECOND_NEW, VIO_MARGIN_NONE = 0, 1, 2
 STAGES = ["setup_imu", "setup_prior", "eval_prior", "eval_imu", "eval_proj", "scale", "schur", "rhs", "cholesky",
           "tri_solve", "quad_form", "dogleg", "cost_eval", "new2old", "marg_build", "marg_chol", "total",
           "p_zero", "p_fact", "p_gram", "p_feat", "c_potrf", "c_trsm", "imu_raw", "c_wait", "q_w", "backsolve",
-          "c_ahead", "tr_vec", "m_prior", "m_imu", "m_fact", "m_gram"]
+          "c_ahead", "tr_vec", "m_prior", "m_imu", "m_fact", "m_gram", "d0", "d1", "d2", "d3", "d4", "d5"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

@@ -60,7 +60,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -82,7 +82,8 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
   s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
-  s.s_Asp = o, o += (size_t)d.Pcap * kSB * pose_jp(d);
+  s.s_Asp = o, o += (size_t)kSB * pose_jp(d);  // the prior's speed-bias x pose block
+  s.s_AspG = o, o += (size_t)d.Pcap * kAS;
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -150,7 +151,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
-  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Asp = sc + B.s.s_Asp, v.Vsave = nullptr;
+  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
@@ -191,7 +192,7 @@ struct Carved {
 };
 
 template <class MP>
-VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global) {
+VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global, double *asp_global = nullptr) {
   Carved<MP> c;
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // pose-side vector length (frame-major; the loop pose uses 6 of its 15)
@@ -215,21 +216,28 @@ VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, l
   ldsd app = nullptr;
   if (lds_matrix) app = take(napp);
   w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
-  w.Dss = take(2 * (size_t)d.Pcap * kSS + 16), w.Css = w.Dss + (size_t)d.Pcap * kSS;
+  w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
+  ldsd aspi = lds_matrix ? take((size_t)d.Pcap * kAS + 16) : nullptr;
+  w.AspI = MatPick<MP>::get(lds_matrix, aspi, asp_global);
   w.nstage = lds_matrix ? (int)(o - o_mat) : (int)napp;
-  w.cpose = take(7 * (size_t)(d.Pcap + 1)), w.csb = take(9 * (size_t)d.Pcap), w.cfeat = take(F);
-  w.gp = take(npc), w.gf = take(F), w.sp = take(npc), w.sf = take(F), w.dp = take(npc);
-  w.gnp = take(npc), w.gnf = take(F), w.stf = take(F);
-  w.hff = take(F), w.ef = take(F), w.einv = take(F);
+  w.cfeat = take(F);
+  w.gf = take(F), w.sf = take(F), w.gnf = take(F), w.stf = take(F), w.hff = take(F), w.einv = take(F), w.tf = take(F);
+  w.gp = take(npc), w.sp = take(npc), w.dp = take(npc);
+  // Aliases. While the Jacobians are evaluated the candidate pose / speed-bias and the Gauss-Newton step are dead: the
+  // sixth accumulator of the landmarks' host-frame coupling (ef) uses their place (when it is large enough). t1 (the
+  // solution of the linear solve), t2, the pose-index work vector and the pivot reciprocals are dead then as well: the
+  // diagonal pose blocks of the projection Gram products (ppd, 36 per frame) accumulate there. The trust-region step
+  // is formed after the solution has been consumed: it shares t1.
+  const size_t o_ef = o;
+  w.cpose = take(7 * (size_t)(d.Pcap + 1)), w.csb = take(9 * (size_t)d.Pcap), w.gnp = take(npc);
+  w.ef = (o - o_ef >= F) ? w.cpose : take(F);
   const size_t jp = (6 * (size_t)d.nblk_cap + 1 + 15) / 16 * 16;
-  w.ldinv = take((size_t)d.Pcap * kSB + jp);
-  // stp, t1, t2 are dead while the Jacobians are evaluated: the diagonal pose blocks of the projection Gram products
-  // (ppd, 36 per frame <= 3 x 15 per frame) accumulate in their place
-  const size_t npe = (npc + 1) & ~(size_t)1, nppd = 36 * (size_t)(d.Pcap + 1);
-  w.stp = take(npc), w.t1 = take(npc), w.t2 = take(nppd > 3 * npe ? nppd - 2 * npe : npc);
-  w.ppd = w.stp;
-  w.xt = take(jp);
-  w.tf = take(F), w.prdx = take(d.Ncap), w.prr = take(d.Ncap);
+  const size_t o_ppd = o;
+  w.t1 = take(npc), w.t2 = take(npc), w.xt = take(jp), w.ldinv = take((size_t)d.Pcap * kSB + jp);
+  w.stp = w.t1;
+  w.ppd = w.t1;
+  if (o - o_ppd < 36 * (size_t)(d.Pcap + 1)) (void)take(36 * (size_t)(d.Pcap + 1) - (o - o_ppd));
+  w.prdx = take(d.Ncap), w.prr = take(d.Ncap);
   w.prcol = reinterpret_cast<ldsi>(take(((size_t)d.Ncap + 1) / 2 + 1));
   w.sbr = reinterpret_cast<ldsi>(take((size_t)d.Pcap + 1));
   w.flag = reinterpret_cast<ldsi>(take(2));
@@ -432,13 +440,14 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
       if (kind < 0 || kind > 2 || idx < 0 || idx >= P || o < 0 || o + ls > p->n) return VIO_EINVAL;
       hb.pr_kind[b * s.pr_int + k] = kind, hb.pr_index[b * s.pr_int + k] = idx, hb.pr_offset[b * s.pr_int + k] = o;
     }
-    // the reduced system stores speed-bias blocks as a block-tridiagonal band (solver_core.h): a prior that couples
-    // speed-bias blocks more than one frame apart has no slot there (no prior made by marginalize() does: it keeps one)
-    for (int k = 0; k < p->n_blocks; k++)
-      for (int k2 = 0; k2 < k; k2++)
-        if (p->block_kind[k] == VIO_BLOCK_SPEEDBIAS && p->block_kind[k2] == VIO_BLOCK_SPEEDBIAS &&
-            std::abs(p->block_index[k] - p->block_index[k2]) > 1)
-          return VIO_EINVAL;
+    // the reduced system keeps the speed-bias x pose coupling of the IMU chain in a compact band and ONE dense row block
+    // for the prior (solver_core.h): a prior with more than one speed-bias block has no slot there (no prior made by
+    // marginalize() has: it keeps the speed-bias of the new oldest frame only, marginalization_factor.cpp:182-300)
+    {
+      int nsb = 0;
+      for (int k = 0; k < p->n_blocks; k++) nsb += p->block_kind[k] == VIO_BLOCK_SPEEDBIAS;
+      if (nsb > 1) return VIO_EINVAL;
+    }
     h[H_PRIOR_N] = p->n, h[H_PRIOR_NB] = p->n_blocks;
     if (!in_store) {
       memcpy(&hb.pr_x0[b * s.pr_x0], p->block_x0, sizeof(double) * 9 * p->n_blocks);

@@ -49,8 +49,21 @@
 #endif
 #if defined(VIO_EMUL)
 #define VIO_SYNC() ((void)0)
+#define VIO_SYNC_LDS() ((void)0)
+#elif defined(VIO_SIMT)
+#define VIO_SYNC() __syncthreads()
+#define VIO_SYNC_LDS() __syncthreads()
 #else
 #define VIO_SYNC() __syncthreads()
+// Workgroup barrier that only orders LDS traffic: __syncthreads() waits for every outstanding memory operation of the
+// wave (s_waitcnt vmcnt(0)), which puts an L2 round trip behind each barrier a global prefetch is meant to cross.
+// ONLY where the waves exchange nothing through global memory across the barrier.
+#define VIO_SYNC_LDS()                                                      \
+  do {                                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");         \
+    __builtin_amdgcn_s_barrier();                                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");         \
+  } while (0)
 #endif
 // The thread index every phase starts from passes through an empty asm: LLVM otherwise hoists the per-lane address
 // arithmetic of ALL phases out of the trust-region loop (loop-invariant), keeps hundreds of values alive across the whole
@@ -61,6 +74,13 @@
 #define VIO_TID(cx) ::vio::opaque_tid((int)(cx).tid)
 #endif
 #define VIO_PARFOR(i, n) for (int i = VIO_TID(cx); i < (int)(n); i += (int)cx.nt)
+// The same for any per-lane value inside a loop: per-lane addresses that do not depend on the loop counter (the 60 tile
+// offsets of a panel step, say) are otherwise computed once, kept alive around the loop and come back as scratch loads.
+#ifdef VIO_HOST_BUILD
+#define VIO_OPAQUE(x) (x)
+#else
+#define VIO_OPAQUE(x) ::vio::opaque_tid(x)
+#endif
 
 // LDS pointers carry their address space in the type: generic pointers make hipcc emit flat_load/flat_store for every
 // LDS access (no ds_read/ds_write at all in the first version of this kernel), which is several times slower.
@@ -97,6 +117,8 @@ __device__ __forceinline__ void atomic_add(double *p, double v) {
 constexpr int kBS = 15;          // unknowns per frame in the pose-side vectors: pose 6 + speed-bias 9 (frame-major)
 constexpr int kSB = 9;           // speed-bias block
 constexpr int kSS = kSB * kSB;   // 81
+constexpr int kAW = 18;          // pose columns an IMU chain couples a speed-bias block to: frames k-1, k, k+1
+constexpr int kAS = kSB * kAW;   // 162
 constexpr int kPreintDoubles = 467;
 constexpr int kMaxTrace = 64;
 constexpr int kStatsDoubles = 4 + 5 * kMaxTrace;  // initial, final, (it_cost, radius, step_norm, rel, gmax)[64]
@@ -113,7 +135,8 @@ enum Stage {
   ST_C_WAIT, ST_Q_W, ST_BACKSOLVE, ST_C_AHEAD,     // trailing-update wait, W part of quad_form, back-substitution, wave-0 look-ahead
   ST_TR_VEC,                                       // trust-region vector phase before the linear solve
   ST_M_PRIOR, ST_M_IMU, ST_M_FACT, ST_M_GRAM,      // marginalization: prior/setup, IMU factor, factor staging, Gram
-  ST_COUNT = 34                                    // (last slot = time of the previous stamp)
+  ST_D0, ST_D1, ST_D2, ST_D3, ST_D4, ST_D5,         // free slots for timing experiments (VIO_AMD_PROF_TID picks the clock's lane)
+  ST_COUNT = 40                                    // (last slot = time of the previous stamp)
 };
 
 struct Ctx {
@@ -121,13 +144,14 @@ struct Ctx {
   ldsd red;           // LDS scratch for block reductions: two halves of [3 nt/64]
   mutable int red_phase = 0;  // which half the next reduction writes (uniform across the block)
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
+  int prof_tid = 0;   // the work-item that keeps the stage clock (0; another wave's first lane to time what wave 0 does not run)
   VIO_AS3 long long *lprof;  // the same counters while the kernel runs (LDS); copied to prof at the end
 };
 
 // Charges the cycles since the previous stamp to `stage` (thread 0 only; call between barriers).
 VIO_DEV void stamp(const Ctx &cx, int stage) {
 #ifndef VIO_EMUL
-  if (cx.prof && cx.tid == 0) {  // accumulators live in LDS (a global read-modify-write per stamp costs ~3k cycles)
+  if (cx.prof && cx.tid == cx.prof_tid) {  // accumulators live in LDS (a global read-modify-write per stamp costs ~3k cycles)
     long long t = clock64();
     cx.lprof[stage] += t - cx.lprof[ST_COUNT - 1];
     cx.lprof[ST_COUNT - 1] = t;
@@ -166,15 +190,15 @@ struct WinView {
   double *imu_Mr;    // [W][15]
   double *prb0;      // [n]    b0 = J0^T r0
   double *prH0;      // [n*n]  J0^T J0
-  double *Asp;       // [P][9][jp]     speed-bias x pose coupling of the UNFACTORED reduced system (IMU factors, prior): row
-                     //                c of frame k holds A(s_k[c], pose index j); only [jlo_k, jhi_k) is ever written or read
+  double *Apri;      // [9][jp]  the prior's speed-bias x pose block A(s_kpr[c], pose index j): constant during a solve (H0),
+                     //          written once by setup_prior; the IMU part of that coupling lives in LDS (WorkT::AspI)
   int n6, nrows, nT, jp;  // pose unknowns 6 (P + has_loop); rows of the pose matrix (n6 + the carried right-hand side);
                           // its 16-row tiles; leading dimension of Asp rows (16 nT)
   double *WT;        // [npose6][Fpad]  pose-major landmark coupling: the marginalization phase only (marg_core.h)
   double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
-  double *Vsave;     // unused by the solver (reserved)
+  double *AspG;      // [P][9][18] the IMU part of the speed-bias x pose coupling when the pose matrix is global (WorkT::AspI)
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
   double *stats_d;
@@ -197,17 +221,21 @@ struct WinView {
 //   Dss   [P][9][9]  diagonal speed-bias blocks (lower triangle read); factored: L below / on, L^-1 transposed above the
 //         diagonal, 1 / L_cc in ldinv
 //   Css   [P][9][9]  Css[k] = A(s_{k-1}, s_k), k >= 1; factored: E_k = L(s_{k-1}, s_k)
-//   Asp   (global, WinView) [P][9][jp]  A(s_k[c], pose index j) of the UNFACTORED system, columns [jlo_k, jhi_k) only
+//   AspI  [P][9][18]  A(s_k[c], pose index alo_k + jj), alo_k = 6 max(k - 1, 0), of the UNFACTORED system: what the IMU
+//         chain couples a speed-bias block to (frames k-1, k, k+1). The speed-bias block the prior keeps also couples to
+//         every pose of the prior: that block is constant during a solve and stays in global memory (WinView::Apri).
 // Pose index a = 6 frame + c; the pose-side VECTORS stay frame-major (15 frame + c, speed-bias at + 6).
-VIO_HD int tri_off(int I) { return 128 * I * (I + 1); }
-VIO_HD int tri_ld(int I) { return 16 * (I + 1); }
+// (Row lengths are ODD, 16 (I + 1) + 1: the operand fetch of a matrix instruction reads 16 rows at the same column, and
+// with a row length that is a multiple of 16 doubles all of them fall into two LDS banks.)
+VIO_HD int tri_ld(int I) { return 16 * (I + 1) + 1; }
+VIO_HD int tri_off(int I) { return 128 * I * (I + 1) + 16 * I; }  // sum_{J < I} 16 (16 (J + 1) + 1)
 VIO_HD int tri_at(int r, int c) {  // c < 16 ((r >> 4) + 1)
   const int I = r >> 4;
-  return 128 * I * (I + 1) + (r & 15) * (16 * (I + 1)) + c;
+  return tri_off(I) + (r & 15) * tri_ld(I) + c;
 }
 VIO_HD size_t tri_doubles(int nrows) {
   const int nT = (nrows + 15) >> 4;
-  return (size_t)128 * (nT - 1) * nT + (size_t)(nrows - 16 * (nT - 1)) * 16 * nT;
+  return (size_t)tri_off(nT - 1) + (size_t)(nrows - 16 * (nT - 1)) * tri_ld(nT - 1);
 }
 
 // LDS (or emulated) working set; all arrays sized by the launcher from the dims. MP is the pointer type of the pose
@@ -218,6 +246,7 @@ struct WorkT {
   MP App;         // pose x pose (+ the carried right-hand side row), tile-row packed lower triangle
   int nstage;     // doubles behind App that are free whenever the reduced matrix is not assembled (Jacobian-row staging)
   ldsd Dss, Css;  // speed-bias band: P blocks of 81 each, Css = Dss + 81 P (contiguous with App when App is in LDS)
+  MP AspI;        // [P][9][18]: behind Css when the pose matrix is in LDS, else in the window's global scratch
   ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
   ldsd cpose, csb, cfeat;   // candidate
   ldsd ex;                  // 7
@@ -234,7 +263,7 @@ struct WorkT {
   ldsd tf;                  // F temporary
   ldsd prdx, prr;           // prior dx / residual: prior_n each
   ldsi prcol;               // prior column -> (frame << 8 | component 0..14) of the reduced system (-1 constant): prior_n
-  ldsi sbr;                 // [2 P]: columns [jlo_k, jhi_k) of Asp row block k that the unfactored system can fill
+  ldsi sbr;                 // [2 P]: first pose column speed-bias block k couples to; 1 if it is the block the prior keeps
   ldsi flag;                // [4] block-uniform flags
   ldsi fh;                  // F: host frame of every feature (-1: it has no factor)
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
@@ -259,9 +288,9 @@ VIO_DEV void red_put(const WinView &v, WK &w, int fr, int cr, int fc, int cc, do
     if (fr - fc > 1) return;
     if (add) VIO_ATOMIC_ADD(p, val);
     else *p = val;
-  } else {
-    double *p = cr >= 6 ? v.Asp + ((size_t)fr * kSB + (cr - 6)) * v.jp + 6 * fc + cc
-                        : v.Asp + ((size_t)fc * kSB + (cc - 6)) * v.jp + 6 * fr + cr;
+  } else {  // speed-bias x pose: the IMU chain only (the prior's part is constant: WinView::Apri)
+    const int k = cr >= 6 ? fr : fc, c = (cr >= 6 ? cr : cc) - 6, j = cr >= 6 ? 6 * fc + cc : 6 * fr + cr;
+    auto p = w.AspI + (k * kSB + c) * kAW + j - 6 * (k > 0 ? k - 1 : 0);
     if (add) VIO_ATOMIC_ADD(p, val);
     else *p = val;
   }
@@ -842,6 +871,13 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
     }
     v.prb0[a] = s;
   }
+  VIO_PARFOR(q, kSB * v.jp) v.Apri[q] = 0.0;
+  VIO_SYNC();
+  // the speed-bias x pose block of H0: constant during the solve
+  VIO_PARFOR(q, n * n) {
+    const int a = q / n, b = q - a * n, pa = w.prcol[a], pb = w.prcol[b];
+    if (pa >= 0 && pb >= 0 && (pa & 255) >= 6 && (pb & 255) < 6) v.Apri[((pa & 255) - 6) * v.jp + 6 * (pb >> 8) + (pb & 255)] = v.prH0[q];
+  }
   VIO_SYNC();
 }
 
@@ -867,27 +903,55 @@ VIO_DEV double quad_sum_f64(double v) {
 // The accumulator layout of a tile T is at the same time the B-operand layout of T over four k-steps (element r = k-step
 // r), so chains of products M1 (M2 T) never leave the registers.
 
+// Under register pressure the scheduler sinks every LDS read to its first use: a ds_read, s_waitcnt lgkmcnt(0), the
+// select that masks it, the next ds_read... -- one LDS latency (~120 cycles) per VALUE on the serial chains of the
+// factorization. The fetch helpers below therefore read raw (clamped addresses, nothing consumes the value), then a
+// scheduling fence, then mask: one latency per batch.
+#ifdef VIO_SIMT
+#define VIO_SCHED_FENCE() ((void)0)
+#else
+#define VIO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // ---- 9 x 9 speed-bias blocks (row-major, ld 9) in 16 x 16 register tiles --------------------------------------------
 // X[li][4 s + kq], zero outside the block (k-steps 0..2 cover k < 12)
-VIO_DEV void load_op9(cldsd X, int li, int kq, double out[3]) {
+VIO_DEV void load_op9_raw(cldsd X, int li, int kq, double out[3]) {
+  cldsd p = X + (li < kSB ? li : 0) * kSB + kq;
+  out[0] = p[0], out[1] = p[4], out[2] = p[kq == 0 ? 8 : 0];
+}
+VIO_DEV void mask_op9(int li, int kq, double out[3]) {
   const bool iok = li < kSB;
-  cldsd p = X + (iok ? li : 0) * kSB + kq;
-  const double x0 = p[0], x1 = p[4], x2 = p[kq == 0 ? 8 : 0];
-  out[0] = iok ? x0 : 0.0, out[1] = iok ? x1 : 0.0, out[2] = (iok && kq == 0) ? x2 : 0.0;
+  out[0] = iok ? out[0] : 0.0, out[1] = iok ? out[1] : 0.0, out[2] = (iok && kq == 0) ? out[2] : 0.0;
+}
+VIO_DEV void load_op9(cldsd X, int li, int kq, double out[3]) {
+  load_op9_raw(X, li, kq, out);
+  VIO_SCHED_FENCE();
+  mask_op9(li, kq, out);
 }
 // Linv[li][4 s + kq] of a factored diagonal block (potrf9_inv_wave): strict lower part of L^-1 transposed above the
 // diagonal (D[kk][n] = Linv[n][kk], kk < n), 1 / L_nn in ldinv_k. As A operand: Linv (.) ; as B operand: (.) L^-T.
-VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[3]) {
-  const bool iok = li < kSB;
-  const int n = iok ? li : 0;
-  const double dg = ldinv_k[n];
+VIO_DEV void load_linv9_raw(cldsd D, cldsd ldinv_k, int li, int kq, double out[4]) {
+  const int n = li < kSB ? li : 0;
+  out[3] = ldinv_k[n];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     const int kk = 4 * s + kq;
-    const bool in = iok && kk < n;
-    const double x = D[(in ? kk : 0) * kSB + n];
-    out[s] = in ? x : ((iok && kk == n) ? dg : 0.0);
+    out[s] = D[(kk < n ? kk : 0) * kSB + n];
   }
+}
+VIO_DEV void mask_linv9(int li, int kq, double out[4]) {
+  const bool iok = li < kSB;
+  const int n = iok ? li : 0;
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    const int kk = 4 * s + kq;
+    out[s] = (iok && kk < n) ? out[s] : ((iok && kk == n) ? out[3] : 0.0);
+  }
+}
+VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[4]) {
+  load_linv9_raw(D, ldinv_k, li, kq, out);
+  VIO_SCHED_FENCE();
+  mask_linv9(li, kq, out);
 }
 
 // Cholesky of one 9 x 9 diagonal block AND the inverse of its factor by one wave, entirely on the matrix cores.
@@ -901,18 +965,24 @@ VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[3]) {
 VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
+  double l[3];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = kq + 4 * r;
     const bool ok = m < kSB && n < kSB;
     const int hi = m > n ? m : n, lo = m > n ? n : m;
-    const double x = D[ok ? hi * kSB + lo : 0];
-    A[r] = ok ? x : 0.0;
+    A[r] = D[ok ? hi * kSB + lo : 0];
+  }
+  load_op9_raw(Eprev, n, kq, l);
+  VIO_SCHED_FENCE();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    A[r] = (m < kSB && n < kSB) ? A[r] : 0.0;
     E[r] = (m == n) ? 1.0 : 0.0;
   }
   if (with_update) {
-    double l[3];
-    load_op9(Eprev, n, kq, l);
+    mask_op9(n, kq, l);
 #pragma unroll
     for (int s = 0; s < 3; s++) A = mfma_f64(-l[s], l[s], A);
   }
@@ -958,25 +1028,45 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
 // ---- 16 x 16 tiles of a row-major matrix (leading dimension per tile row) -------------------------------------------
 // operand X[li][kq + 4 s]; rows >= rows are zero (the lane reads row 0 instead)
 template <class MP>
-VIO_DEV void tile_load_op(MP X, int ld, int rows, int li, int kq, double out[4]) {
+VIO_DEV void tile_load_op_raw(MP X, int ld, int rows, int li, int kq, double out[4]) {
+  auto p = X + (li < rows ? li : 0) * ld + kq;
+  out[0] = p[0], out[1] = p[4], out[2] = p[8], out[3] = p[12];
+}
+VIO_DEV void tile_mask_op(int rows, int li, double out[4]) {
   const bool ok = li < rows;
-  auto p = X + (ok ? li : 0) * ld + kq;
-  const double x0 = p[0], x1 = p[4], x2 = p[8], x3 = p[12];
-  out[0] = ok ? x0 : 0.0, out[1] = ok ? x1 : 0.0, out[2] = ok ? x2 : 0.0, out[3] = ok ? x3 : 0.0;
+  out[0] = ok ? out[0] : 0.0, out[1] = ok ? out[1] : 0.0, out[2] = ok ? out[2] : 0.0, out[3] = ok ? out[3] : 0.0;
 }
 template <class MP>
-VIO_DEV v4d tile_load_acc(MP C, int ld, int rows, int li, int kq) {
+VIO_DEV void tile_load_op(MP X, int ld, int rows, int li, int kq, double out[4]) {
+  tile_load_op_raw(X, ld, rows, li, kq, out);
+  VIO_SCHED_FENCE();
+  tile_mask_op(rows, li, out);
+}
+template <class MP>
+VIO_DEV v4d tile_load_acc_raw(MP C, int ld, int rows, int li, int kq) {
   v4d a;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const bool ok = kq + 4 * r < rows;
-    const double x = C[(ok ? kq + 4 * r : 0) * ld + li];
-    a[r] = ok ? x : 0.0;
-  }
+  for (int r = 0; r < 4; r++) a[r] = C[(kq + 4 * r < rows ? kq + 4 * r : 0) * ld + li];
+  return a;
+}
+VIO_DEV v4d tile_mask_acc(v4d a, int rows, int kq) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) a[r] = kq + 4 * r < rows ? a[r] : 0.0;
   return a;
 }
 template <class MP>
+VIO_DEV v4d tile_load_acc(MP C, int ld, int rows, int li, int kq) {
+  v4d a = tile_load_acc_raw(C, ld, rows, li, kq);
+  VIO_SCHED_FENCE();
+  return tile_mask_acc(a, rows, kq);
+}
+template <class MP>
 VIO_DEV void tile_store_acc(MP C, int ld, int rows, int li, int kq, v4d a) {
+  if (rows >= 16) {  // (uniform: four plain stores instead of four exec-masked regions)
+    auto p = C + kq * ld + li;
+    p[0] = a[0], p[4 * ld] = a[1], p[8 * ld] = a[2], p[12 * ld] = a[3];
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++)
     if (kq + 4 * r < rows) C[(kq + 4 * r) * ld + li] = a[r];
@@ -988,42 +1078,49 @@ template <class MP>
 VIO_DEV bool potrf16_wave(MP D, MP Lprev, int ld, int nvalid, int npiv, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
+  double l[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = kq + 4 * r;
     const bool ok = m < nvalid && n < nvalid;
     const int hi = m > n ? m : n, lo = m > n ? n : m;
-    const double x = D[ok ? hi * ld + lo : 0];
-    A[r] = ok ? x : 0.0;
+    A[r] = D[ok ? hi * ld + lo : 0];
+  }
+  tile_load_op_raw(Lprev, ld, nvalid, n, kq, l);
+  VIO_SCHED_FENCE();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    A[r] = (m < nvalid && n < nvalid) ? A[r] : 0.0;
     E[r] = (m == n) ? 1.0 : 0.0;
   }
   if (with_update) {
-    double l[4];
-    tile_load_op(Lprev, ld, nvalid, n, kq, l);
+    tile_mask_op(nvalid, n, l);
 #pragma unroll
     for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
   }
   double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
   double dcc = lane_bcast(A[0], 0);
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    if (c >= npiv) break;
-    double y = __builtin_amdgcn_rsq(dcc);
-    const double h = 0.5 * dcc;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    const bool sel = kq == (c & 3);
-    const double a = sel ? A[c >> 2] * y : 0.0;
-    const double e = sel ? E[c >> 2] * y : 0.0;
-    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
-    myinv = (n == c) ? y : myinv;
-    if (c + 1 < 16) {
-      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
-      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
-      dcc = fma(-lnext, lnext, dold);
+  for (int c = 0; c < 16; c++) {  // (constant trip count: c is a compile-time constant in every copy of the body)
+    if (c < npiv) {
+      double y = __builtin_amdgcn_rsq(dcc);
+      const double h = 0.5 * dcc;
+      y = y * fma(-h * y, y, 1.5);
+      y = y * fma(-h * y, y, 1.5);
+      const bool sel = kq == (c & 3);
+      const double a = sel ? A[c >> 2] * y : 0.0;
+      const double e = sel ? E[c >> 2] * y : 0.0;
+      keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+      myinv = (n == c) ? y : myinv;
+      if (c + 1 < 16) {
+        const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
+        const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
+        dcc = fma(-lnext, lnext, dold);
+      }
+      A = mfma_f64(-a, a, A);
+      E = mfma_f64(-a, e, E);
     }
-    A = mfma_f64(-a, a, A);
-    E = mfma_f64(-a, e, E);
   }
   if (n < nvalid) {
 #pragma unroll
@@ -1039,15 +1136,18 @@ VIO_DEV bool potrf16_wave(MP D, MP Lprev, int ld, int nvalid, int npiv, bool wit
 // A_ik <- A_ik L_kk^-T (panel tile below a factored FULL diagonal tile: 16 pivots)
 template <class MP>
 VIO_DEV void tile_trsm(MP Aik, int ld_i, int rows, MP Dkk, int ld_k, cldsd ldinv_k, int li, int kq) {
-  double a[4];
-  tile_load_op(Aik, ld_i, rows, li, kq, a);
+  double a[4], x[4];
+  tile_load_op_raw(Aik, ld_i, rows, li, kq, a);
   const double dg = ldinv_k[li];
+#pragma unroll
+  for (int s = 0; s < 4; s++) x[s] = Dkk[(4 * s + kq) * ld_k + li];  // B[kk][li] = Linv[li][kk]: above the diagonal of Dkk for kk < li
+  VIO_SCHED_FENCE();
+  tile_mask_op(rows, li, a);
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    const int kk = 4 * s + kq;  // B[kk][li] = Linv[li][kk]: above the diagonal of Dkk for kk < li
-    const double x = Dkk[kk * ld_k + li];
-    const double bb = kk < li ? x : (kk == li ? dg : 0.0);
+    const int kk = 4 * s + kq;
+    const double bb = kk < li ? x[s] : (kk == li ? dg : 0.0);
     acc = mfma_f64(a[s], bb, acc);
   }
   tile_store_acc(Aik, ld_i, rows, li, kq, acc);
@@ -1056,8 +1156,11 @@ VIO_DEV void tile_trsm(MP Aik, int ld_i, int rows, MP Dkk, int ld_k, cldsd ldinv
 template <class MP>
 VIO_DEV void tile_update(MP C, int ld_i, int rows_i, MP A, MP B, int ld_j, int rows_j, int li, int kq) {
   double a[4], b[4];
-  tile_load_op(A, ld_i, rows_i, li, kq, a), tile_load_op(B, ld_j, rows_j, li, kq, b);
-  v4d acc = tile_load_acc(C, ld_i, rows_i, li, kq);
+  tile_load_op_raw(A, ld_i, rows_i, li, kq, a), tile_load_op_raw(B, ld_j, rows_j, li, kq, b);
+  v4d acc = tile_load_acc_raw(C, ld_i, rows_i, li, kq);
+  VIO_SCHED_FENCE();
+  tile_mask_op(rows_i, li, a), tile_mask_op(rows_j, li, b);
+  acc = tile_mask_acc(acc, rows_i, kq);
 #pragma unroll
   for (int s = 0; s < 4; s++) acc = mfma_f64(-a[s], b[s], acc);
   tile_store_acc(C, ld_i, rows_i, li, kq, acc);
@@ -1278,11 +1381,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     stamp(cx, ST_EVAL_PROJ);
     VIO_PARFOR(q, (int)tri_doubles(v.nrows)) w.App[q] = 0.0;
     VIO_PARFOR(q, 2 * v.P * kSS) w.Dss[q] = 0.0;  // (Css follows Dss)
-    VIO_PARFOR(q, v.P * kSB) {  // the columns of Asp the unfactored system can fill
-      const int k = q / kSB, c = q - k * kSB;
-      double *row = v.Asp + ((size_t)k * kSB + c) * v.jp;
-      for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) row[j] = 0.0;
-    }
+    VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
   }
   // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
   const int n = v.prior_n;
@@ -1332,7 +1431,9 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
             const int a = a0 + u * nwv;
             if (a < n && bok) {
               const int pa = w.prcol[a];
-              if (pa >= 0 && pb >= 0 && pa >= pb) red_put(v, w, pa >> 8, pa & 255, pb >> 8, pb & 255, x[u], false);
+              // (speed-bias x pose entries of H0 are constant and live in WinView::Apri: setup_prior)
+              if (pa >= 0 && pb >= 0 && pa >= pb && ((pa & 255) >= 6) == ((pb & 255) >= 6))
+                red_put(v, w, pa >> 8, pa & 255, pb >> 8, pb & 255, x[u], false);
             }
           }
         }
@@ -1548,10 +1649,15 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
       for (int c = 0; c < kSB; c++) s2 = fma(C[c], w.t1[kBS * k + 6 + c], s2);
       acc = fma(2.0 * w.t1[kBS * (k - 1) + 6 + r], s2, acc);
     }
-    // speed-bias x pose (global, columns the unfactored system fills)
-    const double *A = v.Asp + ((size_t)k * kSB + r) * v.jp;
+    // speed-bias x pose: the IMU chain (LDS) and, for the block the prior keeps, the prior's row (global)
+    const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
+    auto A = w.AspI + (k * kSB + r) * kAW;
     double s3 = 0;
-    for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) s3 = fma(A[j], w.xt[j], s3);
+    for (int jj = 0; jj < aw; jj++) s3 = fma(A[jj], w.xt[alo + jj], s3);
+    if (w.sbr[2 * k + 1]) {
+      const double *Ap = v.Apri + (size_t)r * v.jp;
+      for (int j = 0; j < n6; j++) s3 = fma(Ap[j], w.xt[j], s3);
+    }
     acc = fma(ur, sacc + 2.0 * s3, acc);
   }
   VIO_SYNC();  // tf complete
@@ -1733,19 +1839,22 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
 
 // Band step k on one wave.
 template <class WK>
-VIO_DEV void band_step(const WinView &v, WK &w, int k, int fail_flag, int lane) {
-  const int li = lane & 15, kq = lane >> 4;
+VIO_DEV void band_step(const Ctx &cx, const WinView &v, WK &w, int k, int fail_flag, int lane_) {
+  const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
   ldsd D = w.Dss + k * kSS;
   ldsd ldk = w.ldinv + kSB * k;
   const bool good = potrf9_inv_wave(D, w.Css + (k + 1 <= v.W ? k + 1 : k) * kSS, k < v.W, ldk, lane);
   if (!good && lane == 0) w.flag[fail_flag] = 1;
+  stamp(cx, ST_D3);
   if (k >= 1) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the factor just stored is read back in another lane mapping
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     ldsd C = w.Css + k * kSS;
-    double a[3], b[3];
-    load_op9(C, li, kq, a), load_linv9(D, ldk, li, kq, b);
+    double a[3], b[4];
+    load_op9_raw(C, li, kq, a), load_linv9_raw(D, ldk, li, kq, b);
+    VIO_SCHED_FENCE();
+    mask_op9(li, kq, a), mask_linv9(li, kq, b);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 3; s++) acc = mfma_f64(a[s], b[s], acc);
@@ -1758,85 +1867,263 @@ VIO_DEV void band_step(const WinView &v, WK &w, int k, int fail_flag, int lane) 
   }
 }
 
-// T = Asp_k^T tile t in accumulator layout: element r = A(s_k[kq + 4 r], pose index 16 t + li); column n6 = the
-// gradient of s_k (the right-hand side rides along as one more pose column)
+// Asp_k^T tile t in accumulator layout: element r = A(s_k[kq + 4 r], pose index 16 t + li); column n6 = the gradient of
+// s_k (the right-hand side rides along as one more pose column). Raw fetch (clamped addresses, nothing consumes the
+// values) and the masking at the point of use are separate so that a caller can put every read of a step in one batch.
+struct PanelRaw {
+  double x[3];   // AspI (LDS)
+  double p[3];   // Apri (global): only fetched for the speed-bias block the prior keeps
+};
 template <class WK>
-VIO_DEV v4d panel_load_tile(const WinView &v, WK &w, int k, int t, int li, int kq) {
-  const int j = 16 * t + li;
-  const bool inr = j >= w.sbr[2 * k] && j < w.sbr[2 * k + 1], isr = j == v.n6;
-  const double *A = v.Asp + (size_t)k * kSB * v.jp;
+VIO_DEV PanelRaw panel_fetch(const WinView &v, WK &w, int k, bool is_pr, int t, int li, int kq) {
+  const int j = 16 * t + li, alo = 6 * (k > 0 ? k - 1 : 0);
+  const bool inr = j >= alo && j < alo + kAW && j < v.n6;
+  auto A = w.AspI + k * kAS + (inr ? j - alo : 0);
+  PanelRaw p;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int c = kq + 4 * r < kSB ? kq + 4 * r : 0;
+    p.x[r] = A[c * kAW];
+    p.p[r] = is_pr ? v.Apri[c * v.jp + (j < v.n6 ? j : 0)] : 0.0;
+  }
+  return p;
+}
+// gr[r]: gradient of s_k[kq + 4 r] (raw LDS values, fetched by the caller in its batch)
+VIO_DEV v4d panel_tile(int n6, int k, bool is_pr, int t, int li, int kq, const PanelRaw &p, const double gr[3]) {
+  const int j = 16 * t + li, alo = 6 * (k > 0 ? k - 1 : 0);
+  const bool inr = j >= alo && j < alo + kAW && j < n6, inp = is_pr && j < n6, isr = j == n6;
   v4d T = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    const int c = kq + 4 * r;
-    const bool ok = c < kSB;
-    const double x = A[(ok && inr) ? c * v.jp + j : 0];
-    const double g = w.gp[kBS * k + 6 + (ok ? c : 0)];
-    T[r] = ok ? (inr ? x : (isr ? g : 0.0)) : 0.0;
+    const bool ok = kq + 4 * r < kSB;
+    const double x = (inr ? p.x[r] : 0.0) + (inp ? p.p[r] : 0.0);
+    T[r] = ok ? (isr ? gr[r] : x) : 0.0;
   }
   return T;
+}
+template <class WK>
+VIO_DEV v4d panel_load_tile(const WinView &v, WK &w, int k, int t, int li, int kq) {
+  const bool is_pr = w.sbr[2 * k + 1] != 0;
+  const PanelRaw p = panel_fetch(v, w, k, is_pr, t, li, kq);
+  double gr[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) gr[r] = w.gp[kBS * k + 6 + (kq + 4 * r < kSB ? kq + 4 * r : 0)];
+  return panel_tile(v.n6, k, is_pr, t, li, kq, p, gr);
 }
 
 // Panel step k with the fill tiles in registers (every panel wave computes all of V_k: 6 matrix instructions per tile
 // cost less than a hand-over through LDS and its barrier), then this wave's share of the rank-9 update of App.
-template <int NT, class WK>
-VIO_DEV void panel_step_regs(const WinView &v, WK &w, int k, v4d (&V)[NT], int lane, int pw, int npw) {
-  const int li = lane & 15, kq = lane >> 4;
+// V: three doubles per tile (element 3 of the accumulator layout is sb component 12 + kq: always zero). Tiles below tlo
+// are structurally zero at this step (the fill of s_k only reaches the poses the frames k.. couple to) and are skipped.
+// NPW panel waves: tile q = I (I + 1) / 2 + J of the update belongs to wave q % NPW, which keeps it in accumulator
+// q / NPW. Every read of the step -- Asp_k (global), operands, accumulators, gradient (LDS) -- is issued in ONE batch
+// ahead of the first matrix instruction, every store follows the last. (The Asp fetch is not carried over from the
+// previous step: 30 more registers per lane put scratch reloads into this loop, which cost more than the L2 round trip
+// that hides behind wave 0's longer band step anyway.)
+struct VTile {
+  double x[3];
+};
+template <int NT, int NPW, class WK>
+VIO_DEV void panel_step_regs(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane_, int pw) {
+  const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
   const int nT = v.nT;
-  v4d T[NT];
+  double e[3] = {0.0, 0.0, 0.0}, linv[4], gr[3];
+  constexpr int kTiles = NT * (NT + 1) / 2, kAcc = (kTiles + NPW - 1) / NPW;
+  v4d acc[kAcc];
+  PanelRaw X[NT];
+  const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
 #pragma unroll
   for (int t = 0; t < NT; t++)
-    if (t < nT) T[t] = panel_load_tile(v, w, k, t, li, kq);
-  double e[3] = {0.0, 0.0, 0.0}, linv[3];
-  if (k < v.W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
-  load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
+    if (t >= tlo && t < nT) X[t] = panel_fetch(v, w, k, is_pr, t, li, kq);
+  if (k < v.W) load_op9_raw(w.Css + (k + 1) * kSS, li, kq, e);
+  load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
 #pragma unroll
-  for (int t = 0; t < NT; t++) {
-    if (t >= nT) continue;
-    v4d Tt = T[t];
-    if (k < v.W) {
-#pragma unroll
-      for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t][s], Tt);
-    }
-    v4d Vn = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
-    V[t] = Vn;
-  }
-  int q = 0;
+  for (int r = 0; r < 3; r++) gr[r] = w.gp[kBS * k + 6 + (kq + 4 * r < kSB ? kq + 4 * r : 0)];
 #pragma unroll
   for (int I = 0; I < NT; I++)
 #pragma unroll
     for (int J = 0; J <= I; J++) {
-      if (I < nT && q % npw == pw) {
-        auto C = w.App + tri_off(I) + 16 * J;
-        const int ld = tri_ld(I), rows = v.nrows - 16 * I;
-        v4d acc = tile_load_acc(C, ld, rows, li, kq);
+      const int q = I * (I + 1) / 2 + J;
+      if (I < nT && J >= tlo && q % NPW == pw)
+        acc[q / NPW] = tile_load_acc_raw(w.App + tri_off(I) + 16 * J, tri_ld(I), v.nrows - 16 * I, li, kq);
+    }
+  VIO_SCHED_FENCE();
+  if (k < v.W) mask_op9(li, kq, e);
+  mask_linv9(li, kq, linv);
+  if (cx.prof_tid) {
+    double probe = linv[0] + e[0] + gr[0] + X[NT - 1].x[0] + X[NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
+    asm volatile("" ::"v"(probe));
+    stamp(cx, ST_D4);
+  }
 #pragma unroll
-        for (int s = 0; s < 3; s++) acc = mfma_f64(-V[I][s], V[J][s], acc);
-        tile_store_acc(C, ld, rows, li, kq, acc);
+  for (int t = 0; t < NT; t++) {
+    if (t < tlo || t >= nT) continue;
+    v4d Tt = panel_tile(v.n6, k, is_pr, t, li, kq, X[t], gr);
+    if (k < v.W) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t].x[s], Tt);
+    }
+    v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
+    V[t].x[0] = Vn[0], V[t].x[1] = Vn[1], V[t].x[2] = Vn[2];
+  }
+  if (cx.prof_tid) stamp(cx, ST_D0);
+#pragma unroll
+  for (int I = 0; I < NT; I++)
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      const int q = I * (I + 1) / 2 + J;
+      if (I < nT && J >= tlo && q % NPW == pw) {
+        v4d c = tile_mask_acc(acc[q / NPW], v.nrows - 16 * I, kq);
+#pragma unroll
+        for (int s = 0; s < 3; s++) c = mfma_f64(-V[I].x[s], V[J].x[s], c);
+        acc[q / NPW] = c;
       }
-      q++;
+    }
+  if (cx.prof_tid) {
+    double probe = acc[0][0] + acc[kAcc - 1][0];
+    asm volatile("" ::"v"(probe));
+    stamp(cx, ST_D1);
+  }
+#pragma unroll
+  for (int I = 0; I < NT; I++)
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      const int q = I * (I + 1) / 2 + J;
+      if (I < nT && J >= tlo && q % NPW == pw)
+        tile_store_acc(w.App + tri_off(I) + 16 * J, tri_ld(I), v.nrows - 16 * I, li, kq, acc[q / NPW]);
     }
 }
 
-// Band + panel for pose matrices of up to NT tile rows. false: a pivot of the band was <= 0.
-template <int NT, class WK>
-VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
-  const int W = v.W;
-  v4d V[NT];
+// The same step for a pose matrix of exactly NT tile rows, specialised for panel wave PW of NPW: the tiles of the wave
+// are a compile-time list, so every accumulator access is one ds_read / ds_write at an immediate offset from one of NT
+// per-lane row bases (the generic form spends ~600 instructions per step on predicates and address arithmetic).
+template <int NT, int NPW, int PW, class WK>
+VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane_) {
+  const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
+  double e[3] = {0.0, 0.0, 0.0}, linv[4], gr[3];
+  constexpr int kTiles = NT * (NT + 1) / 2, kAcc = (kTiles + NPW - 1) / NPW;
+  v4d acc[kAcc];
+  PanelRaw X[NT];
+  const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
+  const int rows_last = v.nrows - 16 * (NT - 1);  // rows of the last tile row (the others are full)
 #pragma unroll
-  for (int t = 0; t < NT; t++) V[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < NT; t++)
+    if (t >= tlo) X[t] = panel_fetch(v, w, k, is_pr, t, li, kq);
+  if (k < v.W) load_op9_raw(w.Css + (k + 1) * kSS, li, kq, e);
+  load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
+#pragma unroll
+  for (int r = 0; r < 3; r++) gr[r] = w.gp[kBS * k + 6 + (kq + 4 * r < kSB ? kq + 4 * r : 0)];
+#pragma unroll
+  for (int I = 0; I < NT; I++) {
+    auto rowbase = w.App + tri_off(I) + kq * tri_ld(I) + li;  // element r of tile (I, J): rowbase[4 r ld + 16 J]
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      const int q = I * (I + 1) / 2 + J;
+      if (q % NPW == PW && J >= tlo) {
+        v4d a;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (I < NT - 1) a[r] = rowbase[4 * r * tri_ld(I) + 16 * J];
+          else a[r] = rowbase[(kq + 4 * r < rows_last ? 4 * r * tri_ld(I) : -kq * tri_ld(I)) + 16 * J];
+        }
+        acc[q / NPW] = a;
+      }
+    }
+  }
+  VIO_SCHED_FENCE();
+  if (k < v.W) mask_op9(li, kq, e);
+  mask_linv9(li, kq, linv);
+  if (cx.prof_tid) {
+    double probe = linv[0] + e[0] + gr[0] + X[NT - 1].x[0] + X[NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
+    asm volatile("" ::"v"(probe));
+    stamp(cx, ST_D4);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    if (t < tlo) continue;
+    v4d Tt = panel_tile(v.n6, k, is_pr, t, li, kq, X[t], gr);
+    if (k < v.W) {
+#pragma unroll
+      for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t].x[s], Tt);
+    }
+    v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
+    V[t].x[0] = Vn[0], V[t].x[1] = Vn[1], V[t].x[2] = Vn[2];
+  }
+  if (cx.prof_tid) stamp(cx, ST_D0);
+#pragma unroll
+  for (int I = 0; I < NT; I++)
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      const int q = I * (I + 1) / 2 + J;
+      if (q % NPW == PW && J >= tlo) {
+        v4d c = acc[q / NPW];
+        if (I == NT - 1) c = tile_mask_acc(c, rows_last, kq);
+#pragma unroll
+        for (int s = 0; s < 3; s++) c = mfma_f64(-V[I].x[s], V[J].x[s], c);
+        acc[q / NPW] = c;
+      }
+    }
+  if (cx.prof_tid) {
+    double probe = acc[0][0] + acc[kAcc - 1][0];
+    asm volatile("" ::"v"(probe));
+    stamp(cx, ST_D1);
+  }
+#pragma unroll
+  for (int I = 0; I < NT; I++) {
+    auto rowbase = w.App + tri_off(I) + kq * tri_ld(I) + li;
+#pragma unroll
+    for (int J = 0; J <= I; J++) {
+      const int q = I * (I + 1) / 2 + J;
+      if (q % NPW == PW && J >= tlo) {
+        const v4d c = acc[q / NPW];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (I < NT - 1) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];
+          else if (kq + 4 * r < rows_last) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];
+        }
+      }
+    }
+  }
+}
+template <int NT, int NPW, class WK>
+VIO_DEV void panel_step_dispatch(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane, int pw) {
+  if (v.nT != NT) {
+    panel_step_regs<NT, NPW>(cx, v, w, k, tlo, V, lane, pw);
+    return;
+  }
+  if constexpr (NPW == 3) {
+    if (pw == 0) panel_step_static<NT, 3, 0>(cx, v, w, k, tlo, V, lane);
+    else if (pw == 1) panel_step_static<NT, 3, 1>(cx, v, w, k, tlo, V, lane);
+    else panel_step_static<NT, 3, 2>(cx, v, w, k, tlo, V, lane);
+  } else {
+    panel_step_regs<NT, NPW>(cx, v, w, k, tlo, V, lane, pw);
+  }
+}
+
+// Band + panel for pose matrices of up to NT tile rows, NW waves. false: a pivot of the band was <= 0.
+template <int NT, int NW, class WK>
+VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
+  const int W = v.W;
+  VTile V[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) V[t].x[0] = V[t].x[1] = V[t].x[2] = 0.0;
+  int flo = v.n6;  // first pose column the fill of the steps so far reaches
   for (int slot = 0; slot <= W + 1; slot++) {
     const int kb = W - slot, kp = kb + 1, ff = 2 + (slot & 1);
     if (wave == 0) {
-      if (kb >= 0) band_step(v, w, kb, ff, lane);
+      if (kb >= 0) band_step(cx, v, w, kb, ff, lane);
       stamp(cx, ST_C_AHEAD);
     } else if (kp <= W) {
-      panel_step_regs<NT>(v, w, kp, V, lane, wave - 1, nw - 1);
+      flo = flo < w.sbr[2 * kp] ? flo : w.sbr[2 * kp];  // (0 for the block the prior keeps)
+      panel_step_dispatch<NT, NW - 1>(cx, v, w, kp, flo >> 4, V, lane, wave - 1);
+      if (cx.prof_tid) stamp(cx, ST_D2);  // (clock on a panel wave: the rank-9 updates)
     }
-    VIO_SYNC();
+    VIO_SYNC_LDS();  // (band blocks, pose matrix and flags are all LDS)
     stamp(cx, ST_C_WAIT);
     // (the flag of this slot is not written again before every wave has passed the next barrier)
     if (w.flag[ff]) return false;
@@ -1853,11 +2140,11 @@ VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
   const int W = v.W, nT = v.nT;
   for (int k = W; k >= 0; k--) {
     ldsd Vc = w.vbuf;  // V_{k+1}^T on entry, V_k^T behind the panel phase: element (t, s) of a lane is private to it
-    if (wave == 0) band_step(v, w, k, 2, lane);
+    if (wave == 0) band_step(cx, v, w, k, 2, lane);
     VIO_SYNC();
     stamp(cx, ST_C_AHEAD);
     if (w.flag[2]) return false;
-    double e[3] = {0.0, 0.0, 0.0}, linv[3];
+    double e[3] = {0.0, 0.0, 0.0}, linv[4];
     if (k < W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
     load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
     for (int t = wave; t < nT; t += nw) {
@@ -1897,22 +2184,22 @@ VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
 // Tiled right-looking Cholesky of App with the right-hand side row carried along. false: a pivot was <= 0.
 template <class WK>
 VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
-  const int li = lane & 15, kq = lane >> 4;
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane0 = tid_ & 63;
   const int nT = v.nT, nrows = v.nrows, n6 = v.n6;
   ldsd ldp = w.ldinv + kSB * v.P;
   auto tile = [&](int I, int J) { return w.App + tri_off(I) + 16 * J; };
   auto rows_of = [&](int I) { return nrows - 16 * I < 16 ? nrows - 16 * I : 16; };
   auto piv_of = [&](int I) { return n6 - 16 * I < 16 ? (n6 - 16 * I > 0 ? n6 - 16 * I : 0) : 16; };
   if (wave == 0) {
-    const bool good = potrf16_wave(tile(0, 0), tile(0, 0), tri_ld(0), rows_of(0), piv_of(0), false, ldp, lane);
-    if (!good && lane == 0) w.flag[1] = 1;
+    const bool good = potrf16_wave(tile(0, 0), tile(0, 0), tri_ld(0), rows_of(0), piv_of(0), false, ldp, lane0);
+    if (!good && lane0 == 0) w.flag[1] = 1;
   }
   VIO_SYNC();
   stamp(cx, ST_C_POTRF);
   for (int K = 0; K < nT; K++) {
     if (w.flag[1]) return false;
     const int ntb = nT - K - 1;
+    const int lane = VIO_OPAQUE(lane0), li = lane & 15, kq = lane >> 4;
     for (int bi = wave; bi < ntb; bi += nw)
       tile_trsm(tile(K + 1 + bi, K), tri_ld(K + 1 + bi), rows_of(K + 1 + bi), tile(K, K), tri_ld(K), ldp + 16 * K, li, kq);
     VIO_SYNC();
@@ -1956,7 +2243,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   VIO_PARFOR(a, 16 * nT) x[a] = a < n6 ? w.App[tri_at(n6, a)] : 0.0;
   VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p below
   VIO_SYNC();
-  const int qc = lane >> 2, qp = lane & 3;  // lane = 4 c + p: the four lanes of a quad split a 16-term dot product
+  int qc = lane >> 2, qp = lane & 3;  // lane = 4 c + p: the four lanes of a quad split a 16-term dot product
   // x_K <- L_KK^-T x_K: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
   auto solve_diag = [&](int K) {
     auto D = tile(K, K);
@@ -1993,6 +2280,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   if (wave == 0) solve_diag(nT - 1);
   VIO_SYNC();
   for (int K = nT - 1; K >= 1; K--) {
+    qc = VIO_OPAQUE(qc), qp = VIO_OPAQUE(qp);
     if (wave == 0) {
       apply(K, K - 1);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2008,85 +2296,86 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   VIO_PARFOR(a, n6) w.t1[kBS * (a / 6) + a % 6] = x[a];
   VIO_PARFOR(q, P * kSB) {
     const int k = q / kSB, c = q - k * kSB;
-    const double *A = v.Asp + ((size_t)k * kSB + c) * v.jp;
+    const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
+    auto A = w.AspI + (k * kSB + c) * kAW;
     double sacc = w.gp[kBS * k + 6 + c];
-    for (int j = w.sbr[2 * k]; j < w.sbr[2 * k + 1]; j++) sacc = fma(-A[j], x[j], sacc);
+    for (int jj = 0; jj < aw; jj++) sacc = fma(-A[jj], x[alo + jj], sacc);
+    if (w.sbr[2 * k + 1]) {
+      const double *Ap = v.Apri + (size_t)c * v.jp;
+      for (int j = 0; j < n6; j++) sacc = fma(-Ap[j], x[j], sacc);
+    }
     w.t1[kBS * k + 6 + c] = sacc;
   }
   VIO_SYNC();
   stamp(cx, ST_BACKSOLVE);
   if (wave == 0) {
     // band: u_k = L_k^-1 (t_k - E_{k+1} u_{k+1}), k = W..0; then z_k = L_k^-T (u_k - E_k^T z_{k-1}), k = 0..W.
-    // lane = 4 n + p; the value of row n is complete in the four lanes of its quad
-    const bool ok = qc < kSB;
-    const int n = ok ? qc : 0;
+    // Lane n < 9 owns component n: its rows of the two 9 x 9 blocks of a step sit in registers (fetched one step ahead,
+    // they do not depend on the chain) and the nine components of the running vector travel through v_readlane, so a
+    // step is two dependent chains of nine FMAs instead of four LDS round trips.
+    const bool ok = lane < kSB;
+    const int n = ok ? lane : 0;
+    double ea[kSB], la[kSB], eb[kSB], lb[kSB], ta = 0.0, tb = 0.0;
+    auto fetch_fwd = [&](int k, double (&er)[kSB], double (&lr)[kSB], double &tk) {
+      cldsd E = w.Css + (k + 1 <= W ? k + 1 : k) * kSS + n * kSB, D = w.Dss + k * kSS;  // row n of E_{k+1}: s_k[n] x s_{k+1}
+      const double dg = w.ldinv[kSB * k + n];
+#pragma unroll
+      for (int m = 0; m < kSB; m++) {
+        er[m] = E[m];
+        const double x = D[(m < n ? m : 0) * kSB + n];  // Linv[n][m] sits above the diagonal at D[m][n]
+        lr[m] = m < n ? x : (m == n ? dg : 0.0);
+      }
+      tk = w.t1[kBS * k + 6 + n];
+    };
+    auto fetch_bwd = [&](int k, double (&ec)[kSB], double (&lc)[kSB], double &tk) {
+      cldsd E = w.Css + k * kSS + n, D = w.Dss + k * kSS + n * kSB;  // column n of E_k: s_{k-1} x s_k[n]
+      const double dg = w.ldinv[kSB * k + n];
+#pragma unroll
+      for (int m = 0; m < kSB; m++) {
+        ec[m] = E[m * kSB];
+        const double x = D[m > n ? m : n];  // Linv[m][n] for m > n at D[n][m]
+        lc[m] = m > n ? x : (m == n ? dg : 0.0);
+      }
+      tk = w.t1[kBS * k + 6 + n];
+    };
+    double prev = 0.0;
+    fetch_fwd(W, ea, la, ta);
     for (int k = W; k >= 0; k--) {
-      ldsd tk = w.t1 + kBS * k + 6;
-      cldsd D = w.Dss + k * kSS;
-      double val = qp == 0 ? tk[n] : 0.0;
+      if (k >= 1) fetch_fwd(k - 1, eb, lb, tb);
+      double val = ta;
       if (k < W) {
-        cldsd E = w.Css + (k + 1) * kSS + n * kSB, un = w.t1 + kBS * (k + 1) + 6;  // row n of E_{k+1}: s_k[n] x s_{k+1}
 #pragma unroll
-        for (int t4 = 0; t4 < 3; t4++) {
-          const int m = qp + 4 * t4;
-          const bool in = m < kSB;
-          val = fma(in ? -E[in ? m : 0] : 0.0, un[in ? m : 0], val);
-        }
+        for (int m = 0; m < kSB; m++) val = fma(-ea[m], lane_bcast(prev, m), val);
       }
-      val = quad_sum_f64(val);
-      __builtin_amdgcn_wave_barrier();
-      if (ok && qp == 0) tk[n] = val;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // u[n] = v[n] / L_nn + sum_{m < n} Linv[n][m] v[m], Linv[n][m] at D[m][n]
-      double u = qp == 0 ? w.ldinv[kSB * k + n] * tk[n] : 0.0;
+      double u = 0.0;
 #pragma unroll
-      for (int t4 = 0; t4 < 3; t4++) {
-        const int m = qp + 4 * t4;
-        const bool in = ok && m < n;
-        u = fma(in ? D[(in ? m : 0) * kSB + n] : 0.0, tk[in ? m : 0], u);
-      }
-      u = quad_sum_f64(u);
-      __builtin_amdgcn_wave_barrier();
-      if (ok && qp == 0) tk[n] = u;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int m = 0; m < kSB; m++) u = fma(la[m], lane_bcast(val, m), u);
+      prev = u;
+      if (ok) w.t1[kBS * k + 6 + n] = u;
+#pragma unroll
+      for (int m = 0; m < kSB; m++) ea[m] = eb[m], la[m] = lb[m];
+      ta = tb;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    prev = 0.0;
+    fetch_bwd(0, ea, la, ta);
     for (int k = 0; k <= W; k++) {
-      ldsd tk = w.t1 + kBS * k + 6;
-      cldsd D = w.Dss + k * kSS;
-      double val = qp == 0 ? tk[n] : 0.0;
+      if (k < W) fetch_bwd(k + 1, eb, lb, tb);
+      double val = ta;
       if (k >= 1) {
-        cldsd E = w.Css + k * kSS, zp = w.t1 + kBS * (k - 1) + 6;  // (E_k^T z_{k-1})[n] = sum_m E_k[m][n] z_{k-1}[m]
 #pragma unroll
-        for (int t4 = 0; t4 < 3; t4++) {
-          const int m = qp + 4 * t4;
-          const bool in = m < kSB;
-          val = fma(in ? -E[(in ? m : 0) * kSB + n] : 0.0, zp[in ? m : 0], val);
-        }
+        for (int m = 0; m < kSB; m++) val = fma(-ea[m], lane_bcast(prev, m), val);
       }
-      val = quad_sum_f64(val);
-      __builtin_amdgcn_wave_barrier();
-      if (ok && qp == 0) tk[n] = val;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // z[n] = v[n] / L_nn + sum_{r > n} Linv[r][n] v[r], Linv[r][n] at D[n][r]
-      double z = qp == 0 ? w.ldinv[kSB * k + n] * tk[n] : 0.0;
+      double z = 0.0;
 #pragma unroll
-      for (int t4 = 0; t4 < 3; t4++) {
-        const int r = n + 1 + qp + 4 * t4;
-        const bool in = ok && r < kSB;
-        z = fma(in ? D[n * kSB + (in ? r : n)] : 0.0, tk[in ? r : n], z);
-      }
-      z = quad_sum_f64(z);
-      __builtin_amdgcn_wave_barrier();
-      if (ok && qp == 0) tk[n] = z;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int m = 0; m < kSB; m++) z = fma(la[m], lane_bcast(val, m), z);
+      prev = z;
+      if (ok) w.t1[kBS * k + 6 + n] = z;
+#pragma unroll
+      for (int m = 0; m < kSB; m++) ea[m] = eb[m], la[m] = lb[m];
+      ta = tb;
     }
   } else {
     // landmark back-substitution, first half: w_f^T z_p over (feature, part) items by the waves that do not walk the band
@@ -2150,7 +2439,7 @@ VIO_DEV void state_norms(const Ctx &cx, const WinView &v, cldsd apose, cldsd asb
 // TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
 // =====================================================================================================
 // REGS: the pose matrix has at most kPanelTiles tile rows (the launcher's LDS variant): fill tiles in registers
-template <bool REGS, class WK>
+template <bool REGS, int NW, class WK>
 VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   const int np = v.np, F = v.F;
   double *sd = v.stats_d;
@@ -2233,7 +2522,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         VIO_SYNC();
         bool ok = build_reduced_system(cx, v, w, mu);
         if (ok) {
-          if constexpr (REGS) ok = factor_band_regs<kPanelTiles>(cx, v, w);
+          if constexpr (REGS) ok = factor_band_regs<kPanelTiles, NW>(cx, v, w);
           else ok = factor_band_lds(cx, v, w);
         }
         if (ok) ok = factor_poses(cx, v, w);
@@ -2396,7 +2685,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
 // =====================================================================================================
 // Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs
 // =====================================================================================================
-template <bool REGS, class WK>
+// NW: waves of the workgroup (blockDim.x / 64)
+template <bool REGS, int NW, class WK>
 VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   const int P = v.P, F = v.F;
   VIO_PARFOR(q, P * 7) w.xpose[q] = v.pose0[q];
@@ -2406,17 +2696,17 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   if (v.has_loop) VIO_PARFOR(q, 7) w.xpose[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
   VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
   if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
-  // columns of the speed-bias x pose coupling that the factors can fill: the IMU chain reaches the poses of the frame
-  // and of both neighbours, a speed-bias block kept by the prior reaches every pose the prior holds
+  // first pose column speed-bias block k couples to: the IMU chain reaches the frame and both neighbours, the block the
+  // prior keeps reaches every pose of the prior
   VIO_PARFOR(k, P) {
-    int lo = 6 * (k > 0 ? k - 1 : 0), hi = 6 * (k + 2 < P ? k + 2 : P);
+    int lo = 6 * (k > 0 ? k - 1 : 0), pr = 0;
     for (int b = 0; b < v.prior_nb; b++)
-      if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, hi = 6 * P;
-    w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = hi;
+      if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, pr = 1;
+    w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = pr;
   }
   VIO_SYNC();
 #ifndef VIO_EMUL
-  if (cx.prof && cx.tid == 0) {
+  if (cx.prof && cx.tid == cx.prof_tid) {
     for (int q = 0; q < ST_COUNT; q++) cx.lprof[q] = 0;
     cx.lprof[ST_COUNT - 1] = clock64();
     cx.lprof[ST_TOTAL] = -cx.lprof[ST_COUNT - 1];
@@ -2431,7 +2721,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
   setup_prior(cx, v, w);
   stamp(cx, ST_SETUP_PRIOR);
 
-  minimize<REGS>(cx, v, w);
+  minimize<REGS, NW>(cx, v, w);
 
   VIO_PARFOR(q, P * 7) v.raw_pose[q] = w.xpose[q];
   VIO_PARFOR(q, P * 9) v.raw_sb[q] = w.xsb[q];

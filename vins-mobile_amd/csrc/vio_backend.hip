@@ -38,6 +38,7 @@ struct MargPtrs {
   double *scratch;  // [n][marg_scratch] (global matrix variant only)
   size_t s_ints, s_x0, s_J, s_r, s_scratch;
   long long *prof;  // [n][ST_COUNT] or null
+  int prof_tid;     // work-item that keeps the stage clock (VIO_AMD_PROF_TID, default 0)
 };
 
 // NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
@@ -50,14 +51,15 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
   ldsd lds = (ldsd)smem;
   // (by value: neither struct ever has its address taken, so both live in registers)
-  const Carved<MatP> cw = carve_all<MatP>(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm);
+  const Carved<MatP> cw = carve_all<MatP>(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, v.AspG);
   WorkT<MatP> w = cw.w;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
+  cx.prof_tid = MP.prof_tid;
   cx.red = cw.red, cx.lprof = cw.lprof;
   const size_t state_end = cw.state_end_doubles;
-  solve_window<LDS_MATRIX>(cx, v, w);
+  solve_window<LDS_MATRIX, NT / 64>(cx, v, w);
 
   MargOut mo;
   int *mi = MP.ints + (size_t)b * MP.s_ints;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   MargWorkT<MatP> mw = carve_marg_all<MatP>(B.d, LDS_MATRIX, lds + state_end, mo.scratch, (size_t)lds_doubles - state_end).m;
   __syncthreads();
   marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
-  if (cx.prof && cx.tid == 0) {  // stage counters: LDS -> global
+  if (cx.prof && cx.tid == cx.prof_tid) {  // stage counters: LDS -> global
     cx.lprof[ST_TOTAL] += clock64();
     for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = cx.lprof[q];
   }
@@ -477,6 +479,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   MP.s_ints = m_ints, MP.s_x0 = 9 * kMaxPriorBlocks, MP.s_J = (size_t)d.Ncap * d.Ncap, MP.s_r = d.Ncap;
   MP.s_scratch = m_scr;
   MP.prof = nullptr;
+  MP.prof_tid = getenv("VIO_AMD_PROF_TID") ? atoi(getenv("VIO_AMD_PROF_TID")) : 0;
   if (be->profile) {
     int rcp = be->d_prof.ensure(N * ST_COUNT);
     if (rcp != VIO_OK) return rcp;
