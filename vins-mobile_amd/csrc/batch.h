@@ -60,7 +60,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -84,6 +84,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
   s.s_Asp = o, o += (size_t)kSB * pose_jp(d);  // the prior's speed-bias x pose block
   s.s_AspG = o, o += (size_t)d.Pcap * kAS;
+  s.s_AppPr = o, o += tri_doubles(pose_rows(d)) + 2 * (size_t)d.Pcap * kSS;
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -151,7 +152,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
-  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG;
+  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;

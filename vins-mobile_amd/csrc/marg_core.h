@@ -519,11 +519,12 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       else VIO_ATOMIC_ADD(m.Am + tri_at(ca, ra), val);
     };
     for (int c0 = 0; c0 < S0; c0 += CH) {
-      VIO_PARFOR(k, v.M) {
-        int t = v.ftarget[k], f = v.ffeat[k];
-        if (v.fhost[k] != 0 || t == P) continue;
-        const int slot = v.fslot[k] - c0;
-        if (slot < 0 || slot >= CH) continue;
+      // (the factors hosted at frame 0 occupy the staging slots [0, S0): one pass over the chunk's slots, not over all
+      // M factors per chunk -- every pass costs a global round trip for the index arrays)
+      VIO_PARFOR(slot, (S0 - c0 < CH ? S0 - c0 : CH)) {
+        const int k = v.sfact[c0 + slot];
+        if (k < 0) continue;
+        const int t = v.ftarget[k], f = v.ffeat[k];
         double r[2], Ji[12], Jj[12], Jex[12], Jl[2];
         projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj,
                         Jex, Jl);

@@ -198,6 +198,8 @@ struct WinView {
   double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
+  double *AppPr;     // the prior's H0 scattered into the layout of App | Dss | Css once per solve (setup_prior): every
+                     // linearization starts the reduced matrix as a straight copy of it instead of an element-wise scatter
   double *AspG;      // [P][9][18] the IMU part of the speed-bias x pose coupling when the pose matrix is global (WorkT::AspI)
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
@@ -871,12 +873,23 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
     }
     v.prb0[a] = s;
   }
+  const int napp = (int)tri_doubles(v.nrows), nband = 2 * v.P * kSS;
   VIO_PARFOR(q, kSB * v.jp) v.Apri[q] = 0.0;
+  VIO_PARFOR(q, napp + nband) v.AppPr[q] = 0.0;
   VIO_SYNC();
-  // the speed-bias x pose block of H0: constant during the solve
+  // H0 in the layout of the reduced matrix, constant during the solve: pose x pose -> App, speed-bias x speed-bias ->
+  // Dss / Css (copied into place by every linearization), speed-bias x pose -> Apri (read where it is needed)
   VIO_PARFOR(q, n * n) {
     const int a = q / n, b = q - a * n, pa = w.prcol[a], pb = w.prcol[b];
-    if (pa >= 0 && pb >= 0 && (pa & 255) >= 6 && (pb & 255) < 6) v.Apri[((pa & 255) - 6) * v.jp + 6 * (pb >> 8) + (pb & 255)] = v.prH0[q];
+    if (pa < 0 || pb < 0 || pa < pb) continue;
+    const int fr = pa >> 8, cr = pa & 255, fc = pb >> 8, cc = pb & 255;
+    const double x = v.prH0[q];
+    if (cr < 6 && cc < 6) v.AppPr[tri_at(6 * fr + cr, 6 * fc + cc)] = x;
+    else if (cr >= 6 && cc >= 6) {
+      if (fr == fc) v.AppPr[napp + fr * kSS + (cr - 6) * kSB + (cc - 6)] = x;
+      else if (fr - fc == 1) v.AppPr[napp + v.P * kSS + fr * kSS + (cc - 6) * kSB + (cr - 6)] = x;
+    } else if (cr >= 6) v.Apri[(cr - 6) * v.jp + 6 * fc + cc] = x;
+    else v.Apri[(cc - 6) * v.jp + 6 * fr + cr] = x;
   }
   VIO_SYNC();
 }
@@ -1172,8 +1185,14 @@ VIO_DEV void tile_update(MP C, int ld_i, int rows_i, MP A, MP B, int ld_j, int r
 // Evaluation: cost, and (jac) H -> App / Dss / Css / Asp (unfactored reduced system), WTf, hff, gp, gf, dp
 // =====================================================================================================
 constexpr int kPanelTiles = 5;   // pose matrices of up to 80 rows (W <= 12) keep the fill tiles of the band in registers
-constexpr int kRowLen = 14;      // staged Jacobian row: Ji(6) Jj(6) r Jl
-constexpr int kSlotStride = 29;  // doubles per staged factor: two rows of 14 + 1 pad (odd stride: conflict-free LDS writes)
+constexpr int kRowLen = 14;      // marginalization phase: staged Jacobian row Ji(6) Jj(6) r Jl
+constexpr int kSlotStride = 29;  // marginalization phase: two rows of 14 + 1 pad (odd stride: conflict-free LDS writes)
+// Solver: a staged row is [Ji(6) | Jj(3..5) | r]: the translation part of the target frame's Jacobian is the negated
+// translation part of the host's (projection_facor.cpp:52-73: both are reduce * r_ic^T R_j^T up to the sign) and is
+// rebuilt by the operand fetch of the Gram product; the landmark column only feeds per-landmark sums that the factor
+// threads form themselves. 21 doubles per factor instead of 29: fewer, larger staging chunks.
+constexpr int kGRow = 10;
+constexpr int kGSlot = 2 * kGRow + 1;
 
 // One element D[row][col] of a (host,target) bucket's Gram matrix G^T G, G = [Ji(6) | Jj(6) | r | Jl | 0 0] per row:
 // host-host, target-target and target-host 6x6 blocks go to the pose-pose accumulator PP, row 12 is J^T r.
@@ -1212,7 +1231,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
   auto G = w.App;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
-  const int CH = (w.nstage / kSlotStride) & ~1;
+  const int CH = (w.nstage / kGSlot) & ~1;
   // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
   // are gathered with LDS atomics by the factor threads themselves. The six components of w_h use six F-vectors that
   // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
@@ -1232,12 +1251,14 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       double sum = 1.0 + sq * cc;
       cost += 0.5 * bb * log(sum);
       double sr = rsqrt_f(sum);  // Corrector: rho'' < 0 => scale by sqrt(rho') = 1 / sqrt(1 + s / b)   (sum >= 1)
-      auto g = G + slot * kSlotStride;
+      auto g = G + slot * kGSlot;
 #pragma unroll
       for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) g[rr * kRowLen + c] = Ji[rr * 6 + c] * sr, g[rr * kRowLen + 6 + c] = Jj[rr * 6 + c] * sr;
-        g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
+        for (int c = 0; c < 6; c++) g[rr * kGRow + c] = Ji[rr * 6 + c] * sr;
+#pragma unroll
+        for (int c = 3; c < 6; c++) g[rr * kGRow + 3 + c] = Jj[rr * 6 + c] * sr;
+        g[rr * kGRow + 9] = r[rr] * sr;
       }
       // target-frame coupling w_t = Jj^T Jl: one writer per (feature, frame)
       const double s2 = sr * sr;
@@ -1291,25 +1312,28 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
         if (s_lo >= s_hi) continue;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
-        const bool lv = li < kRowLen;  // operand columns 14, 15 of the 16-wide tile are zero
-        auto g = G + (s_lo - c0 + (kq >> 1)) * kSlotStride + (kq & 1) * kRowLen + (lv ? li : 0);
+        // column li of G = [Ji | Jj | r]: staged entry and sign (columns 13..15 of the 16-wide tile are zero)
+        const bool lv = li < 13;
+        const int src = li < 6 ? li : li < 9 ? li - 6 : li < 12 ? li - 3 : 9;
+        const double sg = (li >= 6 && li < 9) ? -1.0 : (lv ? 1.0 : 0.0);
+        auto g = G + (s_lo - c0 + (kq >> 1)) * kGSlot + (kq & 1) * kGRow + (lv ? src : 0);
         v4d acc2 = {0.0, 0.0, 0.0, 0.0};
         int steps = (s_hi - s_lo) >> 1;  // full two-factor steps; an odd last factor is a masked half step
-        for (; steps >= 4; steps -= 4, g += 8 * kSlotStride) {  // 4 steps per trip: loads first, two accumulators
-          double a0 = g[0], a1 = g[2 * kSlotStride], a2 = g[4 * kSlotStride], a3 = g[6 * kSlotStride];
-          a0 = lv ? a0 : 0.0, a1 = lv ? a1 : 0.0, a2 = lv ? a2 : 0.0, a3 = lv ? a3 : 0.0;
+        for (; steps >= 4; steps -= 4, g += 8 * kGSlot) {  // 4 steps per trip: loads first, two accumulators
+          double a0 = g[0], a1 = g[2 * kGSlot], a2 = g[4 * kGSlot], a3 = g[6 * kGSlot];
+          a0 *= sg, a1 *= sg, a2 *= sg, a3 *= sg;
           acc = mfma_f64(a0, a0, acc), acc2 = mfma_f64(a1, a1, acc2);
           acc = mfma_f64(a2, a2, acc), acc2 = mfma_f64(a3, a3, acc2);
         }
-        for (; steps > 0; steps--, g += 2 * kSlotStride) {
+        for (; steps > 0; steps--, g += 2 * kGSlot) {
           double a = *g;
-          a = lv ? a : 0.0;
+          a *= sg;
           acc = mfma_f64(a, a, acc);
         }
         if ((s_hi - s_lo) & 1) {  // lanes kq >= 2 would fetch the slot behind the bucket: never read, operand zero
           const bool half = lv && kq < 2;
           double a = G[half ? (int)(g - G) : 0];
-          a = half ? a : 0.0;
+          a = half ? a * sg : 0.0;
           acc = mfma_f64(a, a, acc);
         }
         acc += acc2;
@@ -1379,8 +1403,30 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     VIO_SYNC();
     cost += projections_jac(cx, v, w, pose, feat, have_scale);
     stamp(cx, ST_EVAL_PROJ);
-    VIO_PARFOR(q, (int)tri_doubles(v.nrows)) w.App[q] = 0.0;
-    VIO_PARFOR(q, 2 * v.P * kSS) w.Dss[q] = 0.0;  // (Css follows Dss)
+    const int napp = (int)tri_doubles(v.nrows), nband = 2 * v.P * kSS;
+    if (v.prior_n > 0) {
+      // the reduced matrix starts as the prior's H0 (constant during the solve, laid out once by setup_prior): a straight
+      // copy, ten loads in flight per lane, instead of zeroing followed by an element-wise scatter with index decoding
+      constexpr int kU = 10;
+      for (int q0 = VIO_TID(cx); q0 < napp + nband; q0 += kU * (int)cx.nt) {
+        double x[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const int q = q0 + u * (int)cx.nt;
+          x[u] = v.AppPr[q < napp + nband ? q : 0];
+        }
+        VIO_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          const int q = q0 + u * (int)cx.nt;
+          if (q < napp) w.App[q] = x[u];
+          else if (q < napp + nband) w.Dss[q - napp] = x[u];
+        }
+      }
+    } else {
+      VIO_PARFOR(q, napp) w.App[q] = 0.0;
+      VIO_PARFOR(q, nband) w.Dss[q] = 0.0;  // (Css follows Dss)
+    }
     VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
   }
   // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
@@ -1408,37 +1454,6 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
         const int pa = w.prcol[a];
         if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[a]);
       }
-      // H0 -> the reduced matrix: rows by wave, columns by lane, eight rows' loads in flight before the first store
-      // (one dependent global load per row otherwise: the phase is nothing but L2 latency)
-      const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
-      constexpr int kU = 8;
-      for (int b0 = 0; b0 < n; b0 += kLanes) {
-        const int b = b0 + lane;
-        const bool bok = b < n;
-        const int pb = w.prcol[bok ? b : 0];
-        for (int a0 = tid_ / kLanes; a0 < n; a0 += nwv * kU) {
-          double x[kU];
-#pragma unroll
-          for (int u = 0; u < kU; u++) {
-            const int a = a0 + u * nwv;
-            x[u] = v.prH0[(a < n && bok) ? a * n + b : 0];
-          }
-#ifndef VIO_EMUL
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-          for (int u = 0; u < kU; u++) {
-            const int a = a0 + u * nwv;
-            if (a < n && bok) {
-              const int pa = w.prcol[a];
-              // (speed-bias x pose entries of H0 are constant and live in WinView::Apri: setup_prior)
-              if (pa >= 0 && pb >= 0 && pa >= pb && ((pa & 255) >= 6) == ((pb & 255) >= 6))
-                red_put(v, w, pa >> 8, pa & 255, pb >> 8, pb & 255, x[u], false);
-            }
-          }
-        }
-      }
-      VIO_SYNC();
     }
     // pose-pose blocks of the projection factors: diagonal blocks from LDS, one off-diagonal block per bucket
     const int nF = v.P + v.has_loop;
@@ -1654,11 +1669,23 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
     auto A = w.AspI + (k * kSB + r) * kAW;
     double s3 = 0;
     for (int jj = 0; jj < aw; jj++) s3 = fma(A[jj], w.xt[alo + jj], s3);
-    if (w.sbr[2 * k + 1]) {
-      const double *Ap = v.Apri + (size_t)r * v.jp;
-      for (int j = 0; j < n6; j++) s3 = fma(Ap[j], w.xt[j], s3);
-    }
     acc = fma(ur, sacc + 2.0 * s3, acc);
+  }
+  // the prior's speed-bias x pose block (global): (component, strip of 16 columns) items, one fetch batch per item
+  VIO_PARFOR(q, kSB * v.nT) {
+    const int c = q / v.nT, j0 = 16 * (q - c * v.nT);
+    int kpr = -1;
+    for (int k = 0; k < P; k++)
+      if (w.sbr[2 * k + 1]) kpr = k;
+    if (kpr < 0) continue;
+    double xs[16], s3 = 0;
+    const double *Ap = v.Apri + (size_t)c * v.jp + j0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) xs[j] = Ap[j];  // (rows are jp = 16 nT long and zero outside the prior's poses)
+    VIO_SCHED_FENCE();
+#pragma unroll
+    for (int j = 0; j < 16; j++) s3 = fma(xs[j], j0 + j < n6 ? w.xt[j0 + j] : 0.0, s3);
+    acc = fma(2.0 * w.t1[kBS * kpr + 6 + c], s3, acc);
   }
   VIO_SYNC();  // tf complete
   VIO_PARFOR(f, F) {
@@ -2242,6 +2269,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   auto piv_of = [&](int I) { return n6 - 16 * I < 16 ? n6 - 16 * I : 16; };
   VIO_PARFOR(a, 16 * nT) x[a] = a < n6 ? w.App[tri_at(n6, a)] : 0.0;
   VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p below
+  VIO_PARFOR(q, P * kSB) w.t1[kBS * (q / kSB) + 6 + q % kSB] = w.gp[kBS * (q / kSB) + 6 + q % kSB];  // t_s = g_s - A_sp z_p below
   VIO_SYNC();
   int qc = lane >> 2, qp = lane & 3;  // lane = 4 c + p: the four lanes of a quad split a 16-term dot product
   // x_K <- L_KK^-T x_K: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
@@ -2294,17 +2322,29 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   }
   // z_p -> t1 (pose components), t_s = g_s - A_sp z_p -> t1 (speed-bias components)
   VIO_PARFOR(a, n6) w.t1[kBS * (a / 6) + a % 6] = x[a];
-  VIO_PARFOR(q, P * kSB) {
-    const int k = q / kSB, c = q - k * kSB;
-    const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
-    auto A = w.AspI + (k * kSB + c) * kAW;
-    double sacc = w.gp[kBS * k + 6 + c];
-    for (int jj = 0; jj < aw; jj++) sacc = fma(-A[jj], x[alo + jj], sacc);
-    if (w.sbr[2 * k + 1]) {
-      const double *Ap = v.Apri + (size_t)c * v.jp;
-      for (int j = 0; j < n6; j++) sacc = fma(-Ap[j], x[j], sacc);
+  VIO_PARFOR(q, P * kSB + kSB * nT) {
+    if (q < P * kSB) {  // the IMU chain's coupling (LDS)
+      const int k = q / kSB, c = q - k * kSB;
+      const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
+      auto A = w.AspI + (k * kSB + c) * kAW;
+      double sacc = 0.0;
+      for (int jj = 0; jj < aw; jj++) sacc = fma(A[jj], x[alo + jj], sacc);
+      VIO_ATOMIC_ADD(w.t1 + kBS * k + 6 + c, -sacc);
+    } else {  // the prior's block (global): (component, strip of 16 columns) items, one fetch batch each
+      const int qq = q - P * kSB, c = qq / nT, j0 = 16 * (qq - c * nT);
+      int kpr = -1;
+      for (int k = 0; k < P; k++)
+        if (w.sbr[2 * k + 1]) kpr = k;
+      if (kpr < 0) continue;
+      double xs[16], sacc = 0;
+      const double *Ap = v.Apri + (size_t)c * v.jp + j0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) xs[j] = Ap[j];
+      VIO_SCHED_FENCE();
+#pragma unroll
+      for (int j = 0; j < 16; j++) sacc = fma(xs[j], x[j0 + j], sacc);  // (x is zero past n6)
+      VIO_ATOMIC_ADD(w.t1 + kBS * kpr + 6 + c, -sacc);
     }
-    w.t1[kBS * k + 6 + c] = sacc;
   }
   VIO_SYNC();
   stamp(cx, ST_BACKSOLVE);
