@@ -77,6 +77,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     WorkT<double *> w = cw.w;
     Ctx cx;
     cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr;
+    cx.wrot = order % (nthreads / 64);  // (the device takes it from the hardware wave slot: every rotation must work)
     cx.red = cw.red, cx.lprof = cw.lprof;
     const size_t state_end = cw.state_end_doubles;
     if (lds_matrix && nthreads == 256) solve_window<true, 4>(cx, v, w);

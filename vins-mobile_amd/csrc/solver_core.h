@@ -144,6 +144,9 @@ struct Ctx {
   ldsd red;           // LDS scratch for block reductions: two halves of [3 nt/64]
   mutable int red_phase = 0;  // which half the next reduction writes (uniform across the block)
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
+  int wrot = 0;       // rotation of the wave ROLES in the serial phases: role = (wave + wrot) mod waves, role 0 runs the pivot
+                      // chains. Two workgroups share a CU and the hardware puts wave w of both on the same SIMD: with the
+                      // same roles the two chains would fight over one SIMD's matrix pipe while three stand idle.
   int prof_tid = 0;   // the work-item that keeps the stage clock (0; another wave's first lane to time what wave 0 does not run)
   VIO_AS3 long long *lprof;  // the same counters while the kernel runs (LDS); copied to prof at the end
 };
@@ -1977,7 +1980,7 @@ VIO_DEV void panel_step_regs(const Ctx &cx, const WinView &v, WK &w, int k, int 
   VIO_SCHED_FENCE();
   if (k < v.W) mask_op9(li, kq, e);
   mask_linv9(li, kq, linv);
-  if (cx.prof_tid) {
+  if (cx.prof) {
     double probe = linv[0] + e[0] + gr[0] + X[NT - 1].x[0] + X[NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D4);
@@ -1995,7 +1998,7 @@ VIO_DEV void panel_step_regs(const Ctx &cx, const WinView &v, WK &w, int k, int 
     for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
     V[t].x[0] = Vn[0], V[t].x[1] = Vn[1], V[t].x[2] = Vn[2];
   }
-  if (cx.prof_tid) stamp(cx, ST_D0);
+  stamp(cx, ST_D0);
 #pragma unroll
   for (int I = 0; I < NT; I++)
 #pragma unroll
@@ -2008,7 +2011,7 @@ VIO_DEV void panel_step_regs(const Ctx &cx, const WinView &v, WK &w, int k, int 
         acc[q / NPW] = c;
       }
     }
-  if (cx.prof_tid) {
+  if (cx.prof) {
     double probe = acc[0][0] + acc[kAcc - 1][0];
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D1);
@@ -2062,7 +2065,7 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
   VIO_SCHED_FENCE();
   if (k < v.W) mask_op9(li, kq, e);
   mask_linv9(li, kq, linv);
-  if (cx.prof_tid) {
+  if (cx.prof) {
     double probe = linv[0] + e[0] + gr[0] + X[NT - 1].x[0] + X[NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D4);
@@ -2080,7 +2083,7 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
     for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
     V[t].x[0] = Vn[0], V[t].x[1] = Vn[1], V[t].x[2] = Vn[2];
   }
-  if (cx.prof_tid) stamp(cx, ST_D0);
+  stamp(cx, ST_D0);
 #pragma unroll
   for (int I = 0; I < NT; I++)
 #pragma unroll
@@ -2094,7 +2097,7 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
         acc[q / NPW] = c;
       }
     }
-  if (cx.prof_tid) {
+  if (cx.prof) {
     double probe = acc[0][0] + acc[kAcc - 1][0];
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D1);
@@ -2134,7 +2137,7 @@ VIO_DEV void panel_step_dispatch(const Ctx &cx, const WinView &v, WK &w, int k, 
 // Band + panel for pose matrices of up to NT tile rows, NW waves. false: a pivot of the band was <= 0.
 template <int NT, int NW, class WK>
 VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
+  const int tid_ = VIO_TID(cx), wave = (__builtin_amdgcn_readfirstlane(tid_ >> 6) + cx.wrot) & (NW - 1), lane = tid_ & 63;
   const int W = v.W;
   VTile V[NT];
 #pragma unroll
@@ -2148,7 +2151,7 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
     } else if (kp <= W) {
       flo = flo < w.sbr[2 * kp] ? flo : w.sbr[2 * kp];  // (0 for the block the prior keeps)
       panel_step_dispatch<NT, NW - 1>(cx, v, w, kp, flo >> 4, V, lane, wave - 1);
-      if (cx.prof_tid) stamp(cx, ST_D2);  // (clock on a panel wave: the rank-9 updates)
+      stamp(cx, ST_D2);  // (clock on a panel wave: the rank-9 updates)
     }
     VIO_SYNC_LDS();  // (band blocks, pose matrix and flags are all LDS)
     stamp(cx, ST_C_WAIT);
@@ -2211,7 +2214,7 @@ VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
 // Tiled right-looking Cholesky of App with the right-hand side row carried along. false: a pivot was <= 0.
 template <class WK>
 VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane0 = tid_ & 63;
+  const int tid_ = VIO_TID(cx), nw = cx.nt >> 6, wave = (__builtin_amdgcn_readfirstlane(tid_ >> 6) + cx.wrot) & (nw - 1), lane0 = tid_ & 63;
   const int nT = v.nT, nrows = v.nrows, n6 = v.n6;
   ldsd ldp = w.ldinv + kSB * v.P;
   auto tile = [&](int I, int J) { return w.App + tri_off(I) + 16 * J; };
@@ -2261,7 +2264,7 @@ VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
 // While wave 0 walks the band, the other waves accumulate w_f^T z_p of the landmark back-substitution into w.gnf.
 template <class WK>
 VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int tid_ = VIO_TID(cx), nw = cx.nt >> 6, wave = (__builtin_amdgcn_readfirstlane(tid_ >> 6) + cx.wrot) & (nw - 1), lane = tid_ & 63;
   const int nT = v.nT, n6 = v.n6, P = v.P, W = v.W, F = v.F;
   cldsd ldp = w.ldinv + kSB * P;
   ldsd x = w.xt;
@@ -2421,7 +2424,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
     // landmark back-substitution, first half: w_f^T z_p over (feature, part) items by the waves that do not walk the band
     int nparts, per;
     wt_parts((int)cx.nt - 64, F, n6, nparts, per);
-    for (int q = tid_ - 64; q < F * nparts; q += (int)cx.nt - 64) {
+    for (int q = 64 * (wave - 1) + lane; q < F * nparts; q += (int)cx.nt - 64) {
       const int part = q / F, f = q - part * F;
       const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
       double xs[kWStrip], sacc = 0;

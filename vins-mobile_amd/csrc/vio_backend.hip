@@ -39,6 +39,7 @@ struct MargPtrs {
   size_t s_ints, s_x0, s_J, s_r, s_scratch;
   long long *prof;  // [n][ST_COUNT] or null
   int prof_tid;     // work-item that keeps the stage clock (VIO_AMD_PROF_TID, default 0)
+  int wrot;         // wave-role rotation: -1 = from the hardware wave slot (default), else forced (VIO_AMD_WAVE_ROT)
 };
 
 // NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
@@ -57,6 +58,17 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
   cx.prof_tid = MP.prof_tid;
+  {
+    // which workgroup slot of its CU this workgroup occupies (HW_ID.TG_ID, bits 19:16): the second workgroup of a CU
+    // rotates its wave roles so that its pivot-chain wave sits on another SIMD than the first one's
+    if (threadIdx.x == 0) cw.w.flag[0] = (int)__builtin_amdgcn_s_getreg(0x1C04) & 3;
+    __syncthreads();
+    cx.wrot = MP.wrot >= 0 ? MP.wrot : (NT == 256 ? cw.w.flag[0] : 0);
+    __syncthreads();
+  }
+  // (the stage clock follows the chain wave: work-item 0 of role 0)
+  if (MP.prof_tid == 0) cx.prof_tid = ((NT / 64 - cx.wrot) & (NT / 64 - 1)) * 64;
+  else cx.prof_tid = (((MP.prof_tid >> 6) - cx.wrot) & (NT / 64 - 1)) * 64;
   cx.red = cw.red, cx.lprof = cw.lprof;
   const size_t state_end = cw.state_end_doubles;
   solve_window<LDS_MATRIX, NT / 64>(cx, v, w);
@@ -480,6 +492,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   MP.s_scratch = m_scr;
   MP.prof = nullptr;
   MP.prof_tid = getenv("VIO_AMD_PROF_TID") ? atoi(getenv("VIO_AMD_PROF_TID")) : 0;
+  MP.wrot = getenv("VIO_AMD_WAVE_ROT") ? atoi(getenv("VIO_AMD_WAVE_ROT")) : -1;
   if (be->profile) {
     int rcp = be->d_prof.ensure(N * ST_COUNT);
     if (rcp != VIO_OK) return rcp;
