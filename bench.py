@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
 
 
 def algorithmic_flops_per_solve(W, M, n_prior, iters, n_features=150):
@@ -99,7 +99,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sequences", type=int, default=256, help="independent sequences resident per GPU")
+    ap.add_argument("--sequences", type=int, default=512,
+                    help="independent sequences resident per GPU (512 = two windows per CU: the window kernel keeps two "
+                         "256-thread workgroups resident per CU; `resident_256` reports the one-window-per-CU batch too)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="contract line only (no secondary measurements)")
     ap.add_argument("--no-prior", action="store_true", help="aid: first-solve windows without a marginalization prior")
@@ -147,48 +149,58 @@ def main():
     windows = [uniq_w[s % len(uniq_w)].copy() for s in range(S)]
     n_prior = int(np.mean([w.prior.n if w.prior is not None else 0 for w in uniq_w]))
 
-    fe = frontend.FeatureTracker(cfg, n_seq=S)
-    fe.upload_frames(frames)
-    be = backend.WindowSolver(cfg, max_batch=S)
-    be.upload(windows)
-    pingpong = list(range(T)) + list(range(T - 2, 0, -1))  # consecutive frames stay adjacent in time
+    def run_resident(S_, steps, warmup, timed_barrier):
+        """One resident batch of S_ sequences per GPU through `steps` timed steps: (seconds, front-end ms, solver ms, stats)."""
+        fr = frames[:, :S_] if S_ <= S else None
+        ws = windows[:S_]
+        fe = frontend.FeatureTracker(cfg, n_seq=S_)
+        fe.upload_frames(np.ascontiguousarray(fr))
+        be = backend.WindowSolver(cfg, max_batch=S_)
+        be.upload(ws)
+        if world > 1:  # the contexts of this rank live on this rank's GPU (vio_amd.h, DEVICE BINDING)
+            assert be.device() == local_rank and fe.device() == local_rank, (be.device(), fe.device(), local_rank)
+        pingpong = list(range(T)) + list(range(T - 2, 0, -1))  # consecutive frames stay adjacent in time
+        # Both halves fill the chip on their own (the solver holds every CU's LDS), so running them back to back on one
+        # stream beats letting two streams interleave their kernels.
+        one = torch.cuda.Stream().cuda_stream if args.streams == 1 else None
 
-    # Both halves fill the chip on their own (the solver holds every CU's LDS), so running them back to back on one
-    # stream beats letting two streams interleave their kernels.
-    one = torch.cuda.Stream().cuda_stream if args.streams == 1 else None
+        def step(k):
+            publish = k % args.publish_every == 0
+            if args.only != "backend":
+                fe.step(pingpong[k % len(pingpong)], publish=publish, stream=one)
+            if args.only != "frontend" and publish:
+                be.launch(stream=one)
 
-    def step(k):
-        publish = k % args.publish_every == 0
-        if args.only != "backend":
-            fe.step(pingpong[k % len(pingpong)], publish=publish, stream=one)
-        if args.only != "frontend" and publish:
-            be.launch(stream=one)
+        for k in range(warmup):
+            step(k)
+        torch.cuda.synchronize()
+        fe.kernel_ms(), be.kernel_ms()
+        if dist and timed_barrier:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        torch.cuda.synchronize()
+        if dist and timed_barrier:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        fe_ms_, _ = fe.kernel_ms()
+        be_ms_, _ = be.kernel_ms()
+        stats_ = be.download(ws)
+        fe.close(), be.close()
+        return dt_, max(fe_ms_, 1e-9), max(be_ms_, 1e-9), stats_
 
-    for k in range(args.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    fe.kernel_ms(), be.kernel_ms()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, fe_ms, be_ms, stats = run_resident(S, args.steps, args.warmup, True)
     if dist:
         dt = pkg.multi.max_over_ranks(dist, dt, device="cuda")
-
-    fe_ms, _ = fe.kernel_ms()
-    be_ms, _ = be.kernel_ms()
-    fe_ms, be_ms = max(fe_ms, 1e-9), max(be_ms, 1e-9)
-    stats = be.download(windows)
     iters = float(np.mean([s["iterations"] - 1 for s in stats]))
     M = float(np.mean([w.n_factors for w in windows]))
-    fe.close(), be.close()
+
+    multi_gpu = None
+    if dist:
+        multi_gpu = multi_gpu_proof(pkg, dist, cfg, windows, my_ids, pre, rank, local_rank, world)
 
     if rank == 0:
         frames_total = S * world * args.steps
@@ -216,20 +228,32 @@ def main():
                          "frac": achieved / FP64_PEAK_TFLOPS,
                          "flops_per_solve": flops / S, "traffic": be_traffic,
                          "traffic_unit": "bytes per launch; " + (be_src or "no PMC summary for this workload under profiles/")},
-            "roofline_frontend": {"kernel": "front-end step (pyr_down x3 + lk_track + track_update + detect + corner_select)",
+            "roofline_frontend": {"kernel": "front-end step (copy_frames + pyr_down x3 + lk_track + track_update + detect + corner_select)",
                                   "bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": fe_traffic,
                                   "traffic_unit": "bytes per step; " + (fe_src or "no PMC summary for this workload under profiles/")},
         }
+        if multi_gpu is not None:
+            out["multi_gpu"] = multi_gpu
         extras = world == 1 and args.only == "both" and not args.quick
         if world == 1 and not args.no_cpu_baseline:
             base = CpuBaseline(cfg, abi, uniq_frames, uniq_w)
-            out["cpu_baseline"] = base.one_core(seconds=5.0)
+            out["cpu_baseline"] = base.one_core(warmup_frames=20, frames=200)
             if extras:
                 out["cpu_baseline_all_cores"] = base.all_cores(seconds=6.0)
         if extras:
-            out["end_to_end"] = guarded(lambda: end_to_end(S))
+            if S != 256:
+                def at_256():
+                    dt2, fe2, be2, _ = run_resident(256, args.steps, args.warmup, False)
+                    fl = algorithmic_flops_per_solve(cfg.window_size, M, n_prior, iters) * 256
+                    return {"sequences_per_gpu": 256, "value": 256 * args.steps / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
+                            "kernel_ms": {"frontend_step": fe2, "window_solve": be2},
+                            "roofline_frac_window_kernel": fl / (be2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                            "note": "one window per CU: the second resident workgroup of every CU stays empty"}
+                out["resident_256"] = guarded(at_256)
+            out["small_batches"] = guarded(lambda: small_batches(cfg, pkg, windows))
+            out["end_to_end"] = guarded(lambda: end_to_end(min(S, 256)))
             out["ate"] = guarded(lambda: closed_loop_ate(cfg, pkg))
             out["large_windows"] = guarded(lambda: large_windows(pkg))
             out["loop_closure"] = guarded(lambda: loop_closure(pkg))
@@ -258,29 +282,33 @@ class CpuBaseline:
         self.kind = "reference" if ref is not None else "port"
         self.solve = abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
 
-    def _worker(self, idx, seconds, out):
+    def _worker(self, idx, seconds, out, warmup_frames=0, frames=None):
+        """Runs for `seconds`, or -- when `frames` is given -- for exactly that many frames after `warmup_frames` untimed ones."""
         H, abi = self.H, self.abi
         trk = H.OracleTracker(self.cfg)
         stream = self.streams[idx % len(self.streams)]
         order = [0, 1, 2, 3, 2, 1]
         trk.read_image(stream[0], True)
-        n, t_fe, t_so = 0, 0.0, 0.0
+        n, t_fe, t_so, k = 0, 0.0, 0.0, 0
         t_end = time.perf_counter() + seconds
-        while time.perf_counter() < t_end:
+        while (n < frames) if frames is not None else (time.perf_counter() < t_end):
             t0 = time.perf_counter()
-            trk.read_image(stream[order[(n + 1) % len(order)]], True)
+            trk.read_image(stream[order[(k + 1) % len(order)]], True)
             t1 = time.perf_counter()
-            w = self.windows[(idx + n) % len(self.windows)].copy()
+            w = self.windows[(idx + k) % len(self.windows)].copy()
             st = abi.VioSolveStats()
             self.solve(C.byref(self.cfg), C.byref(w.struct()), C.byref(st))
             t2 = time.perf_counter()
+            k += 1
+            if k <= warmup_frames:
+                continue
             t_fe += t1 - t0
             t_so += t2 - t1
             n += 1
         trk.close()
         out[idx] = (n, t_fe, t_so)
 
-    def _run(self, threads, seconds):
+    def _run(self, threads, seconds, **kw):
         devnull = os.open(os.devnull, os.O_WRONLY)
         sys.stdout.flush()
         saved = os.dup(1)
@@ -288,7 +316,7 @@ class CpuBaseline:
         out = [None] * threads
         try:
             t0 = time.perf_counter()
-            ths = [threading.Thread(target=self._worker, args=(i, seconds, out)) for i in range(threads)]
+            ths = [threading.Thread(target=self._worker, args=(i, seconds, out), kwargs=kw) for i in range(threads)]
             [t.start() for t in ths]
             [t.join() for t in ths]
             wall = time.perf_counter() - t0
@@ -298,11 +326,12 @@ class CpuBaseline:
             os.close(devnull)
         return out, wall
 
-    def one_core(self, seconds):
-        out, _ = self._run(1, seconds)
+    def one_core(self, warmup_frames=20, frames=200):
+        """frames processed / wall time over >= 200 frames after 20 warm-up frames, one thread."""
+        out, _ = self._run(1, 0.0, warmup_frames=warmup_frames, frames=frames)
         n, t_fe, t_so = out[0]
         return {"value": n / (t_fe + t_so), "unit": "frames/s", "cores": 1, "kind": "port", "solve_kind": self.kind,
-                "sample": "%d published frames through the KLT restatement (%.1f ms each) + %d steady-state window solves incl. "
+                "sample": "after 20 warm-up frames: %d published frames through the KLT restatement (%.1f ms each) + %d steady-state window solves incl. "
                           "prior and marginalization through %s (%.1f ms each), one thread, %s" % (
                               n, t_fe / n * 1e3, n, "vendored Ceres 1.12 + VINS factors" if self.kind == "reference" else
                               "the C++ restatement", t_so / n * 1e3, cpu_model()),
@@ -337,6 +366,56 @@ def cpu_model():
     except OSError:
         pass
     return "unknown CPU"
+
+
+def multi_gpu_proof(pkg, dist, cfg, windows, my_ids, pre, rank, local_rank, world):
+    """Evidence that an N-GPU run is N independent replicas on N devices: every rank's device / PCI bus id, the
+    collective backend's world size, and the solved poses of each rank's first sequence gathered over RCCL and compared, on
+    rank 0, with a solve of the same sequences on rank 0's own GPU (same seeds -> same windows -> same poses)."""
+    import torch
+    be = pkg.backend.WindowSolver(cfg, max_batch=1)
+    mine = windows[0].copy()
+    be.solve([mine])
+    props = torch.cuda.get_device_properties(local_rank)
+    info = {"rank": rank, "local_rank": local_rank, "device": be.device(), "name": props.name,
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+            "first_sequence": int(my_ids[0])}
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+    poses = pkg.multi.all_gather_array(dist, np.asarray(mine.pose, np.float64).ravel(), device="cuda")
+    be.close()
+    if rank != 0:
+        return None
+    # rank 0 rebuilds the first sequence of every rank (seed = 42 + global id) and solves them on its own GPU
+    seeds = [pkg.multi.seed_of_sequence(i["first_sequence"]) for i in infos]
+    again = steady_state_windows(cfg, pkg, pre, seeds)
+    chk = pkg.backend.WindowSolver(cfg, max_batch=len(again))
+    chk.solve(again)
+    chk.close()
+    err = max(float(np.abs(np.asarray(a.pose).ravel() - p).max()) for a, p in zip(again, poses))
+    assert sorted(i["device"] for i in infos) == list(range(world)), infos
+    assert err < 1e-9, "gathered poses differ from a single-GPU solve of the same sequences: %g" % err
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": infos,
+            "gathered_first_sequence_poses_max_abs_diff_vs_rank0_solve": err,
+            "ownership": "global sequence id % world == rank (vins-mobile_amd/multi.py)"}
+
+
+def small_batches(cfg, pkg, windows):
+    """configs[3] read literally (8 sequences per GPU) and other launches that cannot fill the chip: window-kernel time."""
+    out = {}
+    for B in (1, 8, 64):
+        be = pkg.backend.WindowSolver(cfg, max_batch=B)
+        be.upload(windows[:B])
+        be.launch()
+        be.sync()
+        be.kernel_ms()
+        for _ in range(5):
+            be.launch()
+        be.sync()
+        ms, _ = be.kernel_ms()
+        be.close()
+        out["B=%d" % B] = {"kernel_ms": ms, "solves_per_s": B / (ms * 1e-3)}
+    return out
 
 
 # ---- secondary measurements ------------------------------------------------------------------------------------

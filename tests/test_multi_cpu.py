@@ -37,6 +37,12 @@ def test_two_rank_gloo_barrier_and_max(tmp_path):
         rate = m.aggregate_rate(dist, len(mine) * 10, 1.0 + rank)
         assert dt == float(world), dt
         assert abs(rate - 64 * 10 / world) < 1e-9, rate
+        # result poses of each rank's first sequence, gathered on every rank (bench.py multi_gpu_proof)
+        import numpy as np
+        poses = m.all_gather_array(dist, np.arange(77, dtype=np.float64) + 1000.0 * mine[0])
+        assert len(poses) == world
+        for r, p in enumerate(poses):
+            assert p.shape == (77,) and p[0] == 1000.0 * m.sequences_of_rank(64, r, world)[0] and p[76] == p[0] + 76
         dist.destroy_process_group()
         print("ok", rank)
     """ % H.ROOT))

@@ -1,8 +1,8 @@
 # Round profiling on the GPU box (gpurun): kernel trace, HBM counters (+ calibration), SQ counters, stage cycles.
-# usage: gpurun -- 'bash tools/profile_round.sh r02_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
+# usage: gpurun -- 'bash tools/profile_round.sh r03_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -x
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -25,9 +25,12 @@ python tools/rocpd_summary.py $(db kt) $O/kernel_trace.txt > /dev/null
 python tools/rocpd_pmc_summary.py $(db fetch) $(db write) > $O/pmc_hbm.txt 2>&1
 python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_calib.txt 2>&1
 for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
-python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 256 sequences, prior 75" \
+python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 512 sequences, prior 75" \
   --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
-python tools/time_backend.py 1 256 > $O/stage_cycles.txt 2>&1
+python tools/time_backend.py 1 256 512 1024 > $O/stage_cycles.txt 2>&1
+VIO_AMD_PROF_TID=64 python tools/time_backend.py 1 2>&1 | grep "stage cycles" | sed "s/^/clock on a panel wave: /" >> $O/stage_cycles.txt
+$R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
+$R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5

@@ -9,16 +9,35 @@
 """
 import argparse
 import json
-import re
 import sqlite3
 import sys
 
-FRONTEND = ["pyr_down_kernel", "lk_track_kernel", "track_update_kernel", "detect_kernel<false>", "corner_select_kernel", "copy_frames_kernel"]
+# kernels of one front-end step (bench.py's `roofline_frontend` label names the same set), matched by base name: the
+# demangled names carry template arguments (lk_track_kernel<1>, detect_kernel<false>)
+FRONTEND = ["copy_frames_kernel", "pyr_down_kernel", "lk_track_kernel", "track_update_kernel", "detect_kernel", "corner_select_kernel"]
+ONCE_PER_STEP = "corner_select_kernel"   # every bench step publishes: its dispatch count is the number of steps
 
 
 def short(name):
-    m = re.search(r"(\w+(?:<\w+>)?)\(", name)
-    return m.group(1) if m else name[:40]
+    """'void (anonymous namespace)::lk_track_kernel<1>(unsigned char const*, ...)' -> 'lk_track_kernel<1>'."""
+    name = name.replace("(anonymous namespace)::", "")
+    depth, end = 0, len(name)
+    for i, ch in enumerate(name):  # the argument list opens at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = i
+            break
+    head = name[:end]
+    cut = head.index("<") if "<" in head else len(head)
+    sp, ns = head.rfind(" ", 0, cut), head.rfind("::", 0, cut)
+    return head[max(sp + 1, ns + 2 if ns >= 0 else 0):]
+
+
+def base(name):
+    return name.split("<")[0]
 
 
 def load(path):
@@ -32,6 +51,15 @@ def load(path):
     return agg
 
 
+def by_base(agg, kernel_base, counter):
+    """All dispatches of every instantiation of a kernel."""
+    out = []
+    for (k, c), vs in agg.items():
+        if c == counter and base(k) == kernel_base:
+            out.extend(vs)
+    return out
+
+
 def text(paths):
     for path in paths:
         for (k, c), vs in sorted(load(path).items(), key=lambda t: -sum(t[1])):
@@ -39,15 +67,25 @@ def text(paths):
             print("%-28s %-22s calls=%4d avg=%14.1f min=%14.1f max=%14.1f full_batch_avg=%14.1f" % (k, c, len(vs), sum(vs) / len(vs), min(vs), max(vs), sum(big) / len(big)))
 
 
-def avg(agg, kernel, counter):
+def avg(agg, kernel_base, counter):
     """Mean over the full-size dispatches: the bench's set-up also launches the kernel on a handful of windows (the
     MARGIN_OLD solves that produce the priors), those stay out (anything below 80 % of the largest dispatch)."""
-    vs = agg.get((kernel, counter))
+    vs = by_base(agg, kernel_base, counter)
     if not vs:
         return None
     top = max(vs)
     vs = [v for v in vs if v >= 0.8 * top] or vs
     return sum(vs) / len(vs)
+
+
+def per_step(agg, kernel_base, counter):
+    """Sum over ALL dispatches of a front-end kernel divided by the number of steps (pyr_down runs three times per step on
+    three different level sizes: its dispatches are summed, not 3 x the largest)."""
+    vs = by_base(agg, kernel_base, counter)
+    steps = len(by_base(agg, ONCE_PER_STEP, counter))
+    if not vs or not steps:
+        return None, 0
+    return sum(vs) / steps, len(vs)
 
 
 def main():
@@ -77,7 +115,7 @@ def main():
                      "scaled by the factor measured on tools/microbench/pmc_calib (1 GiB streams, > Infinity Cache): 8 B/lane reads "
                      "for the f64 window kernel, 1 B/lane reads for the front-end, 8 B/lane writes",
            "calibration": calib}
-    wk = "vio_window_kernel<true>"
+    wk = "vio_window_kernel"
     f, w = avg(bf, wk, "FETCH_SIZE"), avg(bw, wk, "WRITE_SIZE")
     if f is not None and w is not None:
         out["vio_window_kernel"] = {"fetch_reported_bytes": f * 1024, "write_reported_bytes": w * 1024,
@@ -85,14 +123,15 @@ def main():
     fe_f = fe_w = 0.0
     per = {}
     for k in FRONTEND:
-        f, w = avg(bf, k, "FETCH_SIZE"), avg(bw, k, "WRITE_SIZE")
+        (f, nf), (w, nw) = per_step(bf, k, "FETCH_SIZE"), per_step(bw, k, "WRITE_SIZE")
         if f is None or w is None:
             continue
-        calls = 3 if k == "pyr_down_kernel" else 1   # three pyramid levels per step
-        per[k] = {"fetch_reported_bytes": f * 1024 * calls, "write_reported_bytes": w * 1024 * calls}
-        fe_f += f * 1024 * calls
-        fe_w += w * 1024 * calls
-    out["frontend_step"] = {"kernels": per, "bytes_per_launch": fe_f * f1 + fe_w * fw}
+        per[k] = {"fetch_reported_bytes_per_step": f * 1024, "write_reported_bytes_per_step": w * 1024, "dispatches": nf,
+                  "bytes_per_step": f * 1024 * f1 + w * 1024 * fw}
+        fe_f += f * 1024
+        fe_w += w * 1024
+    out["frontend_step"] = {"kernels": per, "steps": len(by_base(bf, ONCE_PER_STEP, "FETCH_SIZE")),
+                            "bytes_per_launch": fe_f * f1 + fe_w * fw}
     json.dump(out, open(a.json, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -48,6 +48,12 @@ class FeatureTracker:
         if rc != abi.VIO_OK:
             raise RuntimeError("%s failed rc=%d" % (what, rc))
 
+    def device(self):
+        """HIP device the tracker's contexts live on (vio_frontend_get_device)."""
+        d = C.c_int32(-1)
+        self._check(self.lib.vio_frontend_get_device(self._h, C.byref(d)), "get_device")
+        return d.value
+
     def read_images(self, frames, publish):
         """frames: uint8 [n_seq, rows, cols]. Returns a list (per sequence) of (ids int32[n], xyz float64[n,3])."""
         frames = np.ascontiguousarray(frames, np.uint8)

@@ -1,6 +1,7 @@
 """Replica-parallel helpers for the throughput mode (a trajectory does not shard; independent sequences
-are partitioned over one process per GPU). No data-path collective: only a barrier and a max-over-ranks of the step
-time, over RCCL on GPUs (backend "nccl") or gloo in CPU tests."""
+are partitioned over one process per GPU: global sequence id % world == rank). No data-path collective: a barrier, a
+max-over-ranks of the step time and -- as evidence that the replicas computed what one GPU computes -- an all_gather of
+each rank's result poses of one sequence, over RCCL on GPUs (backend "nccl") or gloo in CPU tests."""
 
 
 def sequences_of_rank(n_total, rank, world):
@@ -26,3 +27,14 @@ def aggregate_rate(dist, local_units, seconds, device="cpu"):
     u = torch.tensor([float(local_units)], dtype=torch.float64, device=device)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item()) / max_over_ranks(dist, seconds, device)
+
+
+def all_gather_array(dist, arr, device="cpu"):
+    """Every rank's 1-D float64 array (same length on all ranks) on every rank: the result poses of a sequence are a few
+    hundred bytes (gather / all_gather of P x 7 poses + stats per sequence)."""
+    import numpy as np
+    import torch
+    t = torch.as_tensor(np.asarray(arr, np.float64), device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().numpy() for o in out]
