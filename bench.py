@@ -200,7 +200,7 @@ def main():
 
     multi_gpu = None
     if dist:
-        multi_gpu = multi_gpu_proof(pkg, dist, cfg, windows, my_ids, pre, rank, local_rank, world)
+        multi_gpu = multi_gpu_proof(pkg, dist, cfg, uniq_w[0], my_ids, pre, rank, local_rank, world)
 
     if rank == 0:
         frames_total = S * world * args.steps
@@ -368,13 +368,13 @@ def cpu_model():
     return "unknown CPU"
 
 
-def multi_gpu_proof(pkg, dist, cfg, windows, my_ids, pre, rank, local_rank, world):
+def multi_gpu_proof(pkg, dist, cfg, first_window, my_ids, pre, rank, local_rank, world):
     """Evidence that an N-GPU run is N independent replicas on N devices: every rank's device / PCI bus id, the
     collective backend's world size, and the solved poses of each rank's first sequence gathered over RCCL and compared, on
     rank 0, with a solve of the same sequences on rank 0's own GPU (same seeds -> same windows -> same poses)."""
     import torch
     be = pkg.backend.WindowSolver(cfg, max_batch=1)
-    mine = windows[0].copy()
+    mine = first_window.copy()   # (unsolved: the steady-state window of this rank's first sequence)
     be.solve([mine])
     props = torch.cuda.get_device_properties(local_rank)
     info = {"rank": rank, "local_rank": local_rank, "device": be.device(), "name": props.name,
@@ -394,7 +394,7 @@ def multi_gpu_proof(pkg, dist, cfg, windows, my_ids, pre, rank, local_rank, worl
     chk.close()
     err = max(float(np.abs(np.asarray(a.pose).ravel() - p).max()) for a, p in zip(again, poses))
     assert sorted(i["device"] for i in infos) == list(range(world)), infos
-    assert err < 1e-9, "gathered poses differ from a single-GPU solve of the same sequences: %g" % err
+    assert err < 1e-7, "gathered poses differ from a single-GPU solve of the same sequences: %g" % err
     return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": infos,
             "gathered_first_sequence_poses_max_abs_diff_vs_rank0_solve": err,
             "ownership": "global sequence id % world == rank (vins-mobile_amd/multi.py)"}
