@@ -24,7 +24,8 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     if (win->factor_target[k] == win->window_size + 1) any_loop = true;
   HostBatch hb;
   hb.resize(make_dims(*cfg, win->window_size, win->n_features, win->n_factors, any_loop), 1);
-  int rc = pack_window(hb, 0, *win);
+  const bool lds_shape = pose_jp(hb.d) <= 16 * kPanelTiles && variant != 0;
+  int rc = pack_window(hb, 0, *win, false, order % 2 ? 0 : stage_chunk_slots(hb.d, lds_shape, nthreads));  // (with and without bucket alignment)
   if (rc != VIO_OK) return rc;
   const BatchStrides &s = hb.s;
   const double kNaN = std::numeric_limits<double>::quiet_NaN();

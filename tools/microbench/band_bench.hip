@@ -11,7 +11,55 @@
 
 using namespace vio;
 
-enum { M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_COUNT };
+// experimental variants of potrf9_inv_wave: what does a pivot cost without the inverse accumulation / the Newton steps?
+template <bool WITH_E, bool NEWTON>
+__device__ __forceinline__ bool potrf9_variant(ldsd D, ldsd ldinv_k, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  v4d A, E;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    const bool ok = m < kSB && n < kSB;
+    const int hi = m > n ? m : n, lo = m > n ? n : m;
+    const double x = D[ok ? hi * kSB + lo : 0];
+    A[r] = ok ? x : 0.0;
+    E[r] = (m == n) ? 1.0 : 0.0;
+  }
+  double keep[3] = {0.0, 0.0, 0.0}, myinv = 0.0;
+  double dcc = lane_bcast(A[0], 0);
+#pragma unroll
+  for (int c = 0; c < kSB; c++) {
+    double y = __builtin_amdgcn_rsq(dcc);
+    if (NEWTON) {
+      const double h = 0.5 * dcc;
+      y = y * fma(-h * y, y, 1.5);
+      y = y * fma(-h * y, y, 1.5);
+    }
+    const bool sel = kq == (c & 3);
+    const double a = sel ? A[c >> 2] * y : 0.0;
+    const double e = sel ? E[c >> 2] * y : 0.0;
+    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+    myinv = (n == c) ? y : myinv;
+    if (c + 1 < kSB) {
+      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
+      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
+      dcc = fma(-lnext, lnext, dold);
+    }
+    A = mfma_f64(-a, a, A);
+    if (WITH_E) E = mfma_f64(-a, e, E);
+  }
+  if (n < kSB) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int c = kq + 4 * j;
+      if (c < kSB) D[n * kSB + c] = keep[j];
+    }
+    if (kq == 0) ldinv_k[n] = myinv;
+  }
+  return __builtin_amdgcn_ballot_w64(n < kSB && !(myinv > 0.0)) == 0;
+}
+
+enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_COUNT };
 static const char *kNames[M_COUNT] = {"potrf9 (no update)", "potrf9 + E update", "9x9 trsm (loads, 3 mfma, store)", "15 mfma, 5 accumulators x 3",
                                       "15 mfma, one accumulator", "5 tiles: acc load, 3 mfma, store", "potrf16 (16 pivots)",
                                       "9x9 mat-vec x2 by v_readlane", "dependent ds_read round trip"};
@@ -30,6 +78,9 @@ __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double 
     __syncthreads();
     if (wave == 0) {
       const long long t0 = clock64();
+      if (mode == M_V_NOE) potrf9_variant<false, true>(D, ldinv, lane);
+      if (mode == M_V_NONEWTON) potrf9_variant<true, false>(D, ldinv, lane);
+      if (mode == M_V_NEITHER) potrf9_variant<false, false>(D, ldinv, lane);
       if (mode == M_POTRF9) potrf9_inv_wave(D, E, false, ldinv, lane);
       if (mode == M_POTRF9_UPD) potrf9_inv_wave(D, E, true, ldinv, lane);
       if (mode == M_TRSM9) {
@@ -112,7 +163,7 @@ static void run(const double *dD, double *dout, long long *dcyc) {
   long long c = 0;
   hipDeviceSynchronize();
   hipMemcpy(&c, dcyc, sizeof(c), hipMemcpyDeviceToHost);
-  printf("%-40s %8lld cycles%s\n", kNames[mode], c, mode == M_LDS_RT ? " per 10" : "");
+  printf("%-40s %8lld cycles%s\n", mode >= 100 ? (mode == M_V_NOE ? "potrf9 without the L^-1 mfma" : mode == M_V_NONEWTON ? "potrf9 without Newton steps" : "potrf9 without either") : kNames[mode], c, mode == M_LDS_RT ? " per 10" : "");
 }
 
 int main() {
@@ -123,6 +174,7 @@ int main() {
   long long *dcyc;
   hipMalloc(&dD, 81 * 8), hipMalloc(&dout, 256 * 8), hipMalloc(&dcyc, 8);
   hipMemcpy(dD, D.data(), 81 * 8, hipMemcpyHostToDevice);
+  run<M_V_NOE>(dD, dout, dcyc), run<M_V_NONEWTON>(dD, dout, dcyc), run<M_V_NEITHER>(dD, dout, dcyc);
   run<M_POTRF9>(dD, dout, dcyc), run<M_POTRF9_UPD>(dD, dout, dcyc), run<M_TRSM9>(dD, dout, dcyc), run<M_MFMA_CHAIN15>(dD, dout, dcyc);
   run<M_MFMA_DEP15>(dD, dout, dcyc), run<M_TILE_RMW5>(dD, dout, dcyc), run<M_POTRF16>(dD, dout, dcyc), run<M_READLANE_MV>(dD, dout, dcyc);
   run<M_LDS_RT>(dD, dout, dcyc);

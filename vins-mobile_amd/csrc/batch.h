@@ -54,13 +54,17 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
 inline int pose_rows(const BatchDims &d) { return 6 * d.nblk_cap + 1; }
 inline int pose_jp(const BatchDims &d) { return (pose_rows(d) + 15) / 16 * 16; }
 
+// Staging slots of a window: its factors, one padding slot per (host, target) bucket (buckets start on even slots), and the
+// slots skipped so that no bucket straddles a staging chunk (pack_window): bounded by the factors once more.
+inline size_t slot_capacity(const BatchDims &d) { return 2 * (size_t)d.Mcap + d.pair_cap + 2; }
+
 // Element counts per window of every array (strides).
 struct BatchStrides {
   size_t pose, sb, ex, feat, fint, pts, preint, pr_int, pr_x0, pr_J, pr_r, fstart, pair;
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -81,10 +85,13 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
-  s.s_sfact = o, o += ((size_t)d.Mcap + d.pair_cap + 3) / 2;  // ints: staging slot -> factor
+  s.s_sfact = o, o += (slot_capacity(d) + 1) / 2;  // ints: staging slot -> factor
   s.s_Asp = o, o += (size_t)kSB * pose_jp(d);  // the prior's speed-bias x pose block
   s.s_AspG = o, o += (size_t)d.Pcap * kAS;
   s.s_AppPr = o, o += tri_doubles(pose_rows(d)) + 2 * (size_t)d.Pcap * kSS;
+  const size_t nslots_cap = slot_capacity(d);
+  s.s_srec_i = o, o += (nslots_cap + 1) / 2;
+  s.s_srec_d = o, o += 6 * nslots_cap;
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -153,6 +160,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
   v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
+  v.srec_i = reinterpret_cast<int *>(sc + B.s.s_srec_i), v.srec_d = sc + B.s.s_srec_d;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
@@ -262,6 +270,14 @@ VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd
   return c.bytes;
 }
 
+// Staging slots per pass of the Jacobian evaluation (projections_jac computes the same from the carved layout).
+inline int stage_chunk_slots(const BatchDims &d, bool lds_matrix, int nthreads) {
+  const Carved<double *> c = carve_all<double *>(d, lds_matrix, nthreads, nullptr, nullptr);
+  int ch = (c.w.nstage / kGSlot) & ~1;
+  if (ch >= nthreads) ch -= ch % nthreads;
+  return ch;
+}
+
 // ---- host-side staging ---------------------------------------------------------------------------------
 // Staging vectors live in page-locked memory in the device build (hipMemcpyAsync then runs at link speed and really is
 // asynchronous); the host emulation of the kernel (tests/emul, -DVIO_EMUL) uses plain vectors.
@@ -364,7 +380,10 @@ struct HostBatch {
 
 // Validates one window against the capacities and writes it into slot b. Returns VIO_OK / VIO_EINVAL / VIO_ECAP.
 // store_ok: the window names a valid slot of a reserved prior store, so a prior without data pointers is acceptable.
-inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok = false) {
+// chunk: staging slots per pass of the device's Jacobian evaluation (stage_chunk_slots), 0 = unknown. A bucket that would
+// straddle a multiple of it starts at the next one: every bucket's Gram product then ends in ONE plain store of its
+// off-diagonal pose block instead of a read-modify-write across two passes (a global round trip on the wave's path).
+inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok = false, int chunk = 0) {
   const BatchDims &d = hb.d;
   const BatchStrides &s = hb.s;
   const int W = w.window_size, P = W + 1, F = w.n_features, M = w.n_factors;
@@ -393,6 +412,9 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
         int c = cnt[(size_t)hh * np1 + tt];
         if (!c) continue;
         if (npairs >= d.pair_cap) return VIO_ECAP;
+        const int cpad = (c + 1) & ~1;
+        if (chunk > 0 && cpad <= chunk && slot % chunk + cpad > chunk) slot = (slot / chunk + 1) * chunk;
+        if ((size_t)slot + cpad > slot_capacity(d)) return VIO_ECAP;
         start[(size_t)hh * np1 + tt] = slot;
         hb.pair_h[b * s.pair + npairs] = hh, hb.pair_t[b * s.pair + npairs] = tt;
         hb.pair_s0[b * s.pair + npairs] = slot;

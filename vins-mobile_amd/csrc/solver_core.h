@@ -200,6 +200,8 @@ struct WinView {
   double *WT;        // [npose6][Fpad]  pose-major landmark coupling: the marginalization phase only (marg_core.h)
   double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
+  int *srec_i;       // staging slot -> host | target << 8 | landmark << 16 (-1: unused slot), built once per solve: the factor
+  double *srec_d;    // data in SLOT order ([slot][6] = pts_i, pts_j), one global round trip per evaluation pass instead of two
   double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
   double *AppPr;     // the prior's H0 scattered into the layout of App | Dss | Css once per solve (setup_prior): every
                      // linearization starts the reduced matrix as a straight copy of it instead of an element-wise scatter
@@ -375,6 +377,11 @@ VIO_DEV double block_max(const Ctx &cx, double v) {
 #endif
 }
 
+#if defined(VIO_HOST_BUILD)
+#define VIO_SCHED_FENCE() ((void)0)
+#else
+#define VIO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // W lives in global memory (L2): a dependent load costs ~3k cycles here, so the mat-vecs with W fetch a whole strip
 // (up to kWStrip entries, predicated) before the first multiply. Strided form: column f of WT (stride Fpad).
 constexpr int kWStrip = 24;
@@ -397,19 +404,22 @@ VIO_DEV void wt_parts(int nt, int F, int n6, int &nparts, int &per) {
 // neighbouring lanes on neighbouring columns (coalesced), a strip of k fetched at once, partial sums through add(c, s).
 template <class XP, class ADD>
 VIO_DEV void dense_matvec_cols(const Ctx &cx, const double *M, int n, XP x, ADD add) {
+  constexpr int kStrip = 32;  // rows an item fetches at once: 75 prior rows over 3 parts are ONE round trip per item
   int nparts = (int)cx.nt / (n > 0 ? n : 1);
-  const int need = (n + 4 * kWStrip - 1) / (4 * kWStrip);
+  const int need = (n + 4 * kStrip - 1) / (4 * kStrip);
   nparts = nparts < need ? need : (nparts > 8 ? 8 : nparts);
   const int per = (n + nparts - 1) / nparts;
   VIO_PARFOR(q, n * nparts) {
     const int part = q / n, c = q - part * n;
     const int k0 = part * per, k1 = k0 + per < n ? k0 + per : n;
-    double xs[kWStrip], s = 0;
-    for (int b0 = k0; b0 < k1; b0 += kWStrip) {
-      const int nb = k1 - b0 < kWStrip ? k1 - b0 : kWStrip;
-      wt_strip_load(M + (size_t)b0 * n + c, (size_t)n, nb, xs);
+    double xs[kStrip], s = 0;
+    for (int b0 = k0; b0 < k1; b0 += kStrip) {
+      const int nb = k1 - b0 < kStrip ? k1 - b0 : kStrip;
 #pragma unroll
-      for (int j = 0; j < kWStrip; j++) s += (j < nb ? xs[j] : 0.0) * x[b0 + (j < nb ? j : 0)];
+      for (int j = 0; j < kStrip; j++) xs[j] = M[(size_t)(b0 + (j < nb ? j : 0)) * n + c];
+      VIO_SCHED_FENCE();
+#pragma unroll
+      for (int j = 0; j < kStrip; j++) s += (j < nb ? xs[j] : 0.0) * x[b0 + (j < nb ? j : 0)];
     }
     if (k1 > k0) add(c, s);
   }
@@ -923,11 +933,6 @@ VIO_DEV double quad_sum_f64(double v) {
 // select that masks it, the next ds_read... -- one LDS latency (~120 cycles) per VALUE on the serial chains of the
 // factorization. The fetch helpers below therefore read raw (clamped addresses, nothing consumes the value), then a
 // scheduling fence, then mask: one latency per batch.
-#ifdef VIO_SIMT
-#define VIO_SCHED_FENCE() ((void)0)
-#else
-#define VIO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // ---- 9 x 9 speed-bias blocks (row-major, ld 9) in 16 x 16 register tiles --------------------------------------------
 // X[li][4 s + kq], zero outside the block (k-steps 0..2 cover k < 12)
@@ -1234,7 +1239,8 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
   auto G = w.App;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
-  const int CH = (w.nstage / kGSlot) & ~1;
+  int CH = (w.nstage / kGSlot) & ~1;
+  if (CH >= (int)cx.nt) CH -= CH % (int)cx.nt;  // whole rounds of the workgroup: no chunk ends in a nearly empty pass
   // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
   // are gathered with LDS atomics by the factor threads themselves. The six components of w_h use six F-vectors that
   // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
@@ -1244,12 +1250,15 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     stamp(cx, ST_P_ZERO);
     const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
     VIO_PARFOR(slot, nsl) {  // slot order: every lane of every wave has a factor (bar the odd tails)
-      const int k = v.sfact[c0 + slot];
-      if (k < 0) continue;
-      int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
+      const int rec = v.srec_i[c0 + slot];
+      double pij[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(c0 + slot) + c];
+      if (rec < 0) continue;
+      const int h = rec & 255, t = (rec >> 8) & 255, f = rec >> 16;
       double r[2], Ji[12], Jj[12], Jl[2];
       projection_eval_rot(v.s_info, w.rot + 9 * h, pose + 7 * h, w.rot + 9 * t, pose + 7 * t, w.rot + 9 * (v.P + 1), w.ex,
-                          feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj, Jl);
+                          feat[f], pij, pij + 3, true, r, Ji, Jj, Jl);
       double sq = r[0] * r[0] + r[1] * r[1];
       double sum = 1.0 + sq * cc;
       cost += 0.5 * bb * log(sum);
@@ -1322,17 +1331,21 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         auto g = G + (s_lo - c0 + (kq >> 1)) * kGSlot + (kq & 1) * kGRow + (lv ? src : 0);
         v4d acc2 = {0.0, 0.0, 0.0, 0.0};
         int steps = (s_hi - s_lo) >> 1;  // full two-factor steps; an odd last factor is a masked half step
-        for (; steps >= 4; steps -= 4, g += 8 * kGSlot) {  // 4 steps per trip: loads first, two accumulators
-          double a0 = g[0], a1 = g[2 * kGSlot], a2 = g[4 * kGSlot], a3 = g[6 * kGSlot];
-          a0 *= sg, a1 *= sg, a2 *= sg, a3 *= sg;
-          acc = mfma_f64(a0, a0, acc), acc2 = mfma_f64(a1, a1, acc2);
-          acc = mfma_f64(a2, a2, acc), acc2 = mfma_f64(a3, a3, acc2);
+        for (; steps > 0; steps -= 8, g += 16 * kGSlot) {  // up to 8 steps per trip: every fetch ahead of the first product
+          double a[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) a[j] = g[(j < steps ? 2 * j : 0) * kGSlot];
+          VIO_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            if (j < steps) {  // (uniform)
+              const double x = a[j] * sg;
+              if (j & 1) acc2 = mfma_f64(x, x, acc2);
+              else acc = mfma_f64(x, x, acc);
+            }
+          }
         }
-        for (; steps > 0; steps--, g += 2 * kGSlot) {
-          double a = *g;
-          a *= sg;
-          acc = mfma_f64(a, a, acc);
-        }
+        g += 2 * kGSlot * steps;  // (steps <= 0: back to the slot behind the last full step)
         if ((s_hi - s_lo) & 1) {  // lanes kq >= 2 would fetch the slot behind the bucket: never read, operand zero
           const bool half = lv && kq < 2;
           double a = G[half ? (int)(g - G) : 0];
@@ -1491,7 +1504,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     }
     VIO_SYNC();
   }
-  if (jac) stamp(cx, ST_IMU_RAW);
+  stamp(cx, jac ? ST_IMU_RAW : ST_D0);
   VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
     int f = q / 15, r = q % 15;
     const double *info = v.imu_info + f * 225 + r * 15;
@@ -1555,15 +1568,34 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     VIO_SYNC();
     stamp(cx, ST_EVAL_IMU);
   } else {
+    stamp(cx, ST_D1);
     // ---- projection factors, cost only: CauchyLoss rho = b log(1 + s / b) (CSI/loss_function.cc:72-79) ----------
     const double bb = v.cauchy_b, cc = 1.0 / bb;
-    VIO_PARFOR(k, v.M) {
-      int h = v.fhost[k], t = v.ftarget[k], f = v.ffeat[k];
-      double r[2];
-      projection_eval_rot(v.s_info, w.rot + 9 * h, pose + 7 * h, w.rot + 9 * t, pose + 7 * t, w.rot + 9 * (v.P + 1), w.ex,
-                          feat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, false, r, nullptr, nullptr, nullptr);
-      cost += 0.5 * bb * log(1.0 + (r[0] * r[0] + r[1] * r[1]) * cc);
+    // slot order (the records built once per solve), the fetch of the next pass in flight while this one is evaluated:
+    // a pass is otherwise one global round trip (thousands of cycles) followed by a few hundred cycles of arithmetic
+    int sl = VIO_TID(cx);
+    int rec = sl < v.nslots ? v.srec_i[sl] : -1;
+    double pij[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(sl < v.nslots ? sl : 0) + c];
+    while (sl < v.nslots) {
+      const int nx = sl + (int)cx.nt;
+      const int rec_n = nx < v.nslots ? v.srec_i[nx] : -1;
+      double pn[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) pn[c] = v.srec_d[6 * (size_t)(nx < v.nslots ? nx : 0) + c];
+      if (rec >= 0) {
+        const int h = rec & 255, t = (rec >> 8) & 255, f = rec >> 16;
+        double r[2];
+        projection_eval_rot(v.s_info, w.rot + 9 * h, pose + 7 * h, w.rot + 9 * t, pose + 7 * t, w.rot + 9 * (v.P + 1), w.ex,
+                            feat[f], pij, pij + 3, false, r, nullptr, nullptr, nullptr);
+        cost += 0.5 * bb * log(1.0 + (r[0] * r[0] + r[1] * r[1]) * cc);
+      }
+      sl = nx, rec = rec_n;
+#pragma unroll
+      for (int c = 0; c < 6; c++) pij[c] = pn[c];
     }
+    stamp(cx, ST_D2);
   }
   double total = block_sum(cx, cost);  // contains barriers
   if (jac) {
@@ -2757,7 +2789,15 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
 #endif
   VIO_PARFOR(q, v.nslots) v.sfact[q] = -1;
   VIO_SYNC();
-  VIO_PARFOR(k, v.M) v.sfact[v.fslot[k]] = k;
+  VIO_PARFOR(q, v.nslots) v.srec_i[q] = -1;
+  VIO_SYNC();
+  VIO_PARFOR(k, v.M) {
+    const int sl = v.fslot[k];
+    v.sfact[sl] = k;
+    v.srec_i[sl] = v.fhost[k] | (v.ftarget[k] << 8) | (v.ffeat[k] << 16);
+    double *d = v.srec_d + 6 * (size_t)sl;
+    for (int c = 0; c < 3; c++) d[c] = v.pts_i[3 * k + c], d[3 + c] = v.pts_j[3 * k + c];
+  }
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
   setup_imu_info(cx, v, w.App);
   stamp(cx, ST_SETUP_IMU);

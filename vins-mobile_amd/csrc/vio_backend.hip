@@ -347,9 +347,12 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   be->hb.resize(d, n, poison_staging);
   {
     std::vector<int> rcs(n, VIO_OK);
+    const bool lds_shape = pose_jp(d) <= 16 * kPanelTiles;
+    static const int thr_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
+    const int chunk = stage_chunk_slots(d, lds_shape, lds_shape ? thr_lds : kThreadsGlb);
     vio::HostPool::get().parallel_for(n, [&](int b) {
       try {
-        rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0);
+        rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0, chunk);
       } catch (const std::bad_alloc &) {  // (worker thread: must not unwind out of the pool)
         rcs[b] = VIO_ENOMEM;
       }
