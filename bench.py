@@ -588,6 +588,39 @@ def loop_closure(pkg, n_graphs=256):
         ex.close()
     out["brief_extract"] = {"keyframes_per_call": nkf, "image": "640x480", "fast_corners_per_frame": float(np.mean([r[2] for r in res])),
                             "window_points": 150, "ms_per_call_host_to_host": de * 1e3, "keyframes_per_s": nkf / de}
+    # ---- bag-of-words query (DBoW2): 64 keyframes x 1000 descriptors -> words + BowVectors, then 64 queries against a
+    # database of 512 keyframes; synthetic vocabulary in the app's file layout (k = 10, L = 5: the app's is k = 10, L = 6)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_dbow as TD
+    blob, desc = TD.make_vocabulary(10, 5, seed=3, flip=20)
+    voc = pkg.loop.BowVocabulary(blob=blob)
+    try:
+        n_inner = sum(10 ** l for l in range(5))
+        leaves = np.arange(n_inner, n_inner + 10 ** 5)
+        r2 = np.random.default_rng(5)
+        kfs = [TD.keyframe_descriptors(desc, leaves[:4000], r2, 890) for _ in range(8)]
+        kfs = [kfs[i % 8] for i in range(64)]
+        voc.transform(kfs)
+        t0 = time.perf_counter()
+        bows = voc.transform(kfs)
+        dtf = time.perf_counter() - t0
+        db = pkg.loop.BowDatabase(voc, max_entries=512, max_total_words=1 << 20)
+        try:
+            for e in range(512):
+                db.add(bows[e % 64][2], bows[e % 64][3])
+            q = [(b[2], b[3]) for b in bows]
+            db.query(q, [400] * 64, max_results=50)
+            t0 = time.perf_counter()
+            db.query(q, [400] * 64, max_results=50)
+            dq = time.perf_counter() - t0
+        finally:
+            db.close()
+    finally:
+        voc.close()
+    out["bow_query"] = {"vocabulary": "synthetic k=10 L=5 (111110 nodes), TF_IDF / L1_NORM", "keyframes_per_call": 64,
+                        "descriptors_per_keyframe": int(len(kfs[0])), "transform_ms_host_to_host": dtf * 1e3,
+                        "descriptors_per_s": 64 * len(kfs[0]) / dtf, "database_entries": 512, "queries_per_call": 64,
+                        "query_ms_host_to_host": dq * 1e3, "query_pairs_per_s": 64 * 400 / dq}
     out["search_by_des"] = {"pairs_per_launch": n_graphs, "queries": 150, "candidates": 500, "ms_per_call_host_to_host": dm * 1e3,
                             "descriptor_comparisons_per_s": n_graphs * 150 * 500 / dm}
     return out

@@ -378,6 +378,42 @@ int vio_loop_find_connection(vio_matcher_t *m, const VioConfig *cfg, int32_t n_c
                              float *matched_old_norm /* [n_cur][2] or NULL */,
                              uint8_t *status /* [n_cur] */, int32_t *n_inliers);
 
+/* Bag-of-words query (DBoW2 as LoopClosure::startLoopClosure drives it, loop/loop_closure.cpp:20-36 ->
+ * TemplatedLoopDetector::detectLoop, loop/TemplatedLoopDetector.h:668-700):
+ *   vocabulary file layout             loop/VocabularyBinary.hpp:17-50 (k, L, scoringType, weightingType, nNodes,
+ *                                      nWords; Node{nodeId, parentId, weight, descriptor[4]}; Word{nodeId, wordId}),
+ *                                      TemplatedVocabulary::loadBin  ThirdParty/DBoW/TemplatedVocabulary.h:1505-1554
+ *   TemplatedVocabulary::transform     TemplatedVocabulary.h:1213-1253 (descriptor -> word id, weight),
+ *                                      :1061-1117 (descriptors of a keyframe -> BowVector, L1-normalised)
+ *   TemplatedDatabase::add / query     ThirdParty/DBoW/TemplatedDatabase.h:439-470, 603-720 (queryL1)
+ * Only L1_NORM scoring (scoringType 0, the app's vocabulary) is implemented; other vocabularies are refused with
+ * VIO_EINVAL. Contexts are bound to the device current at creation.                                                  */
+typedef struct vio_vocabulary vio_vocabulary_t;
+int vio_vocabulary_create(const void *blob, size_t bytes, vio_vocabulary_t **out);  /* the file's bytes            */
+int vio_vocabulary_load(const char *path, vio_vocabulary_t **out);                  /* TemplatedVocabulary(filename) */
+void vio_vocabulary_destroy(vio_vocabulary_t *v);
+int vio_vocabulary_info(const vio_vocabulary_t *v, int32_t info[6]);  /* k, L, scoring, weighting, nodes, words */
+int vio_vocabulary_get_device(const vio_vocabulary_t *v, int32_t *device);
+/* transform for n_keyframes keyframes in one launch. desc: the keyframes' descriptors back to back (sum n_desc x 4
+ * words, vio_matcher_* layout; at most 8192 per keyframe). word_id / word_weight (optional): transform(feature, id, w)
+ * per descriptor. bow_*: the BowVector of keyframe f in [f * bow_stride, ...): bow_count[f] entries, ascending word id.
+ * VIO_ECAP when a keyframe has more distinct words than bow_stride (bow_count[f] = -(needed)).                        */
+int vio_vocabulary_transform(vio_vocabulary_t *v, int32_t n_keyframes, const int32_t *n_desc, const uint64_t *desc,
+                             int32_t *word_id, double *word_weight, int32_t *bow_count, int32_t *bow_word,
+                             double *bow_value, int32_t bow_stride);
+typedef struct vio_bow_database vio_bow_database_t;
+int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t max_total_words, vio_bow_database_t **out);
+void vio_bow_database_destroy(vio_bow_database_t *d);
+int vio_bow_database_size(const vio_bow_database_t *d, int32_t *n_entries);
+/* TemplatedDatabase::add(BowVector) -> entry id = number of entries before the call.                                  */
+int vio_bow_database_add(vio_bow_database_t *d, int32_t n, const int32_t *word, const double *value, int32_t *entry_id);
+/* TemplatedDatabase::query(BowVector, ret, max_results, max_id) for n_queries BowVectors in one launch: entries with
+ * id < max_id[q] (all if -1) that share a word with the query, best first, at most max_results (all if <= 0);
+ * score in [0, 1] = 1 - ||v - w||_1 / 2. Equal scores come out in ascending entry id.                                 */
+int vio_bow_database_query(vio_bow_database_t *d, int32_t n_queries, const int32_t *bow_count, const int32_t *bow_word,
+                           const double *bow_value, int32_t bow_stride, const int32_t *max_id, int32_t max_results,
+                           int32_t *n_results, int32_t *entry, double *score, int32_t result_stride);
+
 /* Keyframe descriptor extraction: BriefExtractor::operator() (loop/keyframe.cpp:395-409) =
  * cv::FAST(im, keys, 20, true); keys += window_pts; DVision::BRIEF::compute
  * (ThirdParty/DVision/BRIEF.cpp:40-105: GaussianBlur 9x9 sigma 2, then n_bits

@@ -1,0 +1,481 @@
+// vio_bow.hip — the bag-of-words query of the loop-closure producer: DBoW2 as the app uses it from
+// LoopClosure::startLoopClosure (VINS_ios/loop/loop_closure.cpp:20-36) -> TemplatedLoopDetector::detectLoop
+// (loop/TemplatedLoopDetector.h:668-700):
+//   * vocabulary in the app's binary layout      loop/VocabularyBinary.hpp:17-50, TemplatedVocabulary::loadBin
+//                                                ThirdParty/DBoW/TemplatedVocabulary.h:1505-1554
+//   * descriptor -> word                         TemplatedVocabulary::transform(feature, id, weight) :1213-1253: descend the
+//                                                k-ary tree, at every level the child with the smallest Hamming distance
+//                                                (FBrief::distance, ThirdParty/DBoW/FBrief.cpp:53-57), first one on ties
+//   * descriptors of a keyframe -> BowVector     transform(features, v) :1061-1117 (TF_IDF / TF accumulate the word's weight
+//                                                per occurrence, IDF / BINARY take it once) + BowVector::normalize(L1)
+//                                                (ThirdParty/DBoW/BowVector.cpp:57-80)
+//   * database add / query                       TemplatedDatabase::add :439-470, queryL1 :651-720 (L1 score of the query
+//                                                against every entry below max_id, best max_results)
+// Three kernels, many keyframes / queries per launch:
+//   bow_lookup_kernel   16 lanes per descriptor: every lane takes children (256-bit XOR + popcount), the key
+//                       distance << 20 | child position is min-reduced inside the 16-lane row; one tree level per
+//                       dependent global fetch, thousands of descriptors in flight
+//   bow_vector_kernel   one workgroup per keyframe: bitonic sort of the word ids in LDS, run heads -> unique words, the
+//                       value of a word by the reference's own sequence of additions, L1 norm summed in ascending word
+//                       order by one lane (the order of std::map iteration: bit-identical values)
+//   bow_score_kernel    one lane per (query, database entry): merge of two ascending word lists,
+//                       sum |q - d| - |q| - |d| over the common words in ascending word order (= the order in which
+//                       queryL1 walks the inverted file, so the sums are bit-identical); the database keeps every entry's
+//                       BowVector in HBM (the direct form of the inverted file)
+// The final sort / cut / scaling of queryL1 (a few hundred candidates) runs on the host inside the ABI call.
+// Scoring other than L1_NORM is refused (the app's vocabulary is TF_IDF / L1_NORM, DBoW2's defaults).
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "vio_amd.h"
+#include "vio_device.h"
+
+namespace {
+
+#define HIP_OK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      fprintf(stderr, "vio_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return VIO_ENODEV;                                                                   \
+    }                                                                                      \
+  } while (0)
+
+constexpr int kMaxBowFeatures = 8192;  // descriptors per keyframe the BowVector kernel sorts in LDS
+
+template <class T>
+struct Buf {
+  T *p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n && p) return VIO_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return VIO_ENOMEM;
+    n = count;
+    return VIO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+  }
+};
+
+// 16 lanes per descriptor, 4 descriptors per wave
+__global__ __launch_bounds__(256) void bow_lookup_kernel(const unsigned long long *node_desc, const double *node_weight, const int *node_word,
+                                                          const int *child_off, const int *child, const unsigned long long *desc,
+                                                          int n, int *word, double *weight) {
+  const int g = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
+  const bool have = g < n;
+  const unsigned long long *f = desc + 4 * (size_t)(have ? g : 0);
+  const unsigned long long f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+  int node = 0;
+  for (;;) {
+    const int c0 = child_off[node], nc = child_off[node + 1] - c0;
+    if (nc <= 0) break;  // leaf (every lane of the row walks the same path)
+    unsigned best = 0xffffffffu;
+    for (int c = l; c < nc; c += 16) {
+      const unsigned long long *d = node_desc + 4 * (size_t)child[c0 + c];
+      const unsigned dist = __popcll(f0 ^ d[0]) + __popcll(f1 ^ d[1]) + __popcll(f2 ^ d[2]) + __popcll(f3 ^ d[3]);
+      const unsigned key = (dist << 20) | (unsigned)c;  // smallest distance, first child on ties (`d < best_d`)
+      best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)best, m, 16);
+      best = o < best ? o : best;
+    }
+    node = child[c0 + (int)(best & 0xfffffu)];
+  }
+  if (have && l == 0) word[g] = node_word[node], weight[g] = node_weight[node];
+}
+
+// one workgroup per keyframe: its descriptors' (word, weight) -> ascending unique words with their L1-normalised values
+__global__ __launch_bounds__(256) void bow_vector_kernel(const int *kf_off, const int *word, const double *weight, const double *word_weight,
+                                                          int accumulate, int *bow_count, int *bow_word, double *bow_value, int stride) {
+  __shared__ int key[kMaxBowFeatures];
+  __shared__ int scan[257];
+  __shared__ double norm_s;
+  const int kf = blockIdx.x, o = kf_off[kf], n = kf_off[kf + 1] - o, tid = threadIdx.x, nt = blockDim.x;
+  int np2 = nt;
+  while (np2 < n) np2 <<= 1;
+  for (int i = tid; i < np2; i += nt) key[i] = (i < n && weight[o + i] > 0.0) ? word[o + i] : 0x7fffffff;  // stopped words drop out
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += nt) {
+        const int p = i ^ j;
+        if (p > i) {
+          const int a = key[i], b = key[p];
+          if (((i & k) == 0) == (a > b)) key[i] = b, key[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // heads of runs of equal words: every lane owns a contiguous piece of the sorted list
+  const int chunk = np2 / nt, i0 = tid * chunk;
+  int cnt = 0;
+  for (int i = i0; i < i0 + chunk; i++) cnt += key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1]);
+  scan[tid + 1] = cnt;
+  if (tid == 0) scan[0] = 0;
+  __syncthreads();
+  if (tid == 0)
+    for (int t = 0; t < nt; t++) scan[t + 1] += scan[t];
+  __syncthreads();
+  const int u = scan[nt];
+  int *ow = bow_word + (size_t)kf * stride;
+  double *ov = bow_value + (size_t)kf * stride;
+  if (u > stride) {  // caller's capacity too small: report the count, write nothing
+    if (tid == 0) bow_count[kf] = -u;
+    return;
+  }
+  int q = scan[tid];
+  for (int i = i0; i < i0 + chunk; i++) {
+    const int wd = key[i];
+    if (wd == 0x7fffffff || (i > 0 && wd == key[i - 1])) continue;
+    int i1 = i + 1;
+    while (i1 < np2 && key[i1] == wd) i1++;
+    // BowVector::addWeight adds the word's weight once per occurrence (in that order: w + w + ...), addIfNotExist keeps it once
+    const double wv = word_weight[wd];
+    double sv = wv;
+    if (accumulate)
+      for (int r = i + 1; r < i1; r++) sv += wv;
+    ow[q] = wd, ov[q] = sv;
+    q++;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double norm = 0.0;
+    for (int r = 0; r < u; r++) norm += fabs(ov[r]);  // ascending word order, like BowVector::normalize over the std::map
+    norm_s = norm;
+    bow_count[kf] = u;
+  }
+  __syncthreads();
+  const double norm = norm_s;
+  if (norm > 0.0)
+    for (int r = tid; r < u; r += nt) ov[r] /= norm;
+}
+
+// thread (e, q): sum over the common words of query q and database entry e; +1 = no common word / e >= max_id[q]
+__global__ __launch_bounds__(256) void bow_score_kernel(const int *db_off, const int *db_word, const double *db_value, int n_entries,
+                                                         const int *q_count, const int *q_word, const double *q_value, int q_stride,
+                                                         const int *max_id, double *raw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (e >= n_entries) return;
+  double s = 0.0;
+  bool any = false;
+  const int mid = max_id[q];
+  if (e < mid || mid == -1) {
+    const int *qw = q_word + (size_t)q * q_stride;
+    const double *qv = q_value + (size_t)q * q_stride;
+    int i = 0, j = db_off[e];
+    const int ni = q_count[q], nj = db_off[e + 1];
+    while (i < ni && j < nj) {
+      const int a = qw[i], b = db_word[j];
+      if (a == b) {
+        const double qq = qv[i], dd = db_value[j];
+        s += fabs(qq - dd) - fabs(qq) - fabs(dd);
+        any = true, i++, j++;
+      } else if (a < b) {
+        i++;
+      } else {
+        j++;
+      }
+    }
+  }
+  raw[(size_t)q * n_entries + e] = any ? s : 1.0;
+}
+
+}  // namespace
+
+struct vio_vocabulary {
+  int device = -1;
+  int32_t k = 0, L = 0, scoring = 0, weighting = 0, n_nodes = 0, n_words = 0;  // n_nodes incl. the root
+  hipStream_t stream = nullptr;
+  Buf<unsigned long long> d_desc;
+  Buf<double> d_weight, d_wweight;  // per node; per word
+  Buf<int> d_word, d_child_off, d_child;
+  // transform scratch
+  Buf<unsigned long long> t_desc;
+  Buf<int> t_word, t_off, t_bcount, t_bword;
+  Buf<double> t_weight, t_bvalue;
+};
+
+struct vio_bow_database {
+  vio_vocabulary *voc = nullptr;
+  int device = -1;
+  int max_entries = 0, n_entries = 0;
+  size_t max_words = 0, n_words = 0;
+  std::vector<int> h_off;  // [n_entries + 1]
+  Buf<int> d_off, d_word, q_count, q_word, q_max;
+  Buf<double> d_value, q_value, raw;
+};
+
+extern "C" {
+
+int vio_vocabulary_create(const void *blob, size_t bytes, vio_vocabulary_t **out) {
+  if (!blob || !out) return VIO_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    fprintf(stderr, "vio_amd: no HIP device visible; the bag-of-words query has no CPU fallback\n");
+    return VIO_ENODEV;
+  }
+  const unsigned char *p = (const unsigned char *)blob;
+  if (bytes < 24) return VIO_EINVAL;
+  int32_t hdr[6];
+  memcpy(hdr, p, 24);  // Vocabulary::staticDataSize(): k, L, scoringType, weightingType, nNodes, nWords
+  const int32_t nNodes = hdr[4], nWords = hdr[5];
+  if (nNodes < 1 || nWords < 1 || bytes < 24 + (size_t)nNodes * 48 + (size_t)nWords * 8) return VIO_EINVAL;
+  if (hdr[2] != 0) return VIO_EINVAL;                  // scoring: only L1_NORM (ScoringType 0) is implemented
+  if (hdr[3] < 0 || hdr[3] > 3) return VIO_EINVAL;     // weighting: TF_IDF, TF, IDF, BINARY
+  try {
+    const size_t N = (size_t)nNodes + 1;
+    std::vector<unsigned long long> desc(4 * N, 0);
+    std::vector<double> weight(N, 0.0);
+    std::vector<int> word(N, 0), parent(N, 0), cnt(N + 1, 0), order(nNodes);
+    const unsigned char *q = p + 24;
+    for (int i = 0; i < nNodes; i++, q += 48) {  // struct Node { int32 nodeId, parentId; double weight; uint64 descriptor[4]; }
+      int32_t nid, pid;
+      memcpy(&nid, q, 4), memcpy(&pid, q + 4, 4);
+      if (nid < 1 || nid > nNodes || pid < 0 || pid > nNodes) return VIO_EINVAL;
+      memcpy(&weight[nid], q + 8, 8);
+      memcpy(&desc[4 * (size_t)nid], q + 16, 32);
+      parent[nid] = pid, order[i] = nid, cnt[pid + 1]++;
+    }
+    for (size_t i = 0; i < N; i++) cnt[i + 1] += cnt[i];  // children of a node, in FILE order (loadBin pushes them back in that order)
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1), child(nNodes);
+    std::vector<double> wweight(nWords, 0.0);
+    for (int i = 0; i < nNodes; i++) child[fill[parent[order[i]]]++] = order[i];
+    for (int i = 0; i < nWords; i++, q += 8) {  // struct Word { int32 nodeId, wordId; }
+      int32_t nid, wid;
+      memcpy(&nid, q, 4), memcpy(&wid, q + 4, 4);
+      if (nid < 1 || nid > nNodes || wid < 0 || wid >= nWords) return VIO_EINVAL;
+      word[nid] = wid, wweight[wid] = weight[nid];
+    }
+    if (cnt[1] - cnt[0] < 1) return VIO_EINVAL;  // the root has no child: an empty vocabulary
+    vio_vocabulary *v = new vio_vocabulary();
+    v->device = vio::current_device();
+    v->k = hdr[0], v->L = hdr[1], v->scoring = hdr[2], v->weighting = hdr[3], v->n_nodes = (int32_t)N, v->n_words = nWords;
+    bool ok = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && v->d_desc.ensure(4 * N) == VIO_OK && v->d_weight.ensure(N) == VIO_OK && v->d_word.ensure(N) == VIO_OK &&
+         v->d_child_off.ensure(N + 1) == VIO_OK && v->d_child.ensure(nNodes) == VIO_OK && v->d_wweight.ensure(nWords) == VIO_OK;
+    ok = ok && hipMemcpy(v->d_desc.p, desc.data(), 32 * N, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_weight.p, weight.data(), 8 * N, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_word.p, word.data(), 4 * N, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_wweight.p, wweight.data(), 8 * (size_t)nWords, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_child_off.p, cnt.data(), 4 * (N + 1), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_child.p, child.data(), 4 * (size_t)nNodes, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+      vio_vocabulary_destroy(v);
+      return VIO_ENOMEM;
+    }
+    *out = v;
+    return VIO_OK;
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+}
+
+int vio_vocabulary_load(const char *path, vio_vocabulary_t **out) {
+  if (!path || !out) return VIO_EINVAL;
+  FILE *f = fopen(path, "rb");
+  if (!f) return VIO_EINVAL;
+  std::vector<unsigned char> blob;
+  try {
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 24) {
+      fclose(f);
+      return VIO_EINVAL;
+    }
+    blob.resize((size_t)sz);
+    const size_t got = fread(blob.data(), 1, blob.size(), f);
+    fclose(f);
+    if (got != blob.size()) return VIO_EINVAL;
+  } catch (const std::bad_alloc &) {
+    fclose(f);
+    return VIO_ENOMEM;
+  }
+  return vio_vocabulary_create(blob.data(), blob.size(), out);
+}
+
+void vio_vocabulary_destroy(vio_vocabulary_t *v) {
+  if (!v) return;
+  vio::DeviceScope scope(v->device);
+  if (v->stream) (void)hipStreamSynchronize(v->stream), (void)hipStreamDestroy(v->stream);
+  v->d_desc.release(), v->d_weight.release(), v->d_wweight.release(), v->d_word.release(), v->d_child_off.release(), v->d_child.release();
+  v->t_desc.release(), v->t_word.release(), v->t_off.release(), v->t_bcount.release(), v->t_bword.release();
+  v->t_weight.release(), v->t_bvalue.release();
+  delete v;
+}
+
+int vio_vocabulary_info(const vio_vocabulary_t *v, int32_t info[6]) {
+  if (!v || !info) return VIO_EINVAL;
+  info[0] = v->k, info[1] = v->L, info[2] = v->scoring, info[3] = v->weighting, info[4] = v->n_nodes - 1, info[5] = v->n_words;
+  return VIO_OK;
+}
+
+int vio_vocabulary_get_device(const vio_vocabulary_t *v, int32_t *device) {
+  if (!v || !device) return VIO_EINVAL;
+  *device = v->device;
+  return VIO_OK;
+}
+
+int vio_vocabulary_transform(vio_vocabulary_t *v, int32_t n_keyframes, const int32_t *n_desc, const uint64_t *desc, int32_t *word_id,
+                             double *word_weight, int32_t *bow_count, int32_t *bow_word, double *bow_value, int32_t bow_stride) {
+  if (!v || n_keyframes < 1 || !n_desc || !bow_count || !bow_word || !bow_value || bow_stride < 1) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(v);
+  try {
+    std::vector<int> off(n_keyframes + 1, 0);
+    for (int k = 0; k < n_keyframes; k++) {
+      if (n_desc[k] < 0) return VIO_EINVAL;
+      if (n_desc[k] > kMaxBowFeatures) return VIO_ECAP;
+      off[k + 1] = off[k] + n_desc[k];
+    }
+    const int total = off[n_keyframes];
+    if (total > 0 && !desc) return VIO_EINVAL;
+    if (v->t_desc.ensure(4 * (size_t)std::max(total, 1)) != VIO_OK || v->t_word.ensure(std::max(total, 1)) != VIO_OK ||
+        v->t_weight.ensure(std::max(total, 1)) != VIO_OK || v->t_off.ensure(n_keyframes + 1) != VIO_OK ||
+        v->t_bcount.ensure(n_keyframes) != VIO_OK || v->t_bword.ensure((size_t)n_keyframes * bow_stride) != VIO_OK ||
+        v->t_bvalue.ensure((size_t)n_keyframes * bow_stride) != VIO_OK)
+      return VIO_ENOMEM;
+    hipStream_t st = v->stream;
+    if (total > 0) HIP_OK(hipMemcpyAsync(v->t_desc.p, desc, 32 * (size_t)total, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(v->t_off.p, off.data(), 4 * (size_t)(n_keyframes + 1), hipMemcpyHostToDevice, st));
+    if (total > 0)
+      hipLaunchKernelGGL(bow_lookup_kernel, dim3((total * 16 + 255) / 256), dim3(256), 0, st, v->d_desc.p, v->d_weight.p, v->d_word.p,
+                         v->d_child_off.p, v->d_child.p, v->t_desc.p, total, v->t_word.p, v->t_weight.p);
+    const int accumulate = v->weighting == 0 || v->weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+    hipLaunchKernelGGL(bow_vector_kernel, dim3(n_keyframes), dim3(256), 0, st, v->t_off.p, v->t_word.p, v->t_weight.p, v->d_wweight.p, accumulate,
+                       v->t_bcount.p, v->t_bword.p, v->t_bvalue.p, bow_stride);
+    HIP_OK(hipGetLastError());
+    if (total > 0 && word_id) HIP_OK(hipMemcpyAsync(word_id, v->t_word.p, 4 * (size_t)total, hipMemcpyDeviceToHost, st));
+    if (total > 0 && word_weight) HIP_OK(hipMemcpyAsync(word_weight, v->t_weight.p, 8 * (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(bow_count, v->t_bcount.p, 4 * (size_t)n_keyframes, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(bow_word, v->t_bword.p, 4 * (size_t)n_keyframes * bow_stride, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(bow_value, v->t_bvalue.p, 8 * (size_t)n_keyframes * bow_stride, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int k = 0; k < n_keyframes; k++)
+      if (bow_count[k] < 0) return VIO_ECAP;  // (bow_count[k] = -(entries needed))
+    return VIO_OK;
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+}
+
+int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t max_total_words, vio_bow_database_t **out) {
+  if (!v || !out || max_entries < 1 || max_total_words < 1) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(v);
+  vio_bow_database *d = new (std::nothrow) vio_bow_database();
+  if (!d) return VIO_ENOMEM;
+  d->voc = v, d->device = v->device, d->max_entries = max_entries, d->max_words = (size_t)max_total_words;
+  try {
+    d->h_off.assign(1, 0);
+  } catch (const std::bad_alloc &) {
+    delete d;
+    return VIO_ENOMEM;
+  }
+  if (d->d_off.ensure((size_t)max_entries + 1) != VIO_OK || d->d_word.ensure(d->max_words) != VIO_OK || d->d_value.ensure(d->max_words) != VIO_OK) {
+    vio_bow_database_destroy(d);
+    return VIO_ENOMEM;
+  }
+  *out = d;
+  return VIO_OK;
+}
+
+void vio_bow_database_destroy(vio_bow_database_t *d) {
+  if (!d) return;
+  vio::DeviceScope scope(d->device);
+  (void)hipStreamSynchronize(d->voc->stream);
+  d->d_off.release(), d->d_word.release(), d->d_value.release(), d->q_count.release(), d->q_word.release(), d->q_max.release();
+  d->q_value.release(), d->raw.release();
+  delete d;
+}
+
+int vio_bow_database_size(const vio_bow_database_t *d, int32_t *n_entries) {
+  if (!d || !n_entries) return VIO_EINVAL;
+  *n_entries = d->n_entries;
+  return VIO_OK;
+}
+
+int vio_bow_database_add(vio_bow_database_t *d, int32_t n, const int32_t *word, const double *value, int32_t *entry_id) {
+  if (!d || n < 0 || (n > 0 && (!word || !value))) return VIO_EINVAL;
+  if (d->n_entries >= d->max_entries || d->n_words + (size_t)n > d->max_words) return VIO_ECAP;
+  for (int i = 0; i < n; i++)
+    if (word[i] < 0 || word[i] >= d->voc->n_words || (i > 0 && word[i] <= word[i - 1])) return VIO_EINVAL;  // a BowVector: ascending unique words
+  VIO_ON_DEVICE_OF(d);
+  hipStream_t st = d->voc->stream;
+  try {
+    d->h_off.push_back((int)(d->n_words + (size_t)n));
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+  if (n > 0) {
+    HIP_OK(hipMemcpyAsync(d->d_word.p + d->n_words, word, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d->d_value.p + d->n_words, value, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+  }
+  HIP_OK(hipMemcpyAsync(d->d_off.p + d->n_entries, d->h_off.data() + d->n_entries, 8, hipMemcpyHostToDevice, st));
+  HIP_OK(hipStreamSynchronize(st));  // (the caller's buffers are pageable)
+  if (entry_id) *entry_id = d->n_entries;
+  d->n_entries++, d->n_words += (size_t)n;
+  return VIO_OK;
+}
+
+int vio_bow_database_query(vio_bow_database_t *d, int32_t n_queries, const int32_t *bow_count, const int32_t *bow_word, const double *bow_value,
+                           int32_t bow_stride, const int32_t *max_id, int32_t max_results, int32_t *n_results, int32_t *entry, double *score,
+                           int32_t result_stride) {
+  if (!d || n_queries < 1 || !bow_count || !bow_word || !bow_value || bow_stride < 1 || !max_id || !n_results || !entry || !score ||
+      result_stride < 1)
+    return VIO_EINVAL;
+  for (int q = 0; q < n_queries; q++)
+    if (bow_count[q] < 0 || bow_count[q] > bow_stride) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(d);
+  const int N = d->n_entries;
+  if (N == 0) {
+    for (int q = 0; q < n_queries; q++) n_results[q] = 0;
+    return VIO_OK;
+  }
+  try {
+    if (d->q_count.ensure(n_queries) != VIO_OK || d->q_max.ensure(n_queries) != VIO_OK ||
+        d->q_word.ensure((size_t)n_queries * bow_stride) != VIO_OK || d->q_value.ensure((size_t)n_queries * bow_stride) != VIO_OK ||
+        d->raw.ensure((size_t)n_queries * N) != VIO_OK)
+      return VIO_ENOMEM;
+    hipStream_t st = d->voc->stream;
+    HIP_OK(hipMemcpyAsync(d->q_count.p, bow_count, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d->q_max.p, max_id, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d->q_word.p, bow_word, 4 * (size_t)n_queries * bow_stride, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d->q_value.p, bow_value, 8 * (size_t)n_queries * bow_stride, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bow_score_kernel, dim3((N + 255) / 256, n_queries), dim3(256), 0, st, d->d_off.p, d->d_word.p, d->d_value.p, N,
+                       d->q_count.p, d->q_word.p, d->q_value.p, bow_stride, d->q_max.p, d->raw.p);
+    HIP_OK(hipGetLastError());
+    std::vector<double> raw((size_t)n_queries * N);
+    HIP_OK(hipMemcpyAsync(raw.data(), d->raw.p, 8 * raw.size(), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    // the tail of queryL1 (TemplatedDatabase.h:696-719): ascending raw score (-2 best .. 0 worst), cut, scale to [0, 1]
+    std::vector<std::pair<double, int>> ret;
+    for (int q = 0; q < n_queries; q++) {
+      ret.clear();
+      for (int e = 0; e < N; e++) {
+        const double s = raw[(size_t)q * N + e];
+        if (s <= 0.0) ret.push_back(std::make_pair(s, e));
+      }
+      std::sort(ret.begin(), ret.end());  // (equal scores: ascending entry id; the reference's std::sort leaves them unspecified)
+      if (max_results > 0 && (int)ret.size() > max_results) ret.resize(max_results);
+      if ((int)ret.size() > result_stride) return VIO_ECAP;
+      n_results[q] = (int)ret.size();
+      for (size_t i = 0; i < ret.size(); i++) entry[(size_t)q * result_stride + i] = ret[i].second, score[(size_t)q * result_stride + i] = -ret[i].first / 2.0;
+    }
+    return VIO_OK;
+  } catch (const std::bad_alloc &) {
+    return VIO_ENOMEM;
+  }
+}
+
+}  // extern "C"

@@ -126,3 +126,125 @@ class BriefExtractor:
         if rc != abi.VIO_OK and not (allow_cut and rc == abi.VIO_ECAP):
             raise RuntimeError("vio_brief_extract failed rc=%d" % rc)
         return [(kp[f, :nk[f]].copy(), desc[f, :nk[f]].copy(), int(nf[f])) for f in range(n)]
+
+
+# ---- bag-of-words query (DBoW2: csrc/vio_bow.hip) ---------------------------------------------------------------------
+_f64p = C.POINTER(C.c_double)
+
+
+def make_vocabulary_blob(k, L, scoring, weighting, nodes, words):
+    """Bytes of a vocabulary in the app's binary layout (loop/VocabularyBinary.hpp): nodes = iterable of
+    (node_id, parent_id, weight, desc[4] uint64), words = iterable of (node_id, word_id)."""
+    import struct
+    nodes, words = list(nodes), list(words)
+    out = [struct.pack("<6i", k, L, scoring, weighting, len(nodes), len(words))]
+    for nid, pid, w, d in nodes:
+        out.append(struct.pack("<iid4Q", nid, pid, w, *[int(x) for x in d]))
+    for nid, wid in words:
+        out.append(struct.pack("<ii", nid, wid))
+    return b"".join(out)
+
+
+def bind_bow(lib):
+    vp = C.c_void_p
+    lib.vio_vocabulary_create.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    lib.vio_vocabulary_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.vio_vocabulary_destroy.argtypes = [vp]
+    lib.vio_vocabulary_destroy.restype = None
+    lib.vio_vocabulary_info.argtypes = [vp, _i32p]
+    lib.vio_vocabulary_get_device.argtypes = [vp, _i32p]
+    lib.vio_vocabulary_transform.argtypes = [vp, C.c_int32, _i32p, _u64p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_int32]
+    lib.vio_bow_database_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.vio_bow_database_destroy.argtypes = [vp]
+    lib.vio_bow_database_destroy.restype = None
+    lib.vio_bow_database_size.argtypes = [vp, _i32p]
+    lib.vio_bow_database_add.argtypes = [vp, C.c_int32, _i32p, _f64p, _i32p]
+    lib.vio_bow_database_query.argtypes = [vp, C.c_int32, _i32p, _i32p, _f64p, C.c_int32, _i32p, C.c_int32, _i32p, _i32p, _f64p, C.c_int32]
+    return lib
+
+
+class BowVocabulary:
+    """TemplatedVocabulary<FBrief> on the device: transform() for batches of keyframes."""
+
+    def __init__(self, blob=None, path=None):
+        self.lib = bind_bow(abi.load_product())
+        self._h = C.c_void_p()
+        rc = self.lib.vio_vocabulary_load(path.encode(), C.byref(self._h)) if path else \
+            self.lib.vio_vocabulary_create(blob, len(blob), C.byref(self._h))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_vocabulary_create failed rc=%d" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_vocabulary_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def info(self):
+        a = np.zeros(6, np.int32)
+        self.lib.vio_vocabulary_info(self._h, a.ctypes.data_as(_i32p))
+        return dict(zip(("k", "L", "scoring", "weighting", "nodes", "words"), [int(x) for x in a]))
+
+    def transform(self, desc_list, bow_stride=None):
+        """desc_list: per keyframe uint64 [n][4]. -> per keyframe (word_id[n], word_weight[n], bow_word[m], bow_value[m])."""
+        n_desc = np.array([len(d) for d in desc_list], np.int32)
+        desc = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint64).reshape(-1, 4) for d in desc_list] + [np.zeros((0, 4), np.uint64)]))
+        total = int(n_desc.sum())
+        stride = int(bow_stride or max(1, int(n_desc.max())))
+        wid, ww = np.zeros(max(1, total), np.int32), np.zeros(max(1, total), np.float64)
+        bc = np.zeros(len(desc_list), np.int32)
+        bw, bv = np.zeros((len(desc_list), stride), np.int32), np.zeros((len(desc_list), stride), np.float64)
+        rc = self.lib.vio_vocabulary_transform(self._h, len(desc_list), n_desc.ctypes.data_as(_i32p), desc.ctypes.data_as(_u64p),
+                                               wid.ctypes.data_as(_i32p), ww.ctypes.data_as(_f64p), bc.ctypes.data_as(_i32p),
+                                               bw.ctypes.data_as(_i32p), bv.ctypes.data_as(_f64p), stride)
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_vocabulary_transform failed rc=%d (bow_count %s)" % (rc, bc))
+        out, o = [], 0
+        for f, n in enumerate(n_desc):
+            out.append((wid[o:o + n].copy(), ww[o:o + n].copy(), bw[f, :bc[f]].copy(), bv[f, :bc[f]].copy()))
+            o += n
+        return out
+
+
+class BowDatabase:
+    """TemplatedDatabase<FBrief>: add(BowVector), query(BowVector, max_results, max_id) for batches of queries."""
+
+    def __init__(self, voc, max_entries=4096, max_total_words=1 << 22):
+        self.voc, self.lib = voc, voc.lib
+        self._h = C.c_void_p()
+        rc = self.lib.vio_bow_database_create(voc._h, max_entries, max_total_words, C.byref(self._h))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_bow_database_create failed rc=%d" % rc)
+
+    def close(self):
+        if self._h:
+            self.lib.vio_bow_database_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def add(self, word, value):
+        word, value = np.ascontiguousarray(word, np.int32), np.ascontiguousarray(value, np.float64)
+        e = C.c_int32(-1)
+        rc = self.lib.vio_bow_database_add(self._h, len(word), word.ctypes.data_as(_i32p), value.ctypes.data_as(_f64p), C.byref(e))
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_bow_database_add failed rc=%d" % rc)
+        return e.value
+
+    def query(self, bows, max_id, max_results=0):
+        """bows: per query (word[m], value[m]); max_id: per query. -> per query (entry[r], score[r]), best first."""
+        nq = len(bows)
+        stride = max(1, max(len(b[0]) for b in bows))
+        bc = np.array([len(b[0]) for b in bows], np.int32)
+        bw, bv = np.zeros((nq, stride), np.int32), np.zeros((nq, stride), np.float64)
+        for q, (w_, v_) in enumerate(bows):
+            bw[q, :len(w_)], bv[q, :len(v_)] = w_, v_
+        mid = np.ascontiguousarray(max_id, np.int32)
+        n = C.c_int32(0)
+        self.lib.vio_bow_database_size(self._h, C.byref(n))
+        rs = max(1, n.value)
+        nr = np.zeros(nq, np.int32)
+        ent, sc = np.zeros((nq, rs), np.int32), np.zeros((nq, rs), np.float64)
+        rc = self.lib.vio_bow_database_query(self._h, nq, bc.ctypes.data_as(_i32p), bw.ctypes.data_as(_i32p), bv.ctypes.data_as(_f64p), stride,
+                                             mid.ctypes.data_as(_i32p), max_results, nr.ctypes.data_as(_i32p), ent.ctypes.data_as(_i32p),
+                                             sc.ctypes.data_as(_f64p), rs)
+        if rc != abi.VIO_OK:
+            raise RuntimeError("vio_bow_database_query failed rc=%d" % rc)
+        return [(ent[q, :nr[q]].copy(), sc[q, :nr[q]].copy()) for q in range(nq)]
