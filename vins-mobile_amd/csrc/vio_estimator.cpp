@@ -547,7 +547,12 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
     // streams onto 4 queues by default; in a process that holds other streams — a torch process, say — four groups
     // alias, two of the kernels serialize and the frame gets slower than with one group: 36 k instead of 48 k solves/s).
     int ng = n_seq >= 64 ? 2 : 1;
-    if (const char *env = getenv("VIO_AMD_EST_GROUPS")) ng = atoi(env);
+    if (const char *env = getenv("VIO_AMD_EST_GROUPS")) {
+      char *end = nullptr;
+      const long val = strtol(env, &end, 10);
+      if (end == env || *end != '\0' || val < 1) fprintf(stderr, "vio_amd: VIO_AMD_EST_GROUPS=\"%s\" is not a positive number, ignored\n", env);
+      else ng = (int)std::min<long>(val, vio_estimator::kMaxGroups);
+    }
     ng = std::max(1, std::min(std::min(ng, (int)vio_estimator::kMaxGroups), n_seq));
     e->group_size = (n_seq + ng - 1) / ng;
     e->n_groups = (n_seq + e->group_size - 1) / e->group_size;
@@ -828,18 +833,22 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
       if (rc != VIO_OK) return fail_all(rc);
     }
     int rc = VIO_OK;
+    bool launched[vio_estimator::kMaxGroups] = {};
     for (int g = 0; g < e->n_groups && rc == VIO_OK; g++) {  // pack + H2D + launch, group after group (no device wait)
       const int ng = g0[g + 1] - g0[g];
       if (ng == 0) continue;
       rc = vio_backend_upload(e->be[g], e->windows.data() + g0[g], ng);
       if (rc == VIO_OK) rc = vio_backend_launch(e->be[g], nullptr);
+      launched[g] = rc == VIO_OK;
     }
-    for (int g = 0; g < e->n_groups; g++) {  // (every launched group is waited for, also after an error)
+    for (int g = 0; g < e->n_groups; g++) {  // (every LAUNCHED group is waited for, also after an error in a later group)
       const int ng = g0[g + 1] - g0[g];
-      if (ng == 0 || !e->be[g]) continue;
+      if (ng == 0 || !launched[g]) continue;
       int rd = vio_backend_download(e->be[g], e->windows.data() + g0[g], ng, e->stats.data() + g0[g]);
       if (rc == VIO_OK) rc = rd;
     }
+    // (a failed frame restarts every sequence of the call -- also those of groups whose launch went through: their prior
+    // slots have advanced, and clear_state drops the header that pointed at them, so the next prior starts from scratch)
     if (rc != VIO_OK) return fail_all(rc);
   }
   const auto t_solve = std::chrono::steady_clock::now();

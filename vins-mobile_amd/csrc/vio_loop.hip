@@ -135,11 +135,13 @@ int vio_matcher_search_by_des(vio_matcher_t *m, int32_t n_pairs, const int32_t *
                               const uint64_t *cur_desc, const uint64_t *old_desc, int32_t *best_index, int32_t *best_dist) {
   if (!m || n_pairs < 0 || (n_pairs > 0 && (!n_cur || !n_old || !best_index || !best_dist))) return VIO_EINVAL;
   if (n_pairs == 0) return VIO_OK;
+  if (n_pairs > 65535) return VIO_ECAP;  // (grid.y: one block row per pair)
   VIO_ON_DEVICE_OF(m);
-  std::vector<int> meta((size_t)4 * n_pairs);
+  std::vector<int> meta;
   long long tc = 0, to = 0;
   int max_cur = 0;
   try {
+    meta.resize((size_t)4 * n_pairs);
     for (int p = 0; p < n_pairs; p++) {
       if (n_cur[p] < 0 || n_old[p] < 0 || n_old[p] > 65535) return n_old[p] > 65535 ? VIO_ECAP : VIO_EINVAL;
       meta[p] = n_cur[p], meta[n_pairs + p] = n_old[p], meta[2 * n_pairs + p] = (int)tc, meta[3 * n_pairs + p] = (int)to;
@@ -178,8 +180,10 @@ int vio_loop_find_connection(vio_matcher_t *m, const VioConfig *cfg, int32_t n_c
                              float *matched_old_pts, float *matched_old_norm, uint8_t *status, int32_t *n_inliers) {
   if (!m || !cfg || n_cur < 0 || n_old < 0 || !status || !n_inliers || (n_cur > 0 && (!cur_desc || !cur_pts || !matched_old_pts)))
     return VIO_EINVAL;
+  if (n_old > 0 && (!old_desc || !old_pts)) return VIO_EINVAL;
   *n_inliers = 0;
   if (n_cur == 0) return VIO_OK;
+  VIO_ON_DEVICE_OF(m);  // (the RANSAC below runs on the matcher's device as well: vio_amd.h, DEVICE BINDING)
   std::vector<int> idx, dist;
   try {
     idx.resize(n_cur), dist.resize(n_cur);

@@ -491,11 +491,25 @@ int vio_posegraph_create(int32_t max_nodes, int32_t max_edges, int32_t n_graphs,
        pg->ej.ensure(G * max_edges) == VIO_OK && pg->ek.ensure(G * max_edges) == VIO_OK && pg->stats_i.ensure(G * kStatsInts) == VIO_OK &&
        pg->node0.ensure(G * max_nodes * 4) == VIO_OK && pg->meas.ensure(G * max_edges * 6) == VIO_OK &&
        pg->xout.ensure(G * pg->ld) == VIO_OK && pg->stats_d.ensure(G * kStatsDoubles) == VIO_OK;
-  ok = ok && hipMalloc(&pg->H, G * mat * sizeof(double)) == hipSuccess && hipMalloc(&pg->A, G * mat * sizeof(double)) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void *)posegraph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vio::kLdsBytes) == hipSuccess;
+  if (!ok) {  // (stream creation is the only non-allocation step above)
+    const bool no_stream = pg->stream == nullptr;
+    vio_posegraph_destroy(pg);
+    return no_stream ? VIO_ENODEV : VIO_ENOMEM;
+  }
+  ok = hipMalloc(&pg->H, G * mat * sizeof(double)) == hipSuccess && hipMalloc(&pg->A, G * mat * sizeof(double)) == hipSuccess;
   if (!ok) {
     vio_posegraph_destroy(pg);
     return VIO_ENOMEM;
+  }
+  // the factorization reads whole 16 x 16 tiles, including the rows past N of the last tile row: no uninitialised
+  // memory may reach the matrix cores (their rows are independent, but a NaN pattern need not stay that way)
+  ok = hipMemsetAsync(pg->H, 0, G * mat * sizeof(double), pg->stream) == hipSuccess &&
+       hipMemsetAsync(pg->A, 0, G * mat * sizeof(double), pg->stream) == hipSuccess &&
+       hipStreamSynchronize(pg->stream) == hipSuccess &&
+       hipFuncSetAttribute((const void *)posegraph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vio::kLdsBytes) == hipSuccess;
+  if (!ok) {
+    vio_posegraph_destroy(pg);
+    return VIO_ENODEV;
   }
   *out = pg;
   return VIO_OK;

@@ -81,8 +81,14 @@ class Estimator:
         self._check(self.lib.vio_estimator_process_image(self._h, seq, obs, n, float(header), C.byref(res)), "process_image")
         return res
 
-    def process_images(self, obs_per_seq, headers, active=None):
-        """obs_per_seq: list of (ids, xyz) per sequence; one launch solves every sequence that has a full window."""
+    def process_images(self, obs_per_seq, headers, active=None, strict=False):
+        """obs_per_seq: list of (ids, xyz) per sequence; one launch solves every sequence that has a full window.
+
+        Error contract (vio_estimator_process_images): bad arguments raise. A failure INSIDE the processing of a sequence
+        (capacity exceeded, a device error of its solve group) does not: that sequence's result carries
+        action == VIO_FRAME_ERROR and its `error` code, the library has restarted it (clearState, like the reference after
+        failureDetection), every other sequence was processed normally, and the first failing code is kept in
+        `last_error`. A warning is emitted for every such frame; strict=True raises instead."""
         stride = max(1, max(len(o[0]) for o in obs_per_seq))
         obs = (abi.VioObs * (stride * self.n_seq))()
         n = np.zeros(self.n_seq, np.int32)
@@ -100,8 +106,15 @@ class Estimator:
         # sequence was processed, solved and slid, so the results are returned (state and caller stay in step) and the code
         # is kept in last_error. Only a failure before any processing (bad arguments) raises.
         self.last_error = rc
-        if rc != 0 and not any(r.action == abi.VIO_FRAME_ERROR for r in out):
+        failed = [q for q, r in enumerate(out) if r.action == abi.VIO_FRAME_ERROR]
+        if rc != 0 and not failed:
             self._check(rc, "process_images")
+        if failed:
+            msg = "vio_estimator_process_images: rc=%d, sequences %s failed and were restarted" % (rc, failed[:8])
+            if strict:
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
         return out
 
     def status(self, seq=0):
