@@ -734,6 +734,23 @@ int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, cons
 /* cv::solvePnP(..., useExtrinsicGuess = true) with K = I as inital_sfm.cpp:57 and
  * VINS.cpp:982 call it: refines world->camera R [9], t [3] in place.            */
 int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok);
+/* GlobalSFM::triangulatePoint inital_sfm.cpp:5-21: linear two-view triangulation.
+ * pose0 / pose1: 3x4 row-major [R | t], world -> camera; xy: normalized image
+ * coordinates; point = the null vector of the 4x4 design matrix, dehomogenised. */
+int vio_init_triangulate_point(const double pose0[12], const double pose1[12], const double xy0[2], const double xy1[2],
+                               double point[3]);
+/* The "full BA" that closes GlobalSFM::construct, inital_sfm.cpp:229-296: ceres
+ * problem over c_rotation [frame_num][4] (w x y z, QuaternionParameterization),
+ * c_translation [frame_num][3] (both world -> camera) and the points with
+ * point_ok != 0; frame l's rotation and the translations of frames l and
+ * frame_num-1 are constant; ReprojectionError3D residuals (inital_sfm.hpp:25-54),
+ * DENSE_SCHUR, Levenberg-Marquardt with the Solver's default options. In/out:
+ * c_rotation, c_translation, points. stats (may be NULL): the Solver::Summary
+ * fields and the per-iteration trace. ok = CONVERGENCE || final_cost < 3e-3
+ * (:279), the value construct() returns.                                        */
+int vio_init_bundle_adjust(int32_t frame_num, int32_t l, double *c_rotation, double *c_translation, int32_t n_points,
+                           double *points, const uint8_t *point_ok, const int32_t *feat_start, const int32_t *obs_frame,
+                           const double *obs_xy, VioSolveStats *stats, int32_t *ok);
 /* GlobalSFM::construct inital_sfm.cpp:117-316. Landmark j has observations
  * obs_frame/obs_xy[feat_start[j] .. feat_start[j+1]) (frame index, normalized xy).
  * Out: q [frame_num][4] (x y z w) and T [frame_num][3] = camera poses in frame l's

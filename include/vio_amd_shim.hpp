@@ -2,19 +2,21 @@
 // the C ABI of vio_amd.h (last row). Header-only; nothing here computes.
 //
 //   vio_shim::FeatureTracker<Traits>::readImage   VINS_ios/feature_tracker.hpp:59, feature_tracker.cpp:162-310
+//   vio_shim::FeatureTracker<Traits>::solveVinsPnP VINS_ios/feature_tracker.hpp:58, feature_tracker.cpp:107-160
 //   vio_shim::VINS<Traits>::processIMU            VINS_ios/VINS.hpp:164,            VINS.cpp:333-375
 //   vio_shim::VINS<Traits>::processImage          VINS_ios/VINS.hpp:163,            VINS.cpp:377-478 (-> solve_ceres :480-831)
 //
 // The classes are templates over the few third-party types the reference's signatures mention, so the same text
 // compiles inside the reference tree,
-//     struct RefTraits { typedef cv::Mat Mat; typedef cv::Point2f Point2f;
+//     struct RefTraits { typedef cv::Mat Mat; typedef cv::Point2f Point2f; typedef Eigen::Vector2d Vector2d;
 //                        typedef Eigen::Vector3d Vector3d; typedef Eigen::Matrix3d Matrix3d; };
 // and, without OpenCV / Eigen, with any types that offer the same members: Mat { data, rows, cols, step },
-// Point2f(float x, float y), Vector3d / Matrix3d with operator()(i) / operator()(i, j) and a default constructor
+// Point2f(float x, float y), Vector2d / Vector3d / Matrix3d with operator()(i) / operator()(i, j) and a default constructor
 // (tests/shim_main.cpp). Public data members keep the reference's names (image_msg, img_cnt, Ps, Rs, ...).
 #ifndef VIO_AMD_SHIM_HPP
 #define VIO_AMD_SHIM_HPP
 
+#include <list>
 #include <map>
 #include <stdexcept>
 #include <vector>
@@ -28,23 +30,104 @@ class FeatureTracker {
  public:
   typedef typename Traits::Mat Mat;
   typedef typename Traits::Point2f Point2f;
+  typedef typename Traits::Vector2d Vector2d;
   typedef typename Traits::Vector3d Vector3d;
   typedef typename Traits::Matrix3d Matrix3d;
+  struct IMU_MSG_LOCAL {  // feature_tracker.hpp:46-50
+    double header;
+    Vector3d acc, gyr;
+  };
+  struct IMG_MSG_LOCAL {  // vins_pnp.hpp:36-41
+    int id;
+    Vector2d observation;
+    Vector3d position;
+    int track_num;
+  };
+  struct VINS_RESULT {  // vins_pnp.hpp:27-34
+    double header;
+    Vector3d Ba, Bg, P;
+    Matrix3d R;
+    Vector3d V;
+  };
 
-  // FeatureTracker::FeatureTracker() (feature_tracker.cpp:13-16) + the compile-time constants as a VioConfig
-  explicit FeatureTracker(const VioConfig &cfg) : img_cnt(0), update_finished(false), cfg_(cfg), fe_(nullptr) {
+  // FeatureTracker::FeatureTracker() (feature_tracker.cpp:13-16) + the compile-time constants as a VioConfig.
+  // Without an extrinsic there is no vinsPnP member: solveVinsPnP then returns false like with vins_normal == false.
+  explicit FeatureTracker(const VioConfig &cfg)
+      : img_cnt(0), current_time(-1.0), use_pnp(false), update_finished(false), cfg_(cfg), fe_(nullptr), pnp_(nullptr), had_points_(false) {
     if (vio_frontend_create(&cfg_, 1, &fe_) != VIO_OK) throw std::runtime_error("vio_frontend_create failed (a gfx950 device is required)");
     obs_.resize(cfg_.max_corners);
   }
-  ~FeatureTracker() { vio_frontend_destroy(fe_); }
+  // ... and with the camera-IMU extrinsic the app hands to vins_pnp.setExtrinsic / setIMUModel (ViewController.mm:318-319): the vinsPnP
+  // member (PNP_SIZE = 6, global_param.hpp:30) exists and readImage runs solveVinsPnP when vins_normal is set.
+  FeatureTracker(const VioConfig &cfg, const double tic[3], const double ric[9]) : FeatureTracker(cfg) {
+    if (vio_pnp_tracker_create(&cfg_, 1, 6, tic, ric, &pnp_) != VIO_OK) {
+      vio_frontend_destroy(fe_);
+      throw std::runtime_error("vio_pnp_tracker_create failed");
+    }
+  }
+  ~FeatureTracker() {
+    if (pnp_) vio_pnp_tracker_destroy(pnp_);
+    vio_frontend_destroy(fe_);
+  }
   FeatureTracker(const FeatureTracker &) = delete;
   FeatureTracker &operator=(const FeatureTracker &) = delete;
 
+  // feature_tracker.hpp:58, feature_tracker.cpp:107-160: the landmarks the back-end has solved (solved_features, ascending
+  // id) joined with the tracker's current points, setInit(solved_vins), the IMU samples since the last frame, then
+  // vinsPnP::processImage(feature_msg, header, use_pnp); P / R = Ps / Rs[PNP_SIZE - 1].
+  // (The join reads the tracker state AFTER the frame: on publishing frames the points setMask dropped at :234 no longer
+  // take part, the reference joins just before.)
+  bool solveVinsPnP(double header, Vector3d &P, Matrix3d &R, bool vins_normal) {
+    if (!vins_normal || !pnp_) return false;
+    const int cap = cfg_.max_corners;
+    std::vector<float> pts(2 * (size_t)cap);
+    std::vector<int32_t> ids(cap), cnt(cap);
+    int32_t n = 0;
+    if (vio_frontend_get_state(fe_, 0, pts.data(), ids.data(), cnt.data(), cap, &n) != VIO_OK) return false;
+    std::vector<VioPnpFeature> solved, msg((size_t)cap + 1);
+    for (typename std::list<IMG_MSG_LOCAL>::const_iterator it = solved_features.begin(); it != solved_features.end(); ++it) {
+      VioPnpFeature f;
+      f.id = it->id, f.track_num = it->track_num;
+      f.observation[0] = f.observation[1] = 0.0;
+      for (int k = 0; k < 3; k++) f.position[k] = it->position(k);
+      solved.push_back(f);
+    }
+    int32_t n_msg = 0;
+    if (vio_pnp_match_features(&cfg_, ids.data(), pts.data(), n, solved.empty() ? nullptr : solved.data(), (int32_t)solved.size(),
+                               msg.data(), cap, &n_msg) != VIO_OK)
+      return false;
+    VioVinsResult r;
+    r.header = solved_vins.header;
+    for (int k = 0; k < 3; k++) {
+      r.Ba[k] = solved_vins.Ba(k), r.Bg[k] = solved_vins.Bg(k), r.P[k] = solved_vins.P(k), r.V[k] = solved_vins.V(k);
+      for (int c = 0; c < 3; c++) r.R[3 * k + c] = solved_vins.R(k, c);
+    }
+    if (vio_pnp_tracker_set_init(pnp_, 0, &r) != VIO_OK) return false;
+    for (size_t i = 0; i < imu_msgs.size(); i++) {
+      const double t = imu_msgs[i].header;
+      if (current_time < 0) current_time = t;
+      const double dt = t - current_time;
+      current_time = t;
+      const double a[3] = {imu_msgs[i].acc(0), imu_msgs[i].acc(1), imu_msgs[i].acc(2)};
+      const double g[3] = {imu_msgs[i].gyr(0), imu_msgs[i].gyr(1), imu_msgs[i].gyr(2)};
+      if (vio_pnp_tracker_process_imu(pnp_, 0, dt, a, g) != VIO_OK) return false;
+    }
+    double Pout[3], Rout[9];
+    int32_t did_solve = 0;
+    if (vio_pnp_tracker_process_images(pnp_, msg.data(), &n_msg, cap + 1, &header, use_pnp ? 1 : 0, nullptr, Pout, Rout, &did_solve) != VIO_OK)
+      return false;
+    for (int k = 0; k < 3; k++) {
+      P(k) = Pout[k];
+      for (int c = 0; c < 3; c++) R(k, c) = Rout[3 * k + c];
+    }
+    return true;
+  }
+
   // feature_tracker.hpp:59. `_frame_cnt` is never read by the reference body; `result` aliases `_img`
-  // (feature_tracker.cpp:165); P / R are written only when vins_normal and USE_PNP (default off, :107-160).
+  // (feature_tracker.cpp:165); P / R are written by solveVinsPnP (:207), which runs once the tracker holds points.
   void readImage(const Mat &_img, Mat &result, int _frame_cnt, std::vector<Point2f> &good_pts, std::vector<double> &track_len,
                  double header, Vector3d &P, Matrix3d &R, bool vins_normal) {
-    (void)_frame_cnt, (void)P, (void)R, (void)vins_normal;
+    (void)_frame_cnt;
     result = _img;
     int n_obs = 0;
     VioTrackViz *viz = nullptr;
@@ -55,6 +138,7 @@ class FeatureTracker {
       update_finished = true;
       return;
     }
+    if (had_points_) solveVinsPnP(header, P, R, vins_normal);  // inside `if (cur_pts.size() > 0)` (:175-207)
     if (publish) {
       image_msg.clear();  // feature_tracker.cpp:290
       for (int i = 0; i < n_obs; i++) {
@@ -72,16 +156,24 @@ class FeatureTracker {
         good_pts.push_back(Point2f(pts[2 * i], pts[2 * i + 1]));
         track_len.push_back(cnt[i] > 20 ? 1.0 : cnt[i] / 20.0);  // std::min(1.0, 1.0 * track_cnt[i] / WINDOW_SIZE_FEATURE_TRACKER) :280
       }
+    had_points_ = n > 0;
     update_finished = true;  // :309
   }
 
-  std::map<int, Vector3d> image_msg;  // feature_tracker.hpp:68
-  int img_cnt;                        // :79 (advanced by the caller)
-  bool update_finished;               // :67
+  int img_cnt;                             // feature_tracker.hpp:81 (advanced by the caller)
+  double current_time;                     // :82
+  bool use_pnp;                            // :84
+  std::map<int, Vector3d> image_msg;       // :89
+  bool update_finished;                    // :90
+  std::list<IMG_MSG_LOCAL> solved_features;  // :91 (copied in by the caller before readImage, ViewController.mm:446-451, 734-755)
+  VINS_RESULT solved_vins;                 // :92
+  std::vector<IMU_MSG_LOCAL> imu_msgs;     // :93
 
  private:
   VioConfig cfg_;
   vio_frontend_t *fe_;
+  vio_pnp_tracker_t *pnp_;
+  bool had_points_;
   std::vector<VioObs> obs_;
 };
 

@@ -2,11 +2,13 @@
 // Eigen: the traits below carry just the members the shim touches. Driven by tests/test_shim_gpu.py:
 //   shim_main frames.bin rows cols n_frames freq obs_out.bin        FeatureTracker::readImage on raw gray frames
 //   shim_main --vins data.bin out.bin                               VINS::processIMU / processImage on a recorded sequence
+//   shim_main --pnp frames.bin rows cols n_frames pnp.bin out.bin   readImage with vins_normal: the solveVinsPnP branch
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <list>
 #include <vector>
 
 #include "vio_amd_shim.hpp"
@@ -26,6 +28,12 @@ struct Vec3 {
   double &operator()(int i) { return v[i]; }
   double operator()(int i) const { return v[i]; }
 };
+struct Vec2 {
+  double v[2];
+  Vec2() { v[0] = v[1] = 0; }
+  double &operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+};
 struct Mat3 {
   double m[9];
   Mat3() { memset(m, 0, sizeof(m)); }
@@ -35,6 +43,7 @@ struct Mat3 {
 struct Traits {
   typedef ::Mat Mat;
   typedef ::Point2f Point2f;
+  typedef Vec2 Vector2d;
   typedef Vec3 Vector3d;
   typedef Mat3 Matrix3d;
 };
@@ -79,6 +88,55 @@ static int run_tracker(int argc, char **argv) {
     int32_t ng = (int32_t)good_pts.size();
     fwrite(&ng, sizeof(ng), 1, out);
     tracker.img_cnt = (tracker.img_cnt + 1) % freq;  // ViewController.mm:494
+  }
+  fclose(out);
+  return 0;
+}
+
+// pnp.bin: int32 first_frame (solved_* are set from that frame on), n_solved, imu_per_frame; n_solved x (int32 id, int32
+// track_num, double position[3]); VINS_RESULT (header, Ba, Bg, P, R[9], V); then per frame imu_per_frame x (header, acc[3],
+// gyr[3]). out.bin: per frame (returned-by-readImage P[3], R[9]).
+static int run_pnp(char **argv) {
+  const int rows = atoi(argv[3]), cols = atoi(argv[4]), n_frames = atoi(argv[5]);
+  std::vector<unsigned char> frames = slurp(argv[2]), d = slurp(argv[6]);
+  const unsigned char *p = d.data();
+  auto rd = [&](void *dst, size_t n) { memcpy(dst, p, n), p += n; };
+  typedef vio_shim::FeatureTracker<Traits> Tracker;
+  VioConfig cfg;
+  vio_config_default(&cfg);
+  cfg.image_rows = rows, cfg.image_cols = cols, cfg.max_corners = 60, cfg.min_dist = 25;
+  const double tic[3] = {0, 0, 0}, ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  Tracker tracker(cfg, tic, ric);
+  tracker.use_pnp = true;  // featuretracker.use_pnp = USE_PNP (ViewController.mm:457)
+  int32_t first, n_solved, ipf;
+  rd(&first, 4), rd(&n_solved, 4), rd(&ipf, 4);
+  std::list<Tracker::IMG_MSG_LOCAL> solved;
+  for (int i = 0; i < n_solved; i++) {
+    Tracker::IMG_MSG_LOCAL m;
+    int32_t id, tn;
+    rd(&id, 4), rd(&tn, 4), rd(m.position.v, 24);
+    m.id = id, m.track_num = tn;
+    solved.push_back(m);
+  }
+  Tracker::VINS_RESULT res;
+  rd(&res.header, 8), rd(res.Ba.v, 24), rd(res.Bg.v, 24), rd(res.P.v, 24), rd(res.R.m, 72), rd(res.V.v, 24);
+  FILE *out = fopen(argv[7], "wb");
+  for (int f = 0; f < n_frames; f++) {
+    tracker.imu_msgs.clear();
+    for (int s = 0; s < ipf; s++) {
+      Tracker::IMU_MSG_LOCAL m;
+      rd(&m.header, 8), rd(m.acc.v, 24), rd(m.gyr.v, 24);
+      tracker.imu_msgs.push_back(m);
+    }
+    if (f >= first) tracker.solved_features = solved, tracker.solved_vins = res;
+    Mat img = {frames.data() + (size_t)f * rows * cols, rows, cols, (size_t)cols}, result = {nullptr, 0, 0, 0};
+    std::vector<Point2f> good_pts;
+    std::vector<double> track_len;
+    Vec3 P;
+    Mat3 R;
+    tracker.readImage(img, result, f, good_pts, track_len, 0.1 * f, P, R, f >= first);
+    fwrite(P.v, sizeof(P.v), 1, out), fwrite(R.m, sizeof(R.m), 1, out);
+    tracker.img_cnt = (tracker.img_cnt + 1) % 3;
   }
   fclose(out);
   return 0;
@@ -144,5 +202,6 @@ static int run_vins(char **argv) {
 
 int main(int argc, char **argv) {
   if (argc >= 4 && !strcmp(argv[1], "--vins")) return run_vins(argv);
+  if (argc >= 8 && !strcmp(argv[1], "--pnp")) return run_pnp(argv);
   return run_tracker(argc, argv);
 }

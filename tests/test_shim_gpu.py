@@ -103,3 +103,69 @@ def test_vins_shim_follows_the_estimator(tmp_path):
             # (two runs of the solver differ in the order of their LDS atomic accumulations: ~1e-9 m)
             assert np.abs(got[k, 3:6] - P).max() < 1e-7 and int(got[k, 6]) == it and abs(got[k, 7] - fc) <= 1e-7 * max(1.0, fc)
     assert solved == n_frames - W
+
+
+@pytest.mark.gpu
+def test_feature_tracker_shim_runs_the_vins_pnp_branch(tmp_path):
+    """readImage with vins_normal (feature_tracker.cpp:207 -> :107-160): solved_features joined with the tracker's points,
+    setInit(solved_vins), the frame's IMU samples, vinsPnP::processImage -- against the same sequence of ABI calls made
+    from python. A static camera looking at landmarks five metres away, camera frame = body frame."""
+    import ctypes as C
+    exe = build_shim(tmp_path)
+    rows, cols, n, first, ipf = 240, 320, 12, 3, 4
+    frames, _ = pkg.synth.make_image_stream(9, n, rows=rows, cols=cols, max_shift=0.8)
+    cfg = abi.default_config(max_corners=60, min_dist=25, image_rows=rows, image_cols=cols)
+    lib = abi.load_product()
+    trk = pkg.frontend.FeatureTracker(cfg, n_seq=1)
+    pnp = pkg.pnp.PnpTracker(cfg, np.zeros(3), np.eye(3), pnp_size=6)
+    acc, gyr = np.array([0.0, 0.0, cfg.gravity]), np.zeros(3)
+    imu = [[(0.1 * f - 0.1 + 0.025 * (s + 1), acc, gyr) for s in range(ipf)] for f in range(n)]
+    solved, want, current_time = None, [], -1.0
+    _ip, _fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    for f in range(n):
+        trk.read_images(frames[f:f + 1], f % 3 == 0)
+        pts, ids, _ = trk.state(0)
+        if f == first - 1:   # the landmarks "the back-end has solved": the points tracked so far, 5 m in front of the camera
+            order = np.argsort(ids)
+            solved = [(int(ids[i]), 7, ((pts[i, 0] - cfg.cx) / cfg.fx * 5.0, (pts[i, 1] - cfg.cy) / cfg.fy * 5.0, 5.0)) for i in order]
+        P, R = np.zeros(3), np.zeros((3, 3))
+        if f >= first and f > 0:
+            arr = (abi.VioPnpFeature * len(solved))()
+            for k, (fid, tn, pos) in enumerate(solved):
+                arr[k].id, arr[k].track_num = fid, tn
+                arr[k].position[:] = [float(v) for v in pos]
+            out, nm = (abi.VioPnpFeature * (cfg.max_corners + 1))(), C.c_int32()
+            assert lib.vio_pnp_match_features(C.byref(cfg), ids.ctypes.data_as(_ip), pts.ctypes.data_as(_fp), len(ids), arr, len(solved),
+                                              out, cfg.max_corners, C.byref(nm)) == 0
+            assert nm.value > 20
+            pnp.set_init(0.1 * (first - 1), np.zeros(3), np.zeros(3), np.zeros(3), np.eye(3), np.zeros(3))
+            for t, a, g in imu[f]:
+                if current_time < 0:
+                    current_time = t
+                pnp.process_imu(t - current_time, a, g)
+                current_time = t
+            feats = [(out[i].id, tuple(out[i].observation), tuple(out[i].position), out[i].track_num) for i in range(nm.value)]
+            Pq, Rq, _ = pnp.process_images([feats], [0.1 * f], use_pnp=True)
+            P, R = Pq[0], Rq[0]
+        want.append((P, R))
+    trk.close(), pnp.close()
+    (tmp_path / "frames.bin").write_bytes(np.ascontiguousarray(frames).tobytes())
+    blob = [struct.pack("<3i", first, len(solved), ipf)]
+    for fid, tn, pos in solved:
+        blob.append(struct.pack("<2i3d", fid, tn, *pos))
+    blob.append(struct.pack("<d3d3d3d9d3d", 0.1 * (first - 1), *np.zeros(3), *np.zeros(3), *np.zeros(3), *np.eye(3).ravel(), *np.zeros(3)))
+    for f in range(n):
+        for t, a, g in imu[f]:
+            blob.append(struct.pack("<d3d3d", t, *a, *g))
+    (tmp_path / "pnp.bin").write_bytes(b"".join(blob))
+    subprocess.check_call([exe, "--pnp", str(tmp_path / "frames.bin"), str(rows), str(cols), str(n), str(tmp_path / "pnp.bin"),
+                           str(tmp_path / "out.bin")])
+    got = np.frombuffer((tmp_path / "out.bin").read_bytes(), np.float64).reshape(n, 12)
+    moved = 0
+    for f in range(n):
+        P, R = want[f]
+        assert np.abs(got[f, :3] - P).max() < 1e-9 and np.abs(got[f, 3:].reshape(3, 3) - R).max() < 1e-9, (f, got[f], P, R)
+        moved += int(np.abs(R).max() > 0)
+    assert moved == n - first                     # P / R are only written once vins_normal is set
+    # the window fills after PNP_SIZE frames: from then on the solve runs and holds the static camera in place
+    assert np.abs(got[-1, :3]).max() < 0.05 and np.abs(got[-1, 3:].reshape(3, 3) - np.eye(3)).max() < 0.02

@@ -518,6 +518,8 @@ def load_product():
     lib.vio_pnp_tracker_get_window.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, u8p, _ip]
     lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _dp, _ip, _ip]
     lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]
+    lib.vio_init_triangulate_point.argtypes = [_dp, _dp, _dp, _dp, _dp]
+    lib.vio_init_bundle_adjust.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _dp, u8p, _ip, _ip, _dp, C.POINTER(VioSolveStats), _ip]
     lib.vio_init_sfm.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _ip, _ip, _dp, _dp, _dp, _dp, u8p, _ip]
     lib.vio_visual_imu_alignment.argtypes = [cfgp, _dp, C.POINTER(VioInitFrame), C.c_int32, C.c_int32, _dp, _dp, _dp, _ip]
     resp, stp = C.POINTER(VioFrameResult), C.POINTER(VioEstimatorStatus)

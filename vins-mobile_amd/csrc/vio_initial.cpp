@@ -477,159 +477,314 @@ void triangulate_two_frames(int f0, const double P0[12], int f1, const double P1
   }
 }
 
-// Full bundle adjustment of GlobalSFM::construct (inital_sfm.cpp:229-296): reprojection error in normalized image
-// coordinates over all rotations (but frame l's), all translations (but frame l's and the last frame's) and all
-// triangulated points, no robust loss. Ceres' default trust-region Levenberg-Marquardt with a dense Schur complement is
-// restated as a plain LM with the same elimination order (points first); the optimum, not the iterate path, is what the
-// initialisation consumes. Returns the final cost (sum of squares / 2) and whether the iteration converged.
-bool bundle_adjust(int frame_num, int l, std::vector<double> &Rc, std::vector<double> &tc, std::vector<SfmFeature> &sfm_f,
-                   double *final_cost) {
-  struct Obs {
-    int frame, point;
-    double u, v;
-  };
-  std::vector<int> pidx;
-  std::vector<Obs> obs;
-  for (size_t j = 0; j < sfm_f.size(); j++) {
-    if (!sfm_f[j].state) continue;
-    for (const auto &o : sfm_f[j].observation) obs.push_back({o.first, (int)pidx.size(), o.second.first, o.second.second});
-    pidx.push_back((int)j);
+// Full bundle adjustment of GlobalSFM::construct (inital_sfm.cpp:229-296) as Ceres runs it, restated step by step so
+// that the iterates -- not only the optimum -- follow the reference's (oracle/ref_sfm_harness.cpp runs the same problem on
+// the vendored Ceres; tests/test_initial_sfm.py compares the iteration traces):
+//   * parameter blocks: c_rotation[i] (w x y z, world -> camera) on ceres::QuaternionParameterization -- Plus(q, d) =
+//     [cos|d|, sin|d| d/|d|] * q (CS/internal/ceres/local_parameterization.cc:164-201) -- c_translation[i] and the
+//     triangulated points; frame l's rotation and the translations of frames l and frame_num-1 are constant (:244-251);
+//   * residual: ReprojectionError3D (inital_sfm.hpp:25-54), no loss; its Jacobian over the local rotation step is
+//     -2 [R X]x (what the automatic derivative times the parameterization's 4x3 Jacobian evaluates to);
+//   * trust region: Levenberg-Marquardt (CS/internal/ceres/levenberg_marquardt_strategy.cc:66-163) with Jacobi scaling,
+//     the loop and termination tests of CS/internal/ceres/trust_region_minimizer.cc:65-123,666-704 with the Solver's
+//     defaults (50 iterations, function 1e-6, gradient 1e-10, parameter 1e-8); the 0.3 s wall-clock limit is not
+//     modelled (a problem of this size takes milliseconds);
+//   * linear solver: DENSE_SCHUR, the points being the e-blocks (CS/internal/ceres/schur_complement_solver.cc:161-224).
+struct BaObs {
+  int frame, point;
+  double u, v;
+};
+
+struct BaSystem {  // JtJ and Jt r of the whole problem at one iterate, local (tangent) coordinates, unscaled
+  std::vector<double> Hpp, Hcp, Hcc, gp, gc;
+};
+
+struct BaLayout {
+  int frame_num = 0, np = 0, nc = 0;
+  std::vector<int> off_q, off_t;  // column of each camera block in the reduced system, -1 = constant
+  std::vector<BaObs> obs;
+};
+
+double ba_evaluate(const BaLayout &L, const std::vector<double> &cq, const std::vector<double> &ct, const std::vector<double> &X,
+                   BaSystem *sys) {
+  const int np = L.np, nc = L.nc;
+  if (sys) {
+    sys->Hpp.assign(9 * (size_t)np, 0.0), sys->Hcp.assign((size_t)nc * 3 * np, 0.0), sys->Hcc.assign((size_t)nc * nc, 0.0);
+    sys->gp.assign(3 * (size_t)np, 0.0), sys->gc.assign(nc, 0.0);
   }
-  const int np = (int)pidx.size();
-  // camera parameter offsets in the reduced system
-  std::vector<int> off_r(frame_num, -1), off_t(frame_num, -1);
-  int nc = 0;
-  for (int i = 0; i < frame_num; i++) {
-    if (i != l) off_r[i] = nc, nc += 3;
-    if (i != l && i != frame_num - 1) off_t[i] = nc, nc += 3;
-  }
-  std::vector<double> X(3 * np);
-  for (int p = 0; p < np; p++) memcpy(&X[3 * p], sfm_f[pidx[p]].position, 24);
-  auto cost_of = [&](const std::vector<double> &R, const std::vector<double> &t, const std::vector<double> &Xp) {
-    double c = 0;
-    for (const Obs &o : obs) {
-      double Y[3];
-      mat3vec(&R[9 * o.frame], &Xp[3 * o.point], Y);
-      for (int k = 0; k < 3; k++) Y[k] += t[3 * o.frame + k];
-      const double ex = Y[0] / Y[2] - o.u, ey = Y[1] / Y[2] - o.v;
-      c += ex * ex + ey * ey;
+  std::vector<double> R(9 * (size_t)L.frame_num);
+  for (int i = 0; i < L.frame_num; i++)  // QuaternionRotatePoint normalizes its quaternion (CS/include/ceres/rotation.h:553-571)
+    qtoR(qnormalized(Quat{cq[4 * i + 1], cq[4 * i + 2], cq[4 * i + 3], cq[4 * i]}), &R[9 * (size_t)i]);
+  double cost = 0.0;
+  for (const BaObs &o : L.obs) {
+    const double *Ri = &R[9 * (size_t)o.frame], *Xw = &X[3 * (size_t)o.point];
+    double RX[3], Y[3];
+    mat3vec(Ri, Xw, RX);
+    for (int k = 0; k < 3; k++) Y[k] = RX[k] + ct[3 * o.frame + k];
+    const double iz = 1.0 / Y[2], r[2] = {Y[0] * iz - o.u, Y[1] * iz - o.v};
+    cost += r[0] * r[0] + r[1] * r[1];
+    if (!sys) continue;
+    const double Jp[6] = {iz, 0, -Y[0] * iz * iz, 0, iz, -Y[1] * iz * iz};
+    double S[9], Jq[6], JX[6];
+    skew3(RX, S);
+    for (int a = 0; a < 2; a++)
+      for (int c = 0; c < 3; c++) {
+        Jq[a * 3 + c] = -2.0 * (Jp[a * 3] * S[c] + Jp[a * 3 + 1] * S[3 + c] + Jp[a * 3 + 2] * S[6 + c]);
+        JX[a * 3 + c] = Jp[a * 3] * Ri[c] + Jp[a * 3 + 1] * Ri[3 + c] + Jp[a * 3 + 2] * Ri[6 + c];
+      }
+    int cols[6], ncol = 0;
+    double Jc[12];
+    if (L.off_q[o.frame] >= 0)
+      for (int c = 0; c < 3; c++) cols[ncol] = L.off_q[o.frame] + c, Jc[ncol] = Jq[c], Jc[6 + ncol] = Jq[3 + c], ncol++;
+    if (L.off_t[o.frame] >= 0)
+      for (int c = 0; c < 3; c++) cols[ncol] = L.off_t[o.frame] + c, Jc[ncol] = Jp[c], Jc[6 + ncol] = Jp[3 + c], ncol++;
+    for (int a = 0; a < ncol; a++) {
+      sys->gc[cols[a]] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+      for (int b = 0; b < ncol; b++) sys->Hcc[(size_t)cols[a] * nc + cols[b]] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+      for (int c = 0; c < 3; c++) sys->Hcp[(size_t)cols[a] * 3 * np + 3 * o.point + c] += Jc[a] * JX[c] + Jc[6 + a] * JX[3 + c];
     }
-    return 0.5 * c;
-  };
-  double cost = cost_of(Rc, tc, X), lambda = 1e-4;
-  bool converged = false;
-  for (int it = 0; it < 50 && !converged; it++) {
-    std::vector<double> Hcc((size_t)nc * nc, 0.0), gc(nc, 0.0), Hpp(9 * (size_t)np, 0.0), gp(3 * (size_t)np, 0.0);
-    std::vector<double> Hcp((size_t)nc * 3 * np, 0.0);  // dense: at most 63 x ~900
-    for (const Obs &o : obs) {
-      const double *R = &Rc[9 * o.frame], *Xw = &X[3 * o.point];
-      double Y[3];
-      mat3vec(R, Xw, Y);
-      for (int k = 0; k < 3; k++) Y[k] += tc[3 * o.frame + k];
-      const double iz = 1.0 / Y[2], r[2] = {Y[0] * iz - o.u, Y[1] * iz - o.v};
-      const double Jp[6] = {iz, 0, -Y[0] * iz * iz, 0, iz, -Y[1] * iz * iz};
-      double Sx[9], RS[9];
-      skew3(Xw, Sx);
-      mat3mul(R, Sx, RS);
-      double Jr[6], Jt[6], JX[6];
-      for (int a = 0; a < 2; a++)
-        for (int c = 0; c < 3; c++) {
-          Jr[a * 3 + c] = -(Jp[a * 3] * RS[c] + Jp[a * 3 + 1] * RS[3 + c] + Jp[a * 3 + 2] * RS[6 + c]);
-          Jt[a * 3 + c] = Jp[a * 3 + c];
-          JX[a * 3 + c] = Jp[a * 3] * R[c] + Jp[a * 3 + 1] * R[3 + c] + Jp[a * 3 + 2] * R[6 + c];
-        }
-      // camera columns of this observation: up to 6
-      int cols[6], ncol = 0;
-      double Jc[12];
-      if (off_r[o.frame] >= 0)
-        for (int c = 0; c < 3; c++) cols[ncol] = off_r[o.frame] + c, Jc[ncol] = Jr[c], Jc[6 + ncol] = Jr[3 + c], ncol++;
-      if (off_t[o.frame] >= 0)
-        for (int c = 0; c < 3; c++) cols[ncol] = off_t[o.frame] + c, Jc[ncol] = Jt[c], Jc[6 + ncol] = Jt[3 + c], ncol++;
-      for (int a = 0; a < ncol; a++) {
-        gc[cols[a]] -= Jc[a] * r[0] + Jc[6 + a] * r[1];
-        for (int b = 0; b < ncol; b++) Hcc[(size_t)cols[a] * nc + cols[b]] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-        for (int c = 0; c < 3; c++) Hcp[(size_t)cols[a] * 3 * np + 3 * o.point + c] += Jc[a] * JX[c] + Jc[6 + a] * JX[3 + c];
-      }
-      for (int a = 0; a < 3; a++) {
-        gp[3 * o.point + a] -= JX[a] * r[0] + JX[3 + a] * r[1];
-        for (int b = 0; b < 3; b++) Hpp[9 * (size_t)o.point + a * 3 + b] += JX[a] * JX[b] + JX[3 + a] * JX[3 + b];
-      }
-    }
-    bool improved = false;
-    for (int tries = 0; tries < 10 && !improved; tries++) {
-      // Schur complement on the points: S = Hcc' - Hcp Hpp'^-1 Hpc, rhs = gc - Hcp Hpp'^-1 gp (damped diagonals)
-      std::vector<double> S(Hcc), rhs(gc), Hinv(9 * (size_t)np);
-      for (int a = 0; a < nc; a++) S[(size_t)a * nc + a] += lambda * (Hcc[(size_t)a * nc + a] + 1e-12);
-      for (int p = 0; p < np; p++) {
-        double M[9];
-        memcpy(M, &Hpp[9 * (size_t)p], sizeof(M));
-        for (int a = 0; a < 3; a++) M[a * 3 + a] += lambda * (M[a * 3 + a] + 1e-12);
-        const double det = dense::det3(M);
-        double *I = &Hinv[9 * (size_t)p];
-        I[0] = (M[4] * M[8] - M[5] * M[7]) / det, I[1] = (M[2] * M[7] - M[1] * M[8]) / det, I[2] = (M[1] * M[5] - M[2] * M[4]) / det;
-        I[3] = (M[5] * M[6] - M[3] * M[8]) / det, I[4] = (M[0] * M[8] - M[2] * M[6]) / det, I[5] = (M[2] * M[3] - M[0] * M[5]) / det;
-        I[6] = (M[3] * M[7] - M[4] * M[6]) / det, I[7] = (M[1] * M[6] - M[0] * M[7]) / det, I[8] = (M[0] * M[4] - M[1] * M[3]) / det;
-      }
-      std::vector<double> W((size_t)nc * 3 * np);  // Hcp Hpp^-1
-      for (int a = 0; a < nc; a++)
-        for (int p = 0; p < np; p++) {
-          const double *h = &Hcp[(size_t)a * 3 * np + 3 * p], *I = &Hinv[9 * (size_t)p];
-          double *w = &W[(size_t)a * 3 * np + 3 * p];
-          for (int c = 0; c < 3; c++) w[c] = h[0] * I[c] + h[1] * I[3 + c] + h[2] * I[6 + c];
-        }
-      for (int a = 0; a < nc; a++) {
-        double acc = 0;
-        for (int k = 0; k < 3 * np; k++) acc += W[(size_t)a * 3 * np + k] * gp[k];
-        rhs[a] -= acc;
-        for (int b = 0; b <= a; b++) {
-          double sum = 0;
-          const double *wa = &W[(size_t)a * 3 * np], *hb = &Hcp[(size_t)b * 3 * np];
-          for (int k = 0; k < 3 * np; k++) sum += wa[k] * hb[k];
-          S[(size_t)a * nc + b] -= sum;
-          if (b != a) S[(size_t)b * nc + a] -= sum;
-        }
-      }
-      std::vector<double> dc;
-      if (!dense::ldlt_solve(S, rhs, nc, dc)) {
-        lambda *= 10;
-        continue;
-      }
-      std::vector<double> Rn(Rc), tn(tc), Xn(X);
-      for (int i = 0; i < frame_num; i++) {
-        if (off_r[i] >= 0) right_update(&Rn[9 * i], &dc[off_r[i]]);
-        if (off_t[i] >= 0)
-          for (int k = 0; k < 3; k++) tn[3 * i + k] += dc[off_t[i] + k];
-      }
-      for (int p = 0; p < np; p++) {
-        double v[3];
-        for (int a = 0; a < 3; a++) {
-          v[a] = gp[3 * p + a];
-          for (int c = 0; c < nc; c++) v[a] -= Hcp[(size_t)c * 3 * np + 3 * p + a] * dc[c];
-        }
-        const double *I = &Hinv[9 * (size_t)p];
-        for (int a = 0; a < 3; a++) Xn[3 * p + a] += I[a * 3] * v[0] + I[a * 3 + 1] * v[1] + I[a * 3 + 2] * v[2];
-      }
-      const double c2 = cost_of(Rn, tn, Xn);
-      if (std::isfinite(c2) && c2 < cost) {
-        const double rel = (cost - c2) / (cost + 1e-300);
-        Rc.swap(Rn), tc.swap(tn), X.swap(Xn);
-        cost = c2, lambda = std::max(lambda / 3, 1e-10), improved = true;
-        if (rel < 1e-6) converged = true;  // function_tolerance of ceres::Solver::Options
-      } else {
-        lambda *= 10;
-      }
-    }
-    if (!improved) {
-      converged = true;  // no further decrease possible: the trust region collapsed at a minimum
-      break;
+    for (int a = 0; a < 3; a++) {
+      sys->gp[3 * (size_t)o.point + a] += JX[a] * r[0] + JX[3 + a] * r[1];
+      for (int b = 0; b < 3; b++) sys->Hpp[9 * (size_t)o.point + a * 3 + b] += JX[a] * JX[b] + JX[3 + a] * JX[3 + b];
     }
   }
-  for (int p = 0; p < np; p++) memcpy(sfm_f[pidx[p]].position, &X[3 * p], 24);
-  *final_cost = cost;
-  return converged;
+  return 0.5 * cost;
+}
+
+// QuaternionParameterization::Plus on (w x y z)
+void ba_quat_plus(const double q[4], const double d[3], double out[4]) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd > 0.0) {
+    const double k = sin(nd) / nd;
+    const Quat dq{k * d[0], k * d[1], k * d[2], cos(nd)}, r = qmul(dq, Quat{q[1], q[2], q[3], q[0]});
+    out[0] = r.w, out[1] = r.x, out[2] = r.y, out[3] = r.z;
+  } else {
+    memcpy(out, q, 32);
+  }
+}
+
+// (Js^T Js + D^2) y = gs by elimination of the points (3x3 blocks), Cholesky on the camera system: y = [yp | yc].
+// Hs = S H S with the Jacobi column scaling S; d2 = D^2 (both in [points | cameras] order).
+bool ba_solve(const BaLayout &L, const BaSystem &sys, const std::vector<double> &scale, const std::vector<double> &d2,
+              std::vector<double> &y) {
+  const int np = L.np, nc = L.nc, n3 = 3 * np;
+  const double *sp = scale.data(), *sc = scale.data() + n3;
+  std::vector<double> Einv(9 * (size_t)np), S((size_t)nc * nc), rhs(nc);
+  for (int p = 0; p < np; p++) {
+    double M[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) M[a * 3 + b] = sp[3 * p + a] * sys.Hpp[9 * (size_t)p + a * 3 + b] * sp[3 * p + b];
+    for (int a = 0; a < 3; a++) M[a * 3 + a] += d2[3 * p + a];
+    // inverse through the Cholesky factor of the 3x3 block (schur_eliminator_impl.h:258-262 InvertPSDMatrix)
+    const double l00 = sqrt(M[0]), l10 = M[3] / l00, l20 = M[6] / l00;
+    const double l11 = sqrt(M[4] - l10 * l10), l21 = (M[7] - l20 * l10) / l11, l22 = sqrt(M[8] - l20 * l20 - l21 * l21);
+    if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) return false;
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = -(l20 * i00 + l21 * i10) * i22;
+    double *I = &Einv[9 * (size_t)p];  // L^-T L^-1
+    I[0] = i00 * i00 + i10 * i10 + i20 * i20, I[1] = I[3] = i10 * i11 + i20 * i21, I[2] = I[6] = i20 * i22;
+    I[4] = i11 * i11 + i21 * i21, I[5] = I[7] = i21 * i22, I[8] = i22 * i22;
+  }
+  std::vector<double> W((size_t)nc * n3), Hs((size_t)nc * n3);  // scaled Hcp and Hcp E^-1
+  for (int a = 0; a < nc; a++)
+    for (int k = 0; k < n3; k++) Hs[(size_t)a * n3 + k] = sc[a] * sys.Hcp[(size_t)a * n3 + k] * sp[k];
+  for (int a = 0; a < nc; a++)
+    for (int p = 0; p < np; p++) {
+      const double *h = &Hs[(size_t)a * n3 + 3 * p], *I = &Einv[9 * (size_t)p];
+      double *w = &W[(size_t)a * n3 + 3 * p];
+      for (int c = 0; c < 3; c++) w[c] = h[0] * I[c] + h[1] * I[3 + c] + h[2] * I[6 + c];
+    }
+  for (int a = 0; a < nc; a++) {
+    double acc = sc[a] * sys.gc[a];
+    for (int k = 0; k < n3; k++) acc -= W[(size_t)a * n3 + k] * (sp[k] * sys.gp[k]);
+    rhs[a] = acc;
+    for (int b = 0; b <= a; b++) {
+      double sum = sc[a] * sys.Hcc[(size_t)a * nc + b] * sc[b];
+      const double *wa = &W[(size_t)a * n3], *hb = &Hs[(size_t)b * n3];
+      for (int k = 0; k < n3; k++) sum -= wa[k] * hb[k];
+      S[(size_t)a * nc + b] = S[(size_t)b * nc + a] = sum;
+    }
+    S[(size_t)a * nc + a] += d2[n3 + a];
+  }
+  // Eigen::LLT of the reduced camera matrix (schur_complement_solver.cc:201-213)
+  for (int j = 0; j < nc; j++) {
+    double d = S[(size_t)j * nc + j];
+    for (int k = 0; k < j; k++) d -= S[(size_t)j * nc + k] * S[(size_t)j * nc + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d), S[(size_t)j * nc + j] = d;
+    for (int i = j + 1; i < nc; i++) {
+      double v = S[(size_t)i * nc + j];
+      for (int k = 0; k < j; k++) v -= S[(size_t)i * nc + k] * S[(size_t)j * nc + k];
+      S[(size_t)i * nc + j] = v / d;
+    }
+  }
+  y.assign((size_t)n3 + nc, 0.0);
+  double *yc = y.data() + n3;
+  for (int i = 0; i < nc; i++) {
+    double v = rhs[i];
+    for (int k = 0; k < i; k++) v -= S[(size_t)i * nc + k] * yc[k];
+    yc[i] = v / S[(size_t)i * nc + i];
+  }
+  for (int i = nc - 1; i >= 0; i--) {
+    double v = yc[i];
+    for (int k = i + 1; k < nc; k++) v -= S[(size_t)k * nc + i] * yc[k];
+    yc[i] = v / S[(size_t)i * nc + i];
+  }
+  for (int p = 0; p < np; p++) {  // back-substitution: yp = E^-1 (gs_p - Hs_pc yc)
+    double v[3];
+    for (int a = 0; a < 3; a++) {
+      v[a] = sp[3 * p + a] * sys.gp[3 * (size_t)p + a];
+      for (int c = 0; c < nc; c++) v[a] -= Hs[(size_t)c * n3 + 3 * p + a] * yc[c];
+    }
+    const double *I = &Einv[9 * (size_t)p];
+    for (int a = 0; a < 3; a++) y[3 * (size_t)p + a] = I[a * 3] * v[0] + I[a * 3 + 1] * v[1] + I[a * 3 + 2] * v[2];
+  }
+  for (double v : y)
+    if (!std::isfinite(v)) return false;
+  return true;
 }
 
 }  // namespace
+
+// cq [frame_num][4] (w x y z) / ct [frame_num][3]: world -> camera, in/out; the triangulated points of sfm_f in/out.
+// Returns the reference's acceptance test (inital_sfm.cpp:279): CONVERGENCE or final cost < 3e-3.
+bool bundle_adjust(int frame_num, int l, std::vector<double> &cq, std::vector<double> &ct, std::vector<SfmFeature> &sfm_f,
+                   VioSolveStats *stats) {
+  BaLayout L;
+  L.frame_num = frame_num;
+  std::vector<int> pidx;
+  for (size_t j = 0; j < sfm_f.size(); j++) {
+    if (!sfm_f[j].state) continue;
+    for (const auto &o : sfm_f[j].observation) L.obs.push_back({o.first, (int)pidx.size(), o.second.first, o.second.second});
+    pidx.push_back((int)j);
+  }
+  const int np = L.np = (int)pidx.size(), n3 = 3 * np;
+  L.off_q.assign(frame_num, -1), L.off_t.assign(frame_num, -1);
+  for (int i = 0; i < frame_num; i++) {
+    if (i != l) L.off_q[i] = L.nc, L.nc += 3;
+    if (i != l && i != frame_num - 1) L.off_t[i] = L.nc, L.nc += 3;
+  }
+  const int nc = L.nc, N = n3 + nc;
+  std::vector<double> X(n3);
+  for (int p = 0; p < np; p++) memcpy(&X[3 * (size_t)p], sfm_f[pidx[p]].position, 24);
+  VioSolveStats st;
+  memset(&st, 0, sizeof(st));
+  auto record = [&](int it, double cost, double radius, double step_norm, double rho, double gmax, bool valid, bool ok) {
+    st.iterations = it + 1;
+    if (it < VIO_MAX_TRACE) {
+      st.it_cost[it] = cost, st.it_radius[it] = radius, st.it_step_norm[it] = step_norm, st.it_relative_decrease[it] = rho;
+      st.it_gradient_max_norm[it] = gmax, st.it_flags[it] = (valid ? 1 : 0) | (ok ? 2 : 0);
+    }
+  };
+  BaSystem sys;
+  auto x_norm_of = [&](const std::vector<double> &q, const std::vector<double> &t, const std::vector<double> &Xp) {
+    double n2 = 0.0;
+    for (double v : Xp) n2 += v * v;
+    for (int i = 0; i < frame_num; i++) {
+      if (L.off_q[i] >= 0)
+        for (int k = 0; k < 4; k++) n2 += q[4 * i + k] * q[4 * i + k];
+      if (L.off_t[i] >= 0)
+        for (int k = 0; k < 3; k++) n2 += t[3 * i + k] * t[3 * i + k];
+    }
+    return sqrt(n2);
+  };
+  auto grad_max = [&]() {  // |Plus(x, -g) - x|_inf (trust_region_minimizer.cc:270-284)
+    double m = 0.0;
+    for (double v : sys.gp) m = std::max(m, fabs(v));
+    for (int i = 0; i < frame_num; i++) {
+      if (L.off_t[i] >= 0)
+        for (int k = 0; k < 3; k++) m = std::max(m, fabs(sys.gc[L.off_t[i] + k]));
+      if (L.off_q[i] >= 0) {
+        const double d[3] = {-sys.gc[L.off_q[i]], -sys.gc[L.off_q[i] + 1], -sys.gc[L.off_q[i] + 2]};
+        double qn[4];
+        ba_quat_plus(&cq[4 * i], d, qn);
+        for (int k = 0; k < 4; k++) m = std::max(m, fabs(qn[k] - cq[4 * i + k]));
+      }
+    }
+    return m;
+  };
+  double x_cost = ba_evaluate(L, cq, ct, X, &sys), x_norm = -1.0;
+  st.initial_cost = x_cost;
+  std::vector<double> scale(N), diag(N), d2(N), y;
+  for (int k = 0; k < n3; k++) scale[k] = 1.0 / (1.0 + sqrt(sys.Hpp[9 * (size_t)(k / 3) + 4 * (k % 3)]));  // Jacobi scaling (:239-254)
+  for (int a = 0; a < nc; a++) scale[n3 + a] = 1.0 / (1.0 + sqrt(sys.Hcc[(size_t)a * nc + a]));
+  double gmax = grad_max(), radius = 1e4, decrease_factor = 2.0;
+  bool last_ok = true, reuse_diagonal = false;
+  int termination = 0, invalid_run = 0, it = 0;
+  st.num_successful_steps = 1;
+  record(0, x_cost, radius, 0, 0, gmax, true, true);
+  while (N > 0) {
+    if (it >= 50) break;
+    if (last_ok && gmax <= 1e-10) { termination = 1; break; }
+    if (radius <= 1e-32) { termination = 1; break; }
+    it++;
+    if (!reuse_diagonal) {  // LevenbergMarquardtStrategy::ComputeStep (:79-89)
+      for (int k = 0; k < n3; k++) diag[k] = std::min(std::max(scale[k] * scale[k] * sys.Hpp[9 * (size_t)(k / 3) + 4 * (k % 3)], 1e-6), 1e32);
+      for (int a = 0; a < nc; a++) diag[n3 + a] = std::min(std::max(scale[n3 + a] * scale[n3 + a] * sys.Hcc[(size_t)a * nc + a], 1e-6), 1e32);
+    }
+    reuse_diagonal = true;
+    for (int k = 0; k < N; k++) d2[k] = diag[k] / radius;  // lm_diagonal_^2 (:91)
+    bool solver_ok = ba_solve(L, sys, scale, d2, y);
+    double a = 0.0, b = 0.0;
+    if (solver_ok)
+      for (int k = 0; k < N; k++) {
+        const double g = k < n3 ? sys.gp[k] : sys.gc[k - n3];
+        a += y[k] * (scale[k] * g), b += d2[k] * y[k] * y[k];
+      }
+    const double model_cost_change = 0.5 * (a + b);  // step = -y; -step^T (gs + Hs step / 2) with (Hs + D^2) y = gs
+    if (!(solver_ok && model_cost_change > 0.0)) {
+      if (++invalid_run >= 5) { termination = 2; break; }
+      radius = radius / decrease_factor, decrease_factor *= 2.0, reuse_diagonal = true;  // StepRejected (:155-159)
+      last_ok = false, st.num_unsuccessful_steps++;
+      record(it, x_cost, radius, 0, 0, gmax, false, false);
+      continue;
+    }
+    invalid_run = 0;
+    std::vector<double> cqn(cq), ctn(ct), Xn(X);
+    double sn = 0.0;
+    for (int k = 0; k < n3; k++) {
+      const double d = -y[k] * scale[k];
+      Xn[k] = X[k] + d, sn += (X[k] - Xn[k]) * (X[k] - Xn[k]);
+    }
+    for (int i = 0; i < frame_num; i++) {
+      if (L.off_q[i] >= 0) {
+        double d[3];
+        for (int k = 0; k < 3; k++) d[k] = -y[n3 + L.off_q[i] + k] * scale[n3 + L.off_q[i] + k];
+        ba_quat_plus(&cq[4 * i], d, &cqn[4 * i]);
+        for (int k = 0; k < 4; k++) sn += (cq[4 * i + k] - cqn[4 * i + k]) * (cq[4 * i + k] - cqn[4 * i + k]);
+      }
+      if (L.off_t[i] >= 0)
+        for (int k = 0; k < 3; k++) {
+          const double d = -y[n3 + L.off_t[i] + k] * scale[n3 + L.off_t[i] + k];
+          ctn[3 * i + k] = ct[3 * i + k] + d, sn += (ct[3 * i + k] - ctn[3 * i + k]) * (ct[3 * i + k] - ctn[3 * i + k]);
+        }
+    }
+    double cand_cost = ba_evaluate(L, cqn, ctn, Xn, nullptr);
+    if (!std::isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    const double step_norm = sqrt(sn);
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { termination = 1; break; }       // ParameterToleranceReached (:666-685)
+    if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { termination = 1; break; }  // FunctionToleranceReached (:687-704)
+    const double rho = (x_cost - cand_cost) / model_cost_change;  // monotonic steps: the step evaluator's reference is x_cost
+    if (rho > 1e-3) {
+      cq.swap(cqn), ct.swap(ctn), X.swap(Xn);
+      x_norm = x_norm_of(cq, ct, X);
+      x_cost = ba_evaluate(L, cq, ct, X, &sys);
+      gmax = grad_max();
+      const double q3 = 2.0 * rho - 1.0;
+      radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - q3 * q3 * q3));  // StepAccepted (:146-153)
+      decrease_factor = 2.0, reuse_diagonal = false, last_ok = true, st.num_successful_steps++;
+      record(it, x_cost, radius, step_norm, rho, gmax, true, true);
+    } else {
+      radius = radius / decrease_factor, decrease_factor *= 2.0, reuse_diagonal = true;  // StepRejected (:155-159)
+      last_ok = false, st.num_unsuccessful_steps++;
+      record(it, cand_cost, radius, step_norm, rho, 0.0, true, false);
+    }
+  }
+  for (int p = 0; p < np; p++) memcpy(sfm_f[pidx[p]].position, &X[3 * (size_t)p], 24);
+  st.final_cost = x_cost, st.termination = termination;
+  if (stats) *stats = st;
+  return termination == 1 || x_cost < 3e-03;
+}
 
 bool sfm_construct(int frame_num, double *q, double *T, int l, const double relative_R[9], const double relative_T[3],
                    std::vector<SfmFeature> &sfm_f, std::map<int, std::vector<double>> &tracked_points) {
@@ -675,16 +830,18 @@ bool sfm_construct(int frame_num, double *q, double *T, int l, const double rela
     triangulate_point(&P[12 * a.first], &P[12 * b.first], x0, x1, f.position);
     f.state = true;
   }
-  // 5: full BA
-  double final_cost = 0;
-  const bool converged = bundle_adjust(frame_num, l, Rc, tc, sfm_f, &final_cost);
-  if (!(converged || final_cost < 3e-03)) return false;  // "vision only BA not converge"
+  // 5: full BA over (c_rotation = Quaterniond(c_Rotation[i]) as w x y z, c_translation)
+  std::vector<double> cq(4 * (size_t)frame_num);
   for (int i = 0; i < frame_num; i++) {
-    double Rt[9], v[3];
-    mat3T(&Rc[9 * i], Rt);  // q[i] = c_rotation^-1
-    const Quat qi = RtoQ(Rt);
+    const Quat qi = RtoQ(&Rc[9 * i]);
+    cq[4 * i] = qi.w, cq[4 * i + 1] = qi.x, cq[4 * i + 2] = qi.y, cq[4 * i + 3] = qi.z;
+  }
+  if (!bundle_adjust(frame_num, l, cq, tc, sfm_f, nullptr)) return false;  // "vision only BA not converge"
+  for (int i = 0; i < frame_num; i++) {
+    const Quat qi = qinv(Quat{cq[4 * i + 1], cq[4 * i + 2], cq[4 * i + 3], cq[4 * i]});  // q[i] = c_rotation^-1 (:287-295)
+    double v[3];
     q[4 * i] = qi.x, q[4 * i + 1] = qi.y, q[4 * i + 2] = qi.z, q[4 * i + 3] = qi.w;
-    mat3vec(Rt, &tc[3 * i], v);
+    qrot(qi, &tc[3 * i], v);
     for (int k = 0; k < 3; k++) T[3 * i + k] = -v[k];
   }
   for (const SfmFeature &f : sfm_f)
@@ -736,6 +893,35 @@ extern "C" int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, d
   if (!pts3 || !pts2 || n < 0 || !R || !t || !ok) return VIO_EINVAL;
   std::vector<double> p3(pts3, pts3 + 3 * (size_t)n), p2(pts2, pts2 + 2 * (size_t)n);
   *ok = init::pnp_refine(p3, p2, R, t) ? 1 : 0;
+  return VIO_OK;
+}
+
+extern "C" int vio_init_triangulate_point(const double pose0[12], const double pose1[12], const double xy0[2], const double xy1[2],
+                                          double point[3]) {
+  if (!pose0 || !pose1 || !xy0 || !xy1 || !point) return VIO_EINVAL;
+  init::triangulate_point(pose0, pose1, xy0, xy1, point);
+  return VIO_OK;
+}
+
+extern "C" int vio_init_bundle_adjust(int32_t frame_num, int32_t l, double *c_rotation, double *c_translation, int32_t n_points,
+                                      double *points, const uint8_t *point_ok, const int32_t *feat_start, const int32_t *obs_frame,
+                                      const double *obs_xy, VioSolveStats *stats, int32_t *ok) {
+  if (frame_num < 2 || l < 0 || l >= frame_num || !c_rotation || !c_translation || n_points < 0 || !points || !point_ok ||
+      !feat_start || !obs_frame || !obs_xy || !ok)
+    return VIO_EINVAL;
+  std::vector<init::SfmFeature> f(n_points);
+  for (int j = 0; j < n_points; j++) {
+    f[j].id = j, f[j].state = point_ok[j] != 0;
+    memcpy(f[j].position, points + 3 * (size_t)j, 24);
+    for (int k = feat_start[j]; k < feat_start[j + 1]; k++) {
+      if (obs_frame[k] < 0 || obs_frame[k] >= frame_num) return VIO_EINVAL;
+      f[j].observation.push_back({obs_frame[k], {obs_xy[2 * k], obs_xy[2 * k + 1]}});
+    }
+  }
+  std::vector<double> cq(c_rotation, c_rotation + 4 * (size_t)frame_num), ct(c_translation, c_translation + 3 * (size_t)frame_num);
+  *ok = init::bundle_adjust(frame_num, l, cq, ct, f, stats) ? 1 : 0;
+  memcpy(c_rotation, cq.data(), sizeof(double) * cq.size()), memcpy(c_translation, ct.data(), sizeof(double) * ct.size());
+  for (int j = 0; j < n_points; j++) memcpy(points + 3 * (size_t)j, f[j].position, 24);
   return VIO_OK;
 }
 
