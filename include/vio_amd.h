@@ -30,6 +30,7 @@
 #ifndef VIO_AMD_H
 #define VIO_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -279,6 +280,18 @@ int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t ro
                              int32_t cols, int32_t stride, const double *headers,
                              int32_t publish, VioObs *out_obs /* [n_seq][max_corners] */,
                              int32_t *n_obs /* [n_seq] */);
+
+/* The same in two halves, for callers that overlap the front-end of frame k+1
+ * with the estimator of frame k (the app runs readImage and processImage on
+ * two threads: ViewController.mm:458 and :688-724). submit gathers the frames,
+ * queues the transfer, the kernels and the copy of the observations and returns
+ * without waiting for the device; collect waits and hands the observations
+ * over. One frame in flight per context: a second submit before collect is
+ * VIO_ESTATE, as is collect without submit.                                    */
+int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows,
+                               int32_t cols, int32_t stride, int32_t publish);
+int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs /* [n_seq][max_corners] */,
+                         int32_t *n_obs /* [n_seq] */);
 
 /* Resident form for throughput runs: frames already in HBM.                  */
 int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t n_frames,
@@ -810,6 +823,12 @@ int vio_measurements_next(vio_measurements_t *q, VioImuMsg *imu, double *dt /* m
                           int32_t *available);
 
 const char *vio_version(void);
+/* The HIP runtime(s) mapped into the calling process (files named libamdhip64*
+ * in /proc/self/maps), ';'-separated, and their number. The library binds to
+ * the copy the process loaded first (next to PyTorch: the one bundled with the
+ * wheel). With more than one copy mapped the device contexts refuse to start
+ * (VIO_ENODEV, both paths on stderr): each copy would keep its own device state. */
+int vio_hip_runtime(char *path, int32_t cap, int32_t *n_runtimes);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,8 @@
 
 using namespace vio;
 
-// variant: 1 = matrix in "LDS" (vio_window_kernel<true>), 0 = matrix in global scratch (<false>), -1 = what the
+// variant: 1 = matrix in "LDS" (vio_window_kernel<true, true>), 2 = the same with the IMU coupling in global scratch
+// (<true, false>: the layout of windows with many landmarks), 0 = matrix in global scratch (<false, false>), -1 = what the
 // launcher would pick. Returns VIO_ECAP when the requested variant does not fit the CU's LDS.
 extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveStats *stats, int nthreads, int variant,
                                  int order) {
@@ -24,6 +25,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     if (win->factor_target[k] == win->window_size + 1) any_loop = true;
   HostBatch hb;
   hb.resize(make_dims(*cfg, win->window_size, win->n_features, win->n_factors, any_loop), 1);
+  hb.d.lds_asp = variant == 2 ? 0 : 1;
   const bool lds_shape = pose_jp(hb.d) <= 16 * kPanelTiles && variant != 0;
   int rc = pack_window(hb, 0, *win, false, order % 2 ? 0 : stage_chunk_slots(hb.d, lds_shape, nthreads));  // (with and without bucket alignment)
   if (rc != VIO_OK) return rc;
@@ -50,6 +52,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   B.raw_pose = raw_pose.data(), B.raw_sb = raw_sb.data(), B.raw_feat = raw_feat.data(), B.out_loop = out_loop.data();
   B.stats_d = stats_d.data(), B.stats_i = stats_i.data();
   B.d.Flds = std::max(1, win->n_features);
+  B.d.lds_asp = variant == 2 ? 0 : 1;  // variant 2: the LDS matrix with the IMU coupling in global scratch
 
   // LDS or global matrix: the launcher's rule (vio_backend.hip backend_upload_impl)
   auto lds_need = [&](bool lds_matrix) {
@@ -59,7 +62,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     return std::max(bs, bm + (lds_matrix ? 64 * kMargSlot * sizeof(double) : 0));
   };
   bool lds_matrix = pose_jp(B.d) <= 16 * kPanelTiles && lds_need(true) <= kLdsBytes;
-  if (variant == 1 && !lds_matrix) return VIO_ECAP;
+  if ((variant == 1 || variant == 2) && !lds_matrix) return VIO_ECAP;
   if (variant == 0) lds_matrix = false;
   if (!lds_matrix && lds_need(false) > kLdsBytes) return VIO_ECAP;
   // (the launcher gives an LDS-variant workgroup half a CU whenever its layout fits there: two windows per CU)

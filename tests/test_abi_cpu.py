@@ -61,3 +61,12 @@ def test_product_preintegration_matches_reference_golden():
         assert np.allclose(out[:17], ref[:17], rtol=1e-12, atol=1e-15)
         assert H.relerr(out[17:242], ref[17:242]) < 1e-12
         assert H.relerr(out[242:], ref[242:]) < 1e-12
+
+
+def test_hip_runtime_report_names_what_is_mapped():
+    """vio_hip_runtime lists the libamdhip64 copies of this process as /proc/self/maps shows them (here: exactly one, the
+    copy the library was linked against or the one PyTorch brought along, whichever was loaded first)."""
+    lib = abi.load_product()
+    paths = abi.hip_runtime(lib)
+    mapped = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+    assert sorted(paths) == mapped and len(paths) == 1

@@ -141,6 +141,36 @@ def test_resident_stepping_equals_read_images():
     a.close(), b.close()
 
 
+def test_submit_collect_equals_read_images():
+    """The two halves of read_images (vio_frontend_submit_images / vio_frontend_collect) with host work between them
+    publish what the one call publishes; a second submit or a collect out of order is VIO_ESTATE."""
+    import ctypes as C
+    cfg = abi.default_config(max_corners=80, min_dist=20, image_rows=240, image_cols=320)
+    S, T, cap = 3, 5, 80
+    streams = [synth.make_image_stream(40 + s, T, rows=240, cols=320)[0] for s in range(S)]
+    a, b = fe.FeatureTracker(cfg, n_seq=S), fe.FeatureTracker(cfg, n_seq=S)
+    lib = b.lib
+    obs = np.zeros(S * cap, fe._OBS_DTYPE)
+    obs_p, n_obs = C.cast(obs.ctypes.data, C.POINTER(abi.VioObs)), np.zeros(S, np.int32)
+    u8p, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    assert lib.vio_frontend_collect(b._h, obs_p, n_obs.ctypes.data_as(ip)) == abi.VIO_ESTATE
+    for f in range(T):
+        frames = np.ascontiguousarray(np.stack([streams[s][f] for s in range(S)]))
+        want = a.read_images(frames, f % 2 == 0)
+        assert lib.vio_frontend_submit_images(b._h, frames.ctypes.data_as(u8p), 240, 320, 320, int(f % 2 == 0)) == 0
+        assert lib.vio_frontend_submit_images(b._h, frames.ctypes.data_as(u8p), 240, 320, 320, 1) == abi.VIO_ESTATE
+        frames[:] = 0      # the caller's buffer is free again once submit has returned
+        assert lib.vio_frontend_collect(b._h, obs_p, n_obs.ctypes.data_as(ip)) == 0
+        o = obs.reshape(S, cap)
+        for s in range(S):
+            ids, xyz = want[s]
+            assert n_obs[s] == len(ids)
+            assert np.array_equal(o[s, :n_obs[s]]["id"], ids) and np.array_equal(o[s, :n_obs[s]]["x"], xyz[:, 0])
+            for x, y in zip(a.state(s), b.state(s)):
+                assert np.array_equal(x, y)
+    a.close(), b.close()
+
+
 @pytest.mark.parametrize("rows,cols,corners,min_dist,T", [
     (250, 333, 60, 12, 5),     # neither a multiple of the 32-row strips nor of the 60-column waves of detect_kernel
     (97, 61, 20, 8, 4),        # one partial strip row, one partial wave; 2 pyramid levels

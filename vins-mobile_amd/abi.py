@@ -42,6 +42,14 @@ class VioConfig(C.Structure):
     ]
 
 
+def hip_runtime(lib=None):
+    """-> (list of libamdhip64 files mapped into this process, as the library sees them)."""
+    lib = lib or load_product()
+    buf, n = C.create_string_buffer(4096), C.c_int32()
+    lib.vio_hip_runtime(buf, 4096, C.byref(n))
+    return [p for p in buf.value.decode().split(";") if p]
+
+
 def default_config(**kw):
     """The reference's iPhone7P values (global_param.cpp:27-42, feature_tracker.hpp:24-29)."""
     c = VioConfig(
@@ -448,6 +456,9 @@ def load_product():
                                             C.POINTER(VioObs), _ip, vp]
     lib.vio_frontend_read_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32,
                                              C.POINTER(VioObs), _ip]
+    lib.vio_hip_runtime.argtypes = [C.c_char_p, C.c_int32, _ip]
+    lib.vio_frontend_submit_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.vio_frontend_collect.argtypes = [vp, C.POINTER(VioObs), _ip]
     lib.vio_frontend_upload_frames.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_step_resident.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.vio_frontend_sync.argtypes = [vp]

@@ -27,6 +27,8 @@ constexpr int kMaxPriorBlocks = VIO_MAX_PRIOR_BLOCKS;
 struct BatchDims {
   int Wcap, Pcap, Fcap, Mcap, Ncap, Fpad, n6cap, nblk_cap, pair_cap;
   int Flds;  // landmarks the LDS layout is carved for (<= Fcap, which sizes the global strides): every landmark costs LDS
+  int lds_asp;  // LDS pose matrix: the IMU speed-bias x pose coupling (AspI, 14 KB at W = 10) sits in LDS too (1, faster)
+                // or in global scratch (0: leaves the room to windows with many landmarks, two of which then share a CU)
   int max_iter;
   double s_info, gravity, cauchy_b;
 };
@@ -39,6 +41,7 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
   d.Ncap = 15 * d.Pcap + 6;
   d.Fpad = (d.Fcap + 7) / 8 * 8;
   d.Flds = d.Fcap;
+  d.lds_asp = 1;
   d.n6cap = 6 * (d.Pcap + 1);  // pose groups 0..P-1 plus one more: loop pose (solve) / extrinsic (marginalization)
   d.nblk_cap = d.Pcap + (any_loop ? 1 : 0);
   d.pair_cap = (d.Pcap + 1) * (d.Pcap + 2) / 2;  // distinct (host, target) pairs incl. the loop pose
@@ -192,17 +195,17 @@ struct MatPick<ldsd> {
 // (A null test of a pointer to a private-memory object is not folded by LLVM -- in the private address space 0 is a
 // valid address -- and one such compare is enough to keep the whole struct out of registers: the first version of the
 // kernel read every w.field and cx.field back from scratch memory, ~1100 scratch_load sites.)
-template <class MP>
+template <class MP, class AP = MP>
 struct Carved {
-  WorkT<MP> w;
+  WorkT<MP, AP> w;
   ldsd red;
   VIO_AS3 long long *lprof;
   size_t bytes, state_end_doubles;
 };
 
-template <class MP>
-VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global, double *asp_global = nullptr) {
-  Carved<MP> c;
+template <class MP, class AP = MP>
+VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global, double *asp_global = nullptr) {
+  Carved<MP, AP> c;
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // pose-side vector length (frame-major; the loop pose uses 6 of its 15)
   const size_t F = d.Flds;
@@ -211,7 +214,7 @@ VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, l
     o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
     return p;
   };
-  WorkT<MP> &w = c.w;
+  WorkT<MP, AP> &w = c.w;
   // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
   w.xpose = take(7 * (size_t)(d.Pcap + 1)), w.xsb = take(9 * (size_t)d.Pcap), w.xfeat = take(F);
   w.ex = take(8);
@@ -226,8 +229,9 @@ VIO_HD Carved<MP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, l
   if (lds_matrix) app = take(napp);
   w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
   w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
-  ldsd aspi = lds_matrix ? take((size_t)d.Pcap * kAS + 16) : nullptr;
-  w.AspI = MatPick<MP>::get(lds_matrix, aspi, asp_global);
+  const bool lds_asp = lds_matrix && d.lds_asp != 0;
+  ldsd aspi = lds_asp ? take((size_t)d.Pcap * kAS + 16) : nullptr;
+  w.AspI = MatPick<AP>::get(lds_asp, aspi, asp_global);
   w.nstage = lds_matrix ? (int)(o - o_mat) : (int)napp;
   w.cfeat = take(F);
   w.gf = take(F), w.sf = take(F), w.gnf = take(F), w.stf = take(F), w.hff = take(F), w.einv = take(F), w.tf = take(F);
@@ -338,9 +342,9 @@ struct HostBatch {
   // padding keeps finite values of earlier windows.
   void resize(const BatchDims &dims, int n_, bool poison = false) {
     BatchDims a = d, b = dims;
-    a.Flds = b.Flds = 0;  // the LDS carve size does not change the staging layout
+    a.Flds = b.Flds = 0, a.lds_asp = b.lds_asp = 0;  // the LDS carve does not change the staging layout
     if (sized && !poison && n == n_ && memcmp(&a, &b, sizeof(BatchDims)) == 0) {
-      d.Flds = dims.Flds;
+      d.Flds = dims.Flds, d.lds_asp = dims.lds_asp;
       return;
     }
     d = dims, s = make_strides(dims), n = n_, sized = true;

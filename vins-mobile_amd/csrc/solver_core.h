@@ -246,14 +246,15 @@ VIO_HD size_t tri_doubles(int nrows) {
 }
 
 // LDS (or emulated) working set; all arrays sized by the launcher from the dims. MP is the pointer type of the pose
-// matrix: LDS when it fits (ldsd), else global (double *).
-template <class MP>
+// matrix: LDS when it fits (ldsd), else global (double *); AP that of the IMU part of the speed-bias x pose coupling,
+// which follows the matrix into LDS unless the landmark arrays need the room (BatchDims::lds_asp).
+template <class MP, class AP = MP>
 struct WorkT {
   typedef MP mat_ptr;
   MP App;         // pose x pose (+ the carried right-hand side row), tile-row packed lower triangle
   int nstage;     // doubles behind App that are free whenever the reduced matrix is not assembled (Jacobian-row staging)
   ldsd Dss, Css;  // speed-bias band: P blocks of 81 each, Css = Dss + 81 P (contiguous with App when App is in LDS)
-  MP AspI;        // [P][9][18]: behind Css when the pose matrix is in LDS, else in the window's global scratch
+  AP AspI;        // [P][9][18]: behind Css in LDS, or in the window's global scratch (WinView::AspG)
   ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
   ldsd cpose, csb, cfeat;   // candidate
   ldsd ex;                  // 7

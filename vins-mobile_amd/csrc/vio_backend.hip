@@ -44,16 +44,18 @@ struct MargPtrs {
 
 // NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
 // 512-thread workgroup per CU)
-template <bool LDS_MATRIX, int NT>
+// LDS_ASP: the IMU speed-bias x pose coupling is in LDS as well (B.d.lds_asp says the same to the layout)
+template <bool LDS_MATRIX, bool LDS_ASP, int NT>
 __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
   WinView v = make_view(B, b);
   typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
+  typedef typename std::conditional<LDS_MATRIX && LDS_ASP, ldsd, double *>::type AspP;
   ldsd lds = (ldsd)smem;
   // (by value: neither struct ever has its address taken, so both live in registers)
-  const Carved<MatP> cw = carve_all<MatP>(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, v.AspG);
-  WorkT<MatP> w = cw.w;
+  const Carved<MatP, AspP> cw = carve_all<MatP, AspP>(B.d, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, v.AspG);
+  WorkT<MatP, AspP> w = cw.w;
   Ctx cx;
   cx.tid = threadIdx.x, cx.nt = blockDim.x;
   cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
@@ -158,6 +160,7 @@ struct vio_backend {
   bool profile = false;
   size_t lds_bytes = 0;
   int threads_lds = kThreadsLds;
+  int n_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   DevBuf<long long> d_prof;
   HostBatch hb;
   BatchPtrs B;
@@ -186,6 +189,18 @@ extern "C" {
 
 const char *vio_version(void) { return "vio_amd 0.1 (gfx950)"; }
 
+int vio_hip_runtime(char *path, int32_t cap, int32_t *n_runtimes) {
+  const std::vector<std::string> r = vio::hip_runtimes();
+  if (n_runtimes) *n_runtimes = (int32_t)r.size();
+  if (path && cap > 0) {
+    std::string all;
+    for (size_t i = 0; i < r.size(); i++) all += (i ? ";" : "") + r[i];
+    strncpy(path, all.c_str(), (size_t)cap - 1);
+    path[cap - 1] = 0;
+  }
+  return VIO_OK;
+}
+
 void vio_config_default(VioConfig *c) {
   // iPhone7P, global_param.cpp:27-42; feature_tracker.hpp:24-29; global_param.hpp:28-58
   c->window_size = 10, c->max_features = 1000, c->max_factors = 8192, c->max_iterations = 10;
@@ -205,17 +220,23 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
     fprintf(stderr, "vio_amd: no HIP device visible; the back-end has no CPU fallback\n");
     return VIO_ENODEV;
   }
+  if (!vio::single_hip_runtime()) return VIO_ENODEV;
   vio_backend *be = new (std::nothrow) vio_backend();
   if (!be) return VIO_ENOMEM;
   be->cfg = *cfg;
   be->max_batch = max_batch;
   be->device = vio::current_device();
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, be->device) == hipSuccess && prop.multiProcessorCount > 0) be->n_cus = prop.multiProcessorCount;
+  }
   // the dynamic-LDS ceiling is a property of the FUNCTION, not of a launch: raised once to the CU's whole LDS for both
   // variants (several contexts on several host threads launch these kernels; a per-launch value could be lowered by
   // another thread between this thread's set and its launch)
-  if (hipFuncSetAttribute((const void *)vio_window_kernel<true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+  if (hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_window_kernel<false, false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
     delete be;
     return VIO_ENODEV;
   }
@@ -340,6 +361,62 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
   d.Flds = std::max(Fmax, 1);
+  // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
+  // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
+  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
+  // variant in one launch -- with half a CU's LDS per workgroup whenever that is enough, so that two windows share a
+  // CU --, everything else the global-matrix variant in a second one. (Decided before packing: the staging chunk the
+  // buckets are aligned to depends on the layout.)
+  static const int threads_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
+  be->threads_lds = threads_lds;
+  auto need_lds = [&](BatchDims dd, int asp) {
+    dd.lds_asp = asp;
+    size_t se = 0;
+    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
+    // the marginalization phase additionally wants >= 64 staging slots behind its matrix
+    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
+  };
+  // (eligibility: the lean layout, IMU coupling in global memory, inside one CU; the 512-thread build of the LDS variant
+  // -- an experiment switch -- only exists with the coupling in LDS)
+  const int lean_asp = threads_lds == kThreadsLds ? 0 : 1;
+  auto fits_lds = [&](const BatchDims &dd) { return pose_jp(dd) <= 16 * kPanelTiles && need_lds(dd, lean_asp) <= kLdsLimit; };
+  std::vector<int> cand, order;
+  for (int b = 0; b < n; b++) cand.push_back(b);
+  std::sort(cand.begin(), cand.end(), [&](int a, int b2) { return windows[a].n_features < windows[b2].n_features; });
+  BatchDims dl = d;
+  int n_lds = (int)cand.size();
+  while (n_lds > 0) {
+    dl.Flds = std::max(1, windows[cand[n_lds - 1]].n_features);
+    if (fits_lds(dl)) break;
+    n_lds--;
+  }
+  std::vector<char> in_lds(n, 0);
+  for (int i = 0; i < n_lds; i++) in_lds[cand[i]] = 1, order.push_back(cand[i]);
+  for (int b = 0; b < n; b++)
+    if (!in_lds[b]) order.push_back(b);
+  be->n_lds = n_lds, be->n_glb = n - n_lds, be->lds_matrix = be->n_glb == 0;
+  // Two workgroups per CU (half its LDS each) beat everything else; inside that, the IMU speed-bias x pose coupling is
+  // better off in LDS. Windows with many landmarks give its 14 KB up (global scratch, L2-resident) to stay two per CU.
+  // The marginalization phase stages Jacobian rows in whatever LDS is left behind its matrix.
+  static const bool one_per_cu = getenv("VIO_AMD_WINDOW_ONE_PER_CU") && getenv("VIO_AMD_WINDOW_ONE_PER_CU")[0] == '1';
+  static const int force_asp = getenv("VIO_AMD_LDS_ASP") ? atoi(getenv("VIO_AMD_LDS_ASP")) : -1;
+  be->lds_bytes = kLdsLimit;
+  if (n_lds > 0) {
+    const size_t fat = need_lds(dl, 1), lean = need_lds(dl, lean_asp);
+    // (the lean layout costs a window ~25 % of its latency -- every Gauss-Newton step then has a few more round trips to
+    // L2 --: it only pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with
+    // closed-loop windows of ~190 landmarks: 2 x 128 windows 6.2 vs 5.1 ms per frame, 2 x 256 windows 8.6 vs 9.4 ms.)
+    const bool crowded = n_lds > be->n_cus / 2;
+    if (!one_per_cu && fat <= kLdsHalf) dl.lds_asp = 1, be->lds_bytes = kLdsHalf;
+    else if (!one_per_cu && crowded && lean <= kLdsHalf) dl.lds_asp = lean_asp, be->lds_bytes = kLdsHalf;
+    else dl.lds_asp = fat <= kLdsLimit ? 1 : lean_asp;
+    if ((force_asp == 0 && lean_asp == 0) || (force_asp == 1 && fat <= kLdsLimit)) {
+      dl.lds_asp = force_asp;
+      be->lds_bytes = (!one_per_cu && need_lds(dl, force_asp) <= kLdsHalf) ? kLdsHalf : kLdsLimit;
+    }
+  }
+  be->d_lds = dl;
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
   // the previous upload's copy may still be reading the staging arena (uploads do not wait for their own transfer)
   HIP_OK(hipStreamSynchronize(be->stream));
@@ -348,8 +425,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   {
     std::vector<int> rcs(n, VIO_OK);
     const bool lds_shape = pose_jp(d) <= 16 * kPanelTiles;
-    static const int thr_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
-    const int chunk = stage_chunk_slots(d, lds_shape, lds_shape ? thr_lds : kThreadsGlb);
+    const int chunk = stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
     vio::HostPool::get().parallel_for(n, [&](int b) {
       try {
         rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0, chunk);
@@ -362,46 +438,10 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   }
   const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
-  // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
-  // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
-  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
-  // variant in one launch -- with half a CU's LDS per workgroup whenever that is enough, so that two windows share a
-  // CU --, everything else the global-matrix variant in a second one.
-  static const int threads_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
-  be->threads_lds = threads_lds;
-  auto need_lds = [&](const BatchDims &dd) {
-    size_t se = 0;
-    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
-    // the marginalization phase additionally wants >= 64 staging slots behind its matrix
-    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
-  };
-  auto fits_lds = [&](const BatchDims &dd) { return pose_jp(dd) <= 16 * kPanelTiles && need_lds(dd) <= kLdsLimit; };
-  std::vector<int> cand, order;
-  for (int b = 0; b < n; b++) cand.push_back(b);
-  std::sort(cand.begin(), cand.end(), [&](int a, int b2) {
-    return be->hb.hdr[(size_t)a * kHdrInts + H_F] < be->hb.hdr[(size_t)b2 * kHdrInts + H_F];
-  });
-  BatchDims dl = d;
-  int n_lds = (int)cand.size();
-  while (n_lds > 0) {
-    dl.Flds = std::max(1, be->hb.hdr[(size_t)cand[n_lds - 1] * kHdrInts + H_F]);
-    if (fits_lds(dl)) break;
-    n_lds--;
-  }
-  std::vector<char> in_lds(n, 0);
-  for (int i = 0; i < n_lds; i++) in_lds[cand[i]] = 1, order.push_back(cand[i]);
-  for (int b = 0; b < n; b++)
-    if (!in_lds[b]) order.push_back(b);
-  be->n_lds = n_lds, be->n_glb = n - n_lds, be->d_lds = dl, be->lds_matrix = be->n_glb == 0;
-  // the marginalization phase stages Jacobian rows in whatever LDS is left: half a CU when the layout fits it (two
-  // workgroups per CU), else the whole CU
-  static const bool one_per_cu = getenv("VIO_AMD_WINDOW_ONE_PER_CU") && getenv("VIO_AMD_WINDOW_ONE_PER_CU")[0] == '1';
-  be->lds_bytes = (n_lds > 0 && need_lds(dl) <= kLdsHalf && !one_per_cu) ? kLdsHalf : kLdsLimit;
   if (be->n_glb > 0) {
     BatchDims dg = d;
     int fg = 1;
-    for (int i = n_lds; i < n; i++) fg = std::max(fg, be->hb.hdr[(size_t)order[i] * kHdrInts + H_F]);
+    for (int i = n_lds; i < n; i++) fg = std::max(fg, windows[order[i]].n_features);
     dg.Flds = fg;
     size_t se = 0;
     const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
@@ -537,17 +577,20 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    if (be->threads_lds == kThreadsLds)
-      hipLaunchKernelGGL((vio_window_kernel<true, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
+    if (be->threads_lds == kThreadsLds && be->d_lds.lds_asp)
+      hipLaunchKernelGGL((vio_window_kernel<true, true, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
+                         (int)(be->lds_bytes / sizeof(double)));
+    else if (be->threads_lds == kThreadsLds)
+      hipLaunchKernelGGL((vio_window_kernel<true, false, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
                          (int)(be->lds_bytes / sizeof(double)));
     else
-      hipLaunchKernelGGL((vio_window_kernel<true, kThreadsGlb>), dim3(be->n_lds), dim3(kThreadsGlb), be->lds_bytes, st, Bl, be->MP,
+      hipLaunchKernelGGL((vio_window_kernel<true, true, kThreadsGlb>), dim3(be->n_lds), dim3(kThreadsGlb), be->lds_bytes, st, Bl, be->MP,
                          (int)(be->lds_bytes / sizeof(double)));
   }
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
     Bg.d = be->d_glb, Bg.order = be->d_order.p + be->n_lds;
-    hipLaunchKernelGGL((vio_window_kernel<false, kThreadsGlb>), dim3(be->n_glb), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
+    hipLaunchKernelGGL((vio_window_kernel<false, false, kThreadsGlb>), dim3(be->n_glb), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
                        (int)(be->lds_bytes_glb / sizeof(double)));
   }
   HIP_OK(hipGetLastError());

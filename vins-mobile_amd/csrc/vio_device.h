@@ -6,8 +6,49 @@
 // of the call (and puts the thread's previous device back), so a context works from any thread.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
 
 namespace vio {
+
+// The HIP runtime(s) mapped into this process: distinct files named libamdhip64* in /proc/self/maps. The library binds
+// to whichever one the process loaded first (next to PyTorch that is the copy bundled with the wheel, not /opt/rocm's).
+// Two different copies in one process each keep their own device state -- streams, allocations and kernels of one are
+// invisible to the other -- so the contexts refuse to start in that case instead of failing in obscure ways later.
+inline std::vector<std::string> hip_runtimes() {
+  std::vector<std::string> out;
+  FILE *f = fopen("/proc/self/maps", "r");
+  if (!f) return out;
+  char line[4096];
+  while (fgets(line, sizeof(line), f)) {
+    const char *lib = strstr(line, "libamdhip64");
+    if (!lib) continue;
+    const char *path = strchr(line, '/');
+    if (!path) continue;
+    std::string p(path);
+    while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+    bool seen = false;
+    for (const std::string &q : out) seen = seen || q == p;
+    if (!seen) out.push_back(p);
+  }
+  fclose(f);
+  return out;
+}
+inline bool single_hip_runtime() {
+  static const int n = [] {
+    const std::vector<std::string> r = hip_runtimes();
+    if (r.size() > 1) {
+      fprintf(stderr, "vio_amd: %zu different HIP runtimes are mapped into this process:\n", r.size());
+      for (const std::string &p : r) fprintf(stderr, "vio_amd:   %s\n", p.c_str());
+      fprintf(stderr, "vio_amd: refusing to create device contexts (load one runtime only, e.g. import torch before this library)\n");
+    }
+    return (int)r.size();
+  }();
+  return n <= 1;
+}
 
 inline int current_device() {
   int d = 0;

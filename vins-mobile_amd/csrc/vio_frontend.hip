@@ -1334,6 +1334,7 @@ struct vio_frontend {
   uint8_t *d_stage = nullptr;
   VioObs *p_obs = nullptr;
   uint8_t *p_frames = nullptr;  // page-locked gathering buffer of read_images
+  bool pending = false, pending_publish = false;  // a submitted frame waits for vio_frontend_collect
   int *p_nobs = nullptr;
   // host staging
   std::vector<VioObs> h_obs;
@@ -1439,6 +1440,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
     fprintf(stderr, "vio_amd: no HIP device visible; the front-end has no CPU fallback\n");
     return VIO_ENODEV;
   }
+  if (!vio::single_hip_runtime()) return VIO_ENODEV;
   vio_frontend *fe = new vio_frontend();
   fe->device = vio::current_device();
   fe->cfg = *cfg, fe->n_seq = n_seq, fe->cap = cfg->max_corners;
@@ -1587,11 +1589,14 @@ int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches
   return VIO_OK;
 }
 
-int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride,
-                             const double *headers, int32_t publish, VioObs *out_obs, int32_t *n_obs) {
-  (void)headers;  // the reference only forwards the header to the (default-off) vinsPnP branch
-  if (!fe || !gray || !n_obs || (publish && !out_obs)) return VIO_EINVAL;
+// The two halves of read_images. submit: gathers the caller's (pageable) frames into page-locked memory, queues their
+// transfer, every kernel of the frame and the copy of the published observations on the context's stream and returns
+// without waiting for the device; collect: waits and hands the observations over. A caller that submits frame k+1 before
+// it runs the estimator on frame k overlaps the front-end's transfers and kernels with the estimator's host phases.
+int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride, int32_t publish) {
+  if (!fe || !gray) return VIO_EINVAL;
   if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;  // one frame in flight per context: collect it first
   VIO_ON_DEVICE_OF(fe);
   const size_t px = (size_t)rows * cols, S = fe->n_seq;
   // host frames land in a device staging buffer kept for the life of the context; observations come back through
@@ -1628,14 +1633,34 @@ int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t ro
     HIP_OK(hipMemcpyAsync(fe->p_obs, fe->obs, sizeof(VioObs) * S * fe->cap, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(fe->p_nobs, fe->n_obs, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   }
-  HIP_OK(hipStreamSynchronize(st));
+  fe->pending = true, fe->pending_publish = publish != 0;
+  return VIO_OK;
+}
+
+int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs, int32_t *n_obs) {
+  if (!fe || !n_obs) return VIO_EINVAL;
+  if (!fe->pending) return VIO_ESTATE;
+  if (fe->pending_publish && !out_obs) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
+  fe->pending = false;
+  HIP_OK(hipStreamSynchronize(fe->stream));
+  const size_t S = fe->n_seq;
   for (size_t s = 0; s < S; s++) n_obs[s] = 0;
-  if (publish)
+  if (fe->pending_publish)
     for (size_t s = 0; s < S; s++) {
       n_obs[s] = fe->p_nobs[s];
       memcpy(out_obs + s * fe->cap, fe->p_obs + s * fe->cap, sizeof(VioObs) * fe->p_nobs[s]);
     }
   return VIO_OK;
+}
+
+int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride,
+                             const double *headers, int32_t publish, VioObs *out_obs, int32_t *n_obs) {
+  (void)headers;  // the reference only forwards the header to the (default-off) vinsPnP branch
+  if (!fe || !gray || !n_obs || (publish && !out_obs)) return VIO_EINVAL;
+  int rc = vio_frontend_submit_images(fe, gray, rows, cols, stride, publish);
+  if (rc != VIO_OK) return rc;
+  return vio_frontend_collect(fe, out_obs, n_obs);
 }
 
 int vio_frontend_read_image(vio_frontend_t *fe, int32_t seq, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride,
