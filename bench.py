@@ -438,8 +438,7 @@ def end_to_end(n_seq):
     """The estimator path (csrc/vio_estimator.cpp): per frame, host observations + IMU in, host states out — landmark
     bookkeeping, window assembly, packing, H2D, ONE window-kernel launch for all sequences, D2H, slides."""
     a = _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, 24, quiet=True); print(json.dumps([s, l]))" % n_seq)
-    b = _tool("import os; os.environ['VIO_AMD_EST_GROUPS'] = '4'; import time_estimator as TE; "
-              "s, _, _, l = TE.run(%d, 20, quiet=True); print(json.dumps([s, l]))" % (4 * n_seq))
+    b = _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, 20, quiet=True); print(json.dumps([s, l]))" % (4 * n_seq))
     solves, lib_s = a
     return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
             "frames_timed": solves // n_seq, "path": "vio_estimator_process_imu_batch + vio_estimator_process_images, one estimator "
@@ -447,7 +446,7 @@ def end_to_end(n_seq):
             "kernels), host buffers in / host states out, priors resident on the device; time inside the two "
             "library calls (closed-loop windows: ~190 landmarks, ~1400 factors, prior); measured in a process of its own",
             "ms_per_frame_of_all_sequences": lib_s / (solves // n_seq) * 1e3,
-            "at_%d_sequences" % (4 * n_seq): {"value": b[0] / b[1], "groups": 4, "ms_per_frame_of_all_sequences": b[1] / (b[0] // (4 * n_seq)) * 1e3}}
+            "at_%d_sequences" % (4 * n_seq): {"value": b[0] / b[1], "groups_of_sequences": 4, "ms_per_frame_of_all_sequences": b[1] / (b[0] // (4 * n_seq)) * 1e3}}
 
 
 def end_to_end_full(n_seq):

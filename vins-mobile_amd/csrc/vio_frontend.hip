@@ -1343,6 +1343,68 @@ struct vio_frontend {
 
 namespace {
 
+// The same for source rows that are whole dwords (scols % 4 == 0, dword-aligned level offsets): the patch arrives as 4
+// pixels per lane and per load instead of 1, the output leaves as 4 pixels per store. One workgroup = 64 x 16 output
+// pixels from a (2*64+8) x (2*16+4) source patch [2 ox - 4, 2 ox + 132) x [2 oy - 2, 2 oy + 34). Rows are reflected as
+// whole rows; the (at most two) reflected columns on either side of the image are patched into the staged dwords.
+// Arithmetic and rounding are those of pyr_down_kernel (bit-identical output).
+constexpr int kPd4H = 16, kPd4Dw = (2 * kPdW + 8) / 4;  // 34 dwords per staged row
+__global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base, uint8_t *dst_base, size_t seq_stride,
+                                                        int srows, int scols, int drows, int dcols) {
+  constexpr int SH = 2 * kPd4H + 4;
+  __shared__ uint32_t raw[SH][kPd4Dw + 1];
+  __shared__ int hsum[SH][kPdW + 1];
+  const uint8_t *src = src_base + (size_t)blockIdx.z * seq_stride;
+  uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
+  const int ox = blockIdx.x * kPdW, oy = blockIdx.y * kPd4H;
+  const int tid = threadIdx.x;
+  const int ndw = scols >> 2, dw0 = (2 * ox - 4) >> 2;  // dwords per source row; dword index of the patch's first column
+  for (int e = tid; e < SH * kPd4Dw; e += 256) {
+    const int ly = e / kPd4Dw, lx = e - ly * kPd4Dw;
+    const int y = reflect101(min(2 * oy + ly - 2, 2 * srows - 2), srows);
+    const int d = min(max(dw0 + lx, 0), ndw - 1);
+    raw[ly][lx] = reinterpret_cast<const uint32_t *>(src + (size_t)y * scols)[d];
+  }
+  __syncthreads();
+  // columns -2, -1 (left-most tile) and scols, scols + 1 (the tile that holds them): BORDER_REFLECT_101
+  if (tid < SH) {
+    if (ox == 0) {  // dword 0 = columns -4 .. -1, dword 1 = columns 0 .. 3
+      const uint32_t d1 = raw[tid][1];
+      raw[tid][0] = ((d1 >> 16) & 0xffu) << 16 | ((d1 >> 8) & 0xffu) << 24;  // col -2 <- col 2, col -1 <- col 1
+    }
+    const int lr = ndw - dw0;  // staged dword that starts at column scols
+    if (lr >= 1 && lr < kPd4Dw) {
+      const uint32_t dl = raw[tid][lr - 1];  // columns scols - 4 .. scols - 1
+      raw[tid][lr] = ((dl >> 16) & 0xffu) | ((dl >> 8) & 0xffu) << 8;  // col scols <- col scols - 2, col scols + 1 <- col scols - 3
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < SH * kPdW; e += 256) {
+    const int ly = e / kPdW, lx = e - ly * kPdW;
+    // output column ox + lx reads columns 2 lx - 2 .. 2 lx + 2 of the tile = staged bytes 2 lx + 2 .. 2 lx + 6
+    const int b = 2 * lx + 2, dwi = b >> 2, sh = (b & 3) * 8;
+    const unsigned long long v = ((unsigned long long)raw[ly][dwi + 1] << 32 | raw[ly][dwi]) >> sh;
+    const int r0 = (int)(v & 0xff), r1 = (int)((v >> 8) & 0xff), r2 = (int)((v >> 16) & 0xff), r3 = (int)((v >> 24) & 0xff),
+              r4 = (int)((v >> 32) & 0xff);
+    hsum[ly][lx] = r0 + 4 * r1 + 6 * r2 + 4 * r3 + r4;
+  }
+  __syncthreads();
+  {
+    const int ly = tid >> 4, lx = (tid & 15) * 4;
+    const int x = ox + lx, y = oy + ly;
+    if (x < dcols && y < drows) {
+      uint32_t out = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int v = hsum[2 * ly][lx + i] + 4 * hsum[2 * ly + 1][lx + i] + 6 * hsum[2 * ly + 2][lx + i] + 4 * hsum[2 * ly + 3][lx + i] +
+                      hsum[2 * ly + 4][lx + i];
+        out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+      }
+      *reinterpret_cast<uint32_t *>(dst + (size_t)y * dcols + x) = out;  // (dcols % 4 == 0: x + 3 < dcols)
+    }
+  }
+}
+
 // forw_img = _img for every sequence: packed frames -> level 0 of each sequence's pyramid (16 B per thread when the
 // layout allows it; the runtime's rectangular copy reaches ~140 GB/s on this shape).
 __global__ __launch_bounds__(256) void copy_frames_kernel(const uint8_t *src, size_t src_stride, uint8_t *dst,
@@ -1390,9 +1452,18 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
                        vec_ok);
   }
   for (int l = 1; l < fe->ld.levels; l++) {
-    dim3 blk(256), grd((fe->ld.cols[l] + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, S);
-    hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, forw + fe->ld.off[l - 1], forw + fe->ld.off[l], fe->ld.pyr_bytes,
-                       fe->ld.rows[l - 1], fe->ld.cols[l - 1], fe->ld.rows[l], fe->ld.cols[l]);
+    const uint8_t *sp = forw + fe->ld.off[l - 1];
+    uint8_t *dp = forw + fe->ld.off[l];
+    const int sc = fe->ld.cols[l - 1], dc = fe->ld.cols[l];
+    // whole-dword rows on both sides (and at least two staged dwords of image): 4 pixels per load and per store
+    const bool dwords = sc % 4 == 0 && dc % 4 == 0 && sc >= 8 && fe->ld.pyr_bytes % 4 == 0 && (uintptr_t)sp % 4 == 0 && (uintptr_t)dp % 4 == 0;
+    if (dwords) {
+      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPd4H - 1) / kPd4H, S);
+      hipLaunchKernelGGL(pyr_down4_kernel, grd, blk, 0, st, sp, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc);
+    } else {
+      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, S);
+      hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, sp, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc);
+    }
   }
   if (!fe->have_img) {  // pre_img = cur_img = forw_img = _img (:166-167); no points to track yet
     fe->have_img = true;
