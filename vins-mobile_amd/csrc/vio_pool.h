@@ -113,7 +113,15 @@ class HostPool {
   void start(const cpu_set_t *cpus) {
     int t = 0;
     if (const char *e = getenv("VIO_AMD_HOST_THREADS")) t = atoi(e);
-    if (t <= 0) t = std::min(32, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    if (t <= 0) {
+      // width from the CPUs this process may run on (a container often sees all of the host's but is bound to a few).
+      // Measured on a 256-thread host, 256 sequences per frame: 4 threads 12.8 ms, 16: 6.4, 32: 5.1, 64: 5.0, 96: 5.3
+      cpu_set_t allowed;
+      CPU_ZERO(&allowed);
+      int usable = (int)std::thread::hardware_concurrency();
+      if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) > 0) usable = std::min(usable > 0 ? usable : 1 << 20, CPU_COUNT(&allowed));
+      t = std::min(64, std::max(1, usable >= 64 ? usable / 4 : usable));
+    }
     for (int i = 1; i < t; i++) {
       workers_.emplace_back([this] { loop(); });
       if (cpus) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(*cpus), cpus);  // best effort
