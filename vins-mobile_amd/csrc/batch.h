@@ -233,6 +233,8 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   ldsd aspi = lds_asp ? take((size_t)d.Pcap * kAS + 16) : nullptr;
   w.AspI = MatPick<AP>::get(lds_asp, aspi, asp_global);
   w.nstage = lds_matrix ? (int)(o - o_mat) : (int)napp;
+  w.asp_ring = lds_matrix && !lds_asp;
+  w.aspring = w.asp_ring ? take(2 * (size_t)kAS + 4) : nullptr;
   w.cfeat = take(F);
   w.gf = take(F), w.sf = take(F), w.gnf = take(F), w.stf = take(F), w.hff = take(F), w.einv = take(F), w.tf = take(F);
   w.gp = take(npc), w.sp = take(npc), w.dp = take(npc);

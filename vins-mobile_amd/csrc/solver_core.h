@@ -255,6 +255,8 @@ struct WorkT {
   int nstage;     // doubles behind App that are free whenever the reduced matrix is not assembled (Jacobian-row staging)
   ldsd Dss, Css;  // speed-bias band: P blocks of 81 each, Css = Dss + 81 P (contiguous with App when App is in LDS)
   AP AspI;        // [P][9][18]: behind Css in LDS, or in the window's global scratch (WinView::AspG)
+  ldsd aspring;   // AspI in global scratch next to an LDS pose matrix: two blocks of it in LDS, refilled by the chain wave
+  bool asp_ring;  // one slot ahead of the panel waves (factor_band_regs)
   ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
   ldsd cpose, csb, cfeat;   // candidate
   ldsd ex;                  // 7
@@ -1703,8 +1705,13 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
     // speed-bias x pose: the IMU chain (LDS) and, for the block the prior keeps, the prior's row (global)
     const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
     auto A = w.AspI + (k * kSB + r) * kAW;
-    double s3 = 0;
-    for (int jj = 0; jj < aw; jj++) s3 = fma(A[jj], w.xt[alo + jj], s3);
+    double s3 = 0, ar[kAW];
+    // (one batch of loads: the row may live in global scratch, where a rolled loop pays an L2 round trip per element)
+#pragma unroll
+    for (int jj = 0; jj < kAW; jj++) ar[jj] = A[jj < aw ? jj : 0];
+    VIO_SCHED_FENCE();
+#pragma unroll
+    for (int jj = 0; jj < kAW; jj++) s3 = fma(jj < aw ? ar[jj] : 0.0, w.xt[alo + (jj < aw ? jj : 0)], s3);
     acc = fma(ur, sacc + 2.0 * s3, acc);
   }
   // the prior's speed-bias x pose block (global): (component, strip of 16 columns) items, one fetch batch per item
@@ -1941,12 +1948,13 @@ template <class WK>
 VIO_DEV PanelRaw panel_fetch(const WinView &v, WK &w, int k, bool is_pr, int t, int li, int kq) {
   const int j = 16 * t + li, alo = 6 * (k > 0 ? k - 1 : 0);
   const bool inr = j >= alo && j < alo + kAW && j < v.n6;
-  auto A = w.AspI + k * kAS + (inr ? j - alo : 0);
+  const int ao = inr ? j - alo : 0;
   PanelRaw p;
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int c = kq + 4 * r < kSB ? kq + 4 * r : 0;
-    p.x[r] = A[c * kAW];
+    if (w.asp_ring) p.x[r] = w.aspring[(k & 1) * kAS + ao + c * kAW];
+    else p.x[r] = w.AspI[k * kAS + ao + c * kAW];
     p.p[r] = is_pr ? v.Apri[c * v.jp + (j < v.n6 ? j : 0)] : 0.0;
   }
   return p;
@@ -2179,7 +2187,21 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
   for (int slot = 0; slot <= W + 1; slot++) {
     const int kb = W - slot, kp = kb + 1, ff = 2 + (slot & 1);
     if (wave == 0) {
+      // AspI in global scratch: the coupling rows of block kb -- what the panel waves need in the NEXT slot -- are fetched
+      // here, travel behind the band step and land in the LDS ring before the slot's barrier (an L2 round trip at the
+      // head of every panel step otherwise: ~3.5 k of a slot's ~10 k cycles)
+      double pf[3] = {0.0, 0.0, 0.0};
+      const bool ring = w.asp_ring && kb >= 0;
+      if (ring) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) pf[r] = w.AspI[kb * kAS + (lane + 64 * r < kAS ? lane + 64 * r : 0)];
+      }
       if (kb >= 0) band_step(cx, v, w, kb, ff, lane);
+      if (ring) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          if (lane + 64 * r < kAS) w.aspring[(kb & 1) * kAS + lane + 64 * r] = pf[r];
+      }
       stamp(cx, ST_C_AHEAD);
     } else if (kp <= W) {
       flo = flo < w.sbr[2 * kp] ? flo : w.sbr[2 * kp];  // (0 for the block the prior keeps)
@@ -2363,8 +2385,12 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
       const int k = q / kSB, c = q - k * kSB;
       const int alo = 6 * (k > 0 ? k - 1 : 0), aw = n6 - alo < kAW ? n6 - alo : kAW;
       auto A = w.AspI + (k * kSB + c) * kAW;
-      double sacc = 0.0;
-      for (int jj = 0; jj < aw; jj++) sacc = fma(A[jj], x[alo + jj], sacc);
+      double sacc = 0.0, ar[kAW];
+#pragma unroll
+      for (int jj = 0; jj < kAW; jj++) ar[jj] = A[jj < aw ? jj : 0];
+      VIO_SCHED_FENCE();
+#pragma unroll
+      for (int jj = 0; jj < kAW; jj++) sacc = fma(jj < aw ? ar[jj] : 0.0, x[alo + (jj < aw ? jj : 0)], sacc);
       VIO_ATOMIC_ADD(w.t1 + kBS * k + 6 + c, -sacc);
     } else {  // the prior's block (global): (component, strip of 16 columns) items, one fetch batch each
       const int qq = q - P * kSB, c = qq / nT, j0 = 16 * (qq - c * nT);

@@ -407,9 +407,10 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   be->lds_bytes = kLdsLimit;
   if (n_lds > 0) {
     const size_t fat = need_lds(dl, 1), lean = need_lds(dl, lean_asp);
-    // (the lean layout costs a window ~25 % of its latency -- every Gauss-Newton step then has a few more round trips to
-    // L2 --: it only pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with
-    // closed-loop windows of ~190 landmarks: 2 x 128 windows 6.2 vs 5.1 ms per frame, 2 x 256 windows 8.6 vs 9.4 ms.)
+    // (the lean layout costs a window ~10 % of its latency -- a few more round trips to L2 per Gauss-Newton step --: it only
+    // pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with closed-loop
+    // windows of ~190 landmarks: 2 x 128 windows are faster with the fat layout on whole CUs, 2 x 256 windows take 7.3
+    // instead of 9.4 ms per frame with the lean one.)
     const bool crowded = n_lds > be->n_cus / 2;
     if (!one_per_cu && fat <= kLdsHalf) dl.lds_asp = 1, be->lds_bytes = kLdsHalf;
     else if (!one_per_cu && crowded && lean <= kLdsHalf) dl.lds_asp = lean_asp, be->lds_bytes = kLdsHalf;
