@@ -1318,12 +1318,21 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       const bool pv = pl < v.npairs;
       const int m_s0 = pv ? v.pair_s0[pl] : 0, m_s1 = pv ? v.pair_s1[pl] : 0;
       const int m_ht = pv ? (v.pair_h[pl] << 16) | v.pair_t[pl] : 0;
-      int round = 0;
-      for (int p = wave; p < v.npairs; p += nw, round++) {
-        const int rl = round & 63;
-        int b_s0 = __builtin_amdgcn_readlane(m_s0, rl), b_s1 = __builtin_amdgcn_readlane(m_s1, rl);
-        int b_ht = __builtin_amdgcn_readlane(m_ht, rl);
-        if (round >= 64) b_s0 = v.pair_s0[p], b_s1 = v.pair_s1[p], b_ht = (v.pair_h[p] << 16) | v.pair_t[p];
+      // rounds of this wave whose bucket reaches into this chunk: one ballot instead of a walk over all of them (a chunk
+      // holds a dozen of the window's ~55 buckets). Rounds past the 64th (more than 64 nw buckets: never at W <= 12) follow.
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(pv && (m_s0 > c0 ? m_s0 : c0) < (m_s1 < c0 + CH ? m_s1 : c0 + CH));
+      int tail_p = wave + 64 * nw;
+      while (todo || tail_p < v.npairs) {
+        int b_s0, b_s1, b_ht;
+        if (todo) {
+          const int rl = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          b_s0 = __builtin_amdgcn_readlane(m_s0, rl), b_s1 = __builtin_amdgcn_readlane(m_s1, rl);
+          b_ht = __builtin_amdgcn_readlane(m_ht, rl);
+        } else {
+          b_s0 = v.pair_s0[tail_p], b_s1 = v.pair_s1[tail_p], b_ht = (v.pair_h[tail_p] << 16) | v.pair_t[tail_p];
+          tail_p += nw;
+        }
         int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
         if (s_lo >= s_hi) continue;
         v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -2067,6 +2076,39 @@ VIO_DEV void panel_step_regs(const Ctx &cx, const WinView &v, WK &w, int k, int 
     }
 }
 
+// Which tiles of the update a panel wave owns and which fill tiles V_t it therefore needs. Default: tile q = I (I + 1) / 2 + J
+// goes to wave q % NPW, which needs (nearly) every V_t. For 5 tile rows on 3 panel waves the tiles are grouped by the
+// indices they touch instead -- {0, 1, 4}, {2, 3, 4} and the 2 x 2 block {2, 3} x {0, 1} -- so that a wave forms 3 or 4 of
+// the 5 fill tiles (6 matrix instructions each) for its 6 / 5 / 4 update tiles: 36 / 33 / 36 matrix instructions per step
+// instead of 45 on a pipe the wave shares with a wave of the CU's other window.
+template <int NT, int NPW, int PW>
+struct PanelMap {
+  static constexpr bool owns(int I, int J) { return (I * (I + 1) / 2 + J) % NPW == PW; }
+  static constexpr bool needs(int) { return true; }
+};
+template <int PW>
+struct PanelMap<5, 3, PW> {
+  static constexpr bool in_a(int t) { return t == 0 || t == 1 || t == 4; }
+  static constexpr bool in_b(int t) { return t == 2 || t == 3 || t == 4; }
+  static constexpr bool owns(int I, int J) {
+    const bool a = in_a(I) && in_a(J), b = in_b(I) && in_b(J) && !a;  // (tile (4, 4) belongs to the first set)
+    return PW == 0 ? a : PW == 1 ? b : !a && !b;
+  }
+  static constexpr bool needs(int t) { return PW == 0 ? in_a(t) : PW == 1 ? in_b(t) : t < 4; }
+};
+template <int NT, int NPW, int PW>
+constexpr int panel_slot(int I, int J) {  // position of tile (I, J) in the wave's accumulator list
+  int n = 0;
+  for (int i = 0; i < NT; i++)
+    for (int j = 0; j <= i; j++) {
+      if (i == I && j == J) return n;
+      if (PanelMap<NT, NPW, PW>::owns(i, j)) n++;
+    }
+  return n;
+}
+template <int NT, int NPW, int PW>
+constexpr int panel_count() { return panel_slot<NT, NPW, PW>(NT, 0); }
+
 // The same step for a pose matrix of exactly NT tile rows, specialised for panel wave PW of NPW: the tiles of the wave
 // are a compile-time list, so every accumulator access is one ds_read / ds_write at an immediate offset from one of NT
 // per-lane row bases (the generic form spends ~600 instructions per step on predicates and address arithmetic).
@@ -2074,14 +2116,15 @@ template <int NT, int NPW, int PW, class WK>
 VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane_) {
   const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
   double e[3] = {0.0, 0.0, 0.0}, linv[4], gr[3];
-  constexpr int kTiles = NT * (NT + 1) / 2, kAcc = (kTiles + NPW - 1) / NPW;
+  typedef PanelMap<NT, NPW, PW> Map;
+  constexpr int kAcc = panel_count<NT, NPW, PW>();
   v4d acc[kAcc];
   PanelRaw X[NT];
   const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
   const int rows_last = v.nrows - 16 * (NT - 1);  // rows of the last tile row (the others are full)
 #pragma unroll
   for (int t = 0; t < NT; t++)
-    if (t >= tlo) X[t] = panel_fetch(v, w, k, is_pr, t, li, kq);
+    if (Map::needs(t) && t >= tlo) X[t] = panel_fetch(v, w, k, is_pr, t, li, kq);
   if (k < v.W) load_op9_raw(w.Css + (k + 1) * kSS, li, kq, e);
   load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
 #pragma unroll
@@ -2091,15 +2134,14 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
     auto rowbase = w.App + tri_off(I) + kq * tri_ld(I) + li;  // element r of tile (I, J): rowbase[4 r ld + 16 J]
 #pragma unroll
     for (int J = 0; J <= I; J++) {
-      const int q = I * (I + 1) / 2 + J;
-      if (q % NPW == PW && J >= tlo) {
+      if (Map::owns(I, J) && J >= tlo) {
         v4d a;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (I < NT - 1) a[r] = rowbase[4 * r * tri_ld(I) + 16 * J];
           else a[r] = rowbase[(kq + 4 * r < rows_last ? 4 * r * tri_ld(I) : -kq * tri_ld(I)) + 16 * J];
         }
-        acc[q / NPW] = a;
+        acc[panel_slot<NT, NPW, PW>(I, J)] = a;
       }
     }
   }
@@ -2107,13 +2149,13 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
   if (k < v.W) mask_op9(li, kq, e);
   mask_linv9(li, kq, linv);
   if (cx.prof) {
-    double probe = linv[0] + e[0] + gr[0] + X[NT - 1].x[0] + X[NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
+    double probe = linv[0] + e[0] + gr[0] + X[PW == 2 ? NT - 2 : NT - 1].x[0] + X[PW == 2 ? NT - 2 : NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D4);
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    if (t < tlo) continue;
+    if (!Map::needs(t) || t < tlo) continue;
     v4d Tt = panel_tile(v.n6, k, is_pr, t, li, kq, X[t], gr);
     if (k < v.W) {
 #pragma unroll
@@ -2129,13 +2171,12 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
   for (int I = 0; I < NT; I++)
 #pragma unroll
     for (int J = 0; J <= I; J++) {
-      const int q = I * (I + 1) / 2 + J;
-      if (q % NPW == PW && J >= tlo) {
-        v4d c = acc[q / NPW];
+      if (Map::owns(I, J) && J >= tlo) {
+        v4d c = acc[panel_slot<NT, NPW, PW>(I, J)];
         if (I == NT - 1) c = tile_mask_acc(c, rows_last, kq);
 #pragma unroll
         for (int s = 0; s < 3; s++) c = mfma_f64(-V[I].x[s], V[J].x[s], c);
-        acc[q / NPW] = c;
+        acc[panel_slot<NT, NPW, PW>(I, J)] = c;
       }
     }
   if (cx.prof) {
@@ -2148,9 +2189,8 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
     auto rowbase = w.App + tri_off(I) + kq * tri_ld(I) + li;
 #pragma unroll
     for (int J = 0; J <= I; J++) {
-      const int q = I * (I + 1) / 2 + J;
-      if (q % NPW == PW && J >= tlo) {
-        const v4d c = acc[q / NPW];
+      if (Map::owns(I, J) && J >= tlo) {
+        const v4d c = acc[panel_slot<NT, NPW, PW>(I, J)];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (I < NT - 1) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -40,10 +41,13 @@ inline std::vector<std::string> hip_runtimes() {
 inline bool single_hip_runtime() {
   static const int n = [] {
     const std::vector<std::string> r = hip_runtimes();
+    const char *allow = getenv("VIO_AMD_ALLOW_TWO_RUNTIMES");
+    if (r.size() > 1 && allow && allow[0] == '1') return 1;  // (the caller knows what it is doing)
     if (r.size() > 1) {
       fprintf(stderr, "vio_amd: %zu different HIP runtimes are mapped into this process:\n", r.size());
       for (const std::string &p : r) fprintf(stderr, "vio_amd:   %s\n", p.c_str());
-      fprintf(stderr, "vio_amd: refusing to create device contexts (load one runtime only, e.g. import torch before this library)\n");
+      fprintf(stderr, "vio_amd: refusing to create device contexts (load one runtime only, e.g. import torch before this library; "
+                      "VIO_AMD_ALLOW_TWO_RUNTIMES=1 overrides)\n");
     }
     return (int)r.size();
   }();
