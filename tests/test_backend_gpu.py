@@ -79,6 +79,53 @@ def test_seeded_windows_match_oracle(solver_cache):
         assert H.relerr(Hg, Hr) < TOL_PRIOR and H.relerr(bg, br) < TOL_PRIOR
 
 
+def _cpu_solver():
+    """The real reference path (vendored Ceres + the VINS factors) when oracle/_ref travelled, else the restatement."""
+    ref = H.ref_lib_or_none()
+    return abi.bind_backend_solver(ref, "ref")[0] if ref is not None else H.oracle_backend()[0]
+
+
+def _follow_traces(cfg, w, solver, cpu, what):
+    g = w.copy()
+    s = solver.solve([g])[0]
+    ref, rs = H.solve_with(cpu, cfg, w)
+    assert s["iterations"] == rs["iterations"] and list(s["it_flags"]) == list(rs["it_flags"]), what
+    assert H.relerr(s["it_cost"], rs["it_cost"]) < 1e-6, what
+    assert H.relerr(s["it_radius"], rs["it_radius"]) < 1e-4, what
+    # the step-quality ratio rho = cost change / model cost change (the device takes the model change from an identity
+    # that assumes an exact Gauss-Newton solve: DESIGN 3.2 "one quadratic form per step")
+    n = s["iterations"]
+    rho_g, rho_r = np.asarray(s["it_relative_decrease"][:n]), np.asarray(rs["it_relative_decrease"][:n])
+    assert np.abs(rho_g - rho_r).max() < 1e-4 * max(1.0, np.abs(rho_r).max()), (what, rho_g, rho_r)
+    assert H.pose_relerr(g.pose, ref.pose) < TOL and H.relerr(g.inv_depth, ref.inv_depth) < TOL, what
+    return s
+
+
+def test_step_quality_traces_on_badly_conditioned_windows(solver_cache):
+    """Windows on which the model cost change is delicate: (a) next to no parallax (a 20 ms frame interval: depths are
+    barely observable, the dogleg mixes Cauchy and Gauss-Newton steps and rejects some), started far off; (b) a prior that
+    outweighs the visual cost by 1e4 (its expanded cost form |r0|^2/2 + b0.dx + dx.H0.dx/2 cancels against |r0|^2/2). The
+    accept / reject sequence, costs, radii and the rho of every iteration follow the CPU path."""
+    cfg = abi.default_config()
+    pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
+    solver, cpu = get_solver(solver_cache, cfg), _cpu_solver()
+    rejected = 0
+    for seed in (3100, 3101, 3102):
+        w = synth.make_window(cfg, pre, seed=seed, frame_dt=0.02, imu_per_frame=4, perturb_scale=6.0)
+        s = _follow_traces(cfg, w, solver, cpu, "low parallax seed %d" % seed)
+        rejected += sum(1 for f in s["it_flags"] if f == 1)
+    # (b): steady-state window whose prior is scaled up
+    a = synth.make_window(cfg, pre, seed=3200, traj_seed=88, frame_offset=0)
+    solver.solve([a])
+    b = synth.make_window(cfg, pre, seed=3201, traj_seed=88, frame_offset=1)
+    b.prior = a.next_prior.copy()
+    n = b.prior.n
+    b.prior.J[: n * n] *= 100.0
+    b.prior.r[:n] *= 100.0
+    _follow_traces(cfg, b, solver, cpu, "heavy prior")
+    assert rejected >= 1, "none of the low-parallax windows rejected a step: pick harder ones"
+
+
 def test_prior_chain_on_device(solver_cache):
     """The prior the device builds is consumed by the next device solve (MARGIN_OLD chain); compared with the
     oracle running the same chain on its own priors."""

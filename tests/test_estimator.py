@@ -120,6 +120,53 @@ def test_reset_when_the_full_initial_window_tracks_too_little():
     est.close()
 
 
+def test_capacity_error_restarts_the_sequence_and_is_reported_not_raised():
+    """A window with more landmarks than cfg.max_features cannot be assembled (VIO_ECAP in the host half of solve_ceres,
+    before any device call): that sequence's result says FRAME_ERROR / VIO_ECAP and the library has restarted it, the other
+    sequence of the call went on normally, the python mirror warns, keeps the code in last_error and only raises with
+    strict=True."""
+    cfg = abi.default_config(window_size=4, max_features=30)
+    W = cfg.window_size
+    est = pkg.estimator.Estimator(cfg, TIC, RIC, n_seq=2)
+    for k in range(W):
+        for q in range(2):
+            est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0], seq=q)
+        res = est.process_images([obs_grid(50, shift=0.03 * k), obs_grid(25, shift=0.03 * k)], [float(k)] * 2, active=[1, int(k >= 2)])
+        assert res[0].action == abi.VIO_FRAME_FILLING and res[1].action == (abi.VIO_FRAME_FILLING if k >= 2 else abi.VIO_FRAME_SKIPPED)
+    P = W + 1
+    est.set_initial_state([float(k) for k in range(P)], np.zeros((P, 3)), np.tile(np.eye(3), (P, 1, 1)), np.zeros((P, 3)),
+                          np.zeros((P, 3)), np.zeros((P, 3)), seq=0)
+    for q in range(2):
+        est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0], seq=q)
+    frame = [obs_grid(50, shift=0.03 * W), obs_grid(25, shift=0.03 * W)]
+    with pytest.warns(RuntimeWarning, match="restarted"):
+        res = est.process_images(frame, [float(W)] * 2)
+    assert res[0].action == abi.VIO_FRAME_ERROR and res[0].error == abi.VIO_ECAP
+    assert res[1].action == abi.VIO_FRAME_FILLING and res[1].error == 0      # the other sequence is untouched
+    assert est.last_error == abi.VIO_ECAP
+    st = est.status(0)
+    assert st.frame_count == 0 and st.solver_flag == abi.VIO_SOLVER_INITIAL and est.features(0).count() == 0   # clearState
+    assert est.status(1).frame_count == 3
+    # the restarted sequence fills its window again from the next frame on
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        res = est.process_images([obs_grid(20, shift=0.0), obs_grid(25, shift=0.03 * (W + 1))], [float(W + 1)] * 2)
+    assert res[0].action == abi.VIO_FRAME_FILLING and est.status(0).frame_count == 1 and est.last_error == 0
+    est.close()
+    # strict=True: the same situation raises
+    est = pkg.estimator.Estimator(cfg, TIC, RIC, n_seq=1)
+    for k in range(W):
+        est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0])
+        est.process_images([obs_grid(50, shift=0.03 * k)], [float(k)])
+    est.set_initial_state([float(k) for k in range(P)], np.zeros((P, 3)), np.tile(np.eye(3), (P, 1, 1)), np.zeros((P, 3)),
+                          np.zeros((P, 3)), np.zeros((P, 3)))
+    est.process_imu(0.01, [0, 0, 9.8], [0, 0, 0])
+    with pytest.raises(RuntimeError, match="restarted"):
+        est.process_images([obs_grid(50, shift=0.03 * W)], [float(W)], strict=True)
+    est.close()
+
+
 def test_argument_errors():
     cfg = abi.default_config()
     lib = abi.load_product()
