@@ -325,6 +325,16 @@ int vio_preprocess_kernel_ms(vio_preprocess_t *p, double *ms_avg, int32_t *launc
  * feature_tracker.hpp:72-75) for parity tests.                               */
 int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts /* [cap][2] */,
                            int32_t *ids, int32_t *track_cnt, int32_t cap, int32_t *n);
+/* forw_pts / ids at the point of readImage where solveVinsPnP joins them with the
+ * solved landmarks (feature_tracker.cpp:207): the last frame's tracked points behind
+ * the first findFundamentalMat rejection (:194-205), AHEAD of the publish-frame
+ * steps rejectWithF (:235) and setMask (:255), which drop more of them.           */
+int vio_frontend_get_pnp_points(vio_frontend_t *fe, int32_t seq, float *forw_pts /* [cap][2] */, int32_t *ids,
+                                int32_t cap, int32_t *n);
+/* While a frame submitted with vio_frontend_submit_images has not been collected,
+ * every other entry point that reads or changes the tracker state or the
+ * observation staging (step_resident, get_state, get_pnp_points, set / update /
+ * get_tracks, a second submit) returns VIO_ESTATE.                                */
 
 /* The tracker's public fields (feature_tracker.hpp:68-80: pre_pts / cur_pts /
  * forw_pts, ids, track_cnt) of one sequence in and out, and the steps of readImage
@@ -415,6 +425,11 @@ int vio_vocabulary_transform(vio_vocabulary_t *v, int32_t n_keyframes, const int
                              int32_t *word_id, double *word_weight, int32_t *bow_count, int32_t *bow_word,
                              double *bow_value, int32_t bow_stride);
 typedef struct vio_bow_database vio_bow_database_t;
+/* The database takes what it needs from the vocabulary (device, word count) at create and
+ * owns its stream: it stays valid after vio_vocabulary_destroy, and a vocabulary and its
+ * database may be used from two threads at the same time. A vocabulary file whose node
+ * records do not form one tree under node 0 (an id twice, a parent cycle) is refused
+ * with VIO_EINVAL by vio_vocabulary_create / _load.                                  */
 int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t max_total_words, vio_bow_database_t **out);
 void vio_bow_database_destroy(vio_bow_database_t *d);
 int vio_bow_database_size(const vio_bow_database_t *d, int32_t *n_entries);

@@ -60,10 +60,8 @@ class FeatureTracker {
   // ... and with the camera-IMU extrinsic the app hands to vins_pnp.setExtrinsic / setIMUModel (ViewController.mm:318-319): the vinsPnP
   // member (PNP_SIZE = 6, global_param.hpp:30) exists and readImage runs solveVinsPnP when vins_normal is set.
   FeatureTracker(const VioConfig &cfg, const double tic[3], const double ric[9]) : FeatureTracker(cfg) {
-    if (vio_pnp_tracker_create(&cfg_, 1, 6, tic, ric, &pnp_) != VIO_OK) {
-      vio_frontend_destroy(fe_);
-      throw std::runtime_error("vio_pnp_tracker_create failed");
-    }
+    // (the delegated-to constructor has completed: the destructor runs for this throw and releases fe_)
+    if (vio_pnp_tracker_create(&cfg_, 1, 6, tic, ric, &pnp_) != VIO_OK) throw std::runtime_error("vio_pnp_tracker_create failed");
   }
   ~FeatureTracker() {
     if (pnp_) vio_pnp_tracker_destroy(pnp_);
@@ -75,15 +73,15 @@ class FeatureTracker {
   // feature_tracker.hpp:58, feature_tracker.cpp:107-160: the landmarks the back-end has solved (solved_features, ascending
   // id) joined with the tracker's current points, setInit(solved_vins), the IMU samples since the last frame, then
   // vinsPnP::processImage(feature_msg, header, use_pnp); P / R = Ps / Rs[PNP_SIZE - 1].
-  // (The join reads the tracker state AFTER the frame: on publishing frames the points setMask dropped at :234 no longer
-  // take part, the reference joins just before.)
+  // The join uses the point list as it stands at :207 -- behind the first F-RANSAC, ahead of rejectWithF / setMask --
+  // which the front-end keeps aside for this purpose (vio_frontend_get_pnp_points).
   bool solveVinsPnP(double header, Vector3d &P, Matrix3d &R, bool vins_normal) {
     if (!vins_normal || !pnp_) return false;
     const int cap = cfg_.max_corners;
     std::vector<float> pts(2 * (size_t)cap);
-    std::vector<int32_t> ids(cap), cnt(cap);
+    std::vector<int32_t> ids(cap);
     int32_t n = 0;
-    if (vio_frontend_get_state(fe_, 0, pts.data(), ids.data(), cnt.data(), cap, &n) != VIO_OK) return false;
+    if (vio_frontend_get_pnp_points(fe_, 0, pts.data(), ids.data(), cap, &n) != VIO_OK) return false;
     std::vector<VioPnpFeature> solved, msg((size_t)cap + 1);
     for (typename std::list<IMG_MSG_LOCAL>::const_iterator it = solved_features.begin(); it != solved_features.end(); ++it) {
       VioPnpFeature f;

@@ -239,3 +239,44 @@ def test_refuses_what_it_does_not_implement():
             voc.transform([np.zeros((9000, 4), np.uint64)])                                 # more than 8192 descriptors
     finally:
         voc.close()
+
+
+@pytest.mark.gpu
+def test_refuses_corrupt_vocabularies_and_outlives_its_vocabulary():
+    """A node id that appears twice, a parent cycle and a node that is its own parent are refused at load (a duplicate used
+    to overrun the child table and leave the root as its own child: an endless descent on the device). A database keeps
+    working, and can be destroyed, after its vocabulary is gone."""
+    import struct
+    blob, desc = make_vocabulary(4, 2, seed=3)
+    n_nodes = struct.unpack("<i", blob[16:20])[0]
+    rec = lambda i: 24 + 48 * i
+
+    def with_node(i, nid=None, pid=None):
+        b = bytearray(blob)
+        o_nid, o_pid = struct.unpack("<2i", blob[rec(i):rec(i) + 8])
+        b[rec(i):rec(i) + 8] = struct.pack("<2i", o_nid if nid is None else nid, o_pid if pid is None else pid)
+        return bytes(b), o_nid, o_pid
+
+    ids = [struct.unpack("<2i", blob[rec(i):rec(i) + 8]) for i in range(n_nodes)]
+    dup, _, _ = with_node(1, nid=ids[0][0])                       # two records with the same node id
+    with pytest.raises(RuntimeError):
+        loop.BowVocabulary(blob=dup)
+    inner = [i for i, (nid, pid) in enumerate(ids) if pid == 0][0]       # a child of the root ...
+    kid = [i for i, (nid, pid) in enumerate(ids) if pid == ids[inner][0]][0]
+    cyc, _, _ = with_node(inner, pid=ids[kid][0])                 # ... made the child of its own child: a cycle off the tree
+    with pytest.raises(RuntimeError):
+        loop.BowVocabulary(blob=cyc)
+    selfp, _, _ = with_node(2, pid=ids[2][0])
+    with pytest.raises(RuntimeError):
+        loop.BowVocabulary(blob=selfp)
+    voc = loop.BowVocabulary(blob=blob)
+    db = loop.BowDatabase(voc, max_entries=4, max_total_words=256)
+    rng = np.random.default_rng(5)
+    leaves = np.arange(1 + 4, 1 + 4 + 16)
+    (_, _, bw, bv), = voc.transform([keyframe_descriptors(desc, leaves, rng, 60)])
+    assert db.add(bw, bv) == 0
+    voc.close()                                                   # the vocabulary goes first
+    assert db.add(bw, bv) == 1
+    ent, sc = db.query([(bw, bv)], [-1], max_results=2)[0]
+    assert sorted(ent.tolist()) == [0, 1] and abs(sc[0] - 1.0) < 1e-12
+    db.close()

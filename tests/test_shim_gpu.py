@@ -125,6 +125,11 @@ def test_feature_tracker_shim_runs_the_vins_pnp_branch(tmp_path):
     for f in range(n):
         trk.read_images(frames[f:f + 1], f % 3 == 0)
         pts, ids, _ = trk.state(0)
+        ppts, pids = trk.pnp_points(0)          # the list at feature_tracker.cpp:207 (ahead of rejectWithF / setMask)
+        if f % 3 != 0:                          # tracking-only frames drop nothing behind :207
+            assert np.array_equal(pids, ids) and np.array_equal(ppts, pts)
+        elif f > 0:                             # publishing frames: the kept tracks are a subset of it (new corners come behind)
+            assert set(ids[np.isin(ids, pids)]) <= set(pids) and len(pids) >= np.isin(ids, pids).sum()
         if f == first - 1:   # the landmarks "the back-end has solved": the points tracked so far, 5 m in front of the camera
             order = np.argsort(ids)
             solved = [(int(ids[i]), 7, ((pts[i, 0] - cfg.cx) / cfg.fx * 5.0, (pts[i, 1] - cfg.cy) / cfg.fy * 5.0, 5.0)) for i in order]
@@ -135,7 +140,7 @@ def test_feature_tracker_shim_runs_the_vins_pnp_branch(tmp_path):
                 arr[k].id, arr[k].track_num = fid, tn
                 arr[k].position[:] = [float(v) for v in pos]
             out, nm = (abi.VioPnpFeature * (cfg.max_corners + 1))(), C.c_int32()
-            assert lib.vio_pnp_match_features(C.byref(cfg), ids.ctypes.data_as(_ip), pts.ctypes.data_as(_fp), len(ids), arr, len(solved),
+            assert lib.vio_pnp_match_features(C.byref(cfg), pids.ctypes.data_as(_ip), ppts.ctypes.data_as(_fp), len(pids), arr, len(solved),
                                               out, cfg.max_corners, C.byref(nm)) == 0
             assert nm.value > 20
             pnp.set_init(0.1 * (first - 1), np.zeros(3), np.zeros(3), np.zeros(3), np.eye(3), np.zeros(3))

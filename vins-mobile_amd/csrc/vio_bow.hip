@@ -70,13 +70,13 @@ struct Buf {
 // 16 lanes per descriptor, 4 descriptors per wave
 __global__ __launch_bounds__(256) void bow_lookup_kernel(const unsigned long long *node_desc, const double *node_weight, const int *node_word,
                                                           const int *child_off, const int *child, const unsigned long long *desc,
-                                                          int n, int *word, double *weight) {
+                                                          int n, int depth, int *word, double *weight) {
   const int g = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
   const bool have = g < n;
   const unsigned long long *f = desc + 4 * (size_t)(have ? g : 0);
   const unsigned long long f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
   int node = 0;
-  for (;;) {
+  for (int level = 0; level < depth; level++) {  // (depth = the tree's height, checked at load: the walk always ends)
     const int c0 = child_off[node], nc = child_off[node + 1] - c0;
     if (nc <= 0) break;  // leaf (every lane of the row walks the same path)
     unsigned best = 0xffffffffu;
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void bow_score_kernel(const int *db_off, const
 struct vio_vocabulary {
   int device = -1;
   int32_t k = 0, L = 0, scoring = 0, weighting = 0, n_nodes = 0, n_words = 0;  // n_nodes incl. the root
+  int height = 0;  // levels below the root: bounds the descent of bow_lookup_kernel
   hipStream_t stream = nullptr;
   Buf<unsigned long long> d_desc;
   Buf<double> d_weight, d_wweight;  // per node; per word
@@ -207,8 +208,11 @@ struct vio_vocabulary {
   Buf<double> t_weight, t_bvalue;
 };
 
+// (A database takes the word count from its vocabulary at create and owns its stream: it keeps working, and can be
+// destroyed, after the vocabulary is gone, and two threads may use a vocabulary and its database side by side.)
 struct vio_bow_database {
-  vio_vocabulary *voc = nullptr;
+  int32_t voc_words = 0;
+  hipStream_t stream = nullptr;
   int device = -1;
   int max_entries = 0, n_entries = 0;
   size_t max_words = 0, n_words = 0;
@@ -239,11 +243,14 @@ int vio_vocabulary_create(const void *blob, size_t bytes, vio_vocabulary_t **out
     std::vector<unsigned long long> desc(4 * N, 0);
     std::vector<double> weight(N, 0.0);
     std::vector<int> word(N, 0), parent(N, 0), cnt(N + 1, 0), order(nNodes);
+    std::vector<char> seen(N, 0);
     const unsigned char *q = p + 24;
     for (int i = 0; i < nNodes; i++, q += 48) {  // struct Node { int32 nodeId, parentId; double weight; uint64 descriptor[4]; }
       int32_t nid, pid;
       memcpy(&nid, q, 4), memcpy(&pid, q + 4, 4);
-      if (nid < 1 || nid > nNodes || pid < 0 || pid > nNodes) return VIO_EINVAL;
+      if (nid < 1 || nid > nNodes || pid < 0 || pid > nNodes || pid == nid) return VIO_EINVAL;
+      if (seen[nid]) return VIO_EINVAL;  // a node id twice: two records would share one slot of their parent's child list
+      seen[nid] = 1;
       memcpy(&weight[nid], q + 8, 8);
       memcpy(&desc[4 * (size_t)nid], q + 16, 32);
       parent[nid] = pid, order[i] = nid, cnt[pid + 1]++;
@@ -252,6 +259,28 @@ int vio_vocabulary_create(const void *blob, size_t bytes, vio_vocabulary_t **out
     std::vector<int> fill(cnt.begin(), cnt.end() - 1), child(nNodes);
     std::vector<double> wweight(nWords, 0.0);
     for (int i = 0; i < nNodes; i++) child[fill[parent[order[i]]]++] = order[i];
+    for (size_t i = 0; i < N; i++)
+      if (fill[i] != cnt[i + 1]) return VIO_EINVAL;
+    // the records must form ONE tree under node 0: every node reaches the root (a cycle of parent links never does), and
+    // the height of the tree bounds the descent of the lookup kernel
+    int height = 0;
+    {
+      std::vector<int> dep(N, -1);
+      dep[0] = 0;
+      std::vector<int> path;
+      for (int i = 1; i <= nNodes; i++) {
+        path.clear();
+        int a = i;
+        while (dep[a] < 0) {
+          path.push_back(a);
+          if ((int)path.size() > nNodes) return VIO_EINVAL;
+          a = parent[a];
+        }
+        int d = dep[a];
+        for (size_t k = path.size(); k-- > 0;) dep[path[k]] = ++d;
+        height = std::max(height, dep[i]);
+      }
+    }
     for (int i = 0; i < nWords; i++, q += 8) {  // struct Word { int32 nodeId, wordId; }
       int32_t nid, wid;
       memcpy(&nid, q, 4), memcpy(&wid, q + 4, 4);
@@ -262,6 +291,7 @@ int vio_vocabulary_create(const void *blob, size_t bytes, vio_vocabulary_t **out
     vio_vocabulary *v = new vio_vocabulary();
     v->device = vio::current_device();
     v->k = hdr[0], v->L = hdr[1], v->scoring = hdr[2], v->weighting = hdr[3], v->n_nodes = (int32_t)N, v->n_words = nWords;
+    v->height = height;
     bool ok = hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && v->d_desc.ensure(4 * N) == VIO_OK && v->d_weight.ensure(N) == VIO_OK && v->d_word.ensure(N) == VIO_OK &&
          v->d_child_off.ensure(N + 1) == VIO_OK && v->d_child.ensure(nNodes) == VIO_OK && v->d_wweight.ensure(nWords) == VIO_OK;
@@ -351,7 +381,7 @@ int vio_vocabulary_transform(vio_vocabulary_t *v, int32_t n_keyframes, const int
     HIP_OK(hipMemcpyAsync(v->t_off.p, off.data(), 4 * (size_t)(n_keyframes + 1), hipMemcpyHostToDevice, st));
     if (total > 0)
       hipLaunchKernelGGL(bow_lookup_kernel, dim3((total * 16 + 255) / 256), dim3(256), 0, st, v->d_desc.p, v->d_weight.p, v->d_word.p,
-                         v->d_child_off.p, v->d_child.p, v->t_desc.p, total, v->t_word.p, v->t_weight.p);
+                         v->d_child_off.p, v->d_child.p, v->t_desc.p, total, v->height + 1, v->t_word.p, v->t_weight.p);
     const int accumulate = v->weighting == 0 || v->weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
     hipLaunchKernelGGL(bow_vector_kernel, dim3(n_keyframes), dim3(256), 0, st, v->t_off.p, v->t_word.p, v->t_weight.p, v->d_wweight.p, accumulate,
                        v->t_bcount.p, v->t_bword.p, v->t_bvalue.p, bow_stride);
@@ -375,12 +405,16 @@ int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t ma
   VIO_ON_DEVICE_OF(v);
   vio_bow_database *d = new (std::nothrow) vio_bow_database();
   if (!d) return VIO_ENOMEM;
-  d->voc = v, d->device = v->device, d->max_entries = max_entries, d->max_words = (size_t)max_total_words;
+  d->voc_words = v->n_words, d->device = v->device, d->max_entries = max_entries, d->max_words = (size_t)max_total_words;
   try {
-    d->h_off.assign(1, 0);
+    d->h_off.assign((size_t)max_entries + 1, 0);
   } catch (const std::bad_alloc &) {
     delete d;
     return VIO_ENOMEM;
+  }
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete d;
+    return VIO_ENODEV;
   }
   if (d->d_off.ensure((size_t)max_entries + 1) != VIO_OK || d->d_word.ensure(d->max_words) != VIO_OK || d->d_value.ensure(d->max_words) != VIO_OK) {
     vio_bow_database_destroy(d);
@@ -393,7 +427,7 @@ int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t ma
 void vio_bow_database_destroy(vio_bow_database_t *d) {
   if (!d) return;
   vio::DeviceScope scope(d->device);
-  (void)hipStreamSynchronize(d->voc->stream);
+  if (d->stream) (void)hipStreamSynchronize(d->stream), (void)hipStreamDestroy(d->stream);
   d->d_off.release(), d->d_word.release(), d->d_value.release(), d->q_count.release(), d->q_word.release(), d->q_max.release();
   d->q_value.release(), d->raw.release();
   delete d;
@@ -409,14 +443,10 @@ int vio_bow_database_add(vio_bow_database_t *d, int32_t n, const int32_t *word, 
   if (!d || n < 0 || (n > 0 && (!word || !value))) return VIO_EINVAL;
   if (d->n_entries >= d->max_entries || d->n_words + (size_t)n > d->max_words) return VIO_ECAP;
   for (int i = 0; i < n; i++)
-    if (word[i] < 0 || word[i] >= d->voc->n_words || (i > 0 && word[i] <= word[i - 1])) return VIO_EINVAL;  // a BowVector: ascending unique words
+    if (word[i] < 0 || word[i] >= d->voc_words || (i > 0 && word[i] <= word[i - 1])) return VIO_EINVAL;  // a BowVector: ascending unique words
   VIO_ON_DEVICE_OF(d);
-  hipStream_t st = d->voc->stream;
-  try {
-    d->h_off.push_back((int)(d->n_words + (size_t)n));
-  } catch (const std::bad_alloc &) {
-    return VIO_ENOMEM;
-  }
+  hipStream_t st = d->stream;
+  d->h_off[d->n_entries + 1] = (int)(d->n_words + (size_t)n);  // (assigned, not appended: a failed copy below leaves nothing behind)
   if (n > 0) {
     HIP_OK(hipMemcpyAsync(d->d_word.p + d->n_words, word, 4 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->d_value.p + d->n_words, value, 8 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -447,7 +477,7 @@ int vio_bow_database_query(vio_bow_database_t *d, int32_t n_queries, const int32
         d->q_word.ensure((size_t)n_queries * bow_stride) != VIO_OK || d->q_value.ensure((size_t)n_queries * bow_stride) != VIO_OK ||
         d->raw.ensure((size_t)n_queries * N) != VIO_OK)
       return VIO_ENOMEM;
-    hipStream_t st = d->voc->stream;
+    hipStream_t st = d->stream;
     HIP_OK(hipMemcpyAsync(d->q_count.p, bow_count, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->q_max.p, max_id, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->q_word.p, bow_word, 4 * (size_t)n_queries * bow_stride, hipMemcpyHostToDevice, st));

@@ -807,6 +807,8 @@ struct TrackerArrays {
   uint8_t *lk_status;                    // [seq][cap]
   int *kept_xy;                          // [seq][cap][2] rounded centres of kept features (for the mask painter)
   int *n_kept;                           // [seq]
+  float *pnp_pts;                        // [seq][cap][2] forw_pts / ids as solveVinsPnP sees them (feature_tracker.cpp:207:
+  int *pnp_ids, *n_pnp;                  // behind the first F-RANSAC, ahead of rejectWithF / setMask)
   const int *hw;                         // [2 r + 1] half-widths of the filled circle
   int radius;
   float f_thresh;
@@ -884,6 +886,13 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
       compact_block(T);
     }
   }
+  // the point list solveVinsPnP joins with the solved landmarks (:207): behind the first rejection, ahead of the
+  // publish-frame steps (rejectWithF :235, setMask :255) that drop more of it
+  for (int i = tid; i < T.n; i += nt) {
+    A.pnp_pts[(base + i) * 2] = T.forw[i][0], A.pnp_pts[(base + i) * 2 + 1] = T.forw[i][1];
+    A.pnp_ids[base + i] = T.ids[i];
+  }
+  if (tid == 0) A.n_pnp[seq] = T.n;
   if (publish) {
     if (T.n >= 8) {  // rejectWithF: (pre_pts, forw_pts) :89-103
       fundamental_ransac_block(R, &T.pre[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep);
@@ -1320,7 +1329,8 @@ struct vio_frontend {
   int *n_cand = nullptr;
   float *cur_pts = nullptr, *pre_pts = nullptr, *forw_pts = nullptr, *lk_err = nullptr;
   int *ids = nullptr, *track_cnt = nullptr, *n_pts = nullptr, *n_forw = nullptr, *n_id = nullptr, *kept_xy = nullptr,
-      *n_kept = nullptr, *hw = nullptr, *n_obs = nullptr;
+      *n_kept = nullptr, *hw = nullptr, *n_obs = nullptr, *pnp_ids = nullptr, *n_pnp = nullptr;
+  float *pnp_pts = nullptr;
   uint8_t *lk_status = nullptr;
   VioObs *obs = nullptr;
   bool attr_set = false;
@@ -1428,6 +1438,7 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
   A.cur_pts = fe->cur_pts, A.pre_pts = fe->pre_pts, A.forw_pts = fe->forw_pts, A.ids = fe->ids, A.track_cnt = fe->track_cnt;
   A.n_pts = fe->n_pts, A.n_forw = fe->n_forw, A.n_id = fe->n_id, A.lk_status = fe->lk_status, A.kept_xy = fe->kept_xy;
   A.n_kept = fe->n_kept, A.hw = fe->hw, A.radius = fe->cfg.min_dist, A.f_thresh = (float)fe->cfg.f_threshold;
+  A.pnp_pts = fe->pnp_pts, A.pnp_ids = fe->pnp_ids, A.n_pnp = fe->n_pnp;
   A.f_conf = fe->cfg.f_confidence;
   const size_t shm = ((sizeof(TrackShared) + 15) & ~(size_t)15) + sizeof(RansacShared);
   if (!fe->attr_set) {
@@ -1552,6 +1563,9 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   ALLOC(fe->n_id, S);
   ALLOC(fe->kept_xy, S * cap * 2);
   ALLOC(fe->n_kept, S);
+  ALLOC(fe->pnp_pts, S * cap * 2);
+  ALLOC(fe->pnp_ids, S * cap);
+  ALLOC(fe->n_pnp, S);
   ALLOC(fe->n_obs, S);
   ALLOC(fe->lk_status, S * cap);
   ALLOC(fe->obs, S * cap);
@@ -1567,6 +1581,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
     ok = ok && hipMemset(fe->n_forw, 0, sizeof(int) * S) == hipSuccess;
     ok = ok && hipMemset(fe->n_id, 0, sizeof(int) * S) == hipSuccess;
     ok = ok && hipMemset(fe->n_kept, 0, sizeof(int) * S) == hipSuccess;
+    ok = ok && hipMemset(fe->n_pnp, 0, sizeof(int) * S) == hipSuccess;
     ok = ok && hipMemset(fe->n_obs, 0, sizeof(int) * S) == hipSuccess;
     if (!ok) rc = VIO_ENODEV;
   }
@@ -1590,7 +1605,7 @@ void vio_frontend_destroy(vio_frontend_t *fe) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {fe->pyr[0], fe->pyr[1], fe->mask, fe->max_bits, fe->cand, fe->n_cand, fe->cur_pts, fe->pre_pts,
                   fe->forw_pts, fe->lk_err, fe->ids, fe->track_cnt, fe->n_pts, fe->n_forw, fe->n_id, fe->kept_xy, fe->n_kept,
-                  fe->n_obs, fe->lk_status, fe->obs, fe->hw, fe->frames};
+                  fe->n_obs, fe->lk_status, fe->obs, fe->hw, fe->frames, fe->pnp_pts, fe->pnp_ids, fe->n_pnp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto &e : fe->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
@@ -1617,6 +1632,7 @@ int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t 
 int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t publish, void *stream) {
   if (!fe) return VIO_EINVAL;
   if (!fe->frames || frame_index < 0 || frame_index >= fe->n_frames) return VIO_ESTATE;
+  if (fe->pending) return VIO_ESTATE;  // a submitted frame owns the tracker state and the observation staging until it is collected
   VIO_ON_DEVICE_OF(fe);
   hipStream_t st = stream ? (hipStream_t)stream : fe->stream;
   if (fe->events_used == fe->events.size()) {
@@ -1744,6 +1760,7 @@ int vio_frontend_read_image(vio_frontend_t *fe, int32_t seq, const uint8_t *gray
 int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int32_t *ids, int32_t *track_cnt, int32_t cap,
                            int32_t *n) {
   if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;
   VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   int m = 0;
@@ -1759,12 +1776,34 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int3
   return VIO_OK;
 }
 
+// forw_pts / ids at the point of readImage where solveVinsPnP runs (feature_tracker.cpp:207): the tracked points behind
+// the first F-RANSAC of the last frame, ahead of rejectWithF / setMask. A frame that tracked nothing (the first one)
+// leaves the list empty.
+int vio_frontend_get_pnp_points(vio_frontend_t *fe, int32_t seq, float *forw_pts, int32_t *ids, int32_t cap, int32_t *n) {
+  if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;
+  VIO_ON_DEVICE_OF(fe);
+  HIP_OK(hipDeviceSynchronize());
+  int m = 0;
+  HIP_OK(hipMemcpy(&m, fe->n_pnp + seq, sizeof(int), hipMemcpyDeviceToHost));
+  *n = m;
+  if (m > cap) return VIO_ECAP;
+  const size_t base = (size_t)seq * fe->cap;
+  if (m > 0) {
+    if (!forw_pts || !ids) return VIO_EINVAL;
+    HIP_OK(hipMemcpy(forw_pts, fe->pnp_pts + base * 2, sizeof(float) * 2 * m, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ids, fe->pnp_ids + base, sizeof(int) * m, hipMemcpyDeviceToHost));
+  }
+  return VIO_OK;
+}
+
 // ---- the tracker's public fields in / out and the update step on its own (isolated tests of F3/F4/F6/F7) ---------------
 int vio_frontend_set_tracks(vio_frontend_t *fe, int32_t seq, int32_t n, const float *pre_pts, const float *cur_pts,
                             const float *forw_pts, const int32_t *ids, const int32_t *track_cnt, const uint8_t *lk_status) {
   if (!fe || seq < 0 || seq >= fe->n_seq || n < 0 || (n > 0 && (!pre_pts || !cur_pts || !forw_pts || !ids || !track_cnt || !lk_status)))
     return VIO_EINVAL;
   if (n > fe->cap) return VIO_ECAP;
+  if (fe->pending) return VIO_ESTATE;
   VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   const size_t base = (size_t)seq * fe->cap;
@@ -1782,6 +1821,7 @@ int vio_frontend_set_tracks(vio_frontend_t *fe, int32_t seq, int32_t n, const fl
 
 int vio_frontend_update_tracks(vio_frontend_t *fe, int32_t publish) {
   if (!fe) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;
   VIO_ON_DEVICE_OF(fe);
   int rc = launch_track_update(fe, publish, fe->stream);
   if (rc != VIO_OK) return rc;
@@ -1793,6 +1833,7 @@ int vio_frontend_update_tracks(vio_frontend_t *fe, int32_t publish) {
 int vio_frontend_get_tracks(vio_frontend_t *fe, int32_t seq, float *forw_pts, int32_t *ids, int32_t *track_cnt, int32_t cap,
                             int32_t *n) {
   if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;
   VIO_ON_DEVICE_OF(fe);
   HIP_OK(hipDeviceSynchronize());
   int m = 0;

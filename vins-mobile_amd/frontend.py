@@ -82,6 +82,16 @@ class FeatureTracker:
                                                     cnt.ctypes.data_as(_ip), cap, C.byref(n)), "get_state")
         return pts[: n.value].copy(), ids[: n.value].copy(), cnt[: n.value].copy()
 
+    def pnp_points(self, seq=0):
+        """forw_pts / ids where solveVinsPnP joins them (feature_tracker.cpp:207): ahead of rejectWithF / setMask."""
+        cap = self.cfg.max_corners
+        pts = np.zeros((cap, 2), np.float32)
+        ids = np.zeros(cap, np.int32)
+        n = C.c_int32()
+        self._check(self.lib.vio_frontend_get_pnp_points(self._h, seq, pts.ctypes.data_as(_fp), ids.ctypes.data_as(_ip), cap,
+                                                         C.byref(n)), "get_pnp_points")
+        return pts[: n.value].copy(), ids[: n.value].copy()
+
     # resident API (throughput runs): frames [n_frames, n_seq, rows, cols] uploaded once
     def upload_frames(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)
