@@ -233,6 +233,19 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
  * last call, measured with HIP events on the launch stream.                  */
 int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches);
 
+/* How the windows of a batch are executed on the device (same results either way):
+ *   VIO_PATH_AUTO    the library chooses per upload (default; env VIO_AMD_PHASE=0/1 overrides)
+ *   VIO_PATH_SINGLE  one launch: one workgroup owns a window for the whole of solve_ceres
+ *   VIO_PATH_PHASE   a fixed sequence of launches with no host round trip: setup, then
+ *                    factor-parallel linearization kernels alternating with per-window
+ *                    trust-region step kernels, then new2old + marginalization
+ *                    (windows of more than 12 frames always take the single launch)
+ * Takes effect at the next vio_backend_upload.                                          */
+#define VIO_PATH_AUTO 0
+#define VIO_PATH_SINGLE 1
+#define VIO_PATH_PHASE 2
+int vio_backend_set_path(vio_backend_t *be, int32_t path);
+
 /* Per-stage device cycle counters of the solve kernel: the kernel-side counterpart
  * of the reference's TS()/TE() printf timers (global_param.hpp:85-92, VINS.cpp:657-662,
  * 753-758). Enable before vio_backend_upload; read after a launch. Stage order:

@@ -14,7 +14,11 @@ abi, synth, backend = pkg.abi, pkg.synth, pkg.backend
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--no-prior"]
+    path = "auto"
+    for a in sys.argv[1:]:
+        if a.startswith("--path="):
+            path = a.split("=")[1]
+    args = [a for a in sys.argv[1:] if a != "--no-prior" and not a.startswith("--path=")]
     batches = [int(x) for x in args] or [1, 64, 256, 512, 1024]
     cfg = abi.default_config()
     pre = lambda *a: backend.preintegrate(cfg, *a)
@@ -25,15 +29,17 @@ def main():
         import bench
         uniq = bench.steady_state_windows(cfg, pkg, pre, [42 + i for i in range(8)])
     solver = backend.WindowSolver(cfg, max_batch=max(batches))
-    solver.set_profile(True)
-    ws = [uniq[0].copy()]
-    solver.upload(ws)
-    solver.launch()
-    solver.sync()
-    cyc = solver.stage_cycles(0)
-    tot = max(1, cyc["total"])
-    print("stage cycles (1 window): " + ", ".join("%s=%d(%.1f%%)" % (k, c, 100.0 * c / tot) for k, c in cyc.items()))
-    solver.set_profile(False)
+    solver.set_path(path)
+    if path != "phase":
+        solver.set_profile(True)
+        ws = [uniq[0].copy()]
+        solver.upload(ws)
+        solver.launch()
+        solver.sync()
+        cyc = solver.stage_cycles(0)
+        tot = max(1, cyc["total"])
+        print("stage cycles (1 window): " + ", ".join("%s=%d(%.1f%%)" % (k, c, 100.0 * c / tot) for k, c in cyc.items()))
+        solver.set_profile(False)
     for B in batches:
         ws = [uniq[i % len(uniq)].copy() for i in range(B)]
         solver.upload(ws)
@@ -48,7 +54,7 @@ def main():
         wall = (time.time() - t0) / reps
         ms, n = solver.kernel_ms()
         st = solver.download(ws)
-        print("B=%5d kernel %.3f ms (wall %.3f ms) -> %.0f solves/s, %.1f us/solve/CU-slot; iters %s final cost %.4f" % (
+        print("path=%s " % path + "B=%5d kernel %.3f ms (wall %.3f ms) -> %.0f solves/s, %.1f us/solve/CU-slot; iters %s final cost %.4f" % (
             B, ms, wall * 1e3, B / (ms * 1e-3), ms * 1e3 / max(1, -(-B // 256)), st[0]["iterations"], st[0]["final_cost"]))
 
 

@@ -102,6 +102,49 @@ inline BatchStrides make_strides(const BatchDims &d) {
   return s;
 }
 
+// ---- phase path (phase_core.h): the solve as a sequence of launches ------------------------------------------------
+// Everything that lives across launches sits in one block of global memory per window:
+//   rec       the minimizer's loop-carried scalars (PhaseRec)
+//   prcol     prior column -> (frame << 8 | component), built once per solve
+//   x[2]      iterate / candidate: pose 7 (Pcap + 1) | speed-bias 9 Pcap | inverse depths Fcap
+//   h[2]      a linearization: cost | g_p | g_f | H_ff | pose matrix App (prior + projections, pre-Schur) | raw IMU Jacobians |
+//             raw IMU residuals | landmark coupling WTf. Buffer `cur` belongs to the accepted iterate, buffer 1 - cur receives the
+//             linearization at the candidate (written speculatively while the step is still undecided).
+//   sp sf     Jacobi scaling (fixed at the first linearization); gpf dp  complete gradient and trust-region diagonal of the
+//   gnp gnf   accepted linearization; Gauss-Newton step of the last linear solve (all needed again after a rejected step)
+struct PhaseLayout {
+  size_t rec, prcol, x[2], h[2], sp, sf, gpf, dp, gnp, gnf, total;
+  size_t x_sb, x_feat;
+  size_t h_gp, h_gf, h_hff, h_App, h_imuJ, h_imur, h_WTf;
+};
+constexpr int kRecDoubles = 64;
+
+inline PhaseLayout make_phase_layout(const BatchDims &d) {
+  PhaseLayout L;
+  auto up = [](size_t n) { return (n + 7) & ~(size_t)7; };
+  const size_t npc = (size_t)d.nblk_cap * kBS, F = d.Fcap;
+  L.x_sb = up(7 * (size_t)(d.Pcap + 1)), L.x_feat = L.x_sb + up(9 * (size_t)d.Pcap);
+  const size_t xs = L.x_feat + up(F);
+  size_t o = 8;  // [0, 8): cost
+  L.h_gp = o, o += up(npc);
+  L.h_gf = o, o += up(F);
+  L.h_hff = o, o += up(F);
+  L.h_App = o, o += up(tri_doubles(pose_rows(d)));
+  L.h_imuJ = o, o += up((size_t)d.Wcap * 450);
+  L.h_imur = o, o += up((size_t)d.Wcap * 15);
+  L.h_WTf = o, o += up(F * (size_t)d.n6cap);
+  const size_t hs = o;
+  o = 0;
+  L.rec = o, o += kRecDoubles;
+  L.prcol = o, o += up(((size_t)d.Ncap + 1) / 2);
+  L.x[0] = o, o += xs, L.x[1] = o, o += xs;
+  L.h[0] = o, o += hs, L.h[1] = o, o += hs;
+  L.sp = o, o += up(npc), L.sf = o, o += up(F), L.gpf = o, o += up(npc), L.dp = o, o += up(npc);
+  L.gnp = o, o += up(npc), L.gnf = o, o += up(F);
+  L.total = o;
+  return L;
+}
+
 // Device-resident prior chain: where window b reads its prior data from (null J: the strided pr_* arrays) and where it
 // writes the next one (null mJ: the strided MargPtrs arrays).
 struct PriorTab {
@@ -127,6 +170,8 @@ struct BatchPtrs {
   double *scratch;   // [n][s.scratch]
   double *hm;        // [n][s.hm] (only used when the matrix does not fit LDS)
   const int *order;  // launch-local block index -> window (null: identity); a batch may be split into two launches
+  double *phase;     // [n][PL.total] phase path: the state that lives across launches (null: single-launch path only)
+  PhaseLayout PL;
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop, *stats_d;
   int *stats_i;
 };

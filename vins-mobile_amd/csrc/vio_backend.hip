@@ -20,6 +20,7 @@
 #include "vio_pool.h"
 #include "vio_device.h"
 #include "marg_core.h"
+#include "phase_core.h"
 #include "vio_amd.h"
 
 using namespace vio;
@@ -94,6 +95,86 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   }
 }
 
+// ---- phase path: the same solve as a sequence of launches (phase_core.h) ----------------------------------------------------
+constexpr int kThreadsLin = 256;
+
+__global__ __launch_bounds__(256, 3) void vio_phase_setup_kernel(BatchPtrs B) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  WinView v = make_view(B, b);
+  const PhaseView pv = make_phase_view(B, b);
+  SetupWork sw;
+  carve_setup(B.d, (ldsd)smem, &sw);
+  Ctx cx;
+  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.red = nullptr, cx.lprof = nullptr;
+  phase_setup(cx, v, pv, sw);
+}
+
+__global__ __launch_bounds__(kThreadsLin, 2) void vio_phase_lin_kernel(BatchPtrs B) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  const WinView v = make_view(B, b);
+  const PhaseView pv = make_phase_view(B, b);
+  LinWork lw;
+  carve_lin(B.d, kThreadsLin, (ldsd)smem, &lw);
+  Ctx cx;
+  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.red = lw.red, cx.lprof = nullptr;
+  phase_linearize(cx, v, pv, lw);
+}
+
+template <bool LDS_ASP>
+__global__ __launch_bounds__(kThreadsLds, 2) void vio_phase_step_kernel(BatchPtrs B, int wrot_forced) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  WinView v = make_view(B, b);
+  const PhaseView pv = make_phase_view(B, b);
+  typedef typename std::conditional<LDS_ASP, ldsd, double *>::type AspP;
+  ldsd lds = (ldsd)smem;
+  BatchDims dims = B.d;
+  dims.lds_asp = LDS_ASP ? 1 : 0;
+  const Carved<ldsd, AspP> cw = carve_all<ldsd, AspP>(dims, true, blockDim.x, lds, nullptr, v.AspG);
+  WorkT<ldsd, AspP> w = cw.w;
+  Ctx cx;
+  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.prof_tid = 0;
+  {
+    if (threadIdx.x == 0) cw.w.flag[0] = (int)__builtin_amdgcn_s_getreg(0x1C04) & 3;
+    __syncthreads();
+    cx.wrot = wrot_forced >= 0 ? wrot_forced : cw.w.flag[0];
+    __syncthreads();
+  }
+  cx.red = cw.red, cx.lprof = cw.lprof;
+  phase_step<true, kThreadsLds / 64>(cx, v, pv, w);
+}
+
+template <bool LDS_ASP>
+__global__ __launch_bounds__(kThreadsLds, 2) void vio_phase_finish_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  WinView v = make_view(B, b);
+  const PhaseView pv = make_phase_view(B, b);
+  typedef typename std::conditional<LDS_ASP, ldsd, double *>::type AspP;
+  ldsd lds = (ldsd)smem;
+  BatchDims dims = B.d;
+  dims.lds_asp = LDS_ASP ? 1 : 0;
+  const Carved<ldsd, AspP> cw = carve_all<ldsd, AspP>(dims, true, blockDim.x, lds, nullptr, v.AspG);
+  WorkT<ldsd, AspP> w = cw.w;
+  Ctx cx;
+  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.prof_tid = 0, cx.wrot = 0;
+  cx.red = cw.red, cx.lprof = cw.lprof;
+  const size_t state_end = cw.state_end_doubles;
+  phase_finish(cx, v, pv, w);
+  MargOut mo;
+  int *mi = MP.ints + (size_t)b * MP.s_ints;
+  mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
+  mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
+  mo.scratch = nullptr;
+  mo.ncap = B.d.Ncap;
+  if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
+  MargWorkT<ldsd> mw = carve_marg_all<ldsd>(B.d, true, lds + state_end, nullptr, (size_t)lds_doubles - state_end).m;
+  __syncthreads();
+  marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
+}
+
 // Debug aid (VIO_AMD_POISON=1): every launch is preceded by NaN patterns in the whole LDS of every CU and in all device
 // scratch / output buffers, so that a read of something the kernel did not write itself cannot go unnoticed.
 __global__ __launch_bounds__(1024) void poison_lds_kernel(int n_doubles) {
@@ -165,6 +246,11 @@ struct vio_backend {
   int threads_lds = kThreadsLds;
   int n_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   DevBuf<long long> d_prof;
+  // phase path (phase_core.h): the solve as a sequence of launches; state that lives across them
+  bool use_phase = false;
+  int path = VIO_PATH_AUTO;
+  size_t lds_setup = 0, lds_lin = 0;
+  DevBuf<double> d_phase;
   HostBatch hb;
   BatchPtrs B;
   MargPtrs MP;
@@ -239,7 +325,13 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
   if (hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
       hipFuncSetAttribute((const void *)vio_window_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
       hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<false, false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+      hipFuncSetAttribute((const void *)vio_window_kernel<false, false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_finish_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+      hipFuncSetAttribute((const void *)vio_phase_finish_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
     delete be;
     return VIO_ENODEV;
   }
@@ -269,7 +361,7 @@ void vio_backend_destroy(vio_backend_t *be) {
                           &be->d_raw_feat, &be->d_out_loop, &be->d_stats_d, &be->d_m_x0, &be->d_m_J, &be->d_m_r,
                           &be->d_m_scratch};
   for (auto *b : db) b->release();
-  be->d_prof.release();
+  be->d_prof.release(), be->d_phase.release();
   for (int k = 0; k < 2; k++) be->d_st_x0[k].release(), be->d_st_J[k].release(), be->d_st_r[k].release();
   be->d_ptab.release();
   (void)hipStreamDestroy(be->stream);
@@ -421,6 +513,15 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     }
   }
   be->d_lds = dl;
+  // Phase path: the windows of the LDS set are solved by a sequence of launches (phase_core.h) instead of one.
+  static const int phase_env = getenv("VIO_AMD_PHASE") ? atoi(getenv("VIO_AMD_PHASE")) : -1;
+  const bool want_phase = be->path == VIO_PATH_PHASE || (be->path == VIO_PATH_AUTO && phase_env == 1);
+  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds && !be->profile;
+  if (be->use_phase) {
+    be->lds_setup = carve_setup(dl, nullptr, nullptr);
+    be->lds_lin = carve_lin(dl, kThreadsLin, nullptr, nullptr);
+    if (be->lds_setup > kLdsLimit || be->lds_lin > kLdsLimit) be->use_phase = false;
+  }
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
   // the previous upload's copy may still be reading the staging arena (uploads do not wait for their own transfer)
   HIP_OK(hipStreamSynchronize(be->stream));
@@ -429,7 +530,8 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   {
     std::vector<int> rcs(n, VIO_OK);
     const bool lds_shape = pose_jp(d) <= 16 * kPanelTiles;
-    const int chunk = stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
+    // (bucket alignment to the staging chunk only serves the single-launch kernel; the phase path walks the slots in strips)
+    const int chunk = be->use_phase && be->n_glb == 0 ? 0 : stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
     vio::HostPool::get().parallel_for(n, [&](int b) {
       try {
         rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0, chunk);
@@ -480,6 +582,8 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   ENSURE(be->d_m_J, N * (size_t)d.Ncap * d.Ncap);
   ENSURE(be->d_m_r, N * (size_t)d.Ncap);
   ENSURE(be->d_m_scratch, m_scr ? N * m_scr : 1);
+  const PhaseLayout PL = make_phase_layout(d);
+  if (be->use_phase) ENSURE(be->d_phase, N * PL.total);
 #undef ENSURE
   hipStream_t st = be->stream;
 #define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
@@ -529,6 +633,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   }
   B.ptab = any_slot ? be->d_ptab.p : nullptr;
   B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
+  B.phase = be->use_phase ? be->d_phase.p : nullptr, B.PL = PL;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
   B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
   B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
@@ -574,11 +679,27 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
     HIP_OK(hipMemsetAsync(be->d_hm.p, 0xff, be->d_hm.n * sizeof(double), st));
     HIP_OK(hipMemsetAsync(be->d_out_pose.p, 0xff, be->d_out_pose.n * sizeof(double), st));
     HIP_OK(hipMemsetAsync(be->d_stats_d.p, 0xff, be->d_stats_d.n * sizeof(double), st));
+    if (be->use_phase) HIP_OK(hipMemsetAsync(be->d_phase.p, 0xff, be->d_phase.n * sizeof(double), st));
     HIP_OK(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), kLdsLimit, st, (int)(kLdsLimit / sizeof(double)));
   }
   HIP_OK(hipEventRecord(ev.first, st));
-  if (be->n_lds > 0) {
+  if (be->n_lds > 0 && be->use_phase) {
+    BatchPtrs Bl = be->B;
+    Bl.d = be->d_lds, Bl.order = be->d_order.p;
+    const dim3 grid(be->n_lds);
+    const int ldsd_n = (int)(be->lds_bytes / sizeof(double));
+    const bool asp = be->d_lds.lds_asp != 0;
+    hipLaunchKernelGGL(vio_phase_setup_kernel, grid, dim3(256), be->lds_setup, st, Bl);
+    hipLaunchKernelGGL(vio_phase_lin_kernel, grid, dim3(kThreadsLin), be->lds_lin, st, Bl);
+    for (int k = 0; k <= be->d_lds.max_iter; k++) {
+      if (asp) hipLaunchKernelGGL(vio_phase_step_kernel<true>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP.wrot);
+      else hipLaunchKernelGGL(vio_phase_step_kernel<false>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP.wrot);
+      if (k < be->d_lds.max_iter) hipLaunchKernelGGL(vio_phase_lin_kernel, grid, dim3(kThreadsLin), be->lds_lin, st, Bl);
+    }
+    if (asp) hipLaunchKernelGGL(vio_phase_finish_kernel<true>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP, ldsd_n);
+    else hipLaunchKernelGGL(vio_phase_finish_kernel<false>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP, ldsd_n);
+  } else if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
     if (be->threads_lds == kThreadsLds && be->d_lds.lds_asp)
@@ -622,6 +743,13 @@ int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches) 
   *launches = (int32_t)be->events_used;
   *ms_avg = be->events_used ? sum / be->events_used : 0.0;
   be->events_used = 0;
+  return VIO_OK;
+}
+
+int vio_backend_set_path(vio_backend_t *be, int32_t path) {
+  if (!be || path < VIO_PATH_AUTO || path > VIO_PATH_PHASE) return VIO_EINVAL;
+  be->path = path;
+  be->uploaded = false;  // takes effect at the next upload
   return VIO_OK;
 }
 
