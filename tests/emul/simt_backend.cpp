@@ -146,7 +146,7 @@ extern "C" int simt_solve_window_phase(const VioConfig *cfg, VioWindow *win, Vio
   const size_t bs = carve_work<double *>(B.d, true, nthreads, nullptr, nullptr, nullptr, nullptr, &se);
   const size_t bm = se * sizeof(double) + carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, 0);
   const size_t need = std::max(bs, bm + 64 * kMargSlot * sizeof(double));
-  if (need > kLdsBytes || carve_setup(B.d, nullptr, nullptr) > kLdsBytes || carve_lin(B.d, nthreads, nullptr, nullptr) > kLdsBytes) return VIO_ECAP;
+  if (need > kLdsBytes || carve_setup(B.d, nullptr, nullptr) > kLdsBytes || carve_lin(B.d, nullptr, nullptr) > kLdsBytes) return VIO_ECAP;
   const size_t lds_bytes = need <= kLdsBytes / 2 ? kLdsBytes / 2 : kLdsBytes;
   const size_t lds_doubles = lds_bytes / sizeof(double);
   std::vector<double> lds(kLdsBytes / sizeof(double) + 2, kNaN);
@@ -170,13 +170,13 @@ extern "C" int simt_solve_window_phase(const VioConfig *cfg, VioWindow *win, Vio
   };
   auto lin = [&]() {
     fresh_lds();
-    simt::launch(nthreads, [&](int tid) {
+    simt::launch(kLinThreads, [&](int tid) {
       const WinView v = make_view(B, 0);
       const PhaseView pv = make_phase_view(B, 0);
       LinWork lw;
-      carve_lin(B.d, nthreads, lds.data(), &lw);
+      carve_lin(B.d, lds.data(), &lw);
       Ctx cx;
-      cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr, cx.red = lw.red, cx.lprof = nullptr;
+      cx.tid = tid, cx.nt = kLinThreads, cx.prof = nullptr, cx.red = lw.red, cx.lprof = nullptr;
       phase_linearize(cx, v, pv, lw);
     }, order);
   };

@@ -30,7 +30,7 @@ def main():
         uniq = bench.steady_state_windows(cfg, pkg, pre, [42 + i for i in range(8)])
     solver = backend.WindowSolver(cfg, max_batch=max(batches))
     solver.set_path(path)
-    if path != "phase":
+    if True:
         solver.set_profile(True)
         ws = [uniq[0].copy()]
         solver.upload(ws)

@@ -105,7 +105,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
 // ---- phase path (phase_core.h): the solve as a sequence of launches ------------------------------------------------
 // Everything that lives across launches sits in one block of global memory per window:
 //   rec       the minimizer's loop-carried scalars (PhaseRec)
-//   prcol     prior column -> (frame << 8 | component), built once per solve
+//   prcol     prior column -> (frame << 8 | component), built once per solve; fh: host frame of every landmark
 //   x[2]      iterate / candidate: pose 7 (Pcap + 1) | speed-bias 9 Pcap | inverse depths Fcap
 //   h[2]      a linearization: cost | g_p | g_f | H_ff | pose matrix App (prior + projections, pre-Schur) | raw IMU Jacobians |
 //             raw IMU residuals | landmark coupling WTf. Buffer `cur` belongs to the accepted iterate, buffer 1 - cur receives the
@@ -113,7 +113,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
 //   sp sf     Jacobi scaling (fixed at the first linearization); gpf dp  complete gradient and trust-region diagonal of the
 //   gnp gnf   accepted linearization; Gauss-Newton step of the last linear solve (all needed again after a rejected step)
 struct PhaseLayout {
-  size_t rec, prcol, x[2], h[2], sp, sf, gpf, dp, gnp, gnf, total;
+  size_t rec, prcol, fh, x[2], h[2], sp, sf, gpf, dp, gnp, gnf, total;
   size_t x_sb, x_feat;
   size_t h_gp, h_gf, h_hff, h_App, h_imuJ, h_imur, h_WTf;
 };
@@ -137,6 +137,7 @@ inline PhaseLayout make_phase_layout(const BatchDims &d) {
   o = 0;
   L.rec = o, o += kRecDoubles;
   L.prcol = o, o += up(((size_t)d.Ncap + 1) / 2);
+  L.fh = o, o += up((F + 1) / 2);  // host frame of every landmark (-1: it has no factor)
   L.x[0] = o, o += xs, L.x[1] = o, o += xs;
   L.h[0] = o, o += hs, L.h[1] = o, o += hs;
   L.sp = o, o += up(npc), L.sf = o, o += up(F), L.gpf = o, o += up(npc), L.dp = o, o += up(npc);

@@ -38,22 +38,33 @@ struct PhaseRec {
 };
 static_assert(sizeof(PhaseRec) <= kRecDoubles * sizeof(double), "PhaseRec outgrew its slot");
 
+// One base pointer and offsets: every buffer address is base + offset arithmetic, so that the compiler keeps the accesses in
+// the global address space (a pointer picked from a two-element pointer array by the run-time buffer index decays to a
+// generic pointer, and flat loads / stores / atomics count against the LDS wait counter as well: every later ds_read
+// then waits for them).
 struct PhaseView {
-  PhaseRec *rec;
-  int *prcol;
-  double *xb[2], *hb[2];
-  double *sp, *sf, *gpf, *dp, *gnp, *gnf;
+  double *base;
+  int o_rec, o_prcol, o_fh, o_x[2], o_h[2], o_sp, o_sf, o_gpf, o_dp, o_gnp, o_gnf;
   int x_sb, x_feat, h_gp, h_gf, h_hff, h_App, h_imuJ, h_imur, h_WTf;
+  VIO_HD PhaseRec *rec_ptr() const { return reinterpret_cast<PhaseRec *>(base + o_rec); }
+  VIO_HD int *prcol() const { return reinterpret_cast<int *>(base + o_prcol); }
+  VIO_HD int *fh() const { return reinterpret_cast<int *>(base + o_fh); }
+  VIO_HD double *xb(int i) const { return base + (i ? o_x[1] : o_x[0]); }
+  VIO_HD double *hb(int i) const { return base + (i ? o_h[1] : o_h[0]); }
+  VIO_HD double *sp() const { return base + o_sp; }
+  VIO_HD double *sf() const { return base + o_sf; }
+  VIO_HD double *gpf() const { return base + o_gpf; }
+  VIO_HD double *dp() const { return base + o_dp; }
+  VIO_HD double *gnp() const { return base + o_gnp; }
+  VIO_HD double *gnf() const { return base + o_gnf; }
 };
 
 VIO_HD PhaseView make_phase_view(const BatchPtrs &B, int b) {
   const PhaseLayout &L = B.PL;
-  double *base = B.phase + (size_t)b * L.total;
   PhaseView p;
-  p.rec = reinterpret_cast<PhaseRec *>(base + L.rec);
-  p.prcol = reinterpret_cast<int *>(base + L.prcol);
-  p.xb[0] = base + L.x[0], p.xb[1] = base + L.x[1], p.hb[0] = base + L.h[0], p.hb[1] = base + L.h[1];
-  p.sp = base + L.sp, p.sf = base + L.sf, p.gpf = base + L.gpf, p.dp = base + L.dp, p.gnp = base + L.gnp, p.gnf = base + L.gnf;
+  p.base = B.phase + (size_t)b * L.total;
+  p.o_rec = (int)L.rec, p.o_prcol = (int)L.prcol, p.o_fh = (int)L.fh, p.o_x[0] = (int)L.x[0], p.o_x[1] = (int)L.x[1], p.o_h[0] = (int)L.h[0], p.o_h[1] = (int)L.h[1];
+  p.o_sp = (int)L.sp, p.o_sf = (int)L.sf, p.o_gpf = (int)L.gpf, p.o_dp = (int)L.dp, p.o_gnp = (int)L.gnp, p.o_gnf = (int)L.gnf;
   p.x_sb = (int)L.x_sb, p.x_feat = (int)L.x_feat;
   p.h_gp = (int)L.h_gp, p.h_gf = (int)L.h_gf, p.h_hff = (int)L.h_hff, p.h_App = (int)L.h_App, p.h_imuJ = (int)L.h_imuJ;
   p.h_imur = (int)L.h_imur, p.h_WTf = (int)L.h_WTf;
@@ -81,7 +92,7 @@ VIO_HD size_t carve_setup(const BatchDims &d, ldsd base, SetupWork *w) {
 template <class SW>
 VIO_DEV void phase_setup(const Ctx &cx, WinView &v, const PhaseView &pv, SW &w) {
   const int P = v.P, F = v.F;
-  double *X = pv.xb[0];
+  double *X = pv.xb(0);
   VIO_PARFOR(q, P * 7) X[q] = v.pose0[q];
   if (v.has_loop) VIO_PARFOR(q, 7) X[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
   VIO_PARFOR(q, P * 9) X[pv.x_sb + q] = v.sb0[q];
@@ -97,14 +108,15 @@ VIO_DEV void phase_setup(const Ctx &cx, WinView &v, const PhaseView &pv, SW &w) 
   }
   // entries of W and of the raw IMU Jacobians that no evaluation writes stay zero: zeroed once, in both buffers
   for (int bf = 0; bf < 2; bf++) {
-    double *H = pv.hb[bf];
+    double *H = pv.hb(bf);
     VIO_PARFOR(q, F * v.n6cap) H[pv.h_WTf + q] = 0.0;
     VIO_PARFOR(q, v.W * 450) H[pv.h_imuJ + q] = 0.0;
   }
-  v.imu_J = pv.hb[0] + pv.h_imuJ;  // (setup_imu_info zeroes v.imu_J: done above for both buffers, harmless to repeat)
+  v.imu_J = pv.hb(0) + pv.h_imuJ;  // (setup_imu_info zeroes v.imu_J: done above for both buffers, harmless to repeat)
   setup_imu_info(cx, v, w.App);
   setup_prior(cx, v, w);
-  VIO_PARFOR(a, v.prior_n) pv.prcol[a] = w.prcol[a];
+  VIO_PARFOR(a, v.prior_n) pv.prcol()[a] = w.prcol[a];
+  VIO_PARFOR(f, F) pv.fh()[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
   if (cx.tid == 0) {
     PhaseRec r;
     r.x_cost = 0, r.x_norm = -1.0, r.gmax = 0, r.radius = 1e4, r.mu = 1e-8, r.mu_used = 1e-8, r.dogleg_step_norm = 0, r.alpha = 0;
@@ -112,7 +124,7 @@ VIO_DEV void phase_setup(const Ctx &cx, WinView &v, const PhaseView &pv, SW &w) 
     r.model_cost_change = 0;
     r.phase = PH_FIRST, r.cur = 1, r.it = 0, r.n_ok = 1, r.n_bad = 0, r.invalid_run = 0, r.termination = 0, r.recorded = 1;
     r.reuse = 0, r.last_ok = 1;
-    *pv.rec = r;
+    *pv.rec_ptr() = r;
   }
 }
 
@@ -120,6 +132,9 @@ VIO_DEV void phase_setup(const Ctx &cx, WinView &v, const PhaseView &pv, SW &w) 
 // linearize
 // =====================================================================================================
 constexpr int kLinStage = 64;  // factors a wave stages at once (its strip of LDS: kLinStage * kGSlot doubles)
+constexpr int kLinWaves = 3;   // projection waves of the linearize workgroup; one more wave takes the IMU factors and the prior
+                               // (the raw IMU evaluation -- one lane per factor, ~1500 dependent f64 operations -- takes as long as five strips)
+constexpr int kLinThreads = 64 * (kLinWaves + 1);
 
 struct LinWork {
   ldsd pose, ex, rot, feat;  // the evaluation point: 7 (P + 1), 7, 9 (P + 2), F
@@ -128,10 +143,11 @@ struct LinWork {
   ldsd wh;                   // [6][F]: host-frame coupling of every landmark
   ldsd prdx, prr;            // prior
   ldsd red;
-  ldsd stage;                // [waves][kLinStage * kGSlot]
+  ldsd lprof;                // stage clock (ST_COUNT long longs)
+  ldsd stage;                // [kLinWaves][kLinStage * kGSlot]
   int Fld;
 };
-VIO_HD size_t carve_lin(const BatchDims &d, int nthreads, ldsd base, LinWork *w) {
+VIO_HD size_t carve_lin(const BatchDims &d, ldsd base, LinWork *w) {
   size_t o = 0;
   auto take = [&](size_t n) {
     ldsd p = base + o;
@@ -145,82 +161,101 @@ VIO_HD size_t carve_lin(const BatchDims &d, int nthreads, ldsd base, LinWork *w)
   t.ppd = take(36 * (size_t)(d.Pcap + 1)), t.gp = take(npc);
   t.hff = take(F), t.gf = take(F), t.wh = take(6 * (size_t)t.Fld);
   t.prdx = take(d.Ncap), t.prr = take(d.Ncap);
-  t.red = take(6 * ((size_t)nthreads / 64) + 2);
-  t.stage = take((size_t)(nthreads / 64) * kLinStage * kGSlot);
+  t.red = take(6 * (size_t)(kLinWaves + 1) + 2);
+  t.lprof = take(ST_COUNT);
+  t.stage = take((size_t)kLinWaves * kLinStage * kGSlot);
   if (w) *w = t;
   return o * sizeof(double);
 }
 
-// One evaluation of every factor of the window at the point xb[1 - cur]: cost and Jacobians -> hb[1 - cur].
+// One evaluation of every factor of the window at the point xb[1 - cur]: cost and Jacobians -> hb[1 - cur]. The pose matrix
+// leaves WITHOUT the prior's H0 (the step kernel adds it while it copies the matrix into LDS): it is zero-filled here and
+// only ever accumulated into.
 template <class LW>
 VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &pv, LW &w) {
-  const int phase = pv.rec->phase;
+  const int phase = pv.rec_ptr()->phase;
   if (phase == PH_DONE) return;
-  const int tgt = 1 - pv.rec->cur;
-  const double *X = pv.xb[tgt];
-  double *H = pv.hb[tgt];
+  const int tgt = 1 - pv.rec_ptr()->cur;
+  const double *X = pv.xb(tgt);
+  double *H = pv.hb(tgt);
   const int P = v.P, F = v.F, np = v.np, nF = v.P + v.has_loop, n = v.prior_n;
   const int napp = (int)tri_doubles(v.nrows);
   double *Happ = H + pv.h_App, *HW = H + pv.h_WTf;
   double cost = 0.0;
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
+  const int NT = (int)cx.nt;
 
-  // ---- A: the evaluation point into LDS, accumulators zeroed, the pose matrix started as the prior's H0 ----------------
-  VIO_PARFOR(q, 7 * nF) w.pose[q] = X[q];
-  VIO_PARFOR(q, 7) w.ex[q] = v.ex[q];
-  VIO_PARFOR(f, F) w.feat[f] = X[pv.x_feat + f];
+  // ---- A: the evaluation point into LDS (every load of a lane issued before its first store), accumulators zeroed ------
+  {
+    const int npv = 7 * nF;
+    const double a0 = X[tid_ < npv ? tid_ : 0], a1 = X[pv.x_feat + (tid_ < F ? tid_ : 0)], a2 = v.ex[tid_ < 7 ? tid_ : 0];
+    double a3 = 0.0, a4 = 0.0;
+    if (n > 0) a3 = v.prb0[tid_ < n ? tid_ : 0];
+    if (tid_ + NT < F) a4 = X[pv.x_feat + tid_ + NT];
+    if (n > 0 && tid_ < v.prior_nb) {  // dx of one prior block (marginalization_factor.cpp:349-367)
+      const int kind = v.pr_kind[tid_], idx = v.pr_index[tid_], o = v.pr_offset[tid_];
+      const double *x0 = v.pr_x0 + 9 * tid_;
+      if (kind == 0) prior_block_dx(7, X + 7 * idx, x0, w.prdx + o);
+      else if (kind == 1) prior_block_dx(9, X + pv.x_sb + 9 * idx, x0, w.prdx + o);
+      else prior_block_dx(7, v.ex, x0, w.prdx + o);
+    }
+    if (tid_ >= NT - (nF + 1)) {  // rotation matrices of the poses under evaluation, then r_ic (straight from global memory)
+      const int i = tid_ - (NT - (nF + 1));
+      const bool is_ex = i == nF;
+      const double *q = is_ex ? v.ex + 3 : X + 7 * i + 3;
+      double R[9];
+      qtoR(Quat{q[0], q[1], q[2], q[3]}, R);
+      auto dst = w.rot + 9 * (is_ex ? v.P + 1 : i);
+      for (int k = 0; k < 9; k++) dst[k] = R[k];
+    }
+    if (tid_ < npv) w.pose[tid_] = a0;
+    if (tid_ < F) w.feat[tid_] = a1;
+    if (tid_ < 7) w.ex[tid_] = a2;
+    if (n > 0 && tid_ < n) w.prr[tid_] = a3;
+    if (tid_ + NT < F) w.feat[tid_ + NT] = a4;
+    for (int f = tid_ + 2 * NT; f < F; f += NT) w.feat[f] = X[pv.x_feat + f];
+    for (int i = tid_ + NT; i < n; i += NT) w.prr[i] = v.prb0[i];
+  }
   VIO_PARFOR(q, 36 * nF) w.ppd[q] = 0.0;
   VIO_PARFOR(q, np) w.gp[q] = 0.0;
   VIO_PARFOR(f, F) {
     w.hff[f] = 0.0, w.gf[f] = 0.0;
     for (int c = 0; c < 6; c++) w.wh[c * w.Fld + f] = 0.0;
   }
-  if (n > 0) {
-    VIO_PARFOR(q, napp) Happ[q] = v.AppPr[q];
-    VIO_PARFOR(b, v.prior_nb) {
-      const int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
-      const double *x0 = v.pr_x0 + 9 * b;
-      if (kind == 0) prior_block_dx(7, X + 7 * idx, x0, w.prdx + o);
-      else if (kind == 1) prior_block_dx(9, X + pv.x_sb + 9 * idx, x0, w.prdx + o);
-      else prior_block_dx(7, v.ex, x0, w.prdx + o);
-    }
-    VIO_PARFOR(i, n) w.prr[i] = v.prb0[i];
-  } else {
-    VIO_PARFOR(q, napp) Happ[q] = 0.0;
-  }
-  VIO_SYNC();
-  VIO_PARFOR(i, nF + 1) {  // rotation matrices of the poses under evaluation, then r_ic
-    const bool is_ex = i == nF;
-    double R[9];
-    if (is_ex) qtoR(Quat{w.ex[3], w.ex[4], w.ex[5], w.ex[6]}, R);
-    else qtoR(Quat{w.pose[7 * i + 3], w.pose[7 * i + 4], w.pose[7 * i + 5], w.pose[7 * i + 6]}, R);
-    auto dst = w.rot + 9 * (is_ex ? v.P + 1 : i);
-    for (int k = 0; k < 9; k++) dst[k] = R[k];
-  }
-  if (n > 0) dense_matvec_cols(cx, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
-  VIO_SYNC();
+  VIO_PARFOR(q, napp) Happ[q] = 0.0;
+  VIO_SYNC();  // (also orders the zero fill of the pose matrix ahead of the accumulation into it)
+  stamp(cx, ST_SETUP_PRIOR);
 
   // ---- B: no workgroup barrier from here to the end of the factor walk ----------------------------------------------
-  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
   const int li = lane & 15, kq = lane >> 4;
   double *HJ = H + pv.h_imuJ, *Hr = H + pv.h_imur;
-  if (wave == nw - 1) {
-    // IMU factors: raw residual + Jacobian by one lane each (the whitened Gram products are formed where the reduced
-    // system is assembled: phase_step), then Mr = cov^-1 r for the cost
+  if (wave == kLinWaves) {
+    // The spare wave: IMU factors -- raw residual + Jacobian by one lane each (the whitened Gram products are formed where
+    // the reduced system is assembled: phase_step), Mr = cov^-1 r for the cost -- and the prior's H0 dx.
     for (int f = lane; f < v.W; f += 64)
       imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, X + 7 * f, X + pv.x_sb + 9 * f, X + 7 * (f + 1), X + pv.x_sb + 9 * (f + 1),
                    Hr + f * 15, HJ + f * 450);
+    stamp(cx, ST_IMU_RAW);
+    if (n > 0) {
+      Ctx sub = cx;
+      sub.tid = lane, sub.nt = 64;
+      dense_matvec_cols(sub, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int q = lane; q < v.W * 15; q += 64) {
       const int f = q / 15, r = q - f * 15;
       const double *info = v.imu_info + f * 225 + r * 15, *rr = Hr + f * 15;
-      double s = 0;
-      for (int k = 0; k < 15; k++) s += info[k] * rr[k];
-      cost += 0.5 * s * rr[r];
+      double iv[15], rv[15], s = 0;
+#pragma unroll
+      for (int k = 0; k < 15; k++) iv[k] = info[k], rv[k] = rr[k];
+#pragma unroll
+      for (int k = 0; k < 15; k++) s += iv[k] * rv[k];
+      cost += 0.5 * s * rv[r];
     }
-  }
-  {
+    stamp(cx, ST_M_PRIOR);
+  } else {
     const double bb = v.cauchy_b, cc = 1.0 / bb;
     // where this lane's four accumulator elements of a bucket's Gram matrix go (a property of the lane, not of the bucket)
     int f_kind[4], f_off[4];  // 0 nothing, 1 LDS base + host * mul, 2 LDS base + target * mul, 3 off-diagonal block (global)
@@ -256,7 +291,7 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
       }
     };
     // this wave's strip of the slot order
-    const int per = (((v.nslots + nw - 1) / nw) + kLinStage - 1) / kLinStage * kLinStage;
+    const int per = (((v.nslots + kLinWaves - 1) / kLinWaves) + kLinStage - 1) / kLinStage * kLinStage;
     const int ws0 = wave * per, ws1 = ws0 + per < v.nslots ? ws0 + per : v.nslots;
     ldsd G = w.stage + wave * (kLinStage * kGSlot);
     // bucket descriptors: a window of 64 of them in the lanes
@@ -268,6 +303,11 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
       m_s0 = pv_ ? v.pair_s0[pl] : 0x7fffffff, m_s1 = pv_ ? v.pair_s1[pl] : 0x7fffffff;
       m_ht = pv_ ? (v.pair_h[pl] << 16) | v.pair_t[pl] : 0;
     };
+    // the first strip's factor records are on their way while the bucket table is searched
+    int rec_n = ws0 + lane < ws1 ? v.srec_i[ws0 + lane] : -1;
+    double pn[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) pn[c] = v.srec_d[6 * (size_t)(ws0 + lane < ws1 ? ws0 + lane : 0) + c];
     int b = 0;  // first bucket that reaches into the strip
     for (int base = 0; base < v.npairs; base += 64) {
       load_table(base);
@@ -276,7 +316,7 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
       b += c;
       if (c < 64) break;
     }
-    if (ws0 < ws1) load_table(b & ~63);
+    if (ws0 < ws1 && (b < tb || b >= tb + 64)) load_table(b & ~63);
     v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
     bool pending = false;
     int pend_ht = 0;
@@ -284,12 +324,16 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
     const int src = li < 6 ? li : li < 9 ? li - 6 : li < 12 ? li - 3 : 9;
     const double sg = (li >= 6 && li < 9) ? -1.0 : (lv ? 1.0 : 0.0);
     for (int p0 = ws0; p0 < ws1; p0 += kLinStage) {
-      const int slot = p0 + lane;
-      const bool have = slot < ws1;
-      const int rec = have ? v.srec_i[slot] : -1;
+      const int rec = rec_n;
       double pij[6];
 #pragma unroll
-      for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(have ? slot : ws0) + c];
+      for (int c = 0; c < 6; c++) pij[c] = pn[c];
+      {  // the next strip's records (a global round trip) travel while this strip is evaluated
+        const int nx = p0 + kLinStage + lane;
+        rec_n = nx < ws1 ? v.srec_i[nx] : -1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) pn[c] = v.srec_d[6 * (size_t)(nx < ws1 ? nx : 0) + c];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // the Gram products of the previous strip have read their operands
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -322,6 +366,7 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      stamp(cx, ST_P_FACT);
       // Gram products of the buckets that reach into [p0, q1): one v_mfma per two factors, A and B operand the same register
       const int q1 = p0 + kLinStage < ws1 ? p0 + kLinStage : ws1;
       while (b < v.npairs) {
@@ -365,26 +410,37 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
         }
         b++;
       }
+      stamp(cx, ST_P_GRAM);
     }
     if (pending) {  // the strip ended inside a bucket: the wave of the next strip adds the rest
       acc += acc2;
       flush(acc, pend_ht);
     }
+    stamp(cx, ST_M_GRAM);
   }
   VIO_SYNC();
+  stamp(cx, ST_M_IMU);
 
   // ---- C: prior cost / gradient, host-frame coupling rows, diagonal pose blocks, vectors out ------------------------------
-  if (n > 0) VIO_PARFOR(i, n) {
+  if (n > 0) {
+    const int i = tid_ < n ? tid_ : 0;
     const double r0 = v.pr_r[i], b0 = v.prb0[i];
-    cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
-    const int pa = pv.prcol[i];
-    if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[i]);
+    const int pa = pv.prcol()[i];
+    if (tid_ < n) {
+      cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
+      if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[i]);
+    }
+    for (int k = tid_ + NT; k < n; k += NT) {
+      const double r0k = v.pr_r[k], b0k = v.prb0[k];
+      cost += 0.5 * r0k * r0k + 0.5 * w.prdx[k] * (w.prr[k] + b0k);
+      const int pk = pv.prcol()[k];
+      if (pk >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pk >> 8) + (pk & 255), w.prr[k]);
+    }
   }
   VIO_PARFOR(f, F) {
-    if (v.fstart[f + 1] > v.fstart[f]) {
-      const int h = v.fhost[v.fstart[f]];
+    const int h = pv.fh()[f];
+    if (h >= 0)
       for (int c = 0; c < 6; c++) HW[(size_t)f * v.n6cap + 6 * h + c] = w.wh[c * w.Fld + f];
-    }
     H[pv.h_gf + f] = w.gf[f], H[pv.h_hff + f] = w.hff[f];
   }
   VIO_PARFOR(q, nF * 36) {
@@ -394,6 +450,7 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
   const double total = block_sum(cx, cost);  // (its barrier also closes the gradient)
   VIO_PARFOR(i, np) H[pv.h_gp + i] = w.gp[i];
   if (cx.tid == 0) H[0] = total;
+  stamp(cx, ST_P_FEAT);
 }
 
 // =====================================================================================================
@@ -402,7 +459,7 @@ VIO_DEV void phase_linearize(const Ctx &cx, const WinView &v, const PhaseView &p
 // minimize() of solver_core.h, re-entered once per evaluation. REGS / NW / WK as there.
 template <bool REGS, int NW, class WK>
 VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
-  PhaseRec R = *pv.rec;
+  PhaseRec R = *pv.rec_ptr();
   if (R.phase == PH_DONE) return;
   const int np = v.np, F = v.F, P = v.P, nposes = v.P + v.has_loop;
   double *sd = v.stats_d;
@@ -427,20 +484,21 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
   // speed-bias band started as the prior's, the IMU factors' whitened Gram products added, Jacobi scaling (first time) and
   // the trust-region diagonal. This is the tail of evaluate(jac = true) in solver_core.h.
   auto adopt = [&](int buf, bool have_scale) {
-    const double *H = pv.hb[buf];
-    v.WTf = pv.hb[buf] + pv.h_WTf, v.imu_J = pv.hb[buf] + pv.h_imuJ, v.imu_r = pv.hb[buf] + pv.h_imur;
+    const double *H = pv.hb(buf);
+    v.WTf = pv.hb(buf) + pv.h_WTf, v.imu_J = pv.hb(buf) + pv.h_imuJ, v.imu_r = pv.hb(buf) + pv.h_imur;
     const int napp = (int)tri_doubles(v.nrows), nband = 2 * v.P * kSS;
-    VIO_PARFOR(i, np) w.gp[i] = H[pv.h_gp + i];
-    VIO_PARFOR(f, F) w.gf[f] = H[pv.h_gf + f], w.hff[f] = H[pv.h_hff + f];
     {
       constexpr int kU = 10;
       const double *Ha = H + pv.h_App;
-      for (int q0 = VIO_TID(cx); q0 < napp + nband; q0 += kU * (int)cx.nt) {
+      const int t = VIO_TID(cx), NT = (int)cx.nt;
+      const double g0 = H[pv.h_gp + (t < np ? t : 0)], g1 = H[pv.h_gf + (t < F ? t : 0)], g2 = H[pv.h_hff + (t < F ? t : 0)];
+      for (int q0 = t; q0 < napp + nband; q0 += kU * (int)cx.nt) {
         double x[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
           const int q = q0 + u * (int)cx.nt;
-          x[u] = q < napp ? Ha[q] : (v.prior_n > 0 ? v.AppPr[q < napp + nband ? q : 0] : 0.0);
+          const double pr = v.prior_n > 0 ? v.AppPr[q < napp + nband ? q : 0] : 0.0;  // the prior's H0 in the matrix layout (setup_prior)
+          x[u] = q < napp ? Ha[q] + pr : pr;
         }
         VIO_SCHED_FENCE();
 #pragma unroll
@@ -450,26 +508,40 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
           else if (q < napp + nband) w.Dss[q - napp] = x[u];
         }
       }
+      if (t < np) w.gp[t] = g0;
+      if (t < F) w.gf[t] = g1, w.hff[t] = g2;
+      for (int f = t + NT; f < F; f += NT) w.gf[f] = H[pv.h_gf + f], w.hff[f] = H[pv.h_hff + f];
     }
     VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
     VIO_SYNC();
+    stamp(cx, ST_EVAL_PRIOR);
     {
       // One wave per IMU factor on the matrix cores (solver_core.h evaluate()): T = info [Jraw | r], G = [Jraw | r]^T T
       const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
       const int n = lane & 15, kq = lane >> 4;
-      for (int f = wave; f < v.W; f += nw) {
+      // the operands of a wave's next factor are fetched before the products of the current one are formed
+      double avs[4], bvs[2][4];
+      auto fetch = [&](int f) {
         const double *info = v.imu_info + f * 225, *Jr = v.imu_J + f * 450, *rr = v.imu_r + f * 15;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int k = 4 * s4 + kq, kc = k < 15 ? k : 0;
+          avs[s4] = info[(n < 15 ? n : 0) * 15 + kc];
+          bvs[0][s4] = Jr[kc * 30 + n];
+          bvs[1][s4] = (n < 14) ? Jr[kc * 30 + 16 + (n < 14 ? n : 0)] : rr[kc];
+        }
+      };
+      if (wave < v.W) fetch(wave);
+      for (int f = wave; f < v.W; f += nw) {
         double av[4], bv[2][4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
-          const int k = 4 * s4 + kq;
-          const bool kok = k < 15;
-          const int kc = kok ? k : 0;
-          av[s4] = (kok && n < 15) ? info[(n < 15 ? n : 0) * 15 + kc] : 0.0;
-          bv[0][s4] = kok ? Jr[kc * 30 + n] : 0.0;
-          double hi = (n < 14) ? Jr[kc * 30 + 16 + (n < 14 ? n : 0)] : (n == 14 ? rr[kc] : 0.0);
-          bv[1][s4] = kok ? hi : 0.0;
+          const bool kok = 4 * s4 + kq < 15;
+          av[s4] = (kok && n < 15) ? avs[s4] : 0.0;
+          bv[0][s4] = kok ? bvs[0][s4] : 0.0;
+          bv[1][s4] = (kok && n < 15) ? bvs[1][s4] : 0.0;
         }
+        if (f + nw < v.W) fetch(f + nw);
         v4d T0 = {0, 0, 0, 0}, T1 = {0, 0, 0, 0};
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) T0 = mfma_f64(av[s4], bv[0][s4], T0), T1 = mfma_f64(av[s4], bv[1][s4], T1);
@@ -499,22 +571,44 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
     VIO_PARFOR(i, np) {
       const int f = i / kBS, c = i - f * kBS;
       const double h = c < 6 ? w.App[tri_at(6 * f + c, 6 * f + c)] : w.Dss[f * kSS + (c - 6) * (kSB + 1)];
-      if (!have_scale) w.sp[i] = rcp_f(1.0 + sqrt_f(h)), pv.sp[i] = w.sp[i];
+      if (!have_scale) w.sp[i] = rcp_f(1.0 + sqrt_f(h)), pv.sp()[i] = w.sp[i];
       const double sc = w.sp[i];
       w.dp[i] = sqrt_f(fmin(fmax(sc * sc * h, 1e-6), 1e32));
-      pv.dp[i] = w.dp[i], pv.gpf[i] = w.gp[i];
+      pv.dp()[i] = w.dp[i], pv.gpf()[i] = w.gp[i];
     }
     VIO_SYNC();
+    stamp(cx, ST_EVAL_IMU);
   };
 
   // ---- entry: the iterate and what the first decision needs -------------------------------------------------------------
   int cur = R.cur;
   {
-    const double *Xc = pv.xb[R.phase == PH_FIRST ? 0 : cur];
-    VIO_PARFOR(q, nposes * 7) w.xpose[q] = Xc[q];
-    VIO_PARFOR(q, P * 9) w.xsb[q] = Xc[pv.x_sb + q];
-    VIO_PARFOR(q, F) w.xfeat[q] = Xc[pv.x_feat + q];
-    VIO_PARFOR(q, 7) w.ex[q] = v.ex[q];
+    // every load of a lane is issued before its first store: one global round trip for the whole state instead of one per array
+    const double *Xc = pv.xb(R.phase == PH_FIRST ? 0 : cur), *Xn = pv.xb(1 - cur);
+    const int t = VIO_TID(cx), NT = (int)cx.nt, n7 = nposes * 7, n9 = P * 9;
+    const bool cand = R.phase == PH_CAND;
+    const double a0 = Xc[t < n7 ? t : 0], a1 = Xc[pv.x_sb + (t < n9 ? t : 0)], a2 = Xc[pv.x_feat + (t < F ? t : 0)], a3 = v.ex[t < 7 ? t : 0];
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if (cand) {
+      c0 = Xn[t < n7 ? t : 0], c1 = Xn[pv.x_sb + (t < n9 ? t : 0)], c2 = Xn[pv.x_feat + (t < F ? t : 0)];
+      c3 = pv.sp()[t < np ? t : 0], c4 = pv.sf()[t < F ? t : 0];
+    }
+    VIO_SCHED_FENCE();
+    if (t < n7) w.xpose[t] = a0;
+    if (t < n9) w.xsb[t] = a1;
+    if (t < F) w.xfeat[t] = a2;
+    if (t < 7) w.ex[t] = a3;
+    if (cand) {
+      if (t < n7) w.cpose[t] = c0;
+      if (t < n9) w.csb[t] = c1;
+      if (t < F) w.cfeat[t] = c2;
+      if (t < np) w.sp[t] = c3;
+      if (t < F) w.sf[t] = c4;
+    }
+    for (int f = t + NT; f < F; f += NT) {  // (windows with more landmarks than work-items)
+      w.xfeat[f] = Xc[pv.x_feat + f];
+      if (cand) w.cfeat[f] = Xn[pv.x_feat + f], w.sf[f] = pv.sf()[f];
+    }
     VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
     if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
     VIO_PARFOR(k, P) {
@@ -523,16 +617,9 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
         if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, pr = 1;
       w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = pr;
     }
-    if (R.phase == PH_CAND) {
-      const double *Xn = pv.xb[1 - cur];
-      VIO_PARFOR(q, nposes * 7) w.cpose[q] = Xn[q];
-      VIO_PARFOR(q, P * 9) w.csb[q] = Xn[pv.x_sb + q];
-      VIO_PARFOR(q, F) w.cfeat[q] = Xn[pv.x_feat + q];
-      VIO_PARFOR(i, np) w.sp[i] = pv.sp[i];
-      VIO_PARFOR(f, F) w.sf[f] = pv.sf[f];
-    }
     VIO_SYNC();
   }
+  stamp(cx, ST_SETUP_IMU);
   double x_cost = R.x_cost, x_norm = R.x_norm, gmax = R.gmax, radius = R.radius, mu = R.mu, mu_used = R.mu_used;
   double dogleg_step_norm = R.dogleg_step_norm, alpha = R.alpha, gd_sq = R.gd_sq, qf_cauchy = R.qf_cauchy;
   double ev_min = R.ev_min, ev_cur = R.ev_cur, ev_ref = R.ev_ref, ev_cand = R.ev_cand, ev_acc_ref = R.ev_acc_ref, ev_acc_cand = R.ev_acc_cand;
@@ -545,8 +632,8 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
   if (R.phase == PH_FIRST) {
     cur = 0;
     adopt(0, false);
-    x_cost = pv.hb[0][0];
-    VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f])), pv.sf[f] = w.sf[f];  // Jacobi scaling, :239-254
+    x_cost = pv.hb(0)[0];
+    VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f])), pv.sf()[f] = w.sf[f];  // Jacobi scaling, :239-254
     VIO_SYNC();
     gmax = grad_max_norm();
     ev_min = ev_cur = ev_ref = ev_cand = x_cost, ev_acc_ref = ev_acc_cand = 0, min_rec = x_cost;
@@ -554,7 +641,7 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
     if (cx.tid == 0) sd[0] = x_cost;
   } else {
     // the candidate written by the previous launch has been evaluated: step acceptance (trust_region_minimizer.cc:428-640)
-    double cand_cost = pv.hb[1 - cur][0];
+    double cand_cost = pv.hb(1 - cur)[0];
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     double step_norm, dummy;
     state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
@@ -596,15 +683,22 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
         recorded = it + 1, min_rec = fmin(min_rec, cand_cost);
         // the accepted linearization's vectors for the next dogleg step (the matrix is only needed again if that step turns
         // out invalid: adopt() then)
-        const double *H = pv.hb[cur];
-        v.WTf = pv.hb[cur] + pv.h_WTf;
-        VIO_PARFOR(i, np) w.gp[i] = pv.gpf[i], w.dp[i] = pv.dp[i], w.gnp[i] = pv.gnp[i];
-        VIO_PARFOR(f, F) w.gf[f] = H[pv.h_gf + f], w.hff[f] = H[pv.h_hff + f], w.gnf[f] = pv.gnf[f];
+        const double *H = pv.hb(cur);
+        v.WTf = pv.hb(cur) + pv.h_WTf;
+        {
+          const int t = VIO_TID(cx), NT = (int)cx.nt, ip = t < np ? t : 0, jf = t < F ? t : 0;
+          const double b0 = pv.gpf()[ip], b1 = pv.dp()[ip], b2 = pv.gnp()[ip], b3 = H[pv.h_gf + jf], b4 = H[pv.h_hff + jf], b5 = pv.gnf()[jf];
+          VIO_SCHED_FENCE();
+          if (t < np) w.gp[t] = b0, w.dp[t] = b1, w.gnp[t] = b2;
+          if (t < F) w.gf[t] = b3, w.hff[t] = b4, w.gnf[t] = b5;
+          for (int f = t + NT; f < F; f += NT) w.gf[f] = H[pv.h_gf + f], w.hff[f] = H[pv.h_hff + f], w.gnf[f] = pv.gnf()[f];
+        }
         VIO_SYNC();
       }
     }
   }
 
+  stamp(cx, ST_COST_EVAL);
   while (!done) {
     if (it >= v.max_iter) break;
     if (last_ok && gmax <= 1e-10) { termination = 1; break; }
@@ -613,6 +707,16 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
     bool solver_ok = true;
     if (!reuse) {
       reuse = true;
+      // The loop-carried scalars that the linear solve does not touch leave the registers for its duration (they are the
+      // same in every lane, but values that come out of LDS reductions live in VGPRs: ~35 registers per lane that the panel
+      // steps of the factorization are short of). prdx / prr are free here: the prior is evaluated by the linearize kernel.
+      ldsd park = w.prdx;
+      if (cx.tid == 0) {
+        park[0] = x_cost, park[1] = x_norm, park[2] = gmax, park[3] = radius, park[4] = dogleg_step_norm, park[5] = ev_min;
+        park[6] = ev_cur, park[7] = ev_ref, park[8] = ev_cand, park[9] = ev_acc_ref, park[10] = ev_acc_cand, park[11] = min_rec;
+        ldsi pi = reinterpret_cast<ldsi>(park + 12);
+        pi[0] = it, pi[1] = n_ok, pi[2] = n_bad, pi[3] = invalid_run, pi[4] = termination, pi[5] = recorded, pi[6] = last_ok ? 1 : 0;
+      }
       double part = 0;
       VIO_PARFOR(i, np) {
         const double g = pose_gd(w, i);
@@ -629,7 +733,9 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
         VIO_SYNC();
       };
       cauchy_direction();
+      stamp(cx, ST_DOGLEG);
       const double qf_h = quad_form_H(cx, v, w, w.t2, w.stf);
+      stamp(cx, ST_QUADFORM);
       solver_ok = false;
       bool first_try = true;
       while (mu < max_mu) {
@@ -646,6 +752,7 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
           else ok = factor_band_lds(cx, v, w);
         }
         if (ok) ok = factor_poses(cx, v, w);
+        stamp(cx, ST_CHOL);
         if (ok) {
           backsolve(cx, v, w);  // z -> t1, w_f^T z_p -> gnf
           double bad = 0;
@@ -660,9 +767,17 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
             if (!isfinite(y)) bad = 1;
           }
           if (block_max(cx, bad) > 0) ok = false;
+          stamp(cx, ST_TRISOLVE);
         }
         if (ok) { solver_ok = true; mu_used = mu; break; }
         mu *= mu_inc;
+      }
+      {
+        VIO_SYNC();
+        x_cost = park[0], x_norm = park[1], gmax = park[2], radius = park[3], dogleg_step_norm = park[4], ev_min = park[5];
+        ev_cur = park[6], ev_ref = park[7], ev_cand = park[8], ev_acc_ref = park[9], ev_acc_cand = park[10], min_rec = park[11];
+        ldsi pi = reinterpret_cast<ldsi>(park + 12);
+        it = pi[0], n_ok = pi[1], n_bad = pi[2], invalid_run = pi[3], termination = pi[4], recorded = pi[5], last_ok = pi[6] != 0;
       }
       if (solver_ok) {
         double part2 = 0;
@@ -671,8 +786,8 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
         const double reg = block_sum(cx, part2);
         qf_cauchy = qf_h + reg;
         alpha = gd_sq / qf_h;
-        VIO_PARFOR(i, np) pv.gnp[i] = w.gnp[i];
-        VIO_PARFOR(f, F) pv.gnf[f] = w.gnf[f];
+        VIO_PARFOR(i, np) pv.gnp()[i] = w.gnp[i];
+        VIO_PARFOR(f, F) pv.gnf()[f] = w.gnf[f];
       }
     }
     bool step_valid = false;
@@ -744,9 +859,10 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
     VIO_PARFOR(f, F) w.tf[f] = w.stf[f] * w.sf[f];
     VIO_SYNC();
     apply_plus(cx, v, w, w.t2, w.tf);
+    stamp(cx, ST_DOGLEG);
     // the candidate leaves for its evaluation (linearize kernel); this kernel is entered again with its cost
     {
-      double *Xn = pv.xb[1 - cur];
+      double *Xn = pv.xb(1 - cur);
       VIO_PARFOR(q, nposes * 7) Xn[q] = w.cpose[q];
       VIO_PARFOR(q, P * 9) Xn[pv.x_sb + q] = w.csb[q];
       VIO_PARFOR(q, F) Xn[pv.x_feat + q] = w.cfeat[q];
@@ -759,8 +875,9 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
       S.min_rec = min_rec, S.model_cost_change = model_cost_change;
       S.phase = PH_CAND, S.cur = cur, S.it = it, S.n_ok = n_ok, S.n_bad = n_bad, S.invalid_run = invalid_run, S.termination = termination;
       S.recorded = recorded, S.reuse = reuse ? 1 : 0, S.last_ok = last_ok ? 1 : 0;
-      *pv.rec = S;
+      *pv.rec_ptr() = S;
     }
+    stamp(cx, ST_NEW2OLD);
     return;
   }
   // the minimizer has returned
@@ -769,7 +886,7 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
     si[0] = recorded, si[1] = termination, si[2] = n_ok, si[3] = n_bad;
     PhaseRec S = R;
     S.phase = PH_DONE, S.cur = cur, S.it = it;
-    *pv.rec = S;
+    *pv.rec_ptr() = S;
   }
 }
 
@@ -780,9 +897,9 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
 template <class WK>
 VIO_DEV void phase_finish(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
   const int P = v.P, F = v.F, nposes = v.P + v.has_loop;
-  const int cur = pv.rec->cur;
-  const double *Xc = pv.xb[cur];
-  v.WTf = pv.hb[cur] + pv.h_WTf, v.imu_J = pv.hb[cur] + pv.h_imuJ, v.imu_r = pv.hb[cur] + pv.h_imur;
+  const int cur = pv.rec_ptr()->cur;
+  const double *Xc = pv.xb(cur);
+  v.WTf = pv.hb(cur) + pv.h_WTf, v.imu_J = pv.hb(cur) + pv.h_imuJ, v.imu_r = pv.hb(cur) + pv.h_imur;
   VIO_PARFOR(q, nposes * 7) w.xpose[q] = Xc[q];
   VIO_PARFOR(q, P * 9) w.xsb[q] = Xc[pv.x_sb + q];
   VIO_PARFOR(q, F) w.xfeat[q] = Xc[pv.x_feat + q];

@@ -20,7 +20,7 @@
 #include "vio_pool.h"
 #include "vio_device.h"
 #include "marg_core.h"
-#include "phase_core.h"
+#include "vio_phase.h"
 #include "vio_amd.h"
 
 using namespace vio;
@@ -31,17 +31,6 @@ constexpr int kThreadsLds = 256, kThreadsGlb = 512;
 constexpr size_t kLdsLimit = vio::kLdsBytes;      // one CU
 constexpr size_t kLdsHalf = vio::kLdsBytes / 2;   // two resident workgroups per CU
 
-struct MargPtrs {
-  int *ints;        // [n][4 + 3 * kMaxPriorBlocks]
-  double *x0;       // [n][9 * kMaxPriorBlocks]
-  double *J;        // [n][Ncap * Ncap]
-  double *r;        // [n][Ncap]
-  double *scratch;  // [n][marg_scratch] (global matrix variant only)
-  size_t s_ints, s_x0, s_J, s_r, s_scratch;
-  long long *prof;  // [n][ST_COUNT] or null
-  int prof_tid;     // work-item that keeps the stage clock (VIO_AMD_PROF_TID, default 0)
-  int wrot;         // wave-role rotation: -1 = from the hardware wave slot (default), else forced (VIO_AMD_WAVE_ROT)
-};
 
 // NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
 // 512-thread workgroup per CU)
@@ -93,86 +82,6 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
     cx.lprof[ST_TOTAL] += clock64();
     for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = cx.lprof[q];
   }
-}
-
-// ---- phase path: the same solve as a sequence of launches (phase_core.h) ----------------------------------------------------
-constexpr int kThreadsLin = 256;
-
-__global__ __launch_bounds__(256, 3) void vio_phase_setup_kernel(BatchPtrs B) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
-  WinView v = make_view(B, b);
-  const PhaseView pv = make_phase_view(B, b);
-  SetupWork sw;
-  carve_setup(B.d, (ldsd)smem, &sw);
-  Ctx cx;
-  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.red = nullptr, cx.lprof = nullptr;
-  phase_setup(cx, v, pv, sw);
-}
-
-__global__ __launch_bounds__(kThreadsLin, 2) void vio_phase_lin_kernel(BatchPtrs B) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
-  const WinView v = make_view(B, b);
-  const PhaseView pv = make_phase_view(B, b);
-  LinWork lw;
-  carve_lin(B.d, kThreadsLin, (ldsd)smem, &lw);
-  Ctx cx;
-  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.red = lw.red, cx.lprof = nullptr;
-  phase_linearize(cx, v, pv, lw);
-}
-
-template <bool LDS_ASP>
-__global__ __launch_bounds__(kThreadsLds, 2) void vio_phase_step_kernel(BatchPtrs B, int wrot_forced) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
-  WinView v = make_view(B, b);
-  const PhaseView pv = make_phase_view(B, b);
-  typedef typename std::conditional<LDS_ASP, ldsd, double *>::type AspP;
-  ldsd lds = (ldsd)smem;
-  BatchDims dims = B.d;
-  dims.lds_asp = LDS_ASP ? 1 : 0;
-  const Carved<ldsd, AspP> cw = carve_all<ldsd, AspP>(dims, true, blockDim.x, lds, nullptr, v.AspG);
-  WorkT<ldsd, AspP> w = cw.w;
-  Ctx cx;
-  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.prof_tid = 0;
-  {
-    if (threadIdx.x == 0) cw.w.flag[0] = (int)__builtin_amdgcn_s_getreg(0x1C04) & 3;
-    __syncthreads();
-    cx.wrot = wrot_forced >= 0 ? wrot_forced : cw.w.flag[0];
-    __syncthreads();
-  }
-  cx.red = cw.red, cx.lprof = cw.lprof;
-  phase_step<true, kThreadsLds / 64>(cx, v, pv, w);
-}
-
-template <bool LDS_ASP>
-__global__ __launch_bounds__(kThreadsLds, 2) void vio_phase_finish_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
-  WinView v = make_view(B, b);
-  const PhaseView pv = make_phase_view(B, b);
-  typedef typename std::conditional<LDS_ASP, ldsd, double *>::type AspP;
-  ldsd lds = (ldsd)smem;
-  BatchDims dims = B.d;
-  dims.lds_asp = LDS_ASP ? 1 : 0;
-  const Carved<ldsd, AspP> cw = carve_all<ldsd, AspP>(dims, true, blockDim.x, lds, nullptr, v.AspG);
-  WorkT<ldsd, AspP> w = cw.w;
-  Ctx cx;
-  cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.prof_tid = 0, cx.wrot = 0;
-  cx.red = cw.red, cx.lprof = cw.lprof;
-  const size_t state_end = cw.state_end_doubles;
-  phase_finish(cx, v, pv, w);
-  MargOut mo;
-  int *mi = MP.ints + (size_t)b * MP.s_ints;
-  mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
-  mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
-  mo.scratch = nullptr;
-  mo.ncap = B.d.Ncap;
-  if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
-  MargWorkT<ldsd> mw = carve_marg_all<ldsd>(B.d, true, lds + state_end, nullptr, (size_t)lds_doubles - state_end).m;
-  __syncthreads();
-  marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
 }
 
 // Debug aid (VIO_AMD_POISON=1): every launch is preceded by NaN patterns in the whole LDS of every CU and in all device
@@ -326,12 +235,7 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
       hipFuncSetAttribute((const void *)vio_window_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
       hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
       hipFuncSetAttribute((const void *)vio_window_kernel<false, false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_setup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_finish_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_phase_finish_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+      vio::phase_prepare() != VIO_OK) {
     delete be;
     return VIO_ENODEV;
   }
@@ -516,10 +420,9 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   // Phase path: the windows of the LDS set are solved by a sequence of launches (phase_core.h) instead of one.
   static const int phase_env = getenv("VIO_AMD_PHASE") ? atoi(getenv("VIO_AMD_PHASE")) : -1;
   const bool want_phase = be->path == VIO_PATH_PHASE || (be->path == VIO_PATH_AUTO && phase_env == 1);
-  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds && !be->profile;
+  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds;
   if (be->use_phase) {
-    be->lds_setup = carve_setup(dl, nullptr, nullptr);
-    be->lds_lin = carve_lin(dl, kThreadsLin, nullptr, nullptr);
+    vio::phase_lds_need(dl, &be->lds_setup, &be->lds_lin);
     if (be->lds_setup > kLdsLimit || be->lds_lin > kLdsLimit) be->use_phase = false;
   }
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
@@ -685,20 +588,10 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   }
   HIP_OK(hipEventRecord(ev.first, st));
   if (be->n_lds > 0 && be->use_phase) {
+    if (be->MP.prof) HIP_OK(hipMemsetAsync(be->d_prof.p, 0, be->d_prof.n * sizeof(long long), st));  // (the launches of a sequence add up)
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    const dim3 grid(be->n_lds);
-    const int ldsd_n = (int)(be->lds_bytes / sizeof(double));
-    const bool asp = be->d_lds.lds_asp != 0;
-    hipLaunchKernelGGL(vio_phase_setup_kernel, grid, dim3(256), be->lds_setup, st, Bl);
-    hipLaunchKernelGGL(vio_phase_lin_kernel, grid, dim3(kThreadsLin), be->lds_lin, st, Bl);
-    for (int k = 0; k <= be->d_lds.max_iter; k++) {
-      if (asp) hipLaunchKernelGGL(vio_phase_step_kernel<true>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP.wrot);
-      else hipLaunchKernelGGL(vio_phase_step_kernel<false>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP.wrot);
-      if (k < be->d_lds.max_iter) hipLaunchKernelGGL(vio_phase_lin_kernel, grid, dim3(kThreadsLin), be->lds_lin, st, Bl);
-    }
-    if (asp) hipLaunchKernelGGL(vio_phase_finish_kernel<true>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP, ldsd_n);
-    else hipLaunchKernelGGL(vio_phase_finish_kernel<false>, grid, dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP, ldsd_n);
+    vio::phase_launch(Bl, be->MP, be->n_lds, be->lds_setup, be->lds_lin, be->lds_bytes, st);
   } else if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
