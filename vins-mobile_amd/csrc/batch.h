@@ -67,7 +67,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -95,6 +95,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   const size_t nslots_cap = slot_capacity(d);
   s.s_srec_i = o, o += (nslots_cap + 1) / 2;
   s.s_srec_d = o, o += 6 * nslots_cap;
+  s.s_stash = o, o += 7 * (size_t)(d.Pcap + 1) + 9 * (size_t)d.Pcap + 4 * (size_t)d.Fcap + 3 * (size_t)(d.Pcap + 1) * kBS;
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -211,6 +212,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
   v.srec_i = reinterpret_cast<int *>(sc + B.s.s_srec_i), v.srec_d = sc + B.s.s_srec_d;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
+  v.stash = sc + B.s.s_stash;
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
   v.raw_pose = B.raw_pose + b * B.s.out_pose, v.raw_sb = B.raw_sb + b * B.s.out_sb;
@@ -302,6 +304,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.prcol = reinterpret_cast<ldsi>(take(((size_t)d.Ncap + 1) / 2 + 1));
   w.sbr = reinterpret_cast<ldsi>(take((size_t)d.Pcap + 1));
   w.flag = reinterpret_cast<ldsi>(take(2));
+  w.park = take(24);
   w.rot = take(9 * (size_t)(d.Pcap + 2));
   w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
   // pose matrices of more than kPanelTiles tile rows: the fill tiles of the band go through LDS

@@ -709,8 +709,8 @@ VIO_DEV void phase_step(const Ctx &cx, WinView &v, const PhaseView &pv, WK &w) {
       reuse = true;
       // The loop-carried scalars that the linear solve does not touch leave the registers for its duration (they are the
       // same in every lane, but values that come out of LDS reductions live in VGPRs: ~35 registers per lane that the panel
-      // steps of the factorization are short of). prdx / prr are free here: the prior is evaluated by the linearize kernel.
-      ldsd park = w.prdx;
+      // steps of the factorization are short of).
+      ldsd park = w.park;
       if (cx.tid == 0) {
         park[0] = x_cost, park[1] = x_norm, park[2] = gmax, park[3] = radius, park[4] = dogleg_step_norm, park[5] = ev_min;
         park[6] = ev_cur, park[7] = ev_ref, park[8] = ev_cand, park[9] = ev_acc_ref, park[10] = ev_acc_cand, park[11] = min_rec;

@@ -206,6 +206,8 @@ struct WinView {
   double *AppPr;     // the prior's H0 scattered into the layout of App | Dss | Css once per solve (setup_prior): every
                      // linearization starts the reduced matrix as a straight copy of it instead of an element-wise scatter
   double *AspG;      // [P][9][18] the IMU part of the speed-bias x pose coupling when the pose matrix is global (WorkT::AspI)
+  double *stash;     // iterate and the vectors of its linearization while the candidate is evaluated in their place (minimize):
+                     // pose 7 (P + 1) | sb 9 P | feat F | gp dp gnp (nblk 15 each) | gf hff gnf (F each); read back after a rejected step
   // outputs
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop;
   double *stats_d;
@@ -275,6 +277,7 @@ struct WorkT {
   ldsi prcol;               // prior column -> (frame << 8 | component 0..14) of the reduced system (-1 constant): prior_n
   ldsi sbr;                 // [2 P]: first pose column speed-bias block k couples to; 1 if it is the block the prior keeps
   ldsi flag;                // [4] block-uniform flags
+  ldsd park;                // [24] loop-carried scalars of the minimizer while the linear solve runs
   ldsi fh;                  // F: host frame of every feature (-1: it has no factor)
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
   ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
@@ -2629,6 +2632,16 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     bool solver_ok = true;
     if (!reuse) {
       reuse = true;
+      // The loop-carried scalars that the linear solve does not touch leave the registers for its duration (the same in every
+      // lane, but values that come out of LDS reductions live in VGPRs: ~35 registers per lane that the panel steps of the
+      // factorization are short of). (w.park: a slot of its own -- an evaluation inside the retry loop uses every other scratch vector.)
+      ldsd park = w.park;
+      if (cx.tid == 0) {
+        park[0] = x_cost, park[1] = x_norm, park[2] = gmax, park[3] = radius, park[4] = dogleg_step_norm, park[5] = ev_min;
+        park[6] = ev_cur, park[7] = ev_ref, park[8] = ev_cand, park[9] = ev_acc_ref, park[10] = ev_acc_cand, park[11] = min_rec;
+        ldsi pi = reinterpret_cast<ldsi>(park + 12);
+        pi[0] = it, pi[1] = n_ok, pi[2] = n_bad, pi[3] = invalid_run, pi[4] = termination, pi[5] = recorded, pi[6] = last_ok ? 1 : 0;
+      }
       double part = 0;
       VIO_PARFOR(i, np) {
         const double g = pose_gd(w, i);
@@ -2688,6 +2701,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
         }
         if (ok) { solver_ok = true; mu_used = mu; have_factor = true; break; }
         mu *= mu_inc;
+      }
+      {
+        VIO_SYNC();
+        x_cost = park[0], x_norm = park[1], gmax = park[2], radius = park[3], dogleg_step_norm = park[4], ev_min = park[5];
+        ev_cur = park[6], ev_ref = park[7], ev_cand = park[8], ev_acc_ref = park[9], ev_acc_cand = park[10], min_rec = park[11];
+        ldsi pi = reinterpret_cast<ldsi>(park + 12);
+        it = pi[0], n_ok = pi[1], n_bad = pi[2], invalid_run = pi[3], termination = pi[4], recorded = pi[5], last_ok = pi[6] != 0;
       }
       if (solver_ok) {
         double part2 = 0;  // mu |D a|^2 of the Cauchy direction a (t2, stf) for the mu the solve ended with
@@ -2777,23 +2797,38 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     VIO_SYNC();
     apply_plus(cx, v, w, w.t2, w.tf);
     stamp(cx, ST_DOGLEG);
-    double cand_cost = evaluate(cx, v, w, w.cpose, w.csb, w.cfeat, false, false, false, true);
-    if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    // The candidate is linearized SPECULATIVELY -- cost and Jacobians in one evaluation, before the step is accepted. Ceres
+    // evaluates the cost at the candidate and, once the step is accepted, residuals + Jacobians at the same point
+    // (trust_region_minimizer.cc:428-640): two passes over the factors per accepted step, one here; a rejected step wastes the
+    // Jacobian half of one pass. The evaluation works in place, so the iterate and the vectors of its linearization that a
+    // rejected step still needs wait in global scratch (stores only; read back after a rejection).
     double step_norm, dummy;
     state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
-    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { termination = 1; break; }      // ParameterToleranceReached
+    const int npose7 = (v.P + v.has_loop) * 7, o_sb = 7 * (v.P + 1), o_f = o_sb + 9 * v.P, o_v = o_f + F, nv = v.nblk * kBS;
+    VIO_PARFOR(q, npose7) v.stash[q] = w.xpose[q], w.xpose[q] = w.cpose[q];
+    VIO_PARFOR(q, v.P * 9) v.stash[o_sb + q] = w.xsb[q], w.xsb[q] = w.csb[q];
+    VIO_PARFOR(q, F) {
+      v.stash[o_f + q] = w.xfeat[q], w.xfeat[q] = w.cfeat[q];
+      v.stash[o_v + 3 * nv + q] = w.gf[q], v.stash[o_v + 3 * nv + F + q] = w.hff[q], v.stash[o_v + 3 * nv + 2 * F + q] = w.gnf[q];
+    }
+    VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
+    VIO_SYNC();
+    double cand_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+    if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+    auto restore_iterate = [&]() {  // x <- the iterate the candidate replaced
+      VIO_PARFOR(q, npose7) w.xpose[q] = v.stash[q];
+      VIO_PARFOR(q, v.P * 9) w.xsb[q] = v.stash[o_sb + q];
+      VIO_PARFOR(q, F) w.xfeat[q] = v.stash[o_f + q];
+    };
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { restore_iterate(); termination = 1; break; }      // ParameterToleranceReached
     double cost_change = x_cost - cand_cost;
-    if (fabs(cost_change) <= 1e-6 * x_cost) { termination = 1; break; }       // FunctionToleranceReached
+    if (fabs(cost_change) <= 1e-6 * x_cost) { restore_iterate(); termination = 1; break; }       // FunctionToleranceReached
     double rel = (ev_cur - cand_cost) / model_cost_change;                    // StepQuality
     double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
     double rho = fmax(rel, hist);
     if (rho > 1e-3) {
-      VIO_PARFOR(q, (v.P + v.has_loop) * 7) w.xpose[q] = w.cpose[q];
-      VIO_PARFOR(q, v.P * 9) w.xsb[q] = w.csb[q];
-      VIO_PARFOR(q, F) w.xfeat[q] = w.cfeat[q];
-      VIO_SYNC();
       state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
-      x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true, /*reuse_aux=*/true);  // (x is the candidate just evaluated)
+      x_cost = cand_cost;  // (x is the candidate; its linearization is in place)
       gmax = grad_max_norm();
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
@@ -2815,6 +2850,12 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       n_bad++;
       record(it, cand_cost, radius, step_norm, rho, 0.0, true, false);
       recorded = it + 1, min_rec = fmin(min_rec, cand_cost);
+      // back to the iterate and to the vectors of ITS linearization: the next dogleg step is formed from them (the matrix
+      // buffer holds the candidate's linearization, which nothing reads: an invalid next step re-evaluates at x)
+      restore_iterate();
+      VIO_PARFOR(q, F) w.gf[q] = v.stash[o_v + 3 * nv + q], w.hff[q] = v.stash[o_v + 3 * nv + F + q], w.gnf[q] = v.stash[o_v + 3 * nv + 2 * F + q];
+      VIO_PARFOR(i, np) w.gp[i] = v.stash[o_v + i], w.dp[i] = v.stash[o_v + nv + i], w.gnp[i] = v.stash[o_v + 2 * nv + i];
+      VIO_SYNC();
     }
   }
   if (cx.tid == 0) {
