@@ -193,7 +193,13 @@ def main():
         return dt_, max(fe_ms_, 1e-9), max(be_ms_, 1e-9), stats_
 
     dt, fe_ms, be_ms, stats = run_resident(S, args.steps, args.warmup, True)
+    replicas = None
     if dist:
+        # one launch of the job answers for both batch sizes: the headline (S sequences per GPU) and BASELINE.json's configs[3]
+        # read literally (64 sequences over 8 GPUs = 8 per GPU); every rank's own step time rides along
+        replicas = {"headline": pkg.multi.replica_report(dist, S, args.steps, dt, device="cuda")}
+        dt8 = run_resident(8, args.steps, args.warmup, True)[0]
+        replicas["configs3_literal"] = pkg.multi.replica_report(dist, 8, args.steps, dt8, device="cuda")
         dt = pkg.multi.max_over_ranks(dist, dt, device="cuda")
     iters = float(np.mean([s["iterations"] - 1 for s in stats]))
     M = float(np.mean([w.n_factors for w in windows]))
@@ -236,6 +242,7 @@ def main():
                                   "traffic_unit": "bytes per step; " + (fe_src or "no PMC summary for this workload under profiles/")},
         }
         if multi_gpu is not None:
+            multi_gpu["replicas"] = replicas
             out["multi_gpu"] = multi_gpu
         extras = world == 1 and args.only == "both" and not args.quick
         if world == 1 and not args.no_cpu_baseline:

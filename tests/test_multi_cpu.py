@@ -43,6 +43,11 @@ def test_two_rank_gloo_barrier_and_max(tmp_path):
         assert len(poses) == world
         for r, p in enumerate(poses):
             assert p.shape == (77,) and p[0] == 1000.0 * m.sequences_of_rank(64, r, world)[0] and p[76] == p[0] + 76
+        # both batch sizes of one job (bench.py: headline and configs[3] literal), with every rank's own step time
+        rep = m.replica_report(dist, 8, 20, 0.5 * (1 + rank))
+        assert rep["n_gpus"] == world and rep["sequences_per_gpu"] == 8
+        assert rep["per_rank_ms_per_step"] == [25.0 * (1 + r) for r in range(world)], rep
+        assert abs(rep["ms_per_step"] - 25.0 * world) < 1e-9 and abs(rep["value"] - 8 * world * 20 / (0.5 * world)) < 1e-6, rep
         dist.destroy_process_group()
         print("ok", rank)
     """ % H.ROOT))

@@ -38,3 +38,20 @@ def all_gather_array(dist, arr, device="cpu"):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [o.cpu().numpy() for o in out]
+
+
+def per_rank_values(dist, value, device="cpu"):
+    """One float per rank, gathered on every rank (rank order): e.g. every rank's own ms_per_step next to the max that
+    defines the job's step time."""
+    return [float(a[0]) for a in all_gather_array(dist, [float(value)], device=device)]
+
+
+def replica_report(dist, sequences_per_gpu, steps, seconds, device="cpu"):
+    """The throughput line of a replica-parallel run at one batch size: whole-job frames/s = all ranks' frames / slowest
+    rank's time, plus every rank's own step time (bench.py emits it for the headline batch AND for BASELINE.json's
+    configs[3] read literally, 8 sequences per GPU, so that one launch of the job yields both)."""
+    world = dist.get_world_size()
+    per_rank = per_rank_values(dist, seconds / steps * 1e3, device=device)
+    worst = max_over_ranks(dist, seconds, device=device)
+    return {"sequences_per_gpu": int(sequences_per_gpu), "n_gpus": world, "value": sequences_per_gpu * world * steps / worst,
+            "unit": "frames/s", "ms_per_step": worst / steps * 1e3, "per_rank_ms_per_step": per_rank}
