@@ -650,7 +650,12 @@ void vio_estimator_destroy(vio_estimator_t *est);
 int vio_estimator_clear(vio_estimator_t *est, int32_t seq);                       /* clearState */
 /* solveInitial (VINS.cpp:833-1145) inside process_image when the window is full and no
  * state was handed over: relative pose, global SfM, PnP of the in-between frames,
- * visual-inertial alignment. Off by default (0): the caller hands states over.   */
+ * visual-inertial alignment. Off by default (0): the caller hands states over.
+ * 1: relativePose as the reference computes it (vio_init_relative_pose_mode 0: five-point
+ * RANSAC; a frame on which it draws a non-physical root fails and the next frame retries,
+ * VINS.cpp:893-901); 2: the fit over all correspondences with the gyroscope's rotation as
+ * tie-breaker (mode 1: succeeds on the first frame with enough parallax, planar scenes
+ * included).                                                                      */
 int vio_estimator_enable_initialization(vio_estimator_t *est, int32_t enable);
 int vio_estimator_process_imu(vio_estimator_t *est, int32_t seq, double dt, const double acc[3],
                               const double gyr[3]);                                /* processIMU */
@@ -772,6 +777,20 @@ int vio_visual_imu_alignment(const VioConfig *cfg, const double tic[3], const Vi
  * gyroscope), used only to pick between the two exact solutions of a planar scene. */
 int vio_init_relative_pose(const double *xy0, const double *xy1, int32_t n, const double *R_hint /* [9] or NULL */,
                            double R[9], double t[3], int32_t *inliers, int32_t *ok);
+/* The two routes to the relative pose. mode 0 = the reference's: cv::findEssentialMat(ll, rr)
+ * (five-point minimal solver inside RANSAC, RNG((uint64)-1), threshold 1.0, confidence 0.999)
+ * followed by cv::recoverPose's cheirality count, restated from OpenCV 3.0.0
+ * (csrc/vio_fivepoint.cpp; parity unpinned: OpenCV is not in the tree). With these arguments the
+ * threshold accepts every correspondence, so the result is the first essential matrix of the
+ * first random sample -- whether it is the physical one is chance, in the reference too; its
+ * caller retries on the next frame. mode 1 = vio_init_relative_pose's fit over all
+ * correspondences (rotation hint for planar scenes).                                   */
+int vio_init_relative_pose_mode(const double *xy0, const double *xy1, int32_t n, int32_t mode, const double *R_hint,
+                                double R[9], double t[3], int32_t *inliers, int32_t *ok);
+/* EMEstimatorCallback::runKernel (OpenCV 3.0.0 calib3d/five-point.cpp): the essential matrices
+ * (row-major, unit Frobenius norm, x2^T E x1 = 0) of five correspondences
+ * xy0 / xy1 [5][2]; E [10][9], n_models <= 10.                                          */
+int vio_init_five_point(const double *xy0, const double *xy1, double *E, int32_t *n_models);
 /* cv::solvePnP(..., useExtrinsicGuess = true) with K = I as inital_sfm.cpp:57 and
  * VINS.cpp:982 call it: refines world->camera R [9], t [3] in place.            */
 int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok);

@@ -11,7 +11,7 @@ def test_host_code_walk_is_clean_under_asan_ubsan_and_tsan(tmp_path):
     csrc = os.path.join(H.ROOT, "vins-mobile_amd", "csrc")
     exe = str(tmp_path / "host_sanity")
     src = [os.path.join(H.ROOT, "tests", "fuzz", "host_sanity.cpp")] + [os.path.join(csrc, f + ".cpp") for f in (
-        "vio_window", "vio_initial", "vio_host", "vio_estimator", "vio_pnp_tracker", "vio_replay")]
+        "vio_window", "vio_initial", "vio_fivepoint", "vio_host", "vio_estimator", "vio_pnp_tracker", "vio_replay")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-I" + os.path.join(H.ROOT, "include"), "-I" + csrc] + src + ["-lz", "-lpthread", "-o", exe])
     for n_seq in ("3", "48"):      # 48 sequences engage the host thread pool

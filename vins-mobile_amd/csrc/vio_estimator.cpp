@@ -111,6 +111,7 @@ struct vio_estimator {
   std::vector<VioWindow> windows;
   std::vector<VioSolveStats> stats;
   bool enable_init = false;
+  bool init_relpose_fit = false;  // relativePose by the all-correspondence fit instead of the reference's five-point RANSAC
   // the marginalization prior of every sequence stays in device memory between launches; only its header comes back
   // (VIO_AMD_HOST_PRIORS=1: carry it through host memory instead, ~45 KB per sequence and direction)
   bool resident_priors = !(getenv("VIO_AMD_HOST_PRIORS") && getenv("VIO_AMD_HOST_PRIORS")[0] == '1');
@@ -415,7 +416,9 @@ bool solve_initial(vio_estimator *e, Sequence &s) {
       qtoR(qnormalized(dq), Rb);
       mat3T(e->ric, ricT);
       mat3mul(ricT, Rb, Rt), mat3mul(Rt, e->ric, hint);
-      if (!init::solve_relative_rt(a, b, relative_R, relative_T, nullptr, hint)) return false;  // FAIL_RELATIVE
+      const bool got = e->init_relpose_fit ? init::solve_relative_rt(a, b, relative_R, relative_T, nullptr, hint)
+                                           : init::solve_relative_rt_five_point(a, b, relative_R, relative_T, nullptr);
+      if (!got) return false;  // FAIL_RELATIVE
       l = i;
       break;
     }
@@ -599,6 +602,7 @@ void vio_estimator_destroy(vio_estimator_t *e) {
 int vio_estimator_enable_initialization(vio_estimator_t *e, int32_t enable) {
   if (!e) return VIO_EINVAL;
   e->enable_init = enable != 0;
+  e->init_relpose_fit = enable == 2;
   return VIO_OK;
 }
 

@@ -1359,12 +1359,16 @@ namespace {
 // whole rows; the (at most two) reflected columns on either side of the image are patched into the staged dwords.
 // Arithmetic and rounding are those of pyr_down_kernel (bit-identical output).
 constexpr int kPd4H = 16, kPd4Dw = (2 * kPdW + 8) / 4;  // 34 dwords per staged row
-__global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base, uint8_t *dst_base, size_t seq_stride,
-                                                        int srows, int scols, int drows, int dcols) {
+// COPY: the source is the caller's frame (forw_img = _img, feature_tracker.cpp:169): the workgroup also writes the core of
+// its staged patch to level 0 of the pyramid, so the frame is read ONCE for the copy and for level 1 (a separate copy kernel
+// plus the level-1 kernel read it twice and the copy wrote what the level-1 kernel read again).
+template <bool COPY>
+__global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base, size_t src_stride, uint8_t *dst_base, size_t seq_stride,
+                                                        int srows, int scols, int drows, int dcols, uint8_t *copy_base) {
   constexpr int SH = 2 * kPd4H + 4;
   __shared__ uint32_t raw[SH][kPd4Dw + 1];
   __shared__ int hsum[SH][kPdW + 1];
-  const uint8_t *src = src_base + (size_t)blockIdx.z * seq_stride;
+  const uint8_t *src = src_base + (size_t)blockIdx.z * src_stride;
   uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
   const int ox = blockIdx.x * kPdW, oy = blockIdx.y * kPd4H;
   const int tid = threadIdx.x;
@@ -1373,7 +1377,13 @@ __global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base,
     const int ly = e / kPd4Dw, lx = e - ly * kPd4Dw;
     const int y = reflect101(min(2 * oy + ly - 2, 2 * srows - 2), srows);
     const int d = min(max(dw0 + lx, 0), ndw - 1);
-    raw[ly][lx] = reinterpret_cast<const uint32_t *>(src + (size_t)y * scols)[d];
+    const uint32_t v = reinterpret_cast<const uint32_t *>(src + (size_t)y * scols)[d];
+    raw[ly][lx] = v;
+    if (COPY) {  // core of the patch: rows 2 oy .. 2 oy + 2 kPd4H - 1, columns 2 ox .. 2 ox + 2 kPdW - 1 (staged dwords 1 .. 32)
+      const int yy = 2 * oy + ly - 2, dd = dw0 + lx;
+      if (ly >= 2 && ly < SH - 2 && lx >= 1 && lx <= (2 * kPdW) / 4 && yy < srows && dd < ndw)
+        reinterpret_cast<uint32_t *>(copy_base + (size_t)blockIdx.z * seq_stride + (size_t)yy * scols)[dd] = v;
+    }
   }
   __syncthreads();
   // columns -2, -1 (left-most tile) and scols, scols + 1 (the tile that holds them): BORDER_REFLECT_101
@@ -1455,7 +1465,11 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   // forw_img = _img : level 0 of the forw pyramid
   const int fidx = fe->have_img ? 1 - fe->cur_idx : fe->cur_idx;
   uint8_t *forw = fe->pyr[fidx];
-  {
+  // level 0 and level 1 from ONE read of the frame when the rows of both are whole dwords (640x480, 720p, 1080p)
+  const bool fused0 = fe->ld.levels >= 2 && cols % 4 == 0 && fe->ld.cols[1] % 4 == 0 && cols >= 8 && fe->ld.pyr_bytes % 4 == 0 &&
+                      img_bytes % 4 == 0 && (uintptr_t)d_frames % 4 == 0 && (uintptr_t)forw % 4 == 0 && fe->ld.off[1] % 4 == 0 &&
+                      !(getenv("VIO_AMD_PYR_UNFUSED") && getenv("VIO_AMD_PYR_UNFUSED")[0] == '1');
+  if (!fused0) {
     const int vec_ok = img_bytes % 16 == 0 && fe->ld.pyr_bytes % 16 == 0 && (uintptr_t)d_frames % 16 == 0 &&
                        (uintptr_t)forw % 16 == 0;
     dim3 grd((unsigned)((img_bytes + 16 * 256 - 1) / (16 * 256)), S);
@@ -1466,11 +1480,17 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     const uint8_t *sp = forw + fe->ld.off[l - 1];
     uint8_t *dp = forw + fe->ld.off[l];
     const int sc = fe->ld.cols[l - 1], dc = fe->ld.cols[l];
+    if (l == 1 && fused0) {
+      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[1] + kPd4H - 1) / kPd4H, S);
+      hipLaunchKernelGGL(pyr_down4_kernel<true>, grd, blk, 0, st, d_frames, img_bytes, dp, fe->ld.pyr_bytes, rows, cols, fe->ld.rows[1], dc, forw);
+      continue;
+    }
     // whole-dword rows on both sides (and at least two staged dwords of image): 4 pixels per load and per store
     const bool dwords = sc % 4 == 0 && dc % 4 == 0 && sc >= 8 && fe->ld.pyr_bytes % 4 == 0 && (uintptr_t)sp % 4 == 0 && (uintptr_t)dp % 4 == 0;
     if (dwords) {
       dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPd4H - 1) / kPd4H, S);
-      hipLaunchKernelGGL(pyr_down4_kernel, grd, blk, 0, st, sp, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc);
+      hipLaunchKernelGGL(pyr_down4_kernel<false>, grd, blk, 0, st, sp, fe->ld.pyr_bytes, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc,
+                         (uint8_t *)nullptr);
     } else {
       dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPdH - 1) / kPdH, S);
       hipLaunchKernelGGL(pyr_down_kernel, grd, blk, 0, st, sp, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc);

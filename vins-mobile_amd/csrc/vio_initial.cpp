@@ -889,6 +889,27 @@ extern "C" int vio_init_relative_pose(const double *xy0, const double *xy1, int3
   return VIO_OK;
 }
 
+// mode 0: cv::findEssentialMat + cv::recoverPose restated (five-point RANSAC; the reference's semantics); mode 1: the fit
+// over all correspondences (vio_init_relative_pose with its rotation hint).
+extern "C" int vio_init_relative_pose_mode(const double *xy0, const double *xy1, int32_t n, int32_t mode, const double *R_hint,
+                                           double R[9], double t[3], int32_t *inliers, int32_t *ok) {
+  if (!xy0 || !xy1 || n < 0 || !R || !t || !ok || mode < 0 || mode > 1) return VIO_EINVAL;
+  std::vector<double> a(xy0, xy0 + 2 * (size_t)n), b(xy1, xy1 + 2 * (size_t)n);
+  int in = 0;
+  *ok = (mode == 0 ? init::solve_relative_rt_five_point(a, b, R, t, &in) : init::solve_relative_rt(a, b, R, t, &in, R_hint)) ? 1 : 0;
+  if (inliers) *inliers = in;
+  return VIO_OK;
+}
+
+extern "C" int vio_init_five_point(const double *xy0, const double *xy1, double *E, int32_t *n_models) {
+  if (!xy0 || !xy1 || !E || !n_models) return VIO_EINVAL;
+  double q1[5][2], q2[5][2], Em[10][9];
+  for (int i = 0; i < 5; i++) q1[i][0] = xy0[2 * i], q1[i][1] = xy0[2 * i + 1], q2[i][0] = xy1[2 * i], q2[i][1] = xy1[2 * i + 1];
+  *n_models = init::five_point_kernel(q1, q2, Em);
+  memcpy(E, Em, sizeof(double) * 9 * (size_t)*n_models);
+  return VIO_OK;
+}
+
 extern "C" int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok) {
   if (!pts3 || !pts2 || n < 0 || !R || !t || !ok) return VIO_EINVAL;
   std::vector<double> p3(pts3, pts3 + 3 * (size_t)n), p2(pts2, pts2 + 2 * (size_t)n);

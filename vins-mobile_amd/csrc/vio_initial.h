@@ -1,5 +1,6 @@
 // vio_initial.h — internal interface of the initialisation (vio_initial.cpp) shared with the estimator.
 #pragma once
+#include <stdint.h>
 #include <map>
 #include <vector>
 
@@ -39,6 +40,15 @@ struct SfmFeature {  // SFMFeature (inital_sfm.hpp:13-21)
 // equally good solutions (planar scenes).
 bool solve_relative_rt(const std::vector<double> &xy0, const std::vector<double> &xy1, double R[9], double t[3], int *inliers,
                        const double *R_hint = nullptr);
+
+// The same as the reference computes it (vio_fivepoint.cpp): cv::findEssentialMat -- five-point minimal solver inside RANSAC
+// with OpenCV's RNG((uint64)-1) stream, threshold 1.0, confidence 0.999 -- then cv::recoverPose's cheirality count.
+bool solve_relative_rt_five_point(const std::vector<double> &xy0, const std::vector<double> &xy1, double R[9], double t[3],
+                                  int *inliers);
+int five_point_kernel(const double q1[5][2], const double q2[5][2], double E[10][9]);
+bool find_essential_ransac(const double *xy0, const double *xy1, int count, double prob, double threshold, double E[9],
+                           uint8_t *mask_out);
+int recover_pose(const double E[9], const double *xy0, const double *xy1, int n, double R[9], double t[3]);
 
 // GlobalSFM::construct (inital_sfm.cpp:117-316): q [frame_num][4] (x y z w), T [frame_num][3] = camera-to-frame-l poses.
 bool sfm_construct(int frame_num, double *q, double *T, int l, const double relative_R[9], const double relative_T[3],

@@ -102,7 +102,12 @@ int main(int argc, char **argv) {
   vio_measurements_t *mq = nullptr;
   CHECK(vio_frontend_create(&cfg, 1, &fe));
   CHECK(vio_estimator_create(&cfg, 1, tic, ric, &est));
-  if (init.empty()) CHECK(vio_estimator_enable_initialization(est, 1));  // no INIT file: the estimator's own solveInitial
+  // no INIT file: the estimator's own solveInitial; relativePose by the fit over all correspondences (2) unless the
+  // reference's five-point route is asked for (VIO_REPLAY_RELPOSE=reference: a frame that draws a wrong root retries)
+  if (init.empty()) {
+    const char *rp = getenv("VIO_REPLAY_RELPOSE");
+    CHECK(vio_estimator_enable_initialization(est, rp && !strcmp(rp, "reference") ? 1 : 2));
+  }
   CHECK(vio_measurements_create(&mq));
   if (clahe) CHECK(vio_preprocess_create(1, rows, cols, &pp));
 

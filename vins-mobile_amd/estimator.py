@@ -38,7 +38,11 @@ class Estimator:
             self._h = C.c_void_p()
 
     def enable_initialization(self, on=True):
-        self._check(self.lib.vio_estimator_enable_initialization(self._h, int(on)), "enable_initialization")
+        """solveInitial inside process_image. on: False / 0 off; True / 2 / "fit": relativePose by the fit over all
+        correspondences; 1 / "reference": by five-point RANSAC + recoverPose as the reference computes it (a lottery over the
+        roots of one minimal sample, see include/vio_amd.h)."""
+        mode = {False: 0, True: 2, "fit": 2, "reference": 1}.get(on, on)
+        self._check(self.lib.vio_estimator_enable_initialization(self._h, int(mode)), "enable_initialization")
 
     def clear(self, seq=0):
         self._check(self.lib.vio_estimator_clear(self._h, seq), "clear")
