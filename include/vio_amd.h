@@ -791,6 +791,11 @@ int vio_init_relative_pose_mode(const double *xy0, const double *xy1, int32_t n,
  * (row-major, unit Frobenius norm, x2^T E x1 = 0) of five correspondences
  * xy0 / xy1 [5][2]; E [10][9], n_models <= 10.                                          */
 int vio_init_five_point(const double *xy0, const double *xy1, double *E, int32_t *n_models);
+/* cv::recoverPose(E, points1, points2, R, t) with focal 1, pp (0, 0): the (R, t) of the four
+ * decompositions of E (x2 ~ R x1 + t) with the most triangulated points in front of both
+ * cameras and closer than 50; inliers = that count.                                     */
+int vio_init_recover_pose(const double E[9], const double *xy0, const double *xy1, int32_t n, double R[9], double t[3],
+                          int32_t *inliers);
 /* cv::solvePnP(..., useExtrinsicGuess = true) with K = I as inital_sfm.cpp:57 and
  * VINS.cpp:982 call it: refines world->camera R [9], t [3] in place.            */
 int vio_init_pnp(const double *pts3, const double *pts2, int32_t n, double R[9], double t[3], int32_t *ok);

@@ -531,6 +531,7 @@ def load_product():
     lib.vio_init_relative_pose.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _dp, _ip, _ip]
     lib.vio_init_relative_pose_mode.argtypes = [_dp, _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, _ip, _ip]
     lib.vio_init_five_point.argtypes = [_dp, _dp, _dp, _ip]
+    lib.vio_init_recover_pose.argtypes = [_dp, _dp, _dp, C.c_int32, _dp, _dp, _ip]
     lib.vio_init_pnp.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, _ip]
     lib.vio_init_triangulate_point.argtypes = [_dp, _dp, _dp, _dp, _dp]
     lib.vio_init_bundle_adjust.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_int32, _dp, u8p, _ip, _ip, _dp, C.POINTER(VioSolveStats), _ip]

@@ -901,6 +901,13 @@ extern "C" int vio_init_relative_pose_mode(const double *xy0, const double *xy1,
   return VIO_OK;
 }
 
+extern "C" int vio_init_recover_pose(const double E[9], const double *xy0, const double *xy1, int32_t n, double R[9], double t[3],
+                                     int32_t *inliers) {
+  if (!E || !xy0 || !xy1 || n < 0 || !R || !t || !inliers) return VIO_EINVAL;
+  *inliers = init::recover_pose(E, xy0, xy1, n, R, t);
+  return VIO_OK;
+}
+
 extern "C" int vio_init_five_point(const double *xy0, const double *xy1, double *E, int32_t *n_models) {
   if (!xy0 || !xy1 || !E || !n_models) return VIO_EINVAL;
   double q1[5][2], q2[5][2], Em[10][9];
