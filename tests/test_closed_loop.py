@@ -109,7 +109,11 @@ def test_product_chain_of_42_solves_follows_the_reference_chain():
         # the two loops make the same discrete decisions all the way
         assert (nf, nfa, flag, pn, nn) == (g["n_feat"][k], g["n_fact"][k], g["flag"][k], g["prior_n"][k], g["next_n"][k]), k
         assert st["iterations"] == g["iters"][k], k
-        assert abs(st["final_cost"] - g["final_cost"][k]) <= 1e-6 * g["final_cost"][k], k
+        # final_cost = the smallest cost the minimizer recorded, REJECTED candidates included: in the windows that end with
+        # a run of rejected steps at the noise floor (window 8: five in a row) those candidates depend on the rounding of the
+        # step, i.e. on the order of the kernel's atomic sums: 2e-7 relative in most runs, 2e-6 in about one of eight
+        # (tools/dbg_chain.py); the iterates themselves stay within 3e-8 m of the reference's (asserted below)
+        assert abs(st["final_cost"] - g["final_cost"][k]) <= 1e-5 * g["final_cost"][k], k
         worst_p = max(worst_p, np.abs(pose[:, :3] - g["pose"][k][:, :3]).max())
         qa, qb = pose[:, 3:], g["pose"][k][:, 3:]
         worst_q = max(worst_q, np.minimum(np.abs(qa - qb).max(1), np.abs(qa + qb).max(1)).max())
