@@ -2,7 +2,7 @@
 # usage: gpurun -- 'bash tools/profile_round.sh r03_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -x
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -19,19 +19,27 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d $O/sq3 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq3.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM -d $O/sq4 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq4.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_FLAT -d $O/sq5 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq5.log 2>&1
+# L2 hit rate of the window kernel's scratch traffic (requests that hit / miss in the XCD's L2)
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -- $BENCH --only backend --steps 6 --warmup 2 > $O/tcc.log 2>&1
+# the phase path (launch sequence) of the same solve: per-kernel trace, for the gate the round-3 review set
+VIO_AMD_PHASE=1 rocprofv3 --kernel-trace --stats -d $O/kt_phase -- $BENCH --only backend --steps 10 --warmup 2 > $O/bench_kt_phase.log 2>&1
 cd $R
 db() { find $O/$1 -name "*.db" | head -1; }
 python tools/rocpd_summary.py $(db kt) $O/kernel_trace.txt > /dev/null
 python tools/rocpd_pmc_summary.py $(db fetch) $(db write) > $O/pmc_hbm.txt 2>&1
 python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_calib.txt 2>&1
 for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
+python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.txt
+python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
 python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 512 sequences, prior 75" \
   --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
-python tools/time_backend.py 1 256 512 1024 > $O/stage_cycles.txt 2>&1
+python tools/time_backend.py --path=single 1 256 512 1024 > $O/stage_cycles.txt 2>&1
+python tools/time_backend.py --path=phase 1 256 512 1024 2>&1 | grep "path=" >> $O/stage_cycles.txt
+python tools/phase_stages.py phase 512 2>&1 | grep "path=" >> $O/stage_cycles.txt
 VIO_AMD_PROF_TID=64 python tools/time_backend.py 1 2>&1 | grep "stage cycles" | sed "s/^/clock on a panel wave: /" >> $O/stage_cycles.txt
 $R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
 $R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5
+rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase
 ls -la $O

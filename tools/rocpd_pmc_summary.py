@@ -85,7 +85,9 @@ def per_step(agg, kernel_base, counter):
     steps = len(by_base(agg, ONCE_PER_STEP, counter))
     if not vs or not steps:
         return None, 0
-    return sum(vs) / steps, len(vs)
+    # a kernel that does not run in every step (lk_track: the first frame of a run has nothing to track) is averaged over
+    # the steps it ran in, i.e. a steady-state step
+    return sum(vs) / (steps if len(vs) >= steps else len(vs)), len(vs)
 
 
 def main():
@@ -113,7 +115,8 @@ def main():
     out = {"workload": a.workload,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (KB per dispatch, averaged); each counter "
                      "scaled by the factor measured on tools/microbench/pmc_calib (1 GiB streams, > Infinity Cache): 8 B/lane reads "
-                     "for the f64 window kernel, 1 B/lane reads for the front-end, 8 B/lane writes",
+                     "for the f64 window kernel, 1 B/lane reads for the front-end, 8 B/lane writes; front-end kernels per steady-state "
+                     "step (a kernel that skips the first frame is averaged over the steps it ran in)",
            "calibration": calib}
     wk = "vio_window_kernel"
     f, w = avg(bf, wk, "FETCH_SIZE"), avg(bw, wk, "WRITE_SIZE")
