@@ -2623,8 +2623,23 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   record(0, x_cost, radius, 0, 0, gmax, true, true);
   if (cx.tid == 0) sd[0] = x_cost;
   double gd_sq = 0, mu_used = mu, qf_cauchy = 0;
+  // a linearization at x is due at the head of the next iteration: after a step that was accepted on a cost-only evaluation
+  // (relin_reuse: the raw IMU Jacobians and the prior's dx of that evaluation are still valid; rec_*: the iteration record
+  // waits for the gradient norm) or after an invalid step (the matrix buffer holds a factorization)
+  bool relin = false, relin_reuse = false, rec_pending = false;
+  int rec_it = 0;
+  double rec_step_norm = 0, rec_rho = 0;
 
   while (true) {
+    if (relin) {
+      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true, relin_reuse);
+      if (rec_pending) {
+        gmax = grad_max_norm();
+        record(rec_it, x_cost, radius, rec_step_norm, rec_rho, gmax, true, true);
+        stamp(cx, ST_DOGLEG);
+      }
+      relin = relin_reuse = rec_pending = false;
+    }
     if (it >= v.max_iter) break;
     if (last_ok && gmax <= 1e-10) { termination = 1; break; }
     if (radius <= 1e-32) { termination = 1; break; }
@@ -2787,8 +2802,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       n_bad++;
       record(it, x_cost, radius, 0, 0, gmax, false, false);
       recorded = it + 1, min_rec = fmin(min_rec, x_cost);
-      // the matrix buffer holds a factorization: H must be rebuilt before the next build_reduced_system
-      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+      relin = true;  // the matrix buffer holds a factorization: H is rebuilt before the next build_reduced_system
       continue;
     }
     invalid_run = 0;
@@ -2797,14 +2811,19 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     VIO_SYNC();
     apply_plus(cx, v, w, w.t2, w.tf);
     stamp(cx, ST_DOGLEG);
-    // The candidate is linearized SPECULATIVELY -- cost and Jacobians in one evaluation, before the step is accepted. Ceres
-    // evaluates the cost at the candidate and, once the step is accepted, residuals + Jacobians at the same point
-    // (trust_region_minimizer.cc:428-640): two passes over the factors per accepted step, one here; a rejected step wastes the
-    // Jacobian half of one pass. The evaluation works in place, so the iterate and the vectors of its linearization that a
-    // rejected step still needs wait in global scratch (stores only; read back after a rejection).
+    // After an ACCEPTED step the next candidate is linearized SPECULATIVELY -- cost and Jacobians in one evaluation, before
+    // its step is accepted. Ceres evaluates the cost at the candidate and, once the step is accepted, residuals + Jacobians at
+    // the same point (trust_region_minimizer.cc:428-640): two passes over the factors per accepted step, one here. The
+    // evaluation works in place, so the iterate and the vectors of its linearization that a rejected step still needs wait
+    // in global scratch (stores only; read back after a rejection). After a REJECTED step the next candidate takes Ceres'
+    // route -- cost only, linearization once it is accepted --: rejections come in runs (a window at its noise floor), and a
+    // rejected speculative evaluation wastes its Jacobian half, which at W = 30 is three quarters of it.
+    const bool speculate = last_ok;
     double step_norm, dummy;
     state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
     const int npose7 = (v.P + v.has_loop) * 7, o_sb = 7 * (v.P + 1), o_f = o_sb + 9 * v.P, o_v = o_f + F, nv = v.nblk * kBS;
+    // (either way the candidate takes the iterate's place for its evaluation -- one code path, fixed LDS addresses -- and the
+    // iterate waits in the stash)
     VIO_PARFOR(q, npose7) v.stash[q] = w.xpose[q], w.xpose[q] = w.cpose[q];
     VIO_PARFOR(q, v.P * 9) v.stash[o_sb + q] = w.xsb[q], w.xsb[q] = w.csb[q];
     VIO_PARFOR(q, F) {
@@ -2813,23 +2832,30 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     }
     VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
     VIO_SYNC();
-    double cand_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+    double cand_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, /*jac=*/speculate, true, false, /*keep_aux=*/!speculate);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     auto restore_iterate = [&]() {  // x <- the iterate the candidate replaced
       VIO_PARFOR(q, npose7) w.xpose[q] = v.stash[q];
       VIO_PARFOR(q, v.P * 9) w.xsb[q] = v.stash[o_sb + q];
       VIO_PARFOR(q, F) w.xfeat[q] = v.stash[o_f + q];
     };
-    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { restore_iterate(); termination = 1; break; }      // ParameterToleranceReached
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) {                                // ParameterToleranceReached
+      restore_iterate();
+      termination = 1;
+      break;
+    }
     double cost_change = x_cost - cand_cost;
-    if (fabs(cost_change) <= 1e-6 * x_cost) { restore_iterate(); termination = 1; break; }       // FunctionToleranceReached
+    if (fabs(cost_change) <= 1e-6 * x_cost) {                                 // FunctionToleranceReached
+      restore_iterate();
+      termination = 1;
+      break;
+    }
     double rel = (ev_cur - cand_cost) / model_cost_change;                    // StepQuality
     double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
     double rho = fmax(rel, hist);
     if (rho > 1e-3) {
       state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
-      x_cost = cand_cost;  // (x is the candidate; its linearization is in place)
-      gmax = grad_max_norm();
+      x_cost = cand_cost;  // (x is the candidate)
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
       mu = fmax(min_mu, 2.0 * mu / mu_inc);
@@ -2840,9 +2866,15 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       ev_ref = ev_cand, ev_acc_ref = ev_acc_cand;
       last_ok = true;
       n_ok++;
-      record(it, x_cost, radius, step_norm, rho, gmax, true, true);
       recorded = it + 1, min_rec = fmin(min_rec, x_cost);
-      stamp(cx, ST_DOGLEG);
+      if (speculate) {  // the linearization is in place
+        gmax = grad_max_norm();
+        record(it, x_cost, radius, step_norm, rho, gmax, true, true);
+        stamp(cx, ST_DOGLEG);
+      } else {          // it follows at the head of the next iteration, the record with it
+        relin = true, relin_reuse = true, rec_pending = true;
+        rec_it = it, rec_step_norm = step_norm, rec_rho = rho;
+      }
     } else {
       radius *= 0.5;                                                          // StepRejected
       reuse = true;
@@ -2850,11 +2882,14 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       n_bad++;
       record(it, cand_cost, radius, step_norm, rho, 0.0, true, false);
       recorded = it + 1, min_rec = fmin(min_rec, cand_cost);
-      // back to the iterate and to the vectors of ITS linearization: the next dogleg step is formed from them (the matrix
-      // buffer holds the candidate's linearization, which nothing reads: an invalid next step re-evaluates at x)
+      // back to the iterate and, after a speculative evaluation, to the vectors of ITS linearization: the next dogleg step is
+      // formed from them (the matrix buffer then holds the candidate's linearization, which nothing reads: an invalid next
+      // step re-evaluates at x)
       restore_iterate();
-      VIO_PARFOR(q, F) w.gf[q] = v.stash[o_v + 3 * nv + q], w.hff[q] = v.stash[o_v + 3 * nv + F + q], w.gnf[q] = v.stash[o_v + 3 * nv + 2 * F + q];
-      VIO_PARFOR(i, np) w.gp[i] = v.stash[o_v + i], w.dp[i] = v.stash[o_v + nv + i], w.gnp[i] = v.stash[o_v + 2 * nv + i];
+      if (speculate) {
+        VIO_PARFOR(q, F) w.gf[q] = v.stash[o_v + 3 * nv + q], w.hff[q] = v.stash[o_v + 3 * nv + F + q], w.gnf[q] = v.stash[o_v + 3 * nv + 2 * F + q];
+        VIO_PARFOR(i, np) w.gp[i] = v.stash[o_v + i], w.dp[i] = v.stash[o_v + nv + i], w.gnp[i] = v.stash[o_v + 2 * nv + i];
+      }
       VIO_SYNC();
     }
   }
