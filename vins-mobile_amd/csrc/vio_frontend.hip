@@ -161,6 +161,20 @@ struct LkWaveLds {
 };
 typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 
+// Four consecutive pixels from an arbitrary byte address (global memory takes unaligned dword loads on this hardware).
+struct __attribute__((packed)) LkU32 {
+  uint32_t v;
+};
+__device__ __forceinline__ uint32_t lk_load4(const uint8_t *p) { return reinterpret_cast<const LkU32 *>(p)->v; }
+// Pair words (v[x] | v[x+1] << 16) of the four pixels of `cur`; the fifth pixel is byte 0 of `next`.
+__device__ __forceinline__ void lk_pairs(uint32_t cur, uint32_t next, uint32_t w[4]) {
+  // v_perm_b32 selects bytes of {src0 (bytes 4..7), src1 (bytes 0..3)}; selector 0x0c yields 0x00
+  w[0] = __builtin_amdgcn_perm(0u, cur, 0x0c010c00u);
+  w[1] = __builtin_amdgcn_perm(0u, cur, 0x0c020c01u);
+  w[2] = __builtin_amdgcn_perm(0u, cur, 0x0c030c02u);
+  w[3] = __builtin_amdgcn_perm(next, cur, 0x0c040c03u);
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -245,7 +259,26 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
     // stage I on [ipx-1, ipx+23) x [ipy-1, ipy+23) (BORDER_REFLECT_101), then its Scharr derivatives on
     // [ipx, ipx+22) x [ipy, ipy+22): zero outside the image (copyMakeBorder BORDER_CONSTANT of derivI)
     wave_lds_fence();  // previous level's readers are done
-    {  // 32 lanes per row (24 used), two rows per trip: the column index is reflected once per lane; the right-hand
+    if (FPW == 1 && ipx >= 1 && ipx + kIP - 1 <= cols && ipy >= 1 && ipy + kIP - 1 <= rows) {
+      // the patch lies inside the image (all but the features within a window of the border): FOUR pixels per lane and
+      // load, 6 lanes per row, 10 rows per trip -- 3 trips instead of 12 (the kernel is VALU-issue-bound: staging the two
+      // patches byte by byte was a quarter of a level's instructions)
+      const int r = lane / 6, d = lane - 6 * r;
+#pragma unroll 1
+      for (int t = 0; t < (kIP + 9) / 10; t++) {  // (uniform trip count: the DPP below needs every lane)
+        const int ly = r + 10 * t;
+        const bool ok = lane < 60 && ly < kIP;
+        const uint32_t cur = lk_load4(I + (size_t)(ipy - 1 + (ly < kIP ? ly : 0)) * cols + ipx - 1 + 4 * d);
+        uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);  // dword of lane + 1
+        if (d == 5) next = cur >> 24;  // (the pair behind the last pixel repeats it, like the byte path's clamped lane)
+        uint32_t w4[4];
+        lk_pairs(cur, next, w4);
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) L.I[ly][4 * d + k] = w4[k];
+        }
+      }
+    } else {  // 32 lanes per row (24 used), two rows per trip: the column index is reflected once per lane; the right-hand
        // neighbour of every pixel comes from the next lane (DPP wave_shl) so that a pair can be stored as one dword
       const int lx = lane & 31;
       const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
@@ -308,7 +341,24 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
     auto stage_j = [&](int iqx, int iqy) {
       jox = iqx - kJMargin, joy = iqy - kJMargin;
       wave_lds_fence();
-      {  // 32 lanes per row (28 used), two rows per trip; pairs (J[x] | J[x+1] << 16) like the template patch
+      if (FPW == 1 && jox >= 0 && jox + kJP <= cols && joy >= 0 && joy + kJP <= rows) {
+        // inside the image: 4 pixels per lane and load, 7 lanes per row, 9 rows per trip -- 4 trips instead of 14
+        const int r = lane / 7, d = lane - 7 * r;
+#pragma unroll 1
+        for (int t = 0; t < (kJP + 8) / 9; t++) {
+          const int ly = r + 9 * t;
+          const bool ok = lane < 63 && ly < kJP;
+          const uint32_t cur = lk_load4(J + (size_t)(joy + (ly < kJP ? ly : 0)) * cols + jox + 4 * d);
+          uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);
+          if (d == 6) next = cur >> 24;
+          uint32_t w4[4];
+          lk_pairs(cur, next, w4);
+          if (ok) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) L.J[ly][4 * d + k] = w4[k];
+          }
+        }
+      } else {  // 32 lanes per row (28 used), two rows per trip; pairs (J[x] | J[x+1] << 16) like the template patch
         const int lx = lane & 31;
         const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
         for (int ly = lane >> 5; ly < kJP; ly += LPF / 32) {
