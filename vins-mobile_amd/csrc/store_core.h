@@ -1,0 +1,542 @@
+// store_core.h — the landmark store of a sequence on the device: FeatureManager's list (feature_manager.cpp:11-407) as flat
+// arrays in HBM, one workgroup per sequence, and the window assembly of solve_ceres (VINS.cpp:528-567) written straight
+// into the solver's batch arrays (batch.h) instead of being packed on the host and uploaded.
+//
+// Three device passes per published frame and sequence, all of them list work (integer / byte traffic, a few hundred
+// landmarks): nothing here is shaped for the matrix cores.
+//   store_ingest   addFeatureCheckParallax (:103-155) -> keyframe decision, triangulate (:189-248), landmark / factor counts
+//   store_pack     para_Feature + the factor list + the (host, target) buckets of pack_window (batch.h) for window b
+//   store_finish   setDepth (:300-313), failureDetection (VINS.cpp:214-265), removeBackShiftDepth / removeFront
+//                  (:250-257, :343-372), removeFailures (:259-268), compacted into the other bank of the store
+//
+// The host-side list (vio_window.cpp) stays the restatement the estimator uses while a sequence initializes; every
+// function here performs the same floating-point operations in the same order (this file is compiled with
+// -ffp-contract=off like vio_window.cpp), so a sequence gives the same bits on either path. tests/emul runs these
+// functions on the host through the SIMT emulator against vio_features_* on random frame streams.
+#pragma once
+
+#include "solver_core.h"
+#include "vio_amd.h"
+
+namespace vio {
+namespace store {
+
+constexpr double kMinParallax = 10.0 / 549;  // MIN_PARALLAX (feature_manager.hpp:23)
+constexpr double kInitDepth = 5.0;           // INIT_DEPTH (feature_manager.hpp:24)
+constexpr int kMaxP = 32;                    // observation columns a landmark can have (window_size + 1 <= kMaxP)
+constexpr int kThreads = 256;
+
+// control block of a sequence (ints)
+enum {
+  C_N = 0,       // list length
+  C_BANK,        // bank the list lives in
+  C_STATUS,      // VIO_OK or the error that stopped this frame (the host restarts the sequence)
+  C_MARG,        // marginalization flag of this frame
+  C_TRACK,       // last_track_num
+  C_PNUM,        // parallax_num
+  C_F,           // landmarks of the window (para_Feature rows)
+  C_M,           // projection factors
+  C_FAIL,        // failureDetection reasons of this frame's solve
+  C_NPAIRS, C_NSLOTS,
+  C_COUNT = 16
+};
+constexpr int kCtlDoubles = 12;  // last_P[3], last_R[9]
+
+struct Dims {
+  int W, Lcap, Ocap;  // window size; list capacity; observations per frame
+};
+
+// One bank of one sequence.
+struct Bank {
+  int *fid, *start, *nobs, *flag;  // [Lcap] feature_id, start_frame, feature_per_frame.size(), solve_flag
+  double *depth;                   // [Lcap] estimated_depth
+  double *obs;                     // [Lcap][P][3] FeaturePerFrame::point
+};
+
+struct Lds {
+  ldsi ids;    // [Ocap] observation ids, ascending
+  ldsi perm;   // [Ocap] sorted position -> index into the frame's observations
+  ldsi aux;    // [Ocap + 1]
+  ldsi scanA;  // [Lcap + 1]
+  ldsi scanB;  // [Lcap + 1]
+  ldsi part;   // [threads + 1]
+  ldsd term;   // [Lcap]
+  ldsi misc;   // [8]
+};
+VIO_HD size_t lds_bytes(const Dims &d) {
+  return sizeof(int) * (3 * (size_t)d.Ocap + 1 + 2 * ((size_t)d.Lcap + 1) + kThreads + 1 + 8 + 8) + sizeof(double) * (size_t)d.Lcap + 64;
+}
+template <class PI, class PD>
+VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
+  // ints first, then the doubles on an 8-byte boundary
+  Lds l;
+  PI p = ibase;
+  l.ids = p, p += d.Ocap;
+  l.perm = p, p += d.Ocap;
+  l.aux = p, p += d.Ocap + 1;
+  l.scanA = p, p += d.Lcap + 1;
+  l.scanB = p, p += d.Lcap + 1;
+  l.part = p, p += kThreads + 1;
+  l.misc = p, p += 8;
+  size_t ints = (size_t)(p - ibase);
+  ints = (ints + 1) & ~(size_t)1;
+  *dbase_out = (PD)(ibase + ints);
+  l.term = *dbase_out;
+  return l;
+}
+
+struct Cx {
+  int tid, nt;
+};
+
+// out[i] = sum of val(k) for k < i, out[n] = the total (returned). Every work-item calls it.
+template <class F>
+VIO_DEV int block_scan(const Cx &cx, int n, ldsi out, ldsi part, F val) {
+  const int t = VIO_TID(cx);
+  const int per = (n + cx.nt - 1) / cx.nt;
+  const int b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+  int s = 0;
+  for (int i = b; i < e; i++) {
+    const int v = val(i);
+    out[i] = s;
+    s += v;
+  }
+  part[t] = s;
+  VIO_SYNC();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < cx.nt; k++) {
+      const int v = part[k];
+      part[k] = acc;
+      acc += v;
+    }
+    part[cx.nt] = acc;
+  }
+  VIO_SYNC();
+  const int off = part[t];
+  for (int i = b; i < e; i++) out[i] += off;
+  if (t == 0) out[n] = part[cx.nt];
+  VIO_SYNC();
+  return out[n];
+}
+
+VIO_DEV bool solved_in_window(int nobs, int start, int W) { return nobs >= 2 && start < W - 2; }
+
+// Right singular vector of the smallest singular value of A (rows x 4): the one-sided Jacobi of vio_window.cpp, same
+// operations in the same order.
+VIO_DEV void smallest_right_singular_vector(double *A, int rows, double v_out[4]) {
+  double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < rows; i++) {
+          const double ap = A[i * 4 + p], aq = A[i * 4 + q];
+          alpha += ap * ap, beta += aq * aq, gamma += ap * aq;
+        }
+        if (gamma == 0.0) continue;
+        const double ratio = fabs(gamma) / sqrt(alpha * beta + 1e-300);
+        off = off < ratio ? ratio : off;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < rows; i++) {
+          const double ap = A[i * 4 + p], aq = A[i * 4 + q];
+          A[i * 4 + p] = c * ap - s * aq, A[i * 4 + q] = s * ap + c * aq;
+        }
+        for (int i = 0; i < 4; i++) {
+          const double vp = V[i * 4 + p], vq = V[i * 4 + q];
+          V[i * 4 + p] = c * vp - s * vq, V[i * 4 + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  int best = 0;
+  double bn = 1e300;
+  for (int j = 0; j < 4; j++) {
+    double nrm = 0;
+    for (int i = 0; i < rows; i++) nrm += A[i * 4 + j] * A[i * 4 + j];
+    if (nrm < bn) bn = nrm, best = j;
+  }
+  for (int i = 0; i < 4; i++) v_out[i] = V[i * 4 + best];
+}
+
+// ---- pass 1 -----------------------------------------------------------------------------------------------------------
+// obs: this frame's image_msg (any order, unique ids). Ps [P][3], Rs [P][9]: the window states triangulate reads (the host's
+// Ps / Rs after processIMU). The frame index of the new observations is W: a resident sequence has a full window.
+VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, const Lds &l, const VioObs *obs, int n_obs,
+                          const double *Ps, const double *Rs, const double *tic, const double *ric) {
+  const int W = d.W, P = W + 1, fc = W;
+  const int t = VIO_TID(cx);
+  if (t == 0) l.misc[0] = VIO_OK, l.misc[1] = 0, l.misc[2] = 0, l.misc[3] = 0;
+  VIO_SYNC();
+  int n = ctl[C_N];
+  if (n_obs < 0 || n_obs > d.Ocap) {
+    if (t == 0) ctl[C_STATUS] = n_obs < 0 ? VIO_EINVAL : VIO_ECAP;
+    return;
+  }
+  // image_msg is a std::map: ascending ids (a stable rank sort; equal ids are an argument error)
+  VIO_PARFOR(j, n_obs) {
+    const int id = obs[j].id;
+    int r = 0;
+    for (int k = 0; k < n_obs; k++) {
+      const int ik = obs[k].id;
+      r += (ik < id) || (ik == id && k < j);
+    }
+    l.ids[r] = id, l.perm[r] = j, l.aux[r] = 0;
+  }
+  VIO_SYNC();
+  VIO_PARFOR(j, n_obs)
+    if (j > 0 && l.ids[j] == l.ids[j - 1]) l.misc[0] = VIO_EINVAL;
+  VIO_SYNC();
+  if (l.misc[0] != VIO_OK) {
+    if (t == 0) ctl[C_STATUS] = l.misc[0];
+    return;
+  }
+  // known landmarks take their observation
+  VIO_PARFOR(i, n) {
+    const int id = bk.fid[i];
+    int lo = 0, hi = n_obs;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (l.ids[mid] < id) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo < n_obs && l.ids[lo] == id) {
+      const int no = bk.nobs[i];
+      if (bk.start[i] + no > fc) {
+        l.misc[0] = VIO_ESTATE;  // a second message for a frame the landmark already has
+      } else {
+        const VioObs &o = obs[l.perm[lo]];
+        double *pt = bk.obs + ((size_t)i * P + no) * 3;
+        pt[0] = o.x / o.z, pt[1] = o.y / o.z, pt[2] = o.z / o.z;
+        bk.nobs[i] = no + 1;
+        l.aux[lo] = 1;
+      }
+    }
+  }
+  VIO_SYNC();
+  if (l.misc[0] != VIO_OK) {
+    if (t == 0) ctl[C_STATUS] = l.misc[0];
+    return;
+  }
+  // new landmarks, in ascending id
+  const int n_new = block_scan(cx, n_obs, l.scanA, l.part, [&](int j) { return l.aux[j] ? 0 : 1; });
+  const int track = n_obs - n_new;
+  if (n + n_new > d.Lcap) {
+    if (t == 0) ctl[C_STATUS] = VIO_ECAP;
+    return;
+  }
+  VIO_PARFOR(j, n_obs) {
+    if (l.aux[j]) continue;
+    const int i = n + l.scanA[j];
+    const VioObs &o = obs[l.perm[j]];
+    bk.fid[i] = o.id, bk.start[i] = fc, bk.nobs[i] = 1, bk.flag[i] = 0, bk.depth[i] = -1.0;
+    double *pt = bk.obs + (size_t)i * P * 3;
+    pt[0] = o.x / o.z, pt[1] = o.y / o.z, pt[2] = o.z / o.z;
+  }
+  const int n_old = n;
+  n += n_new;
+  VIO_SYNC();
+  // compensatedParallax2 over the landmarks seen in the two frames before this one, summed in list order
+  int enough = 1, pnum = 0;
+  if (!(fc < 2 || track < 20)) {
+    VIO_PARFOR(i, n_old) {
+      const int s = bk.start[i], no = bk.nobs[i];
+      int has = 0;
+      double term = 0;
+      if (s <= fc - 2 && s + no - 1 >= fc - 1) {
+        const double *fi = bk.obs + ((size_t)i * P + (fc - 2 - s)) * 3, *fj = bk.obs + ((size_t)i * P + (fc - 1 - s)) * 3;
+        const double u_j = fj[0], v_j = fj[1];
+        const double dep_i = fi[2];
+        const double u_i = fi[0] / dep_i, v_i = fi[1] / dep_i;
+        const double du = u_i - u_j, dv = v_i - v_j;
+        const double du_comp = u_i - u_j, dv_comp = v_i - v_j;
+        const double a = du * du + dv * dv, b = du_comp * du_comp + dv_comp * dv_comp;
+        const double r = sqrt(b < a ? b : a);
+        term = 0.0 < r ? r : 0.0;
+        has = 1;
+      }
+      l.term[i] = term, l.scanA[i] = has;
+    }
+    VIO_SYNC();
+    if (t == 0) {
+      double sum = 0;
+      int cnt = 0;
+      for (int i = 0; i < n_old; i++)
+        if (l.scanA[i]) sum += l.term[i], cnt++;
+      l.misc[1] = cnt;
+      l.misc[2] = cnt == 0 ? 1 : (sum / cnt >= kMinParallax ? 1 : 0);
+    }
+    VIO_SYNC();
+    pnum = l.misc[1], enough = l.misc[2];
+  }
+  // triangulate: landmarks of the window that have no depth yet
+  VIO_PARFOR(i, n) {
+    const int no = bk.nobs[i], s = bk.start[i];
+    if (!solved_in_window(no, s, W)) continue;
+    if (bk.depth[i] > 0) continue;
+    if (s + no - 1 > W) {
+      l.misc[0] = VIO_ESTATE;
+      continue;
+    }
+    double A[2 * kMaxP * 4];
+    double t0[3], R0[9], tmp[3];
+    mat3vec(Rs + 9 * s, tic, tmp);
+    for (int k = 0; k < 3; k++) t0[k] = Ps[3 * s + k] + tmp[k];
+    mat3mul(Rs + 9 * s, ric, R0);
+    int row = 0;
+    for (int jo = 0; jo < no; jo++) {
+      const int imu_j = s + jo;
+      const double *pt = bk.obs + ((size_t)i * P + jo) * 3;
+      double t1[3], R1[9], R0T[9], dd[3], tt[3], R[9], RT[9], mt[3];
+      mat3vec(Rs + 9 * imu_j, tic, tmp);
+      for (int k = 0; k < 3; k++) t1[k] = Ps[3 * imu_j + k] + tmp[k];
+      mat3mul(Rs + 9 * imu_j, ric, R1);
+      mat3T(R0, R0T);
+      for (int k = 0; k < 3; k++) dd[k] = t1[k] - t0[k];
+      mat3vec(R0T, dd, tt);
+      mat3mul(R0T, R1, R);
+      mat3T(R, RT);
+      mat3vec(RT, tt, mt);
+      double Pm[12];  // [R^T | -R^T t]
+      for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) Pm[a * 4 + b] = RT[a * 3 + b];
+        Pm[a * 4 + 3] = -mt[a];
+      }
+      const double nrm = sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+      const double fx = pt[0] / nrm, fy = pt[1] / nrm, fz = pt[2] / nrm;
+      for (int b = 0; b < 4; b++) A[row * 4 + b] = fx * Pm[2 * 4 + b] - fz * Pm[0 * 4 + b];
+      row++;
+      for (int b = 0; b < 4; b++) A[row * 4 + b] = fy * Pm[2 * 4 + b] - fz * Pm[1 * 4 + b];
+      row++;
+    }
+    double v[4];
+    smallest_right_singular_vector(A, row, v);
+    double dep = v[2] / v[3];
+    if (dep < 0.1) dep = kInitDepth;
+    bk.depth[i] = dep;
+  }
+  VIO_SYNC();
+  // para_Feature rows and factors of this window
+  const int F = block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
+  const int M = block_scan(cx, n, l.scanB, l.part,
+                           [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? bk.nobs[i] - 1 : 0; });
+  if (t == 0) {
+    ctl[C_N] = n, ctl[C_STATUS] = l.misc[0];
+    ctl[C_MARG] = enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW;
+    ctl[C_TRACK] = track, ctl[C_PNUM] = pnum, ctl[C_F] = F, ctl[C_M] = M;
+  }
+}
+
+// ---- pass 2 -----------------------------------------------------------------------------------------------------------
+// What build_window + pack_window leave in the batch arrays for the landmark side of window b: para_Feature, the factor
+// list (grouped by landmark, host = start frame, one factor per later observation), fstart, and the (host, target) buckets
+// with their even-padded, chunk-aligned staging slots. keys: [Mcap] unsigned short scratch in LDS.
+struct PackOut {
+  int *hdr;  // [kHdrInts] of window b: H_F, H_M, H_MARG, H_NPAIRS, H_NSLOTS, H_NREV, H_HAS_LOOP, H_LOOP_FRAME are written here
+  double *feat;
+  int *fhost, *ftarget, *ffeat, *fslot, *fstart, *pair_h, *pair_t, *pair_s0, *pair_s1;
+  double *pts_i, *pts_j;
+  int Fcap, Mcap, pair_cap;
+  size_t slot_cap;
+};
+enum { PH_F = 1, PH_M = 2, PH_HAS_LOOP = 3, PH_LOOP_FRAME = 4, PH_MARG = 5, PH_NPAIRS = 9, PH_NSLOTS = 10, PH_NREV = 11 };  // = batch.h H_*
+
+VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, const Lds &l, const PackOut &o, int chunk,
+                        VIO_AS3 unsigned short *keys, ldsi bins /* [2 (P+1)^2] */) {
+  const int W = d.W, P = W + 1, np1 = P + 1;
+  const int t = VIO_TID(cx);
+  const int n = ctl[C_N];
+  if (ctl[C_STATUS] != VIO_OK) return;
+  const int F = block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
+  const int M = block_scan(cx, n, l.scanB, l.part,
+                           [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? bk.nobs[i] - 1 : 0; });
+  if (F > o.Fcap || M > o.Mcap) {
+    if (t == 0) ctl[C_STATUS] = VIO_ECAP;
+    return;
+  }
+  VIO_PARFOR(k, 2 * np1 * np1) bins[k] = 0;
+  VIO_SYNC();
+  ldsi cnt = bins, start = bins + np1 * np1;
+  VIO_PARFOR(i, n) {
+    const int no = bk.nobs[i], s = bk.start[i];
+    if (!solved_in_window(no, s, W)) continue;
+    const int fi = l.scanA[i], k0 = l.scanB[i];
+    o.feat[fi] = 1. / bk.depth[i];
+    o.fstart[fi] = k0;
+    const double *p0 = bk.obs + (size_t)i * P * 3;
+    for (int j = 1; j < no; j++) {
+      const int k = k0 + j - 1;
+      o.fhost[k] = s, o.ftarget[k] = s + j, o.ffeat[k] = fi;
+      const double *pj = p0 + 3 * j;
+      for (int c = 0; c < 3; c++) o.pts_i[3 * k + c] = p0[c], o.pts_j[3 * k + c] = pj[c];
+      keys[k] = (unsigned short)(s * np1 + s + j);
+      __hip_atomic_fetch_add(&cnt[s * np1 + s + j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  if (t == 0) o.fstart[F] = M;
+  VIO_SYNC();
+  // buckets in (host, target) order; every bucket starts on an even slot and does not straddle a staging chunk
+  if (t == 0) {
+    int npairs = 0, slot = 0, rc = VIO_OK;
+    for (int key = 0; key < np1 * np1 && rc == VIO_OK; key++) {
+      const int c = cnt[key];
+      if (!c) continue;
+      if (npairs >= o.pair_cap) {
+        rc = VIO_ECAP;
+        break;
+      }
+      const int cpad = (c + 1) & ~1;
+      if (chunk > 0 && cpad <= chunk && slot % chunk + cpad > chunk) slot = (slot / chunk + 1) * chunk;
+      if ((size_t)slot + cpad > o.slot_cap) {
+        rc = VIO_ECAP;
+        break;
+      }
+      start[key] = slot;
+      o.pair_h[npairs] = key / np1, o.pair_t[npairs] = key % np1;
+      o.pair_s0[npairs] = slot, o.pair_s1[npairs] = slot + c;
+      l.scanB[npairs] = key;  // (the landmark scans are done with; pair_cap <= Lcap is the caller's check)
+      slot += cpad;
+      npairs++;
+    }
+    l.misc[4] = npairs, l.misc[5] = slot, l.misc[6] = rc;
+  }
+  VIO_SYNC();
+  const int npairs = l.misc[4];
+  if (l.misc[6] != VIO_OK) {
+    if (t == 0) ctl[C_STATUS] = l.misc[6];
+    return;
+  }
+  // slot of every factor: its bucket's start + its rank inside the bucket in factor order (one work-item per bucket)
+  VIO_PARFOR(pi, npairs) {
+    const int key = l.scanB[pi];
+    int s = start[key];
+    for (int k = 0; k < M; k++)
+      if (keys[k] == key) o.fslot[k] = s++;
+  }
+  if (t == 0) {
+    o.hdr[PH_F] = F, o.hdr[PH_M] = M, o.hdr[PH_HAS_LOOP] = 0, o.hdr[PH_LOOP_FRAME] = -1, o.hdr[PH_MARG] = ctl[C_MARG];
+    o.hdr[PH_NPAIRS] = npairs, o.hdr[PH_NSLOTS] = l.misc[5], o.hdr[PH_NREV] = 0;
+    ctl[C_NPAIRS] = npairs, ctl[C_NSLOTS] = l.misc[5];
+  }
+}
+
+// ---- pass 3 -----------------------------------------------------------------------------------------------------------
+// failureDetection (VINS.cpp:214-265) on the newest frame of the solved window.
+VIO_DEV int failure_reasons(int last_track_num, const double Bg[3], const double Pn[3], const double Rn[9], const double last_P[3],
+                            const double last_R[9]) {
+  int r = 0;
+  if (last_track_num < 4) r |= VIO_FAIL_FEW_FEATURES;
+  if (sqrt(Bg[0] * Bg[0] + Bg[1] * Bg[1] + Bg[2] * Bg[2]) > 1) r |= VIO_FAIL_GYR_BIAS;
+  const double dd[3] = {Pn[0] - last_P[0], Pn[1] - last_P[1], Pn[2] - last_P[2]};
+  if (sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) > 1) r |= VIO_FAIL_TRANSLATION;
+  if (fabs(Pn[2] - last_P[2]) > 0.5) r |= VIO_FAIL_Z_TRANSLATION;
+  double RT[9], dR[9];
+  mat3T(Rn, RT);
+  mat3mul(RT, last_R, dR);
+  const Quat dq = RtoQ(dR);
+  const double delta_angle = acos(dq.w) * 2.0 / 3.14 * 180.0;
+  if (delta_angle > 40) r |= VIO_FAIL_ROTATION;
+  return r;
+}
+
+// x: the solved para_Feature (after new2old), pose [P][7] / sb [P][9]: the solved window. The list moves from bank `bk`
+// to bank `nb`, with the slide of the frame's marginalization flag applied. ctld: last_P, last_R of the sequence.
+VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Bank &nb, int *ctl, double *ctld, const Lds &l,
+                          const double *x, const double *pose, const double *sb, const double *tic, const double *ric) {
+  const int W = d.W, P = W + 1;
+  const int t = VIO_TID(cx);
+  const int n = ctl[C_N];
+  if (ctl[C_STATUS] != VIO_OK) return;
+  const int marg = ctl[C_MARG];
+  block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
+  if (t == 0) {
+    double Rn[9];
+    qtoR(qfrom_pose(pose + 7 * W), Rn);
+    const int r = failure_reasons(ctl[C_TRACK], sb + 9 * W + 6, pose + 7 * W, Rn, ctld, ctld + 3);
+    l.misc[0] = r;
+    ctl[C_FAIL] = r;
+    if (r) {
+      ctl[C_N] = 0;  // clearState: the host restarts the sequence
+    } else {
+      for (int k = 0; k < 3; k++) ctld[k] = pose[7 * W + k];
+      for (int k = 0; k < 9; k++) ctld[3 + k] = Rn[k];
+    }
+  }
+  VIO_SYNC();
+  if (l.misc[0]) return;
+  double mR[9], mP[3], nR[9], nP[3];
+  if (marg == VIO_MARGIN_OLD) {
+    double R0[9], R1[9], tt[3];
+    qtoR(qfrom_pose(pose), R0), qtoR(qfrom_pose(pose + 7), R1);
+    mat3mul(R0, ric, mR), mat3mul(R1, ric, nR);
+    mat3vec(R0, tic, tt);
+    for (int k = 0; k < 3; k++) mP[k] = pose[k] + tt[k];
+    mat3vec(R1, tic, tt);
+    for (int k = 0; k < 3; k++) nP[k] = pose[7 + k] + tt[k];
+  }
+  // new state of every landmark; scanB = it survives
+  VIO_PARFOR(i, n) {
+    int s = bk.start[i], no = bk.nobs[i], fl = bk.flag[i];
+    double dep = bk.depth[i];
+    if (solved_in_window(no, s, W)) {  // setDepth
+      dep = 1.0 / x[l.scanA[i]];
+      fl = dep < 0 ? 2 : 1;
+    }
+    int alive = 1, drop = -1;  // drop: the observation column that leaves
+    if (marg == VIO_MARGIN_OLD) {
+      if (s != 0) {
+        s--;
+      } else {
+        const double *uv = bk.obs + (size_t)i * P * 3;
+        drop = 0;
+        if (no - 1 < 2) {
+          alive = 0;
+        } else {
+          double pts_i[3], w[3], nRT[9], dd[3], pts_j[3];
+          for (int k = 0; k < 3; k++) pts_i[k] = uv[k] * dep;
+          mat3vec(mR, pts_i, w);
+          for (int k = 0; k < 3; k++) dd[k] = w[k] + mP[k] - nP[k];
+          mat3T(nR, nRT);
+          mat3vec(nRT, dd, pts_j);
+          dep = pts_j[2] > 0 ? pts_j[2] : kInitDepth;
+        }
+      }
+    } else {
+      if (s == W) {
+        s--;
+      } else if (s + no - 1 >= W - 1) {
+        drop = W - 1 - s;
+        if (no - 1 == 0) alive = 0;
+      }
+    }
+    if (fl == 2) alive = 0;  // removeFailures
+    l.term[i] = dep;
+    l.scanB[i] = alive;
+    // start / count / flag / dropped column of the survivor, packed: start (8 bits) | nobs (8) | flag (2) | drop + 1 (8)
+    bk.flag[i] = (s & 0xff) | ((drop >= 0 ? no - 1 : no) & 0xff) << 8 | (fl & 3) << 16 | ((drop + 1) & 0xff) << 18;
+  }
+  VIO_SYNC();
+  // (scanA is read above through x[...]: the survivors' positions go to a scan of their own)
+  const int n_alive = block_scan(cx, n, l.scanA, l.part, [&](int i) { return l.scanB[i]; });
+  VIO_PARFOR(i, n) {
+    if (!l.scanB[i]) continue;
+    const int j = l.scanA[i];
+    const int pk = bk.flag[i];
+    const int s = pk & 0xff, no = (pk >> 8) & 0xff, fl = (pk >> 16) & 3, drop = ((pk >> 18) & 0xff) - 1;
+    nb.fid[j] = bk.fid[i], nb.start[j] = s, nb.nobs[j] = no, nb.flag[j] = fl, nb.depth[j] = l.term[i];
+    const double *src = bk.obs + (size_t)i * P * 3;
+    double *dst = nb.obs + (size_t)j * P * 3;
+    for (int c = 0, cc = 0; cc < no; c++) {
+      if (c == drop) continue;
+      dst[3 * cc] = src[3 * c], dst[3 * cc + 1] = src[3 * c + 1], dst[3 * cc + 2] = src[3 * c + 2];
+      cc++;
+    }
+  }
+  if (t == 0) ctl[C_N] = n_alive, ctl[C_BANK] ^= 1;
+}
+
+}  // namespace store
+}  // namespace vio
