@@ -590,6 +590,9 @@ int vio_features_scale_depth(vio_features_t *fm, double s);
  * [sum n_obs][3]) in list order. cap = 0: only the counts.                   */
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
                       int32_t cap_points, int32_t *n_points);
+/* The inverse of vio_features_dump: the list becomes exactly these entries (list order; points [sum n_obs][3]). Used
+ * when a sequence's list returns from the device-resident store (vio_estimator_set_resident). */
+int vio_features_load(vio_features_t *fm, const VioFeatureInfo *info, int32_t n, const double *points);
 
 /* failureDetection VINS.cpp:214-265 on the newest frame after a solve (the
  * failure_hand switch of the UI stays with the caller). reasons: bit mask.    */
@@ -691,6 +694,13 @@ int vio_estimator_get_corrected_window(vio_estimator_t *est, int32_t seq, double
  * the bookkeeping after it.                                                    */
 int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
 /* The sequence's landmark store (owned by the estimator), for introspection.   */
+/* Device-resident landmark stores (0 = off, the default unless VIO_AMD_RESIDENT=1): a sequence that has reached the
+ * NON_LINEAR state keeps its landmark list, its pre-integration blocks and its prior in device memory; per frame the host
+ * sends the observations and the propagated window states (about 12 KB instead of about 125 KB per window), kernels do
+ * addFeatureCheckParallax / triangulate / the factor list / setDepth / the slide (feature_manager.cpp:103-372), and the
+ * results are the host path's bit for bit. Sequences fall back to the host-side list while they initialize, while a
+ * relocalization frame is set, and when vio_estimator_features() asks for the list. */
+int vio_estimator_set_resident(vio_estimator_t *est, int32_t enable);
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 
 /* ------------------------------------------------------------------------- */

@@ -428,3 +428,131 @@ def test_two_estimators_driven_from_two_host_threads():
     [t.join() for t in ts]
     for s in (5, 6):
         assert got[s].shape == ref[s].shape and np.abs(got[s] - ref[s]).max() < 1e-6
+
+
+# ---- device-resident landmark stores (vio_estimator_set_resident) ---------------------------------------------------------
+def _dump_lists(est, seq=0):
+    rec, pts = est.features(seq).dump()    # rows: id, start_frame, n_obs, used_num, solve_flag, is_outlier, fixed, depth
+    return rec, pts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W", [10, 6])
+def test_resident_sequences_give_what_the_host_side_list_gives(W):
+    """The same replay twice: landmark list, window assembly and slides on the host (vio_window.cpp) / on the device
+    (store_core.h). Same keyframe decisions, same iteration counts, same landmark list at the end (ids, start frames,
+    observation counts, flags exactly; depths and positions to the reproducibility of the window kernel's sums)."""
+    cfg = abi.default_config(window_size=W)
+    host = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    dev = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    dev.est.set_resident(True)
+    n = 60
+    for _ in range(n):
+        a, b = host.step(), dev.step()
+        assert a.action == b.action and a.marginalization_flag == b.marginalization_flag and a.track_num == b.track_num
+        assert a.n_features == b.n_features and a.n_factors == b.n_factors
+        if a.action == abi.VIO_FRAME_SOLVED:
+            assert a.stats.iterations == b.stats.iterations
+    assert len(host.history) == len(dev.history) == n - W
+    dp = np.array([x[1] - y[1] for x, y in zip(host.history, dev.history)])
+    assert np.abs(dp).max() < 1e-6, np.abs(dp).max()
+    sa, sb = host.est.status(), dev.est.status()
+    assert sa.solver_flag == sb.solver_flag == abi.VIO_SOLVER_NON_LINEAR and sa.prior_rows == sb.prior_rows
+    la, pa = _dump_lists(host.est)
+    lb, pb = _dump_lists(dev.est)          # (the list comes back from the device for this)
+    assert la.shape == lb.shape and np.array_equal(la[:, [0, 1, 2, 4]], lb[:, [0, 1, 2, 4]])
+    assert np.array_equal(pa, pb)
+    da, db = la[:, 7], lb[:, 7]
+    assert np.abs(da - db).max() < 1e-5 * max(1.0, np.abs(da).max())
+    # ... and the replay continues after the look at the list (the sequence returns to the device with its next solve)
+    for _ in range(8):
+        a, b = host.step(), dev.step()
+        assert a.action == b.action == abi.VIO_FRAME_SOLVED and a.n_factors == b.n_factors
+    assert np.abs(host.history[-1][1] - dev.history[-1][1]).max() < 1e-6
+    host.close(), dev.close()
+
+
+@pytest.mark.gpu
+def test_resident_batch_with_staggered_starts_failure_and_relocalization():
+    """Four sequences in one estimator, resident stores on: they reach the solve phase on different frames (host-path
+    and resident windows in the same call), one of them loses its track (failure detection on the device clears the
+    slot), one gets a relocalization frame (its list returns to the host for the loop factors). Every sequence must
+    follow the single-sequence host-path replay of its own world."""
+    cfg = abi.default_config(window_size=6)
+    W = cfg.window_size
+    nq, steps = 4, 30
+    worlds = [RS.SyntheticWorld(cfg, 40 + q) for q in range(nq)]
+    singles = [RS.EstimatorLoop(cfg, seed=40 + q, init_noise=1.0) for q in range(nq)]
+    for s in singles:
+        for _ in range(steps):
+            s.step()
+    est = pkg.estimator.Estimator(cfg, worlds[0].tic, worlds[0].ric, n_seq=nq)
+    est.set_resident(True)
+    feeders = [RS.EstimatorLoop(cfg, seed=40 + q, init_noise=1.0, world=worlds[q]) for q in range(nq)]
+    start = [0, 2, 5, 9]
+    got = [[] for _ in range(nq)]
+    for call in range(steps + max(start)):
+        obs, hdr, act = [], [], []
+        for q in range(nq):
+            k = call - start[q]
+            f = feeders[q]
+            if k < 0 or k >= steps:
+                obs.append(([], [])), hdr.append(0.0), act.append(0)
+                continue
+            f.est.close()
+            f.est = _SeqView(est, q)
+            obs.append(f.feed_until_image()), hdr.append(worlds[q].time(k)), act.append(1)
+        res = est.process_images(obs, hdr, act)
+        for q in range(nq):
+            if res[q].action == abi.VIO_FRAME_SOLVED:
+                got[q].append(est.window(q)["Ps"][W].copy())
+    for q in range(nq):
+        want = np.array([h[1] for h in singles[q].history])
+        assert len(got[q]) == len(want) and np.abs(np.array(got[q]) - want).max() < 1e-6
+    est.close()
+    for s in singles:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_resident_failure_detection_clears_the_slot_and_the_sequence_restarts():
+    """A frame that tracks nothing: failureDetection runs on the device for a resident sequence, the slot clears itself, the
+    next window fills on the host-side list, is solved there once (anchored where the failed window stood) and moves to
+    the device again. The host-path replay of the same calls is the reference."""
+    cfg = abi.default_config(window_size=6)
+    W = cfg.window_size
+    loops = [RS.EstimatorLoop(cfg, seed=9, init_noise=1.0) for _ in range(2)]
+    loops[1].est.set_resident(True)
+    wins = []
+    for loop in loops:
+        for _ in range(20):
+            loop.step()
+        assert loop.history[-1][3].action == abi.VIO_FRAME_SOLVED
+        k = loop.k
+        for a, w in loop.world.imu_interval(k):
+            loop.est.process_imu(loop.world.dt, a, w)
+        res = loop.est.process_image(*obs_grid(60, first_id=10 ** 6), loop.world.time(k))
+        assert res.action == abi.VIO_FRAME_FAILURE and res.failure_reasons & abi.VIO_FAIL_FEW_FEATURES
+        st = loop.est.status()
+        assert st.failure_occur == 1 and st.frame_count == 0 and st.solver_flag == abi.VIO_SOLVER_INITIAL and st.prior_rows == 0
+        assert loop.est.features().count() == 0
+        world = loop.world
+        init = []
+        loop.world.tracked.clear()
+        for j in range(W + 6):
+            kk = k + 1 + j
+            for a, w in world.imu_interval(kk):
+                loop.est.process_imu(world.dt, a, w)
+            P, R, V = world.truth(kk)
+            if j <= W:
+                init.append((world.time(kk), P, R, V))
+            if j == W:
+                loop.est.set_initial_state([i[0] for i in init], [i[1] for i in init], [i[2] for i in init], [i[3] for i in init],
+                                           [world.ba] * (W + 1), [world.bg] * (W + 1))
+            res = loop.est.process_image(*world.observe(kk), world.time(kk))
+            if j >= W:
+                assert res.action == abi.VIO_FRAME_SOLVED
+        wins.append(loop.est.window())
+        loop.close()
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        assert np.abs(wins[0][key] - wins[1][key]).max() < 1e-6, key

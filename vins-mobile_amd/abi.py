@@ -543,6 +543,7 @@ def load_product():
     lib.vio_estimator_destroy.restype = None
     lib.vio_estimator_clear.argtypes = [vp, C.c_int32]
     lib.vio_estimator_enable_initialization.argtypes = [vp, C.c_int32]
+    lib.vio_estimator_set_resident.argtypes = [vp, C.c_int32]
     lib.vio_features_scale_depth.argtypes = [vp, C.c_double]
     lib.vio_estimator_process_imu.argtypes = [vp, C.c_int32, C.c_double, _dp, _dp]
     lib.vio_estimator_process_imu_batch.argtypes = [vp, _ip, C.c_int32, _dp, _dp, _dp]

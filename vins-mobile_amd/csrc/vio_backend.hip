@@ -130,8 +130,12 @@ static bool host_timing() {
   return on;
 }
 
+struct vio_resident;
+static void resident_destroy(vio_resident *r);
+
 struct vio_backend {
   VioConfig cfg;
+  vio_resident *res = nullptr;  // device-resident path (vio_resident.h), null until reserved
   int device = -1;  // HIP device the context lives on (current device at create)
   int max_batch = 0;
   hipStream_t stream = nullptr;
@@ -268,6 +272,7 @@ void vio_backend_destroy(vio_backend_t *be) {
   be->d_prof.release(), be->d_phase.release();
   for (int k = 0; k < 2; k++) be->d_st_x0[k].release(), be->d_st_J[k].release(), be->d_st_r[k].release();
   be->d_ptab.release();
+  resident_destroy(be->res);
   (void)hipStreamDestroy(be->stream);
   delete be;
 }
@@ -287,6 +292,150 @@ int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
   }
   be->st_n = n_slots, be->st_ncap = ncap;
   be->st_bank.assign(n_slots, 0);
+  return VIO_OK;
+}
+
+// LDS layout and launch split of a batch whose dims are d: which windows run the LDS variant (be->n_lds, be->d_lds,
+// be->lds_bytes), which the global-matrix one (be->n_glb, be->d_glb), in which order (`order`: launch-local block ->
+// window), and whether the phase path applies. nfeat[b]: landmarks of window b; Fmax: their maximum.
+static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, int Fmax, std::vector<int> &order,
+                       const std::vector<int> *active = nullptr) {  // active: the windows that take part (null: all n)
+  d.Flds = std::max(Fmax, 1);
+  // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
+  // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
+  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
+  // variant in one launch -- with half a CU's LDS per workgroup whenever that is enough, so that two windows share a
+  // CU --, everything else the global-matrix variant in a second one. (Decided before packing: the staging chunk the
+  // buckets are aligned to depends on the layout.)
+  static const int threads_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
+  be->threads_lds = threads_lds;
+  auto need_lds = [&](BatchDims dd, int asp) {
+    dd.lds_asp = asp;
+    size_t se = 0;
+    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
+    // the marginalization phase additionally wants >= 64 staging slots behind its matrix
+    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
+  };
+  // (eligibility: the lean layout, IMU coupling in global memory, inside one CU; the 512-thread build of the LDS variant
+  // -- an experiment switch -- only exists with the coupling in LDS)
+  const int lean_asp = threads_lds == kThreadsLds ? 0 : 1;
+  auto fits_lds = [&](const BatchDims &dd) { return pose_jp(dd) <= 16 * kPanelTiles && need_lds(dd, lean_asp) <= kLdsLimit; };
+  std::vector<int> cand;
+  order.clear();
+  if (active) cand = *active;
+  else
+    for (int b = 0; b < n; b++) cand.push_back(b);
+  const std::vector<int> all = cand;
+  std::stable_sort(cand.begin(), cand.end(), [&](int a, int b2) { return nfeat[a] < nfeat[b2]; });
+  BatchDims dl = d;
+  int n_lds = (int)cand.size();
+  while (n_lds > 0) {
+    dl.Flds = std::max(1, nfeat[cand[n_lds - 1]]);
+    if (fits_lds(dl)) break;
+    n_lds--;
+  }
+  std::vector<char> in_lds(n, 0);
+  for (int i = 0; i < n_lds; i++) in_lds[cand[i]] = 1, order.push_back(cand[i]);
+  for (int b : all)
+    if (!in_lds[b]) order.push_back(b);
+  be->n_lds = n_lds, be->n_glb = (int)all.size() - n_lds, be->lds_matrix = be->n_glb == 0;
+  // Two workgroups per CU (half its LDS each) beat everything else; inside that, the IMU speed-bias x pose coupling is
+  // better off in LDS. Windows with many landmarks give its 14 KB up (global scratch, L2-resident) to stay two per CU.
+  // The marginalization phase stages Jacobian rows in whatever LDS is left behind its matrix.
+  static const bool one_per_cu = getenv("VIO_AMD_WINDOW_ONE_PER_CU") && getenv("VIO_AMD_WINDOW_ONE_PER_CU")[0] == '1';
+  static const int force_asp = getenv("VIO_AMD_LDS_ASP") ? atoi(getenv("VIO_AMD_LDS_ASP")) : -1;
+  be->lds_bytes = kLdsLimit;
+  if (n_lds > 0) {
+    const size_t fat = need_lds(dl, 1), lean = need_lds(dl, lean_asp);
+    // (the lean layout costs a window ~10 % of its latency -- a few more round trips to L2 per Gauss-Newton step --: it only
+    // pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with closed-loop
+    // windows of ~190 landmarks: 2 x 128 windows are faster with the fat layout on whole CUs, 2 x 256 windows take 7.3
+    // instead of 9.4 ms per frame with the lean one.)
+    const bool crowded = n_lds > be->n_cus / 2;
+    if (!one_per_cu && fat <= kLdsHalf) dl.lds_asp = 1, be->lds_bytes = kLdsHalf;
+    else if (!one_per_cu && crowded && lean <= kLdsHalf) dl.lds_asp = lean_asp, be->lds_bytes = kLdsHalf;
+    else dl.lds_asp = fat <= kLdsLimit ? 1 : lean_asp;
+    if ((force_asp == 0 && lean_asp == 0) || (force_asp == 1 && fat <= kLdsLimit)) {
+      dl.lds_asp = force_asp;
+      be->lds_bytes = (!one_per_cu && need_lds(dl, force_asp) <= kLdsHalf) ? kLdsHalf : kLdsLimit;
+    }
+  }
+  be->d_lds = dl;
+  // Phase path: the windows of the LDS set are solved by a sequence of launches (phase_core.h) instead of one.
+  static const int phase_env = getenv("VIO_AMD_PHASE") ? atoi(getenv("VIO_AMD_PHASE")) : -1;
+  const bool want_phase = be->path == VIO_PATH_PHASE || (be->path == VIO_PATH_AUTO && phase_env == 1);
+  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds;
+  if (be->use_phase) {
+    vio::phase_lds_need(dl, &be->lds_setup, &be->lds_lin);
+    if (be->lds_setup > kLdsLimit || be->lds_lin > kLdsLimit) be->use_phase = false;
+  }
+  if (be->n_glb > 0) {
+    BatchDims dg = d;
+    int fg = 1;
+    for (size_t i = n_lds; i < order.size(); i++) fg = std::max(fg, nfeat[order[i]]);
+    dg.Flds = fg;
+    size_t se = 0;
+    const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
+    const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
+    if (std::max(bs, bm) > kLdsLimit) return VIO_ECAP;
+    be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bm);
+  }
+  return VIO_OK;
+}
+
+// Work and output buffers of a batch of N windows with dims d (sticky: they only grow).
+static int ensure_work_buffers(vio_backend *be, const BatchDims &d, const BatchStrides &s, size_t N) {
+  const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
+#define ENSURE(buf, count)                 \
+  do {                                     \
+    int rc_ = (buf).ensure(count);         \
+    if (rc_ != VIO_OK) return rc_;         \
+  } while (0)
+  ENSURE(be->d_scratch, N * s.scratch);
+  ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);  // (indexed by window: sized for the whole batch when any window needs it)
+  ENSURE(be->d_out_pose, N * s.out_pose);
+  ENSURE(be->d_out_sb, N * s.out_sb);
+  ENSURE(be->d_out_feat, N * s.out_feat);
+  ENSURE(be->d_raw_pose, N * s.out_pose);
+  ENSURE(be->d_raw_sb, N * s.out_sb);
+  ENSURE(be->d_raw_feat, N * s.out_feat);
+  ENSURE(be->d_out_loop, N * s.out_loop);
+  ENSURE(be->d_stats_d, N * s.stats_d);
+  ENSURE(be->d_stats_i, N * s.stats_i);
+  ENSURE(be->d_m_ints, N * m_ints);
+  ENSURE(be->d_m_x0, N * 9 * kMaxPriorBlocks);
+  ENSURE(be->d_m_J, N * (size_t)d.Ncap * d.Ncap);
+  ENSURE(be->d_m_r, N * (size_t)d.Ncap);
+  ENSURE(be->d_m_scratch, m_scr ? N * m_scr : 1);
+  if (be->use_phase) ENSURE(be->d_phase, N * make_phase_layout(d).total);
+#undef ENSURE
+  return VIO_OK;
+}
+
+// The work / output side of be->B and be->MP (the input arrays and B.ptab are bound by the caller).
+static int bind_work_buffers(vio_backend *be, const BatchDims &d, const BatchStrides &s, size_t N, const PhaseLayout &PL) {
+  (void)s;
+  const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
+  BatchPtrs &B = be->B;
+  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
+  B.phase = be->use_phase ? be->d_phase.p : nullptr, B.PL = PL;
+  B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
+  B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
+  B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
+  MargPtrs &MP = be->MP;
+  MP.ints = be->d_m_ints.p, MP.x0 = be->d_m_x0.p, MP.J = be->d_m_J.p, MP.r = be->d_m_r.p;
+  MP.scratch = m_scr ? be->d_m_scratch.p : nullptr;
+  MP.s_ints = m_ints, MP.s_x0 = 9 * kMaxPriorBlocks, MP.s_J = (size_t)d.Ncap * d.Ncap, MP.s_r = d.Ncap;
+  MP.s_scratch = m_scr;
+  MP.prof = nullptr;
+  MP.prof_tid = getenv("VIO_AMD_PROF_TID") ? atoi(getenv("VIO_AMD_PROF_TID")) : 0;
+  MP.wrot = getenv("VIO_AMD_WAVE_ROT") ? atoi(getenv("VIO_AMD_WAVE_ROT")) : -1;
+  if (be->profile) {
+    int rcp = be->d_prof.ensure(N * ST_COUNT);
+    if (rcp != VIO_OK) return rcp;
+    MP.prof = be->d_prof.p;
+  }
   return VIO_OK;
 }
 
@@ -359,72 +508,16 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     d = make_dims(be->cfg, Wmax, std::max(Fr, Fmax), std::max(Mr, Mmax), any_loop);
     d.Ncap = std::max(6 * Wmax + 15, Nmax);
   }
-  d.Flds = std::max(Fmax, 1);
-  // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
-  // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
-  // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
-  // variant in one launch -- with half a CU's LDS per workgroup whenever that is enough, so that two windows share a
-  // CU --, everything else the global-matrix variant in a second one. (Decided before packing: the staging chunk the
-  // buckets are aligned to depends on the layout.)
-  static const int threads_lds = (getenv("VIO_AMD_WINDOW_THREADS") && atoi(getenv("VIO_AMD_WINDOW_THREADS")) == 512) ? kThreadsGlb : kThreadsLds;
-  be->threads_lds = threads_lds;
-  auto need_lds = [&](BatchDims dd, int asp) {
-    dd.lds_asp = asp;
-    size_t se = 0;
-    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
-    // the marginalization phase additionally wants >= 64 staging slots behind its matrix
-    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
-  };
-  // (eligibility: the lean layout, IMU coupling in global memory, inside one CU; the 512-thread build of the LDS variant
-  // -- an experiment switch -- only exists with the coupling in LDS)
-  const int lean_asp = threads_lds == kThreadsLds ? 0 : 1;
-  auto fits_lds = [&](const BatchDims &dd) { return pose_jp(dd) <= 16 * kPanelTiles && need_lds(dd, lean_asp) <= kLdsLimit; };
-  std::vector<int> cand, order;
-  for (int b = 0; b < n; b++) cand.push_back(b);
-  std::sort(cand.begin(), cand.end(), [&](int a, int b2) { return windows[a].n_features < windows[b2].n_features; });
-  BatchDims dl = d;
-  int n_lds = (int)cand.size();
-  while (n_lds > 0) {
-    dl.Flds = std::max(1, windows[cand[n_lds - 1]].n_features);
-    if (fits_lds(dl)) break;
-    n_lds--;
+  std::vector<int> order;
+  {
+    std::vector<int> nfeat(n);
+    for (int b = 0; b < n; b++) nfeat[b] = windows[b].n_features;
+    const int rcl = plan_layout(be, d, n, nfeat.data(), Fmax, order);
+    if (rcl != VIO_OK) return rcl;
   }
-  std::vector<char> in_lds(n, 0);
-  for (int i = 0; i < n_lds; i++) in_lds[cand[i]] = 1, order.push_back(cand[i]);
-  for (int b = 0; b < n; b++)
-    if (!in_lds[b]) order.push_back(b);
-  be->n_lds = n_lds, be->n_glb = n - n_lds, be->lds_matrix = be->n_glb == 0;
-  // Two workgroups per CU (half its LDS each) beat everything else; inside that, the IMU speed-bias x pose coupling is
-  // better off in LDS. Windows with many landmarks give its 14 KB up (global scratch, L2-resident) to stay two per CU.
-  // The marginalization phase stages Jacobian rows in whatever LDS is left behind its matrix.
-  static const bool one_per_cu = getenv("VIO_AMD_WINDOW_ONE_PER_CU") && getenv("VIO_AMD_WINDOW_ONE_PER_CU")[0] == '1';
-  static const int force_asp = getenv("VIO_AMD_LDS_ASP") ? atoi(getenv("VIO_AMD_LDS_ASP")) : -1;
-  be->lds_bytes = kLdsLimit;
-  if (n_lds > 0) {
-    const size_t fat = need_lds(dl, 1), lean = need_lds(dl, lean_asp);
-    // (the lean layout costs a window ~10 % of its latency -- a few more round trips to L2 per Gauss-Newton step --: it only
-    // pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with closed-loop
-    // windows of ~190 landmarks: 2 x 128 windows are faster with the fat layout on whole CUs, 2 x 256 windows take 7.3
-    // instead of 9.4 ms per frame with the lean one.)
-    const bool crowded = n_lds > be->n_cus / 2;
-    if (!one_per_cu && fat <= kLdsHalf) dl.lds_asp = 1, be->lds_bytes = kLdsHalf;
-    else if (!one_per_cu && crowded && lean <= kLdsHalf) dl.lds_asp = lean_asp, be->lds_bytes = kLdsHalf;
-    else dl.lds_asp = fat <= kLdsLimit ? 1 : lean_asp;
-    if ((force_asp == 0 && lean_asp == 0) || (force_asp == 1 && fat <= kLdsLimit)) {
-      dl.lds_asp = force_asp;
-      be->lds_bytes = (!one_per_cu && need_lds(dl, force_asp) <= kLdsHalf) ? kLdsHalf : kLdsLimit;
-    }
-  }
-  be->d_lds = dl;
-  // Phase path: the windows of the LDS set are solved by a sequence of launches (phase_core.h) instead of one.
-  static const int phase_env = getenv("VIO_AMD_PHASE") ? atoi(getenv("VIO_AMD_PHASE")) : -1;
-  const bool want_phase = be->path == VIO_PATH_PHASE || (be->path == VIO_PATH_AUTO && phase_env == 1);
-  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds;
-  if (be->use_phase) {
-    vio::phase_lds_need(dl, &be->lds_setup, &be->lds_lin);
-    if (be->lds_setup > kLdsLimit || be->lds_lin > kLdsLimit) be->use_phase = false;
-  }
+  const int threads_lds = be->threads_lds, n_lds = be->n_lds;
+  const BatchDims dl = be->d_lds;
+  (void)n_lds;
   static const bool poison_staging = getenv("VIO_AMD_POISON") && getenv("VIO_AMD_POISON")[0] == '1';
   // the previous upload's copy may still be reading the staging arena (uploads do not wait for their own transfer)
   HIP_OK(hipStreamSynchronize(be->stream));
@@ -447,47 +540,16 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   }
   const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
-  if (be->n_glb > 0) {
-    BatchDims dg = d;
-    int fg = 1;
-    for (int i = n_lds; i < n; i++) fg = std::max(fg, windows[order[i]].n_features);
-    dg.Flds = fg;
-    size_t se = 0;
-    const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
-    if (std::max(bs, bm) > kLdsLimit) return VIO_ECAP;
-    be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bm);
-  }
   if (be->d_order.ensure(n) != VIO_OK) return VIO_ENOMEM;
   be->h_order.assign(order.begin(), order.end());  // page-locked: goes up with the other staging copies below
 
   const size_t N = (size_t)n;
-  const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
-#define ENSURE(buf, count)                 \
-  do {                                     \
-    int rc_ = (buf).ensure(count);         \
-    if (rc_ != VIO_OK) return rc_;         \
-  } while (0)
-  ENSURE(be->d_in, be->hb.total_bytes);
-  ENSURE(be->d_scratch, N * s.scratch);
-  ENSURE(be->d_hm, be->lds_matrix ? 1 : N * s.hm);  // (indexed by window: sized for the whole batch when any window needs it)
-  ENSURE(be->d_out_pose, N * s.out_pose);
-  ENSURE(be->d_out_sb, N * s.out_sb);
-  ENSURE(be->d_out_feat, N * s.out_feat);
-  ENSURE(be->d_raw_pose, N * s.out_pose);
-  ENSURE(be->d_raw_sb, N * s.out_sb);
-  ENSURE(be->d_raw_feat, N * s.out_feat);
-  ENSURE(be->d_out_loop, N * s.out_loop);
-  ENSURE(be->d_stats_d, N * s.stats_d);
-  ENSURE(be->d_stats_i, N * s.stats_i);
-  ENSURE(be->d_m_ints, N * m_ints);
-  ENSURE(be->d_m_x0, N * 9 * kMaxPriorBlocks);
-  ENSURE(be->d_m_J, N * (size_t)d.Ncap * d.Ncap);
-  ENSURE(be->d_m_r, N * (size_t)d.Ncap);
-  ENSURE(be->d_m_scratch, m_scr ? N * m_scr : 1);
+  {
+    int rce = be->d_in.ensure(be->hb.total_bytes);
+    if (rce == VIO_OK) rce = ensure_work_buffers(be, d, s, N);
+    if (rce != VIO_OK) return rce;
+  }
   const PhaseLayout PL = make_phase_layout(d);
-  if (be->use_phase) ENSURE(be->d_phase, N * PL.total);
-#undef ENSURE
   hipStream_t st = be->stream;
 #define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
   H2D(be->d_order, be->h_order);
@@ -535,23 +597,9 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     B.preint = dp(20), B.pr_x0 = dp(21), B.pr_J = dp(22), B.pr_r = dp(23);
   }
   B.ptab = any_slot ? be->d_ptab.p : nullptr;
-  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
-  B.phase = be->use_phase ? be->d_phase.p : nullptr, B.PL = PL;
-  B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
-  B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
-  B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
-  MargPtrs &MP = be->MP;
-  MP.ints = be->d_m_ints.p, MP.x0 = be->d_m_x0.p, MP.J = be->d_m_J.p, MP.r = be->d_m_r.p;
-  MP.scratch = m_scr ? be->d_m_scratch.p : nullptr;
-  MP.s_ints = m_ints, MP.s_x0 = 9 * kMaxPriorBlocks, MP.s_J = (size_t)d.Ncap * d.Ncap, MP.s_r = d.Ncap;
-  MP.s_scratch = m_scr;
-  MP.prof = nullptr;
-  MP.prof_tid = getenv("VIO_AMD_PROF_TID") ? atoi(getenv("VIO_AMD_PROF_TID")) : 0;
-  MP.wrot = getenv("VIO_AMD_WAVE_ROT") ? atoi(getenv("VIO_AMD_WAVE_ROT")) : -1;
-  if (be->profile) {
-    int rcp = be->d_prof.ensure(N * ST_COUNT);
-    if (rcp != VIO_OK) return rcp;
-    MP.prof = be->d_prof.p;
+  {
+    const int rcb = bind_work_buffers(be, d, s, N, PL);
+    if (rcb != VIO_OK) return rcb;
   }
   be->n = n;
   be->uploaded = true, be->slots_advanced = false;
@@ -752,3 +800,5 @@ int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n, 
 }
 
 }  // extern "C"
+
+#include "vio_backend_resident.inc"

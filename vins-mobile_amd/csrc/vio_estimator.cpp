@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "vio_amd.h"
+#include "vio_resident.h"
 #include "vio_math.h"
 #include "vio_initial.h"
 #include "vio_pool.h"
@@ -90,6 +91,10 @@ struct Sequence {
   double ex_pose[7], loop_pose[7];
   int loop_frame = -1, n_loop_factors = 0;
   int last_track_num = 0;
+  // device-resident path (vio_resident.h): the landmark list, the pre-integration blocks and the prior of this sequence live
+  // in its slot of the group's back-end; `fm` is empty meanwhile
+  bool on_device = false;
+  std::vector<char> pre_dirty;  // [W+1] pre[i] changed since the device last saw it
 };
 
 const double kI3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -115,6 +120,11 @@ struct vio_estimator {
   // the marginalization prior of every sequence stays in device memory between launches; only its header comes back
   // (VIO_AMD_HOST_PRIORS=1: carry it through host memory instead, ~45 KB per sequence and direction)
   bool resident_priors = !(getenv("VIO_AMD_HOST_PRIORS") && getenv("VIO_AMD_HOST_PRIORS")[0] == '1');
+  // Sequences in the NON_LINEAR state keep their landmark list on the device and have their windows assembled there
+  // (vio_estimator_set_resident / VIO_AMD_RESIDENT=1); needs the device-resident priors.
+  bool resident = getenv("VIO_AMD_RESIDENT") && getenv("VIO_AMD_RESIDENT")[0] == '1';
+  int res_list_cap = 0, res_obs_cap = 0;
+  std::vector<int> res_rc;  // per sequence: outcome of staging in the current call
   std::vector<int> solving;  // sequences of the current launch
   std::vector<VioWindow> staged;   // per sequence, built in parallel, compacted into `windows`
   std::vector<char> wants_solve;
@@ -139,6 +149,7 @@ void clear_state(vio_estimator *e, Sequence &s) {  // VINS::clearState (VINS.cpp
   s.all_image_frame.clear();
   s.tmp_valid = false;
   s.initial_timestamp = 0;
+  s.on_device = false;
   vio_features_clear(s.fm);
 }
 
@@ -185,8 +196,10 @@ void slide_window(vio_estimator *e, Sequence &s) {
     s.dt_buf[W].clear(), s.acc_buf[W].clear(), s.gyr_buf[W].clear();
     if (s.solver_flag == VIO_SOLVER_INITIAL)  // frames older than the new oldest one leave all_image_frame (VINS.cpp:1190-1197)
       s.all_image_frame.erase(s.all_image_frame.begin(), s.all_image_frame.lower_bound(s.Headers[0]));
-    // slideWindowOld: the landmarks hosted in the departed frame move to the next one
-    if (s.solver_flag == VIO_SOLVER_NON_LINEAR) {
+    // slideWindowOld: the landmarks hosted in the departed frame move to the next one (store_finish did it on the device
+    // for a resident sequence, together with the shift of the pre-integration blocks)
+    if (s.on_device) {
+    } else if (s.solver_flag == VIO_SOLVER_NON_LINEAR) {
       double R0[9], R1[9], P0[3], P1[3], t[3];
       mat3mul(back_R0, e->ric, R0), mat3mul(&s.Rs[0], e->ric, R1);
       mat3vec(back_R0, e->tic, t);
@@ -215,19 +228,17 @@ void slide_window(vio_estimator *e, Sequence &s) {
     }
     new_preintegration(e, s, W);
     s.dt_buf[W].clear(), s.acc_buf[W].clear(), s.gyr_buf[W].clear();
-    vio_features_remove_front(s.fm, s.frame_count);
+    if (s.on_device) s.pre_dirty[fc - 1] = 1;  // the interval that took over the departed frame's samples
+    else vio_features_remove_front(s.fm, s.frame_count);
   }
 }
 
+void fill_pose_arrays(vio_estimator *e, Sequence &s);
+
 // old2new + the factor list + the loop pose: everything solve_ceres hands to the solver (VINS.cpp:89-129, 505-637)
 int build_window(vio_estimator *e, Sequence &s, VioWindow *w) {
-  const int W = e->W, P = W + 1;
-  for (int i = 0; i < P; i++) {
-    const Quat q = RtoQ(&s.Rs[9 * i]);
-    double *p = &s.pose[7 * i], *b = &s.sb[9 * i];
-    p[0] = s.Ps[3 * i], p[1] = s.Ps[3 * i + 1], p[2] = s.Ps[3 * i + 2], p[3] = q.x, p[4] = q.y, p[5] = q.z, p[6] = q.w;
-    for (int k = 0; k < 3; k++) b[k] = s.Vs[3 * i + k], b[3 + k] = s.Bas[3 * i + k], b[6 + k] = s.Bgs[3 * i + k];
-  }
+  const int W = e->W;
+  fill_pose_arrays(e, s);
   {
     const Quat q = RtoQ(e->ric);
     s.ex_pose[0] = e->tic[0], s.ex_pose[1] = e->tic[1], s.ex_pose[2] = e->tic[2];
@@ -272,6 +283,88 @@ int build_window(vio_estimator *e, Sequence &s, VioWindow *w) {
   w->next_prior = &s.prior[1 - s.cur_prior].p;
   w->resident_prior = e->resident_priors ? s.index % e->group_size + 1 : 0;  // slot in the store of the sequence's group
   return VIO_OK;
+}
+
+// para_Pose / para_SpeedBias of the window (vector2double, VINS.cpp:89-129) into s.pose / s.sb.
+void fill_pose_arrays(vio_estimator *e, Sequence &s) {
+  const int P = e->W + 1;
+  for (int i = 0; i < P; i++) {
+    const Quat q = RtoQ(&s.Rs[9 * i]);
+    double *p = &s.pose[7 * i], *b = &s.sb[9 * i];
+    p[0] = s.Ps[3 * i], p[1] = s.Ps[3 * i + 1], p[2] = s.Ps[3 * i + 2], p[3] = q.x, p[4] = q.y, p[5] = q.z, p[6] = q.w;
+    for (int k = 0; k < 3; k++) b[k] = s.Vs[3 * i + k], b[3 + k] = s.Bas[3 * i + k], b[6 + k] = s.Bgs[3 * i + k];
+  }
+}
+
+// ---- device-resident sequences (vio_resident.h) --------------------------------------------------------------------------
+int group_of(const vio_estimator *e, const Sequence &s) { return s.index / e->group_size; }
+int slot_of(const vio_estimator *e, const Sequence &s) { return s.index % e->group_size; }
+
+bool resident_eligible(const vio_estimator *e, const Sequence &s) {
+  return e->resident && e->resident_priors && s.solver_flag == VIO_SOLVER_NON_LINEAR && s.frame_count == e->W && s.retrive.ids.empty() &&
+         s.front.ids.empty() && !s.failure_occur;
+}
+
+// The landmark list of a sequence moves to its slot of the group's back-end (main thread: HIP calls).
+int promote(vio_estimator *e, Sequence &s) {
+  const int g = group_of(e, s);
+  if (!e->be[g]) return VIO_ESTATE;
+  int lcap = 0, ocap = 0;
+  if (vio_backend_resident_caps(e->be[g], &lcap, &ocap) != VIO_OK) {
+    e->res_obs_cap = std::min(1024, std::max(256, 2 * e->cfg.max_corners));
+    e->res_list_cap = std::max(1024, 4 * e->res_obs_cap);
+    double ex[7];
+    const Quat q = RtoQ(e->ric);
+    ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;
+    const int rc = vio_backend_resident_reserve(e->be[g], e->group_size, e->res_list_cap, e->res_obs_cap, ex, e->tic, e->ric);
+    if (rc != VIO_OK) return rc;
+    lcap = e->res_list_cap, ocap = e->res_obs_cap;
+  }
+  int n = 0, np = 0;
+  int rc = vio_features_dump(s.fm, nullptr, 0, &n, nullptr, 0, &np);
+  if (rc != VIO_OK) return rc;
+  if (n > lcap) return VIO_ECAP;
+  std::vector<VioFeatureInfo> info(n + 1);
+  std::vector<double> pts(3 * (size_t)np + 3);
+  rc = vio_features_dump(s.fm, info.data(), n, &n, pts.data(), np, &np);
+  if (rc != VIO_OK) return rc;
+  rc = vio_backend_resident_load(e->be[g], slot_of(e, s), info.data(), n, pts.data(), s.last_P, s.last_R);
+  if (rc != VIO_OK) return rc;
+  vio_features_clear(s.fm);
+  s.pre_dirty.assign(e->W + 1, 1);
+  s.on_device = true;
+  return VIO_OK;
+}
+
+// ... and back: the host-side list takes over again (relocalization, a caller that wants to look at the list).
+int demote(vio_estimator *e, Sequence &s) {
+  if (!s.on_device) return VIO_OK;
+  const int g = group_of(e, s);
+  int n = 0, np = 0;
+  int rc = vio_backend_resident_fetch(e->be[g], slot_of(e, s), nullptr, 0, &n, nullptr, 0, &np);
+  if (rc != VIO_OK) return rc;
+  std::vector<VioFeatureInfo> info(n + 1);
+  std::vector<double> pts(3 * (size_t)np + 3);
+  rc = vio_backend_resident_fetch(e->be[g], slot_of(e, s), info.data(), n + 1, &n, pts.data(), np + 1, &np);
+  if (rc != VIO_OK) return rc;
+  rc = vio_features_load(s.fm, info.data(), n, pts.data());
+  if (rc != VIO_OK) return rc;
+  s.on_device = false;
+  return VIO_OK;
+}
+
+// double2vector of a window solved on the resident path + the prior hand-over (take_solution without the landmark and
+// loop parts: the landmarks took their depths in store_finish, a sequence with a relocalization frame is not resident).
+void take_resident_solution(vio_estimator *e, Sequence &s, const VioResidentResult &r, const VioPrior &next) {
+  const int P = e->W + 1;
+  s.final_cost = r.stats.final_cost;
+  for (int i = 0; i < P; i++) {
+    const double *p = r.pose + 7 * i, *b = r.speed_bias + 9 * i;
+    qtoR(qfrom_pose(p), &s.Rs[9 * i]);
+    for (int k = 0; k < 3; k++)
+      s.Ps[3 * i + k] = p[k], s.Vs[3 * i + k] = b[k], s.Bas[3 * i + k] = b[3 + k], s.Bgs[3 * i + k] = b[6 + k];
+  }
+  if (next.n > 0) s.cur_prior = 1 - s.cur_prior, s.has_prior = true;
 }
 
 double normalize_angle(double a) {  // Utility::normalizeAngle, degrees (utility.hpp:171-179)
@@ -534,6 +627,109 @@ void remember_last(vio_estimator *e, Sequence &s) {  // VINS.cpp:431-434, 472-47
   memcpy(s.last_R_old, &s.Rs[0], 72), memcpy(s.last_P_old, &s.Ps[0], 24);
 }
 
+// One published frame of every resident sequence: what processImage does with it, with the landmark work on the device.
+//   main thread   begin (per group)
+//   pool          per sequence: para_Pose / para_SpeedBias, the pre-integration blocks that changed, the observations -> staging
+//   main thread   ingest (H2D + store_ingest, per group, no wait), then launch per group (waits for the group's counts:
+//                 layout, store_pack, window kernel, store_finish, results queued), then collect per group
+//   pool          per sequence: double2vector, prior header, failure / slide of the host-side states
+int resident_frame(vio_estimator *e, const VioObs *obs, const int32_t *n_obs, int32_t obs_stride, const double *headers,
+                   const uint8_t *active, VioFrameResult *results) {
+  const int W = e->W;
+  std::vector<char> in_group(e->n_groups, 0);
+  std::vector<int> todo;
+  for (int q = 0; q < e->n_seq; q++) {
+    Sequence &s = e->seq[q];
+    if (!s.on_device || (active && !active[q])) continue;
+    in_group[group_of(e, s)] = 1;
+    todo.push_back(q);
+  }
+  if (todo.empty()) return VIO_OK;
+  int rc = VIO_OK;
+  for (int g = 0; g < e->n_groups && rc == VIO_OK; g++)
+    if (in_group[g]) rc = vio_backend_resident_begin(e->be[g]);
+  e->res_rc.assign(e->n_seq, VIO_OK);
+  if (rc == VIO_OK) {
+    HostPool::get().parallel_for((int)todo.size(), [&](int i) {
+      const int q = todo[i];
+      Sequence &s = e->seq[q];
+      VioFrameResult &res = results[q];
+      vio_backend_t *be = e->be[group_of(e, s)];
+      const int slot = slot_of(e, s);
+      int r = VIO_OK;
+      if (n_obs[q] < 0 || (obs_stride > 0 && n_obs[q] > obs_stride)) r = VIO_EINVAL;
+      s.Headers[s.frame_count] = headers[q];
+      fill_pose_arrays(e, s);
+      VioPreintegration blk;
+      for (int k = 1; k <= W && r == VIO_OK; k++) {
+        if (!s.pre_dirty[k] && k != W) continue;  // (the newest interval is new with every frame)
+        if (!s.pre_valid[k]) {
+          r = VIO_ESTATE;
+          break;
+        }
+        host::preint_export(s.pre[k], &blk);
+        r = vio_backend_resident_stage_preint(be, slot, k - 1, &blk);
+        s.pre_dirty[k] = 0;
+      }
+      if (r == VIO_OK)
+        r = vio_backend_resident_stage(be, slot, obs + (size_t)q * obs_stride, n_obs[q], s.Ps.data(), s.Rs.data(), s.pose.data(), s.sb.data(),
+                                       s.has_prior ? &s.prior[s.cur_prior].p : nullptr);
+      e->res_rc[q] = r;
+      (void)res;
+    });
+    for (int g = 0; g < e->n_groups && rc == VIO_OK; g++)
+      if (in_group[g]) rc = vio_backend_resident_ingest(e->be[g]);
+    for (int g = 0; g < e->n_groups && rc == VIO_OK; g++)
+      if (in_group[g]) rc = vio_backend_resident_launch(e->be[g]);
+  }
+  for (int g = 0; g < e->n_groups; g++)  // (every group that began is brought back to idle, also after an error in another)
+    if (in_group[g]) {
+      const int rcc = vio_backend_resident_collect(e->be[g]);
+      if (rc == VIO_OK && rcc != VIO_ESTATE) rc = rcc;
+    }
+  if (rc != VIO_OK) {  // device error: the stores may or may not have advanced; every sequence of this path restarts
+    for (int q : todo) {
+      clear_state(e, e->seq[q]);
+      results[q].action = VIO_FRAME_ERROR, results[q].error = rc;
+    }
+    return rc;
+  }
+  int first_error = VIO_OK;
+  HostPool::get().parallel_for((int)todo.size(), [&](int i) {
+    const int q = todo[i];
+    Sequence &s = e->seq[q];
+    VioFrameResult &res = results[q];
+    VioResidentResult r;
+    VioPrior &next = s.prior[1 - s.cur_prior].p;
+    int rr = e->res_rc[q];
+    if (rr == VIO_OK) rr = vio_backend_resident_result(e->be[group_of(e, s)], slot_of(e, s), &r, &next);
+    if (rr == VIO_OK) rr = r.status;
+    if (rr != VIO_OK) {  // (not staged, or the store refused the frame: the slot's list is undefined now)
+      clear_state(e, s);
+      res.action = VIO_FRAME_ERROR, res.error = rr;
+      return;
+    }
+    s.marginalization_flag = r.marginalization_flag, s.last_track_num = r.track_num;
+    res.marginalization_flag = r.marginalization_flag, res.track_num = r.track_num;
+    res.n_features = r.n_features, res.n_factors = r.n_factors, res.n_loop_factors = 0;
+    res.stats = r.stats;
+    take_resident_solution(e, s, r, next);
+    s.failure_occur = 0;
+    if (r.failure_reasons) {
+      s.failure_occur = 1;
+      clear_state(e, s);
+      res.action = VIO_FRAME_FAILURE, res.failure_reasons = r.failure_reasons;
+      return;
+    }
+    slide_window(e, s);
+    remember_last(e, s);
+    res.action = VIO_FRAME_SOLVED;
+  });
+  for (int q : todo)
+    if (results[q].action == VIO_FRAME_ERROR && first_error == VIO_OK) first_error = results[q].error;
+  return first_error;
+}
+
 }  // namespace
 
 extern "C" {
@@ -583,6 +779,7 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
     s.pts_i.assign((size_t)3 * cfg->max_factors, 0), s.pts_j.assign((size_t)3 * cfg->max_factors, 0);
     s.f_host.assign(cfg->max_factors, 0), s.f_target.assign(cfg->max_factors, 0), s.f_feat.assign(cfg->max_factors, 0);
     s.preint.resize(W);
+    s.pre_dirty.assign(P, 0);
     clear_state(e, s);
   }
   e->windows.resize(n_seq), e->stats.resize(n_seq);
@@ -603,6 +800,18 @@ int vio_estimator_enable_initialization(vio_estimator_t *e, int32_t enable) {
   if (!e) return VIO_EINVAL;
   e->enable_init = enable != 0;
   e->init_relpose_fit = enable == 2;
+  return VIO_OK;
+}
+
+int vio_estimator_set_resident(vio_estimator_t *e, int32_t enable) {
+  if (!e) return VIO_EINVAL;
+  if (enable && !e->resident_priors) return VIO_ESTATE;  // (VIO_AMD_HOST_PRIORS=1: the priors travel through the host)
+  e->resident = enable != 0;
+  if (!e->resident)
+    for (Sequence &s : e->seq) {
+      const int rc = demote(e, s);
+      if (rc != VIO_OK) return rc;
+    }
   return VIO_OK;
 }
 
@@ -707,6 +916,21 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   e->solving.clear();
   int first_error = VIO_OK;
   const auto t_begin = std::chrono::steady_clock::now();
+  // resident sequences that cannot stay on the device for this frame go back to the host-side list first
+  bool any_resident = false;
+  for (int q = 0; q < e->n_seq; q++) {
+    Sequence &s = e->seq[q];
+    if (!s.on_device || (active && !active[q])) continue;
+    if (s.front.header != s.retrive.header) s.front = s.retrive;
+    if (!resident_eligible(e, s) || n_obs[q] > e->res_obs_cap) {
+      const int rcd = demote(e, s);
+      if (rcd != VIO_OK) {
+        clear_state(e, s);
+        if (first_error == VIO_OK) first_error = rcd;
+      }
+    }
+    any_resident = any_resident || s.on_device;
+  }
   // phase A, per sequence and independent of the others (spread over the host pool): landmark bookkeeping, the
   // INITIAL / NON_LINEAR branch, triangulation, the window as solve_ceres hands it to the solver
   e->staged.resize(e->n_seq);
@@ -717,6 +941,7 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     res.action = VIO_FRAME_SKIPPED;
     if (active && !active[q]) return;
     Sequence &s = e->seq[q];
+    if (s.on_device) return;  // its frame goes through the resident path below
     int enough = 0, parallax_num = 0;
     if (n_obs[q] < 0 || (obs_stride > 0 && n_obs[q] > obs_stride)) {
       res.action = VIO_FRAME_ERROR, res.error = VIO_EINVAL;
@@ -891,6 +1116,10 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     HostPool::get().parallel_for(ng, [&](int i) { phase_c(g0[g] + i); });
     ms_c += ms_between(tc, std::chrono::steady_clock::now());
   }
+  if (any_resident) {
+    const int rcr = resident_frame(e, obs, n_obs, obs_stride, headers, active, results);
+    if (rcr != VIO_OK && first_error == VIO_OK) first_error = rcr;
+  }
   if (rc != VIO_OK) {
     // The frame is in the landmark stores of every sequence that wanted a solve. Sequences whose phase C has run (groups
     // before the failing one) have slid their windows and stay; the others did not advance: they restart rather than carry
@@ -906,6 +1135,13 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   const auto t_end = std::chrono::steady_clock::now();
   // (phases A and C are now interleaved with the device work of the other groups: their own sums, and the rest)
   e->ms_pre = ms_a, e->ms_post = ms_c, e->ms_solve = ms_between(t_begin, t_end) - ms_a - ms_c;
+  // sequences that reached the NON_LINEAR state on the host path continue on the device
+  if (e->resident)
+    for (int q = 0; q < e->n_seq; q++) {
+      Sequence &s = e->seq[q];
+      if (s.on_device || results[q].action != VIO_FRAME_SOLVED || !resident_eligible(e, s)) continue;
+      (void)promote(e, s);  // (a list that does not fit the store stays on the host path)
+    }
   return first_error;
 }
 
@@ -975,6 +1211,10 @@ int vio_estimator_get_corrected_window(vio_estimator_t *e, int32_t seq, double *
 
 int vio_estimator_features(vio_estimator_t *e, int32_t seq, vio_features_t **fm) {
   if (!e || seq < 0 || seq >= e->n_seq || !fm) return VIO_EINVAL;
+  {  // a resident sequence's list comes back to the host first (it returns to the device after its next solved frame)
+    const int rc = demote(e, e->seq[seq]);
+    if (rc != VIO_OK) return rc;
+  }
   *fm = e->seq[seq].fm;
   return VIO_OK;
 }

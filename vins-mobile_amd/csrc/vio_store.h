@@ -1,0 +1,36 @@
+// vio_store.h — launchers of the landmark-store kernels (vio_store.hip, store_core.h) for the back-end's resident path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "batch.h"
+#include "store_core.h"
+
+namespace vio {
+
+// Device pointers of the resident state of one back-end context (all of its slots; slot = window index of the batch).
+struct StoreDev {
+  store::Dims d;
+  int n_slots;
+  int *fid, *start, *nobs, *flag;  // [2 banks][n_slots][Lcap]
+  double *depth, *obs;             // [2][n_slots][Lcap], [2][n_slots][Lcap][P][3]
+  int *ctl;                        // [n_slots][store::C_COUNT]
+  double *ctld;                    // [n_slots][store::kCtlDoubles]
+  // this frame's inputs (device mirror of the staging arena)
+  const int *active;               // [n_slots] the slot takes part in this frame
+  const int *n_obs;                // [n_slots]
+  const VioObs *obs_in;            // [n_slots][Ocap]
+  const double *Ps, *Rs;           // [n_slots][P][3], [n_slots][P][9]: the window states triangulate reads
+  const double *tic, *ric;         // camera -> body
+  double *preint;                  // [n_slots][W][kPreintDoubles] the pre-integration blocks of the window, kept across frames
+  const int *pre_idx;              // [n_pre] slot * W + interval of every block that arrives with this frame
+  const double *pre_blk;           // [n_pre][kPreintDoubles]
+  int n_pre;
+};
+
+int store_launch_ingest(const StoreDev &S, hipStream_t st);
+int store_launch_pack(const StoreDev &S, const BatchPtrs &B, int chunk, hipStream_t st);
+int store_launch_finish(const StoreDev &S, const BatchPtrs &B, hipStream_t st);
+size_t store_pack_lds_bytes(const store::Dims &d, int Mcap);
+
+}  // namespace vio

@@ -1,0 +1,132 @@
+// vio_store.hip — kernels of the device-resident landmark store (store_core.h): one workgroup per sequence slot.
+// Built with -ffp-contract=off: the passes give the bits of the host-side list (vio_window.cpp).
+#include "vio_store.h"
+
+#include <stdio.h>
+
+using namespace vio;
+namespace st = vio::store;
+
+static_assert(st::PH_F == H_F && st::PH_M == H_M && st::PH_HAS_LOOP == H_HAS_LOOP && st::PH_LOOP_FRAME == H_LOOP_FRAME &&
+                  st::PH_MARG == H_MARG && st::PH_NPAIRS == H_NPAIRS && st::PH_NSLOTS == H_NSLOTS && st::PH_NREV == H_NREV,
+              "store_core.h writes the header slots of batch.h");
+
+namespace {
+
+__device__ __forceinline__ st::Bank bank_of(const StoreDev &S, int slot, int b) {
+  const size_t e = ((size_t)b * S.n_slots + slot) * S.d.Lcap;
+  return st::Bank{S.fid + e, S.start + e, S.nobs + e, S.flag + e, S.depth + e, S.obs + e * (S.d.W + 1) * 3};
+}
+
+__global__ __launch_bounds__(st::kThreads) void store_ingest_kernel(StoreDev S) {
+  extern __shared__ int lds_raw[];
+  const int slot = blockIdx.x;
+  // pre-integration blocks that arrive with this frame (any slot's: the blocks are spread over the grid)
+  for (int k = blockIdx.x; k < S.n_pre; k += gridDim.x) {
+    const double *src = S.pre_blk + (size_t)k * kPreintDoubles;
+    double *dst = S.preint + (size_t)S.pre_idx[k] * kPreintDoubles;
+    for (int i = threadIdx.x; i < kPreintDoubles; i += blockDim.x) dst[i] = src[i];
+  }
+  if (!S.active[slot]) return;
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  ldsd dbase;
+  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
+  const int P = S.d.W + 1;
+  st::store_ingest(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, S.obs_in + (size_t)slot * S.d.Ocap, S.n_obs[slot],
+                   S.Ps + (size_t)slot * 3 * P, S.Rs + (size_t)slot * 9 * P, S.tic, S.ric);
+}
+
+__global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, BatchPtrs B, int chunk) {
+  extern __shared__ int lds_raw[];
+  const int slot = blockIdx.x;
+  if (!S.active[slot]) return;
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  ldsd dbase;
+  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  // behind the store's own scratch: bucket counters and the factor keys
+  const int np1 = S.d.W + 2;
+  ldsi bins = (ldsi)(dbase + S.d.Lcap);
+  VIO_AS3 unsigned short *keys = (VIO_AS3 unsigned short *)(bins + 2 * np1 * np1);
+  int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
+  const BatchStrides &s = B.s;
+  const size_t b = slot;
+  st::PackOut o;
+  o.hdr = const_cast<int *>(B.hdr) + b * kHdrInts;
+  o.feat = const_cast<double *>(B.feat) + b * s.feat;
+  o.fhost = const_cast<int *>(B.fhost) + b * s.fint, o.ftarget = const_cast<int *>(B.ftarget) + b * s.fint;
+  o.ffeat = const_cast<int *>(B.ffeat) + b * s.fint, o.fslot = const_cast<int *>(B.fslot) + b * s.fint;
+  o.fstart = const_cast<int *>(B.fstart) + b * s.fstart;
+  o.pair_h = const_cast<int *>(B.pair_h) + b * s.pair, o.pair_t = const_cast<int *>(B.pair_t) + b * s.pair;
+  o.pair_s0 = const_cast<int *>(B.pair_s0) + b * s.pair, o.pair_s1 = const_cast<int *>(B.pair_s1) + b * s.pair;
+  o.pts_i = const_cast<double *>(B.pts_i) + b * s.pts, o.pts_j = const_cast<double *>(B.pts_j) + b * s.pts;
+  o.Fcap = B.d.Fcap, o.Mcap = B.d.Mcap, o.pair_cap = B.d.pair_cap, o.slot_cap = 2 * (size_t)B.d.Mcap + B.d.pair_cap + 2;  // = slot_capacity(B.d) (batch.h, host function)
+  st::store_pack(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, o, chunk, keys, bins);
+}
+
+__global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, BatchPtrs B) {
+  extern __shared__ int lds_raw[];
+  const int slot = blockIdx.x;
+  if (!S.active[slot]) return;
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  ldsd dbase;
+  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
+  const BatchStrides &s = B.s;
+  const int bank = ctl[st::C_BANK];
+  st::store_finish(cx, S.d, bank_of(S, slot, bank), bank_of(S, slot, 1 - bank), ctl, S.ctld + (size_t)slot * st::kCtlDoubles, l,
+                   B.out_feat + (size_t)slot * s.out_feat, B.out_pose + (size_t)slot * s.out_pose, B.out_sb + (size_t)slot * s.out_sb,
+                   S.tic, S.ric);
+  __syncthreads();
+  // slideWindow, MARGIN_OLD: the pre-integration of interval i + 1 becomes that of interval i (VINS.cpp:1160-1187); the
+  // newest interval arrives with the next frame
+  if (ctl[st::C_STATUS] == VIO_OK && ctl[st::C_FAIL] == 0 && ctl[st::C_MARG] == VIO_MARGIN_OLD) {
+    double *pre = S.preint + (size_t)slot * S.d.W * kPreintDoubles;
+    for (int i = 0; i + 1 < S.d.W; i++) {
+      for (int k = threadIdx.x; k < kPreintDoubles; k += blockDim.x) pre[(size_t)i * kPreintDoubles + k] = pre[(size_t)(i + 1) * kPreintDoubles + k];
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace
+
+namespace vio {
+
+size_t store_pack_lds_bytes(const store::Dims &d, int Mcap) {
+  const int np1 = d.W + 2;
+  return st::lds_bytes(d) + sizeof(int) * 2 * np1 * np1 + sizeof(unsigned short) * ((size_t)Mcap + 8);
+}
+
+#define STORE_HIP_OK(expr)                                                                                      \
+  do {                                                                                                          \
+    hipError_t e_ = (expr);                                                                                     \
+    if (e_ != hipSuccess) {                                                                                     \
+      fprintf(stderr, "vio_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return VIO_ENODEV;                                                                                        \
+    }                                                                                                           \
+  } while (0)
+
+int store_launch_ingest(const StoreDev &S, hipStream_t stream) {
+  hipLaunchKernelGGL(store_ingest_kernel, dim3(S.n_slots), dim3(st::kThreads), st::lds_bytes(S.d), stream, S);
+  STORE_HIP_OK(hipGetLastError());
+  return VIO_OK;
+}
+
+int store_launch_pack(const StoreDev &S, const BatchPtrs &B, int chunk, hipStream_t stream) {
+  const size_t lds = store_pack_lds_bytes(S.d, B.d.Mcap);
+  if (lds > 160 * 1024) return VIO_ECAP;
+  if (lds > 64 * 1024)
+    STORE_HIP_OK(hipFuncSetAttribute((const void *)store_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(store_pack_kernel, dim3(S.n_slots), dim3(st::kThreads), lds, stream, S, B, chunk);
+  STORE_HIP_OK(hipGetLastError());
+  return VIO_OK;
+}
+
+int store_launch_finish(const StoreDev &S, const BatchPtrs &B, hipStream_t stream) {
+  hipLaunchKernelGGL(store_finish_kernel, dim3(S.n_slots), dim3(st::kThreads), st::lds_bytes(S.d), stream, S, B);
+  STORE_HIP_OK(hipGetLastError());
+  return VIO_OK;
+}
+
+}  // namespace vio

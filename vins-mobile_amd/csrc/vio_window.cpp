@@ -419,6 +419,26 @@ int vio_failure_detection(int32_t last_track_num, const double Bg_newest[3], con
   return VIO_OK;
 }
 
+int vio_features_load(vio_features_t *fm, const VioFeatureInfo *info, int32_t n, const double *points) {
+  if (!fm || n < 0 || (n > 0 && (!info || !points))) return VIO_EINVAL;
+  for (int i = 0; i < n; i++)
+    if (info[i].n_obs < 1 || info[i].start_frame < 0 || info[i].start_frame + info[i].n_obs - 1 > fm->window_size) return VIO_EINVAL;
+  fm->feature.clear();
+  size_t p = 0;
+  for (int i = 0; i < n; i++) {
+    fm->feature.emplace_back(info[i].id, info[i].start_frame);
+    Feature &f = fm->feature.back();
+    f.obs.resize(info[i].n_obs);
+    for (int j = 0; j < info[i].n_obs; j++, p++) {
+      for (int k = 0; k < 3; k++) f.obs[j].point[k] = points[3 * p + k];
+      f.obs[j].z = points[3 * p + 2];
+    }
+    f.used_num = info[i].used_num, f.solve_flag = info[i].solve_flag, f.is_outlier = info[i].is_outlier != 0, f.fixed = info[i].fixed != 0;
+    f.estimated_depth = info[i].estimated_depth;
+  }
+  return VIO_OK;
+}
+
 int vio_features_dump(vio_features_t *fm, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points, int32_t cap_points,
                       int32_t *n_points) {
   if (!fm || !n || (cap > 0 && !info)) return VIO_EINVAL;

@@ -44,6 +44,11 @@ class Estimator:
         mode = {False: 0, True: 2, "fit": 2, "reference": 1}.get(on, on)
         self._check(self.lib.vio_estimator_enable_initialization(self._h, int(mode)), "enable_initialization")
 
+    def set_resident(self, on=True):
+        """Landmark lists of the sequences in the NON_LINEAR state on the device, windows assembled there
+        (vio_estimator_set_resident; include/vio_amd.h)."""
+        self._check(self.lib.vio_estimator_set_resident(self._h, 1 if on else 0), "set_resident")
+
     def clear(self, seq=0):
         self._check(self.lib.vio_estimator_clear(self._h, seq), "clear")
 
