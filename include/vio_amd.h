@@ -694,7 +694,7 @@ int vio_estimator_get_corrected_window(vio_estimator_t *est, int32_t seq, double
  * the bookkeeping after it.                                                    */
 int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
 /* The sequence's landmark store (owned by the estimator), for introspection.   */
-/* Device-resident landmark stores (0 = off, the default unless VIO_AMD_RESIDENT=1): a sequence that has reached the
+/* Device-resident landmark stores (on by default; 0 or VIO_AMD_RESIDENT=0 turn them off): a sequence that has reached the
  * NON_LINEAR state keeps its landmark list, its pre-integration blocks and its prior in device memory; per frame the host
  * sends the observations and the propagated window states (about 12 KB instead of about 125 KB per window), kernels do
  * addFeatureCheckParallax / triangulate / the factor list / setDepth / the slide (feature_manager.cpp:103-372), and the

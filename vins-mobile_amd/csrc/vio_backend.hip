@@ -136,6 +136,7 @@ static void resident_destroy(vio_resident *r);
 struct vio_backend {
   VioConfig cfg;
   vio_resident *res = nullptr;  // device-resident path (vio_resident.h), null until reserved
+  int peers = 2;  // contexts whose window kernels share the device at the same time (vio_backend_set_peers)
   int device = -1;  // HIP device the context lives on (current device at create)
   int max_batch = 0;
   hipStream_t stream = nullptr;
@@ -352,7 +353,7 @@ static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, i
     // pays when the launch has enough windows to fill the second workgroup slot of the CUs. Measured with closed-loop
     // windows of ~190 landmarks: 2 x 128 windows are faster with the fat layout on whole CUs, 2 x 256 windows take 7.3
     // instead of 9.4 ms per frame with the lean one.)
-    const bool crowded = n_lds > be->n_cus / 2;
+    const bool crowded = n_lds * std::max(1, be->peers) > be->n_cus;  // (with the other contexts' launches: more windows than CUs)
     if (!one_per_cu && fat <= kLdsHalf) dl.lds_asp = 1, be->lds_bytes = kLdsHalf;
     else if (!one_per_cu && crowded && lean <= kLdsHalf) dl.lds_asp = lean_asp, be->lds_bytes = kLdsHalf;
     else dl.lds_asp = fat <= kLdsLimit ? 1 : lean_asp;

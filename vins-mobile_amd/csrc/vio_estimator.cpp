@@ -121,8 +121,8 @@ struct vio_estimator {
   // (VIO_AMD_HOST_PRIORS=1: carry it through host memory instead, ~45 KB per sequence and direction)
   bool resident_priors = !(getenv("VIO_AMD_HOST_PRIORS") && getenv("VIO_AMD_HOST_PRIORS")[0] == '1');
   // Sequences in the NON_LINEAR state keep their landmark list on the device and have their windows assembled there
-  // (vio_estimator_set_resident / VIO_AMD_RESIDENT=1); needs the device-resident priors.
-  bool resident = getenv("VIO_AMD_RESIDENT") && getenv("VIO_AMD_RESIDENT")[0] == '1';
+  // (on by default; vio_estimator_set_resident / VIO_AMD_RESIDENT=0 turn it off); needs the device-resident priors.
+  bool resident = !(getenv("VIO_AMD_RESIDENT") && getenv("VIO_AMD_RESIDENT")[0] == '0');
   int res_list_cap = 0, res_obs_cap = 0;
   std::vector<int> res_rc;  // per sequence: outcome of staging in the current call
   std::vector<int> solving;  // sequences of the current launch
@@ -627,6 +627,32 @@ void remember_last(vio_estimator *e, Sequence &s) {  // VINS.cpp:431-434, 472-47
   memcpy(s.last_R_old, &s.Rs[0], 72), memcpy(s.last_P_old, &s.Ps[0], 24);
 }
 
+// The sequences are solved in n_groups contiguous groups, one back-end context each. Decided before the first solve.
+void regroup(vio_estimator *e) {
+  for (int g = 0; g < vio_estimator::kMaxGroups; g++)
+    if (e->be[g]) return;  // (contexts exist: slots and prior stores are bound to the grouping)
+  const int n_seq = e->n_seq;
+  {  // VIO_AMD_EST_GROUPS overrides the number of solve groups (1 = one launch for all sequences)
+    // Two groups by default: more groups only pay while every group's stream has a hardware queue of its own (HIP maps
+    // streams onto 4 queues by default; in a process that holds other streams — a torch process, say — four groups
+    // alias, two of the kernels serialize and the frame gets slower than with one group: 36 k instead of 48 k solves/s).
+    // groups of about 256 sequences (one window-kernel launch that fills every CU's two workgroup slots half), at least two
+    int ng = n_seq >= 64 ? std::max(2, (n_seq + 128) / 256) : 1;
+    // Resident sequences leave the host little to overlap with the kernel, and one launch of all windows fills the CUs'
+    // second workgroup slots by itself (measured, 512 sequences: 4.9 ms per frame with one group, 6.7 ms with two)
+    if (e->resident && e->resident_priors) ng = 1;
+    if (const char *env = getenv("VIO_AMD_EST_GROUPS")) {
+      char *end = nullptr;
+      const long val = strtol(env, &end, 10);
+      if (end == env || *end != '\0' || val < 1) fprintf(stderr, "vio_amd: VIO_AMD_EST_GROUPS=\"%s\" is not a positive number, ignored\n", env);
+      else ng = (int)std::min<long>(val, vio_estimator::kMaxGroups);
+    }
+    ng = std::max(1, std::min(std::min(ng, (int)vio_estimator::kMaxGroups), n_seq));
+    e->group_size = (n_seq + ng - 1) / ng;
+    e->n_groups = (n_seq + e->group_size - 1) / e->group_size;
+  }
+}
+
 // One published frame of every resident sequence: what processImage does with it, with the landmark work on the device.
 //   main thread   begin (per group)
 //   pool          per sequence: para_Pose / para_SpeedBias, the pre-integration blocks that changed, the observations -> staging
@@ -741,22 +767,7 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
   vio_estimator *e = new (std::nothrow) vio_estimator();
   if (!e) return VIO_ENOMEM;
   e->cfg = *cfg, e->W = cfg->window_size, e->n_seq = n_seq;
-  {  // VIO_AMD_EST_GROUPS overrides the number of solve groups (1 = one launch for all sequences)
-    // Two groups by default: more groups only pay while every group's stream has a hardware queue of its own (HIP maps
-    // streams onto 4 queues by default; in a process that holds other streams — a torch process, say — four groups
-    // alias, two of the kernels serialize and the frame gets slower than with one group: 36 k instead of 48 k solves/s).
-    // groups of about 256 sequences (one window-kernel launch that fills every CU's two workgroup slots half), at least two
-    int ng = n_seq >= 64 ? std::max(2, (n_seq + 128) / 256) : 1;
-    if (const char *env = getenv("VIO_AMD_EST_GROUPS")) {
-      char *end = nullptr;
-      const long val = strtol(env, &end, 10);
-      if (end == env || *end != '\0' || val < 1) fprintf(stderr, "vio_amd: VIO_AMD_EST_GROUPS=\"%s\" is not a positive number, ignored\n", env);
-      else ng = (int)std::min<long>(val, vio_estimator::kMaxGroups);
-    }
-    ng = std::max(1, std::min(std::min(ng, (int)vio_estimator::kMaxGroups), n_seq));
-    e->group_size = (n_seq + ng - 1) / ng;
-    e->n_groups = (n_seq + e->group_size - 1) / e->group_size;
-  }
+  regroup(e);
   memcpy(e->tic, tic, 24), memcpy(e->ric, ric, 72);
   const int W = e->W, P = W + 1, cap = vio_prior_capacity(W);
   e->seq.resize(n_seq);
@@ -807,6 +818,7 @@ int vio_estimator_set_resident(vio_estimator_t *e, int32_t enable) {
   if (!e) return VIO_EINVAL;
   if (enable && !e->resident_priors) return VIO_ESTATE;  // (VIO_AMD_HOST_PRIORS=1: the priors travel through the host)
   e->resident = enable != 0;
+  regroup(e);
   if (!e->resident)
     for (Sequence &s : e->seq) {
       const int rc = demote(e, s);
@@ -1099,6 +1111,7 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     if (ng == 0 || rc != VIO_OK) continue;
     if (!e->be[g]) {
       rc = vio_backend_create(&e->cfg, e->group_size, &e->be[g]);
+      if (rc == VIO_OK) rc = vio_backend_set_peers(e->be[g], e->n_groups);
       if (rc == VIO_OK && e->resident_priors) rc = vio_backend_reserve_priors(e->be[g], e->group_size);
     }
     if (rc == VIO_OK) rc = vio_backend_upload(e->be[g], e->windows.data() + g0[g], ng);

@@ -26,6 +26,9 @@ struct VioResidentResult {
   VioSolveStats stats;
 };
 
+// How many contexts launch their window kernels on the device at the same time (default 2, the estimator's two groups):
+// a launch gives every window half a CU once launches * windows exceed the CUs, a whole CU otherwise.
+int vio_backend_set_peers(vio_backend_t *be, int32_t peers);
 int vio_backend_resident_reserve(vio_backend_t *be, int32_t n_slots, int32_t list_cap, int32_t obs_cap, const double ex_pose[7],
                                  const double tic[3], const double ric[9]);
 int vio_backend_resident_caps(const vio_backend_t *be, int32_t *list_cap, int32_t *obs_cap);
