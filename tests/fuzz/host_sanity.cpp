@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "vio_amd.h"
+#include "vio_resident.h"
 
 extern "C" {  // stubs of the device side (this is not the product library)
 int vio_backend_create(const VioConfig *, int32_t, vio_backend_t **) { return VIO_ENODEV; }
@@ -30,6 +31,20 @@ void vio_config_default(VioConfig *c) {
   c->acc_n = 0.5, c->acc_w = 2e-3, c->gyr_n = 0.2, c->gyr_w = 4e-5, c->cauchy_a = 1.0;
 }
 }
+// the device-resident path of the back-end (vio_resident.h): no device, no resident sequences
+int vio_backend_set_peers(vio_backend_t *, int32_t) { return VIO_ENODEV; }
+int vio_backend_resident_reserve(vio_backend_t *, int32_t, int32_t, int32_t, const double *, const double *, const double *) { return VIO_ENODEV; }
+int vio_backend_resident_caps(const vio_backend_t *, int32_t *, int32_t *) { return VIO_ENODEV; }
+int vio_backend_resident_load(vio_backend_t *, int32_t, const VioFeatureInfo *, int32_t, const double *, const double *, const double *) { return VIO_ENODEV; }
+int vio_backend_resident_fetch(vio_backend_t *, int32_t, VioFeatureInfo *, int32_t, int32_t *, double *, int32_t, int32_t *) { return VIO_ENODEV; }
+int vio_backend_resident_begin(vio_backend_t *) { return VIO_ENODEV; }
+int vio_backend_resident_stage(vio_backend_t *, int32_t, const VioObs *, int32_t, const double *, const double *, const double *, const double *,
+                               const VioPrior *) { return VIO_ENODEV; }
+int vio_backend_resident_stage_preint(vio_backend_t *, int32_t, int32_t, const VioPreintegration *) { return VIO_ENODEV; }
+int vio_backend_resident_ingest(vio_backend_t *) { return VIO_ENODEV; }
+int vio_backend_resident_launch(vio_backend_t *) { return VIO_ENODEV; }
+int vio_backend_resident_collect(vio_backend_t *) { return VIO_ENODEV; }
+int vio_backend_resident_result(vio_backend_t *, int32_t, VioResidentResult *, VioPrior *) { return VIO_ENODEV; }
 
 static unsigned long long st = 0x9E3779B97F4A7C15ULL;
 static double urand() { st ^= st << 13, st ^= st >> 7, st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; }
