@@ -245,13 +245,13 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
       o.hdr = hdr.data(), o.feat = o_feat.data(), o.fhost = o_fhost.data(), o.ftarget = o_ftarget.data(), o.ffeat = o_ffeat.data();
       o.fslot = o_fslot.data(), o.fstart = o_fstart.data(), o.pair_h = o_ph.data(), o.pair_t = o_pt.data(), o.pair_s0 = o_s0.data(), o.pair_s1 = o_s1.data();
       o.pts_i = o_pi.data(), o.pts_j = o_pj.data(), o.Fcap = bd.Fcap, o.Mcap = bd.Mcap, o.pair_cap = bd.pair_cap, o.slot_cap = slot_capacity(bd);
-      std::vector<unsigned short> keys(bd.Mcap + 8, 0xffff);
-      std::vector<int> bins(2 * (P + 1) * (P + 1), -1);
+      std::vector<unsigned short> keys(bd.Mcap + 8, 0xffff), own(bd.Mcap + 8, 0xffff);
+      std::vector<int> bins(3 * (P + 1) * (P + 1), -1);
       st::Bank bk = S.bank(S.ctl[st::C_BANK]);
       st::Lds l = S.lds();
       simt::launch(st::kThreads, [&](int tid) {
         st::Cx cx{tid, st::kThreads};
-        st::store_pack(cx, S.d, bk, S.ctl.data(), l, o, chunk, keys.data(), bins.data());
+        st::store_pack(cx, S.d, bk, S.ctl.data(), l, o, chunk, keys.data(), own.data(), bins.data());
       }, order);
       if (S.ctl[st::C_STATUS] != VIO_OK) msg.add("frame %d: store_pack status %d", f, S.ctl[st::C_STATUS]);
       const int *hh = hb.hdr.data();

@@ -25,6 +25,7 @@ constexpr double kMinParallax = 10.0 / 549;  // MIN_PARALLAX (feature_manager.hp
 constexpr double kInitDepth = 5.0;           // INIT_DEPTH (feature_manager.hpp:24)
 constexpr int kMaxP = 32;                    // observation columns a landmark can have (window_size + 1 <= kMaxP)
 constexpr int kThreads = 256;
+constexpr int kTri = 64;                     // landmarks triangulated side by side (store_ingest)
 
 // control block of a sequence (ints)
 enum {
@@ -59,12 +60,14 @@ struct Lds {
   ldsi aux;    // [Ocap + 1]
   ldsi scanA;  // [Lcap + 1]
   ldsi scanB;  // [Lcap + 1]
-  ldsi part;   // [threads + 1]
+  ldsi part;   // [threads + 1 + threads / 16]
   ldsd term;   // [Lcap]
+  ldsd tri;    // [8 (W + 1)][kTri] row matrices of the landmarks being triangulated
   ldsi misc;   // [8]
+  long long *prof;  // null, or [32] cycle stamps of one workgroup's passes (VIO_AMD_STORE_PROF)
 };
 VIO_HD size_t lds_bytes(const Dims &d) {
-  return sizeof(int) * (3 * (size_t)d.Ocap + 1 + 2 * ((size_t)d.Lcap + 1) + kThreads + 1 + 8 + 8) + sizeof(double) * (size_t)d.Lcap + 64;
+  return sizeof(int) * (3 * (size_t)d.Ocap + 1 + 2 * ((size_t)d.Lcap + 1) + kThreads + 1 + kThreads / 16 + 8 + 8) + sizeof(double) * ((size_t)d.Lcap + 8 * ((size_t)d.W + 1) * kTri) + 64;
 }
 template <class PI, class PD>
 VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
@@ -76,18 +79,29 @@ VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
   l.aux = p, p += d.Ocap + 1;
   l.scanA = p, p += d.Lcap + 1;
   l.scanB = p, p += d.Lcap + 1;
-  l.part = p, p += kThreads + 1;
+  l.part = p, p += kThreads + 1 + kThreads / 16;
   l.misc = p, p += 8;
   size_t ints = (size_t)(p - ibase);
   ints = (ints + 1) & ~(size_t)1;
   *dbase_out = (PD)(ibase + ints);
   l.term = *dbase_out;
+  l.tri = l.term + d.Lcap;
+  l.prof = nullptr;
   return l;
 }
 
 struct Cx {
   int tid, nt;
 };
+
+#ifdef VIO_HOST_BUILD
+#define STORE_STAMP(l, k) ((void)0)
+#else
+#define STORE_STAMP(l, k)                                   \
+  do {                                                      \
+    if ((l).prof && cx.tid == 0) (l).prof[k] = clock64();   \
+  } while (0)
+#endif
 
 // out[i] = sum of val(k) for k < i, out[n] = the total (returned). Every work-item calls it.
 template <class F>
@@ -103,17 +117,31 @@ VIO_DEV int block_scan(const Cx &cx, int n, ldsi out, ldsi part, F val) {
   }
   part[t] = s;
   VIO_SYNC();
-  if (t == 0) {
+  // the work-items' partial sums: runs of 16 scanned by 16 work-items, then their totals by one (two short serial chains
+  // instead of one of nt links: an LDS round trip per link)
+  const int runs = (cx.nt + 15) >> 4;
+  if (t < runs) {
     int acc = 0;
-    for (int k = 0; k < cx.nt; k++) {
+    const int k1 = (t << 4) + 16 < cx.nt ? (t << 4) + 16 : cx.nt;
+    for (int k = t << 4; k < k1; k++) {
       const int v = part[k];
       part[k] = acc;
+      acc += v;
+    }
+    part[cx.nt + 1 + t] = acc;
+  }
+  VIO_SYNC();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < runs; k++) {
+      const int v = part[cx.nt + 1 + k];
+      part[cx.nt + 1 + k] = acc;
       acc += v;
     }
     part[cx.nt] = acc;
   }
   VIO_SYNC();
-  const int off = part[t];
+  const int off = part[t] + part[cx.nt + 1 + (t >> 4)];
   for (int i = b; i < e; i++) out[i] += off;
   if (t == 0) out[n] = part[cx.nt];
   VIO_SYNC();
@@ -124,7 +152,13 @@ VIO_DEV bool solved_in_window(int nobs, int start, int W) { return nobs >= 2 && 
 
 // Right singular vector of the smallest singular value of A (rows x 4): the one-sided Jacobi of vio_window.cpp, same
 // operations in the same order.
-VIO_DEV void smallest_right_singular_vector(double *A, int rows, double v_out[4]) {
+struct TriRows {         // element k of a work-item's row matrix: LDS, kTri apart
+  ldsd p;
+  VIO_DEV VIO_AS3 double &operator()(int k) const { return p[k * kTri]; }
+};
+
+template <class Rows>
+VIO_DEV void smallest_right_singular_vector(const Rows &A, int rows, double v_out[4]) {
   double V[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0;
@@ -132,7 +166,7 @@ VIO_DEV void smallest_right_singular_vector(double *A, int rows, double v_out[4]
       for (int q = p + 1; q < 4; q++) {
         double alpha = 0, beta = 0, gamma = 0;
         for (int i = 0; i < rows; i++) {
-          const double ap = A[i * 4 + p], aq = A[i * 4 + q];
+          const double ap = A(i * 4 + p), aq = A(i * 4 + q);
           alpha += ap * ap, beta += aq * aq, gamma += ap * aq;
         }
         if (gamma == 0.0) continue;
@@ -142,8 +176,8 @@ VIO_DEV void smallest_right_singular_vector(double *A, int rows, double v_out[4]
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
         for (int i = 0; i < rows; i++) {
-          const double ap = A[i * 4 + p], aq = A[i * 4 + q];
-          A[i * 4 + p] = c * ap - s * aq, A[i * 4 + q] = s * ap + c * aq;
+          const double ap = A(i * 4 + p), aq = A(i * 4 + q);
+          A(i * 4 + p) = c * ap - s * aq, A(i * 4 + q) = s * ap + c * aq;
         }
         for (int i = 0; i < 4; i++) {
           const double vp = V[i * 4 + p], vq = V[i * 4 + q];
@@ -156,7 +190,7 @@ VIO_DEV void smallest_right_singular_vector(double *A, int rows, double v_out[4]
   double bn = 1e300;
   for (int j = 0; j < 4; j++) {
     double nrm = 0;
-    for (int i = 0; i < rows; i++) nrm += A[i * 4 + j] * A[i * 4 + j];
+    for (int i = 0; i < rows; i++) nrm += A(i * 4 + j) * A(i * 4 + j);
     if (nrm < bn) bn = nrm, best = j;
   }
   for (int i = 0; i < 4; i++) v_out[i] = V[i * 4 + best];
@@ -169,6 +203,7 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
                           const double *Ps, const double *Rs, const double *tic, const double *ric) {
   const int W = d.W, P = W + 1, fc = W;
   const int t = VIO_TID(cx);
+  STORE_STAMP(l, 0);
   if (t == 0) l.misc[0] = VIO_OK, l.misc[1] = 0, l.misc[2] = 0, l.misc[3] = 0;
   VIO_SYNC();
   int n = ctl[C_N];
@@ -176,12 +211,15 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
     if (t == 0) ctl[C_STATUS] = n_obs < 0 ? VIO_EINVAL : VIO_ECAP;
     return;
   }
-  // image_msg is a std::map: ascending ids (a stable rank sort; equal ids are an argument error)
+  // image_msg is a std::map: ascending ids (a stable rank sort; equal ids are an argument error). The ids pass through LDS
+  // first: the rank loop reads every id once per observation, from global memory that is a cache line per id.
+  VIO_PARFOR(j, n_obs) l.scanA[j] = obs[j].id;
+  VIO_SYNC();
   VIO_PARFOR(j, n_obs) {
-    const int id = obs[j].id;
+    const int id = l.scanA[j];
     int r = 0;
     for (int k = 0; k < n_obs; k++) {
-      const int ik = obs[k].id;
+      const int ik = l.scanA[k];
       r += (ik < id) || (ik == id && k < j);
     }
     l.ids[r] = id, l.perm[r] = j, l.aux[r] = 0;
@@ -194,6 +232,7 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
     if (t == 0) ctl[C_STATUS] = l.misc[0];
     return;
   }
+  STORE_STAMP(l, 1);
   // known landmarks take their observation
   VIO_PARFOR(i, n) {
     const int id = bk.fid[i];
@@ -221,6 +260,7 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
     if (t == 0) ctl[C_STATUS] = l.misc[0];
     return;
   }
+  STORE_STAMP(l, 2);
   // new landmarks, in ascending id
   const int n_new = block_scan(cx, n_obs, l.scanA, l.part, [&](int j) { return l.aux[j] ? 0 : 1; });
   const int track = n_obs - n_new;
@@ -239,6 +279,7 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
   const int n_old = n;
   n += n_new;
   VIO_SYNC();
+  STORE_STAMP(l, 3);
   // compensatedParallax2 over the landmarks seen in the two frames before this one, summed in list order
   int enough = 1, pnum = 0;
   if (!(fc < 2 || track < 20)) {
@@ -258,67 +299,79 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
         term = 0.0 < r ? r : 0.0;
         has = 1;
       }
-      l.term[i] = term, l.scanA[i] = has;
+      l.term[i] = term;
+      if (has) __hip_atomic_fetch_add(&l.misc[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     VIO_SYNC();
     if (t == 0) {
+      const int cnt = l.misc[3];
+      // in list order, like the host loop; the landmarks that do not take part contribute +0.0, which leaves the sum's bits
       double sum = 0;
-      int cnt = 0;
-      for (int i = 0; i < n_old; i++)
-        if (l.scanA[i]) sum += l.term[i], cnt++;
+      for (int i = 0; i < n_old; i++) sum += l.term[i];
       l.misc[1] = cnt;
       l.misc[2] = cnt == 0 ? 1 : (sum / cnt >= kMinParallax ? 1 : 0);
     }
     VIO_SYNC();
     pnum = l.misc[1], enough = l.misc[2];
   }
-  // triangulate: landmarks of the window that have no depth yet
-  VIO_PARFOR(i, n) {
-    const int no = bk.nobs[i], s = bk.start[i];
-    if (!solved_in_window(no, s, W)) continue;
-    if (bk.depth[i] > 0) continue;
-    if (s + no - 1 > W) {
-      l.misc[0] = VIO_ESTATE;
-      continue;
-    }
-    double A[2 * kMaxP * 4];
-    double t0[3], R0[9], tmp[3];
-    mat3vec(Rs + 9 * s, tic, tmp);
-    for (int k = 0; k < 3; k++) t0[k] = Ps[3 * s + k] + tmp[k];
-    mat3mul(Rs + 9 * s, ric, R0);
-    int row = 0;
-    for (int jo = 0; jo < no; jo++) {
-      const int imu_j = s + jo;
-      const double *pt = bk.obs + ((size_t)i * P + jo) * 3;
-      double t1[3], R1[9], R0T[9], dd[3], tt[3], R[9], RT[9], mt[3];
-      mat3vec(Rs + 9 * imu_j, tic, tmp);
-      for (int k = 0; k < 3; k++) t1[k] = Ps[3 * imu_j + k] + tmp[k];
-      mat3mul(Rs + 9 * imu_j, ric, R1);
-      mat3T(R0, R0T);
-      for (int k = 0; k < 3; k++) dd[k] = t1[k] - t0[k];
-      mat3vec(R0T, dd, tt);
-      mat3mul(R0T, R1, R);
-      mat3T(R, RT);
-      mat3vec(RT, tt, mt);
-      double Pm[12];  // [R^T | -R^T t]
-      for (int a = 0; a < 3; a++) {
-        for (int b = 0; b < 3; b++) Pm[a * 4 + b] = RT[a * 3 + b];
-        Pm[a * 4 + 3] = -mt[a];
+  STORE_STAMP(l, 4);
+  // triangulate: landmarks of the window that have no depth yet. They are few (the ones that entered the window's solved
+  // range with this frame): listed first, then kTri at a time, one work-item each, the row matrix of the SVD in LDS
+  // (element-major across the work-items: conflict-free) instead of a per-thread array in scratch memory.
+  const int n_tri = block_scan(cx, n, l.scanA, l.part, [&](int i) {
+    return solved_in_window(bk.nobs[i], bk.start[i], W) && !(bk.depth[i] > 0) ? 1 : 0;
+  });
+  VIO_PARFOR(i, n)
+    if (l.scanA[i + 1] != l.scanA[i]) l.scanB[l.scanA[i]] = i;
+  VIO_SYNC();
+  for (int base = 0; base < n_tri; base += kTri) {
+    if (t < kTri && base + t < n_tri) {
+      const int i = l.scanB[base + t];
+      const int no = bk.nobs[i], s = bk.start[i];
+      if (s + no - 1 > W) {
+        l.misc[0] = VIO_ESTATE;
+      } else {
+        TriRows A{l.tri + t};
+        double t0[3], R0[9], tmp[3];
+        mat3vec(Rs + 9 * s, tic, tmp);
+        for (int k = 0; k < 3; k++) t0[k] = Ps[3 * s + k] + tmp[k];
+        mat3mul(Rs + 9 * s, ric, R0);
+        int row = 0;
+        for (int jo = 0; jo < no; jo++) {
+          const int imu_j = s + jo;
+          const double *pt = bk.obs + ((size_t)i * P + jo) * 3;
+          double t1[3], R1[9], R0T[9], dd[3], tt[3], R[9], RT[9], mt[3];
+          mat3vec(Rs + 9 * imu_j, tic, tmp);
+          for (int k = 0; k < 3; k++) t1[k] = Ps[3 * imu_j + k] + tmp[k];
+          mat3mul(Rs + 9 * imu_j, ric, R1);
+          mat3T(R0, R0T);
+          for (int k = 0; k < 3; k++) dd[k] = t1[k] - t0[k];
+          mat3vec(R0T, dd, tt);
+          mat3mul(R0T, R1, R);
+          mat3T(R, RT);
+          mat3vec(RT, tt, mt);
+          double Pm[12];  // [R^T | -R^T t]
+          for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) Pm[a * 4 + b] = RT[a * 3 + b];
+            Pm[a * 4 + 3] = -mt[a];
+          }
+          const double nrm = sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+          const double fx = pt[0] / nrm, fy = pt[1] / nrm, fz = pt[2] / nrm;
+          for (int b = 0; b < 4; b++) A(row * 4 + b) = fx * Pm[2 * 4 + b] - fz * Pm[0 * 4 + b];
+          row++;
+          for (int b = 0; b < 4; b++) A(row * 4 + b) = fy * Pm[2 * 4 + b] - fz * Pm[1 * 4 + b];
+          row++;
+        }
+        double v[4];
+        smallest_right_singular_vector(A, row, v);
+        double dep = v[2] / v[3];
+        if (dep < 0.1) dep = kInitDepth;
+        bk.depth[i] = dep;
       }
-      const double nrm = sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
-      const double fx = pt[0] / nrm, fy = pt[1] / nrm, fz = pt[2] / nrm;
-      for (int b = 0; b < 4; b++) A[row * 4 + b] = fx * Pm[2 * 4 + b] - fz * Pm[0 * 4 + b];
-      row++;
-      for (int b = 0; b < 4; b++) A[row * 4 + b] = fy * Pm[2 * 4 + b] - fz * Pm[1 * 4 + b];
-      row++;
     }
-    double v[4];
-    smallest_right_singular_vector(A, row, v);
-    double dep = v[2] / v[3];
-    if (dep < 0.1) dep = kInitDepth;
-    bk.depth[i] = dep;
   }
   VIO_SYNC();
+  STORE_STAMP(l, 5);
   // para_Feature rows and factors of this window
   const int F = block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
   const int M = block_scan(cx, n, l.scanB, l.part,
@@ -328,12 +381,13 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
     ctl[C_MARG] = enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW;
     ctl[C_TRACK] = track, ctl[C_PNUM] = pnum, ctl[C_F] = F, ctl[C_M] = M;
   }
+  STORE_STAMP(l, 6);
 }
 
 // ---- pass 2 -----------------------------------------------------------------------------------------------------------
 // What build_window + pack_window leave in the batch arrays for the landmark side of window b: para_Feature, the factor
 // list (grouped by landmark, host = start frame, one factor per later observation), fstart, and the (host, target) buckets
-// with their even-padded, chunk-aligned staging slots. keys: [Mcap] unsigned short scratch in LDS.
+// with their even-padded, chunk-aligned staging slots. keys / own: unsigned short scratch in LDS.
 struct PackOut {
   int *hdr;  // [kHdrInts] of window b: H_F, H_M, H_MARG, H_NPAIRS, H_NSLOTS, H_NREV, H_HAS_LOOP, H_LOOP_FRAME are written here
   double *feat;
@@ -345,49 +399,65 @@ struct PackOut {
 enum { PH_F = 1, PH_M = 2, PH_HAS_LOOP = 3, PH_LOOP_FRAME = 4, PH_MARG = 5, PH_NPAIRS = 9, PH_NSLOTS = 10, PH_NREV = 11 };  // = batch.h H_*
 
 VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, const Lds &l, const PackOut &o, int chunk,
-                        VIO_AS3 unsigned short *keys, ldsi bins /* [2 (P+1)^2] */) {
-  const int W = d.W, P = W + 1, np1 = P + 1;
+                        VIO_AS3 unsigned short *keys /* [Mcap + 8] */, VIO_AS3 unsigned short *own /* [Mcap + 8] */,
+                        ldsi bins /* [3 (P+1)^2] */) {
+  const int W = d.W, P = W + 1, np1 = P + 1, nkeys = np1 * np1;
   const int t = VIO_TID(cx);
   const int n = ctl[C_N];
   if (ctl[C_STATUS] != VIO_OK) return;
+  STORE_STAMP(l, 8);
   const int F = block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
   const int M = block_scan(cx, n, l.scanB, l.part,
                            [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? bk.nobs[i] - 1 : 0; });
+  STORE_STAMP(l, 9);
   if (F > o.Fcap || M > o.Mcap) {
     if (t == 0) ctl[C_STATUS] = VIO_ECAP;
     return;
   }
-  VIO_PARFOR(k, 2 * np1 * np1) bins[k] = 0;
-  VIO_SYNC();
-  ldsi cnt = bins, start = bins + np1 * np1;
+  ldsi cnt = bins, start = bins + nkeys, pkey = bins + 2 * nkeys;
+  // start frame and observation count of every landmark of the window, two bytes each (0xffff: not in the window)
+  VIO_AS3 unsigned short *ent = (VIO_AS3 unsigned short *)l.term;
+  VIO_PARFOR(k, nkeys) cnt[k] = 0;
+  // per landmark: its para_Feature row, its factor range, and for each of its factors who owns it and which bucket it is in
   VIO_PARFOR(i, n) {
     const int no = bk.nobs[i], s = bk.start[i];
-    if (!solved_in_window(no, s, W)) continue;
+    if (!solved_in_window(no, s, W)) {
+      ent[i] = 0xffff;
+      continue;
+    }
+    ent[i] = (unsigned short)(s << 8 | no);
     const int fi = l.scanA[i], k0 = l.scanB[i];
     o.feat[fi] = 1. / bk.depth[i];
     o.fstart[fi] = k0;
-    const double *p0 = bk.obs + (size_t)i * P * 3;
-    for (int j = 1; j < no; j++) {
-      const int k = k0 + j - 1;
-      o.fhost[k] = s, o.ftarget[k] = s + j, o.ffeat[k] = fi;
-      const double *pj = p0 + 3 * j;
-      for (int c = 0; c < 3; c++) o.pts_i[3 * k + c] = p0[c], o.pts_j[3 * k + c] = pj[c];
-      keys[k] = (unsigned short)(s * np1 + s + j);
-      __hip_atomic_fetch_add(&cnt[s * np1 + s + j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    for (int j = 1; j < no; j++) keys[k0 + j - 1] = (unsigned short)(s * np1 + s + j), own[k0 + j - 1] = (unsigned short)i;
   }
+  VIO_PARFOR(i, 4) ent[n + i] = 0xffff;  // (the slot pass reads four landmarks at a time)
   if (t == 0) o.fstart[F] = M;
   VIO_SYNC();
-  // buckets in (host, target) order; every bucket starts on an even slot and does not straddle a staging chunk
+  // per factor: host, target, landmark row, the two observations
+  VIO_PARFOR(k, M) {
+    const int i = own[k], key = keys[k];
+    const int s = key / np1, j = key - s * np1 - s;
+    const double *p0 = bk.obs + (size_t)i * P * 3, *pj = p0 + 3 * j;
+    const double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = pj[0], b1 = pj[1], b2 = pj[2];
+    o.fhost[k] = s, o.ftarget[k] = s + j, o.ffeat[k] = l.scanA[i];
+    o.pts_i[3 * k] = a0, o.pts_i[3 * k + 1] = a1, o.pts_i[3 * k + 2] = a2;
+    o.pts_j[3 * k] = b0, o.pts_j[3 * k + 1] = b1, o.pts_j[3 * k + 2] = b2;
+    __hip_atomic_fetch_add(&cnt[key], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  VIO_SYNC();
+  STORE_STAMP(l, 10);
+  // buckets in (host, target) order; every bucket starts on an even slot and does not straddle a staging chunk. The
+  // occupied buckets are listed first (a scan), the slot recurrence then walks that short list.
+  const int npairs = block_scan(cx, nkeys, l.scanA, l.part, [&](int key) { return cnt[key] ? 1 : 0; });
+  VIO_PARFOR(key, nkeys)
+    if (cnt[key]) pkey[l.scanA[key]] = key;
+  VIO_SYNC();
   if (t == 0) {
-    int npairs = 0, slot = 0, rc = VIO_OK;
-    for (int key = 0; key < np1 * np1 && rc == VIO_OK; key++) {
+    int slot = 0, rc = npairs > o.pair_cap ? VIO_ECAP : VIO_OK;
+    for (int pi = 0; pi < npairs && rc == VIO_OK; pi++) {
+      const int key = pkey[pi];
       const int c = cnt[key];
-      if (!c) continue;
-      if (npairs >= o.pair_cap) {
-        rc = VIO_ECAP;
-        break;
-      }
       const int cpad = (c + 1) & ~1;
       if (chunk > 0 && cpad <= chunk && slot % chunk + cpad > chunk) slot = (slot / chunk + 1) * chunk;
       if ((size_t)slot + cpad > o.slot_cap) {
@@ -395,27 +465,34 @@ VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, c
         break;
       }
       start[key] = slot;
-      o.pair_h[npairs] = key / np1, o.pair_t[npairs] = key % np1;
-      o.pair_s0[npairs] = slot, o.pair_s1[npairs] = slot + c;
-      l.scanB[npairs] = key;  // (the landmark scans are done with; pair_cap <= Lcap is the caller's check)
       slot += cpad;
-      npairs++;
     }
-    l.misc[4] = npairs, l.misc[5] = slot, l.misc[6] = rc;
+    l.misc[5] = slot, l.misc[6] = rc;
   }
   VIO_SYNC();
-  const int npairs = l.misc[4];
+  STORE_STAMP(l, 11);
   if (l.misc[6] != VIO_OK) {
     if (t == 0) ctl[C_STATUS] = l.misc[6];
     return;
   }
-  // slot of every factor: its bucket's start + its rank inside the bucket in factor order (one work-item per bucket)
+  // One work-item per bucket: its header, and the slot of every factor in it = the bucket's start + the factor's rank in
+  // factor order. A landmark has at most one factor per bucket and the factors follow the landmarks' order, so the rank is
+  // the number of earlier landmarks hosted in the bucket's host frame that reach its target frame.
   VIO_PARFOR(pi, npairs) {
-    const int key = l.scanB[pi];
+    const int key = pkey[pi];
+    const int h = key / np1, dt = key - h * np1 - h;
     int s = start[key];
-    for (int k = 0; k < M; k++)
-      if (keys[k] == key) o.fslot[k] = s++;
+    o.pair_h[pi] = h, o.pair_t[pi] = h + dt, o.pair_s0[pi] = s, o.pair_s1[pi] = s + cnt[key];
+    for (int i = 0; i < n; i += 4) {
+      const unsigned long long q = *(const VIO_AS3 unsigned long long *)(ent + i);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int e = (int)((q >> (16 * c)) & 0xffff);
+        if ((e >> 8) == h && (e & 0xff) > dt) o.fslot[l.scanB[i + c] + dt - 1] = s++;
+      }
+    }
   }
+  STORE_STAMP(l, 12);
   if (t == 0) {
     o.hdr[PH_F] = F, o.hdr[PH_M] = M, o.hdr[PH_HAS_LOOP] = 0, o.hdr[PH_LOOP_FRAME] = -1, o.hdr[PH_MARG] = ctl[C_MARG];
     o.hdr[PH_NPAIRS] = npairs, o.hdr[PH_NSLOTS] = l.misc[5], o.hdr[PH_NREV] = 0;
@@ -451,6 +528,7 @@ VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Ban
   const int n = ctl[C_N];
   if (ctl[C_STATUS] != VIO_OK) return;
   const int marg = ctl[C_MARG];
+  STORE_STAMP(l, 16);
   block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
   if (t == 0) {
     double Rn[9];
@@ -466,6 +544,7 @@ VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Ban
     }
   }
   VIO_SYNC();
+  STORE_STAMP(l, 17);
   if (l.misc[0]) return;
   double mR[9], mP[3], nR[9], nP[3];
   if (marg == VIO_MARGIN_OLD) {
@@ -519,6 +598,7 @@ VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Ban
     bk.flag[i] = (s & 0xff) | ((drop >= 0 ? no - 1 : no) & 0xff) << 8 | (fl & 3) << 16 | ((drop + 1) & 0xff) << 18;
   }
   VIO_SYNC();
+  STORE_STAMP(l, 18);
   // (scanA is read above through x[...]: the survivors' positions go to a scan of their own)
   const int n_alive = block_scan(cx, n, l.scanA, l.part, [&](int i) { return l.scanB[i]; });
   VIO_PARFOR(i, n) {
@@ -535,6 +615,7 @@ VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Ban
       cc++;
     }
   }
+  STORE_STAMP(l, 19);
   if (t == 0) ctl[C_N] = n_alive, ctl[C_BANK] ^= 1;
 }
 

@@ -26,6 +26,7 @@ struct StoreDev {
   const int *pre_idx;              // [n_pre] slot * W + interval of every block that arrives with this frame
   const double *pre_blk;           // [n_pre][kPreintDoubles]
   int n_pre;
+  long long *prof;                 // null, or [32] cycle stamps written by slot 0's workgroups
 };
 
 int store_launch_ingest(const StoreDev &S, hipStream_t st);

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(st::kThreads) void store_ingest_kernel(StoreDev S) 
   if (!S.active[slot]) return;
   st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
   ldsd dbase;
-  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  if (slot == 0) l.prof = S.prof;
   int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
   const int P = S.d.W + 1;
   st::store_ingest(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, S.obs_in + (size_t)slot * S.d.Ocap, S.n_obs[slot],
@@ -43,11 +44,13 @@ __global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, Ba
   if (!S.active[slot]) return;
   st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
   ldsd dbase;
-  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  if (slot == 0) l.prof = S.prof;
   // behind the store's own scratch: bucket counters and the factor keys
   const int np1 = S.d.W + 2;
-  ldsi bins = (ldsi)(dbase + S.d.Lcap);
-  VIO_AS3 unsigned short *keys = (VIO_AS3 unsigned short *)(bins + 2 * np1 * np1);
+  ldsi bins = (ldsi)(l.tri + 8 * (S.d.W + 1) * st::kTri);
+  VIO_AS3 unsigned short *keys = (VIO_AS3 unsigned short *)(bins + 3 * np1 * np1 + (np1 & 1));
+  VIO_AS3 unsigned short *own = keys + ((B.d.Mcap + 8 + 3) & ~3);
   int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
   const BatchStrides &s = B.s;
   const size_t b = slot;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, Ba
   o.pair_s0 = const_cast<int *>(B.pair_s0) + b * s.pair, o.pair_s1 = const_cast<int *>(B.pair_s1) + b * s.pair;
   o.pts_i = const_cast<double *>(B.pts_i) + b * s.pts, o.pts_j = const_cast<double *>(B.pts_j) + b * s.pts;
   o.Fcap = B.d.Fcap, o.Mcap = B.d.Mcap, o.pair_cap = B.d.pair_cap, o.slot_cap = 2 * (size_t)B.d.Mcap + B.d.pair_cap + 2;  // = slot_capacity(B.d) (batch.h, host function)
-  st::store_pack(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, o, chunk, keys, bins);
+  st::store_pack(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, o, chunk, keys, own, bins);
 }
 
 __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, BatchPtrs B) {
@@ -70,7 +73,8 @@ __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, 
   if (!S.active[slot]) return;
   st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
   ldsd dbase;
-  const st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
+  if (slot == 0) l.prof = S.prof;
   int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
   const BatchStrides &s = B.s;
   const int bank = ctl[st::C_BANK];
@@ -81,10 +85,28 @@ __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, 
   // slideWindow, MARGIN_OLD: the pre-integration of interval i + 1 becomes that of interval i (VINS.cpp:1160-1187); the
   // newest interval arrives with the next frame
   if (ctl[st::C_STATUS] == VIO_OK && ctl[st::C_FAIL] == 0 && ctl[st::C_MARG] == VIO_MARGIN_OLD) {
+    // (every work-item reads what it moves before anything is written: one barrier, not one per interval)
     double *pre = S.preint + (size_t)slot * S.d.W * kPreintDoubles;
-    for (int i = 0; i + 1 < S.d.W; i++) {
-      for (int k = threadIdx.x; k < kPreintDoubles; k += blockDim.x) pre[(size_t)i * kPreintDoubles + k] = pre[(size_t)(i + 1) * kPreintDoubles + k];
+    const int total = (S.d.W - 1) * kPreintDoubles;
+    constexpr int kPer = 24;  // doubles per work-item: enough for W <= 13 at 256 work-items
+    if (total <= kPer * (int)blockDim.x) {
+      double v[kPer];
+#pragma unroll
+      for (int j = 0; j < kPer; j++) {
+        const int k = threadIdx.x + j * blockDim.x;
+        if (k < total) v[j] = pre[kPreintDoubles + k];
+      }
       __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kPer; j++) {
+        const int k = threadIdx.x + j * blockDim.x;
+        if (k < total) pre[k] = v[j];
+      }
+    } else {
+      for (int i = 0; i + 1 < S.d.W; i++) {
+        for (int k = threadIdx.x; k < kPreintDoubles; k += blockDim.x) pre[(size_t)i * kPreintDoubles + k] = pre[(size_t)(i + 1) * kPreintDoubles + k];
+        __syncthreads();
+      }
     }
   }
 }
@@ -95,7 +117,7 @@ namespace vio {
 
 size_t store_pack_lds_bytes(const store::Dims &d, int Mcap) {
   const int np1 = d.W + 2;
-  return st::lds_bytes(d) + sizeof(int) * 2 * np1 * np1 + sizeof(unsigned short) * ((size_t)Mcap + 8);
+  return st::lds_bytes(d) + sizeof(int) * (3 * np1 * np1 + 1) + 2 * sizeof(unsigned short) * ((size_t)Mcap + 12);
 }
 
 #define STORE_HIP_OK(expr)                                                                                      \
