@@ -303,6 +303,11 @@ int vio_frontend_read_images(vio_frontend_t *fe, const uint8_t *gray, int32_t ro
  * VIO_ESTATE, as is collect without submit.                                    */
 int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows,
                                int32_t cols, int32_t stride, int32_t publish);
+/* vio_frontend_submit_images with the submit's own host work (gathering the frames into page-locked memory, queueing
+ * transfers and kernels) on a host thread the context owns: returns at once; `gray` must stay valid and unchanged until
+ * vio_frontend_collect, which also reports an error of the submit. */
+int vio_frontend_submit_images_async(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride,
+                                     int32_t publish);
 int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs /* [n_seq][max_corners] */,
                          int32_t *n_obs /* [n_seq] */);
 

@@ -9,7 +9,9 @@ the observations the estimator receives are the ones the front-end publishes and
 
     tools/time_pipeline.py [n_seq] [n_frames] [overlap] [freq]
         overlap = 1: the front-end of camera frame k+1 is submitted before the estimator of frame k runs
-                     (vio_frontend_submit_images / vio_frontend_collect), 0: strictly one call after the other
+                     (vio_frontend_submit_images / vio_frontend_collect), 0: strictly one call after the other,
+                     2: the same with vio_frontend_submit_images_async (the gathering of the pageable frames and the queueing
+                     run on the context's own host thread, under the estimator call)
         freq    = 1: every camera frame is published and solved (the convention of bench.py's headline number),
                   3: the app's cadence, FREQ = 3 (global_param.hpp:33, ViewController.mm:467,494): the tracker runs on every
                      camera frame, every third one is published to the estimator; n_frames counts published frames
@@ -71,7 +73,8 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
         assert rc == 0, rc
 
     def fe_submit(c):
-        rc = lib.vio_frontend_submit_images(fe._h, frames[c].ctypes.data_as(_u8p), rows, cols, cols, int(c % freq == 0))
+        submit = lib.vio_frontend_submit_images_async if int(overlap) == 2 else lib.vio_frontend_submit_images
+        rc = submit(fe._h, frames[c].ctypes.data_as(_u8p), rows, cols, cols, int(c % freq == 0))
         assert rc == 0, rc
 
     def fe_collect():
@@ -130,7 +133,7 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
            "ms_per_published_frame_of_all_sequences": per_frame * 1e3,
            "camera_frames_per_s": n_seq * freq / per_frame, "solves_per_s": n_seq / per_frame,
            "ms_frontend_calls": float(np.mean(t_fe[steady])) * 1e3,
-           "ms_estimator_calls": float(np.mean(t_est[steady])) * 1e3, "overlap": bool(have_async),
+           "ms_estimator_calls": float(np.mean(t_est[steady])) * 1e3, "overlap": int(overlap) if have_async else 0,
            "mean_published_features": float(np.mean(tracked[steady])), "position_error_m_max": max(errs)}
     if not quiet:
         print(out)
@@ -139,5 +142,5 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    run(int(a[0]) if a else 256, int(a[1]) if len(a) > 1 else 22, bool(int(a[2])) if len(a) > 2 else True,
+    run(int(a[0]) if a else 256, int(a[1]) if len(a) > 1 else 22, int(a[2]) if len(a) > 2 else 1,
         freq=int(a[3]) if len(a) > 3 else 1)

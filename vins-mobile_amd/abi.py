@@ -458,6 +458,7 @@ def load_product():
                                              C.POINTER(VioObs), _ip]
     lib.vio_hip_runtime.argtypes = [C.c_char_p, C.c_int32, _ip]
     lib.vio_frontend_submit_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.vio_frontend_submit_images_async.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_collect.argtypes = [vp, C.POINTER(VioObs), _ip]
     lib.vio_frontend_upload_frames.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_step_resident.argtypes = [vp, C.c_int32, C.c_int32, vp]

@@ -22,6 +22,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "vio_amd.h"
@@ -1395,6 +1398,16 @@ struct vio_frontend {
   VioObs *p_obs = nullptr;
   uint8_t *p_frames = nullptr;  // page-locked gathering buffer of read_images
   bool pending = false, pending_publish = false;  // a submitted frame waits for vio_frontend_collect
+  // vio_frontend_submit_images_async: the submit itself (gather + transfers + launches) runs on this context's own host
+  // thread, the caller returns at once; collect waits for it first
+  struct Async {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool has_job = false, busy = false, quit = false;
+    const uint8_t *gray = nullptr;
+    int rows = 0, cols = 0, stride = 0, publish = 0, rc = VIO_OK;
+  } *async = nullptr;
   int *p_nobs = nullptr;
   // host staging
   std::vector<VioObs> h_obs;
@@ -1671,6 +1684,15 @@ int vio_frontend_get_device(const vio_frontend_t *fe, int32_t *device) {
 
 void vio_frontend_destroy(vio_frontend_t *fe) {
   if (!fe) return;
+  if (fe->async) {
+    {
+      std::lock_guard<std::mutex> lk(fe->async->m);
+      fe->async->quit = true;
+    }
+    fe->async->cv.notify_all();
+    if (fe->async->th.joinable()) fe->async->th.join();
+    delete fe->async;
+  }
   vio::DeviceScope scope(fe->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {fe->pyr[0], fe->pyr[1], fe->mask, fe->max_bits, fe->cand, fe->n_cand, fe->cur_pts, fe->pre_pts,
@@ -1750,10 +1772,7 @@ int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches
 // transfer, every kernel of the frame and the copy of the published observations on the context's stream and returns
 // without waiting for the device; collect: waits and hands the observations over. A caller that submits frame k+1 before
 // it runs the estimator on frame k overlaps the front-end's transfers and kernels with the estimator's host phases.
-int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride, int32_t publish) {
-  if (!fe || !gray) return VIO_EINVAL;
-  if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
-  if (fe->pending) return VIO_ESTATE;  // one frame in flight per context: collect it first
+static int submit_body(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride, int32_t publish) {
   VIO_ON_DEVICE_OF(fe);
   const size_t px = (size_t)rows * cols, S = fe->n_seq;
   // host frames land in a device staging buffer kept for the life of the context; observations come back through
@@ -1790,6 +1809,55 @@ int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t 
     HIP_OK(hipMemcpyAsync(fe->p_obs, fe->obs, sizeof(VioObs) * S * fe->cap, hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(fe->p_nobs, fe->n_obs, sizeof(int) * S, hipMemcpyDeviceToHost, st));
   }
+  return VIO_OK;
+}
+
+int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride, int32_t publish) {
+  if (!fe || !gray) return VIO_EINVAL;
+  if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;  // one frame in flight per context: collect it first
+  const int rc = submit_body(fe, gray, rows, cols, stride, publish);
+  if (rc != VIO_OK) return rc;
+  fe->pending = true, fe->pending_publish = publish != 0;
+  return VIO_OK;
+}
+
+// The same with the submit's host work (gathering the frames into page-locked memory, queueing the transfers and the
+// kernels) on the context's own host thread: the call returns at once, `gray` must stay valid and unchanged until
+// vio_frontend_collect, which reports what the submit returned.
+int vio_frontend_submit_images_async(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, int32_t cols, int32_t stride, int32_t publish) {
+  if (!fe || !gray) return VIO_EINVAL;
+  if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;
+  try {
+    if (!fe->async) {
+      fe->async = new vio_frontend::Async();
+      vio_frontend::Async *a = fe->async;
+      a->th = std::thread([fe, a] {
+        for (;;) {
+          std::unique_lock<std::mutex> lk(a->m);
+          a->cv.wait(lk, [&] { return a->quit || a->has_job; });
+          if (a->quit) return;
+          a->has_job = false;
+          lk.unlock();
+          const int rc = submit_body(fe, a->gray, a->rows, a->cols, a->stride, a->publish);
+          lk.lock();
+          a->rc = rc, a->busy = false;
+          lk.unlock();
+          a->cv.notify_all();
+        }
+      });
+    }
+  } catch (...) {
+    return VIO_ENOMEM;
+  }
+  vio_frontend::Async *a = fe->async;
+  {
+    std::lock_guard<std::mutex> lk(a->m);
+    a->gray = gray, a->rows = rows, a->cols = cols, a->stride = stride, a->publish = publish;
+    a->has_job = true, a->busy = true, a->rc = VIO_OK;
+  }
+  a->cv.notify_all();
   fe->pending = true, fe->pending_publish = publish != 0;
   return VIO_OK;
 }
@@ -1798,6 +1866,15 @@ int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs, int32_t *n_obs) {
   if (!fe || !n_obs) return VIO_EINVAL;
   if (!fe->pending) return VIO_ESTATE;
   if (fe->pending_publish && !out_obs) return VIO_EINVAL;
+  if (fe->async) {  // an asynchronous submit finishes queueing first
+    vio_frontend::Async *a = fe->async;
+    std::unique_lock<std::mutex> lk(a->m);
+    a->cv.wait(lk, [&] { return !a->busy; });
+    if (a->rc != VIO_OK) {
+      fe->pending = false;
+      return a->rc;
+    }
+  }
   VIO_ON_DEVICE_OF(fe);
   fe->pending = false;
   HIP_OK(hipStreamSynchronize(fe->stream));
