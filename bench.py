@@ -454,49 +454,60 @@ def small_batches(cfg, pkg, windows):
 
 
 # ---- secondary measurements ------------------------------------------------------------------------------------
-def _tool(code):
+def _tool(code, env=None):
     """Runs a tools/ measurement in a fresh interpreter WITHOUT torch and returns the JSON it prints last. The library
     binds to whichever libamdhip64 the process loaded first: next to torch that is torch's bundled ROCm 7.0 runtime, on
     which the estimator path (many small transfers and launches per frame) measures ~10 % slower than on /opt/rocm's 7.2.
     A C++ caller of the C ABI has no torch in its process; the contract line above is kernel time and unaffected."""
     import subprocess
     r = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); " % os.path.join(ROOT, "tools") + code],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-400:])
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def end_to_end(n_seq):
-    """The estimator path (csrc/vio_estimator.cpp): per frame, host observations + IMU in, host states out — landmark
-    bookkeeping, window assembly, packing, H2D, ONE window-kernel launch for all sequences, D2H, slides."""
-    a = _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, 24, quiet=True); print(json.dumps([s, l]))" % n_seq)
-    b = _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, 20, quiet=True); print(json.dumps([s, l]))" % (4 * n_seq))
+    """The estimator path (csrc/vio_estimator.cpp): per frame, host observations + IMU in, host states out. Sequences in the
+    NON_LINEAR state keep their landmark lists on the device (vio_estimator_set_resident, the default): observations and
+    propagated states up, store_ingest / store_pack / ONE window-kernel launch for all sequences / store_finish, states
+    back. `host_side_lists`: the same with the lists, the window assembly and the packing on the host (VIO_AMD_RESIDENT=0)."""
+    run = lambda n, frames, env=None: _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, %d, quiet=True); print(json.dumps([s, l]))"
+                                            % (n, frames), env)
+    a, b, c = run(n_seq, 24), run(2 * n_seq, 22), run(4 * n_seq, 20)
+    h = run(n_seq, 24, {"VIO_AMD_RESIDENT": "0"})
     solves, lib_s = a
+    per = lambda r, n: {"value": r[0] / r[1], "ms_per_frame_of_all_sequences": r[1] / (r[0] // n) * 1e3}
     return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
             "frames_timed": solves // n_seq, "path": "vio_estimator_process_imu_batch + vio_estimator_process_images, one estimator "
-            "object on one host thread (it solves its sequences in 2 groups on their own streams so that packing overlaps the "
-            "kernels), host buffers in / host states out, priors resident on the device; time inside the two "
-            "library calls (closed-loop windows: ~190 landmarks, ~1400 factors, prior); measured in a process of its own",
+            "object on one host thread, host buffers in / host states out; landmark lists, pre-integration blocks and priors "
+            "resident on the device, window assembly by kernels (store_core.h); time inside the two library calls "
+            "(closed-loop windows: ~190 landmarks, ~1400 factors, prior); measured in a process of its own",
             "ms_per_frame_of_all_sequences": lib_s / (solves // n_seq) * 1e3,
-            "at_%d_sequences" % (4 * n_seq): {"value": b[0] / b[1], "groups_of_sequences": 4, "ms_per_frame_of_all_sequences": b[1] / (b[0] // (4 * n_seq)) * 1e3}}
+            "at_%d_sequences" % (2 * n_seq): per(b, 2 * n_seq), "at_%d_sequences" % (4 * n_seq): per(c, 4 * n_seq),
+            "host_side_lists": dict(per(h, n_seq), sequences=n_seq, note="VIO_AMD_RESIDENT=0: FeatureManager lists, window assembly "
+                                    "and packing on the host pool, ~125 KB of upload per window (round 3's path)")}
 
 
 def end_to_end_full(n_seq):
-    """The WHOLE pipeline through the C ABI (tools/time_pipeline.py): pageable host frames -> vio_frontend_submit_images /
+    """The WHOLE pipeline through the C ABI (tools/time_pipeline.py): pageable host frames -> vio_frontend_submit_images_async /
     vio_frontend_collect -> observations -> vio_estimator_process_imu_batch + vio_estimator_process_images -> host states;
     frames rendered from textured planes along synthetic trajectories, so the estimator receives what the tracker
     publishes. `value`: every camera frame published and solved (the headline's convention); `app_cadence_freq3`: the
     app's FREQ = 3, every third camera frame published."""
-    run = lambda frames, overlap, freq: _tool("import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %s, quiet=True, freq=%d)))"
-                                              % (n_seq, frames, overlap, freq))
-    every, serial, app = run(20, True, 1), run(20, False, 1), run(18, True, 3)
+    run = lambda n, frames, overlap, freq, env=None: _tool(
+        "import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %d, quiet=True, freq=%d)))" % (n, frames, overlap, freq), env)
+    every, twice, sync_submit, serial, app = run(n_seq, 28, 2, 1), run(2 * n_seq, 26, 2, 1), run(n_seq, 22, 1, 1), run(n_seq, 22, 0, 1), run(n_seq, 20, 2, 3)
+    host_lists = run(n_seq, 22, 1, 1, {"VIO_AMD_RESIDENT": "0"})
     return {"value": every["camera_frames_per_s"], "unit": "camera frames/s, every frame published and solved", "sequences": n_seq,
-            "path": "pageable frames in -> vio_frontend_submit_images (gather to page-locked memory on the host pool, H2D, kernels, "
-                    "D2H queued) -> vio_frontend_collect -> vio_estimator_process_imu_batch -> vio_estimator_process_images -> host "
-                    "states; frame k+1 is submitted before the estimator of frame k runs; one host thread drives both contexts; "
+            "path": "pageable frames in -> vio_frontend_submit_images_async (gather to page-locked memory, H2D, kernels and the D2H "
+                    "of the observations queued by the context's own host thread) -> vio_frontend_collect -> "
+                    "vio_estimator_process_imu_batch -> vio_estimator_process_images (resident landmark stores) -> host states; "
+                    "frame k+1 is submitted before the estimator of frame k runs; one host thread drives both contexts; "
                     "measured in a process of its own",
-            "every_frame_published": every, "one_call_after_the_other": serial, "app_cadence_freq3": app}
+            "every_frame_published": every, "at_%d_sequences" % (2 * n_seq): twice, "synchronous_submit": sync_submit,
+            "one_call_after_the_other": serial, "app_cadence_freq3": app,
+            "host_side_lists_synchronous_submit": host_lists}
 
 
 def se3_align_rmse(est, ref):

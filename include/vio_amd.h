@@ -649,6 +649,8 @@ typedef struct VioEstimatorStatus {
   double final_cost;
   double r_drift[9], t_drift[3];                 /* VINS.hpp r_drift / t_drift    */
   double relative_t[3], relative_q[4], relative_yaw, loop_pose[7]; /* front_pose  */
+  int32_t resident;             /* 1: the landmark list lives in the device store */
+  int32_t reserved;
 } VioEstimatorStatus;
 
 /* tic [3], ric [9] row-major: the camera-to-body extrinsic (TIC_*, RIC_*).     */

@@ -316,7 +316,9 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
     est, world = loop.est, loop.world
     win = est.window()
     i = 4                                               # the window frame the loop detector matched
-    info, pts = est.features().dump()
+    assert est.status().resident == 1                   # (a solved NON_LINEAR sequence keeps its landmark list on the device)
+    info, pts = est.features().dump()                   # ... and a look at the list brings it back to the host
+    assert est.status().resident == 0
     # the old keyframe saw the landmarks of frame i from the (true) pose of frame i, but its own map places that pose
     # 1.5 m away: the drift the relocalization has to report
     k_i = int(round((win["headers"][i] - world.time(0)) / world.frame_dt))
@@ -334,6 +336,7 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
     res = loop.step()
     assert res.action == abi.VIO_FRAME_SOLVED and res.n_loop_factors == len(ids)
     st = est.status()
+    assert st.resident == 0                             # the loop factors are paired with the landmarks on the host-side list
     assert np.abs(np.array(st.r_drift).reshape(3, 3) - np.eye(3)).max() < 2e-2
     assert np.abs(np.array(st.t_drift) - drift).max() < 0.1, st.t_drift[:]
     assert np.abs(np.array(st.relative_t)).max() < 0.1 and abs(st.relative_yaw) < 1.0   # loop pose ~ frame i itself
@@ -348,6 +351,8 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
             break
     assert n_loop[0] > 0 and n_loop[-1] == 0 and all(a >= b for a, b in zip(n_loop, n_loop[1:]))
     assert est.window()["headers"][0] > win["headers"][i]          # ... which happened because its frame left the window
+    loop.step()
+    assert est.status().resident == 1                   # the inert relocalization frame no longer keeps the sequence on the host
     loop.close()
 
 

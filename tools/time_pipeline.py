@@ -134,7 +134,8 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
            "camera_frames_per_s": n_seq * freq / per_frame, "solves_per_s": n_seq / per_frame,
            "ms_frontend_calls": float(np.mean(t_fe[steady])) * 1e3,
            "ms_estimator_calls": float(np.mean(t_est[steady])) * 1e3, "overlap": int(overlap) if have_async else 0,
-           "mean_published_features": float(np.mean(tracked[steady])), "position_error_m_max": max(errs)}
+           "mean_published_features": float(np.mean(tracked[steady])), "position_error_m_max": max(errs),
+           "ms_every_published_frame": [round(t * 1e3, 2) for t in t_frame]}
     if not quiet:
         print(out)
     return out

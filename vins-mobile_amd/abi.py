@@ -159,7 +159,8 @@ class VioEstimatorStatus(C.Structure):
     _fields_ = [("frame_count", C.c_int32), ("solver_flag", C.c_int32), ("marginalization_flag", C.c_int32),
                 ("failure_occur", C.c_int32), ("prior_rows", C.c_int32), ("final_cost", C.c_double),
                 ("r_drift", C.c_double * 9), ("t_drift", C.c_double * 3), ("relative_t", C.c_double * 3),
-                ("relative_q", C.c_double * 4), ("relative_yaw", C.c_double), ("loop_pose", C.c_double * 7)]
+                ("relative_q", C.c_double * 4), ("relative_yaw", C.c_double), ("loop_pose", C.c_double * 7),
+                ("resident", C.c_int32), ("reserved", C.c_int32)]
 
 
 VIO_SOLVER_INITIAL, VIO_SOLVER_NON_LINEAR = 0, 1

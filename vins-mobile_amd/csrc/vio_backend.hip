@@ -108,6 +108,10 @@ struct DevBuf {
   size_t n = 0;
   int ensure(size_t count) {
     if (count <= n && p) return VIO_OK;
+    {
+      static const bool log = getenv("VIO_AMD_HOST_TIMING") && getenv("VIO_AMD_HOST_TIMING")[0] == '1';
+      if (log) fprintf(stderr, "vio_amd: device buffer grows %zu -> %zu elements of %zu bytes\n", n, count, sizeof(T));
+    }
     if (p) (void)hipFree(p);
     p = nullptr, n = 0;
     if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return VIO_ENOMEM;

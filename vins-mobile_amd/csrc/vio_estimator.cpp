@@ -301,8 +301,11 @@ int group_of(const vio_estimator *e, const Sequence &s) { return s.index / e->gr
 int slot_of(const vio_estimator *e, const Sequence &s) { return s.index % e->group_size; }
 
 bool resident_eligible(const vio_estimator *e, const Sequence &s) {
-  return e->resident && e->resident_priors && s.solver_flag == VIO_SOLVER_NON_LINEAR && s.frame_count == e->W && s.retrive.ids.empty() &&
-         s.front.ids.empty() && !s.failure_occur;
+  // (a relocalization frame adds factors against the old keyframe while it is in the window: the host-side list pairs
+  // them with the landmarks; once the frame has left the window it is inert, VINS.cpp:571-596)
+  const bool reloc = !s.retrive.ids.empty() && s.retrive.header >= s.Headers[0];
+  return e->resident && e->resident_priors && s.solver_flag == VIO_SOLVER_NON_LINEAR && s.frame_count == e->W && !reloc && !s.loop_enable &&
+         !s.failure_occur;
 }
 
 // The landmark list of a sequence moves to its slot of the group's back-end (main thread: HIP calls).
@@ -1192,6 +1195,7 @@ int vio_estimator_get_status(vio_estimator_t *e, int32_t seq, VioEstimatorStatus
   st->relative_q[2] = s.front.relative_q.z, st->relative_q[3] = s.front.relative_q.w;
   st->relative_yaw = s.front.relative_yaw;
   memcpy(st->loop_pose, s.front.loop_pose, sizeof(st->loop_pose));
+  st->resident = s.on_device ? 1 : 0;
   return VIO_OK;
 }
 
