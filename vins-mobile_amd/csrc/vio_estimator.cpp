@@ -1125,9 +1125,11 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   for (int g = 0; g < e->n_groups; g++) {  // (every LAUNCHED group is waited for, also after an error in another group)
     const int ng = g0[g + 1] - g0[g];
     if (ng == 0 || !launched[g]) continue;
+    // (status per group: a group whose own launch and download succeeded runs its phase C also when another group failed;
+    // the first error is still what the call returns, and only the sequences of the failed / unlaunched groups restart)
     const int rd = vio_backend_download(e->be[g], e->windows.data() + g0[g], ng, e->stats.data() + g0[g]);
     if (rc == VIO_OK) rc = rd;
-    if (rc != VIO_OK) continue;
+    if (rd != VIO_OK) continue;
     const auto tc = std::chrono::steady_clock::now();
     HostPool::get().parallel_for(ng, [&](int i) { phase_c(g0[g] + i); });
     ms_c += ms_between(tc, std::chrono::steady_clock::now());
@@ -1137,9 +1139,9 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     if (rcr != VIO_OK && first_error == VIO_OK) first_error = rcr;
   }
   if (rc != VIO_OK) {
-    // The frame is in the landmark stores of every sequence that wanted a solve. Sequences whose phase C has run (groups
-    // before the failing one) have slid their windows and stay; the others did not advance: they restart rather than carry
-    // an inconsistent window (and a prior slot that may or may not have advanced) into the next call.
+    // The frame is in the landmark stores of every sequence that wanted a solve. Sequences whose phase C has run (every group
+    // whose own launch and download went through) have slid their windows and stay; the others did not advance: they
+    // restart rather than carry an inconsistent window (and a prior slot that may or may not have advanced) into the next call.
     for (int k = 0; k < n; k++) {
       const int q = e->solving[k];
       if (results[q].action == VIO_FRAME_SOLVED || results[q].action == VIO_FRAME_FAILURE || results[q].action == VIO_FRAME_INIT_FAILED) continue;
