@@ -3,6 +3,7 @@
 #include "vio_store.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 using namespace vio;
 namespace st = vio::store;
@@ -120,6 +121,21 @@ size_t store_pack_lds_bytes(const store::Dims &d, int Mcap) {
   return st::lds_bytes(d) + sizeof(int) * (3 * np1 * np1 + 1) + 2 * sizeof(unsigned short) * ((size_t)Mcap + 12);
 }
 
+// Every store kernel asks for exactly half (or all) of a CU's LDS: a workgroup whose block sits somewhere in the middle
+// of the CU's LDS while a window-kernel workgroup of another context is placed next to it leaves, when it ends, two free
+// pieces neither of which takes the next window-kernel workgroup (half a CU each) -- measured as two contexts' window
+// kernels running one after the other. Blocks of the window kernel's own size keep the halves whole.
+static size_t lds_block(size_t need) {
+  static const bool exact = getenv("VIO_AMD_STORE_LDS_EXACT") && getenv("VIO_AMD_STORE_LDS_EXACT")[0] == '1';
+  if (exact) return need;
+  return need <= kLdsBytes / 2 ? kLdsBytes / 2 : kLdsBytes;
+}
+static int raise_lds(const void *fn, size_t lds) {
+  if (lds > kLdsBytes) return VIO_ECAP;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VIO_ENODEV;
+  return VIO_OK;
+}
+
 #define STORE_HIP_OK(expr)                                                                                      \
   do {                                                                                                          \
     hipError_t e_ = (expr);                                                                                     \
@@ -130,23 +146,28 @@ size_t store_pack_lds_bytes(const store::Dims &d, int Mcap) {
   } while (0)
 
 int store_launch_ingest(const StoreDev &S, hipStream_t stream) {
-  hipLaunchKernelGGL(store_ingest_kernel, dim3(S.n_slots), dim3(st::kThreads), st::lds_bytes(S.d), stream, S);
+  const size_t lds = lds_block(st::lds_bytes(S.d));
+  const int rc = raise_lds((const void *)store_ingest_kernel, lds);
+  if (rc != VIO_OK) return rc;
+  hipLaunchKernelGGL(store_ingest_kernel, dim3(S.n_slots), dim3(st::kThreads), lds, stream, S);
   STORE_HIP_OK(hipGetLastError());
   return VIO_OK;
 }
 
 int store_launch_pack(const StoreDev &S, const BatchPtrs &B, int chunk, hipStream_t stream) {
-  const size_t lds = store_pack_lds_bytes(S.d, B.d.Mcap);
-  if (lds > 160 * 1024) return VIO_ECAP;
-  if (lds > 64 * 1024)
-    STORE_HIP_OK(hipFuncSetAttribute((const void *)store_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = lds_block(store_pack_lds_bytes(S.d, B.d.Mcap));
+  const int rc = raise_lds((const void *)store_pack_kernel, lds);
+  if (rc != VIO_OK) return rc;
   hipLaunchKernelGGL(store_pack_kernel, dim3(S.n_slots), dim3(st::kThreads), lds, stream, S, B, chunk);
   STORE_HIP_OK(hipGetLastError());
   return VIO_OK;
 }
 
 int store_launch_finish(const StoreDev &S, const BatchPtrs &B, hipStream_t stream) {
-  hipLaunchKernelGGL(store_finish_kernel, dim3(S.n_slots), dim3(st::kThreads), st::lds_bytes(S.d), stream, S, B);
+  const size_t lds = lds_block(st::lds_bytes(S.d));
+  const int rc = raise_lds((const void *)store_finish_kernel, lds);
+  if (rc != VIO_OK) return rc;
+  hipLaunchKernelGGL(store_finish_kernel, dim3(S.n_slots), dim3(st::kThreads), lds, stream, S, B);
   STORE_HIP_OK(hipGetLastError());
   return VIO_OK;
 }
