@@ -561,3 +561,42 @@ def test_resident_failure_detection_clears_the_slot_and_the_sequence_restarts():
         loop.close()
     for key in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
         assert np.abs(wins[0][key] - wins[1][key]).max() < 1e-6, key
+
+
+@pytest.mark.gpu
+def test_resident_sequence_moves_between_the_paths_in_mid_run():
+    """set_resident(False) brings every list back to the host in the middle of a replay, set_resident(True) sends them to the
+    device again with the next solved frame; a frame with more observations than a store slot takes is handled on the
+    host-side list. The host-path replay of the same data is the reference throughout."""
+    cfg = abi.default_config(window_size=6, max_corners=40)     # store slots take 256 observations per frame
+    W = cfg.window_size
+    host = RS.EstimatorLoop(cfg, seed=11, init_noise=1.0)
+    dev = RS.EstimatorLoop(cfg, seed=11, init_noise=1.0)
+    host.est.set_resident(False)
+    where = []
+    for k in range(44):
+        if k == 20:
+            dev.est.set_resident(False)
+        if k == 28:
+            dev.est.set_resident(True)
+        if k == 36:       # a burst of 300 extra observations (new ids, seen once): both replays get the same frame
+            for loop in (host, dev):
+                ids, xyz = loop.feed_until_image()
+                extra_ids = list(range(10 ** 6, 10 ** 6 + 300))
+                extra = [[-0.4 + 0.8 * (i % 20) / 19, -0.3 + 0.6 * (i // 20) / 14, 1.0] for i in range(300)]
+                res = loop.est.process_image(list(ids) + extra_ids, list(xyz) + extra, loop.world.time(loop.k - 1))
+                assert res.action == abi.VIO_FRAME_SOLVED
+                loop.history.append((loop.k - 1, loop.est.window()["Ps"][W].copy(), loop.world.truth(loop.k - 1)[0], res))
+            where.append(dev.est.status().resident)
+            continue
+        a, b = host.step(), dev.step()
+        assert a.action == b.action and a.n_features == b.n_features and a.n_factors == b.n_factors
+        where.append(dev.est.status().resident)
+    assert where[W + 1] == 1 and where[19] == 1        # on the device once the first window is solved ...
+    assert where[20] == 0 and where[27] == 0           # ... on the host while resident stores are off ...
+    assert where[29] == 1                              # ... back with the first solved frame after they are on again ...
+    assert where[36] == 1 and where[37] == 1           # ... (the oversized frame ran on the host-side list and moved back at once)
+    assert len(host.history) == len(dev.history)
+    dp = np.array([x[1] - y[1] for x, y in zip(host.history, dev.history)])
+    assert np.abs(dp).max() < 1e-5, np.abs(dp).max()
+    host.close(), dev.close()
