@@ -23,6 +23,8 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_I
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -- $BENCH --only backend --steps 6 --warmup 2 > $O/tcc.log 2>&1
 # the phase path (launch sequence) of the same solve: per-kernel trace, for the gate the round-3 review set
 VIO_AMD_PHASE=1 rocprofv3 --kernel-trace --stats -d $O/kt_phase -- $BENCH --only backend --steps 10 --warmup 2 > $O/bench_kt_phase.log 2>&1
+# the resident estimator path (landmark stores + window assembly on the device): per-kernel trace and timeline of one process
+rocprofv3 --kernel-trace --stats -d $O/kt_res -- python $R/tools/time_estimator.py 512 24 > $O/estimator_kt.log 2>&1
 cd $R
 db() { find $O/$1 -name "*.db" | head -1; }
 python tools/rocpd_summary.py $(db kt) $O/kernel_trace.txt > /dev/null
@@ -33,6 +35,14 @@ python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.
 python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
 python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 512 sequences, prior 75" \
   --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
+python tools/rocpd_summary.py $(db kt_res) $O/kernel_trace_resident_estimator.txt > /dev/null
+python tools/rocpd_timeline.py $(db kt_res) 24 >> $O/kernel_trace_resident_estimator.txt 2>&1
+( for n in 256 512 1024; do for r in 1 0; do echo "== time_estimator.py $n sequences, VIO_AMD_RESIDENT=$r"; VIO_AMD_RESIDENT=$r python tools/time_estimator.py $n 40 2>&1 | tail -2; done; done
+  VIO_AMD_STORE_PROF=1 python tools/time_estimator.py 512 16 2>&1 | grep -A1 "store cycles" | tail -2
+  g++ -O2 -std=c++17 -Iinclude tools/estimator_throughput.cpp -Lvins-mobile_amd/csrc -lvio_amd -Wl,-rpath,$R/vins-mobile_amd/csrc -lpthread -o /tmp/estimator_throughput
+  python tools/estimator_dataset.py /tmp/est.bin 8 60 > /dev/null 2>&1
+  for cfg in "256 1" "512 1" "256 2" "512 2"; do set -- $cfg; echo "== estimator_throughput (C++ driver): $1 sequences x $2 estimator objects"; /tmp/estimator_throughput /tmp/est.bin $1 $2 2>&1 | tail -1; done
+  for n in 256 512; do echo "== time_pipeline.py $n sequences, asynchronous submit"; python tools/time_pipeline.py $n 30 2 1 2>&1 | tail -1; done ) > $O/estimator_paths.txt 2>&1
 python tools/time_backend.py --path=single 1 256 512 1024 > $O/stage_cycles.txt 2>&1
 python tools/time_backend.py --path=phase 1 256 512 1024 2>&1 | grep "path=" >> $O/stage_cycles.txt
 python tools/phase_stages.py phase 512 2>&1 | grep "path=" >> $O/stage_cycles.txt
@@ -41,5 +51,5 @@ $R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
 $R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase
+rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
 ls -la $O
