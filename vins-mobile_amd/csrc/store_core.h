@@ -25,7 +25,7 @@ constexpr double kMinParallax = 10.0 / 549;  // MIN_PARALLAX (feature_manager.hp
 constexpr double kInitDepth = 5.0;           // INIT_DEPTH (feature_manager.hpp:24)
 constexpr int kMaxP = 32;                    // observation columns a landmark can have (window_size + 1 <= kMaxP)
 constexpr int kThreads = 256;
-constexpr int kTri = 64;                     // landmarks triangulated side by side (store_ingest)
+constexpr int kTri = 32;                     // landmarks triangulated side by side (store_ingest)
 
 // control block of a sequence (ints)
 enum {
@@ -63,11 +63,12 @@ struct Lds {
   ldsi part;   // [threads + 1 + threads / 16]
   ldsd term;   // [Lcap]
   ldsd tri;    // [8 (W + 1)][kTri] row matrices of the landmarks being triangulated
+  ldsd cam;    // [12 (W + 1) + 12] Rs | Ps | ric | tic for the triangulation
   ldsi misc;   // [8]
   long long *prof;  // null, or [32] cycle stamps of one workgroup's passes (VIO_AMD_STORE_PROF)
 };
 VIO_HD size_t lds_bytes(const Dims &d) {
-  return sizeof(int) * (3 * (size_t)d.Ocap + 1 + 2 * ((size_t)d.Lcap + 1) + kThreads + 1 + kThreads / 16 + 8 + 8) + sizeof(double) * ((size_t)d.Lcap + 8 * ((size_t)d.W + 1) * kTri) + 64;
+  return sizeof(int) * (3 * (size_t)d.Ocap + 1 + 2 * ((size_t)d.Lcap + 1) + kThreads + 1 + kThreads / 16 + 8 + 8) + sizeof(double) * ((size_t)d.Lcap + 8 * ((size_t)d.W + 1) * kTri + 12 * ((size_t)d.W + 1) + 12) + 64;
 }
 template <class PI, class PD>
 VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
@@ -86,6 +87,7 @@ VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
   *dbase_out = (PD)(ibase + ints);
   l.term = *dbase_out;
   l.tri = l.term + d.Lcap;
+  l.cam = l.tri + 8 * (d.W + 1) * kTri;
   l.prof = nullptr;
   return l;
 }
@@ -324,6 +326,11 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
   VIO_PARFOR(i, n)
     if (l.scanA[i + 1] != l.scanA[i]) l.scanB[l.scanA[i]] = i;
   VIO_SYNC();
+  VIO_PARFOR(k, 12 * P + 12) {
+    const int nr = 9 * P, np = 3 * P;
+    l.cam[k] = k < nr ? Rs[k] : k < nr + np ? Ps[k - nr] : k < nr + np + 9 ? ric[k - nr - np] : tic[k - nr - np - 9];
+  }
+  VIO_SYNC();
   for (int base = 0; base < n_tri; base += kTri) {
     if (t < kTri && base + t < n_tri) {
       const int i = l.scanB[base + t];
@@ -332,18 +339,25 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
         l.misc[0] = VIO_ESTATE;
       } else {
         TriRows A{l.tri + t};
+        double ricl[9], ticl[3], Rf[9], Pf[3];
+        for (int k = 0; k < 9; k++) ricl[k] = l.cam[12 * P + k];
+        for (int k = 0; k < 3; k++) ticl[k] = l.cam[12 * P + 9 + k];
+        for (int k = 0; k < 9; k++) Rf[k] = l.cam[9 * s + k];
+        for (int k = 0; k < 3; k++) Pf[k] = l.cam[9 * P + 3 * s + k];
         double t0[3], R0[9], tmp[3];
-        mat3vec(Rs + 9 * s, tic, tmp);
-        for (int k = 0; k < 3; k++) t0[k] = Ps[3 * s + k] + tmp[k];
-        mat3mul(Rs + 9 * s, ric, R0);
+        mat3vec(Rf, ticl, tmp);
+        for (int k = 0; k < 3; k++) t0[k] = Pf[k] + tmp[k];
+        mat3mul(Rf, ricl, R0);
         int row = 0;
         for (int jo = 0; jo < no; jo++) {
           const int imu_j = s + jo;
           const double *pt = bk.obs + ((size_t)i * P + jo) * 3;
           double t1[3], R1[9], R0T[9], dd[3], tt[3], R[9], RT[9], mt[3];
-          mat3vec(Rs + 9 * imu_j, tic, tmp);
-          for (int k = 0; k < 3; k++) t1[k] = Ps[3 * imu_j + k] + tmp[k];
-          mat3mul(Rs + 9 * imu_j, ric, R1);
+          for (int k = 0; k < 9; k++) Rf[k] = l.cam[9 * imu_j + k];
+          for (int k = 0; k < 3; k++) Pf[k] = l.cam[9 * P + 3 * imu_j + k];
+          mat3vec(Rf, ticl, tmp);
+          for (int k = 0; k < 3; k++) t1[k] = Pf[k] + tmp[k];
+          mat3mul(Rf, ricl, R1);
           mat3T(R0, R0T);
           for (int k = 0; k < 3; k++) dd[k] = t1[k] - t0[k];
           mat3vec(R0T, dd, tt);
@@ -605,14 +619,35 @@ VIO_DEV void store_finish(const Cx &cx, const Dims &d, const Bank &bk, const Ban
     if (!l.scanB[i]) continue;
     const int j = l.scanA[i];
     const int pk = bk.flag[i];
-    const int s = pk & 0xff, no = (pk >> 8) & 0xff, fl = (pk >> 16) & 3, drop = ((pk >> 18) & 0xff) - 1;
+    const int s = pk & 0xff, no = (pk >> 8) & 0xff, fl = (pk >> 16) & 3;
     nb.fid[j] = bk.fid[i], nb.start[j] = s, nb.nobs[j] = no, nb.flag[j] = fl, nb.depth[j] = l.term[i];
-    const double *src = bk.obs + (size_t)i * P * 3;
-    double *dst = nb.obs + (size_t)j * P * 3;
-    for (int c = 0, cc = 0; cc < no; c++) {
-      if (c == drop) continue;
-      dst[3 * cc] = src[3 * c], dst[3 * cc + 1] = src[3 * c + 1], dst[3 * cc + 2] = src[3 * c + 2];
-      cc++;
+  }
+  // the observations move column by column, one work-item per (landmark, column), four columns in flight per work-item
+  // (a landmark-by-landmark copy is a chain of dependent round trips to HBM)
+  {
+    const int total = n * P;
+    for (int q0 = VIO_TID(cx); q0 < total; q0 += 4 * cx.nt) {
+      double v[4][3];
+      long dsti[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u * cx.nt;
+        dsti[u] = -1;
+        if (q >= total) continue;
+        const int i = q / P, c = q - i * P;
+        if (!l.scanB[i]) continue;
+        const int pk = bk.flag[i];
+        const int no = (pk >> 8) & 0xff, drop = ((pk >> 18) & 0xff) - 1;
+        if (c == drop) continue;
+        const int cc = c - (drop >= 0 && c > drop ? 1 : 0);
+        if (cc >= no) continue;
+        const double *src = bk.obs + ((size_t)i * P + c) * 3;
+        v[u][0] = src[0], v[u][1] = src[1], v[u][2] = src[2];
+        dsti[u] = ((long)l.scanA[i] * P + cc) * 3;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (dsti[u] >= 0) nb.obs[dsti[u]] = v[u][0], nb.obs[dsti[u] + 1] = v[u][1], nb.obs[dsti[u] + 2] = v[u][2];
     }
   }
   STORE_STAMP(l, 19);

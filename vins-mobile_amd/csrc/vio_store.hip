@@ -49,7 +49,7 @@ __global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, Ba
   if (slot == 0) l.prof = S.prof;
   // behind the store's own scratch: bucket counters and the factor keys
   const int np1 = S.d.W + 2;
-  ldsi bins = (ldsi)(l.tri + 8 * (S.d.W + 1) * st::kTri);
+  ldsi bins = (ldsi)(l.cam + 12 * (S.d.W + 1) + 12);
   VIO_AS3 unsigned short *keys = (VIO_AS3 unsigned short *)(bins + 3 * np1 * np1 + (np1 & 1));
   VIO_AS3 unsigned short *own = keys + ((B.d.Mcap + 8 + 3) & ~3);
   int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
