@@ -1114,7 +1114,12 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
     if (ng == 0 || rc != VIO_OK) continue;
     if (!e->be[g]) {
       rc = vio_backend_create(&e->cfg, e->group_size, &e->be[g]);
-      if (rc == VIO_OK) rc = vio_backend_set_peers(e->be[g], e->n_groups);
+      if (rc == VIO_OK) {
+        // (VIO_AMD_EST_PEERS: how many launches the layout rule should assume on the device, e.g. 2 when a front-end context
+        // runs its kernels under this estimator's and should find half of every CU's LDS free)
+        const char *pe = getenv("VIO_AMD_EST_PEERS");
+        rc = vio_backend_set_peers(e->be[g], pe && atoi(pe) > 0 ? atoi(pe) : e->n_groups);
+      }
       if (rc == VIO_OK && e->resident_priors) rc = vio_backend_reserve_priors(e->be[g], e->group_size);
     }
     if (rc == VIO_OK) rc = vio_backend_upload(e->be[g], e->windows.data() + g0[g], ng);
