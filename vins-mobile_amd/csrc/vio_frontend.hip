@@ -1132,19 +1132,31 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   float hxx0 = 0.f, hxx1 = 0.f, hxy0 = 0.f, hxy1 = 0.f, hyy0 = 0.f, hyy1 = 0.f;  // horizontal sums of rows -2, -1
   float e0 = 0.f, e1 = 0.f;                                                        // eigenvalues of rows -2, -1
   unsigned my_max = 0;
+  int prev_yr = -1, prev_yp = -1;               // rows of the previous step (uniform) and their (d, t)
+  float pd1 = 0.f, pt1 = 0.f, pd2 = 0.f, pt2 = 0.f;
   const bool out_lane = lane >= 2 && lane < 2 + kDetW && xe < cols;
   for (int step = 0; step < kDetR + 4; step++) {
     const int ye = Y0 - 2 + step;  // extended product row (uniform)
     const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
     const int ym = reflect101(yr - 1, rows), yp = reflect101(yr + 1, rows);
-    const uint8_t *r0 = img + (size_t)ym * cols, *r1 = img + (size_t)yr * cols, *r2 = img + (size_t)yp * cols;
-    const float a00 = (float)r0[xm], a01 = (float)r0[xr], a02 = (float)r0[xp];
-    const float a10 = (float)r1[xm], a12 = (float)r1[xp];
-    const float a20 = (float)r2[xm], a21 = (float)r2[xr], a22 = (float)r2[xp];
-    const float d0 = a02 - a00, d1 = a12 - a10, d2 = a22 - a20;
+    // Per image row the Sobel pair needs two numbers per column: the horizontal difference d = a(x+1) - a(x-1) and the
+    // horizontal smoothing t = 2s a(x) + s (a(x-1) + a(x+1)); dx = 2s d(y) + s (d(y-1) + d(y+1)), dy = t(y+1) - t(y-1). Inside
+    // the image the rows (y-1, y) of this step are the rows (y, y+1) of the previous one: only the entering row is loaded.
+    auto row_dt = [&](int y, float &d, float &t) {
+      const uint8_t *r = img + (size_t)y * cols;
+      const float a0 = (float)r[xm], a1 = (float)r[xr], a2 = (float)r[xp];
+      d = a2 - a0;
+      t = s2 * a1 + s * (a0 + a2);
+    };
+    float d0, t0, d1, t1, d2, t2;
+    if (step > 0 && ym == prev_yr && yr == prev_yp) {
+      d0 = pd1, t0 = pt1, d1 = pd2, t1 = pt2;
+      row_dt(yp, d2, t2);
+    } else {
+      row_dt(ym, d0, t0), row_dt(yr, d1, t1), row_dt(yp, d2, t2);
+    }
+    prev_yr = yr, prev_yp = yp, pd1 = d1, pt1 = t1, pd2 = d2, pt2 = t2;
     const float dx = s2 * d1 + s * (d0 + d2);
-    const float t0 = s2 * a01 + s * (a00 + a02);
-    const float t2 = s2 * a21 + s * (a20 + a22);
     const float dy = t2 - t0;
     const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
     // 3-tap horizontal sums (left + centre) + right, then the 3-row vertical sums (top + middle) + bottom
