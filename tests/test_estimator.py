@@ -442,14 +442,15 @@ def _dump_lists(est, seq=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W", [10, 6])
-def test_resident_sequences_give_what_the_host_side_list_gives(W):
+@pytest.mark.parametrize("W,seed", [(10, 5), (6, 5), (10, 21), (5, 33), (8, 8)])
+def test_resident_sequences_give_what_the_host_side_list_gives(W, seed):
     """The same replay twice: landmark list, window assembly and slides on the host (vio_window.cpp) / on the device
     (store_core.h). Same keyframe decisions, same iteration counts, same landmark list at the end (ids, start frames,
     observation counts, flags exactly; depths and positions to the reproducibility of the window kernel's sums)."""
     cfg = abi.default_config(window_size=W)
-    host = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
-    dev = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    host = RS.EstimatorLoop(cfg, seed=seed, init_noise=1.0)
+    dev = RS.EstimatorLoop(cfg, seed=seed, init_noise=1.0)
+    host.est.set_resident(False)
     dev.est.set_resident(True)
     n = 60
     for _ in range(n):

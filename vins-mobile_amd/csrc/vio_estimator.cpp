@@ -314,8 +314,11 @@ int promote(vio_estimator *e, Sequence &s) {
   if (!e->be[g]) return VIO_ESTATE;
   int lcap = 0, ocap = 0;
   if (vio_backend_resident_caps(e->be[g], &lcap, &ocap) != VIO_OK) {
+    // A frame may bring twice the tracker's feature budget; the list holds a window's worth of frames whose features were
+    // all new (a sequence that tracks nothing fails the failure detection long before: last_track_num < 4). A list that
+    // outgrows its slot ends the frame with VIO_ECAP for that sequence, which restarts.
     e->res_obs_cap = std::min(1024, std::max(256, 2 * e->cfg.max_corners));
-    e->res_list_cap = std::max(1024, 4 * e->res_obs_cap);
+    e->res_list_cap = std::max({1024, (e->W + 2) * e->cfg.max_corners, e->res_obs_cap});
     double ex[7];
     const Quat q = RtoQ(e->ric);
     ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;
