@@ -323,7 +323,10 @@ int promote(vio_estimator *e, Sequence &s) {
     const Quat q = RtoQ(e->ric);
     ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;
     const int rc = vio_backend_resident_reserve(e->be[g], e->group_size, e->res_list_cap, e->res_obs_cap, ex, e->tic, e->ric);
-    if (rc != VIO_OK) return rc;
+    if (rc != VIO_OK) {
+      e->resident = false;  // (a window size the store does not take, or no memory: every sequence stays on the host-side lists)
+      return rc;
+    }
     lcap = e->res_list_cap, ocap = e->res_obs_cap;
   }
   int n = 0, np = 0;
