@@ -601,3 +601,64 @@ def test_resident_sequence_moves_between_the_paths_in_mid_run():
     dp = np.array([x[1] - y[1] for x, y in zip(host.history, dev.history)])
     assert np.abs(dp).max() < 1e-5, np.abs(dp).max()
     host.close(), dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("events_seed", [2024, 7, 99])
+def test_resident_stress_random_path_switches_in_a_batch(events_seed):
+    """Six sequences in one estimator, 70 calls, seeded random events applied to a resident and a host-only estimator alike:
+    sequences skipped in a call (they fall out of step with each other), looks at a landmark list (the list returns to the
+    host and moves back), frames with more observations than a store slot takes, resident stores switched off and on for the
+    whole object. Every sequence must follow the host-only estimator: actions, counts, positions."""
+    cfg = abi.default_config(window_size=6, max_corners=40)
+    W, nq, calls = cfg.window_size, 6, 70
+    rng = np.random.default_rng(events_seed)
+    both = [[RS.SyntheticWorld(cfg, 60 + q) for q in range(nq)] for _ in range(2)]   # (a world keeps track state: one per side)
+    worlds = both[0]
+    ests = [pkg.estimator.Estimator(cfg, worlds[0].tic, worlds[0].ric, n_seq=nq) for _ in range(2)]
+    ests[0].set_resident(False)
+    feeders = [[RS.EstimatorLoop(cfg, seed=60 + q, init_noise=1.0, world=both[side][q]) for q in range(nq)] for side in range(2)]
+    for e, fs in zip(ests, feeders):
+        for q, f in enumerate(fs):
+            f.est.close()
+            f.est = _SeqView(e, q)
+    got = [[[] for _ in range(nq)] for _ in range(2)]
+    resident_calls = 0
+    for call in range(calls):
+        active = [1 if rng.random() > 0.12 else 0 for _ in range(nq)]
+        burst = [bool(a and rng.random() < 0.06) for a in active]
+        peek = [q for q in range(nq) if rng.random() < 0.05]
+        if call in (25, 48):
+            ests[1].set_resident(call == 48)
+        results = []
+        for side in range(2):
+            obs, hdr = [], []
+            for q in range(nq):
+                f = feeders[side][q]
+                if not active[q]:
+                    obs.append(([], [])), hdr.append(0.0)
+                    continue
+                ids, xyz = f.feed_until_image()
+                if burst[q]:
+                    ids = list(ids) + list(range(10 ** 6 + 1000 * call, 10 ** 6 + 1000 * call + 300))
+                    xyz = list(xyz) + [[-0.4 + 0.8 * (i % 20) / 19, -0.3 + 0.6 * (i // 20) / 14, 1.0] for i in range(300)]
+                obs.append((ids, xyz)), hdr.append(worlds[q].time(f.k - 1))
+            res = ests[side].process_images(obs, hdr, active)
+            results.append(res)
+            for q in range(nq):
+                if res[q].action == abi.VIO_FRAME_SOLVED:
+                    got[side][q].append(ests[side].window(q)["Ps"][W].copy())
+        for q in range(nq):
+            a, b = results[0][q], results[1][q]
+            assert a.action == b.action and a.n_features == b.n_features and a.n_factors == b.n_factors, (call, q, a.action, b.action)
+            assert a.marginalization_flag == b.marginalization_flag and a.track_num == b.track_num
+        resident_calls += sum(ests[1].status(q).resident for q in range(nq))
+        for q in peek:
+            la, lb = ests[0].features(q).dump(), ests[1].features(q).dump()
+            assert np.array_equal(la[0][:, [0, 1, 2, 4]], lb[0][:, [0, 1, 2, 4]]) and np.array_equal(la[1], lb[1])
+    assert resident_calls > nq * 20            # the sequences did spend most of the solved frames on the device
+    for q in range(nq):
+        a, b = np.array(got[0][q]), np.array(got[1][q])
+        assert len(a) == len(b) and len(a) > 30 and np.abs(a - b).max() < 1e-5, (q, len(a), len(b))
+    for e in ests:
+        e.close()
