@@ -85,10 +85,10 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     cx.wrot = order % (nthreads / 64);  // (the device takes it from the hardware wave slot: every rotation must work)
     cx.red = cw.red, cx.lprof = cw.lprof;
     const size_t state_end = cw.state_end_doubles;
-    if (lds_matrix && nthreads == 256) solve_window<true, 4>(cx, v, w);
-    else if (lds_matrix) solve_window<true, 8>(cx, v, w);
-    else if (nthreads == 256) solve_window<false, 4>(cx, v, w);
-    else solve_window<false, 8>(cx, v, w);
+    if (lds_matrix && nthreads == 256) solve_window<true, 4>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
+    else if (lds_matrix) solve_window<true, 8>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
+    else if (nthreads == 256) solve_window<false, 4>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
+    else solve_window<false, 8>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
     MargWorkT<double *> mw = carve_marg_all<double *>(B.d, lds_matrix, lds.data() + state_end, mo.scratch, lds_doubles - state_end).m;
     __syncthreads();
     marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);

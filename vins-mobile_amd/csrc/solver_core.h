@@ -2584,8 +2584,23 @@ VIO_DEV void state_norms(const Ctx &cx, const WinView &v, cldsd apose, cldsd asb
 // TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
 // =====================================================================================================
 // REGS: the pose matrix has at most kPanelTiles tile rows (the launcher's LDS variant): fill tiles in registers
-template <bool REGS, int NW, class WK>
-VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
+// The per-window view handed to a phase. A phase reads a few of WinView's ~50 pointers; carried through the whole kernel
+// they are all live everywhere and most of them sit in spilled scalar registers (v_readlane to get one back). `fresh()`
+// derives the view again from the kernel's arguments at the phase's entry: the fields the phase does not use fall away,
+// the ones it uses cost a few scalar instructions. SameView: the stored view as is (host builds).
+struct SameView {
+  const WinView &v;
+  VIO_DEV const WinView &operator()() const { return v; }
+};
+template <class WK>
+struct SameWork {
+  const WK &w;
+  VIO_DEV WK operator()() const { return w; }
+};
+
+template <bool REGS, int NW, class WK, class VP, class WP>
+VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fresh, const WP &fresh_work) {
+  WK &w = w_whole;
   const int np = v.np, F = v.F;
   double *sd = v.stats_d;
   int *si = v.stats_i;
@@ -2602,13 +2617,13 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     VIO_PARFOR(i, np) w.t2[i] = -w.gp[i];
     VIO_PARFOR(f, F) w.tf[f] = -w.gf[f];
     VIO_SYNC();
-    apply_plus(cx, v, w, w.t2, w.tf);
+    apply_plus(cx, fresh(), w, w.t2, w.tf);
     double l2, linf;
-    state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &l2, &linf);
+    state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &l2, &linf);
     return linf;
   };
 
-  double x_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, false);
+  double x_cost = evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, false);
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
   VIO_PARFOR(f, F) w.sf[f] = rcp_f(1.0 + sqrt_f(w.hff[f]));  // Jacobi scaling, :239-254 (poses: at the end of evaluate)
   VIO_SYNC();
@@ -2631,8 +2646,12 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
   double rec_step_norm = 0, rec_rho = 0;
 
   while (true) {
+    // (the LDS layout, like the view: derived again per iteration, so that its ~40 addresses are not carried -- and spilled --
+    // across the whole loop)
+    WK w_iter = fresh_work();
+    WK &w = w_iter;
     if (relin) {
-      evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true, relin_reuse);
+      evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, true, relin_reuse);
       if (rec_pending) {
         gmax = grad_max_norm();
         record(rec_it, x_cost, radius, rec_step_norm, rec_rho, gmax, true, true);
@@ -2676,7 +2695,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       };
       cauchy_direction();
       stamp(cx, ST_DOGLEG);
-      const double qf_h = quad_form_H(cx, v, w, w.t2, w.stf);
+      const double qf_h = quad_form_H(cx, fresh(), w, w.t2, w.stf);
       stamp(cx, ST_QUADFORM);
       // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
       solver_ok = false;
@@ -2684,21 +2703,21 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
       while (mu < max_mu) {
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
-          evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, true, true);
+          evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, true);
           cauchy_direction();  // (stf doubles as an accumulator of the Jacobian evaluation)
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;
         VIO_SYNC();
-        bool ok = build_reduced_system(cx, v, w, mu);
+        bool ok = build_reduced_system(cx, fresh(), w, mu);
         if (ok) {
-          if constexpr (REGS) ok = factor_band_regs<kPanelTiles, NW>(cx, v, w);
-          else ok = factor_band_lds(cx, v, w);
+          if constexpr (REGS) ok = factor_band_regs<kPanelTiles, NW>(cx, fresh(), w);
+          else ok = factor_band_lds(cx, fresh(), w);
         }
-        if (ok) ok = factor_poses(cx, v, w);
+        if (ok) ok = factor_poses(cx, fresh(), w);
         stamp(cx, ST_CHOL);
         if (ok) {
-          backsolve(cx, v, w);  // z -> t1, w_f^T z_p -> gnf
+          backsolve(cx, fresh(), w);  // z -> t1, w_f^T z_p -> gnf
           // back-substitute features: z_f = (g_f - w_f^T z_p) / E_f ; y = z / s ; GN = -d * y
           double bad = 0;
           VIO_PARFOR(f, F) {
@@ -2809,7 +2828,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     VIO_PARFOR(i, np) w.t2[i] = w.stp[i] * w.sp[i];  // delta = step * scale
     VIO_PARFOR(f, F) w.tf[f] = w.stf[f] * w.sf[f];
     VIO_SYNC();
-    apply_plus(cx, v, w, w.t2, w.tf);
+    apply_plus(cx, fresh(), w, w.t2, w.tf);
     stamp(cx, ST_DOGLEG);
     // After an ACCEPTED step the next candidate is linearized SPECULATIVELY -- cost and Jacobians in one evaluation, before
     // its step is accepted. Ceres evaluates the cost at the candidate and, once the step is accepted, residuals + Jacobians at
@@ -2820,7 +2839,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     // rejected speculative evaluation wastes its Jacobian half, which at W = 30 is three quarters of it.
     const bool speculate = last_ok;
     double step_norm, dummy;
-    state_norms(cx, v, w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
+    state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
     const int npose7 = (v.P + v.has_loop) * 7, o_sb = 7 * (v.P + 1), o_f = o_sb + 9 * v.P, o_v = o_f + F, nv = v.nblk * kBS;
     // (either way the candidate takes the iterate's place for its evaluation -- one code path, fixed LDS addresses -- and the
     // iterate waits in the stash)
@@ -2832,7 +2851,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     }
     VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
     VIO_SYNC();
-    double cand_cost = evaluate(cx, v, w, w.xpose, w.xsb, w.xfeat, /*jac=*/speculate, true, false, /*keep_aux=*/!speculate);
+    double cand_cost = evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, /*jac=*/speculate, true, false, /*keep_aux=*/!speculate);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     auto restore_iterate = [&]() {  // x <- the iterate the candidate replaced
       VIO_PARFOR(q, npose7) w.xpose[q] = v.stash[q];
@@ -2854,7 +2873,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
     double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
     double rho = fmax(rel, hist);
     if (rho > 1e-3) {
-      state_norms(cx, v, w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
+      state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
       x_cost = cand_cost;  // (x is the candidate)
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
@@ -2904,8 +2923,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w) {
 // Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs
 // =====================================================================================================
 // NW: waves of the workgroup (blockDim.x / 64)
-template <bool REGS, int NW, class WK>
-VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
+template <bool REGS, int NW, class WK, class VP, class WP>
+VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w, const VP &fresh, const WP &fresh_work) {
   const int P = v.P, F = v.F;
   VIO_PARFOR(q, P * 7) w.xpose[q] = v.pose0[q];
   VIO_PARFOR(q, P * 9) w.xsb[q] = v.sb0[q];
@@ -2942,12 +2961,12 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w) {
     for (int c = 0; c < 3; c++) d[c] = v.pts_i[3 * k + c], d[3 + c] = v.pts_j[3 * k + c];
   }
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
-  setup_imu_info(cx, v, w.App);
+  setup_imu_info(cx, fresh(), w.App);
   stamp(cx, ST_SETUP_IMU);
-  setup_prior(cx, v, w);
+  setup_prior(cx, fresh(), w);
   stamp(cx, ST_SETUP_PRIOR);
 
-  minimize<REGS, NW>(cx, v, w);
+  minimize<REGS, NW>(cx, v, w, fresh, fresh_work);
 
   VIO_PARFOR(q, P * 7) v.raw_pose[q] = w.xpose[q];
   VIO_PARFOR(q, P * 9) v.raw_sb[q] = w.xsb[q];

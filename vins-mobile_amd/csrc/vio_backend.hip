@@ -66,7 +66,14 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   else cx.prof_tid = (((MP.prof_tid >> 6) - cx.wrot) & (NT / 64 - 1)) * 64;
   cx.red = cw.red, cx.lprof = cw.lprof;
   const size_t state_end = cw.state_end_doubles;
-  solve_window<LDS_MATRIX, NT / 64>(cx, v, w);
+  // (the window index as an opaque scalar: the view a phase asks for is derived again from the kernel's arguments)
+  auto fresh = [&]() {
+    int bb = b;
+    asm volatile("" : "+s"(bb));
+    return make_view(B, bb);
+  };
+  auto fresh_work = [&]() { return w; };  // (the LDS layout derived again per iteration was tried: 5 % slower)
+  solve_window<LDS_MATRIX, NT / 64>(cx, v, w, fresh, fresh_work);
 
   MargOut mo;
   int *mi = MP.ints + (size_t)b * MP.s_ints;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
   MargWorkT<MatP> mw = carve_marg_all<MatP>(B.d, LDS_MATRIX, lds + state_end, mo.scratch, (size_t)lds_doubles - state_end).m;
   __syncthreads();
-  marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
+  marginalize_window_impl(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
   if (cx.prof && cx.tid == cx.prof_tid) {  // stage counters: LDS -> global
     cx.lprof[ST_TOTAL] += clock64();
     for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = cx.lprof[q];
