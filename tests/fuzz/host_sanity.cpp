@@ -37,6 +37,8 @@ int vio_backend_resident_reserve(vio_backend_t *, int32_t, int32_t, int32_t, con
 int vio_backend_resident_caps(const vio_backend_t *, int32_t *, int32_t *) { return VIO_ENODEV; }
 int vio_backend_resident_load(vio_backend_t *, int32_t, const VioFeatureInfo *, int32_t, const double *, const double *, const double *) { return VIO_ENODEV; }
 int vio_backend_resident_fetch(vio_backend_t *, int32_t, VioFeatureInfo *, int32_t, int32_t *, double *, int32_t, int32_t *) { return VIO_ENODEV; }
+int vio_backend_resident_load_batch(vio_backend_t *, int32_t, const int32_t *, const VioFeatureInfo *const *, const int32_t *, const double *const *,
+                                    const double *, const double *) { return VIO_ENODEV; }
 int vio_backend_resident_begin(vio_backend_t *) { return VIO_ENODEV; }
 int vio_backend_resident_stage(vio_backend_t *, int32_t, const VioObs *, int32_t, const double *, const double *, const double *, const double *,
                                const VioPrior *) { return VIO_ENODEV; }

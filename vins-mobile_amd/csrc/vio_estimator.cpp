@@ -308,41 +308,62 @@ bool resident_eligible(const vio_estimator *e, const Sequence &s) {
          !s.failure_occur;
 }
 
-// The landmark list of a sequence moves to its slot of the group's back-end (main thread: HIP calls).
-int promote(vio_estimator *e, Sequence &s) {
-  const int g = group_of(e, s);
+// The group's store exists (reserved at the first promotion). Main thread: HIP calls.
+int ensure_store(vio_estimator *e, int g) {
   if (!e->be[g]) return VIO_ESTATE;
   int lcap = 0, ocap = 0;
-  if (vio_backend_resident_caps(e->be[g], &lcap, &ocap) != VIO_OK) {
-    // A frame may bring twice the tracker's feature budget; the list holds a window's worth of frames whose features were
-    // all new (a sequence that tracks nothing fails the failure detection long before: last_track_num < 4). A list that
-    // outgrows its slot ends the frame with VIO_ECAP for that sequence, which restarts.
-    e->res_obs_cap = std::min(1024, std::max(256, 2 * e->cfg.max_corners));
-    e->res_list_cap = std::max({1024, (e->W + 2) * e->cfg.max_corners, e->res_obs_cap});
-    double ex[7];
-    const Quat q = RtoQ(e->ric);
-    ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;
-    const int rc = vio_backend_resident_reserve(e->be[g], e->group_size, e->res_list_cap, e->res_obs_cap, ex, e->tic, e->ric);
-    if (rc != VIO_OK) {
-      e->resident = false;  // (a window size the store does not take, or no memory: every sequence stays on the host-side lists)
-      return rc;
-    }
-    lcap = e->res_list_cap, ocap = e->res_obs_cap;
+  if (vio_backend_resident_caps(e->be[g], &lcap, &ocap) == VIO_OK) return VIO_OK;
+  // A frame may bring twice the tracker's feature budget; the list holds a window's worth of frames whose features were
+  // all new (a sequence that tracks nothing fails the failure detection long before: last_track_num < 4). A list that
+  // outgrows its slot ends the frame with VIO_ECAP for that sequence, which restarts.
+  e->res_obs_cap = std::min(1024, std::max(256, 2 * e->cfg.max_corners));
+  e->res_list_cap = std::max({1024, (e->W + 2) * e->cfg.max_corners, e->res_obs_cap});
+  double ex[7];
+  const Quat q = RtoQ(e->ric);
+  ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;
+  const int rc = vio_backend_resident_reserve(e->be[g], e->group_size, e->res_list_cap, e->res_obs_cap, ex, e->tic, e->ric);
+  if (rc != VIO_OK) e->resident = false;  // (a window size the store does not take, or no memory: every sequence stays on the host-side lists)
+  return rc;
+}
+
+// The landmark lists of these sequences (ascending, one group) move to their slots of the group's back-end: dumped in
+// parallel, uploaded together. A list that does not fit its slot stays on the host.
+void promote_group(vio_estimator *e, int g, const std::vector<int> &seqs) {
+  if (seqs.empty() || ensure_store(e, g) != VIO_OK) return;
+  const int n = (int)seqs.size();
+  std::vector<std::vector<VioFeatureInfo>> infos(n);
+  std::vector<std::vector<double>> pts(n);
+  std::vector<int> ok(n, 0);
+  HostPool::get().parallel_for(n, [&](int k) {
+    Sequence &s = e->seq[seqs[k]];
+    int cnt = 0, np = 0;
+    if (vio_features_dump(s.fm, nullptr, 0, &cnt, nullptr, 0, &np) != VIO_OK || cnt > e->res_list_cap) return;
+    infos[k].resize(cnt + 1), pts[k].resize(3 * (size_t)np + 3);
+    if (vio_features_dump(s.fm, infos[k].data(), cnt, &cnt, pts[k].data(), np, &np) != VIO_OK) return;
+    infos[k].resize(cnt);
+    ok[k] = 1;
+  });
+  std::vector<int32_t> slots, counts;
+  std::vector<const VioFeatureInfo *> ip;
+  std::vector<const double *> pp;
+  std::vector<double> lp, lr;
+  std::vector<int> who;
+  for (int k = 0; k < n; k++) {
+    if (!ok[k]) continue;
+    Sequence &s = e->seq[seqs[k]];
+    slots.push_back(slot_of(e, s)), counts.push_back((int32_t)infos[k].size()), ip.push_back(infos[k].data()), pp.push_back(pts[k].data());
+    lp.insert(lp.end(), s.last_P, s.last_P + 3), lr.insert(lr.end(), s.last_R, s.last_R + 9);
+    who.push_back(seqs[k]);
   }
-  int n = 0, np = 0;
-  int rc = vio_features_dump(s.fm, nullptr, 0, &n, nullptr, 0, &np);
-  if (rc != VIO_OK) return rc;
-  if (n > lcap) return VIO_ECAP;
-  std::vector<VioFeatureInfo> info(n + 1);
-  std::vector<double> pts(3 * (size_t)np + 3);
-  rc = vio_features_dump(s.fm, info.data(), n, &n, pts.data(), np, &np);
-  if (rc != VIO_OK) return rc;
-  rc = vio_backend_resident_load(e->be[g], slot_of(e, s), info.data(), n, pts.data(), s.last_P, s.last_R);
-  if (rc != VIO_OK) return rc;
-  vio_features_clear(s.fm);
-  s.pre_dirty.assign(e->W + 1, 1);
-  s.on_device = true;
-  return VIO_OK;
+  if (who.empty()) return;
+  if (vio_backend_resident_load_batch(e->be[g], (int)who.size(), slots.data(), ip.data(), counts.data(), pp.data(), lp.data(), lr.data()) != VIO_OK)
+    return;
+  for (int q : who) {
+    Sequence &s = e->seq[q];
+    vio_features_clear(s.fm);
+    s.pre_dirty.assign(e->W + 1, 1);
+    s.on_device = true;
+  }
 }
 
 // ... and back: the host-side list takes over again (relocalization, a caller that wants to look at the list).
@@ -1166,10 +1187,13 @@ int vio_estimator_process_images(vio_estimator_t *e, const VioObs *obs, const in
   e->ms_pre = ms_a, e->ms_post = ms_c, e->ms_solve = ms_between(t_begin, t_end) - ms_a - ms_c;
   // sequences that reached the NON_LINEAR state on the host path continue on the device
   if (e->resident)
-    for (int q = 0; q < e->n_seq; q++) {
-      Sequence &s = e->seq[q];
-      if (s.on_device || results[q].action != VIO_FRAME_SOLVED || !resident_eligible(e, s)) continue;
-      (void)promote(e, s);  // (a list that does not fit the store stays on the host path)
+    for (int g = 0; g < e->n_groups; g++) {
+      std::vector<int> go;
+      for (int q = g * e->group_size; q < std::min(e->n_seq, (g + 1) * e->group_size); q++) {
+        Sequence &s = e->seq[q];
+        if (!s.on_device && results[q].action == VIO_FRAME_SOLVED && resident_eligible(e, s)) go.push_back(q);
+      }
+      promote_group(e, g, go);
     }
   return first_error;
 }

@@ -36,6 +36,10 @@ int vio_backend_resident_caps(const vio_backend_t *be, int32_t *list_cap, int32_
 // states failureDetection compares the next solve with.
 int vio_backend_resident_load(vio_backend_t *be, int32_t slot, const VioFeatureInfo *info, int32_t n, const double *points,
                               const double last_P[3], const double last_R[9]);
+// n slots at once (ascending slot numbers): one strided copy per array and run of consecutive slots.
+int vio_backend_resident_load_batch(vio_backend_t *be, int32_t n, const int32_t *slots, const VioFeatureInfo *const *infos,
+                                    const int32_t *counts, const double *const *points, const double *last_P /* [n][3] */,
+                                    const double *last_R /* [n][9] */);
 int vio_backend_resident_fetch(vio_backend_t *be, int32_t slot, VioFeatureInfo *info, int32_t cap, int32_t *n, double *points,
                                int32_t cap_points, int32_t *n_points);
 int vio_backend_resident_begin(vio_backend_t *be);
