@@ -153,7 +153,7 @@ struct Ctx {
 
 // Charges the cycles since the previous stamp to `stage` (thread 0 only; call between barriers).
 VIO_DEV void stamp(const Ctx &cx, int stage) {
-#ifndef VIO_EMUL
+#if !defined(VIO_EMUL) && !defined(VIO_NO_STAMPS)
   if (cx.prof && cx.tid == cx.prof_tid) {  // accumulators live in LDS (a global read-modify-write per stamp costs ~3k cycles)
     long long t = clock64();
     cx.lprof[stage] += t - cx.lprof[ST_COUNT - 1];
