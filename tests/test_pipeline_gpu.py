@@ -28,3 +28,34 @@ def test_frames_in_states_out(freq):
     # the same frames give the same observations whatever the call order: the estimate is the same to rounding noise of the
     # solver's atomic accumulation order
     assert abs(serial["position_error_m_max"] - overlapped["position_error_m_max"]) < 1e-6
+
+
+def test_asynchronous_submit_gives_the_same_observations_and_reports_its_errors():
+    """vio_frontend_submit_images_async: the submit's host work runs on the context's own thread. Same observations as
+    read_images frame by frame (bit-exact: same kernels, same inputs), the pending-frame guards hold meanwhile, a second submit
+    is refused, and the context can be destroyed with its thread idle."""
+    import numpy as np
+    from helpers import abi, pkg
+    cfg = abi.default_config(max_corners=60, min_dist=25, image_rows=240, image_cols=320)
+    streams = [pkg.synth.make_image_stream(30 + q, 6, rows=240, cols=320)[0] for q in range(3)]
+    frames = np.stack(streams, axis=1)                                      # [frame][sequence][rows][cols]
+    ref = pkg.frontend.FeatureTracker(cfg, n_seq=3)
+    got = pkg.frontend.FeatureTracker(cfg, n_seq=3)
+    for k in range(frames.shape[0]):
+        want = ref.read_images(frames[k], True)
+        got.submit(frames[k], True, asynchronous=True)
+        with pytest.raises(RuntimeError):
+            got.submit(frames[k], True, asynchronous=True)               # one frame in flight per context
+        with pytest.raises(RuntimeError):
+            got.state(0)                                                  # the tracker state is in flux until collect
+        have = got.collect()
+        for (ia, xa), (ib, xb) in zip(want, have):
+            assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    with pytest.raises(RuntimeError):
+        got.collect()                                                     # nothing pending
+    # the overlapped pipeline with the asynchronous submit against the synchronous one
+    import time_pipeline as TP
+    a = TP.run(n_seq=6, n_frames=15, overlap=1, n_worlds=2, quiet=True, freq=1)
+    b = TP.run(n_seq=6, n_frames=15, overlap=2, n_worlds=2, quiet=True, freq=1)
+    assert b["overlap"] == 2 and abs(a["position_error_m_max"] - b["position_error_m_max"]) < 1e-6
+    ref.close(), got.close()

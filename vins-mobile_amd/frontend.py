@@ -72,6 +72,33 @@ class FeatureTracker:
             out.append((o["id"].copy(), np.stack([o["x"], o["y"], o["z"]], axis=1)))
         return out
 
+    def submit(self, frames, publish, asynchronous=False):
+        """vio_frontend_submit_images (asynchronous: ..._async, the submit's host work on the context's own thread; the frame
+        buffer is kept alive here until collect)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.shape == (self.n_seq, self.cfg.image_rows, self.cfg.image_cols), frames.shape
+        self._pending_frames = frames
+        fn = self.lib.vio_frontend_submit_images_async if asynchronous else self.lib.vio_frontend_submit_images
+        rc = fn(self._h, frames.ctypes.data_as(_u8p), frames.shape[1], frames.shape[2], frames.shape[2], 1 if publish else 0)
+        if rc != abi.VIO_OK:
+            self._pending_frames = None
+        self._check(rc, "submit_images")
+
+    def collect(self):
+        """vio_frontend_collect -> the list read_images returns."""
+        cap = self.cfg.max_corners
+        obs = np.zeros(self.n_seq * cap, _OBS_DTYPE)
+        n_obs = np.zeros(self.n_seq, np.int32)
+        rc = self.lib.vio_frontend_collect(self._h, C.cast(obs.ctypes.data, C.POINTER(abi.VioObs)), n_obs.ctypes.data_as(_ip))
+        self._pending_frames = None
+        self._check(rc, "collect")
+        obs = obs.reshape(self.n_seq, cap)
+        out = []
+        for s in range(self.n_seq):
+            o = obs[s, :int(n_obs[s])]
+            out.append((o["id"].copy(), np.stack([o["x"], o["y"], o["z"]], axis=1)))
+        return out
+
     def state(self, seq=0):
         cap = self.cfg.max_corners
         pts = np.zeros((cap, 2), np.float32)
