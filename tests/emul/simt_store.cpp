@@ -349,3 +349,51 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
   vio_features_destroy(fm);
   return msg.fails;
 }
+
+// ---- IMU pre-integration on a wave (preint_core.h) against the host restatement (vio_preint.h) -----------------------------
+#include "preint_core.h"
+#include "vio_preint.h"
+
+// n intervals of random length; every second one is integrated in two pieces (store, load, continue: the non-keyframe merge).
+// Returns the number of doubles that differ in any bit.
+extern "C" int simt_preint_fuzz(int seed, int n_intervals, int order) {
+  std::mt19937_64 rng(seed);
+  auto uni = [&](double a, double b) { return a + (b - a) * (double)(rng() >> 11) / 9007199254740992.0; };
+  VioConfig cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.acc_n = 0.5, cfg.acc_w = 0.002, cfg.gyr_n = 0.2, cfg.gyr_w = 4.0e-5;
+  int bad = 0;
+  for (int it = 0; it < n_intervals; it++) {
+    const int n = 1 + (int)(rng() % 24), split = (it & 1) ? 1 + (int)(rng() % n) : n;
+    double acc0[3], gyr0[3], ba[3], bg[3];
+    for (int k = 0; k < 3; k++) acc0[k] = uni(-2, 2) + (k == 2 ? 9.8 : 0), gyr0[k] = uni(-0.5, 0.5), ba[k] = uni(-0.1, 0.1), bg[k] = uni(-0.01, 0.01);
+    std::vector<double> dt(n), acc(3 * n), gyr(3 * n);
+    for (int i = 0; i < n; i++) {
+      dt[i] = uni(0.004, 0.012);
+      for (int k = 0; k < 3; k++) acc[3 * i + k] = uni(-2, 2) + (k == 2 ? 9.8 : 0), gyr[3 * i + k] = uni(-0.5, 0.5);
+    }
+    host::Preint hp;
+    host::preint_init(hp, &cfg, acc0, gyr0, ba, bg);
+    for (int i = 0; i < n; i++) host::propagate(hp, dt[i], &acc[3 * i], &gyr[3 * i]);
+    VioPreintegration want;
+    host::preint_export(hp, &want);
+    std::vector<double> blk(467, -1.0), side(preint::kSide, -1.0), lds(preint::kLdsDoubles, std::numeric_limits<double>::quiet_NaN());
+    auto run = [&](int i0, int i1, bool init) {
+      std::fill(lds.begin(), lds.end(), std::numeric_limits<double>::quiet_NaN());  // nothing survives in LDS between launches
+      simt::launch(64, [&](int lane) {
+        preint::State s;
+        if (init) preint::init_wave(s, lds.data(), lane, acc0, gyr0, ba, bg);
+        else preint::load_wave(s, lds.data(), lane, blk.data(), side.data());
+        for (int i = i0; i < i1; i++) preint::propagate_wave(s, lds.data(), lane, dt[i], &acc[3 * i], &gyr[3 * i], hp.noise);
+        preint::store_wave(s, lds.data(), lane, blk.data(), side.data());
+      }, order);
+    };
+    run(0, split, true);
+    if (split < n) run(split, n, false);
+    static_assert(sizeof(VioPreintegration) == 467 * sizeof(double), "block layout");
+    const double *w = reinterpret_cast<const double *>(&want);
+    for (int k = 0; k < 467; k++) bad += memcmp(&w[k], &blk[k], 8) != 0;
+    for (int k = 0; k < 3; k++) bad += memcmp(&side[k], &hp.acc_0[k], 8) != 0, bad += memcmp(&side[3 + k], &hp.gyr_0[k], 8) != 0;
+  }
+  return bad;
+}

@@ -442,11 +442,12 @@ def _dump_lists(est, seq=0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,seed", [(10, 5), (6, 5), (10, 21), (5, 33), (8, 8)])
-def test_resident_sequences_give_what_the_host_side_list_gives(W, seed):
+@pytest.mark.parametrize("W,seed,device_imu", [(10, 5, False), (6, 5, False), (10, 21, True), (5, 33, False), (8, 8, True)])
+def test_resident_sequences_give_what_the_host_side_list_gives(W, seed, device_imu, monkeypatch):
     """The same replay twice: landmark list, window assembly and slides on the host (vio_window.cpp) / on the device
     (store_core.h). Same keyframe decisions, same iteration counts, same landmark list at the end (ids, start frames,
     observation counts, flags exactly; depths and positions to the reproducibility of the window kernel's sums)."""
+    monkeypatch.setenv("VIO_AMD_RESIDENT_IMU", "1" if device_imu else "0")   # (read when an estimator is created)
     cfg = abi.default_config(window_size=W)
     host = RS.EstimatorLoop(cfg, seed=seed, init_noise=1.0)
     dev = RS.EstimatorLoop(cfg, seed=seed, init_noise=1.0)
@@ -604,12 +605,15 @@ def test_resident_sequence_moves_between_the_paths_in_mid_run():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("events_seed", [2024, 7, 99])
-def test_resident_stress_random_path_switches_in_a_batch(events_seed):
+@pytest.mark.parametrize("events_seed,device_imu", [(2024, False), (7, True), (99, False), (5, True)])
+def test_resident_stress_random_path_switches_in_a_batch(events_seed, device_imu, monkeypatch):
     """Six sequences in one estimator, 70 calls, seeded random events applied to a resident and a host-only estimator alike:
     sequences skipped in a call (they fall out of step with each other), looks at a landmark list (the list returns to the
     host and moves back), frames with more observations than a store slot takes, resident stores switched off and on for the
     whole object. Every sequence must follow the host-only estimator: actions, counts, positions."""
+    # device_imu: VIO_AMD_RESIDENT_IMU=1, the IMU samples of resident sequences are integrated by a kernel (preint_core.h)
+    # instead of on the host; the blocks must come out the same, so everything below must hold unchanged
+    monkeypatch.setenv("VIO_AMD_RESIDENT_IMU", "1" if device_imu else "0")
     cfg = abi.default_config(window_size=6, max_corners=40)
     W, nq, calls = cfg.window_size, 6, 70
     rng = np.random.default_rng(events_seed)

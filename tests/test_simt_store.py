@@ -51,3 +51,13 @@ def test_store_passes_match_the_host_list(seed, W, order, n_landmarks, lib):
         assert keyframes < 2 * frames // 3   # the non-keyframe slide ran often
     else:
         assert keyframes > frames // 2
+
+
+@pytest.mark.parametrize("seed,order", [(1, 0), (2, 1), (3, 2), (4, 3)])
+def test_wave_preintegration_matches_the_host_restatement_bit_for_bit(seed, order, lib):
+    """preint_core.h (one wave64 per interval, the 15 x 15 products spread over the lanes) against host::propagate
+    (vio_preint.h, the restatement of IntegrationBase::propagate): 16 intervals of 1-24 samples, every second one integrated
+    in two pieces (store, load, continue: the non-keyframe merge). Every double of the block and the carried last sample
+    must have the same bits."""
+    lib.simt_preint_fuzz.argtypes = [C.c_int] * 3
+    assert lib.simt_preint_fuzz(seed, 16, order) == 0

@@ -95,6 +95,11 @@ struct Sequence {
   // in its slot of the group's back-end; `fm` is empty meanwhile
   bool on_device = false;
   std::vector<char> pre_dirty;  // [W+1] pre[i] changed since the device last saw it
+  // IMU samples integrated on the device (resident_imu): pre[i] keeps its header (linearization biases, first sample) and
+  // the sample buffers, its Jacobian / covariance are not propagated on the host (pre_stale) until the sequence returns to
+  // the host-side list; pre_merge[i]: trailing samples of interval i that the device has not seen yet (non-keyframe slide)
+  std::vector<char> pre_stale;
+  std::vector<int> pre_merge;
 };
 
 const double kI3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -124,6 +129,10 @@ struct vio_estimator {
   // (on by default; vio_estimator_set_resident / VIO_AMD_RESIDENT=0 turn it off); needs the device-resident priors.
   bool resident = !(getenv("VIO_AMD_RESIDENT") && getenv("VIO_AMD_RESIDENT")[0] == '0');
   int res_list_cap = 0, res_obs_cap = 0;
+  // VIO_AMD_RESIDENT_IMU=1: the IMU samples of their intervals travel instead of the integrated blocks and a kernel integrates
+  // them (preint_core.h: the host's bits). Off by default: measured at 512 sequences the kernel takes what the host pool saves
+  // (124 us against ~120 us of host::propagate on 16 AVX2 threads) and sits on the frame's critical path.
+  bool resident_imu = getenv("VIO_AMD_RESIDENT_IMU") && getenv("VIO_AMD_RESIDENT_IMU")[0] == '1';
   std::vector<int> res_rc;  // per sequence: outcome of staging in the current call
   std::vector<int> solving;  // sequences of the current launch
   std::vector<VioWindow> staged;   // per sequence, built in parallel, compacted into `windows`
@@ -150,6 +159,7 @@ void clear_state(vio_estimator *e, Sequence &s) {  // VINS::clearState (VINS.cpp
   s.tmp_valid = false;
   s.initial_timestamp = 0;
   s.on_device = false;
+  std::fill(s.pre_stale.begin(), s.pre_stale.end(), 0), std::fill(s.pre_merge.begin(), s.pre_merge.end(), 0);
   vio_features_clear(s.fm);
 }
 
@@ -157,6 +167,7 @@ void new_preintegration(vio_estimator *e, Sequence &s, int i) {
   host::preint_init(s.pre[i], &e->cfg, s.acc_0, s.gyr_0, &s.Bas[3 * i], &s.Bgs[3 * i]);
   memcpy(&s.lin_acc[3 * i], s.acc_0, 24), memcpy(&s.lin_gyr[3 * i], s.gyr_0, 24);
   s.pre_valid[i] = 1;
+  s.pre_stale[i] = 0, s.pre_merge[i] = 0;
 }
 
 // IntegrationBase::repropagate (integration_base.h:47-61): the same samples again from new linearization biases
@@ -177,6 +188,7 @@ void slide_window(vio_estimator *e, Sequence &s) {
     for (int i = 0; i < W; i++) {
       for (int k = 0; k < 9; k++) std::swap(s.Rs[9 * i + k], s.Rs[9 * (i + 1) + k]);
       std::swap(s.pre[i], s.pre[i + 1]), std::swap(s.pre_valid[i], s.pre_valid[i + 1]);
+      std::swap(s.pre_stale[i], s.pre_stale[i + 1]), std::swap(s.pre_merge[i], s.pre_merge[i + 1]);
       s.dt_buf[i].swap(s.dt_buf[i + 1]), s.acc_buf[i].swap(s.acc_buf[i + 1]), s.gyr_buf[i].swap(s.gyr_buf[i + 1]);
       for (int k = 0; k < 3; k++)
         std::swap(s.lin_acc[3 * i + k], s.lin_acc[3 * (i + 1) + k]), std::swap(s.lin_gyr[3 * i + k], s.lin_gyr[3 * (i + 1) + k]);
@@ -213,9 +225,11 @@ void slide_window(vio_estimator *e, Sequence &s) {
   } else {
     // the second-newest frame leaves; its IMU samples extend the interval of the frame before it
     const int fc = s.frame_count;
+    const bool dev_imu = s.on_device && e->resident_imu;
+    if (dev_imu) s.pre_stale[fc - 1] = 1, s.pre_merge[fc - 1] += (int)s.dt_buf[fc].size();
     for (size_t i = 0; i < s.dt_buf[fc].size(); i++) {
       const double dt = s.dt_buf[fc][i];
-      if (s.pre_valid[fc - 1]) host::propagate(s.pre[fc - 1], dt, &s.acc_buf[fc][3 * i], &s.gyr_buf[fc][3 * i]);
+      if (s.pre_valid[fc - 1] && !dev_imu) host::propagate(s.pre[fc - 1], dt, &s.acc_buf[fc][3 * i], &s.gyr_buf[fc][3 * i]);
       s.dt_buf[fc - 1].push_back(dt);
       for (int k = 0; k < 3; k++)
         s.acc_buf[fc - 1].push_back(s.acc_buf[fc][3 * i + k]), s.gyr_buf[fc - 1].push_back(s.gyr_buf[fc][3 * i + k]);
@@ -380,6 +394,14 @@ int demote(vio_estimator *e, Sequence &s) {
   rc = vio_features_load(s.fm, info.data(), n, pts.data());
   if (rc != VIO_OK) return rc;
   s.on_device = false;
+  // the intervals the device integrated: integrate them here again from the buffered samples (the same operations in the
+  // same order as the incremental propagation: the same bits)
+  for (int i = 1; i <= e->W; i++)
+    if (s.pre_stale[i]) {
+      const double ba[3] = {s.pre[i].ba[0], s.pre[i].ba[1], s.pre[i].ba[2]}, bg[3] = {s.pre[i].bg[0], s.pre[i].bg[1], s.pre[i].bg[2]};
+      repropagate(e, s, i, ba, bg);
+      s.pre_stale[i] = 0, s.pre_merge[i] = 0;
+    }
   return VIO_OK;
 }
 
@@ -723,8 +745,29 @@ int resident_frame(vio_estimator *e, const VioObs *obs, const int32_t *n_obs, in
           r = VIO_ESTATE;
           break;
         }
-        host::preint_export(s.pre[k], &blk);
-        r = vio_backend_resident_stage_preint(be, slot, k - 1, &blk);
+        if (s.pre_stale[k]) {
+          // the device integrates: the whole of the newest interval, or the samples an older one absorbed at a non-keyframe slide
+          const int ns = (int)s.dt_buf[k].size();
+          const bool fresh = k == W || s.pre_merge[k] <= 0 || s.pre_merge[k] >= ns;
+          const int first = fresh ? 0 : ns - s.pre_merge[k];
+          int ri = VIO_ECAP;
+          if (k == W || s.pre_merge[k] > 0)
+            ri = vio_backend_resident_stage_imu(be, slot, k - 1, fresh ? 1 : 0, &s.lin_acc[3 * k], &s.lin_gyr[3 * k], s.pre[k].ba, s.pre[k].bg,
+                                                ns - first, s.dt_buf[k].data() + first, s.acc_buf[k].data() + 3 * first,
+                                                s.gyr_buf[k].data() + 3 * first);
+          if (ri == VIO_ECAP) {  // (no room for the samples, or a stale interval whose new samples are not known: the block instead)
+            host::Preint tmp = s.pre[k];
+            host::preint_init(tmp, &e->cfg, &s.lin_acc[3 * k], &s.lin_gyr[3 * k], s.pre[k].ba, s.pre[k].bg);
+            for (int i = 0; i < ns; i++) host::propagate(tmp, s.dt_buf[k][i], &s.acc_buf[k][3 * i], &s.gyr_buf[k][3 * i]);
+            host::preint_export(tmp, &blk);
+            ri = vio_backend_resident_stage_preint(be, slot, k - 1, &blk, tmp.acc_0, tmp.gyr_0);
+          }
+          r = ri;
+          s.pre_merge[k] = 0;
+        } else {
+          host::preint_export(s.pre[k], &blk);
+          r = vio_backend_resident_stage_preint(be, slot, k - 1, &blk, s.pre[k].acc_0, s.pre[k].gyr_0);
+        }
         s.pre_dirty[k] = 0;
       }
       if (r == VIO_OK)
@@ -820,7 +863,7 @@ int vio_estimator_create(const VioConfig *cfg, int32_t n_seq, const double tic[3
     s.pts_i.assign((size_t)3 * cfg->max_factors, 0), s.pts_j.assign((size_t)3 * cfg->max_factors, 0);
     s.f_host.assign(cfg->max_factors, 0), s.f_target.assign(cfg->max_factors, 0), s.f_feat.assign(cfg->max_factors, 0);
     s.preint.resize(W);
-    s.pre_dirty.assign(P, 0);
+    s.pre_dirty.assign(P, 0), s.pre_stale.assign(P, 0), s.pre_merge.assign(P, 0);
     clear_state(e, s);
   }
   e->windows.resize(n_seq), e->stats.resize(n_seq);
@@ -875,7 +918,8 @@ int vio_estimator_process_imu(vio_estimator_t *e, int32_t seq, double dt, const 
   const int j = s.frame_count;
   if (!s.pre_valid[j]) new_preintegration(e, s, j);
   if (j != 0) {
-    host::propagate(s.pre[j], dt, acc, gyr);
+    if (s.on_device && e->resident_imu) s.pre_stale[j] = 1;  // (the device integrates this interval from the buffered samples)
+    else host::propagate(s.pre[j], dt, acc, gyr);
     if (s.solver_flag != VIO_SOLVER_NON_LINEAR && s.tmp_valid) {  // tmp_pre_integration->push_back (VINS.cpp:350-351)
       host::propagate(s.tmp.pre, dt, acc, gyr);
       s.tmp.dt.push_back(dt);

@@ -46,7 +46,15 @@ int vio_backend_resident_begin(vio_backend_t *be);
 // prior: the header of the slot's prior (n, blocks) or null; its data is in the slot of the prior store.
 int vio_backend_resident_stage(vio_backend_t *be, int32_t slot, const VioObs *obs, int32_t n_obs, const double *Ps, const double *Rs,
                                const double *pose, const double *speed_bias, const VioPrior *prior);
-int vio_backend_resident_stage_preint(vio_backend_t *be, int32_t slot, int32_t interval, const VioPreintegration *block);
+// An integrated block (+ the interval's last sample: what more samples would continue from).
+int vio_backend_resident_stage_preint(vio_backend_t *be, int32_t slot, int32_t interval, const VioPreintegration *block,
+                                      const double last_acc[3], const double last_gyr[3]);
+// The raw IMU samples of an interval instead of its integrated block (integrated by a kernel, preint_core.h). fresh: a new
+// interval starting from (acc_0, gyr_0) with linearization biases (ba, bg); otherwise more samples for the block in place
+// (the interval that absorbed the departed frame's at a non-keyframe slide). VIO_ECAP: this frame's staging is full.
+int vio_backend_resident_stage_imu(vio_backend_t *be, int32_t slot, int32_t interval, int32_t fresh, const double acc_0[3],
+                                   const double gyr_0[3], const double ba[3], const double bg[3], int32_t n, const double *dt,
+                                   const double *acc, const double *gyr);
 int vio_backend_resident_ingest(vio_backend_t *be);
 int vio_backend_resident_launch(vio_backend_t *be);
 int vio_backend_resident_collect(vio_backend_t *be);

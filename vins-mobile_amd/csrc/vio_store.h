@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "batch.h"
+#include "preint_core.h"
 #include "store_core.h"
 
 namespace vio {
@@ -27,8 +28,16 @@ struct StoreDev {
   const double *pre_blk;           // [n_pre][kPreintDoubles]
   int n_pre;
   long long *prof;                 // null, or [32] cycle stamps written by slot 0's workgroups
+  // IMU samples to integrate on the device (preint_core.h): n_jobs records of 16 doubles
+  //   slot * W + interval | 1: a new interval, 0: more samples for the one in place | samples | first sample | acc_0 gyr_0 ba bg
+  // and the samples they name, 7 doubles each (dt, acc, gyr)
+  const double *imu_jobs, *imu_samples;
+  int n_imu_jobs;
+  double *pre_side;                // [n_slots][W][preint::kSide] last sample of every interval (what a continuation starts from)
+  const double *noise;             // [18] diagonal of the IMU noise (integration_base.h:30-36)
 };
 
+int store_launch_imu(const StoreDev &S, hipStream_t st);
 int store_launch_ingest(const StoreDev &S, hipStream_t st);
 int store_launch_pack(const StoreDev &S, const BatchPtrs &B, int chunk, hipStream_t st);
 int store_launch_finish(const StoreDev &S, const BatchPtrs &B, hipStream_t st);

@@ -19,14 +19,36 @@ __device__ __forceinline__ st::Bank bank_of(const StoreDev &S, int slot, int b) 
   return st::Bank{S.fid + e, S.start + e, S.nobs + e, S.flag + e, S.depth + e, S.obs + e * (S.d.W + 1) * 3};
 }
 
+// One wave per job: the pre-integration block of an interval from its raw samples (a new interval, or more samples for one
+// that absorbed its neighbour's at a non-keyframe slide).
+__global__ __launch_bounds__(256) void preint_jobs_kernel(StoreDev S) {
+  extern __shared__ double lds_pre[];  // (half a CU like every store kernel, see lds_block; four waves use 44 KB of it)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= S.n_imu_jobs) return;
+  const double *job = S.imu_jobs + (size_t)j * 16;
+  const int idx = (int)job[0], fresh = (int)job[1], n = (int)job[2], first = (int)job[3];
+  double *blk = S.preint + (size_t)idx * kPreintDoubles, *side = S.pre_side + (size_t)idx * preint::kSide;
+  ldsd lds = (ldsd)lds_pre + wave * preint::kLdsDoubles;
+  preint::State s;
+  if (fresh) preint::init_wave(s, lds, lane, job + 4, job + 7, job + 10, job + 13);
+  else preint::load_wave(s, lds, lane, blk, side);
+  for (int i = 0; i < n; i++) {
+    const double *smp = S.imu_samples + (size_t)(first + i) * 7;
+    preint::propagate_wave(s, lds, lane, smp[0], smp + 1, smp + 4, S.noise);
+  }
+  preint::store_wave(s, lds, lane, blk, side);
+}
+
 __global__ __launch_bounds__(st::kThreads) void store_ingest_kernel(StoreDev S) {
   extern __shared__ int lds_raw[];
   const int slot = blockIdx.x;
   // pre-integration blocks that arrive with this frame (any slot's: the blocks are spread over the grid)
   for (int k = blockIdx.x; k < S.n_pre; k += gridDim.x) {
-    const double *src = S.pre_blk + (size_t)k * kPreintDoubles;
-    double *dst = S.preint + (size_t)S.pre_idx[k] * kPreintDoubles;
+    const double *src = S.pre_blk + (size_t)k * (kPreintDoubles + 6);
+    double *dst = S.preint + (size_t)S.pre_idx[k] * kPreintDoubles, *side = S.pre_side + (size_t)S.pre_idx[k] * preint::kSide;
     for (int i = threadIdx.x; i < kPreintDoubles; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < 6) side[threadIdx.x] = src[kPreintDoubles + threadIdx.x];
   }
   if (!S.active[slot]) return;
   st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
@@ -87,6 +109,14 @@ __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, 
   // newest interval arrives with the next frame
   if (ctl[st::C_STATUS] == VIO_OK && ctl[st::C_FAIL] == 0 && ctl[st::C_MARG] == VIO_MARGIN_OLD) {
     // (every work-item reads what it moves before anything is written: one barrier, not one per interval)
+    {
+      double *sd = S.pre_side + (size_t)slot * S.d.W * preint::kSide;
+      const int ns = (S.d.W - 1) * preint::kSide;
+      double keep = 0;
+      if ((int)threadIdx.x < ns) keep = sd[preint::kSide + threadIdx.x];
+      __syncthreads();
+      if ((int)threadIdx.x < ns) sd[threadIdx.x] = keep;
+    }
     double *pre = S.preint + (size_t)slot * S.d.W * kPreintDoubles;
     const int total = (S.d.W - 1) * kPreintDoubles;
     constexpr int kPer = 24;  // doubles per work-item: enough for W <= 13 at 256 work-items
@@ -144,6 +174,16 @@ static int raise_lds(const void *fn, size_t lds) {
       return VIO_ENODEV;                                                                                        \
     }                                                                                                           \
   } while (0)
+
+int store_launch_imu(const StoreDev &S, hipStream_t stream) {
+  if (S.n_imu_jobs <= 0) return VIO_OK;
+  const size_t lds = lds_block(4 * preint::kLdsDoubles * sizeof(double));
+  const int rc = raise_lds((const void *)preint_jobs_kernel, lds);
+  if (rc != VIO_OK) return rc;
+  hipLaunchKernelGGL(preint_jobs_kernel, dim3((S.n_imu_jobs + 3) / 4), dim3(256), lds, stream, S);
+  STORE_HIP_OK(hipGetLastError());
+  return VIO_OK;
+}
 
 int store_launch_ingest(const StoreDev &S, hipStream_t stream) {
   const size_t lds = lds_block(st::lds_bytes(S.d));
