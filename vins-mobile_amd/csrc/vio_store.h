@@ -20,7 +20,8 @@ struct StoreDev {
   // this frame's inputs (device mirror of the staging arena)
   const int *active;               // [n_slots] the slot takes part in this frame
   const int *n_obs;                // [n_slots]
-  const VioObs *obs_in;            // [n_slots][Ocap]
+  const VioObs *obs_in;            // the frames' observations, packed; slot s starts at obs_off[s]
+  const int *obs_off;              // [n_slots]
   const double *Ps, *Rs;           // [n_slots][P][3], [n_slots][P][9]: the window states triangulate reads
   const double *tic, *ric;         // camera -> body
   double *preint;                  // [n_slots][W][kPreintDoubles] the pre-integration blocks of the window, kept across frames

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(st::kThreads) void store_ingest_kernel(StoreDev S) 
   if (slot == 0) l.prof = S.prof;
   int *ctl = S.ctl + (size_t)slot * st::C_COUNT;
   const int P = S.d.W + 1;
-  st::store_ingest(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, S.obs_in + (size_t)slot * S.d.Ocap, S.n_obs[slot],
+  st::store_ingest(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, S.obs_in + S.obs_off[slot], S.n_obs[slot],
                    S.Ps + (size_t)slot * 3 * P, S.Rs + (size_t)slot * 9 * P, S.tic, S.ric);
 }
 
