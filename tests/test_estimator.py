@@ -310,6 +310,7 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
     cfg = abi.default_config()
     W = cfg.window_size
     loop = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    loop.est.set_resident(True)                         # (the default; said here so that the checks below hold under VIO_AMD_RESIDENT=0)
     for _ in range(25):
         loop.step()
     assert loop.history and loop.history[-1][0] == 24
@@ -575,6 +576,7 @@ def test_resident_sequence_moves_between_the_paths_in_mid_run():
     host = RS.EstimatorLoop(cfg, seed=11, init_noise=1.0)
     dev = RS.EstimatorLoop(cfg, seed=11, init_noise=1.0)
     host.est.set_resident(False)
+    dev.est.set_resident(True)
     where = []
     for k in range(44):
         if k == 20:
@@ -621,6 +623,7 @@ def test_resident_stress_random_path_switches_in_a_batch(events_seed, device_imu
     worlds = both[0]
     ests = [pkg.estimator.Estimator(cfg, worlds[0].tic, worlds[0].ric, n_seq=nq) for _ in range(2)]
     ests[0].set_resident(False)
+    ests[1].set_resident(True)
     feeders = [[RS.EstimatorLoop(cfg, seed=60 + q, init_noise=1.0, world=both[side][q]) for q in range(nq)] for side in range(2)]
     for e, fs in zip(ests, feeders):
         for q, f in enumerate(fs):
