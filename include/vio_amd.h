@@ -705,8 +705,9 @@ int vio_estimator_get_timing(vio_estimator_t *est, double ms[3]);
  * NON_LINEAR state keeps its landmark list, its pre-integration blocks and its prior in device memory; per frame the host
  * sends the observations and the propagated window states (about 12 KB instead of about 125 KB per window), kernels do
  * addFeatureCheckParallax / triangulate / the factor list / setDepth / the slide (feature_manager.cpp:103-372), and the
- * results are the host path's bit for bit. Sequences fall back to the host-side list while they initialize, while a
- * relocalization frame is set, and when vio_estimator_features() asks for the list. */
+ * results are the host path's bit for bit (relocalization factors included). Sequences use the host-side list while they
+ * initialize, for a frame with more observations (or a relocalization frame with more matched ids) than a store slot takes,
+ * and when vio_estimator_features() asks for the list. */
 int vio_estimator_set_resident(vio_estimator_t *est, int32_t enable);
 int vio_estimator_features(vio_estimator_t *est, int32_t seq, vio_features_t **fm);
 

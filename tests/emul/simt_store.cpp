@@ -72,7 +72,7 @@ void rot_xyz(double rx, double ry, double rz, double R[9]) {
 
 // Returns the number of mismatches (0 = identical); the first ones are described in msg.
 extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_landmarks, char *msg_buf, int msg_cap,
-                               long long *stats /* [8] frames, sum F, sum M, keyframes, failures, max list, removed by depth, triangulated */) {
+                               long long *stats /* [8] frames, sum F, sum M, keyframes, failures, max list, removed by depth, relocalization factors */) {
   Msg msg{msg_buf, msg_cap};
   if (msg_cap > 0) msg_buf[0] = 0;
   const int P = W + 1;
@@ -202,7 +202,19 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
     vio_features_get_depth_vector(fm, inv.data(), cfg.max_features, &nf);
     std::vector<int> fh(cfg.max_factors), ft(cfg.max_factors), ff(cfg.max_factors);
     std::vector<double> pi(3 * (size_t)cfg.max_factors), pj(3 * (size_t)cfg.max_factors);
-    vio_features_export_factors(fm, cfg.max_factors, fh.data(), ft.data(), ff.data(), pi.data(), pj.data(), &m, &nf2);
+    // every fifth frame carries a relocalization frame: an old keyframe matched to window frame lf saw some of the landmarks
+    // (and some ids the window does not know)
+    int lf = -1, n_loopf = 0;
+    std::vector<int> lids;
+    std::vector<double> lxy;
+    if (f % 5 == 2) {
+      lf = (int)(rng() % W);
+      for (int id = 0; id < n_landmarks + 40; id++)
+        if (rng() % 3 == 0) lids.push_back(id), lxy.push_back(uni(-0.5, 0.5)), lxy.push_back(uni(-0.5, 0.5));
+    }
+    vio_features_export_factors_loop(fm, cfg.max_factors, lf, lids.data(), lxy.data(), (int)lids.size(), fh.data(), ft.data(), ff.data(),
+                                     pi.data(), pj.data(), &m, &nf2, &n_loopf);
+    if (stats) stats[7] += n_loopf;
     // ---- store: pass 1
     {
       st::Bank bk = S.bank(S.ctl[st::C_BANK]);
@@ -216,12 +228,13 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
     if (S.ctl[st::C_MARG] != (enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW) || S.ctl[st::C_TRACK] != tr || S.ctl[st::C_PNUM] != pn)
       msg.add("frame %d: marg %d/%d track %d/%d parallax_num %d/%d", f, enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW, S.ctl[st::C_MARG], tr,
               S.ctl[st::C_TRACK], pn, S.ctl[st::C_PNUM]);
-    if (S.ctl[st::C_F] != nf || S.ctl[st::C_M] != m) msg.add("frame %d: F %d/%d M %d/%d", f, nf, S.ctl[st::C_F], m, S.ctl[st::C_M]);
+    if (S.ctl[st::C_F] != nf || S.ctl[st::C_M] != m - n_loopf)
+      msg.add("frame %d: F %d/%d M %d/%d (without %d relocalization factors)", f, nf, S.ctl[st::C_F], m - n_loopf, S.ctl[st::C_M], n_loopf);
     compare_lists("ingest", f);
     if (stats) stats[0]++, stats[1] += nf, stats[2] += m, stats[3] += enough ? 1 : 0, stats[5] = std::max<long long>(stats[5], S.ctl[st::C_N]);
     // ---- pass 2 against pack_window
     {
-      BatchDims bd = make_dims(cfg, W, std::max(nf, 1) + 5, std::max(m, 1) + 9, false);
+      BatchDims bd = make_dims(cfg, W, std::max(nf, 1) + 5, std::max(m, 1) + 9, n_loopf > 0);
       HostBatch hb;
       hb.resize(bd, 1);
       const int chunk = (f % 3 == 0) ? 0 : (f % 3 == 1 ? 96 : 40);
@@ -234,7 +247,7 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
       w.window_size = W, w.n_features = nf, w.n_factors = m, w.marginalization_flag = enough ? VIO_MARGIN_OLD : VIO_MARGIN_SECOND_NEW;
       w.pose = pose.data(), w.speed_bias = sbv.data(), w.ex_pose = ex, w.inv_depth = inv.data();
       w.factor_host = fh.data(), w.factor_target = ft.data(), w.factor_feature = ff.data(), w.factor_pts_i = pi.data(), w.factor_pts_j = pj.data();
-      w.preint = pre.data(), w.loop_frame = -1;
+      w.preint = pre.data(), w.loop_frame = n_loopf > 0 ? lf : -1;
       rc = pack_window(hb, 0, w, false, chunk);
       if (rc != VIO_OK) msg.add("frame %d: pack_window rc %d", f, rc);
       const BatchStrides &s = hb.s;
@@ -249,11 +262,13 @@ extern "C" int simt_store_fuzz(int seed, int frames, int W, int order, int n_lan
       std::vector<int> bins(3 * (P + 1) * (P + 1), -1);
       st::Bank bk = S.bank(S.ctl[st::C_BANK]);
       st::Lds l = S.lds();
+      const st::LoopIn lp{lf, (int)lids.size(), lids.data(), lxy.data()};
       simt::launch(st::kThreads, [&](int tid) {
         st::Cx cx{tid, st::kThreads};
-        st::store_pack(cx, S.d, bk, S.ctl.data(), l, o, chunk, keys.data(), own.data(), bins.data());
+        st::store_pack(cx, S.d, bk, S.ctl.data(), l, o, chunk, keys.data(), own.data(), bins.data(), lp);
       }, order);
       if (S.ctl[st::C_STATUS] != VIO_OK) msg.add("frame %d: store_pack status %d", f, S.ctl[st::C_STATUS]);
+      if (S.ctl[st::C_NLOOP] != n_loopf || S.ctl[st::C_M] != m) msg.add("frame %d: relocalization factors %d/%d, M %d/%d", f, n_loopf, S.ctl[st::C_NLOOP], m, S.ctl[st::C_M]);
       const int *hh = hb.hdr.data();
       const int idx[] = {H_F, H_M, H_HAS_LOOP, H_LOOP_FRAME, H_MARG, H_NPAIRS, H_NSLOTS, H_NREV};
       for (int q : idx)

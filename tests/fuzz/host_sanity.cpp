@@ -41,7 +41,7 @@ int vio_backend_resident_load_batch(vio_backend_t *, int32_t, const int32_t *, c
                                     const double *, const double *) { return VIO_ENODEV; }
 int vio_backend_resident_begin(vio_backend_t *) { return VIO_ENODEV; }
 int vio_backend_resident_stage(vio_backend_t *, int32_t, const VioObs *, int32_t, const double *, const double *, const double *, const double *,
-                               const VioPrior *) { return VIO_ENODEV; }
+                               const VioPrior *, int32_t, const int32_t *, const double *, int32_t) { return VIO_ENODEV; }
 int vio_backend_resident_stage_preint(vio_backend_t *, int32_t, int32_t, const VioPreintegration *, const double *, const double *) { return VIO_ENODEV; }
 int vio_backend_resident_stage_imu(vio_backend_t *, int32_t, int32_t, int32_t, const double *, const double *, const double *, const double *, int32_t,
                                    const double *, const double *, const double *) { return VIO_ENODEV; }

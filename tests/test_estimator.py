@@ -337,7 +337,7 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
     res = loop.step()
     assert res.action == abi.VIO_FRAME_SOLVED and res.n_loop_factors == len(ids)
     st = est.status()
-    assert st.resident == 0                             # the loop factors are paired with the landmarks on the host-side list
+    assert st.resident == 1                             # (solved on the host-side list -- the look above had fetched it --, then back on the device)
     assert np.abs(np.array(st.r_drift).reshape(3, 3) - np.eye(3)).max() < 2e-2
     assert np.abs(np.array(st.t_drift) - drift).max() < 0.1, st.t_drift[:]
     assert np.abs(np.array(st.relative_t)).max() < 0.1 and abs(st.relative_yaw) < 1.0   # loop pose ~ frame i itself
@@ -352,8 +352,7 @@ def test_relocalization_adds_loop_factors_and_reports_the_drift():
             break
     assert n_loop[0] > 0 and n_loop[-1] == 0 and all(a >= b for a, b in zip(n_loop, n_loop[1:]))
     assert est.window()["headers"][0] > win["headers"][i]          # ... which happened because its frame left the window
-    loop.step()
-    assert est.status().resident == 1                   # the inert relocalization frame no longer keeps the sequence on the host
+    assert est.status().resident == 1                   # the loop factors of the later frames were paired on the device
     loop.close()
 
 
@@ -669,3 +668,47 @@ def test_resident_stress_random_path_switches_in_a_batch(events_seed, device_imu
         assert len(a) == len(b) and len(a) > 30 and np.abs(a - b).max() < 1e-5, (q, len(a), len(b))
     for e in ests:
         e.close()
+
+
+@pytest.mark.gpu
+def test_resident_relocalization_factors_match_the_host_side_list():
+    """The same relocalization frame handed to a host-only and a resident estimator: the loop factors are paired with the
+    landmarks by store_pack on the device (the forward walk of VINS.cpp:597-631 as a prefix maximum), the loop pose is solved
+    and the drift reported -- same factor counts frame by frame, same drift, same positions, and the sequence never leaves the
+    device."""
+    cfg = abi.default_config()
+    W = cfg.window_size
+    host = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    dev = RS.EstimatorLoop(cfg, seed=5, init_noise=1.0)
+    host.est.set_resident(False), dev.est.set_resident(True)
+    for _ in range(25):
+        host.step(), dev.step()
+    win = host.est.window()
+    i = 4
+    info, pts = host.est.features().dump()             # (the host-only estimator's list: looking at it moves nothing)
+    ids, xy, off = [], [], 0
+    for fid, start, n_obs in info[:, :3].astype(int):
+        if start <= i <= start + n_obs - 1 and n_obs >= 2 and start < W - 2:
+            p = pts[off + (i - start)]
+            ids.append(fid), xy.append([p[0], p[1]])
+        off += n_obs
+    assert len(ids) > 30
+    drift = np.array([1.5, -0.5, 0.0])
+    for loop in (host, dev):
+        w = loop.est.window()
+        loop.est.set_relocalization(w["headers"][i], w["Ps"][i] + drift, synth.rot_to_quat(w["Rs"][i]), ids, xy)
+    n_loop = []
+    for k in range(14):
+        a, b = host.step(), dev.step()
+        assert a.action == b.action == abi.VIO_FRAME_SOLVED
+        assert a.n_loop_factors == b.n_loop_factors and a.n_factors == b.n_factors and a.stats.iterations == b.stats.iterations
+        assert dev.est.status().resident == 1
+        n_loop.append(b.n_loop_factors)
+        sa, sb = host.est.status(), dev.est.status()
+        for key in ("r_drift", "t_drift", "relative_t", "relative_q", "loop_pose"):
+            assert np.abs(np.array(getattr(sa, key)) - np.array(getattr(sb, key))).max() < 1e-5, (k, key)
+        assert abs(sa.relative_yaw - sb.relative_yaw) < 1e-5
+    assert n_loop[0] == len(ids) and n_loop[-1] == 0                # the constraint entered with every match and left with its frame
+    dp = np.array([x[1] - y[1] for x, y in zip(host.history, dev.history)])
+    assert np.abs(dp).max() < 1e-5
+    host.close(), dev.close()

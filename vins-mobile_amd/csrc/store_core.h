@@ -39,6 +39,7 @@ enum {
   C_M,           // projection factors
   C_FAIL,        // failureDetection reasons of this frame's solve
   C_NPAIRS, C_NSLOTS,
+  C_NLOOP,       // relocalization factors of this window (VINS.cpp:597-631)
   C_COUNT = 16
 };
 constexpr int kCtlDoubles = 12;  // last_P[3], last_R[9]
@@ -148,6 +149,34 @@ VIO_DEV int block_scan(const Cx &cx, int n, ldsi out, ldsi part, F val) {
   if (t == 0) out[n] = part[cx.nt];
   VIO_SYNC();
   return out[n];
+}
+
+// out[i] = max of val(k) for k < i (0 for i = 0), values >= 0. Every work-item calls it. Same shape as block_scan.
+template <class F>
+VIO_DEV void block_prefix_max(const Cx &cx, int n, ldsi out, ldsi part, F val) {
+  const int t = VIO_TID(cx);
+  const int per = (n + cx.nt - 1) / cx.nt;
+  const int b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+  int m = 0;
+  for (int i = b; i < e; i++) {
+    const int v = val(i);
+    out[i] = m;
+    m = v > m ? v : m;
+  }
+  part[t] = m;
+  VIO_SYNC();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < cx.nt; k++) {
+      const int v = part[k];
+      part[k] = acc;
+      acc = v > acc ? v : acc;
+    }
+  }
+  VIO_SYNC();
+  const int off = part[t];
+  for (int i = b; i < e; i++) out[i] = out[i] > off ? out[i] : off;
+  VIO_SYNC();
 }
 
 VIO_DEV bool solved_in_window(int nobs, int start, int W) { return nobs >= 2 && start < W - 2; }
@@ -402,6 +431,14 @@ VIO_DEV void store_ingest(const Cx &cx, const Dims &d, const Bank &bk, int *ctl,
 // What build_window + pack_window leave in the batch arrays for the landmark side of window b: para_Feature, the factor
 // list (grouped by landmark, host = start frame, one factor per later observation), fstart, and the (host, target) buckets
 // with their even-padded, chunk-aligned staging slots. keys / own: unsigned short scratch in LDS.
+// The relocalization frame of a window (VINS.cpp:571-631): the window frame the old keyframe was matched to and the
+// matched landmarks' ids (ascending) with their observations in the old keyframe. frame < 0: none.
+struct LoopIn {
+  int frame, n;
+  const int *ids;
+  const double *xy;  // [n][2]
+};
+
 struct PackOut {
   int *hdr;  // [kHdrInts] of window b: H_F, H_M, H_MARG, H_NPAIRS, H_NSLOTS, H_NREV, H_HAS_LOOP, H_LOOP_FRAME are written here
   double *feat;
@@ -414,36 +451,76 @@ enum { PH_F = 1, PH_M = 2, PH_HAS_LOOP = 3, PH_LOOP_FRAME = 4, PH_MARG = 5, PH_N
 
 VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, const Lds &l, const PackOut &o, int chunk,
                         VIO_AS3 unsigned short *keys /* [Mcap + 8] */, VIO_AS3 unsigned short *own /* [Mcap + 8] */,
-                        ldsi bins /* [3 (P+1)^2] */) {
+                        ldsi bins /* [3 (P+1)^2] */, const LoopIn &loop) {
   const int W = d.W, P = W + 1, np1 = P + 1, nkeys = np1 * np1;
   const int t = VIO_TID(cx);
   const int n = ctl[C_N];
   if (ctl[C_STATUS] != VIO_OK) return;
   STORE_STAMP(l, 8);
+  // start frame and observation count of every landmark of the window, two bytes each (0xffff: not in the window; bit 7:
+  // it has a relocalization factor), and behind them the index of its match in the old keyframe (-1: none)
+  VIO_AS3 unsigned short *ent = (VIO_AS3 unsigned short *)l.term;
+  ldsi lpi = (ldsi)l.term + d.Lcap;
+  // The reference pairs the landmarks with the old keyframe's ids by ONE forward walk over both lists (VINS.cpp:597-631,
+  // vio_window.cpp export_factors): the id pointer r only advances, so a landmark matches when its id is found at or
+  // behind where the landmarks ahead of it in the list left r. r ahead of landmark i = the largest (lower bound + 1 if
+  // found) among the considered landmarks before it: a prefix maximum.
+  VIO_PARFOR(i, n) {
+    const int no = bk.nobs[i], s = bk.start[i];
+    int enc = 0;  // 0: not considered, else 1 + (lower bound << 1 | found)
+    if (loop.frame >= 0 && solved_in_window(no, s, W) && s <= loop.frame && s + no - 1 >= loop.frame) {
+      const int id = bk.fid[i];
+      int lo = 0, hi = loop.n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (loop.ids[mid] < id) lo = mid + 1;
+        else hi = mid;
+      }
+      enc = 1 + (lo << 1 | ((lo < loop.n && loop.ids[lo] == id) ? 1 : 0));
+    }
+    lpi[i] = enc;
+  }
+  VIO_SYNC();
+  block_prefix_max(cx, n, l.scanA, l.part, [&](int i) {
+    const int enc = lpi[i];
+    return enc ? ((enc - 1) >> 1) + ((enc - 1) & 1) : 0;
+  });
+  VIO_PARFOR(i, n) {
+    const int enc = lpi[i];
+    const int lb = (enc - 1) >> 1;
+    lpi[i] = (enc && ((enc - 1) & 1) && lb >= l.scanA[i]) ? lb : -1;
+  }
+  if (t == 0) l.misc[7] = 0;
+  VIO_SYNC();
   const int F = block_scan(cx, n, l.scanA, l.part, [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? 1 : 0; });
-  const int M = block_scan(cx, n, l.scanB, l.part,
-                           [&](int i) { return solved_in_window(bk.nobs[i], bk.start[i], W) ? bk.nobs[i] - 1 : 0; });
+  const int M = block_scan(cx, n, l.scanB, l.part, [&](int i) {
+    return solved_in_window(bk.nobs[i], bk.start[i], W) ? bk.nobs[i] - 1 + (lpi[i] >= 0 ? 1 : 0) : 0;
+  });
   STORE_STAMP(l, 9);
   if (F > o.Fcap || M > o.Mcap) {
     if (t == 0) ctl[C_STATUS] = VIO_ECAP;
     return;
   }
   ldsi cnt = bins, start = bins + nkeys, pkey = bins + 2 * nkeys;
-  // start frame and observation count of every landmark of the window, two bytes each (0xffff: not in the window)
-  VIO_AS3 unsigned short *ent = (VIO_AS3 unsigned short *)l.term;
   VIO_PARFOR(k, nkeys) cnt[k] = 0;
   // per landmark: its para_Feature row, its factor range, and for each of its factors who owns it and which bucket it is in
+  // (the relocalization factor closes the landmark's group; its target is the loop pose, index P)
   VIO_PARFOR(i, n) {
     const int no = bk.nobs[i], s = bk.start[i];
     if (!solved_in_window(no, s, W)) {
       ent[i] = 0xffff;
       continue;
     }
-    ent[i] = (unsigned short)(s << 8 | no);
+    const bool lp = lpi[i] >= 0;
+    ent[i] = (unsigned short)(s << 8 | no | (lp ? 0x80 : 0));
     const int fi = l.scanA[i], k0 = l.scanB[i];
     o.feat[fi] = 1. / bk.depth[i];
     o.fstart[fi] = k0;
     for (int j = 1; j < no; j++) keys[k0 + j - 1] = (unsigned short)(s * np1 + s + j), own[k0 + j - 1] = (unsigned short)i;
+    if (lp) {
+      keys[k0 + no - 1] = (unsigned short)(s * np1 + P), own[k0 + no - 1] = (unsigned short)i;
+      __hip_atomic_fetch_add(&l.misc[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   VIO_PARFOR(i, 4) ent[n + i] = 0xffff;  // (the slot pass reads four landmarks at a time)
   if (t == 0) o.fstart[F] = M;
@@ -451,10 +528,18 @@ VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, c
   // per factor: host, target, landmark row, the two observations
   VIO_PARFOR(k, M) {
     const int i = own[k], key = keys[k];
-    const int s = key / np1, j = key - s * np1 - s;
-    const double *p0 = bk.obs + (size_t)i * P * 3, *pj = p0 + 3 * j;
-    const double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = pj[0], b1 = pj[1], b2 = pj[2];
-    o.fhost[k] = s, o.ftarget[k] = s + j, o.ffeat[k] = l.scanA[i];
+    const int s = key / np1, tg = key - s * np1;
+    const double *p0 = bk.obs + (size_t)i * P * 3;
+    const double a0 = p0[0], a1 = p0[1], a2 = p0[2];
+    double b0, b1, b2;
+    if (tg == P) {
+      const double *q = loop.xy + 2 * lpi[i];
+      b0 = q[0], b1 = q[1], b2 = 1.0;
+    } else {
+      const double *pj = p0 + 3 * (tg - s);
+      b0 = pj[0], b1 = pj[1], b2 = pj[2];
+    }
+    o.fhost[k] = s, o.ftarget[k] = tg, o.ffeat[k] = l.scanA[i];
     o.pts_i[3 * k] = a0, o.pts_i[3 * k + 1] = a1, o.pts_i[3 * k + 2] = a2;
     o.pts_j[3 * k] = b0, o.pts_j[3 * k + 1] = b1, o.pts_j[3 * k + 2] = b2;
     __hip_atomic_fetch_add(&cnt[key], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -494,21 +579,30 @@ VIO_DEV void store_pack(const Cx &cx, const Dims &d, const Bank &bk, int *ctl, c
   // the number of earlier landmarks hosted in the bucket's host frame that reach its target frame.
   VIO_PARFOR(pi, npairs) {
     const int key = pkey[pi];
-    const int h = key / np1, dt = key - h * np1 - h;
+    const int h = key / np1, tg = key - h * np1, dt = tg - h;
+    const bool to_loop = tg == P;
     int s = start[key];
-    o.pair_h[pi] = h, o.pair_t[pi] = h + dt, o.pair_s0[pi] = s, o.pair_s1[pi] = s + cnt[key];
+    o.pair_h[pi] = h, o.pair_t[pi] = tg, o.pair_s0[pi] = s, o.pair_s1[pi] = s + cnt[key];
     for (int i = 0; i < n; i += 4) {
       const unsigned long long q = *(const VIO_AS3 unsigned long long *)(ent + i);
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const int e = (int)((q >> (16 * c)) & 0xffff);
-        if ((e >> 8) == h && (e & 0xff) > dt) o.fslot[l.scanB[i + c] + dt - 1] = s++;
+        if ((e >> 8) != h) continue;
+        const int no = e & 0x7f;
+        if (to_loop) {
+          if (e & 0x80) o.fslot[l.scanB[i + c] + no - 1] = s++;
+        } else if (no > dt) {
+          o.fslot[l.scanB[i + c] + dt - 1] = s++;
+        }
       }
     }
   }
   STORE_STAMP(l, 12);
   if (t == 0) {
-    o.hdr[PH_F] = F, o.hdr[PH_M] = M, o.hdr[PH_HAS_LOOP] = 0, o.hdr[PH_LOOP_FRAME] = -1, o.hdr[PH_MARG] = ctl[C_MARG];
+    const int nl = l.misc[7];
+    o.hdr[PH_F] = F, o.hdr[PH_M] = M, o.hdr[PH_HAS_LOOP] = nl > 0 ? 1 : 0, o.hdr[PH_LOOP_FRAME] = nl > 0 ? loop.frame : -1, o.hdr[PH_MARG] = ctl[C_MARG];
+    ctl[C_M] = M, ctl[C_NLOOP] = nl;
     o.hdr[PH_NPAIRS] = npairs, o.hdr[PH_NSLOTS] = l.misc[5], o.hdr[PH_NREV] = 0;
     ctl[C_NPAIRS] = npairs, ctl[C_NSLOTS] = l.misc[5];
   }

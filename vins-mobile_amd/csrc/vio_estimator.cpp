@@ -315,11 +315,10 @@ int group_of(const vio_estimator *e, const Sequence &s) { return s.index / e->gr
 int slot_of(const vio_estimator *e, const Sequence &s) { return s.index % e->group_size; }
 
 bool resident_eligible(const vio_estimator *e, const Sequence &s) {
-  // (a relocalization frame adds factors against the old keyframe while it is in the window: the host-side list pairs
-  // them with the landmarks; once the frame has left the window it is inert, VINS.cpp:571-596)
-  const bool reloc = !s.retrive.ids.empty() && s.retrive.header >= s.Headers[0];
-  return e->resident && e->resident_priors && s.solver_flag == VIO_SOLVER_NON_LINEAR && s.frame_count == e->W && !reloc && !s.loop_enable &&
-         !s.failure_occur;
+  // (a relocalization frame with more matched ids than a store slot takes stays with the host-side list while the frame
+  // is in the window, VINS.cpp:571-596)
+  const bool reloc = (int)s.retrive.ids.size() > 256 && s.retrive.header >= s.Headers[0];
+  return e->resident && e->resident_priors && s.solver_flag == VIO_SOLVER_NON_LINEAR && s.frame_count == e->W && !reloc && !s.failure_occur;
 }
 
 // The group's store exists (reserved at the first promotion). Main thread: HIP calls.
@@ -405,18 +404,20 @@ int demote(vio_estimator *e, Sequence &s) {
   return VIO_OK;
 }
 
-// double2vector of a window solved on the resident path + the prior hand-over (take_solution without the landmark and
-// loop parts: the landmarks took their depths in store_finish, a sequence with a relocalization frame is not resident).
-void take_resident_solution(vio_estimator *e, Sequence &s, const VioResidentResult &r, const VioPrior &next) {
+void take_solution(vio_estimator *e, Sequence &s, const VioWindow &w, const VioSolveStats &st);
+
+// double2vector of a window solved on the resident path: the results take the places unpack_window gives them on the host
+// path and take_solution runs as it does there (the relocalization bookkeeping included; the landmarks took their depths
+// in store_finish).
+void take_resident_solution(vio_estimator *e, Sequence &s, const VioResidentResult &r, VioPrior &next) {
   const int P = e->W + 1;
-  s.final_cost = r.stats.final_cost;
-  for (int i = 0; i < P; i++) {
-    const double *p = r.pose + 7 * i, *b = r.speed_bias + 9 * i;
-    qtoR(qfrom_pose(p), &s.Rs[9 * i]);
-    for (int k = 0; k < 3; k++)
-      s.Ps[3 * i + k] = p[k], s.Vs[3 * i + k] = b[k], s.Bas[3 * i + k] = b[3 + k], s.Bgs[3 * i + k] = b[6 + k];
-  }
-  if (next.n > 0) s.cur_prior = 1 - s.cur_prior, s.has_prior = true;
+  memcpy(s.pose.data(), r.pose, sizeof(double) * 7 * P), memcpy(s.sb.data(), r.speed_bias, sizeof(double) * 9 * P);
+  if (r.raw_pose) memcpy(s.raw_pose.data(), r.raw_pose, sizeof(double) * 7 * P);
+  if (r.loop_pose && r.n_loop_factors > 0) memcpy(s.loop_pose, r.loop_pose, sizeof(s.loop_pose));
+  VioWindow w;
+  memset(&w, 0, sizeof(w));
+  w.window_size = e->W, w.n_features = r.n_features, w.next_prior = &next;
+  take_solution(e, s, w, r.stats);
 }
 
 double normalize_angle(double a) {  // Utility::normalizeAngle, degrees (utility.hpp:171-179)
@@ -481,7 +482,7 @@ void take_solution(vio_estimator *e, Sequence &s, const VioWindow &w, const VioS
       for (int k = 0; k < 3; k++) s.t_drift[k] = s.front.P_old[k] - t[k];
     }
   }
-  vio_features_set_depth(s.fm, s.inv_depth.data(), w.n_features);
+  if (!s.on_device) vio_features_set_depth(s.fm, s.inv_depth.data(), w.n_features);
   // n == -1: MARGIN_SECOND_NEW without the second-newest pose in the old prior leaves it as it was (VINS.cpp:778-779)
   if (w.next_prior && w.next_prior->n > 0) s.cur_prior = 1 - s.cur_prior, s.has_prior = true;
 }
@@ -770,9 +771,16 @@ int resident_frame(vio_estimator *e, const VioObs *obs, const int32_t *n_obs, in
         }
         s.pre_dirty[k] = 0;
       }
+      // relocalization constraint (build_window): front_pose follows retrive_pose_data; it enters while its frame is in the window
+      if (s.front.header != s.retrive.header) s.front = s.retrive;
+      s.loop_frame = -1;
+      if (!s.front.ids.empty() && s.front.header >= s.Headers[0])
+        for (int i = 0; i < W; i++)
+          if (s.front.header == s.Headers[i]) s.loop_frame = i;
       if (r == VIO_OK)
         r = vio_backend_resident_stage(be, slot, obs + (size_t)q * obs_stride, n_obs[q], s.Ps.data(), s.Rs.data(), s.pose.data(), s.sb.data(),
-                                       s.has_prior ? &s.prior[s.cur_prior].p : nullptr);
+                                       s.has_prior ? &s.prior[s.cur_prior].p : nullptr, s.loop_frame, s.front.ids.data(), s.front.xy.data(),
+                                       (int)s.front.ids.size());
       e->res_rc[q] = r;
       (void)res;
     });
@@ -810,8 +818,11 @@ int resident_frame(vio_estimator *e, const VioObs *obs, const int32_t *n_obs, in
     }
     s.marginalization_flag = r.marginalization_flag, s.last_track_num = r.track_num;
     res.marginalization_flag = r.marginalization_flag, res.track_num = r.track_num;
-    res.n_features = r.n_features, res.n_factors = r.n_factors, res.n_loop_factors = 0;
+    res.n_features = r.n_features, res.n_factors = r.n_factors, res.n_loop_factors = r.n_loop_factors;
     res.stats = r.stats;
+    s.n_loop_factors = r.n_loop_factors;
+    if (s.n_loop_factors > 0) s.loop_enable = true;
+    if (s.loop_frame >= 0 && s.n_loop_factors == 0) s.loop_frame = -1;  // a loop pose without factors is a free block (build_window)
     take_resident_solution(e, s, r, next);
     s.failure_occur = 0;
     if (r.failure_reasons) {

@@ -23,6 +23,9 @@ struct VioResidentResult {
   int32_t failure_reasons;  // failureDetection of the solved window (the store has cleared itself when non-zero)
   const double *pose;       // [W+1][7] solved window after new2old
   const double *speed_bias; // [W+1][9]
+  int32_t n_loop_factors;   // relocalization factors of the window (0: its loop pose was not part of the solve)
+  const double *raw_pose;   // [W+1][7] the solved window before new2old, and
+  const double *loop_pose;  // [7] the solved loop pose: both only when some slot of the frame carried a relocalization frame
   VioSolveStats stats;
 };
 
@@ -44,8 +47,11 @@ int vio_backend_resident_fetch(vio_backend_t *be, int32_t slot, VioFeatureInfo *
                                int32_t cap_points, int32_t *n_points);
 int vio_backend_resident_begin(vio_backend_t *be);
 // prior: the header of the slot's prior (n, blocks) or null; its data is in the slot of the prior store.
+// loop_frame >= 0: the window frame a relocalization frame is matched to, with the matched landmark ids (ascending, at
+// most 256) and their observations in the old keyframe (retrive_pose_data, VINS.cpp:571-631).
 int vio_backend_resident_stage(vio_backend_t *be, int32_t slot, const VioObs *obs, int32_t n_obs, const double *Ps, const double *Rs,
-                               const double *pose, const double *speed_bias, const VioPrior *prior);
+                               const double *pose, const double *speed_bias, const VioPrior *prior, int32_t loop_frame,
+                               const int32_t *loop_ids, const double *loop_xy, int32_t n_loop);
 // An integrated block (+ the interval's last sample: what more samples would continue from).
 int vio_backend_resident_stage_preint(vio_backend_t *be, int32_t slot, int32_t interval, const VioPreintegration *block,
                                       const double last_acc[3], const double last_gyr[3]);

@@ -32,6 +32,10 @@ struct StoreDev {
   // IMU samples to integrate on the device (preint_core.h): n_jobs records of 16 doubles
   //   slot * W + interval | 1: a new interval, 0: more samples for the one in place | samples | first sample | acc_0 gyr_0 ba bg
   // and the samples they name, 7 doubles each (dt, acc, gyr)
+  // relocalization frames (store_core.h LoopIn): per slot the window frame (-1: none), the number of matched ids and where
+  // they start in the packed id / observation arrays
+  const int *loop_frame, *loop_n, *loop_off, *loop_ids;
+  const double *loop_xy;
   const double *imu_jobs, *imu_samples;
   int n_imu_jobs;
   double *pre_side;                // [n_slots][W][preint::kSide] last sample of every interval (what a continuation starts from)

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, Ba
   o.pair_s0 = const_cast<int *>(B.pair_s0) + b * s.pair, o.pair_s1 = const_cast<int *>(B.pair_s1) + b * s.pair;
   o.pts_i = const_cast<double *>(B.pts_i) + b * s.pts, o.pts_j = const_cast<double *>(B.pts_j) + b * s.pts;
   o.Fcap = B.d.Fcap, o.Mcap = B.d.Mcap, o.pair_cap = B.d.pair_cap, o.slot_cap = 2 * (size_t)B.d.Mcap + B.d.pair_cap + 2;  // = slot_capacity(B.d) (batch.h, host function)
-  st::store_pack(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, o, chunk, keys, own, bins);
+  st::LoopIn lp;
+  lp.frame = S.loop_frame[slot], lp.n = S.loop_n[slot], lp.ids = S.loop_ids + S.loop_off[slot], lp.xy = S.loop_xy + 2 * (size_t)S.loop_off[slot];
+  st::store_pack(cx, S.d, bank_of(S, slot, ctl[st::C_BANK]), ctl, l, o, chunk, keys, own, bins, lp);
 }
 
 __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, BatchPtrs B) {
