@@ -629,7 +629,7 @@ def test_resident_stress_random_path_switches_in_a_batch(events_seed, device_imu
             f.est.close()
             f.est = _SeqView(e, q)
     got = [[[] for _ in range(nq)] for _ in range(2)]
-    resident_calls = 0
+    resident_calls, n_reloc, n_loopf = 0, 0, 0
     for call in range(calls):
         active = [1 if rng.random() > 0.12 else 0 for _ in range(nq)]
         burst = [bool(a and rng.random() < 0.06) for a in active]
@@ -659,10 +659,35 @@ def test_resident_stress_random_path_switches_in_a_batch(events_seed, device_imu
             assert a.action == b.action and a.n_features == b.n_features and a.n_factors == b.n_factors, (call, q, a.action, b.action)
             assert a.marginalization_flag == b.marginalization_flag and a.track_num == b.track_num
         resident_calls += sum(ests[1].status(q).resident for q in range(nq))
+        # now and then a sequence gets a relocalization frame: a window frame's landmarks as the host-only estimator lists them,
+        # seen from a shifted old keyframe; both estimators get the same call
+        for q in range(nq):
+            if results[0][q].action != abi.VIO_FRAME_SOLVED or rng.random() > 0.08:
+                continue
+            wq = ests[0].window(q)
+            i = int(rng.integers(1, W - 1))
+            info, pts = ests[0].features(q).dump()
+            ids, xy, off = [], [], 0
+            for fid, start, n_obs in info[:, :3].astype(int):
+                if start <= i <= start + n_obs - 1:
+                    p = pts[off + (i - start)]
+                    ids.append(int(fid)), xy.append([p[0], p[1]])
+                off += n_obs
+            order = np.argsort(ids)
+            ids, xy = [ids[j] for j in order], [xy[j] for j in order]
+            if len(ids) < 8:
+                continue
+            n_reloc += 1
+            for e in ests:
+                e.set_relocalization(wq["headers"][i], wq["Ps"][i] + np.array([0.4, -0.2, 0.0]), synth.rot_to_quat(wq["Rs"][i]), ids, xy, seq=q)
+        for q in range(nq):
+            assert results[0][q].n_loop_factors == results[1][q].n_loop_factors
+            n_loopf += results[1][q].n_loop_factors
         for q in peek:
             la, lb = ests[0].features(q).dump(), ests[1].features(q).dump()
             assert np.array_equal(la[0][:, [0, 1, 2, 4]], lb[0][:, [0, 1, 2, 4]]) and np.array_equal(la[1], lb[1])
     assert resident_calls > nq * 20            # the sequences did spend most of the solved frames on the device
+    assert n_reloc >= 3 and n_loopf > 50       # ... and relocalization factors were paired on both paths
     for q in range(nq):
         a, b = np.array(got[0][q]), np.array(got[1][q])
         assert len(a) == len(b) and len(a) > 30 and np.abs(a - b).max() < 1e-5, (q, len(a), len(b))
