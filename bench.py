@@ -475,7 +475,7 @@ def end_to_end(n_seq):
     run = lambda n, frames, env=None: _tool("import time_estimator as TE; s, _, _, l = TE.run(%d, %d, quiet=True); print(json.dumps([s, l]))"
                                             % (n, frames), env)
     a, b, c = run(n_seq, 40), run(2 * n_seq, 36), run(4 * n_seq, 30)   # (enough frames behind the one-time allocations of the first solves)
-    h = run(n_seq, 40, {"VIO_AMD_RESIDENT": "0"})
+    h = run(n_seq, 40, {"VIO_AMD_RESIDENT": "0", "VIO_AMD_HOST_THREADS": "64"})   # (its own best pool width)
     solves, lib_s = a
     per = lambda r, n: {"value": r[0] / r[1], "ms_per_frame_of_all_sequences": r[1] / (r[0] // n) * 1e3}
     return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
@@ -486,7 +486,7 @@ def end_to_end(n_seq):
             "ms_per_frame_of_all_sequences": lib_s / (solves // n_seq) * 1e3,
             "at_%d_sequences" % (2 * n_seq): per(b, 2 * n_seq), "at_%d_sequences" % (4 * n_seq): per(c, 4 * n_seq),
             "host_side_lists": dict(per(h, n_seq), sequences=n_seq, note="VIO_AMD_RESIDENT=0: FeatureManager lists, window assembly "
-                                    "and packing on the host pool, ~125 KB of upload per window (round 3's path)")}
+                                    "and packing on the host pool (64 threads, its best width), ~125 KB of upload per window (round 3's path)")}
 
 
 def end_to_end_full(n_seq):
@@ -498,7 +498,7 @@ def end_to_end_full(n_seq):
     run = lambda n, frames, overlap, freq, env=None: _tool(
         "import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %d, quiet=True, freq=%d)))" % (n, frames, overlap, freq), env)
     every, twice, sync_submit, serial, app = run(n_seq, 28, 2, 1), run(2 * n_seq, 26, 2, 1), run(n_seq, 22, 1, 1), run(n_seq, 22, 0, 1), run(n_seq, 20, 2, 3)
-    host_lists = run(n_seq, 22, 1, 1, {"VIO_AMD_RESIDENT": "0"})
+    host_lists = run(n_seq, 22, 1, 1, {"VIO_AMD_RESIDENT": "0", "VIO_AMD_HOST_THREADS": "64"})
     return {"value": every["camera_frames_per_s"], "unit": "camera frames/s, every frame published and solved", "sequences": n_seq,
             "path": "pageable frames in -> vio_frontend_submit_images_async (gather to page-locked memory, H2D, kernels and the D2H "
                     "of the observations queued by the context's own host thread) -> vio_frontend_collect -> "
