@@ -886,12 +886,30 @@ struct TrackShared {
 __device__ void compact_block(TrackShared &T) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n = T.n;
-  __syncthreads();  // everyone has read n before thread 0 replaces it
-  // exclusive prefix sum of keep (n <= kMaxCap): one thread is plenty for <= 512 items
-  if (tid == 0) {
-    int c = 0;
-    for (int i = 0; i < n; i++) T.pos[i] = c, c += T.keep[i] ? 1 : 0;
-    T.n = c;
+  __syncthreads();  // everyone has read n
+  // exclusive prefix sum of keep (n <= kMaxCap): a ballot per wave and chunk of blockDim items, the waves' counts through LDS
+  // (one work-item walking the flags was a chain of ~n LDS round trips, three times per frame)
+  {
+    __shared__ int s_wcnt[16];
+    const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
+    int running = 0;
+    for (int base = 0; base < n; base += nt) {
+      const int i = base + tid;
+      const bool k = i < n && T.keep[i];
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(k);
+      if (lane == 0) s_wcnt[wave] = __builtin_popcountll(b);
+      __syncthreads();
+      int off = running, total = 0;
+      for (int w = 0; w < nwv; w++) {
+        const int c = s_wcnt[w];
+        if (w < wave) off += c;
+        total += c;
+      }
+      if (i < n) T.pos[i] = off + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+      running += total;
+      __syncthreads();
+    }
+    if (tid == 0) T.n = running;
   }
   __syncthreads();
   for (int i = tid; i < n; i += nt)
