@@ -225,6 +225,51 @@ def test_device_matches_restatement(k, L, weighting, seed, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,L,n_entries,seed", [(10, 4, 3000, 21), (10, 6, 1500, 22), (4, 3, 700, 23)])
+def test_database_of_a_session(k, L, n_entries, seed):
+    """Thousands of keyframes: the inverted file is merged entry by entry, queries (with detectLoop's max_id windows, with and
+    without a cut) come back as TemplatedDatabase::queryL1 returns them -- same entries, same order, same bits. The three
+    vocabularies put a query's words in very long (4^3 words), medium and mostly single-posting (10^6 words) runs."""
+    blob, desc = make_vocabulary(k, L, seed=seed, flip=20 if L < 6 else 16)
+    ovoc = OracleVoc(blob)
+    voc = loop.BowVocabulary(blob=blob)
+    lib = ovoc.lib
+    odb = lib.oracle_db_create(ovoc.h)
+    db = loop.BowDatabase(voc, max_entries=n_entries, max_total_words=n_entries * 260)
+    try:
+        rng = np.random.default_rng(seed)
+        n_inner = sum(k ** l for l in range(L))
+        leaves = np.arange(n_inner, n_inner + k ** L)
+        pool = leaves[: max(40, min(len(leaves), 20000))]
+        # 48 distinct keyframes (one of them without descriptors), visited again and again like places of a session
+        kfs = [keyframe_descriptors(desc, pool, rng, int(n)) for n in rng.integers(20, 250, 47)] + [np.zeros((0, 4), np.uint64)]
+        bows = [(b[2], b[3]) for b in voc.transform(kfs)]
+        visit = rng.integers(0, len(bows), n_entries)
+        for e, v in enumerate(visit):
+            bw, bv = bows[v]
+            assert db.add(bw, bv) == e
+            assert lib.oracle_db_add(odb, np.ascontiguousarray(bw).ctypes.data_as(_i32p), np.ascontiguousarray(bv).ctypes.data_as(_f64p), len(bw)) == e
+        fresh = [(b[2], b[3]) for b in voc.transform([keyframe_descriptors(desc, pool, rng, 180) for _ in range(5)])]
+        queries = [bows[i] for i in (0, 5, 11, 46)] + fresh + [bows[47]]   # (the last one is the empty BowVector)
+        max_ids = [n_entries, n_entries - 50, -1, 1, n_entries // 2, 0, 17, -1, n_entries, -1]
+        for cut in (0, 4):
+            res = db.query(queries, max_ids, max_results=cut)
+            for (qw, qv), mid, (ent, sc) in zip(queries, max_ids, res):
+                re_, rs_ = np.zeros(n_entries, np.int32), np.zeros(n_entries, np.float64)
+                n = lib.oracle_db_query(odb, np.ascontiguousarray(qw).ctypes.data_as(_i32p), np.ascontiguousarray(qv).ctypes.data_as(_f64p),
+                                        len(qw), cut, mid, re_.ctypes.data_as(_i32p), rs_.ctypes.data_as(_f64p), n_entries)
+                assert n == len(ent)
+                assert np.array_equal(ent, re_[:n]) and np.array_equal(sc, rs_[:n])
+        hit = db.query([bows[5]], [-1], max_results=0)[0]
+        assert set(np.flatnonzero(visit == 5)) <= set(hit[0][np.abs(hit[1] - 1.0) < 1e-12])   # every visit of the place scores 1
+    finally:
+        db.close()
+        lib.oracle_db_destroy(odb)
+        voc.close()
+        lib.oracle_voc_destroy(ovoc.h)
+
+
+@pytest.mark.gpu
 def test_refuses_what_it_does_not_implement():
     blob, _ = make_vocabulary(4, 2, seed=1)
     import struct

@@ -11,17 +11,17 @@
 //                                                (ThirdParty/DBoW/BowVector.cpp:57-80)
 //   * database add / query                       TemplatedDatabase::add :439-470, queryL1 :651-720 (L1 score of the query
 //                                                against every entry below max_id, best max_results)
-// Three kernels, many keyframes / queries per launch:
+// Kernels, many keyframes / queries per launch:
 //   bow_lookup_kernel   16 lanes per descriptor: every lane takes children (256-bit XOR + popcount), the key
 //                       distance << 20 | child position is min-reduced inside the 16-lane row; one tree level per
 //                       dependent global fetch, thousands of descriptors in flight
 //   bow_vector_kernel   one workgroup per keyframe: bitonic sort of the word ids in LDS, run heads -> unique words, the
 //                       value of a word by the reference's own sequence of additions, L1 norm summed in ascending word
 //                       order by one lane (the order of std::map iteration: bit-identical values)
-//   bow_score_kernel    one lane per (query, database entry): merge of two ascending word lists,
-//                       sum |q - d| - |q| - |d| over the common words in ascending word order (= the order in which
-//                       queryL1 walks the inverted file, so the sums are bit-identical); the database keeps every entry's
-//                       BowVector in HBM (the direct form of the inverted file)
+//   bow_insert_kernel / bow_candidates_kernel / bow_score_kernel   the database: an inverted file (sorted postings) finds the
+//                       entries that share a word with a query, one wave per such entry sums |q - d| - |q| - |d| over the
+//                       common words in ascending word order (= the order in which queryL1 meets them: bit-identical sums)
+//                       from the entry's BowVector in the direct file; see the comment above bow_insert_kernel
 // The final sort / cut / scaling of queryL1 (a few hundred candidates) runs on the host inside the ABI call.
 // Scoring other than L1_NORM is refused (the app's vocabulary is TF_IDF / L1_NORM, DBoW2's defaults).
 #include <hip/hip_runtime.h>
@@ -162,34 +162,136 @@ __global__ __launch_bounds__(256) void bow_vector_kernel(const int *kf_off, cons
     for (int r = tid; r < u; r += nt) ov[r] /= norm;
 }
 
-// thread (e, q): sum over the common words of query q and database entry e; +1 = no common word / e >= max_id[q]
-__global__ __launch_bounds__(256) void bow_score_kernel(const int *db_off, const int *db_word, const double *db_value, int n_entries,
-                                                         const int *q_count, const int *q_word, const double *q_value, int q_stride,
-                                                         const int *max_id, double *raw) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
-  if (e >= n_entries) return;
-  double s = 0.0;
-  bool any = false;
-  const int mid = max_id[q];
-  if (e < mid || mid == -1) {
-    const int *qw = q_word + (size_t)q * q_stride;
-    const double *qv = q_value + (size_t)q * q_stride;
-    int i = 0, j = db_off[e];
-    const int ni = q_count[q], nj = db_off[e + 1];
-    while (i < ni && j < nj) {
-      const int a = qw[i], b = db_word[j];
-      if (a == b) {
-        const double qq = qv[i], dd = db_value[j];
-        s += fabs(qq - dd) - fabs(qq) - fabs(dd);
-        any = true, i++, j++;
-      } else if (a < b) {
-        i++;
-      } else {
-        j++;
-      }
+// ---- the database: inverted file + direct file ----------------------------------------------------------------------
+// TemplatedDatabase keeps, per word, the list of (entry, value) pairs that hold it (m_ifile, TemplatedDatabase.h:439-470)
+// and queryL1 walks the lists of the query's words (:651-720): work proportional to the postings touched, not to the
+// database. Here the inverted file is ONE sorted array of postings, key = word << 32 | entry: an entry arrives with
+// ascending unique words and an id above every id in the file, so its postings go to the END of their words' runs and an
+// add is one out-of-place merge (a streaming pass at HBM speed; lists that grow in place would need an allocator on the
+// device). A query is two kernels:
+//   bow_candidates_kernel   one wave per query word: the word's run by two binary searches (cut at max_id), lanes over the
+//                           run; the first posting that reaches an entry puts it on the query's candidate list
+//   bow_score_kernel        one wave per candidate: lanes over the entry's words in the direct file (ascending), each looks
+//                           its word up in the query (staged in LDS); the matched terms are added in ascending word order
+//                           (lane order, chunk after chunk) = the order in which queryL1 meets them: bit-identical sums
+// so entries that share no word with the query (most of a session's database under a 10^6-word vocabulary) cost nothing.
+__global__ __launch_bounds__(256) void bow_insert_kernel(const unsigned long long *old_key, int n_old, const int *new_word, int n_new, int entry,
+                                                          unsigned long long *out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n_old) {
+    const unsigned long long key = old_key[t];
+    const int wk = (int)(key >> 32);
+    int lo = 0, hi = n_new;  // new words below this posting's word
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (new_word[m] < wk) lo = m + 1;
+      else hi = m;
+    }
+    out[t + lo] = key;
+  } else if (t < n_old + n_new) {
+    const int j = t - n_old, w = new_word[j];
+    const unsigned long long bound = (unsigned long long)(unsigned)(w + 1) << 32;
+    int lo = 0, hi = n_old;  // old postings of words <= w
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (old_key[m] < bound) lo = m + 1;
+      else hi = m;
+    }
+    out[lo + j] = (unsigned long long)(unsigned)w << 32 | (unsigned)entry;
+  }
+}
+
+__device__ __forceinline__ int posting_lower_bound(const unsigned long long *key, int n, unsigned long long k) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int m = (lo + hi) >> 1;
+    if (key[m] < k) lo = m + 1;
+    else hi = m;
+  }
+  return lo;
+}
+
+// flag [n_queries][n_entries] (zeroed), n_cand [n_queries] (zeroed), cand [n_queries][n_entries]
+__global__ __launch_bounds__(256) void bow_candidates_kernel(const unsigned long long *key, int n_post, int n_entries, const int *q_count,
+                                                              const int *q_word, int q_stride, const int *max_id, int *flag, int *n_cand,
+                                                              int *cand) {
+  const int q = blockIdx.y, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = gridDim.x * 4;
+  const int ni = q_count[q], mid = max_id[q];
+  for (int i = wave; i < ni; i += n_waves) {
+    const int w = q_word[(size_t)q * q_stride + i];
+    const unsigned long long base = (unsigned long long)(unsigned)w << 32;
+    const unsigned long long top = mid == -1 ? (unsigned long long)(unsigned)(w + 1) << 32 : base | (unsigned)max(mid, 0);  // entries below max_id
+    const int lo = posting_lower_bound(key, n_post, base), hi = posting_lower_bound(key, n_post, top);
+    for (int p = lo + lane; p < hi; p += 64) {
+      const int e = (int)(unsigned)(key[p] & 0xffffffffull);
+      if (atomicExch(&flag[(size_t)q * n_entries + e], 1) == 0) cand[(size_t)q * n_entries + atomicAdd(&n_cand[q], 1)] = e;
     }
   }
-  raw[(size_t)q * n_entries + e] = any ? s : 1.0;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+
+constexpr int kBowQueryLds = 8192;  // query words staged in LDS (a BowVector has at most kMaxBowFeatures words)
+// wave c of query q: candidate cand[q][c] -> cscore[q][c] = sum over the common words, ascending, of |q - d| - |q| - |d|
+__global__ __launch_bounds__(256) void bow_score_kernel(const int *db_off, const int *db_word, const double *db_value, int n_entries,
+                                                         const int *q_count, const int *q_word, const double *q_value, int q_stride,
+                                                         const int *n_cand, const int *cand, double *cscore) {
+  __shared__ int qw_s[kBowQueryLds];
+  const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6)), n_waves = gridDim.x * 4;
+  const int ni = q_count[q];
+  const int *qw = q_word + (size_t)q * q_stride;
+  const double *qv = q_value + (size_t)q * q_stride;
+  const bool staged = ni <= kBowQueryLds;
+  if (staged)
+    for (int i = tid; i < ni; i += 256) qw_s[i] = qw[i];
+  __syncthreads();
+  const int nc = n_cand[q];
+  for (int c = wave; c < nc; c += n_waves) {
+    const int e = cand[(size_t)q * n_entries + c];
+    const int j0 = db_off[e], j1 = db_off[e + 1];
+    double s = 0.0;
+    for (int jb = j0; jb < j1; jb += 64) {
+      const int j = jb + lane;
+      bool hit = false;
+      double t = 0.0;
+      if (j < j1) {
+        const int b = db_word[j];
+        int lo = 0, hi = ni;
+        if (staged) {
+          while (lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if (qw_s[m] < b) lo = m + 1;
+            else hi = m;
+          }
+          hit = lo < ni && qw_s[lo] == b;
+        } else {
+          while (lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if (qw[m] < b) lo = m + 1;
+            else hi = m;
+          }
+          hit = lo < ni && qw[lo] == b;
+        }
+        if (hit) {
+          const double qq = qv[lo], dd = db_value[j];
+          t = fabs(qq - dd) - fabs(qq) - fabs(dd);
+        }
+      }
+      unsigned long long m = __ballot(hit);
+      while (m) {  // ascending lanes = ascending words
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        s += readlane_f64(t, l);
+      }
+    }
+    if (lane == 0) cscore[(size_t)q * n_entries + c] = s;
+  }
 }
 
 }  // namespace
@@ -217,8 +319,12 @@ struct vio_bow_database {
   int max_entries = 0, n_entries = 0;
   size_t max_words = 0, n_words = 0;
   std::vector<int> h_off;  // [n_entries + 1]
-  Buf<int> d_off, d_word, q_count, q_word, q_max;
-  Buf<double> d_value, q_value, raw;
+  Buf<int> d_off, d_word, q_count, q_word, q_max;  // d_off / d_word / d_value: the direct file (every entry's BowVector)
+  Buf<double> d_value, q_value;
+  Buf<unsigned long long> inv[2];  // the inverted file: postings sorted by (word, entry); inv[cur] is the live copy
+  int cur = 0;
+  Buf<int> flag, n_cand, cand;  // query scratch: [n_queries][n_entries] marks, [n_queries], [n_queries][n_entries]
+  Buf<double> cscore;           // [n_queries][n_entries] raw score of candidate c
 };
 
 extern "C" {
@@ -416,7 +522,8 @@ int vio_bow_database_create(vio_vocabulary_t *v, int32_t max_entries, int32_t ma
     delete d;
     return VIO_ENODEV;
   }
-  if (d->d_off.ensure((size_t)max_entries + 1) != VIO_OK || d->d_word.ensure(d->max_words) != VIO_OK || d->d_value.ensure(d->max_words) != VIO_OK) {
+  if (d->d_off.ensure((size_t)max_entries + 1) != VIO_OK || d->d_word.ensure(d->max_words) != VIO_OK || d->d_value.ensure(d->max_words) != VIO_OK ||
+      d->inv[0].ensure(d->max_words) != VIO_OK || d->inv[1].ensure(d->max_words) != VIO_OK) {
     vio_bow_database_destroy(d);
     return VIO_ENOMEM;
   }
@@ -429,7 +536,7 @@ void vio_bow_database_destroy(vio_bow_database_t *d) {
   vio::DeviceScope scope(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream), (void)hipStreamDestroy(d->stream);
   d->d_off.release(), d->d_word.release(), d->d_value.release(), d->q_count.release(), d->q_word.release(), d->q_max.release();
-  d->q_value.release(), d->raw.release();
+  d->q_value.release(), d->inv[0].release(), d->inv[1].release(), d->flag.release(), d->n_cand.release(), d->cand.release(), d->cscore.release();
   delete d;
 }
 
@@ -452,8 +559,15 @@ int vio_bow_database_add(vio_bow_database_t *d, int32_t n, const int32_t *word, 
     HIP_OK(hipMemcpyAsync(d->d_value.p + d->n_words, value, 8 * (size_t)n, hipMemcpyHostToDevice, st));
   }
   HIP_OK(hipMemcpyAsync(d->d_off.p + d->n_entries, d->h_off.data() + d->n_entries, 8, hipMemcpyHostToDevice, st));
+  if (n > 0) {  // the entry's postings into the inverted file: merge into the other copy
+    const size_t total = d->n_words + (size_t)n;
+    hipLaunchKernelGGL(bow_insert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d->inv[d->cur].p, (int)d->n_words,
+                       d->d_word.p + d->n_words, n, d->n_entries, d->inv[1 - d->cur].p);
+    HIP_OK(hipGetLastError());
+  }
   HIP_OK(hipStreamSynchronize(st));  // (the caller's buffers are pageable)
   if (entry_id) *entry_id = d->n_entries;
+  if (n > 0) d->cur = 1 - d->cur;
   d->n_entries++, d->n_words += (size_t)n;
   return VIO_OK;
 }
@@ -475,26 +589,43 @@ int vio_bow_database_query(vio_bow_database_t *d, int32_t n_queries, const int32
   try {
     if (d->q_count.ensure(n_queries) != VIO_OK || d->q_max.ensure(n_queries) != VIO_OK ||
         d->q_word.ensure((size_t)n_queries * bow_stride) != VIO_OK || d->q_value.ensure((size_t)n_queries * bow_stride) != VIO_OK ||
-        d->raw.ensure((size_t)n_queries * N) != VIO_OK)
+        d->flag.ensure((size_t)n_queries * N) != VIO_OK || d->n_cand.ensure(n_queries) != VIO_OK ||
+        d->cand.ensure((size_t)n_queries * N) != VIO_OK || d->cscore.ensure((size_t)n_queries * N) != VIO_OK)
       return VIO_ENOMEM;
     hipStream_t st = d->stream;
+    int max_words = 0;
+    for (int q = 0; q < n_queries; q++) max_words = std::max(max_words, (int)bow_count[q]);
     HIP_OK(hipMemcpyAsync(d->q_count.p, bow_count, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->q_max.p, max_id, 4 * (size_t)n_queries, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->q_word.p, bow_word, 4 * (size_t)n_queries * bow_stride, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(d->q_value.p, bow_value, 8 * (size_t)n_queries * bow_stride, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(bow_score_kernel, dim3((N + 255) / 256, n_queries), dim3(256), 0, st, d->d_off.p, d->d_word.p, d->d_value.p, N,
-                       d->q_count.p, d->q_word.p, d->q_value.p, bow_stride, d->q_max.p, d->raw.p);
-    HIP_OK(hipGetLastError());
-    std::vector<double> raw((size_t)n_queries * N);
-    HIP_OK(hipMemcpyAsync(raw.data(), d->raw.p, 8 * raw.size(), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemsetAsync(d->flag.p, 0, 4 * (size_t)n_queries * N, st));
+    HIP_OK(hipMemsetAsync(d->n_cand.p, 0, 4 * (size_t)n_queries, st));
+    std::vector<int> nc(n_queries, 0);
+    if (max_words > 0 && d->n_words > 0) {
+      hipLaunchKernelGGL(bow_candidates_kernel, dim3(std::min((max_words + 3) / 4, 256), n_queries), dim3(256), 0, st, d->inv[d->cur].p,
+                         (int)d->n_words, N, d->q_count.p, d->q_word.p, bow_stride, d->q_max.p, d->flag.p, d->n_cand.p, d->cand.p);
+      hipLaunchKernelGGL(bow_score_kernel, dim3(std::min((N + 3) / 4, 1024), n_queries), dim3(256), 0, st, d->d_off.p, d->d_word.p, d->d_value.p, N,
+                         d->q_count.p, d->q_word.p, d->q_value.p, bow_stride, d->n_cand.p, d->cand.p, d->cscore.p);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipMemcpyAsync(nc.data(), d->n_cand.p, 4 * (size_t)n_queries, hipMemcpyDeviceToHost, st));
+    }
     HIP_OK(hipStreamSynchronize(st));
+    const int widest = *std::max_element(nc.begin(), nc.end());
+    std::vector<int> h_cand((size_t)n_queries * std::max(widest, 1));
+    std::vector<double> h_score((size_t)n_queries * std::max(widest, 1));
+    if (widest > 0) {  // only the candidates come back: rows of `widest` out of rows of N
+      HIP_OK(hipMemcpy2DAsync(h_cand.data(), 4 * (size_t)widest, d->cand.p, 4 * (size_t)N, 4 * (size_t)widest, n_queries, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipMemcpy2DAsync(h_score.data(), 8 * (size_t)widest, d->cscore.p, 8 * (size_t)N, 8 * (size_t)widest, n_queries, hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+    }
     // the tail of queryL1 (TemplatedDatabase.h:696-719): ascending raw score (-2 best .. 0 worst), cut, scale to [0, 1]
     std::vector<std::pair<double, int>> ret;
     for (int q = 0; q < n_queries; q++) {
       ret.clear();
-      for (int e = 0; e < N; e++) {
-        const double s = raw[(size_t)q * N + e];
-        if (s <= 0.0) ret.push_back(std::make_pair(s, e));
+      for (int c = 0; c < nc[q]; c++) {
+        const double s = h_score[(size_t)q * widest + c];
+        if (s <= 0.0) ret.push_back(std::make_pair(s, h_cand[(size_t)q * widest + c]));
       }
       std::sort(ret.begin(), ret.end());  // (equal scores: ascending entry id; the reference's std::sort leaves them unspecified)
       if (max_results > 0 && (int)ret.size() > max_results) ret.resize(max_results);
