@@ -467,6 +467,30 @@ def _tool(code, env=None):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def cpp_driver(n_seq, n_objects):
+    """tools/estimator_throughput.cpp: the same path driven from C++ (no interpreter in the loop), `n_objects` estimator objects
+    of `n_seq` sequences each on a host thread of their own -- while one object's host code runs, the other's kernels do."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("g++"):
+        return {"skipped": "no g++ on this machine"}
+    lib = os.path.join(ROOT, "vins-mobile_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe, data = os.path.join(tmp, "estimator_throughput"), os.path.join(tmp, "est.bin")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "estimator_throughput.cpp"),
+                        "-L" + lib, "-lvio_amd", "-Wl,-rpath," + lib, "-lpthread", "-o", exe], check=True, capture_output=True, timeout=300)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "estimator_dataset.py"), data, "8", "60"], check=True, capture_output=True,
+                       timeout=300, cwd=ROOT)
+        r = subprocess.run([exe, data, str(n_seq), str(n_objects)], check=True, capture_output=True, text=True, timeout=300)
+    line = r.stdout.strip().splitlines()[-1]
+    import re
+    m = re.search(r"(\d+) window solves in ([0-9.]+) ms", line)
+    n, ms = int(m.group(1)), float(m.group(2))
+    return {"value": n / ms * 1e3, "unit": "window solves/s", "estimator_objects": n_objects, "sequences_each": n_seq, "window_solves": n,
+            "driver": "tools/estimator_throughput.cpp (C++, one host thread per object), host buffers in / host states out"}
+
+
 def end_to_end(n_seq):
     """The estimator path (csrc/vio_estimator.cpp): per frame, host observations + IMU in, host states out. Sequences in the
     NON_LINEAR state keep their landmark lists on the device (vio_estimator_set_resident, the default): observations and
@@ -478,7 +502,9 @@ def end_to_end(n_seq):
     h = run(n_seq // 2, 40, {"VIO_AMD_RESIDENT": "0", "VIO_AMD_HOST_THREADS": "64"})   # (its own best pool width)
     solves, lib_s = a
     per = lambda r, n: {"value": r[0] / r[1], "ms_per_frame_of_all_sequences": r[1] / (r[0] // n) * 1e3}
+    two = guarded(lambda: cpp_driver(n_seq, 2))
     return {"value": solves / lib_s, "unit": "window solves/s (= published frames/s of the back-end half)", "sequences": n_seq,
+            "two_estimator_objects": two,
             "frames_timed": solves // n_seq, "path": "vio_estimator_process_imu_batch + vio_estimator_process_images, one estimator "
             "object on one host thread, host buffers in / host states out; landmark lists, pre-integration blocks and priors "
             "resident on the device, window assembly by kernels (store_core.h); time inside the two library calls "
