@@ -163,6 +163,7 @@ struct LkWaveLds {
   };
 };
 typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
 
 // Four consecutive pixels from an arbitrary byte address (global memory takes unaligned dword loads on this hardware).
 struct __attribute__((packed)) LkU32 {
@@ -205,6 +206,25 @@ __device__ __forceinline__ double feat_sum_exact(int p, int sub) {
   return (double)shi * 65536.0 + (double)slo;
 }
 
+// Two exact sums at once (one feature per wave): the four 32-bit chains advance in lockstep, so that every DPP step finds
+// its operand written three instructions earlier (a chain on its own waits two issue slots after every step).
+__device__ __forceinline__ void wave_sum_exact2(int p, int q, double &sp, double &sq) {
+  int a = p & 0xffff, b = q & 0xffff, c = p >> 16, d = q >> 16;
+#define VIO_DPP4(ctrl, rmask)                                              \
+  {                                                                        \
+    const int ta = __builtin_amdgcn_update_dpp(0, a, ctrl, rmask, 0xf, false); \
+    const int tb = __builtin_amdgcn_update_dpp(0, b, ctrl, rmask, 0xf, false); \
+    const int tc = __builtin_amdgcn_update_dpp(0, c, ctrl, rmask, 0xf, false); \
+    const int td = __builtin_amdgcn_update_dpp(0, d, ctrl, rmask, 0xf, false); \
+    a += ta, b += tb, c += tc, d += td;                                    \
+  }
+  VIO_DPP4(0x111, 0xf) VIO_DPP4(0x112, 0xf) VIO_DPP4(0x114, 0xf) VIO_DPP4(0x118, 0xf) VIO_DPP4(0x142, 0xa) VIO_DPP4(0x143, 0xc)
+#undef VIO_DPP4
+  const int sa = __builtin_amdgcn_readlane(a, 63), sb = __builtin_amdgcn_readlane(b, 63), sc = __builtin_amdgcn_readlane(c, 63),
+            sd = __builtin_amdgcn_readlane(d, 63);
+  sp = (double)sc * 65536.0 + (double)sa, sq = (double)sd * 65536.0 + (double)sb;
+}
+
 // FPW features per wave (64 / FPW lanes each). prev/next pyramids: per sequence `pyr_bytes` apart. pts arrays:
 // [seq][cap][2]. Two features per wave share every wave-uniform instruction (the reductions, the 2x2 solve, the
 // convergence tests, the bilinear weights): the kernel is VALU-issue-bound and those are half of an LK iteration.
@@ -231,12 +251,18 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
   const float half = (kWin - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   constexpr int NPX = (kWin * kWin + LPF - 1) / LPF;  // window pixels per lane: 7 (14 with two features per wave)
-  int joff[NPX];  // this lane's window pixels as element offsets into the staged J region
+  // This lane's window pixels. One feature per wave: lane l owns column l % 21 of rows l / 21 + 3 q (q = 0..6; 63 lanes) --
+  // the q-th pixel sits a CONSTANT 3 q rows below the first, so the LDS reads of an iteration share one address register
+  // (+ immediate offsets) instead of one address computation per pixel. Two features per wave: pixel lane + 32 q of the
+  // row-major window. (The sums over the window are exact integers: which lane owns which pixel does not reach the result.)
+  constexpr bool COLS = FPW == 1;
+  const int wy0 = min(lane / kWin, 2), wx0 = lane % kWin;  // (lane 63 owns nothing: it shadows lane 62's rows, masked below)
+  auto pix_ok = [&](int q) { return COLS ? lane < 3 * kWin : lane + LPF * q < kWin * kWin; };
+  auto pix_y = [&](int q) { return COLS ? wy0 + 3 * q : min(lane + LPF * q, kWin * kWin - 1) / kWin; };  // (always inside the window)
+  auto pix_x = [&](int q) { return COLS ? wx0 : min(lane + LPF * q, kWin * kWin - 1) % kWin; };
+  int joff[COLS ? 1 : NPX];  // element offsets into the staged J region (COLS: of the first pixel)
 #pragma unroll
-  for (int q = 0; q < NPX; q++) {
-    const int e = min(lane + LPF * q, kWin * kWin - 1);
-    joff[q] = (e / kWin) * kJS + (e % kWin);
-  }
+  for (int q = 0; q < (COLS ? 1 : NPX); q++) joff[q] = pix_y(q) * kJS + pix_x(q);
   bool st = true;
   float er = 0.f;
   float nxx = 0.f, nxy = 0.f;
@@ -310,23 +336,30 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
     }
     wave_lds_fence();
     // template patch + derivatives for this lane's window pixels, kept in registers across the iterations
-    short Iv[NPX], Ix[NPX], Iy[NPX];
-      int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: <= 14 products of |v| <= 4080^2 fit 32 bits
+    // (the template value enters the iterations as the accumulator seed of the bilinear sample: rounding constant minus
+    // Iv << n, so that the arithmetic shift that ends the sample yields J - I directly -- (a + r - (Iv << n)) >> n ==
+    // ((a + r) >> n) - Iv exactly)
+    // Ix, Iy of pixels 2h and 2h + 1 share a register: the iterations multiply-accumulate them pairwise (v_dot2_i32_i16).
+    constexpr int NPP = (NPX + 1) / 2;
+    lk_s2 IxP[NPP], IyP[NPP];
+    int Ic[NPX];
+    int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: <= 14 products of |v| <= 4080^2 fit 32 bits
+#pragma unroll
+    for (int h = 0; h < NPP; h++) IxP[h] = IyP[h] = lk_s2{0, 0};
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
-      int e = lane + LPF * q;
-      Iv[q] = Ix[q] = Iy[q] = 0;
-      if (e < kWin * kWin) {
-        int y = e / kWin, x = e - y * kWin;
-        const uint32_t it = L.I[y + 1][x + 1], ib = L.I[y + 2][x + 1];  // (I[x+1], I[x+2]) of the two rows
-        int ival = descale((int)((it & 0xffff) * iw00 + (it >> 16) * iw01 + (ib & 0xffff) * iw10 + (ib >> 16) * iw11),
-                           kWBits - 5);
-        short2 d00 = L.dI[y][x], d01 = L.dI[y][x + 1], d10 = L.dI[y + 1][x], d11 = L.dI[y + 1][x + 1];
-        int ixval = descale(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, kWBits);
-        int iyval = descale(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, kWBits);
-        Iv[q] = (short)ival, Ix[q] = (short)ixval, Iy[q] = (short)iyval;
-        p11 += ixval * ixval, p12 += ixval * iyval, p22 += iyval * iyval;
-      }
+      const int y = pix_y(q), x = pix_x(q);
+      const uint32_t it = L.I[y + 1][x + 1], ib = L.I[y + 2][x + 1];  // (I[x+1], I[x+2]) of the two rows
+      const int ival = descale((int)((it & 0xffff) * iw00 + (it >> 16) * iw01 + (ib & 0xffff) * iw10 + (ib >> 16) * iw11),
+                               kWBits - 5);
+      const short2 d00 = L.dI[y][x], d01 = L.dI[y][x + 1], d10 = L.dI[y + 1][x], d11 = L.dI[y + 1][x + 1];
+      int ixval = descale(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, kWBits);
+      int iyval = descale(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, kWBits);
+      if (!pix_ok(q)) ixval = iyval = 0;  // a pixel this lane does not own: weight zero in every sum below
+      Ic[q] = (1 << (kWBits - 5 - 1)) - (int)((unsigned)ival << (kWBits - 5));
+      if (q & 1) IxP[q >> 1].y = (short)ixval, IyP[q >> 1].y = (short)iyval;
+      else IxP[q >> 1].x = (short)ixval, IyP[q >> 1].x = (short)iyval;
+      p11 += ixval * ixval, p12 += ixval * iyval, p22 += iyval * iyval;
     }
     const double s11 = feat_sum_exact<FPW>(p11, sub), s12 = feat_sum_exact<FPW>(p12, sub), s22 = feat_sum_exact<FPW>(p22, sub);  // exact integer sums
     float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
@@ -375,13 +408,14 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       j_staged = true;
     };
     const uint32_t *Jl = &L.J[0][0];
-    auto sample_j = [&](int base, int q, lk_us2 wtop, lk_us2 wbot) {  // bilinear J at this lane's q-th window pixel
+    auto diff_j = [&](int base, int q, lk_us2 wtop, lk_us2 wbot) {  // bilinear J at this lane's q-th window pixel, minus I there
       lk_us2 top, bot;
-      const uint32_t t32 = Jl[base + joff[q]], b32 = Jl[base + joff[q] + kJS];
+      const int o = base + (COLS ? joff[0] + 3 * q * kJS : joff[COLS ? 0 : q]);  // (q is a constant after unrolling)
+      const uint32_t t32 = Jl[o], b32 = Jl[o + kJS];
       __builtin_memcpy(&top, &t32, 4);
       __builtin_memcpy(&bot, &b32, 4);
-      const unsigned acc = __builtin_amdgcn_udot2(top, wtop, __builtin_amdgcn_udot2(bot, wbot, 0u, false), false);
-      return descale((int)acc, kWBits - 5);
+      const unsigned acc = __builtin_amdgcn_udot2(top, wtop, __builtin_amdgcn_udot2(bot, wbot, (unsigned)Ic[q], false), false);  // (mod 2^32)
+      return (int)acc >> (kWBits - 5);
     };
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
@@ -396,13 +430,16 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
       const int jbase = (iqy - joy) * kJS + (iqx - jox);
 #pragma unroll
-      for (int q = 0; q < NPX; q++) {
-        if (lane + LPF * q < kWin * kWin) {
-          int diff = sample_j(jbase, q, wtop, wbot) - Iv[q];
-          pb1 += diff * Ix[q], pb2 += diff * Iy[q];
-        }
+      for (int h = 0; h < NPP; h++) {  // (a pixel the lane does not own has Ix = Iy = 0)
+        const int d0 = diff_j(jbase, 2 * h, wtop, wbot), d1 = 2 * h + 1 < NPX ? diff_j(jbase, 2 * h + 1, wtop, wbot) : 0;
+        const unsigned pk = __builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x05040100u);  // |J - I| <= 8160: (d0, d1) as two int16
+        lk_s2 dp;
+        __builtin_memcpy(&dp, &pk, 4);
+        pb1 = __builtin_amdgcn_sdot2(dp, IxP[h], pb1, false), pb2 = __builtin_amdgcn_sdot2(dp, IyP[h], pb2, false);
       }
-      const double sb1 = feat_sum_exact<FPW>(pb1, sub), sb2 = feat_sum_exact<FPW>(pb2, sub);
+      double sb1, sb2;
+      if (FPW == 1) wave_sum_exact2(pb1, pb2, sb1, sb2);
+      else sb1 = feat_sum_exact<FPW>(pb1, sub), sb2 = feat_sum_exact<FPW>(pb2, sub);
       float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
       float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
       qx += ddx, qy += ddy;
@@ -429,7 +466,8 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       const int jbase = (iey - joy) * kJS + (iex - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
-        if (lane + LPF * q < kWin * kWin) pe += abs(sample_j(jbase, q, wtop, wbot) - Iv[q]);
+        const int d = abs(diff_j(jbase, q, wtop, wbot));
+        pe += pix_ok(q) ? d : 0;
       }
       const int se = feat_sum_i32<FPW>(pe, sub);  // <= 441 * 16320 < 2^23
       er = (float)se * 1.f / (32 * kWin * kWin);
