@@ -162,7 +162,6 @@ struct LkWaveLds {
     uint32_t J[kJP][kJS];
   };
 };
-typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
 
 // Four consecutive pixels from an arbitrary byte address (global memory takes unaligned dword loads on this hardware).
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       for (int t = 0; t < (kIP + 9) / 10; t++) {  // (uniform trip count: the DPP below needs every lane)
         const int ly = r + 10 * t;
         const bool ok = lane < 60 && ly < kIP;
-        const uint32_t cur = lk_load4(I + (size_t)(ipy - 1 + (ly < kIP ? ly : 0)) * cols + ipx - 1 + 4 * d);
+        const uint32_t cur = lk_load4(I + (unsigned)(__mul24(ipy - 1 + (ly < kIP ? ly : 0), cols) + ipx - 1 + 4 * d));
         uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);  // dword of lane + 1
         if (d == 5) next = cur >> 24;  // (the pair behind the last pixel repeats it, like the byte path's clamped lane)
         uint32_t w4[4];
@@ -312,27 +311,37 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       const int lx = lane & 31;
       const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
       for (int ly = lane >> 5; ly < kIP; ly += LPF / 32) {
-        const int v = I[(size_t)reflect101(ipy - 1 + ly, rows) * cols + x];
+        const int v = I[(unsigned)(__mul24(reflect101(ipy - 1 + ly, rows), cols) + x)];
         const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
         if (lx < kIP) L.I[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
       }
     }
     wave_lds_fence();
-    for (int e = lane; e < kDP * kDP; e += LPF) {
-      int ly = e / kDP, lx = e - ly * kDP;
-      int Y = ipy + ly, X = ipx + lx;
-      short2 d = make_short2(0, 0);
-      if (X >= 0 && X < cols && Y >= 0 && Y < rows) {
-        // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
-        const uint32_t a0 = L.I[ly][lx], a1 = L.I[ly][lx + 1], b0 = L.I[ly + 1][lx], b1 = L.I[ly + 1][lx + 1],
-                       c0 = L.I[ly + 2][lx], c1 = L.I[ly + 2][lx + 1];
-        int p00 = a0 & 0xffff, p01 = a0 >> 16, p02 = a1 >> 16;
-        int p10 = b0 & 0xffff, p12 = b1 >> 16;
-        int p20 = c0 & 0xffff, p21 = c0 >> 16, p22 = c1 >> 16;
-        d.x = (short)(3 * (p02 - p00) + 10 * (p12 - p10) + 3 * (p22 - p20));
-        d.y = (short)(3 * (p20 - p00) + 10 * (p21 - p01) + 3 * (p22 - p02));
+    {
+      // element e = lane + LPF t of the 22 x 22 derivative patch, (ly, lx) advanced by (LPF / 22, LPF % 22) per trip (an
+      // integer division and the 32-bit multiplies of the Scharr sums are quarter-rate instructions: none are left here)
+      int e = lane, ly = lane / kDP, lx = lane - kDP * ly;
+      const bool inside = ipx >= 0 && ipx + kDP <= cols && ipy >= 0 && ipy + kDP <= rows;  // every derivative position is in the image
+#pragma unroll 1
+      for (int t = 0; t < (kDP * kDP + LPF - 1) / LPF; t++) {
+        if (ly < kDP) {
+          uint32_t d = 0;
+          if (inside || (ipx + lx >= 0 && ipx + lx < cols && ipy + ly >= 0 && ipy + ly < rows)) {
+            // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
+            const uint32_t *Ip = &L.I[0][0] + (e + __mul24(kIS - kDP, ly));  // = &L.I[ly][lx]
+            const uint32_t a0 = Ip[0], a1 = Ip[1], b0 = Ip[kIS], b1 = Ip[kIS + 1], c0 = Ip[2 * kIS], c1 = Ip[2 * kIS + 1];
+            const int p00 = a0 & 0xffff, p01 = a0 >> 16, p02 = a1 >> 16;
+            const int p10 = b0 & 0xffff, p12 = b1 >> 16;
+            const int p20 = c0 & 0xffff, p21 = c0 >> 16, p22 = c1 >> 16;
+            const int dx = __mul24(3, (p02 - p00) + (p22 - p20)) + __mul24(10, p12 - p10);
+            const int dy = __mul24(3, (p20 - p00) + (p22 - p02)) + __mul24(10, p21 - p01);
+            d = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u);  // short2 {dx, dy}
+          }
+          __builtin_memcpy(&L.dI[0][0] + e, &d, 4);  // = L.dI[ly][lx]
+        }
+        e += LPF, lx += LPF % kDP, ly += LPF / kDP;
+        if (lx >= kDP) lx -= kDP, ly++;
       }
-      L.dI[ly][lx] = d;
     }
     wave_lds_fence();
     // template patch + derivatives for this lane's window pixels, kept in registers across the iterations
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
     // ((a + r) >> n) - Iv exactly)
     // Ix, Iy of pixels 2h and 2h + 1 share a register: the iterations multiply-accumulate them pairwise (v_dot2_i32_i16).
     constexpr int NPP = (NPX + 1) / 2;
+    const lk_s2 sw_top = {(short)iw00, (short)iw01}, sw_bot = {(short)iw10, (short)iw11};
     lk_s2 IxP[NPP], IyP[NPP];
     int Ic[NPX];
     int p11 = 0, p12 = 0, p22 = 0;  // per-lane partials: <= 14 products of |v| <= 4080^2 fit 32 bits
@@ -349,12 +359,23 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
 #pragma unroll
     for (int q = 0; q < NPX; q++) {
       const int y = pix_y(q), x = pix_x(q);
-      const uint32_t it = L.I[y + 1][x + 1], ib = L.I[y + 2][x + 1];  // (I[x+1], I[x+2]) of the two rows
-      const int ival = descale((int)((it & 0xffff) * iw00 + (it >> 16) * iw01 + (ib & 0xffff) * iw10 + (ib >> 16) * iw11),
-                               kWBits - 5);
-      const short2 d00 = L.dI[y][x], d01 = L.dI[y][x + 1], d10 = L.dI[y + 1][x], d11 = L.dI[y + 1][x + 1];
-      int ixval = descale(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, kWBits);
-      int iyval = descale(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, kWBits);
+      // bilinear taps as dot products of packed pairs (a 32-bit integer multiply is a quarter-rate instruction here; the
+      // element-wise form of this block was 12 of them per pixel): the I patch is staged as pairs already; the derivative
+      // pairs (d[x], d[x+1]) are cut out of two (dx, dy) words with v_perm_b32. Weights <= 2^14 fit int16, and the SIGNED
+      // dot keeps iw11 = 2^14 - iw00 - iw01 - iw10 right when the three roundings push it to -1.
+      lk_s2 it, ib;
+      __builtin_memcpy(&it, &L.I[y + 1][x + 1], 4);  // (I[x+1], I[x+2]) of the two rows
+      __builtin_memcpy(&ib, &L.I[y + 2][x + 1], 4);
+      const int ival = __builtin_amdgcn_sdot2(it, sw_top, __builtin_amdgcn_sdot2(ib, sw_bot, 1 << (kWBits - 5 - 1), false), false) >> (kWBits - 5);
+      uint32_t d00, d01, d10, d11;
+      __builtin_memcpy(&d00, &L.dI[y][x], 4), __builtin_memcpy(&d01, &L.dI[y][x + 1], 4);
+      __builtin_memcpy(&d10, &L.dI[y + 1][x], 4), __builtin_memcpy(&d11, &L.dI[y + 1][x + 1], 4);
+      const uint32_t xt = __builtin_amdgcn_perm(d01, d00, 0x05040100u), yt = __builtin_amdgcn_perm(d01, d00, 0x07060302u);
+      const uint32_t xb = __builtin_amdgcn_perm(d11, d10, 0x05040100u), yb = __builtin_amdgcn_perm(d11, d10, 0x07060302u);
+      lk_s2 sxt, syt, sxb, syb;
+      __builtin_memcpy(&sxt, &xt, 4), __builtin_memcpy(&syt, &yt, 4), __builtin_memcpy(&sxb, &xb, 4), __builtin_memcpy(&syb, &yb, 4);
+      int ixval = __builtin_amdgcn_sdot2(sxt, sw_top, __builtin_amdgcn_sdot2(sxb, sw_bot, 1 << (kWBits - 1), false), false) >> kWBits;
+      int iyval = __builtin_amdgcn_sdot2(syt, sw_top, __builtin_amdgcn_sdot2(syb, sw_bot, 1 << (kWBits - 1), false), false) >> kWBits;
       if (!pix_ok(q)) ixval = iyval = 0;  // a pixel this lane does not own: weight zero in every sum below
       Ic[q] = (1 << (kWBits - 5 - 1)) - (int)((unsigned)ival << (kWBits - 5));
       if (q & 1) IxP[q >> 1].y = (short)ixval, IyP[q >> 1].y = (short)iyval;
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
         for (int t = 0; t < (kJP + 8) / 9; t++) {
           const int ly = r + 9 * t;
           const bool ok = lane < 63 && ly < kJP;
-          const uint32_t cur = lk_load4(J + (size_t)(joy + (ly < kJP ? ly : 0)) * cols + jox + 4 * d);
+          const uint32_t cur = lk_load4(J + (unsigned)(__mul24(joy + (ly < kJP ? ly : 0), cols) + jox + 4 * d));
           uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);
           if (d == 6) next = cur >> 24;
           uint32_t w4[4];
@@ -399,7 +420,7 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
         const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
         for (int ly = lane >> 5; ly < kJP; ly += LPF / 32) {
           const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
-          const int v = J[(size_t)y * cols + x];
+          const int v = J[(unsigned)(__mul24(y, cols) + x)];
           const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
           if (lx < kJP) L.J[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
         }
@@ -408,14 +429,13 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       j_staged = true;
     };
     const uint32_t *Jl = &L.J[0][0];
-    auto diff_j = [&](int base, int q, lk_us2 wtop, lk_us2 wbot) {  // bilinear J at this lane's q-th window pixel, minus I there
-      lk_us2 top, bot;
+    auto diff_j = [&](int base, int q, lk_s2 wtop, lk_s2 wbot) {  // bilinear J at this lane's q-th window pixel, minus I there
+      lk_s2 top, bot;
       const int o = base + (COLS ? joff[0] + 3 * q * kJS : joff[COLS ? 0 : q]);  // (q is a constant after unrolling)
       const uint32_t t32 = Jl[o], b32 = Jl[o + kJS];
       __builtin_memcpy(&top, &t32, 4);
       __builtin_memcpy(&bot, &b32, 4);
-      const unsigned acc = __builtin_amdgcn_udot2(top, wtop, __builtin_amdgcn_udot2(bot, wbot, (unsigned)Ic[q], false), false);  // (mod 2^32)
-      return (int)acc >> (kWBits - 5);
+      return __builtin_amdgcn_sdot2(top, wtop, __builtin_amdgcn_sdot2(bot, wbot, Ic[q], false), false) >> (kWBits - 5);
     };
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
@@ -427,8 +447,8 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
       int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, <= 14 pixels per lane: 9.3e8 fits 32 bits
-      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
-      const int jbase = (iqy - joy) * kJS + (iqx - jox);
+      const lk_s2 wtop = {(short)iw00, (short)iw01}, wbot = {(short)iw10, (short)iw11};
+      const int jbase = __mul24(iqy - joy, kJS) + (iqx - jox);
 #pragma unroll
       for (int h = 0; h < NPP; h++) {  // (a pixel the lane does not own has Ix = Iy = 0)
         const int d0 = diff_j(jbase, 2 * h, wtop, wbot), d1 = 2 * h + 1 < NPX ? diff_j(jbase, 2 * h + 1, wtop, wbot) : 0;
@@ -462,8 +482,8 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       float aa = ex - iex, bb = ey - iey;
       lk_weights(aa, bb, iw00, iw01, iw10, iw11);
       int pe = 0;
-      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01}, wbot = {(unsigned short)iw10, (unsigned short)iw11};
-      const int jbase = (iey - joy) * kJS + (iex - jox);
+      const lk_s2 wtop = {(short)iw00, (short)iw01}, wbot = {(short)iw10, (short)iw11};
+      const int jbase = __mul24(iey - joy, kJS) + (iex - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
         const int d = abs(diff_j(jbase, q, wtop, wbot));
