@@ -16,6 +16,8 @@
 // agree bit for bit; sums that OpenCV accumulates in float (LK's A and b) are accumulated exactly.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -317,30 +319,72 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       }
     }
     wave_lds_fence();
-    {
-      // element e = lane + LPF t of the 22 x 22 derivative patch, (ly, lx) advanced by (LPF / 22, LPF % 22) per trip (an
-      // integer division and the 32-bit multiplies of the Scharr sums are quarter-rate instructions: none are left here)
-      int e = lane, ly = lane / kDP, lx = lane - kDP * ly;
+    if (FPW == 1) {
+      // Scharr derivatives by COLUMN WALK: lanes 0..43 = 22 columns x two segments of 11 rows. Per input row a lane reads its
+      // two pair words once and forms the row's horizontal difference h = p2 - p0 and smoothing v = 3 p0 + 10 p1 + 3 p2;
+      // an output row is dx = 3 (h0 + h2) + 10 h1, dy = v2 - v0 of three consecutive input rows -- the same integers as the
+      // 3 x 3 sums of calcSharrDeriv, from 2 LDS reads and ~8 instructions per output instead of 6 reads and ~27.
+      constexpr int R = kDP / 2;
+      static_assert(kDP % 2 == 0 && 2 * kDP <= 64, "two segments of kDP / 2 rows");
       const bool inside = ipx >= 0 && ipx + kDP <= cols && ipy >= 0 && ipy + kDP <= rows;  // every derivative position is in the image
-#pragma unroll 1
-      for (int t = 0; t < (kDP * kDP + LPF - 1) / LPF; t++) {
-        if (ly < kDP) {
-          uint32_t d = 0;
-          if (inside || (ipx + lx >= 0 && ipx + lx < cols && ipy + ly >= 0 && ipy + ly < rows)) {
-            // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
-            const uint32_t *Ip = &L.I[0][0] + (e + __mul24(kIS - kDP, ly));  // = &L.I[ly][lx]
-            const uint32_t a0 = Ip[0], a1 = Ip[1], b0 = Ip[kIS], b1 = Ip[kIS + 1], c0 = Ip[2 * kIS], c1 = Ip[2 * kIS + 1];
-            const int p00 = a0 & 0xffff, p01 = a0 >> 16, p02 = a1 >> 16;
-            const int p10 = b0 & 0xffff, p12 = b1 >> 16;
-            const int p20 = c0 & 0xffff, p21 = c0 >> 16, p22 = c1 >> 16;
-            const int dx = __mul24(3, (p02 - p00) + (p22 - p20)) + __mul24(10, p12 - p10);
-            const int dy = __mul24(3, (p20 - p00) + (p22 - p02)) + __mul24(10, p21 - p01);
-            d = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u);  // short2 {dx, dy}
+      if (lane < 2 * kDP) {
+        const int seg = lane >= kDP ? 1 : 0, col = lane - kDP * seg, r0 = seg * R;
+        const uint32_t *Ip = &L.I[0][0] + (__mul24(r0, kIS) + col);
+        uint32_t *Dp = reinterpret_cast<uint32_t *>(&L.dI[0][0]) + (__mul24(r0, kDP) + col);
+        const lk_s2 c310 = {3, 10}, c03 = {0, 3};
+        auto walk = [&](auto checked) {  // (checked: the patch leaves the image -- derivI's BORDER_CONSTANT zeros)
+          const bool colok = (unsigned)(ipx + col) < (unsigned)cols;
+          int h0 = 0, h1 = 0, v0 = 0, v1 = 0;
+          lk_s2 w0s[R + 2], w1s[R + 2];  // (p0, p1), (p1, p2) of input row r0 + r: the staged patch holds reflected values at the image border
+#pragma unroll
+          for (int r = 0; r < R + 2; r++)  // (all reads ahead of the first write: one wait instead of one per row)
+            __builtin_memcpy(&w0s[r], Ip + r * kIS, 4), __builtin_memcpy(&w1s[r], Ip + r * kIS + 1, 4);
+#pragma unroll
+          for (int r = 0; r < R + 2; r++) {
+            const lk_s2 w0 = w0s[r], w1 = w1s[r];
+            const int h2 = (int)w1.y - (int)w0.x;
+            const int v2 = __builtin_amdgcn_sdot2(w0, c310, __builtin_amdgcn_sdot2(w1, c03, 0, false), false);
+            if (r >= 2) {
+              const int dx = __mul24(3, h0 + h2) + __mul24(10, h1), dy = v2 - v0;
+              uint32_t d = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u);  // short2 {dx, dy}
+              if (decltype(checked)::value) {
+                const unsigned ok = (unsigned)colok & (unsigned)((unsigned)(ipy + r0 + r - 2) < (unsigned)rows);
+                d &= 0u - ok;
+              }
+              Dp[(r - 2) * kDP] = d;
+            }
+            h0 = h1, h1 = h2, v0 = v1, v1 = v2;
           }
-          __builtin_memcpy(&L.dI[0][0] + e, &d, 4);  // = L.dI[ly][lx]
+        };
+        if (inside) walk(std::false_type{});
+        else walk(std::true_type{});
+      }
+    } else {
+      {
+        // element e = lane + LPF t of the 22 x 22 derivative patch, (ly, lx) advanced by (LPF / 22, LPF % 22) per trip (an
+        // integer division and the 32-bit multiplies of the Scharr sums are quarter-rate instructions: none are left here)
+        int e = lane, ly = lane / kDP, lx = lane - kDP * ly;
+        const bool inside = ipx >= 0 && ipx + kDP <= cols && ipy >= 0 && ipy + kDP <= rows;  // every derivative position is in the image
+#pragma unroll 1
+        for (int t = 0; t < (kDP * kDP + LPF - 1) / LPF; t++) {
+          if (ly < kDP) {
+            uint32_t d = 0;
+            if (inside || (ipx + lx >= 0 && ipx + lx < cols && ipy + ly >= 0 && ipy + ly < rows)) {
+              // the staged patch holds reflected values, i.e. exactly what calcSharrDeriv reads at the image border
+              const uint32_t *Ip = &L.I[0][0] + (e + __mul24(kIS - kDP, ly));  // = &L.I[ly][lx]
+              const uint32_t a0 = Ip[0], a1 = Ip[1], b0 = Ip[kIS], b1 = Ip[kIS + 1], c0 = Ip[2 * kIS], c1 = Ip[2 * kIS + 1];
+              const int p00 = a0 & 0xffff, p01 = a0 >> 16, p02 = a1 >> 16;
+              const int p10 = b0 & 0xffff, p12 = b1 >> 16;
+              const int p20 = c0 & 0xffff, p21 = c0 >> 16, p22 = c1 >> 16;
+              const int dx = __mul24(3, (p02 - p00) + (p22 - p20)) + __mul24(10, p12 - p10);
+              const int dy = __mul24(3, (p20 - p00) + (p22 - p02)) + __mul24(10, p21 - p01);
+              d = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u);  // short2 {dx, dy}
+            }
+            __builtin_memcpy(&L.dI[0][0] + e, &d, 4);  // = L.dI[ly][lx]
+          }
+          e += LPF, lx += LPF % kDP, ly += LPF / kDP;
+          if (lx >= kDP) lx -= kDP, ly++;
         }
-        e += LPF, lx += LPF % kDP, ly += LPF / kDP;
-        if (lx >= kDP) lx -= kDP, ly++;
       }
     }
     wave_lds_fence();
