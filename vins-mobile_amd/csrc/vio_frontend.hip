@@ -294,11 +294,18 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       // load, 6 lanes per row, 10 rows per trip -- 3 trips instead of 12 (the kernel is VALU-issue-bound: staging the two
       // patches byte by byte was a quarter of a level's instructions)
       const int r = lane / 6, d = lane - 6 * r;
-#pragma unroll 1
-      for (int t = 0; t < (kIP + 9) / 10; t++) {  // (uniform trip count: the DPP below needs every lane)
+      constexpr int TI = (kIP + 9) / 10;
+      uint32_t curs[TI];
+#pragma unroll
+      for (int t = 0; t < TI; t++) {  // (the loads of all trips in flight together: one global round trip per patch, not one per trip)
+        const int ly = r + 10 * t;
+        curs[t] = lk_load4(I + (unsigned)(__mul24(ipy - 1 + (ly < kIP ? ly : 0), cols) + ipx - 1 + 4 * d));
+      }
+#pragma unroll
+      for (int t = 0; t < TI; t++) {  // (uniform trip count: the DPP below needs every lane)
         const int ly = r + 10 * t;
         const bool ok = lane < 60 && ly < kIP;
-        const uint32_t cur = lk_load4(I + (unsigned)(__mul24(ipy - 1 + (ly < kIP ? ly : 0), cols) + ipx - 1 + 4 * d));
+        const uint32_t cur = curs[t];
         uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);  // dword of lane + 1
         if (d == 5) next = cur >> 24;  // (the pair behind the last pixel repeats it, like the byte path's clamped lane)
         uint32_t w4[4];
@@ -445,11 +452,18 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       if (FPW == 1 && jox >= 0 && jox + kJP <= cols && joy >= 0 && joy + kJP <= rows) {
         // inside the image: 4 pixels per lane and load, 7 lanes per row, 9 rows per trip -- 4 trips instead of 14
         const int r = lane / 7, d = lane - 7 * r;
-#pragma unroll 1
-        for (int t = 0; t < (kJP + 8) / 9; t++) {
+        constexpr int TJ = (kJP + 8) / 9;
+        uint32_t curs[TJ];
+#pragma unroll
+        for (int t = 0; t < TJ; t++) {
+          const int ly = r + 9 * t;
+          curs[t] = lk_load4(J + (unsigned)(__mul24(joy + (ly < kJP ? ly : 0), cols) + jox + 4 * d));
+        }
+#pragma unroll
+        for (int t = 0; t < TJ; t++) {
           const int ly = r + 9 * t;
           const bool ok = lane < 63 && ly < kJP;
-          const uint32_t cur = lk_load4(J + (unsigned)(__mul24(joy + (ly < kJP ? ly : 0), cols) + jox + 4 * d));
+          const uint32_t cur = curs[t];
           uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, false);
           if (d == 6) next = cur >> 24;
           uint32_t w4[4];
