@@ -165,6 +165,7 @@ struct LkWaveLds {
   };
 };
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short lk_us2 __attribute__((ext_vector_type(2)));
 
 // Four consecutive pixels from an arbitrary byte address (global memory takes unaligned dword loads on this hardware).
 struct __attribute__((packed)) LkU32 {
@@ -487,13 +488,16 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       j_staged = true;
     };
     const uint32_t *Jl = &L.J[0][0];
-    auto diff_j = [&](int base, int q, lk_s2 wtop, lk_s2 wbot) {  // bilinear J at this lane's q-th window pixel, minus I there
-      lk_s2 top, bot;
+    // (the top-row weights are never negative: their dot is the unsigned three-operand instruction, seeded with Ic without
+    // a copy; the bottom row, whose iw11 can be -1, goes through the signed accumulate-in-place one)
+    auto diff_j = [&](int base, int q, lk_us2 wtop, lk_s2 wbot) {  // bilinear J at this lane's q-th window pixel, minus I there
+      lk_us2 top;
+      lk_s2 bot;
       const int o = base + (COLS ? joff[0] + 3 * q * kJS : joff[COLS ? 0 : q]);  // (q is a constant after unrolling)
       const uint32_t t32 = Jl[o], b32 = Jl[o + kJS];
       __builtin_memcpy(&top, &t32, 4);
       __builtin_memcpy(&bot, &b32, 4);
-      return __builtin_amdgcn_sdot2(top, wtop, __builtin_amdgcn_sdot2(bot, wbot, Ic[q], false), false) >> (kWBits - 5);
+      return __builtin_amdgcn_sdot2(bot, wbot, (int)__builtin_amdgcn_udot2(top, wtop, (unsigned)Ic[q], false), false) >> (kWBits - 5);  // (mod 2^32)
     };
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
@@ -505,7 +509,8 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
       int pb1 = 0, pb2 = 0;  // |diff * dI| <= 16320 * 4080 per pixel, <= 14 pixels per lane: 9.3e8 fits 32 bits
-      const lk_s2 wtop = {(short)iw00, (short)iw01}, wbot = {(short)iw10, (short)iw11};
+      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01};
+      const lk_s2 wbot = {(short)iw10, (short)iw11};
       const int jbase = __mul24(iqy - joy, kJS) + (iqx - jox);
 #pragma unroll
       for (int h = 0; h < NPP; h++) {  // (a pixel the lane does not own has Ix = Iy = 0)
@@ -540,7 +545,8 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       float aa = ex - iex, bb = ey - iey;
       lk_weights(aa, bb, iw00, iw01, iw10, iw11);
       int pe = 0;
-      const lk_s2 wtop = {(short)iw00, (short)iw01}, wbot = {(short)iw10, (short)iw11};
+      const lk_us2 wtop = {(unsigned short)iw00, (unsigned short)iw01};
+      const lk_s2 wbot = {(short)iw10, (short)iw11};
       const int jbase = __mul24(iey - joy, kJS) + (iex - jox);
 #pragma unroll
       for (int q = 0; q < NPX; q++) {
