@@ -105,11 +105,14 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *src_base, 
 }
 
 // ---- pyramidal LK -------------------------------------------------------------------------------------
+// Smallest float threshold such that fl(dx*dx + dy*dy) > threshold implies dx^2 + dy^2 > eps_sq in exact arithmetic (the float
+// sum is within 2^-22 relative of the exact one; the margin is 1e-5).
+inline float lk_eps_screen(double eps_sq) { return nextafterf((float)(eps_sq * (1.0 + 1e-5)), INFINITY); }
 struct LkParams {
   LevelDims ld;
   int cap;             // feature slots per sequence
   int max_count;       // criteria.maxCount
-  float epsilon_sq_f;  // unused (double compare below)
+  float epsilon_sq_f;  // screen of the convergence test: a float sum of squares above it cannot pass the double compare
   double epsilon_sq;
   float min_eig;
 };
@@ -210,7 +213,7 @@ __device__ __forceinline__ double feat_sum_exact(int p, int sub) {
 
 // Two exact sums at once (one feature per wave): the four 32-bit chains advance in lockstep, so that every DPP step finds
 // its operand written three instructions earlier (a chain on its own waits two issue slots after every step).
-__device__ __forceinline__ void wave_sum_exact2(int p, int q, double &sp, double &sq) {
+__device__ __forceinline__ void wave_sum_exact2(int p, int q, float &sp, float &sq) {
   int a = p & 0xffff, b = q & 0xffff, c = p >> 16, d = q >> 16;
 #define VIO_DPP4(ctrl, rmask)                                              \
   {                                                                        \
@@ -224,7 +227,26 @@ __device__ __forceinline__ void wave_sum_exact2(int p, int q, double &sp, double
 #undef VIO_DPP4
   const int sa = __builtin_amdgcn_readlane(a, 63), sb = __builtin_amdgcn_readlane(b, 63), sc = __builtin_amdgcn_readlane(c, 63),
             sd = __builtin_amdgcn_readlane(d, 63);
-  sp = (double)sc * 65536.0 + (double)sa, sq = (double)sd * 65536.0 + (double)sb;
+  // |high sum| < 2^20 and low sum < 2^22 are exact floats, the product by 2^16 is exact: the one rounding is that of the add,
+  // i.e. the result is the correctly rounded float of the exact integer (= (float) of the exact double)
+  sp = (float)sc * 65536.f + (float)sa, sq = (float)sd * 65536.f + (float)sb;
+}
+
+// Three at once (the 2 x 2 system's A11, A12, A22): six chains in lockstep.
+__device__ __forceinline__ void wave_sum_exact3(int p, int q, int r, float &sp, float &sq, float &sr) {
+  int v[6] = {p & 0xffff, q & 0xffff, r & 0xffff, p >> 16, q >> 16, r >> 16};
+#define VIO_DPP6(ctrl, rmask)                                                       \
+  {                                                                                 \
+    int t[6];                                                                       \
+    _Pragma("unroll") for (int k = 0; k < 6; k++) t[k] = __builtin_amdgcn_update_dpp(0, v[k], ctrl, rmask, 0xf, false); \
+    _Pragma("unroll") for (int k = 0; k < 6; k++) v[k] += t[k];                     \
+  }
+  VIO_DPP6(0x111, 0xf) VIO_DPP6(0x112, 0xf) VIO_DPP6(0x114, 0xf) VIO_DPP6(0x118, 0xf) VIO_DPP6(0x142, 0xa) VIO_DPP6(0x143, 0xc)
+#undef VIO_DPP6
+  int s[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) s[k] = __builtin_amdgcn_readlane(v[k], 63);
+  sp = (float)s[3] * 65536.f + (float)s[0], sq = (float)s[4] * 65536.f + (float)s[1], sr = (float)s[5] * 65536.f + (float)s[2];
 }
 
 // FPW features per wave (64 / FPW lanes each). prev/next pyramids: per sequence `pyr_bytes` apart. pts arrays:
@@ -434,8 +456,10 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       else IxP[q >> 1].x = (short)ixval, IyP[q >> 1].x = (short)iyval;
       p11 += ixval * ixval, p12 += ixval * iyval, p22 += iyval * iyval;
     }
-    const double s11 = feat_sum_exact<FPW>(p11, sub), s12 = feat_sum_exact<FPW>(p12, sub), s22 = feat_sum_exact<FPW>(p22, sub);  // exact integer sums
-    float A11 = (float)s11 * FLT_SCALE, A12 = (float)s12 * FLT_SCALE, A22 = (float)s22 * FLT_SCALE;
+    float f11, f12, f22;  // exact integer sums, rounded once to float
+    if (FPW == 1) wave_sum_exact3(p11, p12, p22, f11, f12, f22);
+    else f11 = (float)feat_sum_exact<FPW>(p11, sub), f12 = (float)feat_sum_exact<FPW>(p12, sub), f22 = (float)feat_sum_exact<FPW>(p22, sub);
+    float A11 = f11 * FLT_SCALE, A12 = f12 * FLT_SCALE, A22 = f22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * kWin * kWin);
     if (minEig < P.min_eig || D < 1.1920929e-07f) {
@@ -520,15 +544,21 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
         __builtin_memcpy(&dp, &pk, 4);
         pb1 = __builtin_amdgcn_sdot2(dp, IxP[h], pb1, false), pb2 = __builtin_amdgcn_sdot2(dp, IyP[h], pb2, false);
       }
-      double sb1, sb2;
-      if (FPW == 1) wave_sum_exact2(pb1, pb2, sb1, sb2);
-      else sb1 = feat_sum_exact<FPW>(pb1, sub), sb2 = feat_sum_exact<FPW>(pb2, sub);
-      float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+      float fb1, fb2;  // the exact integer sums, rounded once to float (what (float) of the exact double gave)
+      if (FPW == 1) wave_sum_exact2(pb1, pb2, fb1, fb2);
+      else fb1 = (float)feat_sum_exact<FPW>(pb1, sub), fb2 = (float)feat_sum_exact<FPW>(pb2, sub);
+      float b1 = fb1 * FLT_SCALE, b2 = fb2 * FLT_SCALE;
       float ddx = (A12 * b2 - A22 * b1) * D, ddy = (A12 * b1 - A11 * b2) * D;
       qx += ddx, qy += ddy;
       nxx = qx + half, nxy = qy + half;
-      if ((double)ddx * ddx + (double)ddy * ddy <= P.epsilon_sq) break;
-      if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
+      // delta.ddot(delta) <= epsilon in double, behind a float screen that only lets candidates through (conversions to and
+      // from double are slow instructions; all but the last iteration of a level stop at the screen)
+      if (!(ddx * ddx + ddy * ddy > P.epsilon_sq_f) && (double)ddx * ddx + (double)ddy * ddy <= P.epsilon_sq) break;
+      // |x| < 0.01 for a float x: 0.01 (double) lies strictly between 0.01f and the next float up, so the float compare against
+      // that next float decides the same
+      constexpr float kCentiUp = 0.010000000707805157f;
+      static_assert((double)kCentiUp > 0.01 && (double)0.01f < 0.01, "float neighbours of 0.01");
+      if (j > 0 && fabsf(ddx + pdx) < kCentiUp && fabsf(ddy + pdy) < kCentiUp) {
         nxx -= ddx * 0.5f, nxy -= ddy * 0.5f;
         break;
       }
@@ -1719,7 +1749,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     P.ld = fe->ld, P.cap = cap;
     P.max_count = std::min(std::max(fe->cfg.lk_max_iters, 0), 100);
     double eps = std::min(std::max(fe->cfg.lk_eps, 0.), 10.);
-    P.epsilon_sq = eps * eps, P.epsilon_sq_f = (float)(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
+    P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
     dim3 grd((cap + 4 * kLkFpw - 1) / (4 * kLkFpw), S);
     hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
                        fe->forw_pts, fe->lk_status, fe->lk_err);
@@ -2185,7 +2215,7 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
   LkParams P;
   P.ld = fe->ld, P.cap = fe->cap, P.max_count = std::min(std::max(c.lk_max_iters, 0), 100);
   double eps = std::min(std::max(c.lk_eps, 0.), 10.);
-  P.epsilon_sq = eps * eps, P.epsilon_sq_f = (float)(eps * eps), P.min_eig = (float)c.lk_min_eig;
+  P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)c.lk_min_eig;
   hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
                      fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);
