@@ -1249,6 +1249,19 @@ __device__ __forceinline__ float dpp_f32(float v) {
 #define LANE_LEFT(v) dpp_f32<0x138>(v)   /* wave_shr:1 -> value of lane - 1 */
 #define LANE_RIGHT(v) dpp_f32<0x130>(v)  /* wave_shl:1 -> value of lane + 1 */
 
+// sqrtf, correctly rounded, for arguments that are zero or normal numbers (what cornerMinEigenVal feeds it here: the
+// derivative products are multiples of (1 / 3060)^2 rounded to float, so (a - c)^2 + b^2 is either 0 or above 1e-30 -- never a
+// denormal, which is the one case the library expansion spends five more instructions on): the hardware estimate, then the
+// neighbour whose residual changes sign (the same correction step the library uses).
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  const float r = __builtin_amdgcn_sqrtf(x);
+  const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+  const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+  float y = em <= 0.f ? rm : r;
+  y = ep > 0.f ? rp : y;
+  return (x == 0.f || __builtin_isinf(x)) ? x : y;
+}
+
 template <bool IMG_MASK>
 __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
                                                      size_t mask_stride, const int *kept_xy, const int *n_kept, int cap,
@@ -1305,6 +1318,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   int prev_yr = -1, prev_yp = -1;               // rows of the previous step (uniform) and their (d, t)
   float pd1 = 0.f, pt1 = 0.f, pd2 = 0.f, pt2 = 0.f;
   const bool out_lane = lane >= 2 && lane < 2 + kDetW && xe < cols;
+#pragma unroll 6  // (the carried rows rotate with periods 2 and 3: unrolled by 6 the rotation is register renaming, not moves)
   for (int step = 0; step < kDetR + 4; step++) {
     const int ye = Y0 - 2 + step;  // extended product row (uniform)
     const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
@@ -1313,8 +1327,8 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
     // horizontal smoothing t = 2s a(x) + s (a(x-1) + a(x+1)); dx = 2s d(y) + s (d(y-1) + d(y+1)), dy = t(y+1) - t(y-1). Inside
     // the image the rows (y-1, y) of this step are the rows (y, y+1) of the previous one: only the entering row is loaded.
     auto row_dt = [&](int y, float &d, float &t) {
-      const uint8_t *r = img + (size_t)y * cols;
-      const float a0 = (float)r[xm], a1 = (float)r[xr], a2 = (float)r[xp];
+      const uint8_t *r = img + (size_t)y * cols;  // (uniform base + unsigned 32-bit lane offsets: no per-lane 64-bit address arithmetic)
+      const float a0 = (float)r[(unsigned)xm], a1 = (float)r[(unsigned)xr], a2 = (float)r[(unsigned)xp];
       d = a2 - a0;
       t = s2 * a1 + s * (a0 + a2);
     };
@@ -1338,7 +1352,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
       const float a = ((hxx0 + hxx1) + hxx2) * 0.5f;
       const float b = (hxy0 + hxy1) + hxy2;
       const float c = ((hyy0 + hyy1) + hyy2) * 0.5f;
-      e2 = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+      e2 = (a + c) - sqrt_rn_normal((a - c) * (a - c) + b * b);
     }
     if (step >= 4) {  // output row ye - 2: centre e1, neighbours e0 / e2 and the lanes left and right
       const int y = ye - 2, r = step - 4;
