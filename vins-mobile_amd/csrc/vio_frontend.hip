@@ -1308,6 +1308,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   }
   const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
   const float s2 = s * 2.f;
+  const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, rows * cols, 0x00020000);  // (raw bytes, bounds = the frame)
   // this lane's column (reflected like the product image) and its two neighbours for the Sobel taps
   const int xe = X0 - 2 + lane;
   const int xr = reflect101(min(max(xe, -cols + 1), 2 * cols - 2), cols);
@@ -1327,8 +1328,11 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
     // horizontal smoothing t = 2s a(x) + s (a(x-1) + a(x+1)); dx = 2s d(y) + s (d(y-1) + d(y+1)), dy = t(y+1) - t(y-1). Inside
     // the image the rows (y-1, y) of this step are the rows (y, y+1) of the previous one: only the entering row is loaded.
     auto row_dt = [&](int y, float &d, float &t) {
-      const uint8_t *r = img + (size_t)y * cols;  // (uniform base + unsigned 32-bit lane offsets: no per-lane 64-bit address arithmetic)
-      const float a0 = (float)r[(unsigned)xm], a1 = (float)r[(unsigned)xr], a2 = (float)r[(unsigned)xp];
+      // buffer loads: the row offset rides in the scalar offset operand, the column in the lane offset -- no address arithmetic
+      // on the vector unit (three 64-bit adds per row with flat pointers)
+      const int ro = __builtin_amdgcn_readfirstlane(y * cols);
+      const float a0 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xm, ro, 0), a1 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xr, ro, 0),
+                  a2 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xp, ro, 0);
       d = a2 - a0;
       t = s2 * a1 + s * (a0 + a2);
     };
