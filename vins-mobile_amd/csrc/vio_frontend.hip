@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base,
                                                         int srows, int scols, int drows, int dcols, uint8_t *copy_base) {
   constexpr int SH = 2 * kPd4H + 4;
   __shared__ uint32_t raw[SH][kPd4Dw + 1];
-  __shared__ int hsum[SH][kPdW + 1];
+  __shared__ uint32_t hsum[SH / 2][kPdW + 1];
   const uint8_t *src = src_base + (size_t)blockIdx.z * src_stride;
   uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
   const int ox = blockIdx.x * kPdW, oy = blockIdx.y * kPd4H;
@@ -1662,14 +1662,18 @@ __global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base,
     }
   }
   __syncthreads();
-  for (int e = tid; e < SH * kPdW; e += 256) {
-    const int ly = e / kPdW, lx = e - ly * kPdW;
-    // output column ox + lx reads columns 2 lx - 2 .. 2 lx + 2 of the tile = staged bytes 2 lx + 2 .. 2 lx + 6
+  // horizontal pass, two source rows per item: output column ox + lx reads columns 2 lx - 2 .. 2 lx + 2 of the tile = staged
+  // bytes 2 lx + 2 .. 2 lx + 6: four of them cut out of a dword pair with one funnel shift and weighted by ONE byte dot product
+  // (1 4 6 4), the fifth is its accumulator. The sums (<= 16 * 255) of rows 2 p and 2 p + 1 share a dword, so that the vertical
+  // pass below is two 16-bit dot products per output.
+  for (int e = tid; e < (SH / 2) * kPdW; e += 256) {
+    const int p = e / kPdW, lx = e - p * kPdW;
     const int b = 2 * lx + 2, dwi = b >> 2, sh = (b & 3) * 8;
-    const unsigned long long v = ((unsigned long long)raw[ly][dwi + 1] << 32 | raw[ly][dwi]) >> sh;
-    const int r0 = (int)(v & 0xff), r1 = (int)((v >> 8) & 0xff), r2 = (int)((v >> 16) & 0xff), r3 = (int)((v >> 24) & 0xff),
-              r4 = (int)((v >> 32) & 0xff);
-    hsum[ly][lx] = r0 + 4 * r1 + 6 * r2 + 4 * r3 + r4;
+    auto hrow = [&](int ly) {
+      const uint32_t lo = raw[ly][dwi], hi = raw[ly][dwi + 1];
+      return __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(hi, lo, sh), 0x04060401u, __builtin_amdgcn_ubfe(hi, sh, 8), false);
+    };
+    hsum[p][lx] = hrow(2 * p) | hrow(2 * p + 1) << 16;
   }
   __syncthreads();
   {
@@ -1677,11 +1681,13 @@ __global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base,
     const int x = ox + lx, y = oy + ly;
     if (x < dcols && y < drows) {
       uint32_t out = 0;
+      const lk_us2 w14 = {1, 4}, w64 = {6, 4};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int v = hsum[2 * ly][lx + i] + 4 * hsum[2 * ly + 1][lx + i] + 6 * hsum[2 * ly + 2][lx + i] + 4 * hsum[2 * ly + 3][lx + i] +
-                      hsum[2 * ly + 4][lx + i];
-        out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+      for (int i = 0; i < 4; i++) {  // source rows 2 ly .. 2 ly + 4 = pairs ly, ly + 1 and the low half of pair ly + 2
+        lk_us2 p0, p1;
+        __builtin_memcpy(&p0, &hsum[ly][lx + i], 4), __builtin_memcpy(&p1, &hsum[ly + 1][lx + i], 4);
+        const uint32_t v = __builtin_amdgcn_udot2(p0, w14, __builtin_amdgcn_udot2(p1, w64, hsum[ly + 2][lx + i] & 0xffffu, false), false);
+        out |= ((v + 128) >> 8) << (8 * i);
       }
       *reinterpret_cast<uint32_t *>(dst + (size_t)y * dcols + x) = out;  // (dcols % 4 == 0: x + 3 < dcols)
     }
