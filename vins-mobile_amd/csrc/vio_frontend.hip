@@ -342,8 +342,16 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
        // neighbour of every pixel comes from the next lane (DPP wave_shl) so that a pair can be stored as one dword
       const int lx = lane & 31;
       const int x = reflect101(ipx - 1 + min(lx, kIP - 1), cols);
-      for (int ly = lane >> 5; ly < kIP; ly += LPF / 32) {
-        const int v = I[(unsigned)(__mul24(reflect101(ipy - 1 + ly, rows), cols) + x)];
+      // (a third of the features take this path at the coarse levels, where the patch is a quarter of the image: all loads
+      // of the patch are issued before the first is consumed -- one memory round trip instead of one per trip)
+      constexpr int RPT = LPF / 32, TB = kIP / RPT;
+      static_assert(kIP % RPT == 0, "whole trips");
+      int vs[TB];
+#pragma unroll
+      for (int t = 0; t < TB; t++) vs[t] = I[(unsigned)(__mul24(reflect101(ipy - 1 + (lane >> 5) + RPT * t, rows), cols) + x)];
+#pragma unroll
+      for (int t = 0; t < TB; t++) {
+        const int ly = (lane >> 5) + RPT * t, v = vs[t];
         const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
         if (lx < kIP) L.I[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
       }
@@ -501,9 +509,17 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       } else {  // 32 lanes per row (28 used), two rows per trip; pairs (J[x] | J[x+1] << 16) like the template patch
         const int lx = lane & 31;
         const int x = reflect101(min(max(jox + min(lx, kJP - 1), -cols + 1), 2 * cols - 2), cols);
-        for (int ly = lane >> 5; ly < kJP; ly += LPF / 32) {
-          const int y = reflect101(min(max(joy + ly, -rows + 1), 2 * rows - 2), rows);
-          const int v = J[(unsigned)(__mul24(y, cols) + x)];
+        constexpr int RPT = LPF / 32, TB = kJP / RPT;
+        static_assert(kJP % RPT == 0, "whole trips");
+        int vs[TB];
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const int y = reflect101(min(max(joy + (lane >> 5) + RPT * t, -rows + 1), 2 * rows - 2), rows);
+          vs[t] = J[(unsigned)(__mul24(y, cols) + x)];
+        }
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+          const int ly = (lane >> 5) + RPT * t, v = vs[t];
           const int vr = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);  // value of lane + 1
           if (lx < kJP) L.J[ly][lx] = (uint32_t)v | ((uint32_t)vr << 16);
         }
