@@ -232,17 +232,21 @@ __device__ __forceinline__ void wave_sum_exact2(int p, int q, float &sp, float &
   sp = (float)sc * 65536.f + (float)sa, sq = (float)sd * 65536.f + (float)sb;
 }
 
-// Three at once (the 2 x 2 system's A11, A12, A22): six chains in lockstep.
+// Three at once (the 2 x 2 system's A11, A12, A22; per-lane partials |p| <= 7 * 4080^2): the sum of a ROW of 16 lanes still
+// fits 32 bits (< 1.87e9), so the four in-row steps run on the three unsplit values; only the two cross-row steps need the
+// 16-bit halves (six chains).
 __device__ __forceinline__ void wave_sum_exact3(int p, int q, int r, float &sp, float &sq, float &sr) {
-  int v[6] = {p & 0xffff, q & 0xffff, r & 0xffff, p >> 16, q >> 16, r >> 16};
-#define VIO_DPP6(ctrl, rmask)                                                       \
+  int u[3] = {p, q, r};
+#define VIO_DPPN(N, arr, ctrl, rmask)                                               \
   {                                                                                 \
-    int t[6];                                                                       \
-    _Pragma("unroll") for (int k = 0; k < 6; k++) t[k] = __builtin_amdgcn_update_dpp(0, v[k], ctrl, rmask, 0xf, false); \
-    _Pragma("unroll") for (int k = 0; k < 6; k++) v[k] += t[k];                     \
+    int t[N];                                                                       \
+    _Pragma("unroll") for (int k = 0; k < N; k++) t[k] = __builtin_amdgcn_update_dpp(0, arr[k], ctrl, rmask, 0xf, false); \
+    _Pragma("unroll") for (int k = 0; k < N; k++) arr[k] += t[k];                   \
   }
-  VIO_DPP6(0x111, 0xf) VIO_DPP6(0x112, 0xf) VIO_DPP6(0x114, 0xf) VIO_DPP6(0x118, 0xf) VIO_DPP6(0x142, 0xa) VIO_DPP6(0x143, 0xc)
-#undef VIO_DPP6
+  VIO_DPPN(3, u, 0x111, 0xf) VIO_DPPN(3, u, 0x112, 0xf) VIO_DPPN(3, u, 0x114, 0xf) VIO_DPPN(3, u, 0x118, 0xf)
+  int v[6] = {u[0] & 0xffff, u[1] & 0xffff, u[2] & 0xffff, u[0] >> 16, u[1] >> 16, u[2] >> 16};
+  VIO_DPPN(6, v, 0x142, 0xa) VIO_DPPN(6, v, 0x143, 0xc)
+#undef VIO_DPPN
   int s[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) s[k] = __builtin_amdgcn_readlane(v[k], 63);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
   for (int level = max_level; level >= 0; level--) {
     const int rows = P.ld.rows[level], cols = P.ld.cols[level];
     const uint8_t *I = pp + P.ld.off[level], *J = np + P.ld.off[level];
-    float scale = (float)(1. / (1 << level));
+    const float scale = __int_as_float((127 - level) << 23);  // (float)(1. / (1 << level)) = 2^-level, without the double division
     float px = ptx * scale, py = pty * scale;
     float qx, qy;
     if (level == max_level) qx = px, qy = py;
