@@ -1038,24 +1038,30 @@ struct TrackerArrays {
   int radius;
   float f_thresh;
   double f_conf;
+  long long *prof;  // null, or cycle stamps of sequence 0's workgroup (VIO_AMD_TU_PROF, tools/tu_prof.sh)
 };
 
 // Stable compaction of the five per-feature arrays by `keep` flags; all arrays staged in LDS.
+// CAP: capacity the LDS arrays are laid out for. The launcher picks the smallest instantiation that holds the tracker's
+// feature slots: with the arrays of the 512-slot layout (95 KB with the RANSAC state) only ONE workgroup fits a CU and the
+// 512 sequences of the bench ran as two rounds; the 256-slot layout is 47 KB.
+template <int CAP>
 struct TrackShared {
-  float pre[kMaxCap][2], cur[kMaxCap][2], forw[kMaxCap][2];
-  int ids[kMaxCap], cnt[kMaxCap];
-  int keep[kMaxCap];  // (dword flags: sub-dword LDS accesses are slow)
-  int pos[kMaxCap];
-  float t_pre[kMaxCap][2], t_cur[kMaxCap][2], t_forw[kMaxCap][2];
-  int t_ids[kMaxCap], t_cnt[kMaxCap];
+  float pre[CAP][2], cur[CAP][2], forw[CAP][2];
+  int ids[CAP], cnt[CAP];
+  int keep[CAP];  // (dword flags: sub-dword LDS accesses are slow)
+  int pos[CAP];
+  float t_pre[CAP][2], t_cur[CAP][2], t_forw[CAP][2];
+  int t_ids[CAP], t_cnt[CAP];
   int n;
-  int order[kMaxCap];
-  int ixy[kMaxCap][2];
-  unsigned long long inside[kMaxCap][kMaxCap / 64];
+  int order[CAP];
+  int ixy[CAP][2];
+  unsigned long long inside[CAP][CAP / 64];
   int hw[2 * kMaxRadius + 1];  // half-widths of the filled circle (setMask), staged from global memory
 };
 
-__device__ void compact_block(TrackShared &T) {
+template <int CAP>
+__device__ void compact_block(TrackShared<CAP> &T) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int n = T.n;
   __syncthreads();  // everyone has read n
@@ -1103,13 +1109,19 @@ __device__ void compact_block(TrackShared &T) {
 }
 
 // One workgroup per sequence: everything between the LK call and goodFeaturesToTrack.
+template <int CAP>
 __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int publish) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  TrackShared &T = *reinterpret_cast<TrackShared *>(smem_raw);
-  RansacShared &R = *reinterpret_cast<RansacShared *>(smem_raw + ((sizeof(TrackShared) + 15) & ~(size_t)15));
+  TrackShared<CAP> &T = *reinterpret_cast<TrackShared<CAP> *>(smem_raw);
+  RansacShared &R = *reinterpret_cast<RansacShared *>(smem_raw + ((sizeof(TrackShared<CAP>) + 15) & ~(size_t)15));
   const int seq = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const size_t base = (size_t)seq * A.cap;
   const int n0 = A.n_pts[seq];
+#define TU_STAMP(k)                                                  \
+  do {                                                               \
+    if (A.prof && seq == 0 && tid == 0) A.prof[k] = clock64();       \
+  } while (0)
+  TU_STAMP(0);
   if (tid == 0) T.n = n0;
   for (int i = tid; i < n0; i += nt) {
     T.pre[i][0] = A.pre_pts[(base + i) * 2], T.pre[i][1] = A.pre_pts[(base + i) * 2 + 1];
@@ -1122,13 +1134,17 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
     T.keep[i] = (A.lk_status[base + i] && inb) ? 1 : 0;
   }
   __syncthreads();
+  TU_STAMP(1);
   if (n0 > 0) {
     compact_block(T);
+    TU_STAMP(2);
     if (T.n >= 8) {  // findFundamentalMat(cur_pts, forw_pts, FM_RANSAC, F_THRESHOLD, 0.99) :194-205
       fundamental_ransac_block(R, &T.cur[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep);
+      TU_STAMP(3);
       compact_block(T);
     }
   }
+  TU_STAMP(4);
   // the point list solveVinsPnP joins with the solved landmarks (:207): behind the first rejection, ahead of the
   // publish-frame steps (rejectWithF :235, setMask :255) that drop more of it
   for (int i = tid; i < T.n; i += nt) {
@@ -1138,9 +1154,12 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
   if (tid == 0) A.n_pnp[seq] = T.n;
   if (publish) {
     if (T.n >= 8) {  // rejectWithF: (pre_pts, forw_pts) :89-103
+      TU_STAMP(5);
       fundamental_ransac_block(R, &T.pre[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep);
+      TU_STAMP(6);
       compact_block(T);
     }
+    TU_STAMP(7);
     const int n = T.n;
     for (int i = tid; i < n; i += nt) {
       T.cnt[i] += 1;  // for (auto &n : track_cnt) n++ :252-253
@@ -1155,28 +1174,41 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
     }
     const int words = (n + 63) / 64;
     __syncthreads();
+    TU_STAMP(8);
     // inside[i][w] bit j: pixel of i lies in the filled circle painted at j (i, j in ORIGINAL indices). One word per wave
     // instruction: the wave takes (i, w), lane b tests j = 64 w + b, the ballot IS the word. (The per-thread loop over
     // 64 j with the half-width table read from global memory inside it was 57 k cycles; the table now sits in LDS.)
     for (int q = tid; q < 2 * A.radius + 1; q += nt) T.hw[q] = A.hw[q];
     __syncthreads();
     {
+      // lane b keeps the centres j = 64 w + b of the (at most kW) words in registers and walks i: per (i, w) two compares, one
+      // table read and a ballot -- the item loop that re-read both centres per (i, w) was a chain of three dependent LDS round
+      // trips per item (566 cycles each, 18 % of the kernel)
       const int wave = tid >> 6, lane = tid & 63, nwv = nt >> 6;
-      for (int item = wave; item < n * words; item += nwv) {
-        const int i = item / words, w = item - i * words, j = w * 64 + lane;
-        bool in = false;
-        if (j < n) {
-          const int dy = T.ixy[i][1] - T.ixy[j][1], dx = T.ixy[i][0] - T.ixy[j][0];
-          if (dy >= -A.radius && dy <= A.radius) {
-            const int h = T.hw[A.radius + dy];
-            in = dx >= -h && dx <= h;
+      constexpr int kW = CAP / 64;
+      int jx[kW], jy[kW];
+#pragma unroll
+      for (int w = 0; w < kW; w++) {
+        const int j = min(64 * w + lane, n - 1);
+        jx[w] = T.ixy[j][0], jy[w] = T.ixy[j][1];
+      }
+      const int rad = A.radius;
+      for (int i = wave; i < n; i += nwv) {
+        const int ix = T.ixy[i][0], iy = T.ixy[i][1];
+#pragma unroll
+        for (int w = 0; w < kW; w++) {
+          if (w < words) {
+            const int dy = iy - jy[w], dx = ix - jx[w];
+            const int h = T.hw[rad + min(max(dy, -rad), rad)];
+            const bool in = 64 * w + lane < n && dy >= -rad && dy <= rad && dx >= -h && dx <= h;
+            const unsigned long long bits = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) T.inside[i][w] = bits;
           }
         }
-        const unsigned long long bits = __builtin_amdgcn_ballot_w64(in);
-        if (lane == 0) T.inside[i][w] = bits;
       }
     }
     __syncthreads();
+    TU_STAMP(9);
     // greedy in sorted order (:73-83): a feature is kept unless it lies in the circle of an earlier kept one. One wave:
     // lane w owns word w of the kept set in a register, the hit test is a ballot; the index list and the bit rows do not
     // depend on the decisions, so the compiler is free to fetch them ahead. Kept features get their output position
@@ -1188,22 +1220,35 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
       for (int r0 = 0; r0 < n; r0 += 64) {
         const int my_i = r0 + lane < n ? T.order[r0 + lane] : 0;
         const int cnt = n - r0 < 64 ? n - r0 : 64;
-        for (int q = 0; q < cnt; q++) {
-          const int i = __builtin_amdgcn_readlane(my_i, q);
-          const unsigned long long row = lane < words ? T.inside[i][lane] : 0ull;
-          const bool hit = __builtin_amdgcn_ballot_w64((row & mine) != 0) != 0;
-          if (!hit) {
-            if (lane == (i >> 6)) mine |= 1ULL << (i & 63);
-            if (lane == 0) T.keep[i] = 1, T.pos[i] = c;
-            c++;
-          } else if (lane == 0) {
-            T.keep[i] = 0;
+        unsigned long long kept = 0;  // bit q: candidate r0 + q is kept (uniform)
+        for (int q0 = 0; q0 < cnt; q0 += 8) {  // the bit rows of eight candidates are fetched together, then decided in order
+          int is[8];
+          unsigned long long rows[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            is[u] = __builtin_amdgcn_readlane(my_i, (q0 + u) & 63);
+            rows[u] = lane < words ? T.inside[is[u]][lane] : 0ull;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {  // (no LDS traffic and no lane-0 branches inside the chain: the decisions go to a bit mask)
+            const int i = is[u];
+            const bool keep_it = q0 + u < cnt && __builtin_amdgcn_ballot_w64((rows[u] & mine) != 0) == 0;
+            const unsigned long long bit = keep_it ? 1ULL << (i & 63) : 0ull;
+            mine |= lane == (i >> 6) ? bit : 0ull;
+            kept |= (unsigned long long)keep_it << ((q0 + u) & 63);
           }
         }
+        if (lane < cnt) {  // candidate r0 + lane: its decision and, if kept, its output position (forw_pts.push_back order)
+          const bool k = (kept >> lane) & 1ull;
+          T.keep[my_i] = k ? 1 : 0;
+          if (k) T.pos[my_i] = c + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+        }
+        c += __builtin_popcountll(kept);
       }
       if (lane == 0) T.n = c;
     }
     __syncthreads();
+    TU_STAMP(10);
     for (int i = tid; i < n; i += nt)
       if (T.keep[i]) {
         int p = T.pos[i];
@@ -1235,6 +1280,8 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
     A.n_forw[seq] = n;
     if (!publish) A.n_pts[seq] = n;
   }
+  TU_STAMP(11);
+#undef TU_STAMP
 }
 
 // ---- goodFeaturesToTrack -----------------------------------------------------------------------------------------
@@ -1739,12 +1786,31 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
   A.n_kept = fe->n_kept, A.hw = fe->hw, A.radius = fe->cfg.min_dist, A.f_thresh = (float)fe->cfg.f_threshold;
   A.pnp_pts = fe->pnp_pts, A.pnp_ids = fe->pnp_ids, A.n_pnp = fe->n_pnp;
   A.f_conf = fe->cfg.f_confidence;
-  const size_t shm = ((sizeof(TrackShared) + 15) & ~(size_t)15) + sizeof(RansacShared);
+  static const bool tu_prof = getenv("VIO_AMD_TU_PROF") && getenv("VIO_AMD_TU_PROF")[0] == '1';
+  static long long *d_prof = nullptr;
+  if (tu_prof && !d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(long long));
+  A.prof = tu_prof ? d_prof : nullptr;
+  // the smallest LDS layout that holds this tracker's feature slots (fe->cap <= kMaxCap is checked at create)
+  const bool small = fe->cap <= 256;
+  const size_t shm = ((small ? sizeof(TrackShared<256>) : sizeof(TrackShared<kMaxCap>)) + 15 & ~(size_t)15) + sizeof(RansacShared);
+  const void *kern = small ? (const void *)track_update_kernel<256> : (const void *)track_update_kernel<kMaxCap>;
   if (!fe->attr_set) {
-    HIP_OK(hipFuncSetAttribute((const void *)track_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    HIP_OK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     fe->attr_set = true;
   }
-  hipLaunchKernelGGL(track_update_kernel, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
+  if (small) hipLaunchKernelGGL(track_update_kernel<256>, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
+  else hipLaunchKernelGGL(track_update_kernel<kMaxCap>, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
+  if (A.prof) {  // (debug only: synchronises)
+    long long h[16];
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      static const char *name[11] = {"load", "compact", "ransac(cur,forw)", "compact", "pnp list", "ransac(pre,forw)", "compact", "counts+rank",
+                                     "inside bits", "greedy", "outputs"};
+      fprintf(stderr, "track_update cycles (sequence 0, publish %d):", publish);
+      const int map[11][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}};
+      for (int k = 0; k < 11; k++) fprintf(stderr, " %s %lld,", name[k], h[map[k][1]] - h[map[k][0]]);
+      fprintf(stderr, " total %lld\n", h[11] - h[0]);
+    }
+  }
   return VIO_OK;
 }
 
