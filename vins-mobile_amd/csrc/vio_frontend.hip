@@ -838,8 +838,16 @@ struct RansacShared {
 // stream; hypotheses are evaluated a batch at a time and then scanned in order with the adaptive iteration bound.
 template <class MaskT>
 __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const float *m2, int count, float thresh,
-                                         double confidence, MaskT *mask) {
+                                         double confidence, MaskT *mask, long long *prof = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  long long pt = prof ? clock64() : 0;
+#define RS_STAMP(k)                                                    \
+  do {                                                                 \
+    if (prof && tid == 0) {                                            \
+      const long long now = clock64();                                 \
+      prof[k] += now - pt, pt = now;                                   \
+    }                                                                  \
+  } while (0)
   const int model_points = 7, max_iters = 1000;
   // findFundamentalMat (fundam.cpp, 3.0.0) runs RANSAC only from 15 points on, LMedS below; the tracker calls with
   // >= 8 points. LMedS shares the subset stream and the 7-point solver: a fixed number of iterations (300 at
@@ -889,7 +897,8 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     if (tid == 0) {
       // the serial part is the RNG stream only: indices go to LDS, the points are gathered by all threads afterwards.
       // x % count without an integer division: q = umulhi(x, floor((2^32 - 1) / count)) underestimates the quotient
-      // by at most 2.
+      // by at most 2. (Pinning the stream to scalar registers -- the 112 dependent steps on the scalar unit -- measured the
+      // same 21 k cycles per call.)
       const unsigned ucount = (unsigned)count, magic = 0xffffffffu / ucount;
       unsigned long long st = S.rng_state;
       for (int h = 0; h < kHypBatch; h++) {
@@ -915,6 +924,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       S.rng_state = st;
     }
     __syncthreads();
+    RS_STAMP(0);
     for (int it = tid; it < kHypBatch * 7; it += nt) {
       const int h = it / 7, i = it - 7 * h, id = S.idx[h][i];
       S.ms1[h][2 * i] = m1[2 * id], S.ms1[h][2 * i + 1] = m1[2 * id + 1];
@@ -940,6 +950,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       }
     }
     __syncthreads();
+    RS_STAMP(1);
     // ---- phase 2: 7-point models, 16 lanes per hypothesis
     for (int h = tid >> 4; h < kHypBatch; h += nt >> 4) {
       int n = 0;
@@ -950,6 +961,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       }
     }
     __syncthreads();
+    RS_STAMP(2);
     // ---- phase 3: inlier counts for every (hypothesis, model) [RANSAC] / median error of every model [LMedS]
     if (lmeds) {
       for (int hk = tid; hk < kHypBatch * 3; hk += nt) {
@@ -973,6 +985,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
         atomicAdd(&S.good[h][k], 1);
     }
     __syncthreads();
+    RS_STAMP(3);
     // ---- phase 4: sequential scan with the adaptive bound
     if (tid == 0) {
       for (int h = 0; h < kHypBatch; h++) {
@@ -1003,6 +1016,8 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       if (S.iter >= S.niters) S.done = 1;
     }
     __syncthreads();
+    RS_STAMP(4);
+    if (prof && tid == 0) prof[6] += 1;
     if (S.done) break;
   }
   if (lmeds && S.min_median < 1.7976931348623157e308 && !S.failed_first) {
@@ -1018,6 +1033,8 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     for (int i = tid; i < count; i += nt) mask[i] = 1;
   }
   __syncthreads();
+  RS_STAMP(5);
+#undef RS_STAMP
 }
 
 // ---- per-sequence tracker update -------------------------------------------------------------------------------
@@ -1139,7 +1156,7 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
     compact_block(T);
     TU_STAMP(2);
     if (T.n >= 8) {  // findFundamentalMat(cur_pts, forw_pts, FM_RANSAC, F_THRESHOLD, 0.99) :194-205
-      fundamental_ransac_block(R, &T.cur[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep);
+      fundamental_ransac_block(R, &T.cur[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep, A.prof && seq == 0 ? A.prof + 16 : nullptr);
       TU_STAMP(3);
       compact_block(T);
     }
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int 
   if (publish) {
     if (T.n >= 8) {  // rejectWithF: (pre_pts, forw_pts) :89-103
       TU_STAMP(5);
-      fundamental_ransac_block(R, &T.pre[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep);
+      fundamental_ransac_block(R, &T.pre[0][0], &T.forw[0][0], T.n, A.f_thresh, A.f_conf, T.keep, A.prof && seq == 0 ? A.prof + 24 : nullptr);
       TU_STAMP(6);
       compact_block(T);
     }
@@ -1788,7 +1805,7 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
   A.f_conf = fe->cfg.f_confidence;
   static const bool tu_prof = getenv("VIO_AMD_TU_PROF") && getenv("VIO_AMD_TU_PROF")[0] == '1';
   static long long *d_prof = nullptr;
-  if (tu_prof && !d_prof) (void)hipMalloc(&d_prof, 16 * sizeof(long long));
+  if (tu_prof && !d_prof) (void)hipMalloc(&d_prof, 32 * sizeof(long long));
   A.prof = tu_prof ? d_prof : nullptr;
   // the smallest LDS layout that holds this tracker's feature slots (fe->cap <= kMaxCap is checked at create)
   const bool small = fe->cap <= 256;
@@ -1798,10 +1815,11 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
     HIP_OK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     fe->attr_set = true;
   }
+  if (A.prof) (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(long long), st);
   if (small) hipLaunchKernelGGL(track_update_kernel<256>, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
   else hipLaunchKernelGGL(track_update_kernel<kMaxCap>, dim3(fe->n_seq), dim3(256), shm, st, A, publish);
   if (A.prof) {  // (debug only: synchronises)
-    long long h[16];
+    long long h[32];
     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
       static const char *name[11] = {"load", "compact", "ransac(cur,forw)", "compact", "pnp list", "ransac(pre,forw)", "compact", "counts+rank",
                                      "inside bits", "greedy", "outputs"};
@@ -1809,6 +1827,9 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
       const int map[11][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {9, 10}, {10, 11}};
       for (int k = 0; k < 11; k++) fprintf(stderr, " %s %lld,", name[k], h[map[k][1]] - h[map[k][0]]);
       fprintf(stderr, " total %lld\n", h[11] - h[0]);
+      for (int c = 0; c < 2; c++)
+        fprintf(stderr, "   ransac call %d: draw %lld, gather+collinear %lld, 7-point %lld, scoring %lld, scan %lld, mask %lld, rounds %lld\n", c,
+                h[16 + 8 * c], h[17 + 8 * c], h[18 + 8 * c], h[19 + 8 * c], h[20 + 8 * c], h[21 + 8 * c], h[22 + 8 * c]);
     }
   }
   return VIO_OK;
