@@ -127,3 +127,34 @@ def test_tracker_bookkeeping():
         else:
             assert len(ids) == 0
     t.close()
+
+
+def test_integer_identities_behind_the_lk_kernel():
+    """The arithmetic shortcuts of csrc/vio_frontend.hip's lk_track_kernel, checked on random operands (numpy, no device):
+    (1) an exact 36-bit sum hi * 2^16 + lo goes to float with ONE rounding whether it passes through a double or is formed
+    as float(hi) * 65536 + float(lo) (both parts and the product are exact floats); (2) the template value folded into the
+    accumulator seed: (a + r - (I << n)) >> n == ((a + r) >> n) - I for the arithmetic shift; (3) |x| < 0.01 in double
+    for a float x is |x| < nextafter(0.01f, 1) in float; (4) the float screen of the convergence test never rejects a
+    displacement the double compare accepts."""
+    rng = np.random.default_rng(11)
+    hi = rng.integers(-(1 << 20) + 1, 1 << 20, 200000)
+    lo = rng.integers(0, 1 << 22, 200000)
+    via_double = (hi.astype(np.float64) * 65536.0 + lo.astype(np.float64)).astype(np.float32)
+    direct = hi.astype(np.float32) * np.float32(65536.0) + lo.astype(np.float32)
+    assert direct.dtype == np.float32 and np.array_equal(via_double, direct)
+    n, r = 9, 1 << 8
+    a = rng.integers(0, 255 * (1 << 14) + 1, 200000).astype(np.int64)
+    iv = rng.integers(0, 8161, 200000).astype(np.int64)
+    assert np.array_equal((a + r - (iv << n)) >> n, ((a + r) >> n) - iv)
+    c = np.float32(0.01)
+    up = np.nextafter(c, np.float32(1))
+    assert float(c) < 0.01 < float(up) and abs(float(up) - 0.010000000707805157) < 1e-18
+    x = np.concatenate([np.array([c, up, np.nextafter(c, np.float32(0)), np.nextafter(up, np.float32(1))], np.float32),
+                        rng.uniform(0.0099, 0.0101, 10000).astype(np.float32)])
+    assert np.array_equal(np.abs(x.astype(np.float64)) < 0.01, np.abs(x) < up)
+    eps_sq = 0.01 * 0.01
+    screen = np.nextafter(np.float32(eps_sq * (1.0 + 1e-5)), np.float32(np.inf))
+    d = rng.uniform(-0.012, 0.012, (200000, 2)).astype(np.float32)
+    fsum = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+    exact = d[:, 0].astype(np.float64) ** 2 + d[:, 1].astype(np.float64) ** 2
+    assert not np.any((fsum > screen) & (exact <= eps_sq))
