@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
           my_max = max(my_max, ordered_bits(v));
           if (xe >= 1 && y >= 1 && xe < cols - 1 && y < rows - 1 && v > 0.f && v == m) {
             const int slot = atomicAdd(&s_ncand, 1);
-            const unsigned idx = (unsigned)(y * cols + xe);
+            const unsigned idx = (unsigned)y << 16 | (unsigned)xe;  // (row-major order like y * cols + x, and no division to take it apart)
             if (slot < kCandLds) s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
           }
         }
@@ -1569,13 +1569,15 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
   const bool in_lds = s_cnt <= kSelLds;
   unsigned long long *K = in_lds ? keys : cand;
   const int nc = in_lds ? s_cnt : total;
+  // One pass over the candidates per round: it suppresses around the corner just taken AND collects the maximum of what
+  // survives (the next corner) -- the first version walked the list twice per round with a barrier in between.
+  unsigned long long mine = 0;  // this thread's largest live key
+  for (int i = tid; i < nc; i += nt) {
+    const unsigned long long k = K[i];
+    mine = k > mine ? k : mine;
+  }
   for (int round = 0; round < want; round++) {
-    unsigned long long best = 0;
-    for (int i = tid; i < nc; i += nt) {
-      unsigned long long k = K[i];
-      best = k > best ? k : best;
-    }
-    best = wave_max_u64(best);
+    unsigned long long best = wave_max_u64(mine);
     if ((tid & 63) == 0) red[tid >> 6] = best;
     __syncthreads();
     best = red[0];
@@ -1583,26 +1585,30 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
     __syncthreads();
     if (best == 0) break;
     const unsigned bidx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
-    const int bx = bidx % P.cols, by = bidx / P.cols;
+    const int bx = bidx & 0xffffu, by = bidx >> 16;
     if (tid == 0) {
       int p = s_n++;
       forw_pts[(base + p) * 2] = (float)bx, forw_pts[(base + p) * 2 + 1] = (float)by;
       ids[base + p] = -1, track_cnt[base + p] = 1;  // addPoints :36-48
     }
+    mine = 0;
     if (P.min_dist >= 1.f) {
       for (int i = tid; i < nc; i += nt) {
-        unsigned long long c = K[i];
+        const unsigned long long c = K[i];
         if (c) {
-          unsigned idx = 0xffffffffu - (unsigned)(c & 0xffffffffu);
-          float dx = (float)((int)(idx % P.cols) - bx), dy = (float)((int)(idx / P.cols) - by);
+          const unsigned idx = 0xffffffffu - (unsigned)(c & 0xffffffffu);
+          const float dx = (float)((int)(idx & 0xffffu) - bx), dy = (float)((int)(idx >> 16) - by);
           if (dx * dx + dy * dy < md2) K[i] = 0;
+          else mine = c > mine ? c : mine;
         }
       }
     } else {
-      for (int i = tid; i < nc; i += nt)
-        if (K[i] == best) K[i] = 0;
+      for (int i = tid; i < nc; i += nt) {
+        const unsigned long long c = K[i];
+        if (c == best) K[i] = 0;
+        else mine = c > mine ? c : mine;
+      }
     }
-    __syncthreads();
   }
   __syncthreads();
   n = s_n;
@@ -1911,7 +1917,8 @@ extern "C" {
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out) {
   if (!cfg || !out || n_seq < 1) return VIO_EINVAL;
   if (cfg->lk_win != kWin || cfg->lk_levels < 0 || cfg->lk_levels >= kMaxLevels || cfg->max_corners < 1 ||
-      cfg->max_corners > kMaxCap || cfg->image_rows < 32 || cfg->image_cols < 32 || cfg->min_dist < 0 || cfg->min_dist > kMaxRadius)
+      cfg->max_corners > kMaxCap || cfg->image_rows < 32 || cfg->image_cols < 32 || cfg->min_dist < 0 || cfg->min_dist > kMaxRadius ||
+      cfg->image_rows > 32767 || cfg->image_cols > 65535)  // (corner candidates carry their position as y << 16 | x)
     return VIO_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
