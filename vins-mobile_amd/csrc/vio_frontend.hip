@@ -867,7 +867,11 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
   __syncthreads();
   const float t = thresh * thresh;
   while (true) {
-    // ---- phase 1: draw the next kHypBatch subsets sequentially (one RNG stream). The draws are cheap integer
+    // hypotheses of this round. The adaptive bound usually ends a RANSAC call within its first handful of hypotheses (inlier
+    // ratio 0.9: 7 iterations), and every hypothesis of a round is drawn, solved and scored whether the scan reaches it or
+    // not: the first round takes 8, later rounds (and LMedS, whose iteration count is fixed) kHypBatch.
+    const int nb = (!lmeds && S.iter == 0) ? 8 : kHypBatch;
+    // ---- phase 1: draw the next nb subsets sequentially (one RNG stream). The draws are cheap integer
     //      work; checkSubset (collinearity, 2 x 15 cross products in double) is evaluated in parallel afterwards.
     //      Subsets are drawn speculatively as if every check passed, which is the same RNG consumption; if one fails
     //      (rare) the tail from that hypothesis is redrawn with the full serial semantics.
@@ -901,7 +905,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
       // same 21 k cycles per call.)
       const unsigned ucount = (unsigned)count, magic = 0xffffffffu / ucount;
       unsigned long long st = S.rng_state;
-      for (int h = 0; h < kHypBatch; h++) {
+      for (int h = 0; h < nb; h++) {
         S.rng_before[h] = st;
         int idx[7];
 #pragma unroll
@@ -925,24 +929,24 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     }
     __syncthreads();
     RS_STAMP(0);
-    for (int it = tid; it < kHypBatch * 7; it += nt) {
+    for (int it = tid; it < nb * 7; it += nt) {
       const int h = it / 7, i = it - 7 * h, id = S.idx[h][i];
       S.ms1[h][2 * i] = m1[2 * id], S.ms1[h][2 * i + 1] = m1[2 * id + 1];
       S.ms2[h][2 * i] = m2[2 * id], S.ms2[h][2 * i + 1] = m2[2 * id + 1];
     }
     __syncthreads();
-    if (tid < kHypBatch) S.coll[tid] = (have_collinear_dev(S.ms1[tid], 7) || have_collinear_dev(S.ms2[tid], 7)) ? 1 : 0;
+    if (tid < nb) S.coll[tid] = (have_collinear_dev(S.ms1[tid], 7) || have_collinear_dev(S.ms2[tid], 7)) ? 1 : 0;
     __syncthreads();
     if (tid == 0) {
       int first = -1;
-      for (int h = 0; h < kHypBatch && first < 0; h++)
+      for (int h = 0; h < nb && first < 0; h++)
         if (S.coll[h]) first = h;
       if (first >= 0) {
         unsigned long long st = S.rng_before[first];
-        for (int h = first; h < kHypBatch; h++) {
+        for (int h = first; h < nb; h++) {
           S.valid[h] = draw(st, h, true);
           if (!S.valid[h]) {
-            for (int hh = h + 1; hh < kHypBatch; hh++) S.valid[hh] = 0;
+            for (int hh = h + 1; hh < nb; hh++) S.valid[hh] = 0;
             break;
           }
         }
@@ -952,7 +956,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     __syncthreads();
     RS_STAMP(1);
     // ---- phase 2: 7-point models, 16 lanes per hypothesis
-    for (int h = tid >> 4; h < kHypBatch; h += nt >> 4) {
+    for (int h = tid >> 4; h < nb; h += nt >> 4) {
       int n = 0;
       if (S.valid[h]) n = run7point_group(S.ms1[h], S.ms2[h], S.F[h], S.work[h], tid & 15);
       if ((tid & 15) == 0) {
@@ -964,7 +968,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     RS_STAMP(2);
     // ---- phase 3: inlier counts for every (hypothesis, model) [RANSAC] / median error of every model [LMedS]
     if (lmeds) {
-      for (int hk = tid; hk < kHypBatch * 3; hk += nt) {
+      for (int hk = tid; hk < nb * 3; hk += nt) {
         const int h = hk / 3, k = hk - 3 * h;
         if (k >= S.nmodels[h]) continue;
         int bits[14];  // count <= 14; std::sort on the float bit patterns as ints (ptsetreg.cpp)
@@ -978,7 +982,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
                                   : (double)(__int_as_float(bits[count / 2 - 1]) + __int_as_float(bits[count / 2])) * 0.5;
       }
     } else
-    for (int item = tid; item < kHypBatch * 3 * count; item += nt) {
+    for (int item = tid; item < nb * 3 * count; item += nt) {
       int hk = item / count, i = item - hk * count;
       int h = hk / 3, k = hk - 3 * h;
       if (k < S.nmodels[h] && epipolar_inlier(S.F[h] + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1], t))
@@ -988,7 +992,7 @@ __device__ void fundamental_ransac_block(RansacShared &S, const float *m1, const
     RS_STAMP(3);
     // ---- phase 4: sequential scan with the adaptive bound
     if (tid == 0) {
-      for (int h = 0; h < kHypBatch; h++) {
+      for (int h = 0; h < nb; h++) {
         if (S.iter >= S.niters) { S.done = 1; break; }
         if (!S.valid[h]) {
           if (S.iter == 0) S.failed_first = 1;
