@@ -526,7 +526,7 @@ def end_to_end_full(n_seq):
     app's FREQ = 3, every third camera frame published."""
     run = lambda n, frames, overlap, freq, env=None: _tool(
         "import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %d, quiet=True, freq=%d)))" % (n, frames, overlap, freq), env)
-    every, twice, sync_submit, serial, app = run(n_seq, 28, 2, 1), run(2 * n_seq, 26, 2, 1), run(n_seq, 22, 1, 1), run(n_seq, 22, 0, 1), run(n_seq, 20, 2, 3)
+    every, twice, sync_submit, serial, app = run(n_seq, 44, 2, 1), run(2 * n_seq, 34, 2, 1), run(n_seq, 22, 1, 1), run(n_seq, 22, 0, 1), run(n_seq, 20, 2, 3)   # (the headline legs time ~30 / ~20 frames: one host hiccup of 10 ms in 15 frames moved the mean by 15 %)
     host_lists = run(n_seq, 22, 1, 1, {"VIO_AMD_RESIDENT": "0", "VIO_AMD_HOST_THREADS": "64"})
     return {"value": every["camera_frames_per_s"], "unit": "camera frames/s, every frame published and solved", "sequences": n_seq,
             "path": "pageable frames in -> vio_frontend_submit_images_async (gather to page-locked memory, H2D, kernels and the D2H "
