@@ -1332,7 +1332,7 @@ constexpr int kDetR = 32;      // output rows per strip
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));  // (bound_ctrl: an edge lane reads 0 without a zero-initialised destination)
 }
 #define LANE_LEFT(v) dpp_f32<0x138>(v)   /* wave_shr:1 -> value of lane - 1 */
 #define LANE_RIGHT(v) dpp_f32<0x130>(v)  /* wave_shl:1 -> value of lane + 1 */
