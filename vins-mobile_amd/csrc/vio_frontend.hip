@@ -1130,8 +1130,10 @@ __device__ void compact_block(TrackShared<CAP> &T) {
 }
 
 // One workgroup per sequence: everything between the LK call and goodFeaturesToTrack.
+// (two waves per SIMD: left to itself the compiler takes 289 registers per work-item for the double-precision 7-point code --
+// ONE wave per SIMD, one workgroup per CU, and the 512 sequences of the bench ran as two rounds of 256 workgroups)
 template <int CAP>
-__global__ __launch_bounds__(256) void track_update_kernel(TrackerArrays A, int publish) {
+__global__ __launch_bounds__(256, 2) void track_update_kernel(TrackerArrays A, int publish) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   TrackShared<CAP> &T = *reinterpret_cast<TrackShared<CAP> *>(smem_raw);
   RansacShared &R = *reinterpret_cast<RansacShared *>(smem_raw + ((sizeof(TrackShared<CAP>) + 15) & ~(size_t)15));
