@@ -274,7 +274,10 @@ typedef struct VioTrackViz { /* good_pts / track_len (UI only), optional */
   int32_t n;
 } VioTrackViz;
 
-/* n_seq independent trackers (sequences) share one context and one launch.   */
+/* n_seq independent trackers (sequences) share one context and one launch.
+ * VIO_EINVAL for configurations the kernels are not laid out for: lk_win != 21,
+ * more than 512 corners, images below 32 x 32 or above 32767 rows / 65535
+ * columns (corner candidates carry their position as y << 16 | x).            */
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out);
 int vio_frontend_get_device(const vio_frontend_t *fe, int32_t *device);
 void vio_frontend_destroy(vio_frontend_t *fe);
