@@ -67,7 +67,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WT, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -85,7 +85,6 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_Mr = o, o += (size_t)d.Wcap * 15;
   s.s_prJT = o, o += (size_t)d.Ncap;  // b0 = J0^T r0
   s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
-  s.s_WT = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
   s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
   s.s_sfact = o, o += (slot_capacity(d) + 1) / 2;  // ints: staging slot -> factor
@@ -209,7 +208,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   double *sc = B.scratch + b * B.s.scratch;
   v.imu_info = sc + B.s.s_info, v.imu_aug = sc + B.s.s_aug, v.imu_J = sc + B.s.s_J, v.imu_M = sc + B.s.s_M;
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
-  v.WT = sc + B.s.s_WT, v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
+  v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
   v.srec_i = reinterpret_cast<int *>(sc + B.s.s_srec_i), v.srec_d = sc + B.s.s_srec_d;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.stash = sc + B.s.s_stash;

@@ -426,8 +426,14 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
   VIO_PARFOR(q, (int)tri_doubles(pos)) m.Am[q] = 0.0;
   VIO_PARFOR(q, pos) m.bm[q] = 0.0;
   VIO_PARFOR(f, F) m.hff[f] = 0.0, m.gf[f] = 0.0;
-  const int n6 = 6 * (P + 1);  // WT row groups: poses 0..P-1 at 6 i, extrinsic at 6 P
-  if (flag == 0) VIO_PARFOR(q, n6 * v.Fpad) v.WT[q] = 0.0;
+  // The landmark coupling of this phase lives in the solver's feature-major W (v.WTf [F][n6cap], column groups: pose i at
+  // 6 i, the extrinsic at 6 P where the solver keeps the relocalization pose): every factor of a landmark hosted at frame 0
+  // is re-evaluated below and overwrites its (landmark, target frame) entries, the host and extrinsic groups accumulate and
+  // are zeroed here; rows of landmarks hosted elsewhere keep the solver's (finite) values and drop out through 1 / E_f = 0.
+  if (flag == 0) VIO_PARFOR(q, 12 * F) {
+    const int f = q / 12, c = q - 12 * f;
+    v.WTf[(size_t)f * v.n6cap + (c < 6 ? c : 6 * P + c - 6)] = 0.0;
+  }
   VIO_SYNC();
   // ---- prior as a factor (MarginalizationFactor evaluated at the current state) ------------------------
   if (pn > 0) {
@@ -446,12 +452,22 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
     VIO_SYNC();
     dense_matvec_cols(cx, v.prH0, pn, m.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(m.prr + i, sacc); });
     {
-      const int tid_ = VIO_TID(cx), kLanes = (int)cx.nt < 64 ? (int)cx.nt : 64, lane = tid_ % kLanes, nwv = (int)cx.nt / kLanes;  // (host emulation: one thread)
-      for (int a = tid_ / kLanes; a < pn; a += nwv) {
+      // H0 into the dense matrix through the column map: (row, strip of columns) items, every load of an item in flight
+      // before its first store (a rolled element loop pays an L2 round trip per element)
+      constexpr int kU = 12;
+      const int nst = (pn + kU - 1) / kU;
+      VIO_PARFOR(q, pn * nst) {
+        const int a = q / nst, b0 = kU * (q - a * nst);
         const int ca = m.pcol[a];
-        for (int b = lane; b < pn; b += kLanes) {
-          const int cb = m.pcol[b];
-          if (ca >= cb) m.Am[tri_at(ca, cb)] = v.prH0[a * pn + b];
+        double x[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) x[u] = v.prH0[a * pn + (b0 + u < pn ? b0 + u : b0)];
+        VIO_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+          if (b0 + u >= pn) continue;
+          const int cb = m.pcol[b0 + u];
+          if (ca >= cb) m.Am[tri_at(ca, cb)] = x[u];
         }
       }
     }
@@ -510,24 +526,32 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
       if (cx.tid == 0) out.n[0] = -3, out.n[1] = 0;
       return;
     }
-    double fw0[6] = {0, 0, 0, 0, 0, 0}, fwx[6] = {0, 0, 0, 0, 0, 0}, fe = 0, fgf = 0;
-    bool ftouched = false;
-    const bool one_thread_per_feature = F <= (int)cx.nt;
     // dense-matrix add, lower triangle only
     auto add_lower = [&](int ra, int ca, double val) {
       if (ra >= ca) VIO_ATOMIC_ADD(m.Am + tri_at(ra, ca), val);
       else VIO_ATOMIC_ADD(m.Am + tri_at(ca, ra), val);
     };
+    // bucket descriptors (0, t): one per lane, fetched once (a dependent global round trip per Gram round otherwise)
+    const int lane_d = VIO_TID(cx) & 63;
+    const bool dv = lane_d < nb0;
+    const int d_s0 = dv ? v.pair_s0[lane_d] : 0, d_s1 = dv ? v.pair_s1[lane_d] : 0;
+    const int d_t = dv ? ((v.pair_h[lane_d] != 0 || v.pair_t[lane_d] == P) ? -1 : v.pair_t[lane_d]) : -1;
     for (int c0 = 0; c0 < S0; c0 += CH) {
-      // (the factors hosted at frame 0 occupy the staging slots [0, S0): one pass over the chunk's slots, not over all
-      // M factors per chunk -- every pass costs a global round trip for the index arrays)
+      // The factors hosted at frame 0 occupy the staging slots [0, S0) of the solver's slot order: the slot records built
+      // at the start of the solve (srec_i / srec_d) give host | target | landmark and the observation pair in ONE global
+      // round trip per pass (factor index -> target / landmark / points were three dependent ones). The per-landmark sums
+      // (H_ff, g_f in LDS; the host and extrinsic coupling in the window's W) are gathered by the factor threads
+      // themselves with atomics, like in the solver: no second pass over the landmarks' factor lists.
       VIO_PARFOR(slot, (S0 - c0 < CH ? S0 - c0 : CH)) {
-        const int k = v.sfact[c0 + slot];
-        if (k < 0) continue;
-        const int t = v.ftarget[k], f = v.ffeat[k];
+        const int rec = v.srec_i[c0 + slot];
+        double pij[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(c0 + slot) + c];
+        if (rec < 0) continue;
+        const int t = (rec >> 8) & 255, f = rec >> 16;
+        if ((rec & 255) != 0 || t == P) continue;
         double r[2], Ji[12], Jj[12], Jex[12], Jl[2];
-        projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], v.pts_i + 3 * k, v.pts_j + 3 * k, true, r, Ji, Jj,
-                        Jex, Jl);
+        projection_eval(v.s_info, xpose, xpose + 7 * t, ex, xfeat[f], pij, pij + 3, true, r, Ji, Jj, Jex, Jl);
         double sq = r[0] * r[0] + r[1] * r[1];
         double sr = sqrt(1.0 / (1.0 + sq * cc));
         auto g = G + slot * kMargSlot; auto gx = g + kSlotStride;
@@ -540,9 +564,16 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
           }
           g[rr * kRowLen + 12] = r[rr] * sr, g[rr * kRowLen + 13] = Jl[rr] * sr;
         }
+        const double s2 = sr * sr;
+        double *wf = v.WTf + (size_t)f * v.n6cap;
 #pragma unroll
-        for (int c = 0; c < 6; c++)  // target-frame coupling: one writer per (feature, frame)
-          v.WT[(6 * t + c) * v.Fpad + f] = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * (sr * sr);
+        for (int c = 0; c < 6; c++) {
+          wf[6 * t + c] = (Jj[c] * Jl[0] + Jj[6 + c] * Jl[1]) * s2;  // target-frame coupling: one writer per (feature, frame)
+          VIO_ATOMIC_ADD(wf + c, (Ji[c] * Jl[0] + Ji[6 + c] * Jl[1]) * s2);
+          VIO_ATOMIC_ADD(wf + 6 * P + c, (Jex[c] * Jl[0] + Jex[6 + c] * Jl[1]) * s2);
+        }
+        VIO_ATOMIC_ADD(m.hff + f, (Jl[0] * Jl[0] + Jl[1] * Jl[1]) * s2);
+        VIO_ATOMIC_ADD(m.gf + f, (Jl[0] * r[0] + Jl[1] * r[1]) * s2);
       }
       VIO_SYNC();
       stamp(cx, ST_M_FACT);
@@ -570,77 +601,70 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
         if (row < 6 && col <= row) VIO_ATOMIC_ADD(m.Am + tri_at(m.col_ex[0] + row, m.col_ex[0] + col), val);
       };
       {
-        const int wave = cx.tid >> 6, nw = cx.nt >> 6, lane = cx.tid & 63;
+        const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
         const int li = lane & 15, kq = lane >> 4;
-        for (int p = wave; p < nb0; p += nw) {
-          if (v.pair_h[p] != 0 || v.pair_t[p] == P) continue;
-          int s_lo = v.pair_s0[p] > c0 ? v.pair_s0[p] : c0, s_hi = v.pair_s1[p] < c0 + CH ? v.pair_s1[p] : c0 + CH;
+        for (int p = wave; p < nb0 && p < 64; p += nw) {
+          const int b_s0 = __builtin_amdgcn_readlane(d_s0, p), b_s1 = __builtin_amdgcn_readlane(d_s1, p);
+          const int t = __builtin_amdgcn_readlane(d_t, p);
+          if (t < 0) continue;
+          const int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
           if (s_lo >= s_hi) continue;
           v4d a1 = {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1;
           const bool lv = li < kRowLen, lx = li < kMargRowX;
-          auto g = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
-          auto gx = G + (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
-          for (int sl = s_lo; sl < s_hi; sl += 2, g += 2 * kMargSlot, gx += 2 * kMargSlot) {
-            const bool in = sl + (kq >> 1) < s_hi;  // odd tail: the second factor of the step does not exist
-            double a = G[in ? (int)(g - G) : 0], x = G[in ? (int)(gx - G) : 0];
-            a = (lv && in) ? a : 0.0, x = (lx && in) ? x : 0.0;
-            a1 = mfma_f64(a, a, a1), a2 = mfma_f64(x, a, a2), a3 = mfma_f64(x, x, a3);
+          const int go = (s_lo - c0 + (kq >> 1)) * kMargSlot + (kq & 1) * kRowLen + (lv ? li : 0);
+          const int gxo = (s_lo - c0 + (kq >> 1)) * kMargSlot + kSlotStride + (kq & 1) * kMargRowX + (lx ? li : 0);
+          const int nsteps = (s_hi - s_lo + 1) >> 1;
+          constexpr int kB = 6;  // two-factor steps whose operands are fetched together
+          for (int st0 = 0; st0 < nsteps; st0 += kB) {
+            double av[kB], xv[kB];
+#pragma unroll
+            for (int j = 0; j < kB; j++) {
+              const bool in = st0 + j < nsteps && s_lo + 2 * (st0 + j) + (kq >> 1) < s_hi;  // odd tail: no second factor
+              av[j] = G[in ? go + 2 * (st0 + j) * kMargSlot : 0], xv[j] = G[in ? gxo + 2 * (st0 + j) * kMargSlot : 0];
+            }
+            VIO_SCHED_FENCE();
+#pragma unroll
+            for (int j = 0; j < kB; j++) {
+              const bool in = st0 + j < nsteps && s_lo + 2 * (st0 + j) + (kq >> 1) < s_hi;
+              const double a = (lv && in) ? av[j] : 0.0, x = (lx && in) ? xv[j] : 0.0;
+              if (st0 + j < nsteps) a1 = mfma_f64(a, a, a1), a2 = mfma_f64(x, a, a2), a3 = mfma_f64(x, x, a3);  // (uniform)
+            }
           }
-          const int t = v.pair_t[p];
 #pragma unroll
           for (int r4 = 0; r4 < 4; r4++) {
             flush1(t, kq + 4 * r4, li, a1[r4]), flush2(t, kq + 4 * r4, li, a2[r4]), flush3(kq + 4 * r4, li, a3[r4]);
           }
         }
       }
-      stamp(cx, ST_M_GRAM);
-      // per-feature sums: host coupling, extrinsic coupling, H_ff, g_f
-      VIO_PARFOR(f, F) {
-        double w0[6] = {0, 0, 0, 0, 0, 0}, wx[6] = {0, 0, 0, 0, 0, 0}, e = 0, gf = 0;
-        bool touched = false;
-        for (int k = v.fstart[f]; k < v.fstart[f + 1]; k++) {
-          if (v.fhost[k] != 0 || v.ftarget[k] == P) continue;
-          const int slot = v.fslot[k] - c0;
-          if (slot < 0 || slot >= CH) continue;
-          touched = true;
-          auto g = G + slot * kMargSlot; auto gx = g + kSlotStride;
-#pragma unroll
-          for (int rr = 0; rr < 2; rr++) {
-            double jl = g[rr * kRowLen + 13];
-#pragma unroll
-            for (int c = 0; c < 6; c++) w0[c] += g[rr * kRowLen + c] * jl, wx[c] += gx[rr * kMargRowX + c] * jl;
-            e += jl * jl, gf += jl * g[rr * kRowLen + 12];
-          }
-        }
-        if (!touched) continue;
-        if (one_thread_per_feature) {
-          ftouched = true, fe += e, fgf += gf;
-#pragma unroll
-          for (int c = 0; c < 6; c++) fw0[c] += w0[c], fwx[c] += wx[c];
-        } else {
-          m.hff[f] += e, m.gf[f] += gf;
-#pragma unroll
-          for (int c = 0; c < 6; c++) v.WT[c * v.Fpad + f] += w0[c], v.WT[(6 * P + c) * v.Fpad + f] += wx[c];
-        }
-      }
       VIO_SYNC();
+      stamp(cx, ST_M_GRAM);
     }
-    if (one_thread_per_feature && (int)cx.tid < F && ftouched) {
-      const int f = cx.tid;
-      m.hff[f] = fe, m.gf[f] = fgf;
-#pragma unroll
-      for (int c = 0; c < 6; c++) v.WT[c * v.Fpad + f] = fw0[c], v.WT[(6 * P + c) * v.Fpad + f] = fwx[c];
-    }
-    VIO_SYNC();
     // ---- eliminate the landmarks hosted at frame 0 (pseudo-inverse: e <= eps contributes nothing) --------
-    VIO_PARFOR(f, F) m.einv[f] = m.hff[f] > 1e-8 ? 1.0 / m.hff[f] : 0.0;
+    VIO_PARFOR(f, F) {
+      const double ei = m.hff[f] > 1e-8 ? 1.0 / m.hff[f] : 0.0;
+      m.einv[f] = ei, m.gf[f] *= ei;  // g_f / E_f
+    }
     VIO_SYNC();
-    // pose-type groups: g in [0, P] -> (WT row base 6 g, dense column base)
-    const int ng = P + 1;
-    {
-      // (W E^-1) W^T over the pose-type index space as a GEMM on the matrix cores, like the solver's Schur term
-      const int n6m = 6 * ng, T = (n6m + 15) / 16, npairs_t = T * (T + 1) / 2;
-      const int wave = cx.tid >> 6, lane = cx.tid & 63, nw = cx.nt >> 6;
+    // pose-type groups: g in [0, P] -> (W column base 6 g, dense column base). (W E^-1) W^T over that index space on the
+    // matrix cores, the solver's K-split product (solver_core.h); its tiles scatter into the dense matrix by group.
+    const int ng = P + 1, n6m = 6 * ng;
+    auto dense_col = [&](int a) {
+      const int ga = a / 6, ca = ga == P ? m.col_ex[0] : m.col_pose[ga];
+      return ca < 0 ? -1 : ca + a - 6 * ga;
+    };
+    if (n6m <= 80) {
+      schur_ksplit5(cx, v.WTf, v.n6cap, n6m, F, m.einv, m.gf,
+                    [&](int arow, int bcol, double val) {
+                      const int rr = dense_col(arow), cc2 = dense_col(bcol);
+                      if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -val);
+                    },
+                    [&](int a, double val) {
+                      const int rr = dense_col(a);
+                      if (rr >= 0) VIO_ATOMIC_ADD(m.bm + rr, -val);
+                    });
+    } else {
+      const int T = (n6m + 15) / 16, npairs_t = T * (T + 1) / 2;
+      const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
       const int li = lane & 15, kq = lane >> 4;
       const int ksteps = (F + 3) / 4;
       for (int p = wave; p < npairs_t; p += nw) {
@@ -649,41 +673,51 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
         const int tj = p - ti * (ti + 1) / 2;
         const int ra = 16 * ti + li, rb = 16 * tj + li;
         const bool va = ra < n6m, vb = rb < n6m;
-        const double *pa = v.WT + (size_t)(va ? ra : 0) * v.Fpad, *pb = v.WT + (size_t)(vb ? rb : 0) * v.Fpad;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int st = 0; st < ksteps; st++) {
-          int f = 4 * st + kq;
-          bool vf = f < F;
-          int fc = vf ? f : 0;
-          double a = pa[fc] * m.einv[fc], b = pb[fc];
-          a = (va && vf) ? a : 0.0, b = (vb && vf) ? b : 0.0;
-          acc = mfma_f64(a, b, acc);
+        const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
+        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        constexpr int kChunk = 12;  // k-steps whose operands are fetched together
+        for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
+          double av[kChunk], bv[kChunk], ev[kChunk];
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) {
+            const int f = 4 * (s0 + j) + kq;
+            const int fc = (f < F && s0 + j < ksteps) ? f : 0;
+            av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = m.einv[fc];
+          }
+          VIO_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) {
+            const int f = 4 * (s0 + j) + kq;
+            const bool vf = f < F && s0 + j < ksteps;
+            av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
         }
+        acc += acc1;
         const int bcol = 16 * tj + li;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-          int arow = 16 * ti + kq + 4 * r4;
+        for (int r4 = 0; r4 < 4; r4++) {  // (one wave per tile)
+          const int arow = 16 * ti + kq + 4 * r4;
           if (arow < n6m && bcol < n6m && bcol <= arow) {
-            int ga = arow / 6, gb = bcol / 6;
-            int ca = ga == P ? m.col_ex[0] : m.col_pose[ga], cb = gb == P ? m.col_ex[0] : m.col_pose[gb];
-            if (ca >= 0 && cb >= 0) {
-              int rr = ca + arow % 6, cc2 = cb + bcol % 6;
-              if (rr >= cc2) m.Am[tri_at(rr, cc2)] -= acc[r4];
-              else m.Am[tri_at(cc2, rr)] -= acc[r4];
-            }
+            const int rr = dense_col(arow), cc2 = dense_col(bcol);
+            if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -acc[r4]);
           }
         }
       }
-    }
-    VIO_PARFOR(a, 6 * ng) {
-      int ga = a / 6;
-      int ca = ga == P ? m.col_ex[0] : m.col_pose[ga];
-      if (ca < 0) continue;
-      const double *wa = v.WT + a * v.Fpad;
-      double s = 0;
-      for (int f = 0; f < F; f++) s += wa[f] * m.gf[f] * m.einv[f];
-      m.bm[ca + a % 6] -= s;
+      // b -= W (g_f / E_f): (pose-type index, feature chunk) items, one fetch batch each
+      const int nch = (F + kWStrip - 1) / kWStrip, chunk = kWStrip;
+      VIO_PARFOR(q, n6m * nch) {
+        const int ch = q / n6m, a = q - ch * n6m;
+        const int f0 = ch * chunk, nb = F - f0 < chunk ? F - f0 : chunk;
+        const int rr = dense_col(a);
+        if (rr < 0 || nb <= 0) continue;
+        double x[kWStrip], sacc = 0;
+        wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);
+#pragma unroll
+        for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * m.gf[f0 + (j < nb ? j : 0)];
+        VIO_ATOMIC_ADD(m.bm + rr, -sacc);
+      }
     }
     VIO_SYNC();
   }

@@ -168,8 +168,8 @@ VIO_DEV void stamp(const Ctx &cx, int stage) {
 struct WinView {
   int W, P, F, M, np, nblk, has_loop, loop_frame, marg_flag, max_iter;
   int prior_n, prior_nb;
-  int Fpad;      // leading dimension of WT (F rounded up to a multiple of 8)
-  int npose6;    // 6 * (P + has_loop): rows of WT
+  int Fpad;      // F rounded up to a multiple of 8
+  int npose6;    // 6 * (P + has_loop)
   double s_info, gravity, cauchy_b;
   const double *pose0, *sb0, *ex, *feat0;
   const int *fhost, *ftarget, *ffeat;
@@ -197,8 +197,8 @@ struct WinView {
                      //          written once by setup_prior; the IMU part of that coupling lives in LDS (WorkT::AspI)
   int n6, nrows, nT, jp;  // pose unknowns 6 (P + has_loop); rows of the pose matrix (n6 + the carried right-hand side);
                           // its 16-row tiles; leading dimension of Asp rows (16 nT)
-  double *WT;        // [npose6][Fpad]  pose-major landmark coupling: the marginalization phase only (marg_core.h)
-  double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the solver's only copy)
+  double *WTf;       // [F][n6cap]      H_fp feature-major: row = feature, col = 6*frame + c (the marginalization phase reuses it
+                     //                 with the extrinsic in the column group of the relocalization pose, marg_core.h)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   int *srec_i;       // staging slot -> host | target << 8 | landmark << 16 (-1: unused slot), built once per solve: the factor
   double *srec_d;    // data in SLOT order ([slot][6] = pts_i, pts_j), one global round trip per evaluation pass instead of two
@@ -1664,16 +1664,18 @@ VIO_DEV double pose_gd(const WK &w, int i) {
 // (dogleg_strategy.cc:172-192); the first two versions evaluated it after the factorization through L, which forced the
 // fill of the factor to be kept. Uses w.t1 (u_p, frame-major), w.xt (u_p by pose index) and w.tf as scratch.
 template <class WK>
-VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf) {
+VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf, bool prepared = false) {
   const int np = v.np, F = v.F, n6 = v.n6, P = v.P;
-  VIO_PARFOR(f, F) w.tf[f] = 0.0;
-  VIO_PARFOR(i, np) {
-    const int f = i / kBS, c = i - f * kBS;
-    const double u = w.sp[i] * vp[i];
-    w.t1[i] = u;
-    if (c < 6) w.xt[6 * f + c] = u;
+  if (!prepared) {  // (prepared: the caller's pass that formed vp also left t1 / xt / tf = 0 behind, barrier included)
+    VIO_PARFOR(f, F) w.tf[f] = 0.0;
+    VIO_PARFOR(i, np) {
+      const int f = i / kBS, c = i - f * kBS;
+      const double u = w.sp[i] * vp[i];
+      w.t1[i] = u;
+      if (c < 6) w.xt[6 * f + c] = u;
+    }
+    VIO_SYNC();
   }
-  VIO_SYNC();
   int nparts, per;
   wt_parts((int)cx.nt, F, n6, nparts, per);
   VIO_PARFOR(q, F * nparts) {  // (W^T u_p)_f += sum_{a in part} W[f][a] u_p[a]
@@ -1750,6 +1752,75 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
   return block_sum(cx, acc);
 }
 
+// C = (W E^-1) W^T (lower 16 x 16 tiles) and c = W (g / E) for a feature-major coupling matrix Wf [F][ldw] with n6 <= 80
+// pose-type indices, K-split on the matrix cores: every wave owns a slice of the features and forms ALL lower tiles from it.
+// A and B operands are the same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one
+// latency) feeding 75 matrix instructions; the partial results of the waves meet through the callers' atomic adds:
+// flush_tile(row, col <= row, value), flush_rhs(index, value). ge = g_f / E_f.
+template <class FT, class FR>
+VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, cldsd ge, FT flush_tile,
+                           FR flush_rhs) {
+  constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
+  const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int ksteps = (F + 3) / 4;
+  const int ksw = (ksteps + nw - 1) / nw;
+  const int s_begin = wave * ksw, s_end = s_begin + ksw < ksteps ? s_begin + ksw : ksteps;
+  v4d acc[kT * (kT + 1) / 2];
+  double rp[kT];  // the same fetch also yields this slice's part of W (g_f / E_f)
+#pragma unroll
+  for (int q = 0; q < kT * (kT + 1) / 2; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < kT; t++) rp[t] = 0.0;
+  for (int s0 = s_begin; s0 < s_end; s0 += 5) {
+    double wv[5][kT], ev[5], gv[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int f = 4 * (s0 + j) + kq;
+      const int fc = (s0 + j < s_end && f < F) ? f : 0;
+      ev[j] = einv[fc], gv[j] = ge[fc];
+#pragma unroll
+      for (int t = 0; t < kT; t++) {
+        const int col = 16 * t + li;
+        wv[j][t] = Wf[(size_t)fc * ldw + (col < n6 ? col : 0)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int f = 4 * (s0 + j) + kq;
+      const bool vf = s0 + j < s_end && f < F;
+#pragma unroll
+      for (int t = 0; t < kT; t++) {
+        wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
+        rp[t] = fma(wv[j][t], gv[j], rp[t]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < kT; ti++) {
+        const double a = wv[j][ti] * ev[j];
+#pragma unroll
+        for (int tj = 0; tj <= ti; tj++) acc[ti * (ti + 1) / 2 + tj] = mfma_f64(a, wv[j][tj], acc[ti * (ti + 1) / 2 + tj]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < kT; ti++)
+#pragma unroll
+    for (int tj = 0; tj <= ti; tj++) {
+      const int bcol = 16 * tj + li;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int arow = 16 * ti + kq + 4 * r;
+        if (arow < n6 && bcol <= arow) flush_tile(arow, bcol, acc[ti * (ti + 1) / 2 + tj][r]);
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < kT; t++) {
+    const int a = 16 * t + li;
+    if (a < n6 && rp[t] != 0.0) flush_rhs(a, rp[t]);
+  }
+}
+
 // In place: (H + mu C) on the diagonals, then the landmark Schur term  App -= (W E^-1) W^T  and the right-hand side row
 // App[n6][:] = g_p - W (g_f / E_f). Returns false if some E_f <= 0.
 template <class WK>
@@ -1790,64 +1861,9 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     const int ksteps = (F + 3) / 4;
     constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
     if (T <= kT) {
-      // K-split: every wave owns a slice of the features and forms ALL lower tiles from it. A and B operands are the
-      // same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one latency) feeding
-      // 75 matrix instructions; the partial results of the waves meet in the matrix through LDS atomics.
-      const int ksw = (ksteps + nw - 1) / nw;
-      const int s_begin = wave * ksw, s_end = s_begin + ksw < ksteps ? s_begin + ksw : ksteps;
-      v4d acc[kT * (kT + 1) / 2];
-      double rp[kT];  // the same fetch also yields this slice's part of rhs_p -= W (g_f / E_f)
-#pragma unroll
-      for (int q = 0; q < kT * (kT + 1) / 2; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int t = 0; t < kT; t++) rp[t] = 0.0;
-      for (int s0 = s_begin; s0 < s_end; s0 += 5) {
-        double wv[5][kT], ev[5], gv[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const int f = 4 * (s0 + j) + kq;
-          const int fc = (s0 + j < s_end && f < F) ? f : 0;
-          ev[j] = w.einv[fc], gv[j] = w.tf[fc];
-#pragma unroll
-          for (int t = 0; t < kT; t++) {
-            const int col = 16 * t + li;
-            wv[j][t] = v.WTf[(size_t)fc * v.n6cap + (col < n6 ? col : 0)];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const int f = 4 * (s0 + j) + kq;
-          const bool vf = s0 + j < s_end && f < F;
-#pragma unroll
-          for (int t = 0; t < kT; t++) {
-            wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
-            rp[t] = fma(wv[j][t], gv[j], rp[t]);
-          }
-#pragma unroll
-          for (int ti = 0; ti < kT; ti++) {
-            const double a = wv[j][ti] * ev[j];
-#pragma unroll
-            for (int tj = 0; tj <= ti; tj++) acc[ti * (ti + 1) / 2 + tj] = mfma_f64(a, wv[j][tj], acc[ti * (ti + 1) / 2 + tj]);
-          }
-        }
-      }
-#pragma unroll
-      for (int ti = 0; ti < kT; ti++)
-#pragma unroll
-        for (int tj = 0; tj <= ti; tj++) {
-          const int bcol = 16 * tj + li;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int arow = 16 * ti + kq + 4 * r;
-            if (arow < n6 && bcol <= arow) VIO_ATOMIC_ADD(w.App + tri_at(arow, bcol), -acc[ti * (ti + 1) / 2 + tj][r]);
-          }
-        }
-#pragma unroll
-      for (int t = 0; t < kT; t++) {
-        const int a = 16 * t + li;
-        if (a < n6 && rp[t] != 0.0) VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -rp[t]);
-      }
+      schur_ksplit5(cx, v.WTf, v.n6cap, n6, F, w.einv, w.tf,
+                    [&](int arow, int bcol, double val) { VIO_ATOMIC_ADD(w.App + tri_at(arow, bcol), -val); },
+                    [&](int a, double val) { VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -val); });
     } else {
       for (int p = wave; p < npairs; p += nw) {
         int ti = 0;
@@ -2580,6 +2596,69 @@ VIO_DEV void state_norms(const Ctx &cx, const WinView &v, cldsd apose, cldsd asb
   if (linf) *linf = block_max(cx, m);
 }
 
+// The O(n) vector work of one trust-region iteration used to be a dozen barrier-separated passes of one element per
+// work-item each (Plus, three norms, the step, its three inner products, the parking of the iterate ...): every pass costs
+// its LDS round trips and a block reduction whatever it computes. The two fused passes below replace eight of them.
+//
+// x <- x [+] (delta_p, delta_f) IN PLACE (PoseLocalParameterization::Plus on every block), the old iterate parked in
+// `stash` (global: pose 7 (P + 1) | sb at o_sb | feat at o_f). Partial sums: d2 += |x_new - x_old|^2, n2 += |x_new|^2 over
+// the global-size parameters (what state_norms sums).
+template <class WK>
+VIO_DEV void plus_in_place(const Ctx &cx, const WinView &v, WK &w, cldsd dpv, cldsd dfv, double *stash, int o_sb, int o_f,
+                           double &d2, double &n2) {
+  const int npose = v.P + v.has_loop;
+  VIO_PARFOR(i, npose) {
+    auto p0 = w.xpose + 7 * i;
+    auto d = dpv + off_pose(v, i);
+    double o[7], c[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) o[k] = p0[k];
+    for (int k = 0; k < 3; k++) c[k] = o[k] + d[k];
+    Quat q = qnormalized(qmul(Quat{o[3], o[4], o[5], o[6]}, Quat{d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0}));
+    c[3] = q.x, c[4] = q.y, c[5] = q.z, c[6] = q.w;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const double e = c[k] - o[k];
+      d2 = fma(e, e, d2), n2 = fma(c[k], c[k], n2);
+      stash[7 * i + k] = o[k], p0[k] = c[k];
+    }
+  }
+  VIO_PARFOR(q, v.P * 9) {
+    const double o = w.xsb[q], c = o + dpv[off_sb(q / 9) + q % 9], e = c - o;
+    d2 = fma(e, e, d2), n2 = fma(c, c, n2);
+    stash[o_sb + q] = o, w.xsb[q] = c;
+  }
+  VIO_PARFOR(f, v.F) {
+    const double o = w.xfeat[f], c = o + dfv[f], e = c - o;
+    d2 = fma(e, e, d2), n2 = fma(c, c, n2);
+    stash[o_f + f] = o, w.xfeat[f] = c;
+  }
+}
+
+// |x - Plus(x, -g)|_inf (trust_region_minimizer.cc:270-284) in one pass and one reduction: the candidate is not stored.
+template <class WK>
+VIO_DEV double gradient_max_norm(const Ctx &cx, const WinView &v, WK &w) {
+  const int npose = v.P + v.has_loop;
+  double m = 0.0;
+  VIO_PARFOR(i, npose) {
+    auto p0 = w.xpose + 7 * i;
+    auto g = w.gp + off_pose(v, i);
+    for (int k = 0; k < 3; k++) m = fmax(m, fabs(p0[k] - (p0[k] - g[k])));
+    const Quat q0{p0[3], p0[4], p0[5], p0[6]};
+    const Quat q = qnormalized(qmul(q0, Quat{-g[3] / 2.0, -g[4] / 2.0, -g[5] / 2.0, 1.0}));
+    m = fmax(fmax(m, fabs(q0.x - q.x)), fmax(fabs(q0.y - q.y), fmax(fabs(q0.z - q.z), fabs(q0.w - q.w))));
+  }
+  VIO_PARFOR(q, v.P * 9) {
+    const double o = w.xsb[q];
+    m = fmax(m, fabs(o - (o - w.gp[off_sb(q / 9) + q % 9])));
+  }
+  VIO_PARFOR(f, v.F) {
+    const double o = w.xfeat[f];
+    m = fmax(m, fabs(o - (o - w.gf[f])));
+  }
+  return block_max(cx, m);
+}
+
 // =====================================================================================================
 // TrustRegionMinimizer + DoglegStrategy (CSI/trust_region_minimizer.cc, CSI/dogleg_strategy.cc)
 // =====================================================================================================
@@ -2612,16 +2691,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       si[4 + i] = (valid ? 1 : 0) | (ok ? 2 : 0);
     }
   };
-  // |x - Plus(x, -g)|_inf (trust_region_minimizer.cc:270-284)
-  auto grad_max_norm = [&]() {
-    VIO_PARFOR(i, np) w.t2[i] = -w.gp[i];
-    VIO_PARFOR(f, F) w.tf[f] = -w.gf[f];
-    VIO_SYNC();
-    apply_plus(cx, fresh(), w, w.t2, w.tf);
-    double l2, linf;
-    state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &l2, &linf);
-    return linf;
-  };
+  auto grad_max_norm = [&]() { return gradient_max_norm(cx, fresh(), w); };
 
   double x_cost = evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, false);
   double x_norm = -1.0;  // "Invalid value", trust_region_minimizer.cc:168
@@ -2676,26 +2746,28 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         ldsi pi = reinterpret_cast<ldsi>(park + 12);
         pi[0] = it, pi[1] = n_ok, pi[2] = n_bad, pi[3] = invalid_run, pi[4] = termination, pi[5] = recorded, pi[6] = last_ok ? 1 : 0;
       }
-      double part = 0;
-      VIO_PARFOR(i, np) {
-        const double g = pose_gd(w, i);
-        part += g * g;
+      // |g_d|^2, the Cauchy direction a = D^-2 S g (-> t2 poses, stf landmarks) and the vectors quad_form_H starts from
+      // (u = S a frame-major -> t1, by pose index -> xt, its landmark accumulator tf = 0) in ONE pass; the reduction's barrier
+      // publishes them. Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192); |J_s a|^2 = u^T H u
+      // is taken from the unfactored system, i.e. before the linear solve consumes it (it does not depend on mu).
+      {
+        double part = 0;
+        VIO_PARFOR(i, np) {
+          const int f = i / kBS, c = i - f * kBS;
+          const double g = pose_gd(w, i), a = g * rcp_f(w.dp[i]), u = w.sp[i] * a;
+          part += g * g;
+          w.t2[i] = a, w.t1[i] = u;
+          if (c < 6) w.xt[6 * f + c] = u;
+        }
+        VIO_PARFOR(f, F) {
+          const double d2 = feat_d2(w, f), sg = w.sf[f] * w.gf[f], g = sg * rsqrt_f(d2);
+          part += g * g;
+          w.stf[f] = sg * rcp_f(d2), w.tf[f] = 0.0;
+        }
+        gd_sq = block_sum(cx, part);
       }
-      VIO_PARFOR(f, F) {
-        const double g = feat_gd(w, f);
-        part += g * g;
-      }
-      gd_sq = block_sum(cx, part);
-      // Cauchy point: alpha = |g_d|^2 / |J_s (g_d / d)|^2 (dogleg_strategy.cc:172-192). |J_s a|^2 = u^T H u is taken from
-      // the unfactored system, i.e. before the linear solve consumes it (it does not depend on mu).
-      auto cauchy_direction = [&]() {  // a = D^-2 S g -> t2 (poses), stf (landmarks)
-        VIO_PARFOR(i, np) w.t2[i] = pose_gd(w, i) * rcp_f(w.dp[i]);
-        VIO_PARFOR(f, F) w.stf[f] = w.sf[f] * w.gf[f] * rcp_f(feat_d2(w, f));
-        VIO_SYNC();
-      };
-      cauchy_direction();
       stamp(cx, ST_DOGLEG);
-      const double qf_h = quad_form_H(cx, fresh(), w, w.t2, w.stf);
+      const double qf_h = quad_form_H(cx, fresh(), w, w.t2, w.stf, /*prepared=*/true);
       stamp(cx, ST_QUADFORM);
       // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
       solver_ok = false;
@@ -2704,7 +2776,6 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
           evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, true);
-          cauchy_direction();  // (stf doubles as an accumulator of the Jacobian evaluation)
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;
@@ -2744,10 +2815,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         it = pi[0], n_ok = pi[1], n_bad = pi[2], invalid_run = pi[3], termination = pi[4], recorded = pi[5], last_ok = pi[6] != 0;
       }
       if (solver_ok) {
-        double part2 = 0;  // mu |D a|^2 of the Cauchy direction a (t2, stf) for the mu the solve ended with
-        VIO_PARFOR(i, np) part2 += mu_used * w.dp[i] * w.dp[i] * w.t2[i] * w.t2[i];
-        VIO_PARFOR(f, F) part2 += mu_used * feat_d2(w, f) * w.stf[f] * w.stf[f];
-        const double reg = block_sum(cx, part2);
+        // mu |D a|^2 of the Cauchy direction a = D^-2 S g for the mu the solve ended with: D a = g_d, so it is mu |g_d|^2
+        const double reg = mu_used * gd_sq;
         qf_cauchy = qf_h + reg;
         alpha = gd_sq / qf_h;
         stamp(cx, ST_DOGLEG);
@@ -2781,28 +2850,21 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         ca = -alpha * (1.0 - beta), cb = beta;
         need_norm = true;
       }
-      double pn = 0, psg = 0, preg = 0;
+      // The step  s = ca g_d + cb gn  (d-scaled coordinates) is a combination of two vectors whose inner products are reduced
+      // already: |s|^2 = ca^2 |g_d|^2 + 2 ca cb g_d.gn + cb^2 |gn|^2, (step)^T S g = s . g_d = ca |g_d|^2 + cb g_d.gn,
+      // mu |D step|^2 = mu |s|^2 -- no reduction pass over the step. What is stored is delta = S D^-1 s, the argument of Plus.
       VIO_PARFOR(i, np) {
-        double s = ca * pose_gd(w, i) + cb * w.gnp[i];
-        pn += s * s;
-        double st = s * rcp_f(w.dp[i]);
-        w.stp[i] = st;
-        psg += st * w.sp[i] * w.gp[i];
-        preg += mu_used * w.dp[i] * w.dp[i] * st * st;
+        const double s_ = ca * pose_gd(w, i) + cb * w.gnp[i];
+        w.t2[i] = s_ * rcp_f(w.dp[i]) * w.sp[i];
       }
       VIO_PARFOR(f, F) {
-        const double d2 = feat_d2(w, f), id = rsqrt_f(d2);
-        double s = ca * (w.sf[f] * w.gf[f] * id) + cb * w.gnf[f];
-        pn += s * s;
-        double st = s * id;
-        w.stf[f] = st;
-        psg += st * w.sf[f] * w.gf[f];
-        preg += mu_used * d2 * st * st;
+        const double id = rsqrt_f(feat_d2(w, f));
+        const double s_ = ca * (w.sf[f] * w.gf[f] * id) + cb * w.gnf[f];
+        w.tf[f] = s_ * id * w.sf[f];
       }
-      VIO_SYNC();
-      block_sum3(cx, pn, psg, preg);
-      double n2 = pn, sg = psg, reg = preg;
+      const double n2 = ca * ca * gd_sq + 2.0 * ca * cb * gdot + cb * cb * gnn2, sg = ca * gd_sq + cb * gdot, reg = mu_used * n2;
       if (need_norm) dogleg_step_norm = sqrt(n2);
+      VIO_SYNC();
       // model_cost_change = -(J step)^T (r + J step / 2) (trust_region_minimizer.cc:402-416). The dogleg step is a
       // combination  v = ca a - cb y  of the Cauchy direction a = D^-2 S g and the Gauss-Newton solution y of
       // M y = S g, M = S H S + mu D^2, so its quadratic form needs no third pass over the factor and the landmark
@@ -2825,10 +2887,6 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       continue;
     }
     invalid_run = 0;
-    VIO_PARFOR(i, np) w.t2[i] = w.stp[i] * w.sp[i];  // delta = step * scale
-    VIO_PARFOR(f, F) w.tf[f] = w.stf[f] * w.sf[f];
-    VIO_SYNC();
-    apply_plus(cx, fresh(), w, w.t2, w.tf);
     stamp(cx, ST_DOGLEG);
     // After an ACCEPTED step the next candidate is linearized SPECULATIVELY -- cost and Jacobians in one evaluation, before
     // its step is accepted. Ceres evaluates the cost at the candidate and, once the step is accepted, residuals + Jacobians at
@@ -2838,19 +2896,20 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
     // route -- cost only, linearization once it is accepted --: rejections come in runs (a window at its noise floor), and a
     // rejected speculative evaluation wastes its Jacobian half, which at W = 30 is three quarters of it.
     const bool speculate = last_ok;
-    double step_norm, dummy;
-    state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.cpose, w.csb, w.cfeat, &step_norm, &dummy);
     const int npose7 = (v.P + v.has_loop) * 7, o_sb = 7 * (v.P + 1), o_f = o_sb + 9 * v.P, o_v = o_f + F, nv = v.nblk * kBS;
     // (either way the candidate takes the iterate's place for its evaluation -- one code path, fixed LDS addresses -- and the
-    // iterate waits in the stash)
-    VIO_PARFOR(q, npose7) v.stash[q] = w.xpose[q], w.xpose[q] = w.cpose[q];
-    VIO_PARFOR(q, v.P * 9) v.stash[o_sb + q] = w.xsb[q], w.xsb[q] = w.csb[q];
-    VIO_PARFOR(q, F) {
-      v.stash[o_f + q] = w.xfeat[q], w.xfeat[q] = w.cfeat[q];
-      v.stash[o_v + 3 * nv + q] = w.gf[q], v.stash[o_v + 3 * nv + F + q] = w.hff[q], v.stash[o_v + 3 * nv + 2 * F + q] = w.gnf[q];
+    // iterate waits in the stash.) Plus, the step norm |x_cand - x|, the candidate's norm (x_norm once the step is accepted)
+    // and the parking of the iterate are ONE pass and one reduction.
+    double step_norm, cand_norm;
+    {
+      double d2 = 0, c2 = 0, dummy3 = 0;
+      plus_in_place(cx, fresh(), w, w.t2, w.tf, v.stash, o_sb, o_f, d2, c2);
+      VIO_PARFOR(q, F)
+        v.stash[o_v + 3 * nv + q] = w.gf[q], v.stash[o_v + 3 * nv + F + q] = w.hff[q], v.stash[o_v + 3 * nv + 2 * F + q] = w.gnf[q];
+      VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
+      block_sum3(cx, d2, c2, dummy3);
+      step_norm = sqrt(d2), cand_norm = sqrt(c2);
     }
-    VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
-    VIO_SYNC();
     double cand_cost = evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, /*jac=*/speculate, true, false, /*keep_aux=*/!speculate);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
     auto restore_iterate = [&]() {  // x <- the iterate the candidate replaced
@@ -2873,7 +2932,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
     double hist = (ev_ref - cand_cost) / (ev_acc_ref + model_cost_change);
     double rho = fmax(rel, hist);
     if (rho > 1e-3) {
-      state_norms(cx, fresh(), w.xpose, w.xsb, w.xfeat, nullptr, nullptr, nullptr, &x_norm, nullptr);
+      x_norm = cand_norm;
       x_cost = cand_cost;  // (x is the candidate)
       if (rho < 0.25) radius *= 0.5;                                          // StepAccepted
       if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);

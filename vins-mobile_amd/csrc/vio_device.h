@@ -38,6 +38,22 @@ inline std::vector<std::string> hip_runtimes() {
   fclose(f);
   return out;
 }
+// The host-only translation units are built with $(HOST_ARCH) (csrc/Makefile: -mavx2 by default). On a host CPU without
+// that instruction set the first such function would die with SIGILL; the *_create entries (built without the flag: every
+// .hip file) refuse with VIO_ENODEV instead.
+inline bool host_isa_ok() {
+#if defined(VIO_HOST_NEEDS_AVX2) && !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+  static const bool ok = [] {
+    __builtin_cpu_init();
+    const bool have = __builtin_cpu_supports("avx2");
+    if (!have) fprintf(stderr, "vio_amd: this host CPU has no AVX2 and the library's host code was built with it (rebuild with `make HOST_ARCH=`)\n");
+    return have;
+  }();
+  return ok;
+#else
+  return true;
+#endif
+}
 inline bool single_hip_runtime() {
   static const int n = [] {
     const std::vector<std::string> r = hip_runtimes();
@@ -51,7 +67,7 @@ inline bool single_hip_runtime() {
     }
     return (int)r.size();
   }();
-  return n <= 1;
+  return n <= 1 && host_isa_ok();
 }
 
 inline int current_device() {

@@ -330,7 +330,8 @@ int ensure_store(vio_estimator *e, int g) {
   // all new (a sequence that tracks nothing fails the failure detection long before: last_track_num < 4). A list that
   // outgrows its slot ends the frame with VIO_ECAP for that sequence, which restarts.
   e->res_obs_cap = std::min(1024, std::max(256, 2 * e->cfg.max_corners));
-  e->res_list_cap = std::max({1024, (e->W + 2) * e->cfg.max_corners, e->res_obs_cap});
+  // (the last term: store_pack scans its (W + 2)^2 bucket keys through a landmark-sized array, vio_backend_resident_reserve)
+  e->res_list_cap = std::max({1024, (e->W + 2) * e->cfg.max_corners, e->res_obs_cap, (e->W + 2) * (e->W + 2)});
   double ex[7];
   const Quat q = RtoQ(e->ric);
   ex[0] = e->tic[0], ex[1] = e->tic[1], ex[2] = e->tic[2], ex[3] = q.x, ex[4] = q.y, ex[5] = q.z, ex[6] = q.w;

@@ -1694,6 +1694,7 @@ struct vio_frontend {
   VioObs *p_obs = nullptr;
   uint8_t *p_frames = nullptr;  // page-locked gathering buffer of read_images
   bool pending = false, pending_publish = false;  // a submitted frame waits for vio_frontend_collect
+  bool pending_async = false;                     // ... and it was queued by vio_frontend_submit_images_async (Async::rc is its status)
   // vio_frontend_submit_images_async: the submit itself (gather + transfers + launches) runs on this context's own host
   // thread, the caller returns at once; collect waits for it first
   struct Async {
@@ -2144,7 +2145,7 @@ int vio_frontend_submit_images(vio_frontend_t *fe, const uint8_t *gray, int32_t 
   if (fe->pending) return VIO_ESTATE;  // one frame in flight per context: collect it first
   const int rc = submit_body(fe, gray, rows, cols, stride, publish);
   if (rc != VIO_OK) return rc;
-  fe->pending = true, fe->pending_publish = publish != 0;
+  fe->pending = true, fe->pending_publish = publish != 0, fe->pending_async = false;
   return VIO_OK;
 }
 
@@ -2184,7 +2185,7 @@ int vio_frontend_submit_images_async(vio_frontend_t *fe, const uint8_t *gray, in
     a->has_job = true, a->busy = true, a->rc = VIO_OK;
   }
   a->cv.notify_all();
-  fe->pending = true, fe->pending_publish = publish != 0;
+  fe->pending = true, fe->pending_publish = publish != 0, fe->pending_async = true;
   return VIO_OK;
 }
 
@@ -2192,7 +2193,7 @@ int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs, int32_t *n_obs) {
   if (!fe || !n_obs) return VIO_EINVAL;
   if (!fe->pending) return VIO_ESTATE;
   if (fe->pending_publish && !out_obs) return VIO_EINVAL;
-  if (fe->async) {  // an asynchronous submit finishes queueing first
+  if (fe->async && fe->pending_async) {  // an asynchronous submit finishes queueing first (a->rc belongs to THAT submit only)
     vio_frontend::Async *a = fe->async;
     std::unique_lock<std::mutex> lk(a->m);
     a->cv.wait(lk, [&] { return !a->busy; });

@@ -41,7 +41,13 @@ class Estimator:
         """solveInitial inside process_image. on: False / 0 off; True / 2 / "fit": relativePose by the fit over all
         correspondences; 1 / "reference": by five-point RANSAC + recoverPose as the reference computes it (a lottery over the
         roots of one minimal sample, see include/vio_amd.h)."""
-        mode = {False: 0, True: 2, "fit": 2, "reference": 1}.get(on, on)
+        # (dispatch on type: in Python 1 == True with the same hash, a dict lookup would send 1 to the fit)
+        if isinstance(on, bool):
+            mode = 2 if on else 0
+        elif isinstance(on, str):
+            mode = {"fit": 2, "reference": 1, "off": 0}[on]
+        else:
+            mode = int(on)
         self._check(self.lib.vio_estimator_enable_initialization(self._h, int(mode)), "enable_initialization")
 
     def set_resident(self, on=True):
