@@ -86,7 +86,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_prJT = o, o += (size_t)d.Ncap;  // b0 = J0^T r0
   s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
-  s.s_PP = o, o += (size_t)(d.Pcap + 1) * (d.Pcap + 2) / 2 * 36;
+  s.s_PP = o, o += tri_doubles(pose_rows(d));  // (layout of App)
   s.s_sfact = o, o += (slot_capacity(d) + 1) / 2;  // ints: staging slot -> factor
   s.s_Asp = o, o += (size_t)kSB * pose_jp(d);  // the prior's speed-bias x pose block
   s.s_AspG = o, o += (size_t)d.Pcap * kAS;

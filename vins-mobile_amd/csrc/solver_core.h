@@ -202,7 +202,9 @@ struct WinView {
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   int *srec_i;       // staging slot -> host | target << 8 | landmark << 16 (-1: unused slot), built once per solve: the factor
   double *srec_d;    // data in SLOT order ([slot][6] = pts_i, pts_j), one global round trip per evaluation pass instead of two
-  double *PP;        // pose-pose accumulator of the projection factors: lower 6x6 blocks [(a(a+1)/2 + b)][6][6]
+  double *PP;        // off-diagonal pose-pose blocks of the projection Gram products IN THE LAYOUT OF App (tri_at; zero where no
+                     // (host, target) bucket writes: zeroed once per solve), so that a linearization starts the pose matrix as
+                     // AppPr + PP with two independent loads per element and no bucket descriptors
   double *AppPr;     // the prior's H0 scattered into the layout of App | Dss | Css once per solve (setup_prior): every
                      // linearization starts the reduced matrix as a straight copy of it instead of an element-wise scatter
   double *AspG;      // [P][9][18] the IMU part of the speed-bias x pose coupling when the pose matrix is global (WorkT::AspI)
@@ -1208,32 +1210,6 @@ constexpr int kSlotStride = 29;  // marginalization phase: two rows of 14 + 1 pa
 constexpr int kGRow = 10;
 constexpr int kGSlot = 2 * kGRow + 1;
 
-// One element D[row][col] of a (host,target) bucket's Gram matrix G^T G, G = [Ji(6) | Jj(6) | r | Jl | 0 0] per row:
-// host-host, target-target and target-host 6x6 blocks go to the pose-pose accumulator PP, row 12 is J^T r.
-// pp_mode: how the target-host block reaches PP. A (host, target) bucket belongs to ONE wave and, unless the window also
-// holds the reversed pair, is the only contributor of its off-diagonal block: 1 = plain store (the bucket's first chunk:
-// nothing has to be zeroed beforehand), 2 = plain read-modify-write (a bucket continued from the previous chunk, same
-// wave), 0 = atomic add into a zeroed PP (windows with reversed pairs; an L2 atomic round trip per element).
-template <class WK>
-VIO_DEV void gram_flush(const WinView &v, WK &w, int h, int t, int row, int col, double val, int pp_mode) {
-  if (row < 6) {
-    if (col <= row) VIO_ATOMIC_ADD(w.ppd + h * 36 + row * 6 + col, val);
-  } else if (row < 12) {
-    if (col < 6) {
-      double *dst = t > h ? v.PP + (t * (t + 1) / 2 + h) * 36 + (row - 6) * 6 + col
-                          : v.PP + (h * (h + 1) / 2 + t) * 36 + col * 6 + (row - 6);
-      if (pp_mode == 1) *dst = val;
-      else if (pp_mode == 2) *dst += val;
-      else VIO_ATOMIC_ADD(dst, val);
-    } else if (col < 12 && col <= row) {
-      VIO_ATOMIC_ADD(w.ppd + t * 36 + (row - 6) * 6 + (col - 6), val);
-    }
-  } else if (row == 12) {
-    if (col < 6) VIO_ATOMIC_ADD(w.gp + off_pose(v, h) + col, val);
-    else if (col < 12) VIO_ATOMIC_ADD(w.gp + off_pose(v, t) + col - 6, val);
-  }
-}
-
 // Projection factors with Jacobians. The (not yet assembled) matrix buffer is used as a staging area: every factor
 // writes its two robustified Jacobian rows into its slot of the (host,target)-bucketed order; each bucket's
 // J^T J / J^T r is then ONE Gram product on the matrix cores (the operand fetch of an MFMA step is 64 consecutive
@@ -1326,15 +1302,15 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       unsigned long long todo = __builtin_amdgcn_ballot_w64(pv && (m_s0 > c0 ? m_s0 : c0) < (m_s1 < c0 + CH ? m_s1 : c0 + CH));
       int tail_p = wave + 64 * nw;
       while (todo || tail_p < v.npairs) {
-        int b_s0, b_s1, b_ht;
+        int b_s0, b_s1, b_ht, b_pair;
         if (todo) {
           const int rl = __builtin_ctzll(todo);
           todo &= todo - 1;
           b_s0 = __builtin_amdgcn_readlane(m_s0, rl), b_s1 = __builtin_amdgcn_readlane(m_s1, rl);
-          b_ht = __builtin_amdgcn_readlane(m_ht, rl);
+          b_ht = __builtin_amdgcn_readlane(m_ht, rl), b_pair = wave + rl * nw;
         } else {
           b_s0 = v.pair_s0[tail_p], b_s1 = v.pair_s1[tail_p], b_ht = (v.pair_h[tail_p] << 16) | v.pair_t[tail_p];
-          tail_p += nw;
+          b_pair = tail_p, tail_p += nw;
         }
         int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
         if (s_lo >= s_hi) continue;
@@ -1369,17 +1345,20 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
         }
         acc += acc2;
         const int h = b_ht >> 16, t = b_ht & 0xffff;
-        if (v.nrev) {  // (windows with reversed (host, target) pairs: general element-wise path)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; r4++) gram_flush(v, w, h, t, kq + 4 * r4, li, acc[r4], 0);
-        } else {
-          // the bucket's off-diagonal block (t > h): first chunk of the bucket stores, a continued bucket adds
-          double *ppb = v.PP + (t * (t + 1) / 2 + h) * 36;
+        {
+          // the bucket's target x host block goes to its place in PP (layout of App; a reversed pair transposed): first chunk
+          // of the bucket stores, a continued bucket adds; windows with reversed pairs (two buckets per block, never produced
+          // by the reference's factor list) add atomically into a PP zeroed per evaluation
           const bool first = b_s0 >= c0;
 #pragma unroll
           for (int r4 = 0; r4 < 4; r4++) {
             if (f_lds[r4]) VIO_ATOMIC_ADD(f_base[r4] + (f_t[r4] ? t : h) * f_mul[r4], acc[r4]);
-            if (f_glb[r4]) ppb[f_goff[r4]] = first ? acc[r4] : ppb[f_goff[r4]] + acc[r4];
+            if (f_glb[r4]) {
+              const int rt = 6 * t + kq + 4 * r4 - 6, ch = 6 * h + li;
+              double *dst = v.PP + (t > h ? tri_at(rt, ch) : tri_at(ch, rt));
+              if (v.nrev) VIO_ATOMIC_ADD(dst, acc[r4]);
+              else *dst = first ? acc[r4] : *dst + acc[r4];
+            }
           }
         }
       }
@@ -1429,114 +1408,122 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       // when each feature has its own thread, so zeroing is needed once (first evaluation of the solve)
       VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
     }
-    if (v.nrev) VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
+    if (v.nrev) VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
     VIO_PARFOR(q, nF * 36) w.ppd[q] = 0.0;
     VIO_SYNC();
     cost += projections_jac(cx, v, w, pose, feat, have_scale);
     stamp(cx, ST_EVAL_PROJ);
+    // ---- the rest of the linearization in three barrier intervals, every global fetch of an interval in flight at once
+    //      (each dependent round trip costs ~3.5 k cycles here; the first versions took six of them, one phase at a time):
+    //  1  reduced matrix <- the prior's H0 + the projection factors' off-diagonal pose blocks; prior dx; raw IMU residuals / Jacobians on the LAST W work-items
+    //     (one lane per factor, ~1.5 k dependent operations: they run beside the copy instead of in a phase of their own)
+    //  2  prr = b0 + H0 dx (MarginalizationFactor::Evaluate as J^T r); diagonal pose blocks of the projection factors -> App
+    //  3  prior cost and gradient; IMU factors on the matrix cores (Gram products, gradient, cost)
     const int napp = (int)tri_doubles(v.nrows), nband = 2 * v.P * kSS;
-    if (v.prior_n > 0) {
-      // the reduced matrix starts as the prior's H0 (constant during the solve, laid out once by setup_prior): a straight
-      // copy, ten loads in flight per lane, instead of zeroing followed by an element-wise scatter with index decoding
-      constexpr int kU = 10;
-      for (int q0 = VIO_TID(cx); q0 < napp + nband; q0 += kU * (int)cx.nt) {
-        double x[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int q = q0 + u * (int)cx.nt;
-          x[u] = v.AppPr[q < napp + nband ? q : 0];
-        }
-        VIO_SCHED_FENCE();
-#pragma unroll
-        for (int u = 0; u < kU; u++) {
-          const int q = q0 + u * (int)cx.nt;
-          if (q < napp) w.App[q] = x[u];
-          else if (q < napp + nband) w.Dss[q - napp] = x[u];
-        }
-      }
-    } else {
-      VIO_PARFOR(q, napp) w.App[q] = 0.0;
-      VIO_PARFOR(q, nband) w.Dss[q] = 0.0;  // (Css follows Dss)
-    }
-    VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
-  }
-  // ---- prior: r = r0 + J0 dx (MarginalizationFactor::Evaluate) -------------------------------------
-  const int n = v.prior_n;
-  if (n > 0 && !reuse_aux) {
-    VIO_PARFOR(b, v.prior_nb) {
-      int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
-      const double *x0 = v.pr_x0 + 9 * b;
-      if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
-      else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
-      else prior_block_dx(7, w.ex, x0, w.prdx + o);
-    }
-    VIO_PARFOR(i, n) w.prr[i] = v.prb0[i];
-    VIO_SYNC();
-    dense_matvec_cols(cx, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
-  }
-  VIO_SYNC();  // Hm zeroed, prr ready
-  if (n > 0) VIO_PARFOR(i, n) {
-    const double r0 = v.pr_r[i], b0 = v.prb0[i];
-    cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
-  }
-  if (jac) {
-    if (n > 0) {
-      VIO_PARFOR(a, n) {
-        const int pa = w.prcol[a];
-        if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[a]);
-      }
-    }
-    // pose-pose blocks of the projection factors: diagonal blocks from LDS, one off-diagonal block per bucket
-    const int nF = v.P + v.has_loop;
-    VIO_PARFOR(q, nF * 36) {
-      const int a = q / 36, e = q - a * 36, r = e / 6, c = e - r * 6;
-      if (r >= c) w.App[tri_at(6 * a + r, 6 * a + c)] += w.ppd[q];
-    }
-    if (v.nrev) {
-      VIO_PARFOR(q, nF * (nF + 1) / 2 * 36) {
-        int blk = q / 36, e = q - blk * 36, r = e / 6, c = e - r * 6;
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= blk) a++;
-        int b = blk - a * (a + 1) / 2;
-        if (a != b) w.App[tri_at(6 * a + r, 6 * b + c)] += v.PP[q];
-      }
-    } else {
-      VIO_PARFOR(q, v.npairs * 36) {  // (blocks without a bucket were never written and are not read)
-        const int pq = q / 36, e = q - pq * 36, r = e / 6, c = e - r * 6;
-        const int h = v.pair_h[pq], t = v.pair_t[pq];
-        const int a = t > h ? t : h, b = t > h ? h : t;
-        w.App[tri_at(6 * a + r, 6 * b + c)] += v.PP[(a * (a + 1) / 2 + b) * 36 + e];
-      }
-    }
-    VIO_SYNC();
-  }
-  stamp(cx, jac ? ST_EVAL_PRIOR : ST_COST_EVAL);
-  // ---- IMU factors -------------------------------------------------------------------------------
-  if (!reuse_aux) {
-    VIO_PARFOR(f, v.W) {
-      imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
-                   sb + 9 * (f + 1), v.imu_r + f * 15, (jac || keep_aux) ? v.imu_J + f * 450 : nullptr);
-    }
-    VIO_SYNC();
-  }
-  stamp(cx, jac ? ST_IMU_RAW : ST_D0);
-  VIO_PARFOR(q, v.W * 15) {  // Mr = info * r ; cost += r^T info r / 2
-    int f = q / 15, r = q % 15;
-    const double *info = v.imu_info + f * 225 + r * 15;
-    const double *rr = v.imu_r + f * 15;
-    double s = 0;
-    for (int k = 0; k < 15; k++) s += info[k] * rr[k];
-    v.imu_Mr[q] = s;
-    cost += 0.5 * s * rr[r];
-  }
-  if (jac) {
-#ifndef VIO_EMUL
-    // One wave per IMU factor on the matrix cores. B = [Jraw | r | 0] (15 x 32, k padded to 16):
-    //   T = info B            (2 column tiles x 4 k-steps)
-    //   G = B^T T             (lower tiles (0,0), (1,0), (1,1)): G[a][b] = (J^T info J)_ab, G[30][b] = (J^T info r)_b
-    // The f64 accumulator layout of T (lane l, element r <-> T[(l>>4)+4r][l&15]) IS the B-operand layout of k-step r,
-    // so T never leaves the registers.
+    const int n = v.prior_n, nt_ = (int)cx.nt;
+    const bool do_prior = n > 0 && !reuse_aux;
     {
+      const int tid_ = VIO_TID(cx);
+      {
+        // the pose matrix starts as the prior's H0 (constant during the solve, laid out once by setup_prior) plus the
+        // off-diagonal blocks of the projection factors (PP, same layout), the band as the prior's part alone: straight
+        // sums / copies, two dozen loads in flight per lane, no zeroing pass, no scatter with index decoding
+        constexpr int kU = 12;
+        const bool pr = n > 0;
+        for (int q0 = tid_; q0 < napp; q0 += kU * nt_) {
+          double x[kU], y[kU];
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int q = q0 + u * nt_, qc = q < napp ? q : 0;
+            x[u] = pr ? v.AppPr[qc] : 0.0, y[u] = v.PP[qc];
+          }
+          VIO_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int q = q0 + u * nt_;
+            if (q < napp) w.App[q] = x[u] + y[u];
+          }
+        }
+        for (int q0 = tid_; q0 < nband; q0 += kU * nt_) {
+          double x[kU];
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int q = q0 + u * nt_;
+            x[u] = pr ? v.AppPr[napp + (q < nband ? q : 0)] : 0.0;
+          }
+          VIO_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < kU; u++) {
+            const int q = q0 + u * nt_;
+            if (q < nband) w.Dss[q] = x[u];  // (Css follows Dss)
+          }
+        }
+      }
+      VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
+      if (do_prior) {
+        VIO_PARFOR(b, v.prior_nb) {
+          int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+          const double *x0 = v.pr_x0 + 9 * b;
+          if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
+          else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
+          else prior_block_dx(7, w.ex, x0, w.prdx + o);
+        }
+        VIO_PARFOR(i, n) w.prr[i] = v.prb0[i];
+      }
+      if (!reuse_aux) {
+        const int f = nt_ - 1 - tid_;
+        if (f < v.W)
+          imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1), sb + 9 * (f + 1),
+                       v.imu_r + f * 15, v.imu_J + f * 450);
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_IMU_RAW);
+    {
+      // H0 dx: (column, part) items like dense_matvec_cols, ONE strip per item when the prior fits (75 rows: 225 items)
+      const int tid_ = VIO_TID(cx);
+      constexpr int kStrip = 25;
+      int nparts = do_prior ? nt_ / n : 1;
+      const int need = (n + 4 * kStrip - 1) / (4 * kStrip);
+      nparts = nparts < need ? need : (nparts > 8 ? 8 : nparts);
+      const int per = do_prior ? (n + nparts - 1) / nparts : 0;
+      const bool one_strip = do_prior && n * nparts <= nt_ && per <= kStrip;
+      if (one_strip && tid_ < n * nparts) {
+        const int hpart = tid_ / n, hc = tid_ - hpart * n;
+        const int hk0 = hpart * per, hnb = hk0 + per < n ? per : n - hk0;
+        if (hnb > 0) {
+          double hs[kStrip], sacc = 0;
+#pragma unroll
+          for (int j = 0; j < kStrip; j++) hs[j] = v.prH0[(size_t)(hk0 + (j < hnb ? j : 0)) * n + hc];
+          VIO_SCHED_FENCE();
+#pragma unroll
+          for (int j = 0; j < kStrip; j++) sacc += (j < hnb ? hs[j] : 0.0) * w.prdx[hk0 + (j < hnb ? j : 0)];
+          VIO_ATOMIC_ADD(w.prr + hc, sacc);
+        }
+      }
+      if (do_prior && !one_strip)
+        dense_matvec_cols(cx, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
+      const int nF = v.P + v.has_loop;
+      VIO_PARFOR(q, nF * 36) {
+        const int a = q / 36, e = q - a * 36, r = e / 6, c = e - r * 6;
+        if (r >= c) VIO_ATOMIC_ADD(w.App + tri_at(6 * a + r, 6 * a + c), w.ppd[q]);
+      }
+    }
+    VIO_SYNC();
+    stamp(cx, ST_EVAL_PRIOR);
+    if (n > 0) VIO_PARFOR(i, n) {
+      const double r0 = v.pr_r[i], b0 = v.prb0[i];
+      cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
+      const int pa = w.prcol[i];
+      if (pa >= 0) VIO_ATOMIC_ADD(w.gp + kBS * (pa >> 8) + (pa & 255), w.prr[i]);
+    }
+    {
+      // One wave per IMU factor on the matrix cores. B = [Jraw | r | 0] (15 x 32, k padded to 16):
+      //   T = info B            (2 column tiles x 4 k-steps)
+      //   G = B^T T             (lower tiles (0,0), (1,0), (1,1)): G[a][b] = (J^T info J)_ab, G[30][b] = (J^T info r)_b,
+      //                         G[30][30] = r^T info r (twice the factor's cost)
+      // The f64 accumulator layout of T (lane l, element r <-> T[(l>>4)+4r][l&15]) IS the B-operand layout of k-step r,
+      // so T never leaves the registers.
       const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
       const int n = lane & 15, kq = lane >> 4;
       for (int f = wave; f < v.W; f += nw) {
@@ -1575,14 +1562,50 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
           } else if (R == 30) {
             VIO_ATOMIC_ADD(w.gp + 15 * f + n, G10[r4]);
             if (n < 14) VIO_ATOMIC_ADD(w.gp + 15 * f + 16 + n, G11[r4]);
+            if (n == 14) cost += 0.5 * G11[r4];
           }
         }
       }
     }
-#endif
     VIO_SYNC();
     stamp(cx, ST_EVAL_IMU);
   } else {
+    // ---- cost only (a candidate after a rejected step): prior, IMU factors, projection factors -----------------------
+    const int n = v.prior_n;
+    if (n > 0 && !reuse_aux) {
+      VIO_PARFOR(b, v.prior_nb) {
+        int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
+        const double *x0 = v.pr_x0 + 9 * b;
+        if (kind == 0) prior_block_dx(7, pose + 7 * idx, x0, w.prdx + o);
+        else if (kind == 1) prior_block_dx(9, sb + 9 * idx, x0, w.prdx + o);
+        else prior_block_dx(7, w.ex, x0, w.prdx + o);
+      }
+      VIO_PARFOR(i, n) w.prr[i] = v.prb0[i];
+      VIO_SYNC();
+      dense_matvec_cols(cx, v.prH0, n, w.prdx, [&](int i, double sacc) { VIO_ATOMIC_ADD(w.prr + i, sacc); });  // prr = b0 + H0 dx = J^T r
+    }
+    VIO_SYNC();
+    if (n > 0) VIO_PARFOR(i, n) {
+      const double r0 = v.pr_r[i], b0 = v.prb0[i];
+      cost += 0.5 * r0 * r0 + 0.5 * w.prdx[i] * (w.prr[i] + b0);  // |r0|^2 / 2 + b0 . dx + dx . H0 dx / 2
+    }
+    stamp(cx, ST_COST_EVAL);
+    if (!reuse_aux) {
+      VIO_PARFOR(f, v.W) {
+        imu_eval_raw(v.gravity, v.preint + f * kPreintDoubles, pose + 7 * f, sb + 9 * f, pose + 7 * (f + 1),
+                     sb + 9 * (f + 1), v.imu_r + f * 15, keep_aux ? v.imu_J + f * 450 : nullptr);
+      }
+      VIO_SYNC();
+    }
+    stamp(cx, ST_D0);
+    VIO_PARFOR(q, v.W * 15) {  // cost += r^T info r / 2
+      int f = q / 15, r = q % 15;
+      const double *info = v.imu_info + f * 225 + r * 15;
+      const double *rr = v.imu_r + f * 15;
+      double s = 0;
+      for (int k = 0; k < 15; k++) s += info[k] * rr[k];
+      cost += 0.5 * s * rr[r];
+    }
     stamp(cx, ST_D1);
     // ---- projection factors, cost only: CauchyLoss rho = b log(1 + s / b) (CSI/loss_function.cc:72-79) ----------
     const double bb = v.cauchy_b, cc = 1.0 / bb;
@@ -3020,6 +3043,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w, const VP &fres
     for (int c = 0; c < 3; c++) d[c] = v.pts_i[3 * k + c], d[3 + c] = v.pts_j[3 * k + c];
   }
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
+  VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (blocks without a (host, target) bucket stay zero for the whole solve)
   setup_imu_info(cx, fresh(), w.App);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, fresh(), w);
