@@ -1024,8 +1024,9 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
   for (int c = 0; c < kSB; c++) {
     double y = __builtin_amdgcn_rsq(dcc);
     const double h = 0.5 * dcc;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);  // (v_rsq_f64 is good to ~26 bits: one Newton step leaves ~2^-51, a perturbation of the pivot far
+                                  //  below what the 1e-6 bar against the reference sees; the second step cost 3 dependent operations
+                                  //  on the pivot chain)
     const bool sel = kq == (c & 3);
     const double a = sel ? A[c >> 2] * y : 0.0;  // l[n] = L[n][c]  (n == c: dcc / sqrt(dcc))
     const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
@@ -1135,8 +1136,7 @@ VIO_DEV bool potrf16_wave(MP D, MP Lprev, int ld, int nvalid, int npiv, bool wit
     if (c < npiv) {
       double y = __builtin_amdgcn_rsq(dcc);
       const double h = 0.5 * dcc;
-      y = y * fma(-h * y, y, 1.5);
-      y = y * fma(-h * y, y, 1.5);
+      y = y * fma(-h * y, y, 1.5);  // (one Newton step: potrf9_inv_wave)
       const bool sel = kq == (c & 3);
       const double a = sel ? A[c >> 2] * y : 0.0;
       const double e = sel ? E[c >> 2] * y : 0.0;
