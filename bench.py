@@ -391,7 +391,9 @@ def multi_gpu_proof(pkg, dist, cfg, first_window, my_ids, pre, rank, local_rank,
     props = torch.cuda.get_device_properties(local_rank)
     info = {"rank": rank, "local_rank": local_rank, "device": be.device(), "name": props.name,
             "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
-            "first_sequence": int(my_ids[0])}
+            "first_sequence": int(my_ids[0]),
+            # threads of this process's host pool: its share of the node's CPUs / quota (csrc/vio_pool.h: divided by LOCAL_WORLD_SIZE)
+            "host_pool_width": pkg.abi.host_pool_width()[0], "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
     infos = [None] * world
     dist.all_gather_object(infos, info)
     poses = pkg.multi.all_gather_array(dist, np.asarray(mine.pose, np.float64).ravel(), device="cuda")

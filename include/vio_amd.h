@@ -902,6 +902,12 @@ const char *vio_version(void);
  * wheel). With more than one copy mapped the device contexts refuse to start
  * (VIO_ENODEV, both paths on stderr): each copy would keep its own device state. */
 int vio_hip_runtime(char *path, int32_t cap, int32_t *n_runtimes);
+/* Width (threads, the caller's included) of the process-wide host pool that spreads per-sequence host work
+ * (window packing, IMU feeds, observation gathers: csrc/vio_pool.h) and the number of such pools. (None in the
+ * reference: one sequence per phone.) Sized from the CPUs the process may run on, its cgroup CPU quota and -- one
+ * process per GPU on a node -- divided by LOCAL_WORLD_SIZE; VIO_AMD_HOST_THREADS overrides. A launcher that is
+ * not torchrun sets one of the two per rank. Creates the pools on first use. */
+int vio_host_pool_width(int32_t *n_pools /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,13 @@ TOL = 1e-6
 TOL_PRIOR = 1e-5
 
 
-# every test that takes `solver_cache` runs twice: through the single-launch kernel and through the launch sequence of the
-# phase path (csrc/phase_core.h; windows of more than 12 frames take the single launch in both)
-@pytest.fixture(scope="module", params=["single", "phase"])
+# The launch-sequence ("phase") path of the same solve (csrc/phase_core.h, opt-in through vio_backend_set_path) is a measured
+# experiment that is slower at every batch size: it is not part of the default run. VIO_TEST_PHASE=1 runs every
+# test that takes `solver_cache` a second time through it (windows of more than 12 frames take the single launch in both).
+PATHS = ["single", "phase"] if os.environ.get("VIO_TEST_PHASE") == "1" else ["single"]
+
+
+@pytest.fixture(scope="module", params=PATHS)
 def solver_cache(request):
     cache = {"_path": request.param}
     yield cache
@@ -257,7 +261,7 @@ def test_one_batch_split_over_both_kernel_variants(solver_cache):
         assert g.next_prior.n == ref.next_prior.n
 
 
-@pytest.mark.parametrize("path", ["single", "phase"])
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("W,F,loop,seed", H.ODD_SHAPES)
 def test_odd_shapes_match_oracle(W, F, loop, seed, path):
     """Awkward window sizes (1..260 landmarks, W = 3..13, loop pose) through the device kernel against the CPU oracle; the

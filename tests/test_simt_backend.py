@@ -77,6 +77,11 @@ def test_device_sections_odd_shapes(W, F, loop, seed, simt):
 PHASE_MODES = [(0, 0), (1, 1), (0, 2)]   # (IMU coupling in global scratch?, lane order)
 
 
+# (the phase path is a measured experiment that lost at every batch size, DESIGN.md 3.6: VIO_TEST_PHASE=1 puts it back into the run)
+phase_only = pytest.mark.skipif(os.environ.get("VIO_TEST_PHASE") != "1", reason="phase path: opt-in experiment (VIO_TEST_PHASE=1)")
+
+
+@phase_only
 @pytest.mark.parametrize("mode", PHASE_MODES)
 @pytest.mark.parametrize("name", H.golden_window_names())
 def test_phase_path_on_simt_emulator(name, mode, simt):
@@ -89,6 +94,7 @@ def test_phase_path_on_simt_emulator(name, mode, simt):
     H.check_solution(got, stats, d, tol=1e-6, tol_prior=1e-5)
 
 
+@phase_only
 @pytest.mark.parametrize("W,F,loop,seed", H.ODD_SHAPES)
 def test_phase_path_odd_shapes(W, F, loop, seed, simt):
     cfg = abi.default_config(window_size=W)

@@ -50,6 +50,13 @@ def hip_runtime(lib=None):
     return [p for p in buf.value.decode().split(";") if p]
 
 
+def host_pool_width():
+    """(threads of one host pool incl. the caller, number of pools) of this process (vio_host_pool_width; csrc/vio_pool.h)."""
+    lib = load_product()
+    n = C.c_int32(0)
+    return int(lib.vio_host_pool_width(C.byref(n))), int(n.value)
+
+
 def default_config(**kw):
     """The reference's iPhone7P values (global_param.cpp:27-42, feature_tracker.hpp:24-29)."""
     c = VioConfig(
@@ -458,6 +465,7 @@ def load_product():
     lib.vio_frontend_read_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32,
                                              C.POINTER(VioObs), _ip]
     lib.vio_hip_runtime.argtypes = [C.c_char_p, C.c_int32, _ip]
+    lib.vio_host_pool_width.argtypes = [_ip]
     lib.vio_frontend_submit_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_submit_images_async.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_collect.argtypes = [vp, C.POINTER(VioObs), _ip]

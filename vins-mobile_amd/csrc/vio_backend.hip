@@ -203,6 +203,11 @@ extern "C" {
 
 const char *vio_version(void) { return "vio_amd 0.1 (gfx950)"; }
 
+int vio_host_pool_width(int32_t *n_pools) {
+  if (n_pools) *n_pools = vio::HostPool::count();
+  return vio::HostPool::get().width();
+}
+
 int vio_hip_runtime(char *path, int32_t cap, int32_t *n_runtimes) {
   const std::vector<std::string> r = vio::hip_runtimes();
   if (n_runtimes) *n_runtimes = (int32_t)r.size();

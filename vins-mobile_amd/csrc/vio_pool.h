@@ -27,11 +27,12 @@ namespace vio {
 class HostPool {
  public:
   static HostPool &get() {  // the calling thread's pool: assigned round-robin at its first call
-    static Pools pools;
+    Pools &pools = all();
     static std::atomic<unsigned> next_caller{0};
     thread_local const unsigned mine = next_caller.fetch_add(1);
     return pools.p[mine % pools.n];
   }
+  static int count() { return all().n; }
   int width() const { return (int)workers_.size() + 1; }
 
   // fn(i) for i in [0, n), dynamically distributed; returns when all are done. One parallel region at a time: a caller
@@ -129,6 +130,10 @@ class HostPool {
     }
     ~Pools() { delete[] p; }
   };
+  static Pools &all() {
+    static Pools pools;
+    return pools;
+  }
   HostPool() {}
   void start(const cpu_set_t *cpus) {
     int t = 0;
@@ -147,6 +152,16 @@ class HostPool {
       // grants 16 CPUs: 40 k camera frames/s; 16 threads: 74 k, no stalls).
       const int quota = cpu_quota();
       if (quota > 0) t = std::min(t, quota);
+      // Several ranks of one node share the CPUs and the quota (one process per GPU under torchrun / mpirun): every
+      // process takes its share, not all of it -- eight ranks of full-width pools bring the throttling stalls back times
+      // eight. LOCAL_WORLD_SIZE is what torchrun exports; other launchers set VIO_AMD_HOST_THREADS per rank.
+      int local_world = 1;
+      for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"})
+        if (const char *e = getenv(name)) {
+          local_world = std::max(1, atoi(e));
+          break;
+        }
+      t = std::max(1, t / local_world);
     }
     for (int i = 1; i < t; i++) {
       workers_.emplace_back([this] { loop(); });
