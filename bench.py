@@ -191,8 +191,12 @@ def main():
         fe_ms_, _ = fe.kernel_ms()
         be_ms_, _ = be.kernel_ms()
         stats_ = be.download(ws)
+        if args.only != "backend" and S_ == S and not lk_stats:
+            lk_stats.extend(measured_lk_iterations(fe, lambda k: fe.step(pingpong[(warmup + steps + k) % len(pingpong)], publish=True, stream=one)))
         fe.close(), be.close()
         return dt_, max(fe_ms_, 1e-9), max(be_ms_, 1e-9), stats_
+
+    lk_stats = []  # (mean LK iterations per (feature, level) visit, per level) of the headline batch, measured once
 
     dt, fe_ms, be_ms, stats = run_resident(S, args.steps, args.warmup, True)
     replicas = None
@@ -241,6 +245,10 @@ def main():
                                   "bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": fe_traffic,
+                                  # the byte formula assumes 10 LK iterations per (feature, level); what the kernel actually ran:
+                                  "lk_mean_iterations": lk_stats[0] if lk_stats else None,
+                                  "lk_mean_iterations_per_level": lk_stats[1] if lk_stats else None,
+                                  "frac_at_measured_lk_iterations": (algorithmic_bytes_per_tracked_frame(rows, cols, 150, mean_iters=lk_stats[0]) * S / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lk_stats and lk_stats[0] else None,
                                   "traffic_unit": "bytes per step; " + (fe_src or "no PMC summary for this workload under profiles/")},
         }
         if multi_gpu is not None:
@@ -268,6 +276,8 @@ def main():
             out["end_to_end_full"] = guarded(lambda: end_to_end_full(256))
             out["ate"] = guarded(lambda: closed_loop_ate(cfg, pkg))
             out["large_windows"] = guarded(lambda: large_windows(pkg))
+            out["configs2"] = guarded(lambda: config_leg(pkg, "configs[2]"))
+            out["configs4"] = guarded(lambda: config_leg(pkg, "configs[4]"))
             out["loop_closure"] = guarded(lambda: loop_closure(pkg))
         print(json.dumps(out))
     if dist:
@@ -638,6 +648,101 @@ def large_windows(pkg, batches=(64, 256)):
                 out[name] = rec
             else:
                 out[name]["batch_%d" % batch] = {k: rec[k] for k in ("batch", "kernel_ms", "ms_per_solve_at_batch", "solves_per_s", "frac_of_fp64_peak")}
+    return out
+
+
+CONFIG_LEGS = {
+    # BASELINE.json configs[2] / configs[4]: frame geometry, corners (MIN_DIST as tests/test_frontend_gpu.py), window, landmarks,
+    # IMU samples per frame (200 Hz IMU at 10 Hz frames: 20), steady-state prior + 40 relocalization factors for [4]
+    "configs[2]": dict(rows=720, cols=1280, corners=300, min_dist=30, imu_per_frame=20, full=False,
+                       cam=dict(window_size=20, fx=1053.2, fy=1053.4, cx=640.0, cy=360.0)),
+    "configs[4]": dict(rows=1080, cols=1920, corners=500, min_dist=30, imu_per_frame=10, full=True,
+                       cam=dict(window_size=30, fx=1579.8, fy=1580.0, cx=960.0, cy=540.0)),
+}
+
+
+def measured_lk_iterations(fe, step, n_steps=4):
+    """Mean LK iterations per (feature, level) visit, per pyramid level (level 0 first), over n_steps more steps with the
+    kernel's counters on (vio_frontend_lk_iterations); untimed."""
+    fe.lk_iterations(enable=True, read=True)
+    for k in range(n_steps):
+        step(k)
+    fe.sync()
+    it, vis = fe.lk_iterations(enable=False, read=True)
+    per_level = [float(i / v) if v > 0 else None for i, v in zip(it, vis)]
+    mean = float(it.sum() / vis.sum()) if vis.sum() > 0 else None
+    return mean, [x for x in per_level if x is not None]
+
+
+def config_leg(pkg, name, S=64, steps=10, warmup=2, cpu_frames=12):
+    """One BASELINE config end to end like the headline: S resident sequences, every step = front-end step on S frames
+    (track + F-RANSAC + detect, every frame published) + the window solve of S windows (incl. marginalization), inputs resident in
+    HBM; frames/s, per-kernel ms, both rooflines with the image-size-scaled byte count of SURVEY 8(d), and the CPU path (KLT
+    restatement frame + reference Ceres solve, one thread) on a bounded sample of the same workload."""
+    import torch
+    abi, synth, backend, frontend = pkg.abi, pkg.synth, pkg.backend, pkg.frontend
+    sp = CONFIG_LEGS[name]
+    rows, cols, nf = sp["rows"], sp["cols"], sp["corners"]
+    cfg = abi.default_config(max_corners=nf, min_dist=sp["min_dist"], image_rows=rows, image_cols=cols, **sp["cam"])
+    pre = lambda *a: backend.preintegrate(cfg, *a)
+    T, n_unique = 4, 2
+    uniq_frames = [synth.make_image_stream(300 + u, T, rows=rows, cols=cols)[0] for u in range(n_unique)]
+    frames = np.stack([np.stack([uniq_frames[s % n_unique][f] for s in range(S)]) for f in range(T)])
+    if sp["full"]:
+        uniq_w = steady_state_windows(cfg, pkg, pre, [7, 8], n_features=nf, with_loop=40, imu_per_frame=sp["imu_per_frame"])
+    else:
+        uniq_w = [synth.make_window(cfg, pre, seed=20 + s, n_features=nf, imu_per_frame=sp["imu_per_frame"]) for s in range(2)]
+    ws = [uniq_w[s % len(uniq_w)].copy() for s in range(S)]
+    fe = frontend.FeatureTracker(cfg, n_seq=S)
+    fe.upload_frames(np.ascontiguousarray(frames))
+    be = backend.WindowSolver(cfg, max_batch=S)
+    be.upload(ws)
+    pingpong = list(range(T)) + list(range(T - 2, 0, -1))
+    one = torch.cuda.Stream().cuda_stream
+
+    def step(k):
+        fe.step(pingpong[k % len(pingpong)], publish=True, stream=one)
+        be.launch(stream=one)
+
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    fe.kernel_ms(), be.kernel_ms()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fe_ms, _ = fe.kernel_ms()
+    be_ms, _ = be.kernel_ms()
+    stats = be.download(ws)
+    lk_mean, lk_levels = measured_lk_iterations(fe, lambda k: fe.step(pingpong[(warmup + steps + k) % len(pingpong)], publish=True, stream=one))
+    fe.close(), be.close()
+    iters = float(np.mean([s_["iterations"] - 1 for s_ in stats]))
+    M = float(np.mean([w.n_factors for w in ws]))
+    n_prior = int(np.mean([w.prior.n if w.prior is not None else 0 for w in uniq_w]))
+    flops = algorithmic_flops_per_solve(cfg.window_size, M, n_prior, iters, nf) * S
+    levels = len(lk_levels) if lk_levels else 4
+    fe_bytes = algorithmic_bytes_per_tracked_frame(rows, cols, nf, levels=levels) * S
+    fe_bytes_measured = algorithmic_bytes_per_tracked_frame(rows, cols, nf, levels=levels, mean_iters=lk_mean or 10) * S
+    out = {"workload": "%s: %dx%d stream, %d feats (MIN_DIST %d), window=%d, %d projection factors, %d IMU samples per frame%s; "
+                       "every frame published and solved" % (name, cols, rows, nf, sp["min_dist"], cfg.window_size, M, sp["imu_per_frame"],
+                                                             ", %d-row marginalization prior, 40 relocalization factors" % n_prior if sp["full"] else ""),
+           "sequences_per_gpu": S, "steps": steps, "value": S * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+           "gn_iterations": iters, "kernel_ms": {"frontend_step": fe_ms, "window_solve": be_ms},
+           "roofline": {"kernel": "vio_window_kernel<false> (pose matrix in global scratch)", "bound": "mfma",
+                        "achieved": flops / (be_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (be_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_per_solve": flops / S, "traffic": None},
+           "roofline_frontend": {"bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "lk_mean_iterations": lk_mean, "lk_mean_iterations_per_level": lk_levels,
+                                 "frac_at_measured_lk_iterations": fe_bytes_measured / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_frame": fe_bytes / S, "algorithmic_bytes_per_frame_at_measured_iterations": fe_bytes_measured / S}}
+    if cpu_frames:
+        base = CpuBaseline(cfg, abi, uniq_frames, uniq_w)
+        out["cpu_baseline"] = base.one_core(warmup_frames=2, frames=cpu_frames)
+        out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].replace("after 20 warm-up frames", "after 2 warm-up frames")
+        out["vs_cpu_one_core"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
 

@@ -352,6 +352,14 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts /* [c
  * steps rejectWithF (:235) and setMask (:255), which drop more of them.           */
 int vio_frontend_get_pnp_points(vio_frontend_t *fe, int32_t seq, float *forw_pts /* [cap][2] */, int32_t *ids,
                                 int32_t cap, int32_t *n);
+/* Measured iteration counts of calcOpticalFlowPyrLK's inner loop (the reference passes
+ * TermCriteria(COUNT + EPS, 30, 0.01), feature_tracker.cpp:181; how many iterations a
+ * level takes is data dependent): enable = 1 / 0 switches the counters of the LK kernel
+ * on / off (-1: leave), iterations / visits (may both be NULL) receive, per pyramid level,
+ * the iterations run and the (feature, level) visits since the last read and are reset.
+ * Diagnostics for the roofline's byte formula (bench.py: roofline_frontend.lk_mean_iterations);
+ * with the counters on the kernel adds two atomics per (feature, level).               */
+int vio_frontend_lk_iterations(vio_frontend_t *fe, int32_t enable, uint64_t *iterations, uint64_t *visits, int32_t levels_cap);
 /* While a frame submitted with vio_frontend_submit_images has not been collected,
  * every other entry point that reads or changes the tracker state or the
  * observation staging (step_resident, get_state, get_pnp_points, set / update /

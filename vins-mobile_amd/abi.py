@@ -475,6 +475,7 @@ def load_product():
     lib.vio_frontend_kernel_ms.argtypes = [vp, _dp, _ip]
     lib.vio_frontend_get_state.argtypes = [vp, C.c_int32, fp, _ip, _ip, C.c_int32, _ip]
     lib.vio_frontend_get_pnp_points.argtypes = [vp, C.c_int32, fp, _ip, C.c_int32, _ip]
+    lib.vio_frontend_lk_iterations.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]
     lib.vio_klt_track.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, fp, u8p, fp]
     lib.vio_good_features.argtypes = [cfgp, u8p, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, _ip]
     lib.vio_fundamental_ransac.argtypes = [cfgp, fp, fp, C.c_int32, u8p]

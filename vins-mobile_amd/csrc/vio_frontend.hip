@@ -115,6 +115,8 @@ struct LkParams {
   float epsilon_sq_f;  // screen of the convergence test: a float sum of squares above it cannot pass the double compare
   double epsilon_sq;
   float min_eig;
+  unsigned long long *stats;  // null, or [2 * levels]: iterations run / (feature, level) visits, summed over the launch
+                              // (vio_frontend_lk_iterations: the measured mean iteration count of the roofline's byte formula)
 };
 
 // Wave-wide integer sum on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips. The total lands
@@ -543,12 +545,14 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       __builtin_memcpy(&bot, &b32, 4);
       return __builtin_amdgcn_sdot2(bot, wbot, (int)__builtin_amdgcn_udot2(top, wtop, (unsigned)Ic[q], false), false) >> (kWBits - 5);  // (mod 2^32)
     };
+    int nit = 0;
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
       if (iqx < -kWin || iqx >= cols || iqy < -kWin || iqy >= rows) {
         if (level == 0) st = false;
         break;
       }
+      nit++;
       if (!j_staged || iqx < jox || iqx > jox + 2 * kJMargin || iqy < joy || iqy > joy + 2 * kJMargin) stage_j(iqx, iqy);
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
@@ -583,6 +587,10 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
         break;
       }
       pdx = ddx, pdy = ddy;
+    }
+    if (P.stats && lane == 0) {
+      atomicAdd(P.stats + level, (unsigned long long)nit);
+      atomicAdd(P.stats + P.ld.levels + level, 1ull);
     }
     if (st && level == 0) {
       float ex = nxx - half, ey = nxy - half;
@@ -1677,6 +1685,8 @@ struct vio_frontend {
   int nseg = 0, seg_cap = 0;  // candidate list: one segment per strip of kDetR rows
   int *n_cand = nullptr;
   float *cur_pts = nullptr, *pre_pts = nullptr, *forw_pts = nullptr, *lk_err = nullptr;
+  unsigned long long *lk_stats = nullptr;  // [2 * 8] iteration counters of lk_track_kernel (vio_frontend_lk_iterations)
+  bool lk_stats_on = false;
   int *ids = nullptr, *track_cnt = nullptr, *n_pts = nullptr, *n_forw = nullptr, *n_id = nullptr, *kept_xy = nullptr,
       *n_kept = nullptr, *hw = nullptr, *n_obs = nullptr, *pnp_ids = nullptr, *n_pnp = nullptr;
   float *pnp_pts = nullptr;
@@ -1894,6 +1904,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     P.max_count = std::min(std::max(fe->cfg.lk_max_iters, 0), 100);
     double eps = std::min(std::max(fe->cfg.lk_eps, 0.), 10.);
     P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
+    P.stats = fe->lk_stats_on ? fe->lk_stats : nullptr;
     dim3 grd((cap + 4 * kLkFpw - 1) / (4 * kLkFpw), S);
     hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
                        fe->forw_pts, fe->lk_status, fe->lk_err);
@@ -2029,6 +2040,7 @@ void vio_frontend_destroy(vio_frontend_t *fe) {
     if (p) (void)hipFree(p);
   for (auto &e : fe->events) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   if (fe->d_stage) (void)hipFree(fe->d_stage);
+  if (fe->lk_stats) (void)hipFree(fe->lk_stats);
   if (fe->p_obs) (void)hipHostFree(fe->p_obs);
   if (fe->p_frames) (void)hipHostFree(fe->p_frames);
   if (fe->stream) (void)hipStreamDestroy(fe->stream);
@@ -2253,6 +2265,26 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int3
 // forw_pts / ids at the point of readImage where solveVinsPnP runs (feature_tracker.cpp:207): the tracked points behind
 // the first F-RANSAC of the last frame, ahead of rejectWithF / setMask. A frame that tracked nothing (the first one)
 // leaves the list empty.
+int vio_frontend_lk_iterations(vio_frontend_t *fe, int32_t enable, uint64_t *iterations, uint64_t *visits, int32_t levels_cap) {
+  if (!fe || (iterations && (!visits || levels_cap < 1))) return VIO_EINVAL;
+  VIO_ON_DEVICE_OF(fe);
+  constexpr int kSlots = 16;
+  if (!fe->lk_stats) {
+    if (dev_alloc(&fe->lk_stats, (size_t)kSlots) != VIO_OK) return VIO_ENOMEM;
+    HIP_OK(hipMemset(fe->lk_stats, 0, sizeof(unsigned long long) * kSlots));
+  }
+  HIP_OK(hipStreamSynchronize(fe->stream));
+  if (iterations) {
+    unsigned long long h[kSlots];
+    HIP_OK(hipMemcpy(h, fe->lk_stats, sizeof(h), hipMemcpyDeviceToHost));
+    const int L = fe->ld.levels;
+    for (int l = 0; l < levels_cap; l++) iterations[l] = l < L ? h[l] : 0, visits[l] = l < L ? h[L + l] : 0;
+    HIP_OK(hipMemset(fe->lk_stats, 0, sizeof(h)));
+  }
+  if (enable >= 0) fe->lk_stats_on = enable != 0;
+  return VIO_OK;
+}
+
 int vio_frontend_get_pnp_points(vio_frontend_t *fe, int32_t seq, float *forw_pts, int32_t *ids, int32_t cap, int32_t *n) {
   if (!fe || seq < 0 || seq >= fe->n_seq || !n) return VIO_EINVAL;
   if (fe->pending) return VIO_ESTATE;
@@ -2361,6 +2393,7 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
   P.ld = fe->ld, P.cap = fe->cap, P.max_count = std::min(std::max(c.lk_max_iters, 0), 100);
   double eps = std::min(std::max(c.lk_eps, 0.), 10.);
   P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)c.lk_min_eig;
+  P.stats = nullptr;
   hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
                      fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);

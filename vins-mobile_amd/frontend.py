@@ -119,6 +119,15 @@ class FeatureTracker:
                                                          C.byref(n)), "get_pnp_points")
         return pts[: n.value].copy(), ids[: n.value].copy()
 
+    def lk_iterations(self, enable=None, read=True):
+        """vio_frontend_lk_iterations: switches the LK kernel's iteration counters (enable True / False / None = leave) and,
+        with read, returns (iterations, visits) per pyramid level since the last read."""
+        it = (C.c_uint64 * 8)()
+        vis = (C.c_uint64 * 8)()
+        self._check(self.lib.vio_frontend_lk_iterations(self._h, -1 if enable is None else (1 if enable else 0),
+                                                        it if read else None, vis if read else None, 8), "lk_iterations")
+        return (np.array(it[:], np.float64), np.array(vis[:], np.float64)) if read else None
+
     # resident API (throughput runs): frames [n_frames, n_seq, rows, cols] uploaded once
     def upload_frames(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)
