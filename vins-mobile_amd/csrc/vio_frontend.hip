@@ -115,8 +115,6 @@ struct LkParams {
   float epsilon_sq_f;  // screen of the convergence test: a float sum of squares above it cannot pass the double compare
   double epsilon_sq;
   float min_eig;
-  unsigned long long *stats;  // null, or [2 * levels]: iterations run / (feature, level) visits, summed over the launch
-                              // (vio_frontend_lk_iterations: the measured mean iteration count of the roofline's byte formula)
 };
 
 // Wave-wide integer sum on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips. The total lands
@@ -263,10 +261,10 @@ __device__ __forceinline__ void wave_sum_exact3(int p, int q, int r, float &sp, 
 // SLOWER (1.36 vs 1.28 ms per front-end step), more resident waves are faster: with the LDS per feature down to 4.3 KB the
 // register count is what limits residency, so the kernel is compiled for 6 waves per SIMD (80 VGPRs, no spills; 95 -> 5
 // waves before): front-end step 1.28 -> 1.17 ms. (8 waves per SIMD = 64 VGPRs spills 17 registers and gains another 0.5 %.)
-template <int FPW>
+template <int FPW, bool STATS = false>
 __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const uint8_t *prev_pyr, const uint8_t *next_pyr, LkParams P,
                                                        const int *n_pts, const float *prev_pts, float *next_pts,
-                                                       uint8_t *status, float *err) {
+                                                       uint8_t *status, float *err, unsigned long long *stats) {
   constexpr int LPF = 64 / FPW;  // lanes per feature
   __shared__ LkWaveLds lds_all[4 * FPW];
   const int seq = blockIdx.y;
@@ -545,14 +543,14 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       __builtin_memcpy(&bot, &b32, 4);
       return __builtin_amdgcn_sdot2(bot, wbot, (int)__builtin_amdgcn_udot2(top, wtop, (unsigned)Ic[q], false), false) >> (kWBits - 5);  // (mod 2^32)
     };
-    int nit = 0;
+    int nit = 0;  // (STATS only)
     for (int j = 0; j < P.max_count; j++) {
       int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
       if (iqx < -kWin || iqx >= cols || iqy < -kWin || iqy >= rows) {
         if (level == 0) st = false;
         break;
       }
-      nit++;
+      if (STATS) nit++;
       if (!j_staged || iqx < jox || iqx > jox + 2 * kJMargin || iqy < joy || iqy > joy + 2 * kJMargin) stage_j(iqx, iqy);
       a = qx - iqx, b = qy - iqy;
       lk_weights(a, b, iw00, iw01, iw10, iw11);
@@ -588,9 +586,9 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       }
       pdx = ddx, pdy = ddy;
     }
-    if (P.stats && lane == 0) {
-      atomicAdd(P.stats + level, (unsigned long long)nit);
-      atomicAdd(P.stats + P.ld.levels + level, 1ull);
+    if (STATS && lane == 0) {
+      atomicAdd(stats + level, (unsigned long long)nit);
+      atomicAdd(stats + P.ld.levels + level, 1ull);
     }
     if (st && level == 0) {
       float ex = nxx - half, ey = nxy - half;
@@ -1338,7 +1336,8 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
 // The quality threshold needs the global maximum, so it is applied later by the selection kernel.
 constexpr int kDetW = 60;      // output columns per wave
 constexpr int kDetWaves = 4;   // waves per workgroup, side by side
-constexpr int kDetR = 32;      // output rows per strip
+constexpr int kDetR = 32;      // output rows per strip (64 halves the halo rows but its 31 KB candidate buffer halves the resident
+                               // workgroups: 548 instead of 413 us per 512 frames)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
@@ -1413,7 +1412,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   const int xm = reflect101(xr - 1, cols), xp = reflect101(xr + 1, cols);
   float hxx0 = 0.f, hxx1 = 0.f, hxy0 = 0.f, hxy1 = 0.f, hyy0 = 0.f, hyy1 = 0.f;  // horizontal sums of rows -2, -1
   float e0 = 0.f, e1 = 0.f;                                                        // eigenvalues of rows -2, -1
-  unsigned my_max = 0;
+  float my_max = -INFINITY;  // running masked maximum of this lane's column (one v_max per row; mapped to ordered bits once)
   int prev_yr = -1, prev_yp = -1;               // rows of the previous step (uniform) and their (d, t)
   float pd1 = 0.f, pt1 = 0.f, pd2 = 0.f, pt2 = 0.f;
   const bool out_lane = lane >= 2 && lane < 2 + kDetW && xe < cols;
@@ -1466,7 +1465,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
         if (IMG_MASK) unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + xe] != 0;
         else unmasked = ((s_mask[wave][r] >> lane) & 1ull) == 0ull;
         if (unmasked) {
-          my_max = max(my_max, ordered_bits(v));
+          my_max = fmaxf(my_max, v);
           if (xe >= 1 && y >= 1 && xe < cols - 1 && y < rows - 1 && v > 0.f && v == m) {
             const int slot = atomicAdd(&s_ncand, 1);
             const unsigned idx = (unsigned)y << 16 | (unsigned)xe;  // (row-major order like y * cols + x, and no division to take it apart)
@@ -1480,7 +1479,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   }
   // masked maximum: wave max on the DPP/shuffle network, then one LDS atomic per wave
   {
-    unsigned m = my_max;
+    unsigned m = my_max == -INFINITY ? 0u : ordered_bits(my_max);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     if (lane == 0 && m) atomicMax(&smax, m);
@@ -1904,10 +1903,15 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     P.max_count = std::min(std::max(fe->cfg.lk_max_iters, 0), 100);
     double eps = std::min(std::max(fe->cfg.lk_eps, 0.), 10.);
     P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
-    P.stats = fe->lk_stats_on ? fe->lk_stats : nullptr;
     dim3 grd((cap + 4 * kLkFpw - 1) / (4 * kLkFpw), S);
-    hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
-                       fe->forw_pts, fe->lk_status, fe->lk_err);
+    // (the counting variant is a kernel of its own: STATS = [2 * levels] iterations run / (feature, level) visits of this launch,
+    // vio_frontend_lk_iterations; the product kernel sits at 80 registers for six waves per SIMD and has none to spare)
+    if (fe->lk_stats_on && fe->lk_stats)
+      hipLaunchKernelGGL((lk_track_kernel<kLkFpw, true>), grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
+                         fe->forw_pts, fe->lk_status, fe->lk_err, fe->lk_stats);
+    else
+      hipLaunchKernelGGL((lk_track_kernel<kLkFpw, false>), grd, dim3(256), 0, st, fe->pyr[fe->cur_idx], forw, P, fe->n_pts, fe->cur_pts,
+                         fe->forw_pts, fe->lk_status, fe->lk_err, (unsigned long long *)nullptr);
   }
   int rcu = launch_track_update(fe, publish, st);
   if (rcu != VIO_OK) return rcu;
@@ -2393,9 +2397,8 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
   P.ld = fe->ld, P.cap = fe->cap, P.max_count = std::min(std::max(c.lk_max_iters, 0), 100);
   double eps = std::min(std::max(c.lk_eps, 0.), 10.);
   P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)c.lk_min_eig;
-  P.stats = nullptr;
-  hipLaunchKernelGGL(lk_track_kernel<kLkFpw>, dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
-                     fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err);
+  hipLaunchKernelGGL((lk_track_kernel<kLkFpw, false>), dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
+                     fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err, (unsigned long long *)nullptr);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);
   if (hipMemcpy(next_pts, fe->forw_pts, sizeof(float) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return fail(VIO_ENODEV);
   if (hipMemcpy(status, fe->lk_status, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(VIO_ENODEV);
