@@ -60,7 +60,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     size_t se = 0;
     const size_t bs = carve_work<double *>(B.d, lds_matrix, nthreads, nullptr, nullptr, nullptr, nullptr, &se);
     const size_t bm = se * sizeof(double) + carve_marg<double *>(B.d, lds_matrix, nullptr, nullptr, nullptr, 0);
-    return std::max(bs, bm + (lds_matrix ? 64 * kMargSlot * sizeof(double) : 0));
+    return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
   };
   bool lds_matrix = pose_jp(B.d) <= 16 * kPanelTiles && lds_need(true) <= kLdsBytes;
   if ((variant == 1 || variant == 2) && !lds_matrix) return VIO_ECAP;

@@ -275,11 +275,13 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   ldsd app = nullptr;
   if (lds_matrix) app = take(napp);
   w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
-  w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
+  // (pose matrix in global scratch: the band, the fill-tile buffer and what LDS is left over sit at the END of the layout,
+  // contiguous, and stage the Jacobian rows -- see below)
+  if (lds_matrix) w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
   const bool lds_asp = lds_matrix && d.lds_asp != 0;
   ldsd aspi = lds_asp ? take((size_t)d.Pcap * kAS + 16) : nullptr;
   w.AspI = MatPick<AP>::get(lds_asp, aspi, asp_global);
-  w.nstage = lds_matrix ? (int)(o - o_mat) : (int)napp;
+  w.stage = app, w.nstage = lds_matrix ? (int)(o - o_mat) : 0;
   w.asp_ring = lds_matrix && !lds_asp;
   w.aspring = w.asp_ring ? take(2 * (size_t)kAS + 4) : nullptr;
   w.cfeat = take(F);
@@ -308,7 +310,20 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
   // pose matrices of more than kPanelTiles tile rows: the fill tiles of the band go through LDS
   w.vbuf = nullptr;
-  if (!lds_matrix || jp > 16 * (size_t)kPanelTiles) w.vbuf = take((jp / 16) * 192);
+  if (lds_matrix) {
+    if (jp > 16 * (size_t)kPanelTiles) w.vbuf = take((jp / 16) * 192);
+  } else {
+    // Pose matrix in global scratch (W > 12): while the Jacobians are evaluated the band, the fill-tile buffer and whatever
+    // LDS the layout leaves free (a workgroup of this variant has the CU to itself) stage the Jacobian rows of the projection
+    // factors, a chunk of up to one slot per work-item -- the first three versions staged them in the global matrix buffer,
+    // two L2 round trips per Gram operand batch.
+    const size_t o_st = o;
+    w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
+    w.vbuf = take((jp / 16) * 192);
+    const size_t want = (size_t)nthreads * kGSlot, have = o - o_st, room = kLdsBytes / sizeof(double) > o ? kLdsBytes / sizeof(double) - o : 0;
+    if (want > have) (void)take(want - have < room ? want - have : (room & ~(size_t)1));
+    w.stage = w.Dss, w.nstage = (int)(o - o_st);
+  }
   c.bytes = o * sizeof(double);
   return c;
 }

@@ -46,8 +46,8 @@ struct MargWorkT {
   ldsi col_ex;    // [1]
   ldsi pcol;      // prior column -> dense column: prior_n
   ldsi meta;      // [4]: pos, m, n, nblocks
-  MP stage;       // staging of robustified Jacobian rows for the Gram products (same memory space as Am)
-  int stage_slots;
+  ldsd stage;     // staging of robustified Jacobian rows for the Gram products: LDS in both variants (whatever the phase's
+  int stage_slots;  // vectors -- and the matrix, when it is in LDS -- leave of the workgroup's allocation)
 };
 
 // int pointer in the address space of a double pointer type (LDS or global)
@@ -71,7 +71,7 @@ VIO_HD constexpr int kMargMaxPos(int W) { return 15 + 6 * W + 15; }
 
 VIO_HD size_t marg_scratch_doubles(const int Wcap) {
   size_t p = (size_t)kMargMaxPos(Wcap);
-  return tri_doubles((int)p) + 8 + 512 * 64;  // packed matrix + Jacobian-row staging (global-matrix variant)
+  return tri_doubles((int)p) + 8;  // packed matrix (global-matrix variant)
 }
 
 // LDS carve for the marginalization phase. The solver's iterate (xpose, xsb, xfeat, ex) sits at the front of LDS and
@@ -100,19 +100,13 @@ VIO_HD CarvedMarg<MP> carve_marg_all(const Dims &d, bool lds_matrix, ldsd base_a
   m.hff = take(F), m.gf = take(F), m.einv = take(F);
   m.prdx = take(d.Ncap), m.prr = take(d.Ncap);
   ldsd ints = take(((size_t)(2 * d.Pcap + 2 + d.Ncap + 4) + 1) / 2 + 1);
-  // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows;
-  // in the global-matrix variant the staging area follows the matrix in the scratch buffer
+  // whatever LDS is left (the solver's footprint is larger than the marginalization core) stages Jacobian rows -- also when
+  // the matrix lives in global scratch (the staging area used to follow it there: two L2 round trips per operand batch)
   size_t stage_slots = 0;
-  ldsd stage = nullptr;
-  double *stage_global = nullptr;
-  if (lds_matrix) {
-    if (avail_doubles > o + kMargSlot * 2) stage_slots = ((avail_doubles - o) / kMargSlot) & ~(size_t)1;
-    stage = take(stage_slots * kMargSlot);
-  } else {
-    stage_slots = 512;
-    stage_global = am_global ? am_global + nam + 8 : nullptr;
-  }
-  m.stage = MatPick<MP>::get(lds_matrix, stage, stage_global), m.stage_slots = (int)stage_slots;
+  if (avail_doubles > o + kMargSlot * 2) stage_slots = ((avail_doubles - o) / kMargSlot) & ~(size_t)1;
+  if (stage_slots > 1024) stage_slots = 1024;
+  ldsd stage = take(stage_slots * kMargSlot);
+  m.stage = stage, m.stage_slots = (int)stage_slots;
   m.Am = MatPick<MP>::get(lds_matrix, Am, am_global), m.ld = (int)pos;
   ldsi ip = reinterpret_cast<ldsi>(ints);
   m.col_pose = ip, m.col_sb = ip + d.Pcap + 1, m.col_ex = m.col_sb + d.Pcap;

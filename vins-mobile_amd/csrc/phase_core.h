@@ -79,13 +79,14 @@ VIO_HD PhaseView make_phase_view(const BatchPtrs &B, int b) {
 struct SetupWork {
   ldsd App;     // staging area (named like the member of WorkT that setup_imu_info / setup_prior use)
   int nstage;
+  ldsd stage;   // (= App: the name setup_prior uses)
   ldsi prcol;
 };
 VIO_HD size_t carve_setup(const BatchDims &d, ldsd base, SetupWork *w) {
   // (a prior too large for the staging area is read from global memory by setup_prior: 6144 doubles hold the 75 x 75 prior
   // of a W = 10 window and leave room for three workgroups per CU)
   const size_t want = ((size_t)d.Ncap * d.Ncap + 1) & ~(size_t)1, nst = want < 6144 ? (want < 1024 ? 1024 : want) : 6144, npr = (((size_t)d.Ncap + 1) / 2 + 1 + 1) & ~(size_t)1;
-  if (w) w->App = base, w->nstage = (int)nst, w->prcol = reinterpret_cast<ldsi>(base + nst);
+  if (w) w->App = base, w->stage = base, w->nstage = (int)nst, w->prcol = reinterpret_cast<ldsi>(base + nst);
   return (nst + npr) * sizeof(double);
 }
 

@@ -256,7 +256,9 @@ template <class MP, class AP = MP>
 struct WorkT {
   typedef MP mat_ptr;
   MP App;         // pose x pose (+ the carried right-hand side row), tile-row packed lower triangle
-  int nstage;     // doubles behind App that are free whenever the reduced matrix is not assembled (Jacobian-row staging)
+  ldsd stage;     // LDS staging area of the Jacobian rows (and of the set-up's J0 / pivot mailboxes): App itself when the matrix is
+  int nstage;     // in LDS (doubles from App on that are free whenever the reduced matrix is not assembled), else the band + the
+                  // fill-tile buffer + spare LDS (carve_all)
   ldsd Dss, Css;  // speed-bias band: P blocks of 81 each, Css = Dss + 81 P (contiguous with App when App is in LDS)
   AP AspI;        // [P][9][18]: behind Css in LDS, or in the window's global scratch (WinView::AspG)
   ldsd aspring;   // AspI in global scratch next to an LDS pose matrix: two blocks of it in LDS, refilled by the chain wave
@@ -817,7 +819,7 @@ VIO_DEV void setup_prior(const Ctx &cx, const WinView &v, WK &w) {
   }
   // J0 goes through the (not yet assembled) matrix buffer when it fits: the n^2 dot products then read LDS
   const bool stage = (size_t)n * n <= (size_t)w.nstage;
-  auto Js = w.App;
+  auto Js = w.stage;
   if (stage) {
     VIO_PARFOR(q, n * n) Js[q] = v.pr_J[q];
     VIO_SYNC();
@@ -1220,7 +1222,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
                                bool /*later_eval*/) {
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
-  auto G = w.App;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
+  auto G = w.stage;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
   int CH = (w.nstage / kGSlot) & ~1;
   if (CH >= (int)cx.nt) CH -= CH % (int)cx.nt;  // whole rounds of the workgroup: no chunk ends in a nearly empty pass
   // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
@@ -3044,7 +3046,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w, const VP &fres
   }
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
   VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (blocks without a (host, target) bucket stay zero for the whole solve)
-  setup_imu_info(cx, fresh(), w.App);
+  setup_imu_info(cx, fresh(), w.stage);
   stamp(cx, ST_SETUP_IMU);
   setup_prior(cx, fresh(), w);
   stamp(cx, ST_SETUP_PRIOR);

@@ -395,8 +395,10 @@ static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, i
     size_t se = 0;
     const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
     const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
-    if (std::max(bs, bm) > kLdsLimit) return VIO_ECAP;
-    be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bm);
+    // (the marginalization phase stages its Jacobian rows in LDS in this variant too: at least 64 slots behind its vectors)
+    const size_t bmm = bm + 64 * kMargSlot * sizeof(double);
+    if (std::max(bs, bmm) > kLdsLimit) return VIO_ECAP;
+    be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bmm);
   }
   return VIO_OK;
 }
