@@ -59,6 +59,8 @@ inline int pose_jp(const BatchDims &d) { return (pose_rows(d) + 15) / 16 * 16; }
 
 // Staging slots of a window: its factors, one padding slot per (host, target) bucket (buckets start on even slots), and the
 // slots skipped so that no bucket straddles a staging chunk (pack_window): bounded by the factors once more.
+// Cooperative windows (several workgroups per window, solver_core.h): flags and payload of one window in its scratch.
+inline size_t coop_doubles(const BatchDims &d) { return CoopLayout::make(d.Pcap, d.Fcap, d.nblk_cap).total; }
 inline size_t slot_capacity(const BatchDims &d) { return 2 * (size_t)d.Mcap + d.pair_cap + 2; }
 
 // Element counts per window of every array (strides).
@@ -67,7 +69,7 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash, s_coop;
 };
 
 inline BatchStrides make_strides(const BatchDims &d) {
@@ -95,6 +97,7 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_srec_i = o, o += (nslots_cap + 1) / 2;
   s.s_srec_d = o, o += 6 * nslots_cap;
   s.s_stash = o, o += 7 * (size_t)(d.Pcap + 1) + 9 * (size_t)d.Pcap + 4 * (size_t)d.Fcap + 3 * (size_t)(d.Pcap + 1) * kBS;
+  s.s_coop = o, o += coop_doubles(d);  // cooperative windows: flags + payload (solver_core.h, CoopLayout)
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -171,6 +174,8 @@ struct BatchPtrs {
   double *scratch;   // [n][s.scratch]
   double *hm;        // [n][s.hm] (only used when the matrix does not fit LDS)
   const int *order;  // launch-local block index -> window (null: identity); a batch may be split into two launches
+  int coop;          // workgroups per window of this launch (1: each window is solved by one workgroup)
+  int n_launch;      // windows of this launch (cooperative launches pad their grid to whole groups of eight windows)
   double *phase;     // [n][PL.total] phase path: the state that lives across launches (null: single-launch path only)
   PhaseLayout PL;
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop, *stats_d;
@@ -187,6 +192,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.np = kBS * v.P + (v.has_loop ? 6 : 0);
   v.nblk = v.P + (v.has_loop ? 1 : 0);
   v.max_iter = B.d.max_iter;
+  v.Pcap = B.d.Pcap, v.Fcap = B.d.Fcap, v.nblk_cap = B.d.nblk_cap;
   v.Fpad = B.d.Fpad;
   v.npose6 = 6 * (v.P + (v.has_loop ? 1 : 0));
   v.n6 = v.npose6, v.nrows = v.n6 + 1, v.nT = (v.nrows + 15) >> 4, v.jp = (6 * B.d.nblk_cap + 1 + 15) / 16 * 16;
@@ -212,6 +218,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.srec_i = reinterpret_cast<int *>(sc + B.s.s_srec_i), v.srec_d = sc + B.s.s_srec_d;
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.stash = sc + B.s.s_stash;
+  v.coop = sc + B.s.s_coop;
   v.out_pose = B.out_pose + b * B.s.out_pose, v.out_sb = B.out_sb + b * B.s.out_sb;
   v.out_feat = B.out_feat + b * B.s.out_feat;
   v.raw_pose = B.raw_pose + b * B.s.out_pose, v.raw_sb = B.raw_sb + b * B.s.out_sb;
@@ -452,7 +459,9 @@ struct HostBatch {
 // chunk: staging slots per pass of the device's Jacobian evaluation (stage_chunk_slots), 0 = unknown. A bucket that would
 // straddle a multiple of it starts at the next one: every bucket's Gram product then ends in ONE plain store of its
 // off-diagonal pose block instead of a read-modify-write across two passes (a global round trip on the wave's path).
-inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok = false, int chunk = 0) {
+// straddles: set when some bucket of the window crosses a chunk boundary after all (chunk unknown, or a bucket larger than a chunk):
+// cooperative launches need every bucket inside one chunk (one writer per off-diagonal block).
+inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok = false, int chunk = 0, bool *straddles = nullptr) {
   const BatchDims &d = hb.d;
   const BatchStrides &s = hb.s;
   const int W = w.window_size, P = W + 1, F = w.n_features, M = w.n_factors;
@@ -483,6 +492,7 @@ inline int pack_window(HostBatch &hb, int b, const VioWindow &w, bool store_ok =
         if (npairs >= d.pair_cap) return VIO_ECAP;
         const int cpad = (c + 1) & ~1;
         if (chunk > 0 && cpad <= chunk && slot % chunk + cpad > chunk) slot = (slot / chunk + 1) * chunk;
+        if (straddles && (chunk <= 0 || cpad > chunk)) *straddles = true;
         if ((size_t)slot + cpad > slot_capacity(d)) return VIO_ECAP;
         start[(size_t)hh * np1 + tt] = slot;
         hb.pair_h[b * s.pair + npairs] = hh, hb.pair_t[b * s.pair + npairs] = tt;

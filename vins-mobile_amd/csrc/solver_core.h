@@ -149,6 +149,9 @@ struct Ctx {
                       // same roles the two chains would fight over one SIMD's matrix pipe while three stand idle.
   int prof_tid = 0;   // the work-item that keeps the stage clock (0; another wave's first lane to time what wave 0 does not run)
   VIO_AS3 long long *lprof;  // the same counters while the kernel runs (LDS); copied to prof at the end
+  // cooperative windows (round 5): `coop` workgroups serve one window; member 0 owns the solve, the others wait for commands
+  int coop = 1, member = 0;
+  mutable unsigned coop_seq = 0;  // commands issued (owner) / served (helper) so far: the same value in every work-item
 };
 
 // Charges the cycles since the previous stamp to `stage` (thread 0 only; call between barriers).
@@ -184,6 +187,7 @@ struct WinView {
   const double *pr_x0, *pr_J, *pr_r;
   int use_origin;
   double origin_yaw, origin_p[3];
+  int Pcap, Fcap, nblk_cap;  // capacities of the batch (the layout of the cooperative payload depends on them)
   // scratch
   double *imu_info;  // [W][225]  sym(cov^-1)
   double *imu_aug;   // [W][15*30] Gauss-Jordan work area
@@ -208,6 +212,7 @@ struct WinView {
   double *AppPr;     // the prior's H0 scattered into the layout of App | Dss | Css once per solve (setup_prior): every
                      // linearization starts the reduced matrix as a straight copy of it instead of an element-wise scatter
   double *AspG;      // [P][9][18] the IMU part of the speed-bias x pose coupling when the pose matrix is global (WorkT::AspI)
+  double *coop;      // cooperative windows: flags + payload shared by the workgroups of this window (CoopLayout)
   double *stash;     // iterate and the vectors of its linearization while the candidate is evaluated in their place (minimize):
                      // pose 7 (P + 1) | sb 9 P | feat F | gp dp gnp (nblk 15 each) | gf hff gnf (F each); read back after a rejected step
   // outputs
@@ -312,6 +317,93 @@ VIO_DEV void red_put(const WinView &v, WK &w, int fr, int cr, int fc, int cc, do
     else *p = val;
   }
 }
+
+// =====================================================================================================
+// Cooperative windows: several workgroups per window (round 5)
+// =====================================================================================================
+// A launch of few large windows (W = 20 / 30: one 512-thread workgroup per window and CU) leaves most of the chip idle while
+// each window spends half its time in phases that are parallel over factors or tiles. With `coop` > 1 a window gets that
+// many workgroups (all resident at once: the launcher only asks for it when windows x coop fits the CUs, and maps the
+// members of a window to one XCD so that they meet in one L2). Member 0 (the owner) runs the solve as before; at a parallel
+// phase it publishes the phase's inputs in the window's scratch, posts a command, takes its own share, waits for the others
+// and merges. The helpers idle on the command word between phases (s_sleep). Shared phases: the projection factors of a
+// linearization (Jacobian-row chunks round-robin over the members; partial sums merged by the owner) and the landmark Schur
+// complement of the general path (tile pairs round-robin; every tile of App -- global scratch in this variant -- has one
+// writer). Everything serial (band / pose factorization, trust-region logic, marginalization) stays with the owner.
+// Ordering: payload stores, workgroup barrier, device-scope fence, flag store by one lane | flag load by one lane, barrier,
+// device-scope fence by EVERY wave (their vector L1 may hold the previous round's lines), payload loads.
+enum CoopCmd { COOP_EXIT = 1, COOP_EVAL = 2, COOP_SCHUR = 3 };
+constexpr int kCoopMax = 4;
+struct CoopLayout {
+  size_t o_pose, o_feat, o_ex, o_einv, o_tf, o_part, part, total;  // (doubles; [0, 8) are the flag words)
+  size_t p_gp, p_ppd, p_f, p_cost;                                 // inside one helper's partial record
+  static VIO_HD CoopLayout make(int Pcap, int Fcap, int nblk_cap) {
+    CoopLayout L;
+    auto up = [](size_t n) { return (n + 7) & ~(size_t)7; };
+    size_t o = 8;
+    L.o_pose = o, o += up(7 * (size_t)(Pcap + 1));
+    L.o_feat = o, o += up((size_t)Fcap);
+    L.o_ex = o, o += 8;
+    L.o_einv = o, o += up((size_t)Fcap);
+    L.o_tf = o, o += up((size_t)Fcap);
+    size_t q = 0;
+    L.p_gp = q, q += up((size_t)nblk_cap * kBS);
+    L.p_ppd = q, q += up(36 * (size_t)(Pcap + 1));
+    L.p_f = q, q += 8 * up((size_t)Fcap);  // hff, gf, six host-coupling accumulators
+    L.p_cost = q, q += 8;
+    L.part = q, L.o_part = o, o += (kCoopMax - 1) * q;
+    L.total = o;
+    return L;
+  }
+};
+#ifndef VIO_HOST_BUILD
+__device__ __forceinline__ unsigned *coop_flags(const WinView &v) { return reinterpret_cast<unsigned *>(v.coop); }
+// (a wait that never ends would hang the device: after ~2^24 polls the error word is set and everybody moves on -- the solve
+// is then wrong and says so in its termination code)
+__device__ __forceinline__ void coop_spin(unsigned *word, unsigned want_at_least, unsigned *err, bool exact_seq) {
+  unsigned n = 0;
+  for (;;) {
+    const unsigned x = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (exact_seq ? (x >> 4) >= want_at_least : x >= want_at_least) break;
+    __builtin_amdgcn_s_sleep(8);
+    if (++n > (1u << 24)) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+// owner: every work-item has stored its part of the payload -> post command `code`
+VIO_DEV void coop_post(const Ctx &cx, const WinView &v, int code) {
+  __syncthreads();
+  cx.coop_seq++;
+  if (cx.tid == 0) {
+    __threadfence();
+    __hip_atomic_store(coop_flags(v), (cx.coop_seq << 4) | (unsigned)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// owner: until every helper has completed the commands posted so far; then their stores are visible to every work-item
+VIO_DEV void coop_wait_helpers(const Ctx &cx, const WinView &v) {
+  if (cx.tid == 0) coop_spin(coop_flags(v) + 1, cx.coop_seq * (unsigned)(cx.coop - 1), coop_flags(v) + 2, false);
+  __syncthreads();
+  __threadfence();
+}
+// helper: the next command (its inputs are visible to every work-item on return)
+VIO_DEV int coop_wait_cmd(const Ctx &cx, const WinView &v) {
+  cx.coop_seq++;
+  if (cx.tid == 0) coop_spin(coop_flags(v), cx.coop_seq, coop_flags(v) + 2, true);
+  __syncthreads();
+  __threadfence();
+  return (int)(__hip_atomic_load(coop_flags(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u);
+}
+// helper: every work-item has stored its results -> count this workgroup as done with the command
+VIO_DEV void coop_done(const Ctx &cx, const WinView &v) {
+  __syncthreads();
+  if (cx.tid == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(coop_flags(v) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#endif
 
 // ---- block reductions: every thread receives the same value ------------------------------------------------------
 // Wave level on the DPP network (row_shr 1/2/4/8, row_bcast 15/31; total in lane 63, broadcast through SGPRs), block
@@ -1219,7 +1311,7 @@ constexpr int kGSlot = 2 * kGRow + 1;
 // Per-feature sums (host coupling w_h, H_ff, g_f) are gathered by one thread per feature. Returns the cost partial.
 template <class WK>
 VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pose, cldsd feat,
-                               bool /*later_eval*/) {
+                               bool /*later_eval*/, int share = 0, int nshare = 1, bool host_tail = true) {
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
   auto G = w.stage;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
@@ -1230,7 +1322,9 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
   // scratch of the previous linear solve are all recomputed before their next use): see evaluate().
   ldsd whv[6] = {w.cfeat, w.stf, w.gnf, w.tf, w.ef, w.einv};
-  for (int c0 = 0; c0 < v.nslots; c0 += CH) {
+  // (cooperative windows: chunk share, share + nshare, ... -- the host packer keeps a bucket inside one chunk, so every
+  // bucket's off-diagonal block still has one writer)
+  for (int c0 = share * CH; c0 < v.nslots; c0 += nshare * CH) {
     stamp(cx, ST_P_ZERO);
     const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
     VIO_PARFOR(slot, nsl) {  // slot order: every lane of every wave has a factor (bar the odd tails)
@@ -1369,6 +1463,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
     stamp(cx, ST_P_GRAM);
     stamp(cx, ST_P_FEAT);
   }
+  if (!host_tail) return cost;  // (cooperative windows: the owner writes it after the partial sums are merged)
   // host-frame coupling of every feature: LDS sums -> both layouts of W
   VIO_PARFOR(f, v.F) {
     const int h = w.fh[f];
@@ -1413,7 +1508,41 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
     if (v.nrev) VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
     VIO_PARFOR(q, nF * 36) w.ppd[q] = 0.0;
     VIO_SYNC();
-    cost += projections_jac(cx, v, w, pose, feat, have_scale);
+#ifndef VIO_HOST_BUILD
+    if (cx.coop > 1) {
+      // cooperative window: the evaluation point goes to the window's scratch, every workgroup stages and multiplies the
+      // Jacobian-row chunks of its share; the owner then adds the helpers' partial sums (gradient, diagonal pose blocks,
+      // per-landmark sums, cost) to its own and writes the landmarks' host-frame coupling, which needs the complete sums
+      const CoopLayout L = CoopLayout::make(v.Pcap, v.Fcap, v.nblk_cap);
+      const int nFr = v.P + v.has_loop;
+      VIO_PARFOR(q, 7 * nFr) v.coop[L.o_pose + q] = pose[q];
+      VIO_PARFOR(q, v.F) v.coop[L.o_feat + q] = feat[q];
+      VIO_PARFOR(q, 7) v.coop[L.o_ex + q] = w.ex[q];
+      coop_post(cx, v, COOP_EVAL);
+      cost += projections_jac(cx, v, w, pose, feat, have_scale, 0, cx.coop, false);
+      coop_wait_helpers(cx, v);
+      ldsd whv[6] = {w.cfeat, w.stf, w.gnf, w.tf, w.ef, w.einv};
+      const size_t fs = ((size_t)v.Fcap + 7) & ~(size_t)7;
+      for (int m = 1; m < cx.coop; m++) {
+        const double *pr = v.coop + L.o_part + (size_t)(m - 1) * L.part;
+        VIO_PARFOR(q, np) w.gp[q] += pr[L.p_gp + q];
+        VIO_PARFOR(q, nFr * 36) w.ppd[q] += pr[L.p_ppd + q];
+        VIO_PARFOR(f, v.F) {
+          w.hff[f] += pr[L.p_f + f], w.gf[f] += pr[L.p_f + fs + f];
+#pragma unroll
+          for (int c = 0; c < 6; c++) whv[c][f] += pr[L.p_f + (2 + c) * fs + f];
+        }
+        if (cx.tid == 0) cost += pr[L.p_cost];
+      }
+      VIO_SYNC();
+      VIO_PARFOR(f, v.F) {
+        const int h = w.fh[f];
+        if (h >= 0)
+          for (int c = 0; c < 6; c++) v.WTf[(size_t)f * v.n6cap + 6 * h + c] = whv[c][f];
+      }
+    } else
+#endif
+      cost += projections_jac(cx, v, w, pose, feat, have_scale);
     stamp(cx, ST_EVAL_PROJ);
     // ---- the rest of the linearization in three barrier intervals, every global fetch of an interval in flight at once
     //      (each dependent round trip costs ~3.5 k cycles here; the first versions took six of them, one phase at a time):
@@ -1846,6 +1975,67 @@ VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int
   }
 }
 
+// The landmark Schur term of the general path (more than 5 tile rows: one wave per tile pair, K = F in chunks of 12 k-steps)
+// and the right-hand side row: App -= (W E^-1) W^T, App[n6][:] -= W (g_f / E_f). share / nshare: the tile pairs and right-hand
+// side items of THIS workgroup of a cooperative window (every tile has one writer; App is global scratch in this variant).
+template <class WK>
+VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
+  const int n6 = v.n6, F = v.F;
+  const int T = (n6 + 15) / 16, npairs = T * (T + 1) / 2;
+  const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int ksteps = (F + 3) / 4;
+  for (int p = share * nw + wave; p < npairs; p += nshare * nw) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
+    const int tj = p - ti * (ti + 1) / 2;
+    const int ra = 16 * ti + li, rb = 16 * tj + li;
+    const bool va = ra < n6, vb = rb < n6;
+    const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
+    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
+    for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
+      double av[kChunk], bv[kChunk], ev[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
+        const int f = 4 * (s0 + j) + kq;
+        const int fc = (f < F && s0 + j < ksteps) ? f : 0;
+        av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kChunk; j++) {
+        const int f = 4 * (s0 + j) + kq;
+        const bool vf = f < F && s0 + j < ksteps;
+        av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
+    }
+    acc += acc1;
+    const int bcol = 16 * tj + li;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {  // (one wave per tile: plain read-modify-write)
+      const int arow = 16 * ti + kq + 4 * r;
+      if (arow < n6 && bcol <= arow) w.App[tri_at(arow, bcol)] -= acc[r];
+    }
+  }
+  stamp(cx, ST_SCHUR);
+  // rhs_p -= sum_f W_f (g_f / E_f): (row, feature-chunk) items
+  const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
+  for (int q = share * (int)cx.nt + VIO_TID(cx); q < n6 * nch; q += nshare * (int)cx.nt) {
+    int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
+    int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
+    double x[kWStrip], sacc = 0;
+    const int nb = f1 - f0;  // <= kWStrip by the choice of nch
+    if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
+    wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
+#pragma unroll
+    for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
+    VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -sacc);
+  }
+}
+
 // In place: (H + mu C) on the diagonals, then the landmark Schur term  App -= (W E^-1) W^T  and the right-hand side row
 // App[n6][:] = g_p - W (g_f / E_f). Returns false if some E_f <= 0.
 template <class WK>
@@ -1890,55 +2080,18 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
                     [&](int arow, int bcol, double val) { VIO_ATOMIC_ADD(w.App + tri_at(arow, bcol), -val); },
                     [&](int a, double val) { VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -val); });
     } else {
-      for (int p = wave; p < npairs; p += nw) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
-        const int tj = p - ti * (ti + 1) / 2;
-        const int ra = 16 * ti + li, rb = 16 * tj + li;
-        const bool va = ra < n6, vb = rb < n6;
-        const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
-        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
-        for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
-          double av[kChunk], bv[kChunk], ev[kChunk];
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
-            const int f = 4 * (s0 + j) + kq;
-            const int fc = (f < F && s0 + j < ksteps) ? f : 0;
-            av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) {
-            const int f = 4 * (s0 + j) + kq;
-            const bool vf = f < F && s0 + j < ksteps;
-            av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
-          }
-#pragma unroll
-          for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
-        }
-        acc += acc1;
-        const int bcol = 16 * tj + li;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {  // (one wave per tile: plain read-modify-write)
-          const int arow = 16 * ti + kq + 4 * r;
-          if (arow < n6 && bcol <= arow) w.App[tri_at(arow, bcol)] -= acc[r];
-        }
-      }
-      stamp(cx, ST_SCHUR);
-      // rhs_p -= sum_f W_f (g_f / E_f): (row, feature-chunk) items
-      const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
-      VIO_PARFOR(q, n6 * nch) {
-        int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
-        int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
-        double x[kWStrip], sacc = 0;
-        const int nb = f1 - f0;  // <= kWStrip by the choice of nch
-        if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
-        wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
-#pragma unroll
-        for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
-        VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -sacc);
-      }
+#ifndef VIO_HOST_BUILD
+      if (cx.coop > 1) {
+        // cooperative window: the helpers need 1 / E_f and g_f / E_f (the matrix and W are global); every workgroup takes its
+        // share of the tile pairs, the owner goes on when all of them are done
+        const CoopLayout L = CoopLayout::make(v.Pcap, v.Fcap, v.nblk_cap);
+        VIO_PARFOR(f, F) v.coop[L.o_einv + f] = w.einv[f], v.coop[L.o_tf + f] = w.tf[f];
+        coop_post(cx, v, COOP_SCHUR);
+        schur_general(cx, v, w, 0, cx.coop);
+        coop_wait_helpers(cx, v);
+      } else
+#endif
+        schur_general(cx, v, w, 0, 1);
     }
   }
   VIO_SYNC();
@@ -3002,6 +3155,59 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
   }
   VIO_SYNC();
 }
+
+#ifndef VIO_HOST_BUILD
+// A helper workgroup of a cooperative window (member >= 1): serves the owner's commands until COOP_EXIT. Its LDS has the
+// owner's layout; it only ever touches the staging area, the evaluation point and the accumulators of its partial sums.
+template <class WK>
+VIO_DEV void coop_helper(const Ctx &cx, const WinView &v, WK &w) {
+  const CoopLayout L = CoopLayout::make(v.Pcap, v.Fcap, v.nblk_cap);
+  const int np = v.np, F = v.F, nFr = v.P + v.has_loop;
+  const size_t fs = ((size_t)v.Fcap + 7) & ~(size_t)7;
+  double *part = v.coop + L.o_part + (size_t)(cx.member - 1) * L.part;
+  for (;;) {
+    const int cmd = coop_wait_cmd(cx, v);
+    if (cmd == COOP_EVAL) {
+      VIO_PARFOR(q, 7 * nFr) w.xpose[q] = v.coop[L.o_pose + q];
+      VIO_PARFOR(q, F) w.xfeat[q] = v.coop[L.o_feat + q];
+      VIO_PARFOR(q, 7) w.ex[q] = v.coop[L.o_ex + q];
+      VIO_PARFOR(q, np) w.gp[q] = 0.0;
+      VIO_PARFOR(q, F) {
+        w.gf[q] = 0.0, w.hff[q] = 0.0;
+        w.cfeat[q] = w.stf[q] = w.gnf[q] = w.tf[q] = w.ef[q] = w.einv[q] = 0.0;
+      }
+      VIO_PARFOR(q, nFr * 36) w.ppd[q] = 0.0;
+      VIO_SYNC();
+      VIO_PARFOR(i, nFr + 1) {  // rotation matrices (evaluate())
+        const bool is_ex = i == nFr;
+        double R[9];
+        if (is_ex) qtoR(Quat{w.ex[3], w.ex[4], w.ex[5], w.ex[6]}, R);
+        else qtoR(Quat{w.xpose[7 * i + 3], w.xpose[7 * i + 4], w.xpose[7 * i + 5], w.xpose[7 * i + 6]}, R);
+        auto dst = w.rot + 9 * (is_ex ? v.P + 1 : i);
+        for (int k = 0; k < 9; k++) dst[k] = R[k];
+      }
+      VIO_SYNC();
+      const double cost = block_sum(cx, projections_jac(cx, v, w, w.xpose, w.xfeat, true, cx.member, cx.coop, false));
+      ldsd whv[6] = {w.cfeat, w.stf, w.gnf, w.tf, w.ef, w.einv};
+      VIO_PARFOR(q, np) part[L.p_gp + q] = w.gp[q];
+      VIO_PARFOR(q, nFr * 36) part[L.p_ppd + q] = w.ppd[q];
+      VIO_PARFOR(f, F) {
+        part[L.p_f + f] = w.hff[f], part[L.p_f + fs + f] = w.gf[f];
+#pragma unroll
+        for (int c = 0; c < 6; c++) part[L.p_f + (2 + c) * fs + f] = whv[c][f];
+      }
+      if (cx.tid == 0) part[L.p_cost] = cost;
+    } else if (cmd == COOP_SCHUR) {
+      VIO_PARFOR(f, F) w.einv[f] = v.coop[L.o_einv + f], w.tf[f] = v.coop[L.o_tf + f];
+      VIO_SYNC();
+      schur_general(cx, v, w, cx.member, cx.coop);
+    } else {
+      break;  // COOP_EXIT (or a timed-out wait)
+    }
+    coop_done(cx, v);
+  }
+}
+#endif
 
 // =====================================================================================================
 // Whole solve for one window: load, setup, minimize, raw outputs, new2old, outputs

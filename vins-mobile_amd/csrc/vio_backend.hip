@@ -38,7 +38,17 @@ constexpr size_t kLdsHalf = vio::kLdsBytes / 2;   // two resident workgroups per
 template <bool LDS_MATRIX, bool LDS_ASP, int NT>
 __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int b = B.order ? B.order[blockIdx.x] : (int)blockIdx.x;
+  // Cooperative windows (B.coop > 1 workgroups per window, solver_core.h): the members of window i are the blocks
+  // 8 coop (i / 8) + 8 m + i % 8 -- workgroups go to the XCDs round-robin by block index, so the members of a window share
+  // an XCD and meet in its L2.
+  const int coop = LDS_MATRIX ? 1 : B.coop;
+  int widx = (int)blockIdx.x, member = 0;
+  if (coop > 1) {
+    const int grp = (int)blockIdx.x / (8 * coop), r = (int)blockIdx.x - grp * 8 * coop;
+    member = r >> 3, widx = grp * 8 + (r & 7);
+    if (widx >= B.n_launch) return;  // (the last group of eight is padded)
+  }
+  const int b = B.order ? B.order[widx] : widx;
   WinView v = make_view(B, b);
   typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
   typedef typename std::conditional<LDS_MATRIX && LDS_ASP, ldsd, double *>::type AspP;
@@ -65,6 +75,11 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   if (MP.prof_tid == 0) cx.prof_tid = ((NT / 64 - cx.wrot) & (NT / 64 - 1)) * 64;
   else cx.prof_tid = (((MP.prof_tid >> 6) - cx.wrot) & (NT / 64 - 1)) * 64;
   cx.red = cw.red, cx.lprof = cw.lprof;
+  cx.coop = coop, cx.member = member;
+  if (!LDS_MATRIX && member > 0) {
+    coop_helper(cx, v, w);
+    return;
+  }
   const size_t state_end = cw.state_end_doubles;
   // (the window index as an opaque scalar: the view a phase asks for is derived again from the kernel's arguments)
   auto fresh = [&]() {
@@ -84,6 +99,10 @@ __global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs
   if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
   MargWorkT<MatP> mw = carve_marg_all<MatP>(B.d, LDS_MATRIX, lds + state_end, mo.scratch, (size_t)lds_doubles - state_end).m;
   __syncthreads();
+  if (coop > 1) {  // the helpers go home (the marginalization below is the owner's alone)
+    coop_post(cx, v, COOP_EXIT);
+    if (cx.tid == 0 && coop_flags(v)[2]) v.stats_i[1] = -9;  // (a wait between the workgroups of this window timed out)
+  }
   marginalize_window_impl(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
   if (cx.prof && cx.tid == cx.prof_tid) {  // stage counters: LDS -> global
     cx.lprof[ST_TOTAL] += clock64();
@@ -170,6 +189,7 @@ struct vio_backend {
   size_t lds_bytes = 0;
   int threads_lds = kThreadsLds;
   int n_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  bool coop_ok = false;  // the global-matrix windows of the uploaded batch may run as cooperative windows (host-packed, no bucket across chunks)
   DevBuf<long long> d_prof;
   // phase path (phase_core.h): the solve as a sequence of launches; state that lives across them
   bool use_phase = false;
@@ -437,7 +457,7 @@ static int bind_work_buffers(vio_backend *be, const BatchDims &d, const BatchStr
   (void)s;
   const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
   BatchPtrs &B = be->B;
-  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr;
+  B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr, B.coop = 1, B.n_launch = 0;
   B.phase = be->use_phase ? be->d_phase.p : nullptr, B.PL = PL;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
   B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
@@ -547,15 +567,24 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     const bool lds_shape = pose_jp(d) <= 16 * kPanelTiles;
     // (bucket alignment to the staging chunk only serves the single-launch kernel; the phase path walks the slots in strips)
     const int chunk = be->use_phase && be->n_glb == 0 ? 0 : stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
+    // (windows of the global-matrix launch have their own layout and chunk; a cooperative launch needs every bucket inside a chunk)
+    const int chunk_glb = be->n_glb > 0 ? stage_chunk_slots(be->d_glb, false, kThreadsGlb) : 0;
+    std::vector<char> glb(n, 0), strad(n, 0);
+    for (size_t i = (size_t)n_lds; i < order.size(); i++) glb[order[i]] = 1;
     vio::HostPool::get().parallel_for(n, [&](int b) {
       try {
-        rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0, chunk);
+        bool st_ = false;
+        rcs[b] = pack_window(be->hb, b, windows[b], be->slot_of[b] >= 0, glb[b] ? chunk_glb : chunk, &st_);
+        strad[b] = st_ ? 1 : 0;
       } catch (const std::bad_alloc &) {  // (worker thread: must not unwind out of the pool)
         rcs[b] = VIO_ENOMEM;
       }
     });
     for (int b = 0; b < n; b++)
       if (rcs[b] != VIO_OK) return rcs[b];
+    be->coop_ok = be->n_glb > 0;
+    for (int b = 0; b < n; b++)
+      if (glb[b] && strad[b]) be->coop_ok = false;
   }
   const double t1 = now_ms();
   const BatchStrides &s = be->hb.s;
@@ -675,7 +704,25 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
     Bg.d = be->d_glb, Bg.order = be->d_order.p + be->n_lds;
-    hipLaunchKernelGGL((vio_window_kernel<false, false, kThreadsGlb>), dim3(be->n_glb), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
+    // Cooperative windows (solver_core.h): few large windows leave most CUs idle -- a window gets 2 or 4 workgroups when all of
+    // them fit the chip at once (one per CU: this variant's workgroup takes more than half a CU's LDS). VIO_AMD_COOP = 1 / 2 / 4
+    // forces the width (1: off). The profiling clock follows one workgroup per window: off while it runs.
+    int coop = 1;
+    if (be->coop_ok && !be->MP.prof && be->lds_bytes_glb > kLdsHalf) {
+      static const int forced = getenv("VIO_AMD_COOP") ? atoi(getenv("VIO_AMD_COOP")) : 0;
+      const int cus = be->n_cus / std::max(1, be->peers);
+      const int groups = (be->n_glb + 7) / 8;  // (grids are padded to whole groups of eight windows: the XCD mapping)
+      coop = groups * 8 * 4 <= cus ? 4 : groups * 8 * 2 <= cus ? 2 : 1;
+      if (forced >= 1 && forced <= vio::kCoopMax && groups * 8 * forced <= be->n_cus) coop = forced;
+    }
+    Bg.coop = coop, Bg.n_launch = be->n_glb;
+    int grid = be->n_glb;
+    if (coop > 1) {
+      grid = (be->n_glb + 7) / 8 * 8 * coop;
+      // flag words of every window of the batch: command, completions, error (the first 32 bytes of the cooperative area)
+      HIP_OK(hipMemset2DAsync(be->d_scratch.p + be->B.s.s_coop, be->B.s.scratch * sizeof(double), 0, 32, (size_t)be->B.n, st));
+    }
+    hipLaunchKernelGGL((vio_window_kernel<false, false, kThreadsGlb>), dim3(grid), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
                        (int)(be->lds_bytes_glb / sizeof(double)));
   }
   HIP_OK(hipGetLastError());
