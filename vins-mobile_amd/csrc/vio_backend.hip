@@ -712,7 +712,10 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
       static const int forced = getenv("VIO_AMD_COOP") ? atoi(getenv("VIO_AMD_COOP")) : 0;
       const int cus = be->n_cus / std::max(1, be->peers);
       const int groups = (be->n_glb + 7) / 8;  // (grids are padded to whole groups of eight windows: the XCD mapping)
-      coop = groups * 8 * 4 <= cus ? 4 : groups * 8 * 2 <= cus ? 2 : 1;
+      // (measured, profiles/r05_*_large_windows.txt: four members pay at W = 30 up to a full chip, at W = 20 only while half the
+      // CUs stay free -- with every CU busy the shared phases of 64 windows hit the memory system together)
+      const bool four = groups * 8 * 4 <= cus && (be->d_glb.Wcap >= 24 || groups * 8 * 8 <= cus);
+      coop = four ? 4 : groups * 8 * 2 <= cus ? 2 : 1;
       if (forced >= 1 && forced <= vio::kCoopMax && groups * 8 * forced <= be->n_cus) coop = forced;
     }
     Bg.coop = coop, Bg.n_launch = be->n_glb;
