@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
 
 
 def algorithmic_flops_per_solve(W, M, n_prior, iters, n_features=150):
@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--publish-every", type=int, default=1,
                     help="aid: publish (detect + solve) only every N-th frame like the app's FREQ = 3; with N != 1 the "
                          "reported value is NOT the benchmark metric, which publishes and solves every frame")
+    ap.add_argument("--leg", choices=["configs2", "configs4"], default=None,
+                    help="profiling aid: run ONE secondary leg (BASELINE configs[2] / configs[4] end to end) and print its record")
     ap.add_argument("--only", choices=["both", "frontend", "backend"], default="both",
                     help="profiling aid: run one half alone (the reported value is then NOT the benchmark metric)")
     args = ap.parse_args()
@@ -128,6 +130,10 @@ def main():
 
     pkg = importlib.import_module("vins-mobile_amd")
     abi, synth, backend, frontend = pkg.abi, pkg.synth, pkg.backend, pkg.frontend
+    if args.leg:
+        print(json.dumps(config_leg(pkg, {"configs2": "configs[2]", "configs4": "configs[4]"}[args.leg], steps=args.steps, warmup=args.warmup,
+                                    cpu_frames=0 if args.no_cpu_baseline else 12)))
+        return
 
     S = args.sequences
     cfg = abi.default_config(max_corners=150, min_dist=20)  # 150 features need MIN_DIST 20 at 640x480
@@ -191,7 +197,7 @@ def main():
         fe_ms_, _ = fe.kernel_ms()
         be_ms_, _ = be.kernel_ms()
         stats_ = be.download(ws)
-        if args.only != "backend" and S_ == S and not lk_stats:
+        if args.only != "backend" and S_ == S and not lk_stats and not args.quick:  # (--quick: profiling runs keep their kernel trace clean)
             lk_stats.extend(measured_lk_iterations(fe, lambda k: fe.step(pingpong[(warmup + steps + k) % len(pingpong)], publish=True, stream=one)))
         fe.close(), be.close()
         return dt_, max(fe_ms_, 1e-9), max(be_ms_, 1e-9), stats_

@@ -2,7 +2,7 @@
 # usage: gpurun -- 'bash tools/profile_round.sh r03_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -x
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -23,6 +23,12 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_I
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -- $BENCH --only backend --steps 6 --warmup 2 > $O/tcc.log 2>&1
 # the phase path (launch sequence) of the same solve: per-kernel trace, for the gate the round-3 review set
 VIO_AMD_PHASE=1 rocprofv3 --kernel-trace --stats -d $O/kt_phase -- $BENCH --only backend --steps 10 --warmup 2 > $O/bench_kt_phase.log 2>&1
+# BASELINE configs[2] / configs[4] end to end (front-end at 1280x720 / 1920x1080 + the cooperative W = 20 / 30 window solve)
+for leg in configs2 configs4; do
+  rocprofv3 --kernel-trace --stats -d $O/kt_$leg -- python $R/bench.py --leg $leg --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_$leg.log 2>&1
+done
+# instruction cache of the window kernel (one body of ~70 k instructions against 64 KB per CU pair)
+rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES -d $O/ic -- $BENCH --only backend --steps 6 --warmup 2 > $O/ic.log 2>&1
 # the resident estimator path (landmark stores + window assembly on the device): per-kernel trace and timeline of one process
 rocprofv3 --kernel-trace --stats -d $O/kt_res -- python $R/tools/time_estimator.py 512 24 > $O/estimator_kt.log 2>&1
 cd $R
@@ -33,6 +39,9 @@ python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_c
 for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
 python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.txt
 python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
+for leg in configs2 configs4; do python tools/rocpd_summary.py $(db kt_$leg) $O/kernel_trace_$leg.txt > /dev/null; tail -1 $O/bench_$leg.log > $O/bench_$leg.json; done
+python tools/rocpd_pmc_summary.py $(db ic) 2>&1 | grep vio_window >> $O/pmc_sq.txt
+for kb in 8 32 48 64 96 192 384; do $R/tools/microbench/bin/icache_probe_$kb; done > $O/icache_probe.txt 2>&1
 python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 512 sequences, prior 75" \
   --calib $(db calib_fetch) $(db calib_write) --fetch $(db fetch) --write $(db write) > /dev/null 2> $O/pmc_json.err
 python tools/rocpd_summary.py $(db kt_res) $O/kernel_trace_resident_estimator.txt > /dev/null
@@ -51,5 +60,5 @@ $R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
 $R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
+rm -rf $O/kt_configs2 $O/kt_configs4 $O/ic $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
 ls -la $O

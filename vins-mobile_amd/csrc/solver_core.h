@@ -1818,7 +1818,7 @@ VIO_DEV double pose_gd(const WK &w, int i) {
 // (dogleg_strategy.cc:172-192); the first two versions evaluated it after the factorization through L, which forced the
 // fill of the factor to be kept. Uses w.t1 (u_p, frame-major), w.xt (u_p by pose index) and w.tf as scratch.
 template <class WK>
-VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf, bool prepared = false) {
+VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cldsd vf, bool prepared = false, bool w_part = true) {
   const int np = v.np, F = v.F, n6 = v.n6, P = v.P;
   if (!prepared) {  // (prepared: the caller's pass that formed vp also left t1 / xt / tf = 0 behind, barrier included)
     VIO_PARFOR(f, F) w.tf[f] = 0.0;
@@ -1832,7 +1832,8 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
   }
   int nparts, per;
   wt_parts((int)cx.nt, F, n6, nparts, per);
-  VIO_PARFOR(q, F * nparts) {  // (W^T u_p)_f += sum_{a in part} W[f][a] u_p[a]
+  // (w_part = false: the caller takes 2 u_f^T W^T u_p from the Schur sweep that follows, schur_ksplit5; tf stays zero here)
+  if (w_part) VIO_PARFOR(q, F * nparts) {  // (W^T u_p)_f += sum_{a in part} W[f][a] u_p[a]
     const int part = q / F, f = q - part * F;
     const int a0 = part * per, a1 = a0 + per < n6 ? a0 + per : n6;
     double x[kWStrip], sacc = 0;
@@ -1898,7 +1899,7 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
     for (int j = 0; j < 16; j++) s3 = fma(xs[j], j0 + j < n6 ? w.xt[j0 + j] : 0.0, s3);
     acc = fma(2.0 * w.t1[kBS * kpr + 6 + c], s3, acc);
   }
-  VIO_SYNC();  // tf complete
+  if (w_part) VIO_SYNC();  // tf complete
   VIO_PARFOR(f, F) {
     const double u = w.sf[f] * vf[f];
     acc = fma(u, fma(w.hff[f], u, 2.0 * w.tf[f]), acc);
@@ -1911,9 +1912,12 @@ VIO_DEV double quad_form_H(const Ctx &cx, const WinView &v, WK &w, cldsd vp, cld
 // A and B operands are the same 5 loads per k-step (A = W e^-1, B = W), so a chunk of 5 k-steps is 25 global loads (one
 // latency) feeding 75 matrix instructions; the partial results of the waves meet through the callers' atomic adds:
 // flush_tile(row, col <= row, value), flush_rhs(index, value). ge = g_f / E_f.
+// up / tq (optional): the same sweep also leaves tq[f] = sum_a W[f][a] up[a] (the landmark coupling applied to a pose-index
+// vector: the W part of the Cauchy point's quadratic form) -- five multiply-adds and a 16-lane DPP sum per k-step in the
+// shadow of its 15 matrix instructions instead of another pass over W in global memory.
 template <class FT, class FR>
 VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, cldsd ge, FT flush_tile,
-                           FR flush_rhs) {
+                           FR flush_rhs, cldsd up = nullptr, ldsd tq = nullptr) {
   constexpr int kT = 5;  // row tiles the K-split form holds in registers (15 accumulators)
   const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1926,6 +1930,9 @@ VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int
   for (int q = 0; q < kT * (kT + 1) / 2; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int t = 0; t < kT; t++) rp[t] = 0.0;
+  double u5[kT];
+#pragma unroll
+  for (int t = 0; t < kT; t++) u5[t] = (tq && 16 * t + li < n6) ? up[16 * t + li] : 0.0;
   for (int s0 = s_begin; s0 < s_end; s0 += 5) {
     double wv[5][kT], ev[5], gv[5];
 #pragma unroll
@@ -1948,6 +1955,16 @@ VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int
       for (int t = 0; t < kT; t++) {
         wv[j][t] = (vf && 16 * t + li < n6) ? wv[j][t] : 0.0;
         rp[t] = fma(wv[j][t], gv[j], rp[t]);
+      }
+      if (tq) {  // (uniform) row f of W against up: this lane's five columns, then the 16 lanes of the row (total in lane 15)
+        double pq = wv[j][0] * u5[0];
+#pragma unroll
+        for (int t = 1; t < kT; t++) pq = fma(wv[j][t], u5[t], pq);
+        pq += dpp_move_f64<0x111, 0xf>(pq);
+        pq += dpp_move_f64<0x112, 0xf>(pq);
+        pq += dpp_move_f64<0x114, 0xf>(pq);
+        pq += dpp_move_f64<0x118, 0xf>(pq);
+        if (li == 15 && vf) tq[f] = pq;
       }
 #pragma unroll
       for (int ti = 0; ti < kT; ti++) {
@@ -2039,7 +2056,7 @@ VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, in
 // In place: (H + mu C) on the diagonals, then the landmark Schur term  App -= (W E^-1) W^T  and the right-hand side row
 // App[n6][:] = g_p - W (g_f / E_f). Returns false if some E_f <= 0.
 template <class WK>
-VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu) {
+VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double mu, ldsd tq = nullptr) {
   const int np = v.np, F = v.F;
   stamp(cx, ST_TR_VEC);
   // Ceres solves (S H S + mu D^2) y = S g with the Jacobi scaling S and D^2 = clamp(diag(S H S)). The same system in
@@ -2078,7 +2095,7 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     if (T <= kT) {
       schur_ksplit5(cx, v.WTf, v.n6cap, n6, F, w.einv, w.tf,
                     [&](int arow, int bcol, double val) { VIO_ATOMIC_ADD(w.App + tri_at(arow, bcol), -val); },
-                    [&](int a, double val) { VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -val); });
+                    [&](int a, double val) { VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -val); }, w.xt, tq);
     } else {
 #ifndef VIO_HOST_BUILD
       if (cx.coop > 1) {
@@ -2885,7 +2902,8 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
   double min_rec = x_cost;
   record(0, x_cost, radius, 0, 0, gmax, true, true);
   if (cx.tid == 0) sd[0] = x_cost;
-  double gd_sq = 0, mu_used = mu, qf_cauchy = 0;
+  double gd_sq = 0, mu_used = mu, qf_cauchy = 0, qf_part = 0;
+  bool qf_pending = false;  // the W part of the Cauchy point's quadratic form is still to be added (first dogleg step after a solve)
   // a linearization at x is due at the head of the next iteration: after a step that was accepted on a cost-only evaluation
   // (relin_reuse: the raw IMU Jacobians and the prior's dx of that evaluation are still valid; rec_*: the iteration record
   // waits for the gradient norm) or after an invalid step (the matrix buffer holds a factorization)
@@ -2945,7 +2963,11 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         gd_sq = block_sum(cx, part);
       }
       stamp(cx, ST_DOGLEG);
-      const double qf_h = quad_form_H(cx, fresh(), w, w.t2, w.stf, /*prepared=*/true);
+      // (pose matrices of up to five tile rows: the W part of the form, 2 u_f^T W^T u_p, comes out of the Schur sweep of
+      // build_reduced_system -- tq -> cfeat, dead between a linearization and the next Plus -- and joins the reductions of the
+      // dogleg step below: one pass over W in global memory and one barrier less per iteration)
+      const bool fuse_qw = ((v.n6 + 15) >> 4) <= 5;
+      const double qf_h0 = quad_form_H(cx, fresh(), w, w.t2, w.stf, /*prepared=*/true, /*w_part=*/!fuse_qw);
       stamp(cx, ST_QUADFORM);
       // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
       solver_ok = false;
@@ -2958,7 +2980,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;
         VIO_SYNC();
-        bool ok = build_reduced_system(cx, fresh(), w, mu);
+        bool ok = build_reduced_system(cx, fresh(), w, mu, fuse_qw ? w.cfeat : nullptr);
         if (ok) {
           if constexpr (REGS) ok = factor_band_regs<kPanelTiles, NW>(cx, fresh(), w);
           else ok = factor_band_lds(cx, fresh(), w);
@@ -2994,9 +3016,11 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       }
       if (solver_ok) {
         // mu |D a|^2 of the Cauchy direction a = D^-2 S g for the mu the solve ended with: D a = g_d, so it is mu |g_d|^2
-        const double reg = mu_used * gd_sq;
-        qf_cauchy = qf_h + reg;
-        alpha = gd_sq / qf_h;
+        qf_part = qf_h0, qf_pending = fuse_qw;
+        if (!fuse_qw) {
+          qf_cauchy = qf_h0 + mu_used * gd_sq;
+          alpha = gd_sq / qf_h0;
+        }
         stamp(cx, ST_DOGLEG);
       }
     }
@@ -3005,11 +3029,20 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
     double model_cost_change = 0;
     if (solver_ok) {
       // ComputeTraditionalDoglegStep (dogleg_strategy.cc:199-255)
-      double p1 = 0, p2 = 0;
+      double p1 = 0, p2 = 0, p3 = 0;
       VIO_PARFOR(i, np) p1 += w.gnp[i] * w.gnp[i], p2 += pose_gd(w, i) * w.gnp[i];
-      VIO_PARFOR(f, F) p1 += w.gnf[f] * w.gnf[f], p2 += feat_gd(w, f) * w.gnf[f];
-      double pdummy = 0;
-      block_sum3(cx, p1, p2, pdummy);
+      VIO_PARFOR(f, F) {
+        p1 += w.gnf[f] * w.gnf[f], p2 += feat_gd(w, f) * w.gnf[f];
+        // (first step after a solve: u_f (W^T u_p)_f of the Cauchy direction, u_f = s_f^2 g_f / D_f^2, W^T u_p from the Schur sweep)
+        if (qf_pending) p3 += 2.0 * (w.sf[f] * w.sf[f] * w.gf[f] * rcp_f(feat_d2(w, f))) * w.cfeat[f];
+      }
+      block_sum3(cx, p1, p2, p3);
+      if (qf_pending) {
+        const double qf_h = qf_part + p3;
+        qf_cauchy = qf_h + mu_used * gd_sq;
+        alpha = gd_sq / qf_h;
+        qf_pending = false;
+      }
       double gnn2 = p1, gdot = p2;
       double gradient_norm = sqrt(gd_sq), gauss_newton_norm = sqrt(gnn2);
       double ca, cb;
