@@ -291,3 +291,30 @@ def test_odd_shapes_match_oracle(W, F, loop, seed, path):
         lam, V = np.linalg.eigh(Hr)
         keep = V[:, lam > 1e-6 * lam.max()]       # b = J^T r on the well-determined directions
         assert np.abs(keep.T @ (bg - br)).max() <= tol * np.abs(br).max() + 1e-6
+
+
+@pytest.mark.parametrize("name", ["win_c3_w20", "win_c5_w30_a", "win_c5_w30_b_prior_loop"])
+def test_cooperative_windows_match_the_reference(name, monkeypatch):
+    """Large windows (pose matrix in global scratch) solved by 1, 2 and 4 workgroups per window (csrc/solver_core.h, cooperative
+    windows: projection-factor chunks and Schur tile pairs shared, inputs and partial sums through the window's scratch): every
+    width against the reference's golden output, with the reference's accept / reject trace, alone and in a batch whose grid is
+    padded to whole groups of eight windows."""
+    cfg, w, d = H.load_golden_window(name)
+    ref_pose = None
+    for width in (1, 2, 4):
+        monkeypatch.setenv("VIO_AMD_COOP", str(width))
+        solver = pkg.backend.WindowSolver(cfg, max_batch=16)
+        got = w.copy()
+        stats = solver.solve([got])[0]
+        H.check_solution(got, stats, d, tol=TOL, tol_prior=TOL_PRIOR)
+        batch = [w.copy() for _ in range(9)]   # two groups of eight, seven padded blocks per member row
+        bstats = solver.solve(batch)
+        for g, s in zip(batch, bstats):
+            assert s["iterations"] == stats["iterations"] and list(s["it_flags"]) == list(stats["it_flags"])
+            assert H.pose_relerr(g.pose, got.pose) < 1e-9 and H.relerr(g.inv_depth, got.inv_depth) < 1e-9
+        solver.close()
+        if ref_pose is None:
+            ref_pose = np.asarray(got.pose).copy()
+        else:  # the widths differ in summation order only
+            assert H.pose_relerr(got.pose, ref_pose) < 1e-8, width
+

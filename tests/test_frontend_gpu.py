@@ -219,3 +219,27 @@ def test_good_features_mask_image_odd_size():
         ref = H.oracle_good_features(cfg, frames[0], mask, 80)
         assert np.array_equal(got, ref)
     assert len(got) > 10
+
+
+def test_lk_iteration_counters():
+    """vio_frontend_lk_iterations: the counting variant of the LK kernel reports, per pyramid level, one visit per (tracked
+    feature, level) and between 1 and lk_max_iters iterations per visit; the tracker's results do not depend on it."""
+    cfg = abi.default_config(max_corners=80, min_dist=20, image_rows=240, image_cols=320)
+    frames = synth.make_image_stream(5, 4, rows=240, cols=320)[0]
+    a, b = fe.FeatureTracker(cfg, n_seq=1), fe.FeatureTracker(cfg, n_seq=1)
+    a.lk_iterations(enable=True, read=True)
+    n_tracked = 0
+    for f in range(4):
+        ga = a.read_images(frames[f:f + 1], True)[0]
+        gb = b.read_images(frames[f:f + 1], True)[0]
+        assert np.array_equal(ga[0], gb[0]) and np.array_equal(ga[1], gb[1])
+        if f < 3:
+            n_tracked += len(a.state(0)[1])   # the points the next frame's LK call starts from
+    it, vis = a.lk_iterations(enable=False, read=True)
+    levels = int((vis > 0).sum())
+    assert levels >= 2 and np.all(vis[:levels] == vis[0]) and vis[0] == n_tracked, (vis, n_tracked)
+    mean = it[:levels] / vis[:levels]
+    assert np.all(mean >= 1.0) and np.all(mean <= cfg.lk_max_iters), mean
+    it2, vis2 = a.lk_iterations(read=True)
+    assert it2.sum() == 0 and vis2.sum() == 0   # reading resets
+    a.close(), b.close()

@@ -709,7 +709,8 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
     // forces the width (1: off). The profiling clock follows one workgroup per window: off while it runs.
     int coop = 1;
     if (be->coop_ok && !be->MP.prof && be->lds_bytes_glb > kLdsHalf) {
-      static const int forced = getenv("VIO_AMD_COOP") ? atoi(getenv("VIO_AMD_COOP")) : 0;
+      const char *fe_ = getenv("VIO_AMD_COOP");  // (read per launch: tests switch it within one process)
+      const int forced = fe_ ? atoi(fe_) : 0;
       const int cus = be->n_cus / std::max(1, be->peers);
       const int groups = (be->n_glb + 7) / 8;  // (grids are padded to whole groups of eight windows: the XCD mapping)
       // (measured, profiles/r05_*_large_windows.txt: four members pay at W = 30 up to a full chip, at W = 20 only while half the

@@ -586,9 +586,10 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       }
       pdx = ddx, pdy = ddy;
     }
-    if (STATS && lane == 0) {
-      atomicAdd(stats + level, (unsigned long long)nit);
-      atomicAdd(stats + P.ld.levels + level, 1ull);
+    if (STATS && lane == 0) {  // (64 copies of the counters, picked by block: one address would serialize every wave of the launch)
+      unsigned long long *sl = stats + ((blockIdx.x + 7 * blockIdx.y) & 63) * 16;
+      atomicAdd(sl + level, (unsigned long long)nit);
+      atomicAdd(sl + P.ld.levels + level, 1ull);
     }
     if (st && level == 0) {
       float ex = nxx - half, ey = nxy - half;
@@ -1684,7 +1685,7 @@ struct vio_frontend {
   int nseg = 0, seg_cap = 0;  // candidate list: one segment per strip of kDetR rows
   int *n_cand = nullptr;
   float *cur_pts = nullptr, *pre_pts = nullptr, *forw_pts = nullptr, *lk_err = nullptr;
-  unsigned long long *lk_stats = nullptr;  // [2 * 8] iteration counters of lk_track_kernel (vio_frontend_lk_iterations)
+  unsigned long long *lk_stats = nullptr;  // [64][16] iteration counters of lk_track_kernel (vio_frontend_lk_iterations)
   bool lk_stats_on = false;
   int *ids = nullptr, *track_cnt = nullptr, *n_pts = nullptr, *n_forw = nullptr, *n_id = nullptr, *kept_xy = nullptr,
       *n_kept = nullptr, *hw = nullptr, *n_obs = nullptr, *pnp_ids = nullptr, *n_pnp = nullptr;
@@ -2272,7 +2273,7 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int3
 int vio_frontend_lk_iterations(vio_frontend_t *fe, int32_t enable, uint64_t *iterations, uint64_t *visits, int32_t levels_cap) {
   if (!fe || (iterations && (!visits || levels_cap < 1))) return VIO_EINVAL;
   VIO_ON_DEVICE_OF(fe);
-  constexpr int kSlots = 16;
+  constexpr int kSlots = 16 * 64;  // 64 copies of [iterations (levels) | visits (levels)], summed here
   if (!fe->lk_stats) {
     if (dev_alloc(&fe->lk_stats, (size_t)kSlots) != VIO_OK) return VIO_ENOMEM;
     HIP_OK(hipMemset(fe->lk_stats, 0, sizeof(unsigned long long) * kSlots));
@@ -2282,7 +2283,10 @@ int vio_frontend_lk_iterations(vio_frontend_t *fe, int32_t enable, uint64_t *ite
     unsigned long long h[kSlots];
     HIP_OK(hipMemcpy(h, fe->lk_stats, sizeof(h), hipMemcpyDeviceToHost));
     const int L = fe->ld.levels;
-    for (int l = 0; l < levels_cap; l++) iterations[l] = l < L ? h[l] : 0, visits[l] = l < L ? h[L + l] : 0;
+    for (int l = 0; l < levels_cap; l++) {
+      iterations[l] = visits[l] = 0;
+      for (int c = 0; c < 64 && l < L; c++) iterations[l] += h[16 * c + l], visits[l] += h[16 * c + L + l];
+    }
     HIP_OK(hipMemset(fe->lk_stats, 0, sizeof(h)));
   }
   if (enable >= 0) fe->lk_stats_on = enable != 0;
