@@ -137,6 +137,8 @@ def main():
 
     S = args.sequences
     cfg = abi.default_config(max_corners=150, min_dist=20)  # 150 features need MIN_DIST 20 at 640x480
+    if os.environ.get("VIO_BENCH_MAX_ITER"):  # diagnostics only (tools/profile_round.sh: instructions per trust-region iteration = the
+        cfg.max_iterations = int(os.environ["VIO_BENCH_MAX_ITER"])  # difference of two PMC passes); not the metric's config
     if os.environ.get("VIO_BENCH_LK_ITERS"):  # diagnostics only (tools/fe_iters.sh): what the LK iterations cost; not the metric's config
         cfg.lk_max_iters = int(os.environ["VIO_BENCH_LK_ITERS"])
     rows, cols = cfg.image_rows, cfg.image_cols

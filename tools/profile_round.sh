@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d $O/sq3 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq3.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM -d $O/sq4 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq4.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_FLAT -d $O/sq5 -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq5.log 2>&1
+# dynamic instruction mix per trust-region iteration: the same counters with 2 instead of 10 iterations (difference / 8)
+VIO_BENCH_MAX_ITER=2 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -d $O/sq3b -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq3b.log 2>&1
+VIO_BENCH_MAX_ITER=2 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/sq4b -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq4b.log 2>&1
 # L2 hit rate of the window kernel's scratch traffic (requests that hit / miss in the XCD's L2)
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -- $BENCH --only backend --steps 6 --warmup 2 > $O/tcc.log 2>&1
 # the phase path (launch sequence) of the same solve: per-kernel trace, for the gate the round-3 review set
@@ -38,6 +41,7 @@ python tools/rocpd_pmc_summary.py $(db fetch) $(db write) > $O/pmc_hbm.txt 2>&1
 python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_calib.txt 2>&1
 for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
 python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.txt
+for k in 3b 4b; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window | sed 's/^/max_iter=2: /' >> $O/pmc_sq.txt; done
 python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
 for leg in configs2 configs4; do python tools/rocpd_summary.py $(db kt_$leg) $O/kernel_trace_$leg.txt > /dev/null; tail -1 $O/bench_$leg.log > $O/bench_$leg.json; done
 python tools/rocpd_pmc_summary.py $(db ic) 2>&1 | grep vio_window >> $O/pmc_sq.txt
@@ -60,5 +64,5 @@ $R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
 $R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf $O/kt_configs2 $O/kt_configs4 $O/ic $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
+rm -rf $O/sq3b $O/sq4b $O/kt_configs2 $O/kt_configs4 $O/ic $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
 ls -la $O
