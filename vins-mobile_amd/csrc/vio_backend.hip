@@ -20,6 +20,7 @@
 #include "vio_pool.h"
 #include "vio_device.h"
 #include "marg_core.h"
+#include "vio_window_kernel.inc"
 #include "vio_phase.h"
 #include "vio_amd.h"
 
@@ -27,88 +28,11 @@ using namespace vio;
 
 namespace {
 
-constexpr int kThreadsLds = 256, kThreadsGlb = 512;
+using vio_wk::kThreadsGlb;
+using vio_wk::kThreadsLds;
 constexpr size_t kLdsLimit = vio::kLdsBytes;      // one CU
 constexpr size_t kLdsHalf = vio::kLdsBytes / 2;   // two resident workgroups per CU
 
-
-// NT threads; WPE: waves per SIMD the register budget is sized for (2: 256 VGPRs, two 256-thread workgroups or one
-// 512-thread workgroup per CU)
-// LDS_ASP: the IMU speed-bias x pose coupling is in LDS as well (B.d.lds_asp says the same to the layout)
-template <bool LDS_MATRIX, bool LDS_ASP, int NT>
-__global__ __launch_bounds__(NT, 2) void vio_window_kernel(BatchPtrs B, MargPtrs MP, int lds_doubles) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  // Cooperative windows (B.coop > 1 workgroups per window, solver_core.h): the members of window i are the blocks
-  // 8 coop (i / 8) + 8 m + i % 8 -- workgroups go to the XCDs round-robin by block index, so the members of a window share
-  // an XCD and meet in its L2.
-  const int coop = LDS_MATRIX ? 1 : B.coop;
-  int widx = (int)blockIdx.x, member = 0;
-  if (coop > 1) {
-    const int grp = (int)blockIdx.x / (8 * coop), r = (int)blockIdx.x - grp * 8 * coop;
-    member = r >> 3, widx = grp * 8 + (r & 7);
-    if (widx >= B.n_launch) return;  // (the last group of eight is padded)
-  }
-  const int b = B.order ? B.order[widx] : widx;
-  WinView v = make_view(B, b);
-  typedef typename std::conditional<LDS_MATRIX, ldsd, double *>::type MatP;
-  typedef typename std::conditional<LDS_MATRIX && LDS_ASP, ldsd, double *>::type AspP;
-  ldsd lds = (ldsd)smem;
-  // (by value: neither struct ever has its address taken, so both live in registers)
-  // (the layout flag as a compile-time constant: as a run-time value it costs the LDS variant ~80 more scratch reloads)
-  BatchDims dims = B.d;
-  dims.lds_asp = LDS_ASP ? 1 : 0;
-  const Carved<MatP, AspP> cw = carve_all<MatP, AspP>(dims, LDS_MATRIX, blockDim.x, lds, B.hm + (size_t)b * B.s.hm, v.AspG);
-  WorkT<MatP, AspP> w = cw.w;
-  Ctx cx;
-  cx.tid = threadIdx.x, cx.nt = blockDim.x;
-  cx.prof = MP.prof ? MP.prof + (size_t)b * ST_COUNT : nullptr;
-  cx.prof_tid = MP.prof_tid;
-  {
-    // which workgroup slot of its CU this workgroup occupies (HW_ID.TG_ID, bits 19:16): the second workgroup of a CU
-    // rotates its wave roles so that its pivot-chain wave sits on another SIMD than the first one's
-    if (threadIdx.x == 0) cw.w.flag[0] = (int)__builtin_amdgcn_s_getreg(0x1C04) & 3;
-    __syncthreads();
-    cx.wrot = MP.wrot >= 0 ? MP.wrot : (NT == 256 ? cw.w.flag[0] : 0);
-    __syncthreads();
-  }
-  // (the stage clock follows the chain wave: work-item 0 of role 0)
-  if (MP.prof_tid == 0) cx.prof_tid = ((NT / 64 - cx.wrot) & (NT / 64 - 1)) * 64;
-  else cx.prof_tid = (((MP.prof_tid >> 6) - cx.wrot) & (NT / 64 - 1)) * 64;
-  cx.red = cw.red, cx.lprof = cw.lprof;
-  cx.coop = coop, cx.member = member;
-  if (!LDS_MATRIX && member > 0) {
-    coop_helper(cx, v, w);
-    return;
-  }
-  const size_t state_end = cw.state_end_doubles;
-  // (the window index as an opaque scalar: the view a phase asks for is derived again from the kernel's arguments)
-  auto fresh = [&]() {
-    int bb = b;
-    asm volatile("" : "+s"(bb));
-    return make_view(B, bb);
-  };
-  auto fresh_work = [&]() { return w; };  // (the LDS layout derived again per iteration was tried: 5 % slower)
-  solve_window<LDS_MATRIX, NT / 64>(cx, v, w, fresh, fresh_work);
-
-  MargOut mo;
-  int *mi = MP.ints + (size_t)b * MP.s_ints;
-  mo.n = mi, mo.kind = mi + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
-  mo.x0 = MP.x0 + (size_t)b * MP.s_x0, mo.J = MP.J + (size_t)b * MP.s_J, mo.r = MP.r + (size_t)b * MP.s_r;
-  mo.scratch = MP.scratch ? MP.scratch + (size_t)b * MP.s_scratch : nullptr;
-  mo.ncap = B.d.Ncap;
-  if (B.ptab && B.ptab[b].mJ) mo.x0 = B.ptab[b].mx0, mo.J = B.ptab[b].mJ, mo.r = B.ptab[b].mr, mo.ncap = B.ptab[b].ncap;
-  MargWorkT<MatP> mw = carve_marg_all<MatP>(B.d, LDS_MATRIX, lds + state_end, mo.scratch, (size_t)lds_doubles - state_end).m;
-  __syncthreads();
-  if (coop > 1) {  // the helpers go home (the marginalization below is the owner's alone)
-    coop_post(cx, v, COOP_EXIT);
-    if (cx.tid == 0 && coop_flags(v)[2]) v.stats_i[1] = -9;  // (a wait between the workgroups of this window timed out)
-  }
-  marginalize_window_impl(cx, fresh(), w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
-  if (cx.prof && cx.tid == cx.prof_tid) {  // stage counters: LDS -> global
-    cx.lprof[ST_TOTAL] += clock64();
-    for (int q = 0; q < ST_COUNT; q++) cx.prof[q] = cx.lprof[q];
-  }
-}
 
 // Debug aid (VIO_AMD_POISON=1): every launch is preceded by NaN patterns in the whole LDS of every CU and in all device
 // scratch / output buffers, so that a read of something the kernel did not write itself cannot go unnoticed.
@@ -272,10 +196,7 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
   // the dynamic-LDS ceiling is a property of the FUNCTION, not of a launch: raised once to the CU's whole LDS for both
   // variants (several contexts on several host threads launch these kernels; a per-launch value could be lowered by
   // another thread between this thread's set and its launch)
-  if (hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<true, false, kThreadsLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<true, true, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
-      hipFuncSetAttribute((const void *)vio_window_kernel<false, false, kThreadsGlb>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess ||
+  if (vio_wk::window_kernel_attrs<false>((int)kLdsLimit) != hipSuccess || vio_window_attrs_prof((int)kLdsLimit) != hipSuccess ||
       vio::phase_prepare() != VIO_OK) {
     delete be;
     return VIO_ENODEV;
@@ -691,15 +612,9 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
   } else if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    if (be->threads_lds == kThreadsLds && be->d_lds.lds_asp)
-      hipLaunchKernelGGL((vio_window_kernel<true, true, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
-                         (int)(be->lds_bytes / sizeof(double)));
-    else if (be->threads_lds == kThreadsLds)
-      hipLaunchKernelGGL((vio_window_kernel<true, false, kThreadsLds>), dim3(be->n_lds), dim3(kThreadsLds), be->lds_bytes, st, Bl, be->MP,
-                         (int)(be->lds_bytes / sizeof(double)));
-    else
-      hipLaunchKernelGGL((vio_window_kernel<true, true, kThreadsGlb>), dim3(be->n_lds), dim3(kThreadsGlb), be->lds_bytes, st, Bl, be->MP,
-                         (int)(be->lds_bytes / sizeof(double)));
+    const int variant = be->threads_lds == kThreadsLds ? (be->d_lds.lds_asp ? 0 : 1) : 2;
+    if (be->MP.prof) vio_window_launch_prof(variant, be->n_lds, be->lds_bytes, st, Bl, be->MP);
+    else vio_wk::window_kernel_launch<false>(variant, be->n_lds, be->lds_bytes, st, Bl, be->MP);
   }
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
@@ -726,8 +641,8 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
       // flag words of every window of the batch: command, completions, error (the first 32 bytes of the cooperative area)
       HIP_OK(hipMemset2DAsync(be->d_scratch.p + be->B.s.s_coop, be->B.s.scratch * sizeof(double), 0, 32, (size_t)be->B.n, st));
     }
-    hipLaunchKernelGGL((vio_window_kernel<false, false, kThreadsGlb>), dim3(grid), dim3(kThreadsGlb), be->lds_bytes_glb, st, Bg, be->MP,
-                       (int)(be->lds_bytes_glb / sizeof(double)));
+    if (be->MP.prof) vio_window_launch_prof(3, grid, be->lds_bytes_glb, st, Bg, be->MP);
+    else vio_wk::window_kernel_launch<false>(3, grid, be->lds_bytes_glb, st, Bg, be->MP);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ev.second, st));
