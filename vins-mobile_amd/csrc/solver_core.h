@@ -2326,19 +2326,35 @@ constexpr int panel_count() { return panel_slot<NT, NPW, PW>(NT, 0); }
 // The same step for a pose matrix of exactly NT tile rows, specialised for panel wave PW of NPW: the tiles of the wave
 // are a compile-time list, so every accumulator access is one ds_read / ds_write at an immediate offset from one of NT
 // per-lane row bases (the generic form spends ~600 instructions per step on predicates and address arithmetic).
-template <int NT, int NPW, int PW, class WK>
+// (ISPR: block k is the speed-bias block the prior keeps -- one step of a factorization --: its coupling has the prior's dense
+// row in global memory on top of the IMU chain's 18 columns. The common instantiation carries neither the loads nor the selects.)
+template <int NT, int NPW, int PW, bool ISPR, class WK>
 VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane_) {
   const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
   double e[3] = {0.0, 0.0, 0.0}, linv[4], gr[3];
   typedef PanelMap<NT, NPW, PW> Map;
   constexpr int kAcc = panel_count<NT, NPW, PW>();
   v4d acc[kAcc];
-  PanelRaw X[NT];
-  const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
+  double X[NT][3], Xp[NT][3];
   const int rows_last = v.nrows - 16 * (NT - 1);  // rows of the last tile row (the others are full)
+  const int n6 = v.n6, alo = 6 * (k > 0 ? k - 1 : 0);
+  // The IMU chain couples s_k to the 18 pose columns from alo on: two of the five tiles. A tile outside them (and outside the
+  // prior's row, ISPR) is zero except for the right-hand side column (last tile): nothing to fetch, nothing to select.
+  auto touches = [&](int t) { return ISPR || (16 * t + 15 >= alo && 16 * t < alo + kAW); };  // (uniform)
 #pragma unroll
-  for (int t = 0; t < NT; t++)
-    if (Map::needs(t) && t >= tlo) X[t] = panel_fetch(v, w, k, is_pr, t, li, kq);
+  for (int t = 0; t < NT; t++) {
+    if (!(Map::needs(t) && t >= tlo) || !touches(t)) continue;
+    const int j = 16 * t + li;
+    const bool inr = j >= alo && j < alo + kAW && j < n6;
+    const int ao = inr ? j - alo : 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int c = kq + 4 * r < kSB ? kq + 4 * r : 0;
+      if (w.asp_ring) X[t][r] = w.aspring[(k & 1) * kAS + ao + c * kAW];
+      else X[t][r] = w.AspI[k * kAS + ao + c * kAW];
+      if (ISPR) Xp[t][r] = v.Apri[c * v.jp + (j < n6 ? j : 0)];
+    }
+  }
   if (k < v.W) load_op9_raw(w.Css + (k + 1) * kSS, li, kq, e);
   load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
 #pragma unroll
@@ -2363,14 +2379,32 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
   if (k < v.W) mask_op9(li, kq, e);
   mask_linv9(li, kq, linv);
   if (cx.prof) {
-    double probe = linv[0] + e[0] + gr[0] + X[PW == 2 ? NT - 2 : NT - 1].x[0] + X[PW == 2 ? NT - 2 : NT - 1].p[0] + acc[0][0];  // (timing run only: the batch has landed)
+    double probe = linv[0] + e[0] + gr[0] + acc[0][0];  // (timing run only: the batch has landed)
     asm volatile("" ::"v"(probe));
     stamp(cx, ST_D4);
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     if (!Map::needs(t) || t < tlo) continue;
-    v4d Tt = panel_tile(v.n6, k, is_pr, t, li, kq, X[t], gr);
+    // Asp_k^T tile t in accumulator layout: element r = A(s_k[kq + 4 r], pose index 16 t + li); column n6 (last tile) = the
+    // gradient of s_k. Rows kq + 4 r >= 9 only exist for r = 2, kq >= 1.
+    v4d Tt = {0.0, 0.0, 0.0, 0.0};
+    if (touches(t)) {
+      const int j = 16 * t + li;
+      const bool inr = j >= alo && j < alo + kAW && j < n6;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double x = inr ? X[t][r] : 0.0;
+        if (ISPR) x += j < n6 ? Xp[t][r] : 0.0;
+        Tt[r] = x;
+      }
+    }
+    if (t == NT - 1) {  // (the right-hand side column: n6 = 66 or 72 sits in the last tile)
+      const bool isr = 16 * t + li == n6;
+#pragma unroll
+      for (int r = 0; r < 3; r++) Tt[r] = isr ? gr[r] : Tt[r];
+    }
+    Tt[2] = kq == 0 ? Tt[2] : 0.0;
     if (k < v.W) {
 #pragma unroll
       for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t].x[s], Tt);
@@ -2408,7 +2442,12 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (I < NT - 1) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];
-          else if (kq + 4 * r < rows_last) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];
+          else {
+            // (rows past the matrix: the store goes to the padding element behind row 0 of this tile row -- every row is
+            // 16 (I + 1) + 1 long and its last element is never read -- instead of an exec-masked region per store)
+            const int off = kq + 4 * r < rows_last ? 4 * r * tri_ld(I) + 16 * J : 16 * (I + 1) - li - kq * tri_ld(I);
+            rowbase[off] = c[r];
+          }
         }
       }
     }
@@ -2421,9 +2460,16 @@ VIO_DEV void panel_step_dispatch(const Ctx &cx, const WinView &v, WK &w, int k, 
     return;
   }
   if constexpr (NPW == 3) {
-    if (pw == 0) panel_step_static<NT, 3, 0>(cx, v, w, k, tlo, V, lane);
-    else if (pw == 1) panel_step_static<NT, 3, 1>(cx, v, w, k, tlo, V, lane);
-    else panel_step_static<NT, 3, 2>(cx, v, w, k, tlo, V, lane);
+    const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
+    if (is_pr) {
+      if (pw == 0) panel_step_static<NT, 3, 0, true>(cx, v, w, k, tlo, V, lane);
+      else if (pw == 1) panel_step_static<NT, 3, 1, true>(cx, v, w, k, tlo, V, lane);
+      else panel_step_static<NT, 3, 2, true>(cx, v, w, k, tlo, V, lane);
+    } else {
+      if (pw == 0) panel_step_static<NT, 3, 0, false>(cx, v, w, k, tlo, V, lane);
+      else if (pw == 1) panel_step_static<NT, 3, 1, false>(cx, v, w, k, tlo, V, lane);
+      else panel_step_static<NT, 3, 2, false>(cx, v, w, k, tlo, V, lane);
+    }
   } else {
     panel_step_regs<NT, NPW>(cx, v, w, k, tlo, V, lane, pw);
   }
