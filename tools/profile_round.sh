@@ -43,7 +43,7 @@ for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep 
 python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.txt
 for k in 3b 4b; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window | sed 's/^/max_iter=2: /' >> $O/pmc_sq.txt; done
 python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
-for leg in configs2 configs4; do python tools/rocpd_summary.py $(db kt_$leg) $O/kernel_trace_$leg.txt > /dev/null; tail -1 $O/bench_$leg.log > $O/bench_$leg.json; done
+for leg in configs2 configs4; do python tools/rocpd_summary.py $(db kt_$leg) $O/kernel_trace_$leg.txt > /dev/null; grep "^{\"workload\"" $O/bench_$leg.log | tail -1 > $O/bench_$leg.json; done
 python tools/rocpd_pmc_summary.py $(db ic) 2>&1 | grep vio_window >> $O/pmc_sq.txt
 for kb in 8 32 48 64 96 192 384; do $R/tools/microbench/bin/icache_probe_$kb; done > $O/icache_probe.txt 2>&1
 python tools/rocpd_pmc_summary.py --json $O/pmc.json --workload "configs[1] x 512 sequences, prior 75" \
