@@ -1566,23 +1566,78 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
     }
   }
   __syncthreads();
-  const int total = nseg * seg_cap;
-  if (s_cnt > kSelLds) {
-    // more survivors than LDS holds: the greedy selection runs in place over the whole nseg * seg_cap range, so
-    // rejected candidates and the unused tail of every segment are zeroed now
-    for (int i = tid; i < total; i += nt) {
-      int g = i / seg_cap, j = i - g * seg_cap;
-      const bool used = j < s_off[g + 1] - s_off[g];
-      const unsigned long long k = used ? cand[i] : 0;
-      if (!(k && __uint_as_float((unsigned)(k >> 32)) > thr)) cand[i] = 0;
-    }
-    __syncthreads();
-  }
   // this kernel is the only consumer of the per-segment counters: leave them zeroed for the next detection pass
   for (int g = tid; g < nseg; g += nt) n_cand[(size_t)seq * nseg + g] = 0, max_bits[(size_t)seq * nseg + g] = 0;
-  const bool in_lds = s_cnt <= kSelLds;
-  unsigned long long *K = in_lds ? keys : cand;
-  const int nc = in_lds ? s_cnt : total;
+  if (s_cnt > kSelLds) {
+    // More survivors than LDS holds (a cold start at 1280 x 720 / 1920 x 1080: ~10^5 candidates for 300 / 500 corners). The
+    // first versions ran the round loop below over the WHOLE candidate range in HBM -- want x nseg x seg_cap visits, 43 ms /
+    // 170 ms per frame at those sizes. The candidates are already bucketed: segment g holds the local maxima of strip g
+    // (kDetR rows). So: one live maximum per strip in LDS, the global best is the maximum of those, and taking a corner only
+    // touches the strips within min_dist of its row -- their candidates are suppressed and their maxima recomputed, the
+    // others are not visited. Same picks in the same order (greedy in sorted order).
+    __shared__ unsigned long long smax[kSelMaxSeg];
+    __shared__ unsigned long long part[kSelThreads / 64][4];
+    const int wv = tid >> 6, nwv = nt >> 6;
+    // strips [g0, g0 + ng) (ng <= 4): suppress around (bx, by) when md2s >= 0 (else apply the quality threshold: first visit),
+    // new maxima -> smax
+    auto rescan = [&](int g0, int ng, int bx, int by, bool first) {
+      unsigned long long m[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (q >= ng) continue;
+        unsigned long long *seg = cand + (size_t)(g0 + q) * seg_cap;
+        const int cnt = s_off[g0 + q + 1] - s_off[g0 + q];
+        for (int j = tid; j < cnt; j += nt) {
+          const unsigned long long c = seg[j];
+          if (!c) continue;
+          bool dead;
+          if (first) {
+            dead = !(__uint_as_float((unsigned)(c >> 32)) > thr);
+          } else if (P.min_dist >= 1.f) {
+            const unsigned idx = 0xffffffffu - (unsigned)(c & 0xffffffffu);
+            const float dx = (float)((int)(idx & 0xffffu) - bx), dy = (float)((int)(idx >> 16) - by);
+            dead = dx * dx + dy * dy < md2;
+          } else {
+            const unsigned idx = 0xffffffffu - (unsigned)(c & 0xffffffffu);
+            dead = (int)(idx & 0xffffu) == bx && (int)(idx >> 16) == by;
+          }
+          if (dead) seg[j] = 0;
+          else m[q] = c > m[q] ? c : m[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const unsigned long long x = wave_max_u64(m[q]);
+        if ((tid & 63) == 0) part[wv][q] = x;
+      }
+      __syncthreads();
+      if (tid < ng) {
+        unsigned long long x = part[0][tid];
+        for (int w2 = 1; w2 < nwv; w2++) x = part[w2][tid] > x ? part[w2][tid] : x;
+        smax[g0 + tid] = x;
+      }
+      __syncthreads();
+    };
+    for (int g0 = 0; g0 < nseg; g0 += 4) rescan(g0, min(4, nseg - g0), 0, 0, true);
+    const int reach = P.min_dist >= 1.f ? (int)ceilf(P.min_dist) : 0;
+    for (int round = 0; round < want; round++) {
+      unsigned long long best = 0;  // (every wave takes the maximum over the strips for itself: no barrier)
+      for (int g = tid & 63; g < nseg; g += 64) best = smax[g] > best ? smax[g] : best;
+      best = wave_max_u64(best);
+      if (best == 0) break;
+      const unsigned bidx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
+      const int bx = bidx & 0xffffu, by = bidx >> 16;
+      if (tid == 0) {
+        int p = s_n++;
+        forw_pts[(base + p) * 2] = (float)bx, forw_pts[(base + p) * 2 + 1] = (float)by;
+        ids[base + p] = -1, track_cnt[base + p] = 1;  // addPoints :36-48
+      }
+      const int glo = max(0, (by - reach) / kDetR), ghi = min(nseg - 1, (by + reach) / kDetR);
+      for (int g0 = glo; g0 <= ghi; g0 += 4) rescan(g0, min(4, ghi - g0 + 1), bx, by, false);
+    }
+  } else {
+  unsigned long long *K = keys;
+  const int nc = s_cnt;
   // One pass over the candidates per round: it suppresses around the corner just taken AND collects the maximum of what
   // survives (the next corner) -- the first version walked the list twice per round with a barrier in between.
   unsigned long long mine = 0;  // this thread's largest live key
@@ -1623,6 +1678,7 @@ __global__ __launch_bounds__(kSelThreads) void corner_select_kernel(unsigned lon
         else mine = c > mine ? c : mine;
       }
     }
+  }
   }
   __syncthreads();
   n = s_n;
