@@ -9,7 +9,7 @@ path, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 sub = next((a for a in sys.argv[4:] if not a.startswith('--')), 'solver_core.h')
 dump = '--dump' in sys.argv
 lines = open(path).read().split('\n')
-start = next(i for i, l in enumerate(lines) if l.startswith('_ZN12_GLOBAL__N_117vio_window_kernelILb1ELb1ELi256E'))
+start = next(i for i, l in enumerate(lines) if l.startswith('_ZN6vio_wk17vio_window_kernelILb1ELb1ELi256ELb0E'))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
 files = {}
 for l in lines:
