@@ -121,6 +121,38 @@ def test_tracker_sequence_matches_oracle():
         o.close()
 
 
+def test_no_detection_when_no_corner_is_needed(monkeypatch):
+    """feature_tracker.cpp:256-266: goodFeaturesToTrack is only called while n_max_cnt = MAX_CNT - forw_pts.size() > 0. A sequence
+    that shows the same frame again keeps every feature, so detect_kernel returns at once for it (the other sequence of the batch
+    moves and tops up as usual); results equal the oracle's, and equal what the kernel gives when it is made to run for every
+    sequence (VIO_AMD_DETECT_ALWAYS=1, the bench's setting)."""
+    cfg = abi.default_config(max_corners=60, min_dist=30)
+    T = 6
+    moving = synth.make_image_stream(31, T, rows=640, cols=480)[0]
+    still = [moving[0]] * T
+    streams = [still, moving]
+    outs = []
+    for always in ("0", "1"):
+        monkeypatch.setenv("VIO_AMD_DETECT_ALWAYS", always)
+        trk = fe.FeatureTracker(cfg, n_seq=2)
+        oracles = [H.OracleTracker(cfg) for _ in range(2)]
+        rec = []
+        for f in range(T):
+            got = trk.read_images(np.stack([streams[s][f] for s in range(2)]), True)
+            for s in range(2):
+                rids, rxyz = oracles[s].read_image(streams[s][f], True)
+                assert np.array_equal(got[s][0], rids) and np.array_equal(got[s][1], rxyz), (always, f, s)
+                rec.append((got[s][0].copy(), got[s][1].copy()))
+            if f >= 1:
+                assert len(got[0][0]) == 60  # the still sequence tracks all of its MAX_CNT features: nothing to detect
+        trk.close()
+        for o in oracles:
+            o.close()
+        outs.append(rec)
+    for (ia, xa), (ib, xb) in zip(*outs):
+        assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+
+
 def test_resident_stepping_equals_read_images():
     cfg = abi.default_config(max_corners=100, min_dist=25)
     S, T = 2, 4

@@ -1364,7 +1364,11 @@ template <bool IMG_MASK>
 __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
                                                      size_t mask_stride, const int *kept_xy, const int *n_kept, int cap,
                                                      const int *hw, int radius, unsigned *max_bits, int rows, int cols,
-                                                     unsigned long long *cand_base, int seg_cap, int *n_cand) {
+                                                     unsigned long long *cand_base, int seg_cap, int *n_cand, const int *n_have,
+                                                     int max_corners) {
+  // n_max_cnt = MAX_CNT - forw_pts.size() <= 0: the reference does not call goodFeaturesToTrack at all (feature_tracker.cpp:256-266);
+  // the sequence's candidate counters and maxima stay zero, which is "no corners" to the selection kernel
+  if (n_have && n_have[blockIdx.z] >= max_corners) return;
   constexpr int kCandLds = kDetWaves * kDetW * kDetR / 4 + 64;  // a 3x3 maximum occupies at most one pixel in four
   __shared__ unsigned long long s_mask[kDetWaves][kDetR];
   __shared__ unsigned long long s_cand[kCandLds];
@@ -1749,6 +1753,7 @@ struct vio_frontend {
   uint8_t *lk_status = nullptr;
   VioObs *obs = nullptr;
   bool attr_set = false;
+  bool detect_always = false;  // VIO_AMD_DETECT_ALWAYS=1 (measurement aid): detect_kernel also runs for sequences that need no new corner
   // resident frames (throughput runs)
   uint8_t *frames = nullptr;
   int n_frames = 0;
@@ -1976,7 +1981,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
     hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
                        fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
-                       fe->seg_cap, fe->n_cand);
+                       fe->seg_cap, fe->n_cand, fe->detect_always ? (const int *)nullptr : fe->n_forw, fe->cfg.max_corners);
     SelectParams SP;
     SP.cap = cap, SP.rows = rows, SP.cols = cols, SP.max_corners = fe->cfg.max_corners, SP.min_dist = (float)fe->cfg.min_dist;
     SP.fx = fe->cfg.fx, SP.fy = fe->cfg.fy, SP.cx = fe->cfg.cx, SP.cy = fe->cfg.cy;
@@ -2008,6 +2013,7 @@ int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **ou
   vio_frontend *fe = new vio_frontend();
   fe->device = vio::current_device();
   fe->cfg = *cfg, fe->n_seq = n_seq, fe->cap = cfg->max_corners;
+  fe->detect_always = getenv("VIO_AMD_DETECT_ALWAYS") && getenv("VIO_AMD_DETECT_ALWAYS")[0] == '1';
   // buildOpticalFlowPyramid: levels stop when one would not hold the window
   LevelDims &ld = fe->ld;
   ld.rows[0] = cfg->image_rows, ld.cols[0] = cfg->image_cols, ld.off[0] = 0, ld.levels = 1;
@@ -2493,7 +2499,7 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
     return fail(VIO_ENODEV);
   dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, 1);
   hipLaunchKernelGGL(detect_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
-                     fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand);
+                     fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand, (const int *)nullptr, 0);
   SelectParams SP;
   SP.cap = fe->cap, SP.rows = rows, SP.cols = cols, SP.max_corners = max_corners, SP.min_dist = (float)c.min_dist;
   SP.fx = c.fx, SP.fy = c.fy, SP.cx = c.cx, SP.cy = c.cy;
