@@ -277,7 +277,12 @@ typedef struct VioTrackViz { /* good_pts / track_len (UI only), optional */
 /* n_seq independent trackers (sequences) share one context and one launch.
  * VIO_EINVAL for configurations the kernels are not laid out for: lk_win != 21,
  * more than 512 corners, images below 32 x 32 or above 32767 rows / 65535
- * columns (corner candidates carry their position as y << 16 | x).            */
+ * columns (corner candidates carry their position as y << 16 | x).
+ * Environment, read here: VIO_AMD_DETECT_ALWAYS=1 (measurement aid) runs the
+ * corner detector on every published frame of every sequence; by default a
+ * sequence that still tracks max_corners features skips it, like the
+ * reference's n_max_cnt > 0 test (feature_tracker.cpp:256-266) -- the results
+ * are the same either way.                                                    */
 int vio_frontend_create(const VioConfig *cfg, int32_t n_seq, vio_frontend_t **out);
 int vio_frontend_get_device(const vio_frontend_t *fe, int32_t *device);
 void vio_frontend_destroy(vio_frontend_t *fe);
