@@ -45,6 +45,10 @@ extern "C" {
 #define VIO_ENOMEM (-3)   /* host or device allocation failed             */
 #define VIO_ECAP (-4)     /* problem exceeds the context's capacity       */
 #define VIO_ESTATE (-5)   /* call order violated                          */
+#define VIO_ETIMEOUT (-6) /* the workgroups of a cooperative window did not
+                             meet on the device (co-residency lost): the
+                             window's termination reads 2 (FAILURE), its
+                             outputs and next prior must be discarded      */
 
 #define VIO_SIZE_POSE 7       /* global_param.hpp:30 */
 #define VIO_SIZE_SPEEDBIAS 9  /* global_param.hpp:31 */
@@ -232,19 +236,6 @@ int vio_backend_download(vio_backend_t *be, VioWindow *windows, int32_t n, VioSo
 /* Average device time (ms) of the solve kernel over the launches since the
  * last call, measured with HIP events on the launch stream.                  */
 int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches);
-
-/* How the windows of a batch are executed on the device (same results either way):
- *   VIO_PATH_AUTO    the library chooses per upload (default; env VIO_AMD_PHASE=0/1 overrides)
- *   VIO_PATH_SINGLE  one launch: one workgroup owns a window for the whole of solve_ceres
- *   VIO_PATH_PHASE   a fixed sequence of launches with no host round trip: setup, then
- *                    factor-parallel linearization kernels alternating with per-window
- *                    trust-region step kernels, then new2old + marginalization
- *                    (windows of more than 12 frames always take the single launch)
- * Takes effect at the next vio_backend_upload.                                          */
-#define VIO_PATH_AUTO 0
-#define VIO_PATH_SINGLE 1
-#define VIO_PATH_PHASE 2
-int vio_backend_set_path(vio_backend_t *be, int32_t path);
 
 /* Per-stage device cycle counters of the solve kernel: the kernel-side counterpart
  * of the reference's TS()/TE() printf timers (global_param.hpp:85-92, VINS.cpp:657-662,

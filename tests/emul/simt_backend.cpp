@@ -11,7 +11,6 @@
 
 #include "batch.h"
 #include "marg_core.h"
-#include "phase_core.h"
 
 using namespace vio;
 
@@ -57,9 +56,9 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
 
   // LDS or global matrix: the launcher's rule (vio_backend.hip backend_upload_impl)
   auto lds_need = [&](bool lds_matrix) {
-    size_t se = 0;
-    const size_t bs = carve_work<double *>(B.d, lds_matrix, nthreads, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<double *>(B.d, lds_matrix, nullptr, nullptr, nullptr, 0);
+    size_t se = 0, tail = 0;
+    const size_t bs = carve_work<double *>(B.d, lds_matrix, nthreads, nullptr, nullptr, nullptr, nullptr, &se, &tail);
+    const size_t bm = (se + tail) * sizeof(double) + carve_marg<double *>(B.d, lds_matrix, nullptr, nullptr, nullptr, 0);
     return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
   };
   bool lds_matrix = pose_jp(B.d) <= 16 * kPanelTiles && lds_need(true) <= kLdsBytes;
@@ -78,7 +77,7 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
   // the body of vio_window_kernel (vio_backend.hip), one fiber per work-item
   simt::launch(nthreads, [&](int tid) {
     WinView v = make_view(B, 0);
-    const Carved<double *> cw = carve_all<double *>(B.d, lds_matrix, nthreads, lds.data(), hm.data(), v.AspG);
+    const Carved<double *> cw = carve_all<double *>(B.d, lds_matrix, nthreads, lds.data(), hm.data(), v.AspG, lds_doubles);
     WorkT<double *> w = cw.w;
     Ctx cx;
     cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr;
@@ -89,133 +88,10 @@ extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveS
     else if (lds_matrix) solve_window<true, 8>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
     else if (nthreads == 256) solve_window<false, 4>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
     else solve_window<false, 8>(cx, v, w, SameView{v}, SameWork<decltype(w)>{w});
-    MargWorkT<double *> mw = carve_marg_all<double *>(B.d, lds_matrix, lds.data() + state_end, mo.scratch, lds_doubles - state_end).m;
+    MargWorkT<double *> mw = carve_marg_all<double *>(B.d, lds_matrix, lds.data() + state_end, mo.scratch, lds_doubles - state_end - cw.tail_doubles).m;
     __syncthreads();
     marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
   }, order);
-
-  unpack_window(s, 0, out_pose.data(), out_sb.data(), out_feat.data(), raw_pose.data(), raw_sb.data(),
-                raw_feat.data(), out_loop.data(), stats_d.data(), stats_i.data(), *win, stats);
-  if (win->next_prior) unpack_prior(mo, *win->next_prior);
-  return VIO_OK;
-}
-
-// The phase path (phase_core.h): the same solve as the launch sequence of vio_backend_launch -- setup, linearize,
-// (step, linearize) x max_iter, step, finish -- every kernel body run as one emulated workgroup with freshly NaN-filled LDS
-// (nothing survives in LDS from one launch to the next on the device either). lean: 0 = IMU coupling in LDS, 1 = in global
-// scratch (vio_phase_step_kernel<false>).
-extern "C" int simt_solve_window_phase(const VioConfig *cfg, VioWindow *win, VioSolveStats *stats, int lean, int order) {
-  const int nthreads = 256;
-  bool any_loop = false;
-  for (int k = 0; k < win->n_factors; k++)
-    if (win->factor_target[k] == win->window_size + 1) any_loop = true;
-  HostBatch hb;
-  hb.resize(make_dims(*cfg, win->window_size, win->n_features, win->n_factors, any_loop), 1);
-  hb.d.lds_asp = lean ? 0 : 1;
-  if (pose_jp(hb.d) > 16 * kPanelTiles) return VIO_ECAP;
-  int rc = pack_window(hb, 0, *win, false, 0);
-  if (rc != VIO_OK) return rc;
-  const BatchStrides &s = hb.s;
-  const double kNaN = std::numeric_limits<double>::quiet_NaN();
-  std::vector<double> scratch(s.scratch, kNaN), out_pose(s.out_pose), out_sb(s.out_sb), out_feat(s.out_feat), raw_pose(s.out_pose),
-      raw_sb(s.out_sb), raw_feat(s.out_feat), out_loop(7), stats_d(s.stats_d);
-  std::vector<int> stats_i(s.stats_i);
-  std::vector<double> m_x0(9 * kMaxPriorBlocks), m_J((size_t)hb.d.Ncap * hb.d.Ncap), m_r(hb.d.Ncap);
-  std::vector<int> m_int(4 + 3 * kMaxPriorBlocks);
-  BatchPtrs B;
-  B.n = 1, B.d = hb.d, B.s = s, B.order = nullptr, B.ptab = nullptr;
-  B.hdr = hb.hdr.data(), B.hdr_d = hb.hdr_d.data();
-  B.pose = hb.pose.data(), B.sb = hb.sb.data(), B.ex = hb.ex.data(), B.feat = hb.feat.data();
-  B.fhost = hb.fhost.data(), B.ftarget = hb.ftarget.data(), B.ffeat = hb.ffeat.data();
-  B.fslot = hb.fslot.data(), B.fstart = hb.fstart.data();
-  B.pair_h = hb.pair_h.data(), B.pair_t = hb.pair_t.data(), B.pair_s0 = hb.pair_s0.data(), B.pair_s1 = hb.pair_s1.data();
-  B.pts_i = hb.pts_i.data(), B.pts_j = hb.pts_j.data(), B.preint = hb.preint.data();
-  B.pr_kind = hb.pr_kind.data(), B.pr_index = hb.pr_index.data(), B.pr_offset = hb.pr_offset.data();
-  B.pr_x0 = hb.pr_x0.data(), B.pr_J = hb.pr_J.data(), B.pr_r = hb.pr_r.data();
-  B.scratch = scratch.data(), B.hm = nullptr;
-  B.out_pose = out_pose.data(), B.out_sb = out_sb.data(), B.out_feat = out_feat.data();
-  B.raw_pose = raw_pose.data(), B.raw_sb = raw_sb.data(), B.raw_feat = raw_feat.data(), B.out_loop = out_loop.data();
-  B.stats_d = stats_d.data(), B.stats_i = stats_i.data();
-  B.d.Flds = std::max(1, win->n_features);
-  B.d.lds_asp = lean ? 0 : 1;
-  B.PL = make_phase_layout(B.d);
-  std::vector<double> phase(B.PL.total, kNaN);
-  B.phase = phase.data();
-
-  size_t se = 0;
-  const size_t bs = carve_work<double *>(B.d, true, nthreads, nullptr, nullptr, nullptr, nullptr, &se);
-  const size_t bm = se * sizeof(double) + carve_marg<double *>(B.d, true, nullptr, nullptr, nullptr, 0);
-  const size_t need = std::max(bs, bm + 64 * kMargSlot * sizeof(double));
-  if (need > kLdsBytes || carve_setup(B.d, nullptr, nullptr) > kLdsBytes || carve_lin(B.d, nullptr, nullptr) > kLdsBytes) return VIO_ECAP;
-  const size_t lds_bytes = need <= kLdsBytes / 2 ? kLdsBytes / 2 : kLdsBytes;
-  const size_t lds_doubles = lds_bytes / sizeof(double);
-  std::vector<double> lds(kLdsBytes / sizeof(double) + 2, kNaN);
-  auto fresh_lds = [&]() { std::fill(lds.begin(), lds.end(), kNaN); };
-
-  MargOut mo;
-  mo.n = m_int.data(), mo.kind = m_int.data() + 4, mo.index = mo.kind + kMaxPriorBlocks, mo.offset = mo.index + kMaxPriorBlocks;
-  mo.x0 = m_x0.data(), mo.J = m_J.data(), mo.r = m_r.data(), mo.scratch = nullptr, mo.ncap = hb.d.Ncap;
-
-  auto setup = [&]() {
-    fresh_lds();
-    simt::launch(256, [&](int tid) {
-      WinView v = make_view(B, 0);
-      const PhaseView pv = make_phase_view(B, 0);
-      SetupWork sw;
-      carve_setup(B.d, lds.data(), &sw);
-      Ctx cx;
-      cx.tid = tid, cx.nt = 256, cx.prof = nullptr, cx.red = nullptr, cx.lprof = nullptr;
-      phase_setup(cx, v, pv, sw);
-    }, order);
-  };
-  auto lin = [&]() {
-    fresh_lds();
-    simt::launch(kLinThreads, [&](int tid) {
-      const WinView v = make_view(B, 0);
-      const PhaseView pv = make_phase_view(B, 0);
-      LinWork lw;
-      carve_lin(B.d, lds.data(), &lw);
-      Ctx cx;
-      cx.tid = tid, cx.nt = kLinThreads, cx.prof = nullptr, cx.red = lw.red, cx.lprof = nullptr;
-      phase_linearize(cx, v, pv, lw);
-    }, order);
-  };
-  auto step = [&](int k) {
-    fresh_lds();
-    simt::launch(nthreads, [&](int tid) {
-      WinView v = make_view(B, 0);
-      const PhaseView pv = make_phase_view(B, 0);
-      const Carved<double *> cw = carve_all<double *>(B.d, true, nthreads, lds.data(), nullptr, v.AspG);
-      WorkT<double *> w = cw.w;
-      Ctx cx;
-      cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr;
-      cx.wrot = (order + k) % (nthreads / 64);
-      cx.red = cw.red, cx.lprof = cw.lprof;
-      phase_step<true, 4>(cx, v, pv, w);
-    }, order);
-  };
-  setup();
-  lin();
-  for (int k = 0; k <= B.d.max_iter; k++) {
-    step(k);
-    if (k < B.d.max_iter) lin();
-  }
-  fresh_lds();
-  simt::launch(nthreads, [&](int tid) {
-    WinView v = make_view(B, 0);
-    const PhaseView pv = make_phase_view(B, 0);
-    const Carved<double *> cw = carve_all<double *>(B.d, true, nthreads, lds.data(), nullptr, v.AspG);
-    WorkT<double *> w = cw.w;
-    Ctx cx;
-    cx.tid = tid, cx.nt = nthreads, cx.prof = nullptr, cx.wrot = 0;
-    cx.red = cw.red, cx.lprof = cw.lprof;
-    const size_t state_end = cw.state_end_doubles;
-    phase_finish(cx, v, pv, w);
-    MargWorkT<double *> mw = carve_marg_all<double *>(B.d, true, lds.data() + state_end, nullptr, lds_doubles - state_end).m;
-    __syncthreads();
-    marginalize_window_impl(cx, v, w.xpose, w.xsb, w.xfeat, w.ex, mw, mo);
-  }, order);
-  if (reinterpret_cast<PhaseRec *>(phase.data() + B.PL.rec)->phase != PH_DONE) return VIO_ESTATE;
 
   unpack_window(s, 0, out_pose.data(), out_sb.data(), out_feat.data(), raw_pose.data(), raw_sb.data(),
                 raw_feat.data(), out_loop.data(), stats_d.data(), stats_i.data(), *win, stats);

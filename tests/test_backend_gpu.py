@@ -18,26 +18,18 @@ TOL = 1e-6
 TOL_PRIOR = 1e-5
 
 
-# The launch-sequence ("phase") path of the same solve (csrc/phase_core.h, opt-in through vio_backend_set_path) is a measured
-# experiment that is slower at every batch size: it is not part of the default run. VIO_TEST_PHASE=1 runs every
-# test that takes `solver_cache` a second time through it (windows of more than 12 frames take the single launch in both).
-PATHS = ["single", "phase"] if os.environ.get("VIO_TEST_PHASE") == "1" else ["single"]
-
-
-@pytest.fixture(scope="module", params=PATHS)
-def solver_cache(request):
-    cache = {"_path": request.param}
+@pytest.fixture(scope="module")
+def solver_cache():
+    cache = {}
     yield cache
-    for k, s in cache.items():
-        if k != "_path":
-            s.close()
+    for s in cache.values():
+        s.close()
 
 
 def get_solver(cache, cfg, max_batch=64):
     key = (cfg.window_size, cfg.max_features, cfg.max_factors, cfg.max_iterations, cfg.fx, max_batch)
     if key not in cache:
         cache[key] = pkg.backend.WindowSolver(cfg, max_batch=max_batch)
-        cache[key].set_path(cache["_path"])
     return cache[key]
 
 
@@ -261,9 +253,8 @@ def test_one_batch_split_over_both_kernel_variants(solver_cache):
         assert g.next_prior.n == ref.next_prior.n
 
 
-@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("W,F,loop,seed", H.ODD_SHAPES)
-def test_odd_shapes_match_oracle(W, F, loop, seed, path):
+def test_odd_shapes_match_oracle(W, F, loop, seed):
     """Awkward window sizes (1..260 landmarks, W = 3..13, loop pose) through the device kernel against the CPU oracle; the
     poisoned-buffer run below repeats them with NaN-filled LDS and scratch."""
     cfg = abi.default_config(window_size=W)
@@ -271,7 +262,6 @@ def test_odd_shapes_match_oracle(W, F, loop, seed, path):
     w = synth.make_window(cfg, lambda *a: abi.preintegrate_with(opre, cfg, *a), seed=900 + seed, n_features=F, W=W,
                           with_loop=loop)
     solver = pkg.backend.WindowSolver(cfg, max_batch=1)
-    solver.set_path(path)
     got = w.copy()
     gs = solver.solve([got])[0]
     solver.close()

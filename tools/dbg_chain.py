@@ -11,7 +11,6 @@ cfg = abi.default_config()
 path = sys.argv[1] if len(sys.argv) > 1 else "auto"
 for run in range(int(sys.argv[2]) if len(sys.argv) > 2 else 1):
     solver = pkg.backend.WindowSolver(cfg, max_batch=1)
-    solver.set_path(path)
     pre = lambda *a: pkg.backend.preintegrate(cfg, *a)
     rec = []
     def solve(w):

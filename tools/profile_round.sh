@@ -2,7 +2,7 @@
 # usage: gpurun -- 'bash tools/profile_round.sh r03_a'     -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -x
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -24,8 +24,6 @@ VIO_BENCH_MAX_ITER=2 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA 
 VIO_BENCH_MAX_ITER=2 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/sq4b -- $BENCH --only backend --steps 6 --warmup 2 > $O/sq4b.log 2>&1
 # L2 hit rate of the window kernel's scratch traffic (requests that hit / miss in the XCD's L2)
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/tcc -- $BENCH --only backend --steps 6 --warmup 2 > $O/tcc.log 2>&1
-# the phase path (launch sequence) of the same solve: per-kernel trace, for the gate the round-3 review set
-VIO_AMD_PHASE=1 rocprofv3 --kernel-trace --stats -d $O/kt_phase -- $BENCH --only backend --steps 10 --warmup 2 > $O/bench_kt_phase.log 2>&1
 # BASELINE configs[2] / configs[4] end to end (front-end at 1280x720 / 1920x1080 + the cooperative W = 20 / 30 window solve)
 for leg in configs2 configs4; do
   rocprofv3 --kernel-trace --stats -d $O/kt_$leg -- python $R/bench.py --leg $leg --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_$leg.log 2>&1
@@ -42,7 +40,6 @@ python tools/rocpd_pmc_summary.py $(db calib_fetch) $(db calib_write) > $O/pmc_c
 for k in 1 2 3 4 5; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window >> $O/pmc_sq.txt; done
 python tools/rocpd_pmc_summary.py $(db tcc) 2>&1 | grep vio_window >> $O/pmc_sq.txt
 for k in 3b 4b; do python tools/rocpd_pmc_summary.py $(db sq$k) 2>&1 | grep vio_window | sed 's/^/max_iter=2: /' >> $O/pmc_sq.txt; done
-python tools/rocpd_summary.py $(db kt_phase) $O/kernel_trace_phase_path.txt > /dev/null
 for leg in configs2 configs4; do python tools/rocpd_summary.py $(db kt_$leg) $O/kernel_trace_$leg.txt > /dev/null; grep "^{\"workload\"" $O/bench_$leg.log | tail -1 > $O/bench_$leg.json; done
 python tools/rocpd_pmc_summary.py $(db ic) 2>&1 | grep vio_window >> $O/pmc_sq.txt
 for kb in 8 32 48 64 96 192 384; do $R/tools/microbench/bin/icache_probe_$kb; done > $O/icache_probe.txt 2>&1
@@ -57,12 +54,10 @@ python tools/rocpd_timeline.py $(db kt_res) 24 >> $O/kernel_trace_resident_estim
   for cfg in "256 1" "512 1" "256 2" "512 2"; do set -- $cfg; echo "== estimator_throughput (C++ driver): $1 sequences x $2 estimator objects"; /tmp/estimator_throughput /tmp/est.bin $1 $2 2>&1 | tail -1; done
   for n in 256 512; do echo "== time_pipeline.py $n sequences, asynchronous submit"; python tools/time_pipeline.py $n 30 2 1 2>&1 | tail -1; done ) > $O/estimator_paths.txt 2>&1
 python tools/time_backend.py --path=single 1 256 512 1024 > $O/stage_cycles.txt 2>&1
-python tools/time_backend.py --path=phase 1 256 512 1024 2>&1 | grep "path=" >> $O/stage_cycles.txt
-python tools/phase_stages.py phase 512 2>&1 | grep "path=" >> $O/stage_cycles.txt
 VIO_AMD_PROF_TID=64 python tools/time_backend.py 1 2>&1 | grep "stage cycles" | sed "s/^/clock on a panel wave: /" >> $O/stage_cycles.txt
 $R/tools/microbench/bin/band_bench > $O/microbench.txt 2>&1
 $R/tools/microbench/bin/mfma_share >> $O/microbench.txt 2>&1
 python tools/time_large.py > $O/large_windows.txt 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf $O/sq3b $O/sq4b $O/kt_configs2 $O/kt_configs4 $O/ic $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_phase $O/kt_res
+rm -rf $O/sq3b $O/sq4b $O/kt_configs2 $O/kt_configs4 $O/ic $O/kt $O/fetch $O/write $O/calib_fetch $O/calib_write $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/tcc $O/kt_res
 ls -la $O

@@ -1,4 +1,4 @@
-# gpurun -- 'bash tools/quick_gpu.sh [tests] [large]': backend GPU tests (optional) + single-launch / phase timings
+# gpurun -- 'bash tools/quick_gpu.sh [tests] [large]': backend GPU tests (optional) + window-kernel timings
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/quick
@@ -12,5 +12,4 @@ for a in "$@"; do
   if [ "$a" = "large" ]; then python tools/time_large.py 2>&1 | grep "kernel" ; fi
 done
 python tools/time_backend.py --path=single 1 8 256 512 1024 2>&1 | grep "path=\|stage" > $O/time_single.txt
-python tools/time_backend.py --path=phase 512 2>&1 | grep "path=" > $O/time_phase.txt
-cat $O/time_single.txt $O/time_phase.txt | cut -c1-1200
+cat $O/time_single.txt | cut -c1-1200

@@ -14,11 +14,12 @@ abi, synth, backend = pkg.abi, pkg.synth, pkg.backend
 
 
 def main():
-    path = "auto"
+    path = "single"  # (the launch-sequence path of rounds 4-5 left the library in round 6; the flag is still accepted)
+    prof_batches = [1]
     for a in sys.argv[1:]:
-        if a.startswith("--path="):
-            path = a.split("=")[1]
-    args = [a for a in sys.argv[1:] if a != "--no-prior" and not a.startswith("--path=")]
+        if a.startswith("--prof-batch="):  # stage clock of window 0 (and the last one) with that many windows in the launch
+            prof_batches = [int(x) for x in a.split("=")[1].split(",")]
+    args = [a for a in sys.argv[1:] if a != "--no-prior" and not a.startswith("--path=") and not a.startswith("--prof-batch=")]
     batches = [int(x) for x in args] or [1, 64, 256, 512, 1024]
     cfg = abi.default_config()
     pre = lambda *a: backend.preintegrate(cfg, *a)
@@ -28,17 +29,17 @@ def main():
         sys.path.insert(0, ROOT)
         import bench
         uniq = bench.steady_state_windows(cfg, pkg, pre, [42 + i for i in range(8)])
-    solver = backend.WindowSolver(cfg, max_batch=max(batches))
-    solver.set_path(path)
-    if True:
+    solver = backend.WindowSolver(cfg, max_batch=max(batches + prof_batches))
+    for pb in prof_batches:
         solver.set_profile(True)
-        ws = [uniq[0].copy()]
+        ws = [uniq[i % len(uniq)].copy() for i in range(pb)]
         solver.upload(ws)
         solver.launch()
         solver.sync()
-        cyc = solver.stage_cycles(0)
-        tot = max(1, cyc["total"])
-        print("stage cycles (1 window): " + ", ".join("%s=%d(%.1f%%)" % (k, c, 100.0 * c / tot) for k, c in cyc.items()))
+        for wi in sorted({0, pb - 1}):
+            cyc = solver.stage_cycles(wi)
+            tot = max(1, cyc["total"])
+            print("stage cycles (window %d of %d): " % (wi, pb) + ", ".join("%s=%d(%.1f%%)" % (k, c, 100.0 * c / tot) for k, c in cyc.items()))
         solver.set_profile(False)
     for B in batches:
         ws = [uniq[i % len(uniq)].copy() for i in range(B)]

@@ -568,7 +568,6 @@ def load_product():
     lib.vio_estimator_features.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     lib.vio_estimator_get_timing.argtypes = [vp, _dp]
     lib.vio_backend_set_profile.argtypes = [vp, C.c_int32]
-    lib.vio_backend_set_path.argtypes = [vp, C.c_int32]
     lib.vio_backend_stage_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.c_int32]
     _product = lib
     return lib

@@ -81,12 +81,6 @@ class WindowSolver:
         self._check(self.lib.vio_backend_download(self._h, arr, len(windows), stats), "download")
         return [abi.stats_to_dict(s) for s in stats]
 
-    PATHS = {"auto": 0, "single": 1, "phase": 2}
-
-    def set_path(self, path):
-        """'auto' / 'single' (one launch per batch) / 'phase' (launch sequence, phase_core.h); from the next upload on."""
-        self._check(self.lib.vio_backend_set_path(self._h, self.PATHS[path]), "set_path")
-
     def set_profile(self, enable=True):
         self._check(self.lib.vio_backend_set_profile(self._h, 1 if enable else 0), "set_profile")
 

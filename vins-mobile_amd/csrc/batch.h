@@ -105,50 +105,6 @@ inline BatchStrides make_strides(const BatchDims &d) {
   return s;
 }
 
-// ---- phase path (phase_core.h): the solve as a sequence of launches ------------------------------------------------
-// Everything that lives across launches sits in one block of global memory per window:
-//   rec       the minimizer's loop-carried scalars (PhaseRec)
-//   prcol     prior column -> (frame << 8 | component), built once per solve; fh: host frame of every landmark
-//   x[2]      iterate / candidate: pose 7 (Pcap + 1) | speed-bias 9 Pcap | inverse depths Fcap
-//   h[2]      a linearization: cost | g_p | g_f | H_ff | pose matrix App (prior + projections, pre-Schur) | raw IMU Jacobians |
-//             raw IMU residuals | landmark coupling WTf. Buffer `cur` belongs to the accepted iterate, buffer 1 - cur receives the
-//             linearization at the candidate (written speculatively while the step is still undecided).
-//   sp sf     Jacobi scaling (fixed at the first linearization); gpf dp  complete gradient and trust-region diagonal of the
-//   gnp gnf   accepted linearization; Gauss-Newton step of the last linear solve (all needed again after a rejected step)
-struct PhaseLayout {
-  size_t rec, prcol, fh, x[2], h[2], sp, sf, gpf, dp, gnp, gnf, total;
-  size_t x_sb, x_feat;
-  size_t h_gp, h_gf, h_hff, h_App, h_imuJ, h_imur, h_WTf;
-};
-constexpr int kRecDoubles = 64;
-
-inline PhaseLayout make_phase_layout(const BatchDims &d) {
-  PhaseLayout L;
-  auto up = [](size_t n) { return (n + 7) & ~(size_t)7; };
-  const size_t npc = (size_t)d.nblk_cap * kBS, F = d.Fcap;
-  L.x_sb = up(7 * (size_t)(d.Pcap + 1)), L.x_feat = L.x_sb + up(9 * (size_t)d.Pcap);
-  const size_t xs = L.x_feat + up(F);
-  size_t o = 8;  // [0, 8): cost
-  L.h_gp = o, o += up(npc);
-  L.h_gf = o, o += up(F);
-  L.h_hff = o, o += up(F);
-  L.h_App = o, o += up(tri_doubles(pose_rows(d)));
-  L.h_imuJ = o, o += up((size_t)d.Wcap * 450);
-  L.h_imur = o, o += up((size_t)d.Wcap * 15);
-  L.h_WTf = o, o += up(F * (size_t)d.n6cap);
-  const size_t hs = o;
-  o = 0;
-  L.rec = o, o += kRecDoubles;
-  L.prcol = o, o += up(((size_t)d.Ncap + 1) / 2);
-  L.fh = o, o += up((F + 1) / 2);  // host frame of every landmark (-1: it has no factor)
-  L.x[0] = o, o += xs, L.x[1] = o, o += xs;
-  L.h[0] = o, o += hs, L.h[1] = o, o += hs;
-  L.sp = o, o += up(npc), L.sf = o, o += up(F), L.gpf = o, o += up(npc), L.dp = o, o += up(npc);
-  L.gnp = o, o += up(npc), L.gnf = o, o += up(F);
-  L.total = o;
-  return L;
-}
-
 // Device-resident prior chain: where window b reads its prior data from (null J: the strided pr_* arrays) and where it
 // writes the next one (null mJ: the strided MargPtrs arrays).
 struct PriorTab {
@@ -176,10 +132,24 @@ struct BatchPtrs {
   const int *order;  // launch-local block index -> window (null: identity); a batch may be split into two launches
   int coop;          // workgroups per window of this launch (1: each window is solved by one workgroup)
   int n_launch;      // windows of this launch (cooperative launches pad their grid to whole groups of eight windows)
-  double *phase;     // [n][PL.total] phase path: the state that lives across launches (null: single-launch path only)
-  PhaseLayout PL;
+  unsigned coop_spin;  // polls before a wait between the workgroups of a cooperative window gives up (kCoopSpinLimit; tests lower it)
+  int coop_fault;      // test hook (VIO_AMD_COOP_FAULT=1): the helper workgroups leave at once, so that the owner's first wait times out
   double *out_pose, *out_sb, *out_feat, *raw_pose, *raw_sb, *raw_feat, *out_loop, *stats_d;
   int *stats_i;
+};
+
+// Where the marginalization phase of the window kernel writes the next prior (strided arrays; a window that names a slot of
+// the resident prior store writes through PriorTab instead), and the stage clock's switches.
+struct MargPtrs {
+  int *ints;        // [n][4 + 3 * kMaxPriorBlocks]
+  double *x0;       // [n][9 * kMaxPriorBlocks]
+  double *J;        // [n][Ncap * Ncap]
+  double *r;        // [n][Ncap]
+  double *scratch;  // [n][marg_scratch] (global matrix variant only)
+  size_t s_ints, s_x0, s_J, s_r, s_scratch;
+  long long *prof;  // [n][ST_COUNT] or null
+  int prof_tid;     // work-item that keeps the stage clock (VIO_AMD_PROF_TID, default 0)
+  int wrot;         // wave-role rotation: -1 = from the hardware wave slot (default), else forced (VIO_AMD_WAVE_ROT)
 };
 
 VIO_HD WinView make_view(const BatchPtrs &B, int b) {
@@ -255,26 +225,35 @@ struct Carved {
   ldsd red;
   VIO_AS3 long long *lprof;
   size_t bytes, state_end_doubles;
+  size_t tail_doubles;  // the landmarks of the iterate sit at the END of the workgroup's LDS (see below)
 };
 
+// Layout (round 6): the fixed-size part of the iterate (poses, speed-bias, extrinsic) and the reduction scratch come first --
+// the marginalization phase re-carves everything behind them (marg_core.h) --, then every array whose size depends on the
+// window size alone, then the per-landmark arrays, and the landmarks of the ITERATE (xfeat) at the very end of the
+// workgroup's LDS (total_doubles; 0 = measuring: directly behind the rest). With the window size a compile-time constant
+// (vio_window_kernel.inc, WS > 0) every address of the first two groups is then a constant -- an immediate offset of a
+// ds_read / ds_write instead of a scalar register --, and the per-landmark arrays are one base plus multiples of one stride.
 template <class MP, class AP = MP>
-VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global, double *asp_global = nullptr) {
+VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global, double *asp_global = nullptr,
+                                size_t total_doubles = 0) {
   Carved<MP, AP> c;
   size_t o = 0;
   const size_t npc = (size_t)d.nblk_cap * kBS;  // pose-side vector length (frame-major; the loop pose uses 6 of its 15)
-  const size_t F = d.Flds;
+  const size_t F = d.Flds, Fe = (F + 1) & ~(size_t)1;
   auto take = [&](size_t n) {
     ldsd p = base + o;  // (a null base only measures; the pointers are then never used)
     o += (n + 1) & ~(size_t)1;  // keep 16-byte alignment
     return p;
   };
   WorkT<MP, AP> &w = c.w;
-  // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h)
-  w.xpose = take(7 * (size_t)(d.Pcap + 1)), w.xsb = take(9 * (size_t)d.Pcap), w.xfeat = take(F);
+  // the iterate comes first: the marginalization phase re-carves everything behind it (marg_core.h) up to the landmarks at the end
+  w.xpose = take(7 * (size_t)(d.Pcap + 1)), w.xsb = take(9 * (size_t)d.Pcap);
   w.ex = take(8);
   c.red = take(6 * ((size_t)nthreads / 64) + 2);
   c.lprof = reinterpret_cast<VIO_AS3 long long *>(take(ST_COUNT));
   c.state_end_doubles = o;
+  c.tail_doubles = Fe;
   // the reduced matrix: pose matrix (LDS or global) and the speed-bias band (always LDS), contiguous when both are in
   // LDS so that the Jacobian rows of the projection factors can be staged across them
   const size_t napp = tri_doubles(6 * (size_t)d.nblk_cap + 1);
@@ -282,7 +261,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   ldsd app = nullptr;
   if (lds_matrix) app = take(napp);
   w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
-  // (pose matrix in global scratch: the band, the fill-tile buffer and what LDS is left over sit at the END of the layout,
+  // (pose matrix in global scratch: the band, the fill-tile buffer and what LDS is left over sit behind the vectors,
   // contiguous, and stage the Jacobian rows -- see below)
   if (lds_matrix) w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
   const bool lds_asp = lds_matrix && d.lds_asp != 0;
@@ -291,8 +270,6 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.stage = app, w.nstage = lds_matrix ? (int)(o - o_mat) : 0;
   w.asp_ring = lds_matrix && !lds_asp;
   w.aspring = w.asp_ring ? take(2 * (size_t)kAS + 4) : nullptr;
-  w.cfeat = take(F);
-  w.gf = take(F), w.sf = take(F), w.gnf = take(F), w.stf = take(F), w.hff = take(F), w.einv = take(F), w.tf = take(F);
   w.gp = take(npc), w.sp = take(npc), w.dp = take(npc);
   // Aliases. While the Jacobians are evaluated the candidate pose / speed-bias and the Gauss-Newton step are dead: the
   // sixth accumulator of the landmarks' host-frame coupling (ef) uses their place (when it is large enough). t1 (the
@@ -301,7 +278,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   // is formed after the solution has been consumed: it shares t1.
   const size_t o_ef = o;
   w.cpose = take(7 * (size_t)(d.Pcap + 1)), w.csb = take(9 * (size_t)d.Pcap), w.gnp = take(npc);
-  w.ef = (o - o_ef >= F) ? w.cpose : take(F);
+  const bool ef_alias = o - o_ef >= F;
   const size_t jp = (6 * (size_t)d.nblk_cap + 1 + 15) / 16 * 16;
   const size_t o_ppd = o;
   w.t1 = take(npc), w.t2 = take(npc), w.xt = take(jp), w.ldinv = take((size_t)d.Pcap * kSB + jp);
@@ -314,12 +291,15 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.flag = reinterpret_cast<ldsi>(take(2));
   w.park = take(24);
   w.rot = take(9 * (size_t)(d.Pcap + 2));
-  w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
   // pose matrices of more than kPanelTiles tile rows: the fill tiles of the band go through LDS
   w.vbuf = nullptr;
-  if (lds_matrix) {
-    if (jp > 16 * (size_t)kPanelTiles) w.vbuf = take((jp / 16) * 192);
-  } else {
+  if (lds_matrix && jp > 16 * (size_t)kPanelTiles) w.vbuf = take((jp / 16) * 192);
+  // ---- per-landmark arrays: one base, multiples of Fe
+  w.cfeat = take(F);
+  w.gf = take(F), w.sf = take(F), w.gnf = take(F), w.stf = take(F), w.hff = take(F), w.einv = take(F), w.tf = take(F);
+  w.ef = ef_alias ? w.cpose : take(F);
+  w.fh = reinterpret_cast<ldsi>(take((F + 1) / 2 + 1));
+  if (!lds_matrix) {
     // Pose matrix in global scratch (W > 12): while the Jacobians are evaluated the band, the fill-tile buffer and whatever
     // LDS the layout leaves free (a workgroup of this variant has the CU to itself) stage the Jacobian rows of the projection
     // factors, a chunk of up to one slot per work-item -- the first three versions staged them in the global matrix buffer,
@@ -327,22 +307,28 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
     const size_t o_st = o;
     w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;
     w.vbuf = take((jp / 16) * 192);
-    const size_t want = (size_t)nthreads * kGSlot, have = o - o_st, room = kLdsBytes / sizeof(double) > o ? kLdsBytes / sizeof(double) - o : 0;
+    const size_t want = (size_t)nthreads * kGSlot, have = o - o_st, cap = kLdsBytes / sizeof(double);
+    const size_t room = cap > o + Fe ? cap - o - Fe : 0;
     if (want > have) (void)take(want - have < room ? want - have : (room & ~(size_t)1));
     w.stage = w.Dss, w.nstage = (int)(o - o_st);
   }
+  // the landmarks of the iterate: the last Fe doubles of the workgroup's LDS
+  w.xfeat = base + (total_doubles ? total_doubles - Fe : o);
+  o += Fe;
   c.bytes = o * sizeof(double);
   return c;
 }
 
-// Pointer form for host code (sizing: all outputs optional). Returns the number of bytes used.
+// Pointer form for host code (sizing: all outputs optional). Returns the number of bytes used. tail_doubles: what the
+// marginalization phase must leave alone at the end of the LDS (the iterate's landmarks).
 template <class MP>
 VIO_HD size_t carve_work(const BatchDims &d, bool lds_matrix, int nthreads, ldsd base, double *hm_global,
-                         WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr) {
+                         WorkT<MP> *w, Ctx *cx, size_t *state_end_doubles = nullptr, size_t *tail_doubles = nullptr) {
   const Carved<MP> c = carve_all<MP>(d, lds_matrix, nthreads, base, hm_global);
   if (w) *w = c.w;
   if (cx) cx->red = c.red, cx->lprof = c.lprof;
   if (state_end_doubles) *state_end_doubles = c.state_end_doubles;
+  if (tail_doubles) *tail_doubles = c.tail_doubles;
   return c.bytes;
 }
 

@@ -151,6 +151,7 @@ struct Ctx {
   VIO_AS3 long long *lprof;  // the same counters while the kernel runs (LDS); copied to prof at the end
   // cooperative windows (round 5): `coop` workgroups serve one window; member 0 owns the solve, the others wait for commands
   int coop = 1, member = 0;
+  unsigned coop_spin = 1u << 24;  // polls before a wait between the workgroups of a window gives up (BatchPtrs::coop_spin)
   mutable unsigned coop_seq = 0;  // commands issued (owner) / served (helper) so far: the same value in every work-item
 };
 
@@ -333,6 +334,7 @@ VIO_DEV void red_put(const WinView &v, WK &w, int fr, int cr, int fc, int cc, do
 // Ordering: payload stores, workgroup barrier, device-scope fence, flag store by one lane | flag load by one lane, barrier,
 // device-scope fence by EVERY wave (their vector L1 may hold the previous round's lines), payload loads.
 enum CoopCmd { COOP_EXIT = 1, COOP_EVAL = 2, COOP_SCHUR = 3 };
+constexpr unsigned kCoopSpinLimit = 1u << 24;  // polls (s_sleep 8 between them) before a wait gives up: seconds (Ctx::coop_spin)
 constexpr int kCoopMax = 4;
 struct CoopLayout {
   size_t o_pose, o_feat, o_ex, o_einv, o_tf, o_part, part, total;  // (doubles; [0, 8) are the flag words)
@@ -360,13 +362,15 @@ struct CoopLayout {
 __device__ __forceinline__ unsigned *coop_flags(const WinView &v) { return reinterpret_cast<unsigned *>(v.coop); }
 // (a wait that never ends would hang the device: after ~2^24 polls the error word is set and everybody moves on -- the solve
 // is then wrong and says so in its termination code)
-__device__ __forceinline__ void coop_spin(unsigned *word, unsigned want_at_least, unsigned *err, bool exact_seq) {
+// (once the error word is set every later wait of the window returns at once: one timeout, not one per phase)
+__device__ __forceinline__ void coop_spin(unsigned *word, unsigned want_at_least, unsigned *err, bool exact_seq, unsigned limit) {
   unsigned n = 0;
   for (;;) {
     const unsigned x = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (exact_seq ? (x >> 4) >= want_at_least : x >= want_at_least) break;
+    if ((n & 63u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     __builtin_amdgcn_s_sleep(8);
-    if (++n > (1u << 24)) {
+    if (++n > limit) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
@@ -383,16 +387,18 @@ VIO_DEV void coop_post(const Ctx &cx, const WinView &v, int code) {
 }
 // owner: until every helper has completed the commands posted so far; then their stores are visible to every work-item
 VIO_DEV void coop_wait_helpers(const Ctx &cx, const WinView &v) {
-  if (cx.tid == 0) coop_spin(coop_flags(v) + 1, cx.coop_seq * (unsigned)(cx.coop - 1), coop_flags(v) + 2, false);
+  if (cx.tid == 0) coop_spin(coop_flags(v) + 1, cx.coop_seq * (unsigned)(cx.coop - 1), coop_flags(v) + 2, false, cx.coop_spin);
   __syncthreads();
   __threadfence();
 }
 // helper: the next command (its inputs are visible to every work-item on return)
 VIO_DEV int coop_wait_cmd(const Ctx &cx, const WinView &v) {
   cx.coop_seq++;
-  if (cx.tid == 0) coop_spin(coop_flags(v), cx.coop_seq, coop_flags(v) + 2, true);
+  if (cx.tid == 0) coop_spin(coop_flags(v), cx.coop_seq, coop_flags(v) + 2, true, cx.coop_spin);
   __syncthreads();
   __threadfence();
+  // (a wait that gave up -- here or in another workgroup of the window -- reads as COOP_EXIT: the helper goes home)
+  if (__hip_atomic_load(coop_flags(v) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return COOP_EXIT;
   return (int)(__hip_atomic_load(coop_flags(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 15u);
 }
 // helper: every work-item has stored its results -> count this workgroup as done with the command
@@ -1118,9 +1124,11 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
   for (int c = 0; c < kSB; c++) {
     double y = __builtin_amdgcn_rsq(dcc);
     const double h = 0.5 * dcc;
-    y = y * fma(-h * y, y, 1.5);  // (v_rsq_f64 is good to ~26 bits: one Newton step leaves ~2^-51, a perturbation of the pivot far
-                                  //  below what the 1e-6 bar against the reference sees; the second step cost 3 dependent operations
-                                  //  on the pivot chain)
+    y = y * fma(-h * y, y, 1.5);  // (v_rsq_f64 is specified to 2^29 ulp, ~2^-23 relative: one Newton step leaves ~1.5 e^2 = ~2^-45
+                                  //  in every pivot -- not the ~2^-51 an earlier comment claimed --, still nine orders below the
+                                  //  1e-6 bar against the reference (tests/test_backend_gpu.py::test_ill_conditioned_windows
+                                  //  holds near-degenerate windows at the smallest mu to it); the second step cost 3
+                                  //  dependent operations on the pivot chain)
     const bool sel = kq == (c & 3);
     const double a = sel ? A[c >> 2] * y : 0.0;  // l[n] = L[n][c]  (n == c: dcc / sqrt(dcc))
     const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
@@ -3022,6 +3030,16 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         if (!first_try) {
           // retry with a larger mu: the in-place system was consumed, rebuild H from the factors (rare path)
           evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, true, true);
+          // (the Schur sweep below takes u_p = S D^-2 S g from xt for the W part of the Cauchy form: a first try that got as far
+          // as the back-substitution has left z there)
+          if (fuse_qw) {
+            VIO_PARFOR(i, np) {
+              const int f = i / kBS, c = i - f * kBS;
+              const double u = w.sp[i] * (pose_gd(w, i) * rcp_f(w.dp[i]));
+              w.t1[i] = u;
+              if (c < 6) w.xt[6 * f + c] = u;
+            }
+          }
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;

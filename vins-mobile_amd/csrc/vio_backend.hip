@@ -20,8 +20,7 @@
 #include "vio_pool.h"
 #include "vio_device.h"
 #include "marg_core.h"
-#include "vio_window_kernel.inc"
-#include "vio_phase.h"
+#include "vio_window_variants.h"
 #include "vio_amd.h"
 
 using namespace vio;
@@ -76,6 +75,17 @@ struct DevBuf {
 
 }  // namespace
 
+// The instantiations of the window kernel, one translation unit each (vio_wk_unit.hip, csrc/Makefile).
+#define VIO_WK_DECL(v) vio_wk::VariantFns vio_wk_variant_##v##_0(); vio_wk::VariantFns vio_wk_variant_##v##_1();
+VIO_WK_DECL(0) VIO_WK_DECL(1) VIO_WK_DECL(2) VIO_WK_DECL(3) VIO_WK_DECL(4) VIO_WK_DECL(5)
+#undef VIO_WK_DECL
+const vio_wk::VariantFns &vio_wk::variant(int v, bool prof) {
+  static const VariantFns tab[kVariants][2] = {{vio_wk_variant_0_0(), vio_wk_variant_0_1()}, {vio_wk_variant_1_0(), vio_wk_variant_1_1()},
+                                               {vio_wk_variant_2_0(), vio_wk_variant_2_1()}, {vio_wk_variant_3_0(), vio_wk_variant_3_1()},
+                                               {vio_wk_variant_4_0(), vio_wk_variant_4_1()}, {vio_wk_variant_5_0(), vio_wk_variant_5_1()}};
+  return tab[v][prof ? 1 : 0];
+}
+
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -113,13 +123,9 @@ struct vio_backend {
   size_t lds_bytes = 0;
   int threads_lds = kThreadsLds;
   int n_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  bool static_w = false;  // every window of the LDS launch has W = vio_wk::kStaticW frames and the batch has that window's capacities
   bool coop_ok = false;  // the global-matrix windows of the uploaded batch may run as cooperative windows (host-packed, no bucket across chunks)
   DevBuf<long long> d_prof;
-  // phase path (phase_core.h): the solve as a sequence of launches; state that lives across them
-  bool use_phase = false;
-  int path = VIO_PATH_AUTO;
-  size_t lds_setup = 0, lds_lin = 0;
-  DevBuf<double> d_phase;
   HostBatch hb;
   BatchPtrs B;
   MargPtrs MP;
@@ -196,11 +202,12 @@ int vio_backend_create(const VioConfig *cfg, int32_t max_batch, vio_backend_t **
   // the dynamic-LDS ceiling is a property of the FUNCTION, not of a launch: raised once to the CU's whole LDS for both
   // variants (several contexts on several host threads launch these kernels; a per-launch value could be lowered by
   // another thread between this thread's set and its launch)
-  if (vio_wk::window_kernel_attrs<false>((int)kLdsLimit) != hipSuccess || vio_window_attrs_prof((int)kLdsLimit) != hipSuccess ||
-      vio::phase_prepare() != VIO_OK) {
-    delete be;
-    return VIO_ENODEV;
-  }
+  for (int v = 0; v < vio_wk::kVariants; v++)
+    for (int p = 0; p < 2; p++)
+      if (hipFuncSetAttribute(vio_wk::variant(v, p != 0).fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess) {
+        delete be;
+        return VIO_ENODEV;
+      }
   if (hipStreamCreateWithFlags(&be->stream, hipStreamNonBlocking) != hipSuccess) {
     delete be;
     return VIO_ENODEV;
@@ -227,7 +234,7 @@ void vio_backend_destroy(vio_backend_t *be) {
                           &be->d_raw_feat, &be->d_out_loop, &be->d_stats_d, &be->d_m_x0, &be->d_m_J, &be->d_m_r,
                           &be->d_m_scratch};
   for (auto *b : db) b->release();
-  be->d_prof.release(), be->d_phase.release();
+  be->d_prof.release();
   for (int k = 0; k < 2; k++) be->d_st_x0[k].release(), be->d_st_J[k].release(), be->d_st_r[k].release();
   be->d_ptab.release();
   resident_destroy(be->res);
@@ -255,7 +262,7 @@ int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
 
 // LDS layout and launch split of a batch whose dims are d: which windows run the LDS variant (be->n_lds, be->d_lds,
 // be->lds_bytes), which the global-matrix one (be->n_glb, be->d_glb), in which order (`order`: launch-local block ->
-// window), and whether the phase path applies. nfeat[b]: landmarks of window b; Fmax: their maximum.
+// window). nfeat[b]: landmarks of window b; Fmax: their maximum.
 static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, int Fmax, std::vector<int> &order,
                        const std::vector<int> *active = nullptr) {  // active: the windows that take part (null: all n)
   d.Flds = std::max(Fmax, 1);
@@ -269,9 +276,9 @@ static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, i
   be->threads_lds = threads_lds;
   auto need_lds = [&](BatchDims dd, int asp) {
     dd.lds_asp = asp;
-    size_t se = 0;
-    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
+    size_t se = 0, tail = 0;
+    const size_t bs = carve_work<ldsd>(dd, true, threads_lds, nullptr, nullptr, nullptr, nullptr, &se, &tail);
+    const size_t bm = (se + tail) * sizeof(double) + carve_marg<ldsd>(dd, true, nullptr, nullptr, nullptr, 0);
     // the marginalization phase additionally wants >= 64 staging slots behind its matrix
     return std::max(bs, bm + 64 * kMargSlot * sizeof(double));
   };
@@ -320,28 +327,30 @@ static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, i
     }
   }
   be->d_lds = dl;
-  // Phase path: the windows of the LDS set are solved by a sequence of launches (phase_core.h) instead of one.
-  static const int phase_env = getenv("VIO_AMD_PHASE") ? atoi(getenv("VIO_AMD_PHASE")) : -1;
-  const bool want_phase = be->path == VIO_PATH_PHASE || (be->path == VIO_PATH_AUTO && phase_env == 1);
-  be->use_phase = want_phase && n_lds > 0 && threads_lds == kThreadsLds;
-  if (be->use_phase) {
-    vio::phase_lds_need(dl, &be->lds_setup, &be->lds_lin);
-    if (be->lds_setup > kLdsLimit || be->lds_lin > kLdsLimit) be->use_phase = false;
-  }
   if (be->n_glb > 0) {
     BatchDims dg = d;
     int fg = 1;
     for (size_t i = n_lds; i < order.size(); i++) fg = std::max(fg, nfeat[order[i]]);
     dg.Flds = fg;
-    size_t se = 0;
-    const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se);
-    const size_t bm = se * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
+    size_t se = 0, tail = 0;
+    const size_t bs = carve_work<double *>(dg, false, kThreadsGlb, nullptr, nullptr, nullptr, nullptr, &se, &tail);
+    const size_t bm = (se + tail) * sizeof(double) + carve_marg<double *>(dg, false, nullptr, nullptr, nullptr, 0);
     // (the marginalization phase stages its Jacobian rows in LDS in this variant too: at least 64 slots behind its vectors)
     const size_t bmm = bm + 64 * kMargSlot * sizeof(double);
     if (std::max(bs, bmm) > kLdsLimit) return VIO_ECAP;
     be->d_glb = dg, be->lds_bytes_glb = std::max(bs, bmm);
   }
   return VIO_OK;
+}
+
+// May the LDS launch of this batch take the instantiations with the window size at compile time (vio_window_variants.h)? Every
+// window has W = kStaticW frames, no window carries a relocalization pose (one more 6-dof block: other strides, another LDS
+// layout) and the prior capacity is what marginalize() can leave at that size. VIO_AMD_STATIC_W=0 keeps the run-time variants (A/B).
+static bool static_launch_ok(const vio_backend *be, const BatchDims &d, bool all_windows_static_w) {
+  static const bool off = getenv("VIO_AMD_STATIC_W") && getenv("VIO_AMD_STATIC_W")[0] == '0';
+  constexpr int W = vio_wk::kStaticW;
+  return !off && all_windows_static_w && be->threads_lds == kThreadsLds && d.Wcap == W && d.Pcap == W + 1 && d.nblk_cap == W + 1 &&
+         d.n6cap == 6 * (W + 2) && d.Ncap == 6 * W + 15 && d.pair_cap == (W + 2) * (W + 3) / 2;
 }
 
 // Work and output buffers of a batch of N windows with dims d (sticky: they only grow).
@@ -368,18 +377,17 @@ static int ensure_work_buffers(vio_backend *be, const BatchDims &d, const BatchS
   ENSURE(be->d_m_J, N * (size_t)d.Ncap * d.Ncap);
   ENSURE(be->d_m_r, N * (size_t)d.Ncap);
   ENSURE(be->d_m_scratch, m_scr ? N * m_scr : 1);
-  if (be->use_phase) ENSURE(be->d_phase, N * make_phase_layout(d).total);
 #undef ENSURE
   return VIO_OK;
 }
 
 // The work / output side of be->B and be->MP (the input arrays and B.ptab are bound by the caller).
-static int bind_work_buffers(vio_backend *be, const BatchDims &d, const BatchStrides &s, size_t N, const PhaseLayout &PL) {
+static int bind_work_buffers(vio_backend *be, const BatchDims &d, const BatchStrides &s, size_t N) {
   (void)s;
   const size_t m_ints = 4 + 3 * kMaxPriorBlocks, m_scr = be->lds_matrix ? 0 : marg_scratch_doubles(d.Wcap);
   BatchPtrs &B = be->B;
   B.scratch = be->d_scratch.p, B.hm = be->d_hm.p, B.order = nullptr, B.coop = 1, B.n_launch = 0;
-  B.phase = be->use_phase ? be->d_phase.p : nullptr, B.PL = PL;
+  B.coop_spin = vio::kCoopSpinLimit, B.coop_fault = 0;
   B.out_pose = be->d_out_pose.p, B.out_sb = be->d_out_sb.p, B.out_feat = be->d_out_feat.p;
   B.raw_pose = be->d_raw_pose.p, B.raw_sb = be->d_raw_sb.p, B.raw_feat = be->d_raw_feat.p;
   B.out_loop = be->d_out_loop.p, B.stats_d = be->d_stats_d.p, B.stats_i = be->d_stats_i.p;
@@ -414,6 +422,7 @@ int vio_backend_upload(vio_backend_t *be, const VioWindow *windows, int32_t n) {
 }
 
 static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int32_t n) {
+  be->coop_ok = false;  // (set again below once every global-matrix window is known to be packed for a cooperative launch)
   // an earlier launch may still be reading the device inputs this upload overwrites (it may have gone to a caller's
   // stream): wait for it first
   if (be->last_stream && be->last_stream != be->stream) HIP_OK(hipStreamSynchronize(be->last_stream));
@@ -475,6 +484,11 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     const int rcl = plan_layout(be, d, n, nfeat.data(), Fmax, order);
     if (rcl != VIO_OK) return rcl;
   }
+  {
+    bool all_w = true;
+    for (int b = 0; b < n; b++) all_w = all_w && windows[b].window_size == vio_wk::kStaticW;
+    be->static_w = static_launch_ok(be, d, all_w);
+  }
   const int threads_lds = be->threads_lds, n_lds = be->n_lds;
   const BatchDims dl = be->d_lds;
   (void)n_lds;
@@ -486,8 +500,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   {
     std::vector<int> rcs(n, VIO_OK);
     const bool lds_shape = pose_jp(d) <= 16 * kPanelTiles;
-    // (bucket alignment to the staging chunk only serves the single-launch kernel; the phase path walks the slots in strips)
-    const int chunk = be->use_phase && be->n_glb == 0 ? 0 : stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
+    const int chunk = stage_chunk_slots(dl, lds_shape, lds_shape ? threads_lds : kThreadsGlb);
     // (windows of the global-matrix launch have their own layout and chunk; a cooperative launch needs every bucket inside a chunk)
     const int chunk_glb = be->n_glb > 0 ? stage_chunk_slots(be->d_glb, false, kThreadsGlb) : 0;
     std::vector<char> glb(n, 0), strad(n, 0);
@@ -518,7 +531,6 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
     if (rce == VIO_OK) rce = ensure_work_buffers(be, d, s, N);
     if (rce != VIO_OK) return rce;
   }
-  const PhaseLayout PL = make_phase_layout(d);
   hipStream_t st = be->stream;
 #define H2D(dst, src) HIP_OK(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, st))
   H2D(be->d_order, be->h_order);
@@ -567,7 +579,7 @@ static int backend_upload_impl(vio_backend_t *be, const VioWindow *windows, int3
   }
   B.ptab = any_slot ? be->d_ptab.p : nullptr;
   {
-    const int rcb = bind_work_buffers(be, d, s, N, PL);
+    const int rcb = bind_work_buffers(be, d, s, N);
     if (rcb != VIO_OK) return rcb;
   }
   be->n = n;
@@ -599,22 +611,16 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
     HIP_OK(hipMemsetAsync(be->d_hm.p, 0xff, be->d_hm.n * sizeof(double), st));
     HIP_OK(hipMemsetAsync(be->d_out_pose.p, 0xff, be->d_out_pose.n * sizeof(double), st));
     HIP_OK(hipMemsetAsync(be->d_stats_d.p, 0xff, be->d_stats_d.n * sizeof(double), st));
-    if (be->use_phase) HIP_OK(hipMemsetAsync(be->d_phase.p, 0xff, be->d_phase.n * sizeof(double), st));
     HIP_OK(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), kLdsLimit, st, (int)(kLdsLimit / sizeof(double)));
   }
   HIP_OK(hipEventRecord(ev.first, st));
-  if (be->n_lds > 0 && be->use_phase) {
-    if (be->MP.prof) HIP_OK(hipMemsetAsync(be->d_prof.p, 0, be->d_prof.n * sizeof(long long), st));  // (the launches of a sequence add up)
+  if (be->n_lds > 0) {
     BatchPtrs Bl = be->B;
     Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    vio::phase_launch(Bl, be->MP, be->n_lds, be->lds_setup, be->lds_lin, be->lds_bytes, st);
-  } else if (be->n_lds > 0) {
-    BatchPtrs Bl = be->B;
-    Bl.d = be->d_lds, Bl.order = be->d_order.p;
-    const int variant = be->threads_lds == kThreadsLds ? (be->d_lds.lds_asp ? 0 : 1) : 2;
-    if (be->MP.prof) vio_window_launch_prof(variant, be->n_lds, be->lds_bytes, st, Bl, be->MP);
-    else vio_wk::window_kernel_launch<false>(variant, be->n_lds, be->lds_bytes, st, Bl, be->MP);
+    int variant = be->threads_lds == kThreadsLds ? (be->d_lds.lds_asp ? 0 : 1) : 2;
+    if (variant < 2 && be->static_w) variant += 4;  // (every window of the launch has the compile-time window size: vio_window_variants.h)
+    vio_wk::variant(variant, be->MP.prof != nullptr).launch(be->n_lds, be->lds_bytes, st, Bl, be->MP);
   }
   if (be->n_glb > 0) {
     BatchPtrs Bg = be->B;
@@ -632,17 +638,30 @@ int vio_backend_launch(vio_backend_t *be, void *stream) {
       // CUs stay free -- with every CU busy the shared phases of 64 windows hit the memory system together)
       const bool four = groups * 8 * 4 <= cus && (be->d_glb.Wcap >= 24 || groups * 8 * 8 <= cus);
       coop = four ? 4 : groups * 8 * 2 <= cus ? 2 : 1;
-      if (forced >= 1 && forced <= vio::kCoopMax && groups * 8 * forced <= be->n_cus) coop = forced;
+      if (forced >= 1 && forced <= vio::kCoopMax && groups * 8 * forced <= cus) coop = forced;  // (a forced width obeys the peers bound too)
+      if (coop > 1) {
+        // every workgroup of the launch has to be resident at once (the members of a window wait for each other): ask the runtime
+        // what the device holds of this kernel at this LDS size instead of trusting the arithmetic above alone
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vio_wk::variant(3, false).fn,
+                                                         kThreadsGlb, be->lds_bytes_glb) != hipSuccess ||
+            (long long)per_cu * cus < (long long)groups * 8 * coop)
+          coop = 1;
+      }
     }
     Bg.coop = coop, Bg.n_launch = be->n_glb;
+    {  // test hooks of the timeout path (tests/test_backend_gpu.py): read per launch
+      const char *sp_ = getenv("VIO_AMD_COOP_SPIN"), *ft_ = getenv("VIO_AMD_COOP_FAULT");
+      Bg.coop_spin = sp_ && atoi(sp_) > 0 ? (unsigned)atoi(sp_) : vio::kCoopSpinLimit;
+      Bg.coop_fault = ft_ && ft_[0] == '1' ? 1 : 0;
+    }
     int grid = be->n_glb;
     if (coop > 1) {
       grid = (be->n_glb + 7) / 8 * 8 * coop;
       // flag words of every window of the batch: command, completions, error (the first 32 bytes of the cooperative area)
       HIP_OK(hipMemset2DAsync(be->d_scratch.p + be->B.s.s_coop, be->B.s.scratch * sizeof(double), 0, 32, (size_t)be->B.n, st));
     }
-    if (be->MP.prof) vio_window_launch_prof(3, grid, be->lds_bytes_glb, st, Bg, be->MP);
-    else vio_wk::window_kernel_launch<false>(3, grid, be->lds_bytes_glb, st, Bg, be->MP);
+    vio_wk::variant(3, be->MP.prof != nullptr).launch(grid, be->lds_bytes_glb, st, Bg, be->MP);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ev.second, st));
@@ -669,13 +688,6 @@ int vio_backend_kernel_ms(vio_backend_t *be, double *ms_avg, int32_t *launches) 
   *launches = (int32_t)be->events_used;
   *ms_avg = be->events_used ? sum / be->events_used : 0.0;
   be->events_used = 0;
-  return VIO_OK;
-}
-
-int vio_backend_set_path(vio_backend_t *be, int32_t path) {
-  if (!be || path < VIO_PATH_AUTO || path > VIO_PATH_PHASE) return VIO_EINVAL;
-  be->path = path;
-  be->uploaded = false;  // takes effect at the next upload
   return VIO_OK;
 }
 
@@ -756,6 +768,15 @@ static int backend_download_impl(vio_backend_t *be, VioWindow *windows, int32_t 
       unpack_prior(mo, *windows[b].next_prior, k < 0);
     }
   });
+  // a cooperative window whose workgroups did not meet (solver_core.h, coop_spin): FAILURE, and the call says so
+  bool timed_out = false;
+  for (int b = 0; b < n; b++)
+    if (be->h_stats_i[(size_t)b * s.stats_i + 1] == -9) {
+      timed_out = true;
+      if (stats) stats[b].termination = 2;
+      if (windows[b].next_prior) windows[b].next_prior->n = 0, windows[b].next_prior->n_blocks = 0;
+      be->h_m_ints[(size_t)b * be->MP.s_ints] = 0;  // (its slot keeps the previous prior)
+    }
   // advance the slots whose window produced a new prior; once per upload (a second download of the same launch, or a
   // re-launch of the same upload, reads and writes the same banks again)
   if (!be->slots_advanced) {
@@ -767,7 +788,7 @@ static int backend_download_impl(vio_backend_t *be, VioWindow *windows, int32_t 
   }
   if (host_timing())
     fprintf(stderr, "vio_backend_download: wait for kernel %.2f ms, D2H %.2f ms, unpack %.2f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
-  return VIO_OK;
+  return timed_out ? VIO_ETIMEOUT : VIO_OK;
 }
 
 int vio_backend_solve_windows(vio_backend_t *be, VioWindow *windows, int32_t n, int32_t buf_num, VioSolveStats *stats) {

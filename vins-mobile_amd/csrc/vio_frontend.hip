@@ -2334,6 +2334,7 @@ int vio_frontend_get_state(vio_frontend_t *fe, int32_t seq, float *cur_pts, int3
 // leaves the list empty.
 int vio_frontend_lk_iterations(vio_frontend_t *fe, int32_t enable, uint64_t *iterations, uint64_t *visits, int32_t levels_cap) {
   if (!fe || (iterations && (!visits || levels_cap < 1))) return VIO_EINVAL;
+  if (fe->pending) return VIO_ESTATE;  // (a submitted frame's worker reads lk_stats_on / lk_stats while it queues the step)
   VIO_ON_DEVICE_OF(fe);
   constexpr int kSlots = 16 * 64;  // 64 copies of [iterations (levels) | visits (levels)], summed here
   if (!fe->lk_stats) {
