@@ -22,7 +22,9 @@ VIO_MARGIN_OLD, VIO_MARGIN_SECOND_NEW, VIO_MARGIN_NONE = 0, 1, 2
 STAGES = ["setup_imu", "setup_prior", "eval_prior", "eval_imu", "eval_proj", "scale", "schur", "rhs", "cholesky",
           "tri_solve", "quad_form", "dogleg", "cost_eval", "new2old", "marg_build", "marg_chol", "total",
           "p_zero", "p_fact", "p_gram", "p_feat", "c_potrf", "c_trsm", "imu_raw", "c_wait", "q_w", "backsolve",
-          "c_ahead", "tr_vec", "m_prior", "m_imu", "m_fact", "m_gram", "d0", "d1", "d2", "d3", "d4", "d5"]
+          "c_ahead", "tr_vec", "m_prior", "m_imu", "m_fact", "m_gram", "d0", "d1", "d2", "d3", "d4", "d5",
+          "v_gd", "v_dot", "v_step", "v_plus", "v_gmax", "v_rest", "b_init", "b_pose", "b_asp", "b_band", "b_gn",
+          "e_head", "e_copy", "e_h0dx", "e_tail", "x0", "x1", "x2", "x3"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

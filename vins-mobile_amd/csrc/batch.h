@@ -29,6 +29,7 @@ struct BatchDims {
   int Flds;  // landmarks the LDS layout is carved for (<= Fcap, which sizes the global strides): every landmark costs LDS
   int lds_asp;  // LDS pose matrix: the IMU speed-bias x pose coupling (AspI, 14 KB at W = 10) sits in LDS too (1, faster)
                 // or in global scratch (0: leaves the room to windows with many landmarks, two of which then share a CU)
+  int prof_stages;  // LDS slots of the stage clock: ST_COUNT for the launches of vio_backend_set_profile, 0 for the product's
   int max_iter;
   double s_info, gravity, cauchy_b;
 };
@@ -42,6 +43,7 @@ inline BatchDims make_dims(const VioConfig &cfg, int Wcap, int Fcap, int Mcap, b
   d.Fpad = (d.Fcap + 7) / 8 * 8;
   d.Flds = d.Fcap;
   d.lds_asp = 1;
+  d.prof_stages = 0;
   d.n6cap = 6 * (d.Pcap + 1);  // pose groups 0..P-1 plus one more: loop pose (solve) / extrinsic (marginalization)
   d.nblk_cap = d.Pcap + (any_loop ? 1 : 0);
   d.pair_cap = (d.Pcap + 1) * (d.Pcap + 2) / 2;  // distinct (host, target) pairs incl. the loop pose
@@ -62,6 +64,9 @@ inline int pose_jp(const BatchDims &d) { return (pose_rows(d) + 15) / 16 * 16; }
 // Cooperative windows (several workgroups per window, solver_core.h): flags and payload of one window in its scratch.
 inline size_t coop_doubles(const BatchDims &d) { return CoopLayout::make(d.Pcap, d.Fcap, d.nblk_cap).total; }
 inline size_t slot_capacity(const BatchDims &d) { return 2 * (size_t)d.Mcap + d.pair_cap + 2; }
+// Gram pieces (solver_core.h): a (host, target) bucket is cut at staging-chunk boundaries and into runs of kGramPiece slots
+inline size_t gram_piece_capacity(const BatchDims &d) { return slot_capacity(d) / kGramPiece + 2 * (size_t)d.pair_cap + 64; }
+inline size_t gram_chunk_capacity(const BatchDims &d) { return slot_capacity(d) / kGramMinChunk + 8; }
 
 // Element counts per window of every array (strides).
 struct BatchStrides {
@@ -69,8 +74,29 @@ struct BatchStrides {
   size_t scratch, hm;
   size_t out_pose, out_sb, out_feat, out_loop, stats_d, stats_i;
   // offsets inside the per-window scratch block (doubles)
-  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash, s_coop;
+  size_t s_info, s_aug, s_J, s_M, s_r, s_Mr, s_prJT, s_prH0, s_WTf, s_PP, s_sfact, s_Asp, s_AspG, s_AppPr, s_srec_i, s_srec_d, s_stash, s_coop, s_gpiece, s_gstart;
 };
+
+// The arrays of the per-window scratch block whose size depends on the window size alone (and on the prior capacity, itself a
+// function of the window size in every batch the product builds) come FIRST: with the window size a compile-time constant
+// (vio_window_kernel.inc, WS > 0) their offsets are constants and the view of a window is one base address. Returns the end.
+VIO_HD size_t scratch_fixed_offsets(int Wcap, int Ncap, int nblk_cap, BatchStrides &s) {
+  const int Pcap = Wcap + 1, prows = 6 * nblk_cap + 1, jp = (prows + 15) / 16 * 16;
+  size_t o = 0;
+  s.s_info = o, o += (size_t)Wcap * 225;
+  s.s_aug = o, o += (size_t)Wcap * 450;
+  s.s_J = o, o += (size_t)Wcap * 450;
+  s.s_M = o, o += (size_t)Wcap * 450;
+  s.s_r = o, o += (size_t)Wcap * 15;
+  s.s_Mr = o, o += (size_t)Wcap * 15;
+  s.s_prJT = o, o += (size_t)Ncap;  // b0 = J0^T r0
+  s.s_prH0 = o, o += (size_t)Ncap * Ncap;
+  s.s_PP = o, o += tri_doubles(prows);  // (layout of App)
+  s.s_Asp = o, o += (size_t)kSB * jp;  // the prior's speed-bias x pose block
+  s.s_AspG = o, o += (size_t)Pcap * kAS;
+  s.s_AppPr = o, o += tri_doubles(prows) + 2 * (size_t)Pcap * kSS;
+  return o;
+}
 
 inline BatchStrides make_strides(const BatchDims &d) {
   BatchStrides s;
@@ -78,26 +104,18 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.fint = d.Mcap, s.pts = 3 * (size_t)d.Mcap, s.preint = (size_t)d.Wcap * kPreintDoubles;
   s.fstart = (size_t)d.Fcap + 1, s.pair = d.pair_cap;
   s.pr_int = kMaxPriorBlocks, s.pr_x0 = 9 * (size_t)kMaxPriorBlocks, s.pr_J = (size_t)d.Ncap * d.Ncap, s.pr_r = d.Ncap;
-  size_t o = 0;
-  s.s_info = o, o += (size_t)d.Wcap * 225;
-  s.s_aug = o, o += (size_t)d.Wcap * 450;
-  s.s_J = o, o += (size_t)d.Wcap * 450;
-  s.s_M = o, o += (size_t)d.Wcap * 450;
-  s.s_r = o, o += (size_t)d.Wcap * 15;
-  s.s_Mr = o, o += (size_t)d.Wcap * 15;
-  s.s_prJT = o, o += (size_t)d.Ncap;  // b0 = J0^T r0
-  s.s_prH0 = o, o += (size_t)d.Ncap * d.Ncap;
+  const size_t fixed_end = scratch_fixed_offsets(d.Wcap, d.Ncap, d.nblk_cap, s);
+  size_t o = fixed_end;
+  // ---- arrays sized by the landmark / factor capacities of the batch
   s.s_WTf = o, o += (size_t)d.n6cap * d.Fpad;
-  s.s_PP = o, o += tri_doubles(pose_rows(d));  // (layout of App)
   s.s_sfact = o, o += (slot_capacity(d) + 1) / 2;  // ints: staging slot -> factor
-  s.s_Asp = o, o += (size_t)kSB * pose_jp(d);  // the prior's speed-bias x pose block
-  s.s_AspG = o, o += (size_t)d.Pcap * kAS;
-  s.s_AppPr = o, o += tri_doubles(pose_rows(d)) + 2 * (size_t)d.Pcap * kSS;
   const size_t nslots_cap = slot_capacity(d);
   s.s_srec_i = o, o += (nslots_cap + 1) / 2;
   s.s_srec_d = o, o += 6 * nslots_cap;
   s.s_stash = o, o += 7 * (size_t)(d.Pcap + 1) + 9 * (size_t)d.Pcap + 4 * (size_t)d.Fcap + 3 * (size_t)(d.Pcap + 1) * kBS;
   s.s_coop = o, o += coop_doubles(d);  // cooperative windows: flags + payload (solver_core.h, CoopLayout)
+  s.s_gpiece = o, o += (gram_piece_capacity(d) + 1) / 2;  // ints: the Gram pieces of the window (solver_core.h, build_gram_pieces)
+  s.s_gstart = o, o += (gram_chunk_capacity(d) + 1) / 2;  // ints: first piece of every staging chunk
   s.scratch = (o + 7) / 8 * 8;
   s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
@@ -186,6 +204,7 @@ VIO_HD WinView make_view(const BatchPtrs &B, int b) {
   v.imu_r = sc + B.s.s_r, v.imu_Mr = sc + B.s.s_Mr, v.prb0 = sc + B.s.s_prJT, v.prH0 = sc + B.s.s_prH0;
   v.WTf = sc + B.s.s_WTf, v.PP = sc + B.s.s_PP, v.Apri = sc + B.s.s_Asp, v.AspG = sc + B.s.s_AspG, v.AppPr = sc + B.s.s_AppPr;
   v.srec_i = reinterpret_cast<int *>(sc + B.s.s_srec_i), v.srec_d = sc + B.s.s_srec_d;
+  v.gpiece = reinterpret_cast<int *>(sc + B.s.s_gpiece), v.gstart = reinterpret_cast<int *>(sc + B.s.s_gstart);
   v.sfact = reinterpret_cast<int *>(sc + B.s.s_sfact);
   v.stash = sc + B.s.s_stash;
   v.coop = sc + B.s.s_coop;
@@ -251,7 +270,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.xpose = take(7 * (size_t)(d.Pcap + 1)), w.xsb = take(9 * (size_t)d.Pcap);
   w.ex = take(8);
   c.red = take(6 * ((size_t)nthreads / 64) + 2);
-  c.lprof = reinterpret_cast<VIO_AS3 long long *>(take(ST_COUNT));
+  c.lprof = reinterpret_cast<VIO_AS3 long long *>(take((size_t)d.prof_stages));
   c.state_end_doubles = o;
   c.tail_doubles = Fe;
   // the reduced matrix: pose matrix (LDS or global) and the speed-bias band (always LDS), contiguous when both are in
@@ -400,9 +419,9 @@ struct HostBatch {
   // padding keeps finite values of earlier windows.
   void resize(const BatchDims &dims, int n_, bool poison = false) {
     BatchDims a = d, b = dims;
-    a.Flds = b.Flds = 0, a.lds_asp = b.lds_asp = 0;  // the LDS carve does not change the staging layout
+    a.Flds = b.Flds = 0, a.lds_asp = b.lds_asp = 0, a.prof_stages = b.prof_stages = 0;  // the LDS carve does not change the staging layout
     if (sized && !poison && n == n_ && memcmp(&a, &b, sizeof(BatchDims)) == 0) {
-      d.Flds = dims.Flds, d.lds_asp = dims.lds_asp;
+      d.Flds = dims.Flds, d.lds_asp = dims.lds_asp, d.prof_stages = dims.prof_stages;
       return;
     }
     d = dims, s = make_strides(dims), n = n_, sized = true;

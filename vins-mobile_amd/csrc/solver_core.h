@@ -105,7 +105,13 @@ typedef VIO_AS3 int *ldsi;
 
 #ifdef VIO_HOST_BUILD
 inline void atomic_add(double *p, double v) { *p += v; }
+inline void atomic_add_noret(double *p, double v) { *p += v; }
 #else
+// Global memory that several workgroups of ONE window may add to (cooperative windows): device scope. No return value: the
+// instruction is fire-and-forget (global_atomic_add_f64 at the L2).
+__device__ __forceinline__ void atomic_add_noret(double *p, double v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void atomic_add(ldsd p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -136,7 +142,16 @@ enum Stage {
   ST_TR_VEC,                                       // trust-region vector phase before the linear solve
   ST_M_PRIOR, ST_M_IMU, ST_M_FACT, ST_M_GRAM,      // marginalization: prior/setup, IMU factor, factor staging, Gram
   ST_D0, ST_D1, ST_D2, ST_D3, ST_D4, ST_D5,         // free slots for timing experiments (VIO_AMD_PROF_TID picks the clock's lane)
-  ST_COUNT = 40                                    // (last slot = time of the previous stamp)
+  // round 6: the O(n) vector phases of a trust-region iteration, one slot per barrier interval
+  ST_V_GD,                                         // |g_d|^2, Cauchy direction, quad_form vectors (one pass + reduction)
+  ST_V_DOT, ST_V_STEP,                             // dogleg: the two inner products (+ reduction); step -> t2 / tf (+ barrier)
+  ST_V_PLUS,                                       // Plus in place, stash of the iterate, norms (+ reduction)
+  ST_V_GMAX,                                       // gradient max norm + the iteration record
+  ST_V_REST,                                       // restore after a rejected step
+  ST_B_INIT, ST_B_POSE, ST_B_ASP, ST_B_BAND, ST_B_GN,  // backsolve: copies; pose tiles; A_sp z_p; band chains (+ landmarks); GN step
+  ST_E_HEAD, ST_E_COPY, ST_E_H0DX, ST_E_TAIL,      // evaluate(jac): rotations + zeroing; AppPr + PP copy (+ raw IMU); H0 dx + diagonal blocks; diag / scaling tail
+  ST_X0, ST_X1, ST_X2, ST_X3,
+  ST_COUNT = 64                                    // (last slot = time of the previous stamp)
 };
 
 struct Ctx {
@@ -206,6 +221,8 @@ struct WinView {
                      //                 with the extrinsic in the column group of the relocalization pose, marg_core.h)
   int *sfact;        // staging slot -> factor index (-1: unused tail slot of an odd bucket), built once per solve
   int *srec_i;       // staging slot -> host | target << 8 | landmark << 16 (-1: unused slot), built once per solve: the factor
+  int *gpiece;       // Gram pieces in slot order, built once per solve: slot offset in its chunk | slots << 10 | host << 15 | target << 21
+  int *gstart;       // [chunks + 1] first piece of every staging chunk
   double *srec_d;    // data in SLOT order ([slot][6] = pts_i, pts_j), one global round trip per evaluation pass instead of two
   double *PP;        // off-diagonal pose-pose blocks of the projection Gram products IN THE LAYOUT OF App (tri_at; zero where no
                      // (host, target) bucket writes: zeroed once per solve), so that a linearization starts the pose matrix as
@@ -1311,6 +1328,63 @@ constexpr int kSlotStride = 29;  // marginalization phase: two rows of 14 + 1 pa
 // threads form themselves. 21 doubles per factor instead of 29: fewer, larger staging chunks.
 constexpr int kGRow = 10;
 constexpr int kGSlot = 2 * kGRow + 1;
+constexpr int kGramPiece = 30;     // slots (15 matrix instructions) of one Gram piece at most: two operand batches, one flush
+constexpr int kGramMinChunk = 32;  // a staging chunk never holds fewer slots than this (gram_chunk_slots)
+
+// Staging slots per pass of the Jacobian evaluation (batch.h stage_chunk_slots computes the same on the host).
+template <class WK>
+VIO_DEV int gram_chunk_slots(const Ctx &cx, const WK &w) {
+  int CH = (w.nstage / kGSlot) & ~1;
+  if (CH >= (int)cx.nt) CH -= CH % (int)cx.nt;  // whole rounds of the workgroup: no chunk ends in a nearly empty pass
+  return CH;
+}
+
+// The Gram pieces of a window, once per solve (the bucket layout does not change during it). A (host, target) bucket is cut at
+// the staging-chunk boundaries and into runs of kGramPiece slots: piece = slot offset inside its chunk | slots << 10 |
+// host << 15 | target << 21, in slot order; gstart[c] = first piece of chunk c. The waves of a workgroup take the pieces of a
+// chunk round-robin (projections_jac): the buckets themselves are very uneven -- a dozen pairs of neighbouring frames hold 30 to
+// 90 factors each, forty others 3 to 16 -- and with a bucket per wave (rounds 3-5) the wave with the 87-factor bucket ran 44
+// matrix instructions while the others waited at the barrier.
+template <class WK>
+VIO_DEV void build_gram_pieces(const Ctx &cx, const WinView &v, WK &w) {
+  const int CH = gram_chunk_slots(cx, w), nchunks = (v.nslots + CH - 1) / CH;
+  ldsi cnt = reinterpret_cast<ldsi>(w.stage);  // [npairs] pieces of every bucket, then [nchunks + 1] pieces per chunk
+  ldsi cc = cnt + v.npairs;
+  VIO_PARFOR(c, nchunks + 1) cc[c] = 0;
+  VIO_SYNC();
+  VIO_PARFOR(b, v.npairs) {
+    const int s0 = v.pair_s0[b], s1 = v.pair_s1[b];
+    int n = 0;
+    for (int c = s0 / CH; c * CH < s1; c++) {
+      const int lo = s0 > c * CH ? s0 : c * CH, hi = s1 < (c + 1) * CH ? s1 : (c + 1) * CH;
+      const int np_ = (hi - lo + kGramPiece - 1) / kGramPiece;
+      n += np_;
+#ifdef VIO_HOST_BUILD
+      cc[c + 1] += np_;
+#else
+      __hip_atomic_fetch_add(cc + c + 1, np_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
+    cnt[b] = n;
+  }
+  VIO_SYNC();
+  VIO_PARFOR(b, v.npairs) {
+    int idx = 0;
+    for (int q = 0; q < b; q++) idx += cnt[q];
+    const int s0 = v.pair_s0[b], s1 = v.pair_s1[b], ht = (v.pair_h[b] << 15) | (v.pair_t[b] << 21);
+    for (int c = s0 / CH; c * CH < s1; c++) {
+      const int lo = s0 > c * CH ? s0 : c * CH, hi = s1 < (c + 1) * CH ? s1 : (c + 1) * CH;
+      for (int p0 = lo; p0 < hi; p0 += kGramPiece)
+        v.gpiece[idx++] = (p0 - c * CH) | ((hi - p0 < kGramPiece ? hi - p0 : kGramPiece) << 10) | ht;
+    }
+  }
+  VIO_PARFOR(c, nchunks + 1) {
+    int sacc = 0;
+    for (int q = 0; q <= c; q++) sacc += cc[q];
+    v.gstart[c] = sacc;
+  }
+  VIO_SYNC();
+}
 
 // Projection factors with Jacobians. The (not yet assembled) matrix buffer is used as a staging area: every factor
 // writes its two robustified Jacobian rows into its slot of the (host,target)-bucketed order; each bucket's
@@ -1323,8 +1397,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   const double bb = v.cauchy_b, cc = 1.0 / bb;
   double cost = 0.0;
   auto G = w.stage;  // (the reduced matrix is assembled after the last chunk: its buffer stages the Jacobian rows)
-  int CH = (w.nstage / kGSlot) & ~1;
-  if (CH >= (int)cx.nt) CH -= CH % (int)cx.nt;  // whole rounds of the workgroup: no chunk ends in a nearly empty pass
+  const int CH = gram_chunk_slots(cx, w);
   // Per-feature sums (host coupling w_h = sum Ji^T Jl, H_ff = sum Jl^T Jl, g_f = sum Jl^T r over the feature's factors)
   // are gathered with LDS atomics by the factor threads themselves. The six components of w_h use six F-vectors that
   // are dead whenever Jacobians are evaluated (the candidate, the step, the Gauss-Newton step and the e / 1/e / g/e
@@ -1332,14 +1405,45 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   ldsd whv[6] = {w.cfeat, w.stf, w.gnf, w.tf, w.ef, w.einv};
   // (cooperative windows: chunk share, share + nshare, ... -- the host packer keeps a bucket inside one chunk, so every
   // bucket's off-diagonal block still has one writer)
+  // first piece of every chunk, one chunk per lane (read ahead of the chunk loop: a dependent global round trip at the head of
+  // every chunk's Gram phase otherwise); chunks past the 63rd are read where they are needed
+  const int g_lane = VIO_TID(cx) & 63, g_nch = (v.nslots + CH - 1) / CH;
+  const int g_start = v.gstart[g_lane <= g_nch ? g_lane : 0];
+  // The slot records of a chunk (one global round trip) are fetched one chunk ahead: the fetch of chunk c + 1 travels behind the
+  // arithmetic of chunk c and its Gram phase (one slot per work-item and chunk whenever the chunk is the workgroup's size).
+  const bool one_pass = CH <= (int)cx.nt;
+  int rec_n = -1;
+  double pij_n[6] = {0, 0, 0, 0, 0, 0};
+  if (one_pass) {
+    const int sl0 = share * CH + VIO_TID(cx);
+    if (sl0 < v.nslots && VIO_TID(cx) < CH) {
+      rec_n = v.srec_i[sl0];
+#pragma unroll
+      for (int c = 0; c < 6; c++) pij_n[c] = v.srec_d[6 * (size_t)sl0 + c];
+    }
+  }
   for (int c0 = share * CH; c0 < v.nslots; c0 += nshare * CH) {
     stamp(cx, ST_P_ZERO);
     const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
     VIO_PARFOR(slot, nsl) {  // slot order: every lane of every wave has a factor (bar the odd tails)
-      const int rec = v.srec_i[c0 + slot];
+      int rec;
       double pij[6];
+      if (one_pass) {
+        rec = rec_n;
 #pragma unroll
-      for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(c0 + slot) + c];
+        for (int c = 0; c < 6; c++) pij[c] = pij_n[c];
+        const int sln = c0 + nshare * CH + slot;  // this work-item's slot of the next chunk
+        rec_n = -1;
+        if (sln < v.nslots) {
+          rec_n = v.srec_i[sln];
+#pragma unroll
+          for (int c = 0; c < 6; c++) pij_n[c] = v.srec_d[6 * (size_t)sln + c];
+        }
+      } else {
+        rec = v.srec_i[c0 + slot];
+#pragma unroll
+        for (int c = 0; c < 6; c++) pij[c] = v.srec_d[6 * (size_t)(c0 + slot) + c];
+      }
       if (rec < 0) continue;
       const int h = rec & 255, t = (rec >> 8) & 255, f = rec >> 16;
       double r[2], Ji[12], Jj[12], Jl[2];
@@ -1396,73 +1500,87 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
           else if (col < 12) f_lds[r4] = true, f_t[r4] = true, f_mul[r4] = kBS, f_base[r4] = w.gp + col - 6;
         }
       }
-      // bucket descriptors of this wave's rounds, one round per lane (a dependent global load per round otherwise)
-      const int pl = wave + lane * nw;
-      const bool pv = pl < v.npairs;
-      const int m_s0 = pv ? v.pair_s0[pl] : 0, m_s1 = pv ? v.pair_s1[pl] : 0;
-      const int m_ht = pv ? (v.pair_h[pl] << 16) | v.pair_t[pl] : 0;
-      // rounds of this wave whose bucket reaches into this chunk: one ballot instead of a walk over all of them (a chunk
-      // holds a dozen of the window's ~55 buckets). Rounds past the 64th (more than 64 nw buckets: never at W <= 12) follow.
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(pv && (m_s0 > c0 ? m_s0 : c0) < (m_s1 < c0 + CH ? m_s1 : c0 + CH));
-      int tail_p = wave + 64 * nw;
-      while (todo || tail_p < v.npairs) {
-        int b_s0, b_s1, b_ht, b_pair;
-        if (todo) {
-          const int rl = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          b_s0 = __builtin_amdgcn_readlane(m_s0, rl), b_s1 = __builtin_amdgcn_readlane(m_s1, rl);
-          b_ht = __builtin_amdgcn_readlane(m_ht, rl), b_pair = wave + rl * nw;
-        } else {
-          b_s0 = v.pair_s0[tail_p], b_s1 = v.pair_s1[tail_p], b_ht = (v.pair_h[tail_p] << 16) | v.pair_t[tail_p];
-          b_pair = tail_p, tail_p += nw;
-        }
-        int s_lo = b_s0 > c0 ? b_s0 : c0, s_hi = b_s1 < c0 + CH ? b_s1 : c0 + CH;
-        if (s_lo >= s_hi) continue;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        // column li of G = [Ji | Jj | r]: staged entry and sign (columns 13..15 of the 16-wide tile are zero)
-        const bool lv = li < 13;
-        const int src = li < 6 ? li : li < 9 ? li - 6 : li < 12 ? li - 3 : 9;
-        const double sg = (li >= 6 && li < 9) ? -1.0 : (lv ? 1.0 : 0.0);
-        auto g = G + (s_lo - c0 + (kq >> 1)) * kGSlot + (kq & 1) * kGRow + (lv ? src : 0);
-        v4d acc2 = {0.0, 0.0, 0.0, 0.0};
-        int steps = (s_hi - s_lo) >> 1;  // full two-factor steps; an odd last factor is a masked half step
-        for (; steps > 0; steps -= 8, g += 16 * kGSlot) {  // up to 8 steps per trip: every fetch ahead of the first product
-          double a[8];
+      // Pieces (round 6, build_gram_pieces): the waves take the pieces of this chunk round-robin; a piece is at most 8 matrix
+      // instructions on ONE batch of operand reads, the next piece's reads are in flight while this one multiplies. Pieces of one
+      // bucket meet through atomics -- LDS for the diagonal blocks and the gradient, no-return global atomics for the off-diagonal
+      // block in PP, which every linearization finds zeroed (evaluate()).
+      const int ci = c0 / CH;
+      int p_lo, p_hi;
+      if (ci < 63) p_lo = __builtin_amdgcn_readlane(g_start, ci), p_hi = __builtin_amdgcn_readlane(g_start, ci + 1);
+      else p_lo = v.gstart[ci], p_hi = v.gstart[ci + 1];
+      // column li of G = [Ji | Jj | r]: staged entry; its sign (the translation part of the target's Jacobian is the negated
+      // host's) is applied to the PRODUCT: element (row, col) of G^T G carries sign(row) sign(col)
+      const int src = li < 6 ? li : li < 9 ? li - 6 : li < 12 ? li - 3 : li < 13 ? 9 : 0;
+      double sgn[4];
 #pragma unroll
-          for (int j = 0; j < 8; j++) a[j] = g[(j < steps ? 2 * j : 0) * kGSlot];
+      for (int r4 = 0; r4 < 4; r4++) {
+        const int row = kq + 4 * r4;
+        sgn[r4] = ((row >= 6 && row < 9) != (li >= 6 && li < 9)) ? -1.0 : 1.0;
+      }
+      auto gl = G + (kq >> 1) * kGSlot + (kq & 1) * kGRow + src;  // this lane's entry of the chunk's first two factors
+      // issue: the operand reads of a piece's first eight steps (raw: steps past the piece read its last step again, nothing
+      // consumes them)
+      auto issue = [&](int desc, double (&a)[8]) {
+        const int off = desc & 1023, n = (desc >> 10) & 31, last = ((n + 1) >> 1) - 1;
+        auto g = gl + off * kGSlot;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = g[(j < last ? j : last) * 2 * kGSlot];
+      };
+      // consume: the products of a piece and its flush
+      auto consume = [&](int desc, double (&a)[8]) {
+        const int n = (desc >> 10) & 31, h = (desc >> 15) & 63, t = (desc >> 21) & 63;
+        const int total = (n + 1) >> 1;  // matrix instructions: two factors each, an odd last factor is a masked half step
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (j < total) {  // (uniform)
+            double x = a[j];
+            if ((n & 1) && j == total - 1) x = kq < 2 ? x : 0.0;  // (lanes kq >= 2 read the padding slot behind the bucket)
+            acc = mfma_f64(x, x, acc);
+          }
+        }
+        if (kGramPiece > 16 && total > 8) {  // (the second half of a long piece: its own batch of reads)
+          const int off = desc & 1023, last = total - 1;
+          auto g = gl + off * kGSlot;
+          double a2[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) a2[j] = g[(8 + j < last ? 8 + j : last) * 2 * kGSlot];
           VIO_SCHED_FENCE();
 #pragma unroll
           for (int j = 0; j < 8; j++) {
-            if (j < steps) {  // (uniform)
-              const double x = a[j] * sg;
-              if (j & 1) acc2 = mfma_f64(x, x, acc2);
-              else acc = mfma_f64(x, x, acc);
+            if (8 + j < total) {
+              double x = a2[j];
+              if ((n & 1) && 8 + j == total - 1) x = kq < 2 ? x : 0.0;
+              acc = mfma_f64(x, x, acc);
             }
           }
         }
-        g += 2 * kGSlot * steps;  // (steps <= 0: back to the slot behind the last full step)
-        if ((s_hi - s_lo) & 1) {  // lanes kq >= 2 would fetch the slot behind the bucket: never read, operand zero
-          const bool half = lv && kq < 2;
-          double a = G[half ? (int)(g - G) : 0];
-          a = half ? a * sg : 0.0;
-          acc = mfma_f64(a, a, acc);
-        }
-        acc += acc2;
-        const int h = b_ht >> 16, t = b_ht & 0xffff;
-        {
-          // the bucket's target x host block goes to its place in PP (layout of App; a reversed pair transposed): first chunk
-          // of the bucket stores, a continued bucket adds; windows with reversed pairs (two buckets per block, never produced
-          // by the reference's factor list) add atomically into a PP zeroed per evaluation
-          const bool first = b_s0 >= c0;
 #pragma unroll
-          for (int r4 = 0; r4 < 4; r4++) {
-            if (f_lds[r4]) VIO_ATOMIC_ADD(f_base[r4] + (f_t[r4] ? t : h) * f_mul[r4], acc[r4]);
-            if (f_glb[r4]) {
-              const int rt = 6 * t + kq + 4 * r4 - 6, ch = 6 * h + li;
-              double *dst = v.PP + (t > h ? tri_at(rt, ch) : tri_at(ch, rt));
-              if (v.nrev) VIO_ATOMIC_ADD(dst, acc[r4]);
-              else *dst = first ? acc[r4] : *dst + acc[r4];
-            }
+        for (int r4 = 0; r4 < 4; r4++) {
+          const double val = acc[r4] * sgn[r4];
+          if (f_lds[r4]) VIO_ATOMIC_ADD(f_base[r4] + (f_t[r4] ? t : h) * f_mul[r4], val);
+          if (f_glb[r4]) {
+            const int rt = 6 * t + kq + 4 * r4 - 6, ch = 6 * h + li;
+            atomic_add_noret(v.PP + (t > h ? tri_at(rt, ch) : tri_at(ch, rt)), val);
+          }
+        }
+      };
+      for (int pb = p_lo + wave; pb < p_hi; pb += 64 * nw) {  // (rounds of 64 pieces per wave: one is enough below 64 nw pieces per chunk)
+        const int pl = pb + lane * nw;
+        const int m_desc = pl < p_hi ? v.gpiece[pl] : 0;
+        const int cnt = (p_hi - pb + nw - 1) / nw < 64 ? (p_hi - pb + nw - 1) / nw : 64;
+        double A[8], Bq[8];
+        issue(__builtin_amdgcn_readlane(m_desc, 0), A);
+        for (int k = 0; k < cnt; k += 2) {
+          const int d0 = __builtin_amdgcn_readlane(m_desc, k);
+          const int d1 = k + 1 < cnt ? __builtin_amdgcn_readlane(m_desc, k + 1) : 0;
+          if (k + 1 < cnt) issue(d1, Bq);
+          VIO_SCHED_FENCE();
+          consume(d0, A);
+          if (k + 1 < cnt) {
+            if (k + 2 < cnt) issue(__builtin_amdgcn_readlane(m_desc, k + 2), A);
+            VIO_SCHED_FENCE();
+            consume(d1, Bq);
           }
         }
       }
@@ -1513,7 +1631,6 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       // when each feature has its own thread, so zeroing is needed once (first evaluation of the solve)
       VIO_PARFOR(q, v.F * v.n6cap) v.WTf[q] = 0.0;
     }
-    if (v.nrev) VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (only windows with reversed (host, target) pairs accumulate atomically)
     VIO_PARFOR(q, nF * 36) w.ppd[q] = 0.0;
     VIO_SYNC();
 #ifndef VIO_HOST_BUILD
@@ -1550,7 +1667,10 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       }
     } else
 #endif
+    {
+      stamp(cx, ST_E_HEAD);
       cost += projections_jac(cx, v, w, pose, feat, have_scale);
+    }
     stamp(cx, ST_EVAL_PROJ);
     // ---- the rest of the linearization in three barrier intervals, every global fetch of an interval in flight at once
     //      (each dependent round trip costs ~3.5 k cycles here; the first versions took six of them, one phase at a time):
@@ -1580,7 +1700,7 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
 #pragma unroll
           for (int u = 0; u < kU; u++) {
             const int q = q0 + u * nt_;
-            if (q < napp) w.App[q] = x[u] + y[u];
+            if (q < napp) w.App[q] = x[u] + y[u], v.PP[q] = 0.0;  // (PP is added to atomically: every linearization finds it zeroed)
           }
         }
         for (int q0 = tid_; q0 < nband; q0 += kU * nt_) {
@@ -2637,6 +2757,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   VIO_PARFOR(f, F) w.gnf[f] = 0.0;  // accumulates w_f^T z_p below
   VIO_PARFOR(q, P * kSB) w.t1[kBS * (q / kSB) + 6 + q % kSB] = w.gp[kBS * (q / kSB) + 6 + q % kSB];  // t_s = g_s - A_sp z_p below
   VIO_SYNC();
+  stamp(cx, ST_B_INIT);
   int qc = lane >> 2, qp = lane & 3;  // lane = 4 c + p: the four lanes of a quad split a 16-term dot product
   // x_K <- L_KK^-T x_K: (L^-T x)[c] = x[c] / L_cc + sum_{r > c} Linv[r][c] x[r], Linv[r][c] at D[c][r]
   auto solve_diag = [&](int K) {
@@ -2686,6 +2807,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
     }
     VIO_SYNC();
   }
+  stamp(cx, ST_B_POSE);
   // z_p -> t1 (pose components), t_s = g_s - A_sp z_p -> t1 (speed-bias components)
   VIO_PARFOR(a, n6) w.t1[kBS * (a / 6) + a % 6] = x[a];
   VIO_PARFOR(q, P * kSB + kSB * nT) {
@@ -2719,76 +2841,138 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
   VIO_SYNC();
   stamp(cx, ST_BACKSOLVE);
   if (wave == 0) {
-    // band: u_k = L_k^-1 (t_k - E_{k+1} u_{k+1}), k = W..0; then z_k = L_k^-T (u_k - E_k^T z_{k-1}), k = 0..W.
-    // Lane n < 9 owns component n: its rows of the two 9 x 9 blocks of a step sit in registers (fetched one step ahead,
-    // they do not depend on the chain) and the nine components of the running vector travel through v_readlane, so a
-    // step is two dependent chains of nine FMAs instead of four LDS round trips.
-    const bool ok = lane < kSB;
-    const int n = ok ? lane : 0;
-    double ea[kSB], la[kSB], eb[kSB], lb[kSB], ta = 0.0, tb = 0.0;
-    auto fetch_fwd = [&](int k, double (&er)[kSB], double (&lr)[kSB], double &tk) {
-      cldsd E = w.Css + (k + 1 <= W ? k + 1 : k) * kSS + n * kSB, D = w.Dss + k * kSS;  // row n of E_{k+1}: s_k[n] x s_{k+1}
-      const double dg = w.ldinv[kSB * k + n];
-#pragma unroll
-      for (int m = 0; m < kSB; m++) {
-        er[m] = E[m];
-        const double x = D[(m < n ? m : 0) * kSB + n];  // Linv[n][m] sits above the diagonal at D[m][n]
-        lr[m] = m < n ? x : (m == n ? dg : 0.0);
-      }
-      tk = w.t1[kBS * k + 6 + n];
+    // band: u_k = L_k^-1 (t_k - E_{k+1} u_{k+1}), k = W..0; then z_k = L_k^-T (u_k - E_k^T z_{k-1}), k = 0..W: two chains of 9 x 9
+    // mat-vecs on the matrix cores. The running vector is a B operand replicated over the 16 columns: the accumulator layout of a
+    // product (lane (li, kq), element r = component kq + 4 r, the same in every column li) IS the B-operand layout of the next
+    // one, so a step is 3 + 3 dependent v_mfma and nothing else on the chain; the blocks of the next step are fetched while this
+    // one multiplies. (Rounds 3-5 ran these chains on v_readlane broadcasts: 18 dependent multiply-adds and 36 broadcasts per
+    // step, ~1.0 k cycles of the ~22 k the two chains took per solve.)
+    const int li = lane & 15, kq = lane >> 4;
+    struct Blk {
+      double e[3], l[4], t[3];
     };
-    auto fetch_bwd = [&](int k, double (&ec)[kSB], double (&lc)[kSB], double &tk) {
-      cldsd E = w.Css + k * kSS + n, D = w.Dss + k * kSS + n * kSB;  // column n of E_k: s_{k-1} x s_k[n]
-      const double dg = w.ldinv[kSB * k + n];
+    // forward operands of step k: E_{k+1} (rows s_k, columns s_{k+1}) and L_k^-1 as A operands X[li][4 s + kq]; t_k in accumulator layout
+    auto fetch_fwd = [&](int k, Blk &b) {
+      load_op9_raw(w.Css + (k + 1 <= W ? k + 1 : k) * kSS, li, kq, b.e);
+      load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, b.l);
 #pragma unroll
-      for (int m = 0; m < kSB; m++) {
-        ec[m] = E[m * kSB];
-        const double x = D[m > n ? m : n];  // Linv[m][n] for m > n at D[n][m]
-        lc[m] = m > n ? x : (m == n ? dg : 0.0);
-      }
-      tk = w.t1[kBS * k + 6 + n];
+      for (int r = 0; r < 3; r++) b.t[r] = w.t1[kBS * k + 6 + (kq + 4 * r < kSB ? kq + 4 * r : 0)];
     };
-    double prev = 0.0;
-    fetch_fwd(W, ea, la, ta);
+    // backward operands of step k: E_k^T (X[li][j] = E_k[j][li]) and L_k^-T (X[li][j] = Linv[j][li]: above the diagonal of the
+    // stored block for j > li, 1 / L_ii on it, zero below)
+    auto fetch_bwd = [&](int k, Blk &b) {
+      const int n = li < kSB ? li : 0;
+      cldsd E = w.Css + k * kSS + n, D = w.Dss + k * kSS + n * kSB;
+      b.l[3] = w.ldinv[kSB * k + n];
+#pragma unroll
+      for (int s4 = 0; s4 < 3; s4++) {
+        const int j = 4 * s4 + kq, jc = j < kSB ? j : 0;
+        b.e[s4] = E[jc * kSB];
+        b.l[s4] = D[jc > n ? jc : n];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) b.t[r] = w.t1[kBS * k + 6 + (kq + 4 * r < kSB ? kq + 4 * r : 0)];
+    };
+    auto mask_bwd = [&](Blk &b) {
+      const bool iok = li < kSB;
+#pragma unroll
+      for (int s4 = 0; s4 < 3; s4++) {
+        const int j = 4 * s4 + kq;
+        const bool jok = iok && j < kSB;
+        b.e[s4] = jok ? b.e[s4] : 0.0;
+        b.l[s4] = (jok && j > li) ? b.l[s4] : ((jok && j == li) ? b.l[3] : 0.0);
+      }
+    };
+    auto acc_of = [&](const Blk &b) {
+      v4d T = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 3; r++) T[r] = kq + 4 * r < kSB ? b.t[r] : 0.0;
+      return T;
+    };
+    auto put = [&](int k, v4d U) {
+      if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          if (kq + 4 * r < kSB) w.t1[kBS * k + 6 + kq + 4 * r] = U[r];
+      }
+    };
+    Blk cur, nxt;
+    v4d U = {0.0, 0.0, 0.0, 0.0};
+    fetch_fwd(W, cur);
     for (int k = W; k >= 0; k--) {
-      if (k >= 1) fetch_fwd(k - 1, eb, lb, tb);
-      double val = ta;
+      if (k >= 1) fetch_fwd(k - 1, nxt);
+      VIO_SCHED_FENCE();
+      mask_op9(li, kq, cur.e), mask_linv9(li, kq, cur.l);
+      v4d T = acc_of(cur);
       if (k < W) {
 #pragma unroll
-        for (int m = 0; m < kSB; m++) val = fma(-ea[m], lane_bcast(prev, m), val);
+        for (int s4 = 0; s4 < 3; s4++) T = mfma_f64(-cur.e[s4], U[s4], T);
       }
-      double u = 0.0;
+      v4d Un = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int m = 0; m < kSB; m++) u = fma(la[m], lane_bcast(val, m), u);
-      prev = u;
-      if (ok) w.t1[kBS * k + 6 + n] = u;
-#pragma unroll
-      for (int m = 0; m < kSB; m++) ea[m] = eb[m], la[m] = lb[m];
-      ta = tb;
+      for (int s4 = 0; s4 < 3; s4++) Un = mfma_f64(cur.l[s4], T[s4], Un);
+      U = Un;
+      put(k, U);
+      cur = nxt;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    prev = 0.0;
-    fetch_bwd(0, ea, la, ta);
+    U = v4d{0.0, 0.0, 0.0, 0.0};
+    fetch_bwd(0, cur);
     for (int k = 0; k <= W; k++) {
-      if (k < W) fetch_bwd(k + 1, eb, lb, tb);
-      double val = ta;
+      if (k < W) fetch_bwd(k + 1, nxt);
+      VIO_SCHED_FENCE();
+      mask_bwd(cur);
+      v4d T = acc_of(cur);
       if (k >= 1) {
 #pragma unroll
-        for (int m = 0; m < kSB; m++) val = fma(-ea[m], lane_bcast(prev, m), val);
+        for (int s4 = 0; s4 < 3; s4++) T = mfma_f64(-cur.e[s4], U[s4], T);
       }
-      double z = 0.0;
+      v4d Zn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int m = 0; m < kSB; m++) z = fma(la[m], lane_bcast(val, m), z);
-      prev = z;
-      if (ok) w.t1[kBS * k + 6 + n] = z;
-#pragma unroll
-      for (int m = 0; m < kSB; m++) ea[m] = eb[m], la[m] = lb[m];
-      ta = tb;
+      for (int s4 = 0; s4 < 3; s4++) Zn = mfma_f64(cur.l[s4], T[s4], Zn);
+      U = Zn;
+      put(k, U);
+      cur = nxt;
     }
+    stamp(cx, ST_X0);  // (the two band chains; ST_B_BAND behind the barrier is then the wait for the landmark part)
   } else {
-    // landmark back-substitution, first half: w_f^T z_p over (feature, part) items by the waves that do not walk the band
+    // landmark back-substitution, first half: w_f^T z_p by the waves that do not walk the band. Pose matrices of up to five tile
+    // rows: a row of the feature-major W per 16 lanes (lane li takes columns li, li + 16, ...: 128 contiguous bytes per load and
+    // row), four rows per wave and step, the 16-lane sum on the DPP network -- the (feature, part) items below read a strip of 22
+    // consecutive doubles per LANE, 64 cache lines per load instruction, and took longer than the band chains beside them.
+    if (nT <= 5) {
+      constexpr int kT = 5, kIt = 7;  // rows in flight per lane: kIt steps of four rows, five columns each
+      const int li = lane & 15, kq = lane >> 4, pw = wave - 1, npw = nw - 1;
+      double u5[kT];
+#pragma unroll
+      for (int t = 0; t < kT; t++) u5[t] = 16 * t + li < n6 ? x[16 * t + li] : 0.0;
+      const int steps = (F + 3) >> 2, per_w = (steps + npw - 1) / npw;
+      const int s_begin = pw * per_w, s_end = s_begin + per_w < steps ? s_begin + per_w : steps;
+      for (int s0 = s_begin; s0 < s_end; s0 += kIt) {
+        double wv[kIt][kT];
+#pragma unroll
+        for (int j = 0; j < kIt; j++) {
+          const int f = 4 * (s0 + j) + kq, fc = (s0 + j < s_end && f < F) ? f : 0;
+#pragma unroll
+          for (int t = 0; t < kT; t++) wv[j][t] = v.WTf[(size_t)fc * v.n6cap + (16 * t + li < n6 ? 16 * t + li : 0)];
+        }
+        VIO_SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < kIt; j++) {
+          const int f = 4 * (s0 + j) + kq;
+          double pq = 0.0;
+#pragma unroll
+          for (int t = 0; t < kT; t++) pq = fma(16 * t + li < n6 ? wv[j][t] : 0.0, u5[t], pq);
+          pq += dpp_move_f64<0x111, 0xf>(pq);
+          pq += dpp_move_f64<0x112, 0xf>(pq);
+          pq += dpp_move_f64<0x114, 0xf>(pq);
+          pq += dpp_move_f64<0x118, 0xf>(pq);
+          if (li == 15 && s0 + j < s_end && f < F) w.gnf[f] = pq;  // (one writer per landmark)
+        }
+      }
+    } else {
     int nparts, per;
     wt_parts((int)cx.nt - 64, F, n6, nparts, per);
     for (int q = 64 * (wave - 1) + lane; q < F * nparts; q += (int)cx.nt - 64) {
@@ -2803,8 +2987,10 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
       }
       VIO_ATOMIC_ADD(w.gnf + f, sacc);
     }
+    }
   }
   VIO_SYNC();
+  stamp(cx, ST_B_BAND);
 }
 
 // PoseLocalParameterization::Plus on all blocks: c = x [+] (delta_p, delta_f)
@@ -2975,7 +3161,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       if (rec_pending) {
         gmax = grad_max_norm();
         record(rec_it, x_cost, radius, rec_step_norm, rec_rho, gmax, true, true);
-        stamp(cx, ST_DOGLEG);
+        stamp(cx, ST_V_GMAX);
       }
       relin = relin_reuse = rec_pending = false;
     }
@@ -3016,7 +3202,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         }
         gd_sq = block_sum(cx, part);
       }
-      stamp(cx, ST_DOGLEG);
+      stamp(cx, ST_V_GD);
       // (pose matrices of up to five tile rows: the W part of the form, 2 u_f^T W^T u_p, comes out of the Schur sweep of
       // build_reduced_system -- tq -> cfeat, dead between a linearization and the next Plus -- and joins the reductions of the
       // dogleg step below: one pass over W in global memory and one barrier less per iteration)
@@ -3101,6 +3287,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         if (qf_pending) p3 += 2.0 * (w.sf[f] * w.sf[f] * w.gf[f] * rcp_f(feat_d2(w, f))) * w.cfeat[f];
       }
       block_sum3(cx, p1, p2, p3);
+      stamp(cx, ST_V_DOT);
       if (qf_pending) {
         const double qf_h = qf_part + p3;
         qf_cauchy = qf_h + mu_used * gd_sq;
@@ -3145,7 +3332,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       // M y = S g, M = S H S + mu D^2, so its quadratic form needs no third pass over the factor and the landmark
       // coupling:  v^T M v = ca^2 a^T M a - 2 ca cb a^T (S g) + cb^2 y^T (S g), with a^T M a the Cauchy form above,
       // a^T S g = |g_d|^2 and y^T S g = -g_d . gn, all reduced already. (Exact up to the residual of the linear solve.)
-      stamp(cx, ST_DOGLEG);
+      stamp(cx, ST_V_STEP);
       double shs = ca * ca * qf_cauchy - 2.0 * ca * cb * gd_sq - cb * cb * gdot - reg;
       model_cost_change = -sg - 0.5 * shs;
       step_valid = model_cost_change > 0.0;
@@ -3184,6 +3371,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       VIO_PARFOR(i, np) v.stash[o_v + i] = w.gp[i], v.stash[o_v + nv + i] = w.dp[i], v.stash[o_v + 2 * nv + i] = w.gnp[i];
       block_sum3(cx, d2, c2, dummy3);
       step_norm = sqrt(d2), cand_norm = sqrt(c2);
+      stamp(cx, ST_V_PLUS);
     }
     double cand_cost = evaluate(cx, fresh(), w, w.xpose, w.xsb, w.xfeat, /*jac=*/speculate, true, false, /*keep_aux=*/!speculate);
     if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
@@ -3223,7 +3411,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       if (speculate) {  // the linearization is in place
         gmax = grad_max_norm();
         record(it, x_cost, radius, step_norm, rho, gmax, true, true);
-        stamp(cx, ST_DOGLEG);
+        stamp(cx, ST_V_GMAX);
       } else {          // it follows at the head of the next iteration, the record with it
         relin = true, relin_reuse = true, rec_pending = true;
         rec_it = it, rec_step_norm = step_norm, rec_rho = rho;
@@ -3244,6 +3432,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         VIO_PARFOR(i, np) w.gp[i] = v.stash[o_v + i], w.dp[i] = v.stash[o_v + nv + i], w.gnp[i] = v.stash[o_v + 2 * nv + i];
       }
       VIO_SYNC();
+      stamp(cx, ST_V_REST);
     }
   }
   if (cx.tid == 0) {
@@ -3347,6 +3536,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w, const VP &fres
     double *d = v.srec_d + 6 * (size_t)sl;
     for (int c = 0; c < 3; c++) d[c] = v.pts_i[3 * k + c], d[3 + c] = v.pts_j[3 * k + c];
   }
+  build_gram_pieces(cx, v, w);
   VIO_PARFOR(f, F) w.fh[f] = v.fstart[f + 1] > v.fstart[f] ? v.fhost[v.fstart[f]] : -1;
   VIO_PARFOR(q, (int)tri_doubles(v.nrows)) v.PP[q] = 0.0;  // (blocks without a (host, target) bucket stay zero for the whole solve)
   setup_imu_info(cx, fresh(), w.stage);

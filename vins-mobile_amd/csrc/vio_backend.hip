@@ -266,6 +266,7 @@ int vio_backend_reserve_priors(vio_backend_t *be, int32_t n_slots) {
 static int plan_layout(vio_backend *be, BatchDims &d, int n, const int *nfeat, int Fmax, std::vector<int> &order,
                        const std::vector<int> *active = nullptr) {  // active: the windows that take part (null: all n)
   d.Flds = std::max(Fmax, 1);
+  d.prof_stages = be->profile ? ST_COUNT : 0;  // (the stage clock's accumulators live in LDS: only the profiling launches pay for them)
   // LDS or global pose matrix, per window. The LDS variant keeps the fill tiles of the speed-bias band in registers (pose
   // matrices of at most kPanelTiles tile rows: W <= 12) and needs both phases inside the CU's LDS. Eligible windows are
   // ordered by landmark count; the largest prefix whose layout (carved for its own landmark maximum) fits runs the LDS
