@@ -1785,18 +1785,34 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
       // so T never leaves the registers.
       const int tid_ = VIO_TID(cx), wave = tid_ >> 6, nw = cx.nt >> 6, lane = tid_ & 63;
       const int n = lane & 15, kq = lane >> 4;
-      for (int f = wave; f < v.W; f += nw) {
+      // (the operands of a wave's NEXT factor are fetched -- raw, clamped addresses -- before this one's products: one global round
+      // trip per evaluation on the wave's path instead of one per factor)
+      struct ImuOps {
+        double a[4], b0[4], b1[4];
+      };
+      auto imu_fetch = [&](int f, ImuOps &o) {
         const double *info = v.imu_info + f * 225, *Jr = v.imu_J + f * 450, *rr = v.imu_r + f * 15;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int k = 4 * s4 + kq, kc = k < 15 ? k : 0;
+          o.a[s4] = info[(n < 15 ? n : 0) * 15 + kc];
+          o.b0[s4] = Jr[kc * 30 + n];
+          o.b1[s4] = n == 14 ? rr[kc] : Jr[kc * 30 + 16 + (n < 14 ? n : 0)];
+        }
+      };
+      ImuOps nxt;
+      if (wave < v.W) imu_fetch(wave, nxt);
+      for (int f = wave; f < v.W; f += nw) {
+        const ImuOps cur = nxt;
+        if (f + nw < v.W) imu_fetch(f + nw, nxt);
+        VIO_SCHED_FENCE();
         double av[4], bv[2][4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
-          const int k = 4 * s4 + kq;
-          const bool kok = k < 15;
-          const int kc = kok ? k : 0;
-          av[s4] = (kok && n < 15) ? info[(n < 15 ? n : 0) * 15 + kc] : 0.0;
-          bv[0][s4] = kok ? Jr[kc * 30 + n] : 0.0;
-          double hi = (n < 14) ? Jr[kc * 30 + 16 + (n < 14 ? n : 0)] : (n == 14 ? rr[kc] : 0.0);
-          bv[1][s4] = kok ? hi : 0.0;
+          const bool kok = 4 * s4 + kq < 15;
+          av[s4] = (kok && n < 15) ? cur.a[s4] : 0.0;
+          bv[0][s4] = kok ? cur.b0[s4] : 0.0;
+          bv[1][s4] = (kok && n < 15) ? cur.b1[s4] : 0.0;
         }
         v4d T0 = {0, 0, 0, 0}, T1 = {0, 0, 0, 0};
 #pragma unroll
