@@ -381,7 +381,7 @@ inline double hilo2d(int hi, int lo) {
 #define __builtin_amdgcn_ballot_w64(p) (::simt::ballot((p), __LINE__))
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) (::simt::mfma((a), (b), (c), __LINE__))
 #define __builtin_amdgcn_wave_barrier() (::simt::wave_barrier(__LINE__))
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(order, ...) ((void)0)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))

@@ -36,6 +36,11 @@ def main():
         solver.upload(ws)
         solver.launch()
         solver.sync()
+        solver.kernel_ms()
+        solver.launch()
+        solver.sync()
+        pms, _ = solver.kernel_ms()
+        print("profiling launch of %d windows: kernel %.3f ms" % (pb, pms))
         for wi in sorted({0, pb - 1}):
             cyc = solver.stage_cycles(wi)
             tot = max(1, cyc["total"])

@@ -308,6 +308,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.prcol = reinterpret_cast<ldsi>(take(((size_t)d.Ncap + 1) / 2 + 1));
   w.sbr = reinterpret_cast<ldsi>(take((size_t)d.Pcap + 1));
   w.flag = reinterpret_cast<ldsi>(take(2));
+  w.ready = reinterpret_cast<ldsi>(take(((size_t)d.Pcap + 1) / 2 + 1));
   w.park = take(24);
   w.rot = take(9 * (size_t)(d.Pcap + 2));
   // pose matrices of more than kPanelTiles tile rows: the fill tiles of the band go through LDS

@@ -304,6 +304,7 @@ struct WorkT {
   ldsi prcol;               // prior column -> (frame << 8 | component 0..14) of the reduced system (-1 constant): prior_n
   ldsi sbr;                 // [2 P]: first pose column speed-bias block k couples to; 1 if it is the block the prior keeps
   ldsi flag;                // [4] block-uniform flags
+  ldsi ready;               // [P] band block k is factored (L_k, L_k^-1, E_k in place): set by the chain wave, polled by the panel waves
   ldsd park;                // [24] loop-carried scalars of the minimizer while the linear solve runs
   ldsi fh;                  // F: host frame of every feature (-1: it has no factor)
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
@@ -502,6 +503,14 @@ VIO_DEV double block_max(const Ctx &cx, double v) {
 #endif
 }
 
+// A flag in LDS that one wave posts and others poll (factor_band_regs)
+#if defined(VIO_HOST_BUILD)
+#define VIO_FLAG_STORE(p, x) (*(volatile int *)(p) = (x))
+#define VIO_FLAG_LOAD(p) (*(volatile int *)(p))
+#else
+#define VIO_FLAG_STORE(p, x) __hip_atomic_store((p), (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VIO_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
 #if defined(VIO_HOST_BUILD)
 #define VIO_SCHED_FENCE() ((void)0)
 #else
@@ -2628,6 +2637,32 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
 #pragma unroll
   for (int t = 0; t < NT; t++) V[t].x[0] = V[t].x[1] = V[t].x[2] = 0.0;
   int flo = v.n6;  // first pose column the fill of the steps so far reaches
+  if (!w.asp_ring) {
+    // Decoupled (round 6). The chain wave needs nothing from the panel waves while it walks the band (they only write the pose
+    // matrix), so it runs ahead at its own pace and posts a flag per finished block; a panel wave waits for the flag of ITS block
+    // only. With a workgroup barrier per slot (rounds 3-5) a slot took the longer of the two -- the early panel steps touch two
+    // fill tiles, the late ones five, a band block always costs the same -- and the band phase the sum of those maxima.
+    if (wave == 0) {
+      for (int kb = W; kb >= 0; kb--) {
+        band_step(cx, v, w, kb, 2, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();  // (every lane's stores of the block precede the flag)
+        if (lane == 0) VIO_FLAG_STORE(w.ready + kb, 1);
+        stamp(cx, ST_C_AHEAD);
+      }
+    } else {
+      for (int kp = W; kp >= 0; kp--) {
+        while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + kp)) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        flo = flo < w.sbr[2 * kp] ? flo : w.sbr[2 * kp];  // (0 for the block the prior keeps)
+        panel_step_dispatch<NT, NW - 1>(cx, v, w, kp, flo >> 4, V, lane, wave - 1);
+        stamp(cx, ST_D2);
+      }
+    }
+    VIO_SYNC_LDS();
+    stamp(cx, ST_C_WAIT);
+    return w.flag[2] == 0;
+  }
   for (int slot = 0; slot <= W + 1; slot++) {
     const int kb = W - slot, kp = kb + 1, ff = 2 + (slot & 1);
     if (wave == 0) {
@@ -3245,6 +3280,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
         }
         first_try = false;
         if (cx.tid == 0) w.flag[0] = 0, w.flag[1] = 0, w.flag[2] = 0, w.flag[3] = 0;
+        VIO_PARFOR(k, v.P) w.ready[k] = 0;
         VIO_SYNC();
         bool ok = build_reduced_system(cx, fresh(), w, mu, fuse_qw ? w.cfeat : nullptr);
         if (ok) {
