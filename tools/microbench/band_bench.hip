@@ -11,7 +11,58 @@
 
 using namespace vio;
 
-// experimental variants of potrf9_inv_wave: what does a pivot cost without the inverse accumulation / the Newton steps?
+// potrf9 on the VECTOR unit (round 6, asked for by the round-4 and round-5 reviews): lane m < 9 keeps row m of the block and row m
+// of L^-1 in registers; the pivot column / pivot row reach the other rows as scalars (v_readlane of RAW registers: the scale
+// 1 / L_cc is folded into the multiplier, so the broadcasts are off the pivot chain). Same storage as potrf9_inv_wave.
+// Measured (profiles/r06_microbench.txt): 2.44 k cycles per block -- 18 v_readlane + 9 multiply-adds + the reciprocal-root chain
+// per pivot, ~270 cycles -- against 2.65 k for the two-accumulator matrix-core form of rounds 3-5 and ~2.1 k for the
+// one-instruction-per-pivot form the product uses since round 6 (the inverse in the border of the pivot tile). A variant with
+// the square-root-free elimination on the chain (only 1 / d_c ahead of the next pivot, 1 / sqrt(d_c) beside it) measured 2.78 k:
+// the block is bound by instruction issue, not by the length of the chain. Not adopted (the mark was <= 1.3 k).
+__device__ __forceinline__ bool potrf9_rows_wave(ldsd D, ldsd ldinv_k, int lane) {
+  const bool act = lane < kSB;
+  const int m = act ? lane : 0;
+  double A[kSB], E[kSB];
+#pragma unroll
+  for (int n = 0; n < kSB; n++) A[n] = D[m * kSB + n];  // (entries right of the diagonal are never used)
+  VIO_SCHED_FENCE();
+#pragma unroll
+  for (int n = 0; n < kSB; n++) E[n] = n == m ? 1.0 : 0.0;
+  double myinv = 0.0;
+  double dcc = lane_bcast(A[0], 0);
+#pragma unroll
+  for (int c = 0; c < kSB; c++) {
+    double an[kSB], en[kSB];
+#pragma unroll
+    for (int n = c + 1; n < kSB; n++) an[n] = lane_bcast(A[c], n);  // A[n][c], raw
+#pragma unroll
+    for (int n = 0; n <= c; n++) en[n] = lane_bcast(E[n], c);       // row c of the inverse so far, raw
+    double y = __builtin_amdgcn_rsq(dcc);
+    const double h = 0.5 * dcc;
+    y = y * fma(-h * y, y, 1.5);
+    const double l = A[c] * y;    // L[m][c]
+    const double lzy = (m > c ? l : 0.0) * y;
+    A[c] = l;
+#pragma unroll
+    for (int n = c + 1; n < kSB; n++) A[n] = fma(-lzy, an[n], A[n]);
+    if (c + 1 < kSB) dcc = lane_bcast(A[c + 1], c + 1);
+#pragma unroll
+    for (int n = 0; n <= c; n++) E[n] = fma(-lzy, en[n], E[n]);
+    myinv = m == c ? y : myinv;
+  }
+  if (act) {
+#pragma unroll
+    for (int n = 0; n < kSB; n++) {
+      if (n <= m) D[m * kSB + n] = A[n];
+      if (n < m) D[n * kSB + m] = E[n] * myinv;  // L^-1[m][n], transposed into the upper triangle
+    }
+    ldinv_k[m] = myinv;
+  }
+  const bool bad = act && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
+  return __builtin_amdgcn_ballot_w64(bad) == 0;
+}
+
+// experimental variants of the ROUND 3-5 potrf9_inv_wave (two accumulators): what does a pivot cost without the inverse accumulation / the Newton steps?
 template <bool WITH_E, bool NEWTON>
 __device__ __forceinline__ bool potrf9_variant(ldsd D, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
@@ -59,8 +110,8 @@ __device__ __forceinline__ bool potrf9_variant(ldsd D, ldsd ldinv_k, int lane) {
   return __builtin_amdgcn_ballot_w64(n < kSB && !(myinv > 0.0)) == 0;
 }
 
-enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_COUNT };
-static const char *kNames[M_COUNT] = {"potrf9 (no update)", "potrf9 + E update", "9x9 trsm (loads, 3 mfma, store)", "15 mfma, 5 accumulators x 3",
+enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_P9_ROWS, M_P9_ROWS_CHECK, M_V_OLD, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_COUNT };
+static const char *kNames[M_COUNT] = {"potrf9 (product: inverse in the tile border)", "potrf9 (product) + E update", "9x9 trsm (loads, 3 mfma, store)", "15 mfma, 5 accumulators x 3",
                                       "15 mfma, one accumulator", "5 tiles: acc load, 3 mfma, store", "potrf16 (16 pivots)",
                                       "9x9 mat-vec x2 by v_readlane", "dependent ds_read round trip"};
 
@@ -81,6 +132,22 @@ __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double 
       if (mode == M_V_NOE) potrf9_variant<false, true>(D, ldinv, lane);
       if (mode == M_V_NONEWTON) potrf9_variant<true, false>(D, ldinv, lane);
       if (mode == M_V_NEITHER) potrf9_variant<false, false>(D, ldinv, lane);
+      if (mode == M_V_OLD) potrf9_variant<true, true>(D, ldinv, lane);
+      if (mode == M_P9_ROWS) potrf9_rows_wave(D, ldinv, lane);
+      if (mode == M_P9_ROWS_CHECK) {  // (correctness: the vector-unit form against the matrix-core form on the same block)
+        potrf9_rows_wave(D, ldinv, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double mine = lane < 81 ? D[lane] : 0.0, mine2 = lane + 64 < 81 ? D[lane + 64] : 0.0, li_ = lane < 9 ? ldinv[lane] : 0.0;
+        for (int i = lane; i < 81; i += 64) D[i] = gD[i];
+        __builtin_amdgcn_wave_barrier();
+        potrf9_inv_wave(D, E, false, ldinv, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double d = fabs(mine - (lane < 81 ? D[lane] : 0.0)) + fabs(mine2 - (lane + 64 < 81 ? D[lane + 64] : 0.0)) + fabs(li_ - (lane < 9 ? ldinv[lane] : 0.0));
+        d = wave_max_f64(d);
+        if (lane == 0) gout[300] = d;
+      }
       if (mode == M_POTRF9) potrf9_inv_wave(D, E, false, ldinv, lane);
       if (mode == M_POTRF9_UPD) potrf9_inv_wave(D, E, true, ldinv, lane);
       if (mode == M_TRSM9) {
@@ -163,7 +230,13 @@ static void run(const double *dD, double *dout, long long *dcyc) {
   long long c = 0;
   hipDeviceSynchronize();
   hipMemcpy(&c, dcyc, sizeof(c), hipMemcpyDeviceToHost);
-  printf("%-40s %8lld cycles%s\n", mode >= 100 ? (mode == M_V_NOE ? "potrf9 without the L^-1 mfma" : mode == M_V_NONEWTON ? "potrf9 without Newton steps" : "potrf9 without either") : kNames[mode], c, mode == M_LDS_RT ? " per 10" : "");
+  if (mode == M_P9_ROWS_CHECK) {
+    double d = -1;
+    hipMemcpy(&d, dout + 300, sizeof(d), hipMemcpyDeviceToHost);
+    printf("potrf9 on the vector unit vs the matrix-core form: max |difference| of L, L^-1, 1 / L_cc = %.3e\n", d);
+    return;
+  }
+  printf("%-40s %8lld cycles%s\n", mode >= 100 ? (mode == M_V_NOE ? "potrf9, 2 accumulators, without the L^-1 mfma" : mode == M_V_NONEWTON ? "potrf9, 2 accumulators, 2 Newton steps -> 0" : mode == M_P9_ROWS ? "potrf9 on the vector unit (rows in lanes)" : mode == M_V_OLD ? "potrf9, 2 accumulators (rounds 3-5, 2 Newton steps)" : "potrf9, 2 accumulators, without either") : kNames[mode], c, mode == M_LDS_RT ? " per 10" : "");
 }
 
 int main() {
@@ -172,9 +245,10 @@ int main() {
     for (int j = 0; j < 9; j++) D[i * 9 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
   double *dD, *dout;
   long long *dcyc;
-  hipMalloc(&dD, 81 * 8), hipMalloc(&dout, 256 * 8), hipMalloc(&dcyc, 8);
+  hipMalloc(&dD, 81 * 8), hipMalloc(&dout, 512 * 8), hipMalloc(&dcyc, 8);
   hipMemcpy(dD, D.data(), 81 * 8, hipMemcpyHostToDevice);
   run<M_V_NOE>(dD, dout, dcyc), run<M_V_NONEWTON>(dD, dout, dcyc), run<M_V_NEITHER>(dD, dout, dcyc);
+  run<M_V_OLD>(dD, dout, dcyc), run<M_P9_ROWS>(dD, dout, dcyc), run<M_P9_ROWS_CHECK>(dD, dout, dcyc);
   run<M_POTRF9>(dD, dout, dcyc), run<M_POTRF9_UPD>(dD, dout, dcyc), run<M_TRSM9>(dD, dout, dcyc), run<M_MFMA_CHAIN15>(dD, dout, dcyc);
   run<M_MFMA_DEP15>(dD, dout, dcyc), run<M_TILE_RMW5>(dD, dout, dcyc), run<M_POTRF16>(dD, dout, dcyc), run<M_READLANE_MV>(dD, dout, dcyc);
   run<M_LDS_RT>(dD, dout, dcyc);

@@ -1118,8 +1118,14 @@ VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[4]) {
 // band. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
 // triangle, 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
 VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k, int lane) {
+  // Round 6: ONE matrix instruction per pivot. The block only fills 9 x 9 of the 16 x 16 tile; the inverse rides in the rest of
+  // the SAME tile as a symmetric border:  T = [ A  E ; E^T  * ],  E = columns 0..6 of the running inverse (rows 0..8, tile
+  // columns 9..15; initially the identity). The rank-1 update T -= v v^T with v = (row c of T) / L_cc = [l | e] then applies
+  // A -= l l^T and E -= l e^T at once -- rounds 3-5 kept the inverse in a second accumulator and paid a second 64-cycle
+  // instruction per pivot (an f64 matrix instruction is 16 passes of the vector unit's own double-precision pipe on this chip).
+  // Column 7 of the inverse has ONE entry below the diagonal, L^-1[8][7] = -L[8][7] / (L_77 L_88): formed by hand; column 8 none.
   const int n = lane & 15, kq = lane >> 4;
-  v4d A, E;
+  v4d A;
   double l[3];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -1133,8 +1139,8 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int m = kq + 4 * r;
-    A[r] = (m < kSB && n < kSB) ? A[r] : 0.0;
-    E[r] = (m == n) ? 1.0 : 0.0;
+    // (the border: E[m][n - 9] = [m == n - 9] right of the block, its transpose below it)
+    A[r] = (m < kSB && n < kSB) ? A[r] : ((m + 9 == n || n + 9 == m) ? 1.0 : 0.0);
   }
   if (with_update) {
     mask_op9(n, kq, l);
@@ -1142,42 +1148,45 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
     for (int s = 0; s < 3; s++) A = mfma_f64(-l[s], l[s], A);
   }
   // Everything in this loop is on the critical path of the solve and nothing in a wave overlaps its own matrix
-  // instructions (an f64 MFMA holds the SIMD for 64 cycles), so the loop carries no bookkeeping: a pivot <= 0 shows up
-  // as a NaN / inf reciprocal root and is tested once at the end.
-  double keep[3] = {0.0, 0.0, 0.0}, myinv = 0.0;
+  // instructions, so the loop carries no bookkeeping: a pivot <= 0 shows up as a NaN / inf reciprocal root and is tested
+  // once at the end.
+  double keep[3] = {0.0, 0.0, 0.0}, myinv = 0.0, l87 = 0.0, y7 = 0.0, linv87 = 0.0;
   double dcc = lane_bcast(A[0], 0);
 #pragma unroll
   for (int c = 0; c < kSB; c++) {
     double y = __builtin_amdgcn_rsq(dcc);
     const double h = 0.5 * dcc;
     y = y * fma(-h * y, y, 1.5);  // (v_rsq_f64 is specified to 2^29 ulp, ~2^-23 relative: one Newton step leaves ~1.5 e^2 = ~2^-45
-                                  //  in every pivot -- not the ~2^-51 an earlier comment claimed --, still nine orders below the
-                                  //  1e-6 bar against the reference (tests/test_backend_gpu.py::test_ill_conditioned_windows
-                                  //  holds near-degenerate windows at the smallest mu to it); the second step cost 3
-                                  //  dependent operations on the pivot chain)
+                                  //  in every pivot, nine orders below the 1e-6 bar against the reference
+                                  //  (tests/test_backend_gpu.py::test_ill_conditioned_windows holds near-degenerate windows at
+                                  //  the smallest mu to it); the second step cost 3 dependent operations on the pivot chain)
     const bool sel = kq == (c & 3);
-    const double a = sel ? A[c >> 2] * y : 0.0;  // l[n] = L[n][c]  (n == c: dcc / sqrt(dcc))
-    const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
-    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
+    const double a = sel ? A[c >> 2] * y : 0.0;  // v: l[n] = L[n][c] for n < 9 (n == c: dcc / sqrt(dcc)), e[n - 9] = L^-1[c][n - 9] right of it
+    keep[c >> 2] = sel ? a : keep[c >> 2];
     myinv = (n == c) ? y : myinv;
+    if (c == 7) l87 = lane_bcast(a, 16 * 3 + 8), y7 = y;
+    if (c == 8) linv87 = -(l87 * y7) * y;
     if (c + 1 < kSB) {
       // the next pivot D[c+1][c+1] - l[c+1]^2 is formed ahead of the matrix instruction, so its rsqrt chain runs in
-      // the shadow of the two v_mfma instead of behind them
+      // its shadow instead of behind it
       const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
       const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
       dcc = fma(-lnext, lnext, dold);
     }
     A = mfma_f64(-a, a, A);
-    E = mfma_f64(-a, e, E);
   }
-  if (n < kSB) {
+  // lane (n, kq) captured, at pivot c = kq + 4 j, L[n][c] (n >= c) or -- in the border -- L^-1[c][n - 9] (n - 9 < c), which goes
+  // TRANSPOSED above the diagonal of the stored block
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int c = kq + 4 * j;
-      if (c < kSB) D[n * kSB + c] = keep[j];
+  for (int j = 0; j < 3; j++) {
+    const int c = kq + 4 * j;
+    if (c < kSB) {
+      if (n < kSB && n >= c) D[n * kSB + c] = keep[j];
+      if (n >= kSB && n - kSB < c) D[(n - kSB) * kSB + c] = keep[j];
     }
-    if (kq == 0) ldinv_k[n] = myinv;
   }
+  if (lane == 0) D[7 * kSB + 8] = linv87;
+  if (kq == 0 && n < kSB) ldinv_k[n] = myinv;
   // rsq of a pivot <= 0 (or NaN) is NaN / inf, and every later pivot inherits it
   const bool bad = n < kSB && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
   return __builtin_amdgcn_ballot_w64(bad) == 0;
