@@ -503,6 +503,13 @@ VIO_DEV double block_max(const Ctx &cx, double v) {
 #endif
 }
 
+// Issue priority of the wave that walks a serial chain (pivots, band substitutions): with two windows per CU its SIMD is shared
+// with a wave of the other window, and every cycle that wave wins the issue slot is a cycle on this window's critical path.
+#if defined(VIO_HOST_BUILD)
+#define VIO_PRIO(n) ((void)0)
+#else
+#define VIO_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 // A flag in LDS that one wave posts and others poll (factor_band_regs)
 #if defined(VIO_HOST_BUILD)
 #define VIO_FLAG_STORE(p, x) (*(volatile int *)(p) = (x))
@@ -2652,6 +2659,7 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
     // only. With a workgroup barrier per slot (rounds 3-5) a slot took the longer of the two -- the early panel steps touch two
     // fill tiles, the late ones five, a band block always costs the same -- and the band phase the sum of those maxima.
     if (wave == 0) {
+      VIO_PRIO(3);
       for (int kb = W; kb >= 0; kb--) {
         band_step(cx, v, w, kb, 2, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -2659,6 +2667,7 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
         if (lane == 0) VIO_FLAG_STORE(w.ready + kb, 1);
         stamp(cx, ST_C_AHEAD);
       }
+      VIO_PRIO(0);
     } else {
       for (int kp = W; kp >= 0; kp--) {
         while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + kp)) == 0) __builtin_amdgcn_s_sleep(1);
@@ -2764,8 +2773,10 @@ VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
   auto rows_of = [&](int I) { return nrows - 16 * I < 16 ? nrows - 16 * I : 16; };
   auto piv_of = [&](int I) { return n6 - 16 * I < 16 ? (n6 - 16 * I > 0 ? n6 - 16 * I : 0) : 16; };
   if (wave == 0) {
+    VIO_PRIO(3);
     const bool good = potrf16_wave(tile(0, 0), tile(0, 0), tri_ld(0), rows_of(0), piv_of(0), false, ldp, lane0);
     if (!good && lane0 == 0) w.flag[1] = 1;
+    VIO_PRIO(0);
   }
   VIO_SYNC();
   stamp(cx, ST_C_POTRF);
@@ -2781,9 +2792,11 @@ VIO_DEV bool factor_poses(const Ctx &cx, const WinView &v, WK &w) {
     // the other waves update the remaining tiles
     if (wave == 0) {
       if (ntb > 0) {
+        VIO_PRIO(3);
         const bool good = potrf16_wave(tile(K + 1, K + 1), tile(K + 1, K), tri_ld(K + 1), rows_of(K + 1), piv_of(K + 1), true,
                                        ldp + 16 * (K + 1), lane);
         if (!good && lane == 0) w.flag[1] = 1;
+        VIO_PRIO(0);
       }
       stamp(cx, ST_C_AHEAD);
     } else {
@@ -2956,6 +2969,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
           if (kq + 4 * r < kSB) w.t1[kBS * k + 6 + kq + 4 * r] = U[r];
       }
     };
+    VIO_PRIO(3);
     Blk cur, nxt;
     v4d U = {0.0, 0.0, 0.0, 0.0};
     fetch_fwd(W, cur);
@@ -2996,6 +3010,7 @@ VIO_DEV void backsolve(const Ctx &cx, const WinView &v, WK &w) {
       put(k, U);
       cur = nxt;
     }
+    VIO_PRIO(0);
     stamp(cx, ST_X0);  // (the two band chains; ST_B_BAND behind the barrier is then the wait for the landmark part)
   } else {
     // landmark back-substitution, first half: w_f^T z_p by the waves that do not walk the band. Pose matrices of up to five tile
