@@ -71,7 +71,10 @@
 #ifdef VIO_HOST_BUILD
 #define VIO_TID(cx) ((int)(cx).tid)
 #else
-#define VIO_TID(cx) ::vio::opaque_tid((int)(cx).tid)
+// (round 6: the index is REBUILT where it is asked for -- lane count of the wave + the wave's first index from a scalar register, two
+// vector instructions -- instead of passing the kernel's v0 through the empty asm: the register allocator kept that one value in
+// scratch and every phase began with a scratch_load of it, 111 of them in the W = 10 variant)
+#define VIO_TID(cx) ::vio::hw_tid((cx).wave64)
 #endif
 #define VIO_PARFOR(i, n) for (int i = VIO_TID(cx); i < (int)(n); i += (int)cx.nt)
 // The same for any per-lane value inside a loop: per-lane addresses that do not depend on the loop counter (the 60 tile
@@ -95,6 +98,11 @@ namespace vio {
 #ifndef VIO_HOST_BUILD
 __device__ __forceinline__ int opaque_tid(int t) {
   asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ int hw_tid(int wave64) {
+  int t;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %1\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t) : "s"(wave64));
   return t;
 }
 #endif
@@ -156,6 +164,7 @@ enum Stage {
 
 struct Ctx {
   int tid, nt;
+  int wave64 = 0;     // index of the wave's first work-item (device: a scalar register, VIO_TID builds the index from it)
   ldsd red;           // LDS scratch for block reductions: two halves of [3 nt/64]
   mutable int red_phase = 0;  // which half the next reduction writes (uniform across the block)
   long long *prof;    // global [ST_COUNT] cycle accumulators of this window, or null; prof[ST_COUNT-1] = last stamp
@@ -849,13 +858,13 @@ VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP) {
   VIO_SYNC();
 }
 #else
-// Device form: 32 lanes per factor, lane j keeps column j of [cov | I] in registers through all 15 pivots; the pivot
-// column travels through a 16-double mailbox per factor (in the still unused matrix buffer). Same arithmetic, same
-// order as the loop above.
+// Device form of the Gauss-Jordan elimination: 32 lanes per factor, lane j keeps column j of [cov | I] in registers through all
+// 15 pivots; the pivot column travels through a 16-double mailbox per factor (in the still unused matrix buffer). Same
+// arithmetic, same order as the loop above. Since round 6 the fallback of setup_imu_info below (a covariance that is not
+// positive definite to working precision).
 template <class MP>
-VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
+VIO_DEV void setup_imu_info_gj(const Ctx &cx, const WinView &v, MP mbox) {
   const int W = v.W;
-  VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
   const int tid_ = VIO_TID(cx), j = tid_ & 31, slot = tid_ >> 5, nslots = cx.nt >> 5;
   for (int f0 = 0; f0 < W; f0 += nslots) {
     const int f = f0 + slot;
@@ -1337,6 +1346,73 @@ VIO_DEV void tile_update(MP C, int ld_i, int rows_i, MP A, MP B, int ld_j, int r
 #pragma unroll
   for (int s = 0; s < 4; s++) acc = mfma_f64(-a[s], b[s], acc);
   tile_store_acc(C, ld_i, rows_i, li, kq, acc);
+}
+// cov^-1 of every IMU factor (round 6): the covariance of a pre-integration is symmetric positive definite, so one wave
+// factors it on the matrix cores -- potrf16_wave on a 15-pivot tile, which leaves L and L^-1 -- and forms cov^-1 = L^-T L^-1
+// as ONE Gram product of the inverse factor: 15 pivots + 4 matrix instructions per factor, 10 factors on 4 waves. The
+// Gauss-Jordan elimination with partial pivoting of rounds 1-5 (the CPU restatement's order, 32 lanes per factor, a mailbox
+// round trip per pivot) took 75 k cycles per solve, 120 k with two windows per CU; it stays as the fallback for a covariance
+// whose factorization meets a non-positive pivot. The reference inverts with Eigen's partial-pivoting LU (imu_factor.h:72 via
+// integration_base.h): any backward-stable inverse agrees with it to cond(cov) eps, far inside the 1e-6 bar (goldens).
+template <class MP>
+VIO_DEV void setup_imu_info(const Ctx &cx, const WinView &v, MP mbox) {
+  const int W = v.W;
+  VIO_PARFOR(q, W * 450) v.imu_J[q] = 0.0;
+  constexpr int kLd = 17, kTile = 16 * kLd + 16;  // one tile (odd leading dimension) + 16 pivot reciprocals per wave
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int n = lane & 15, kq = lane >> 4;
+  auto T = mbox + wave * kTile;
+  auto ldv = T + 16 * kLd;
+  bool all_good = true;
+  if (cx.tid == 0) mbox[nw * kTile] = 0.0;  // (fallback flag)
+  VIO_SYNC();
+  for (int f = wave; f < W; f += nw) {
+    const double *cov = v.preint + f * kPreintDoubles + 242;
+    double c4[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {  // element (row kq + 4 r, column n): the lower triangle is what the factorization reads
+      const int row = kq + 4 * r, hi = row > n ? row : n, lo = row > n ? n : row;
+      c4[r] = cov[(hi < 15 ? hi : 0) * 15 + (lo < 15 ? lo : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = kq + 4 * r;
+      T[row * kLd + n] = (row < 15 && n < 15) ? c4[r] : (row == n ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool good = potrf16_wave(T, T, kLd, 15, 15, false, ldv, lane);
+    all_good = all_good && good;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // X = L^-1 (lower): X[k][i] sits above the diagonal of the stored tile at T[i][k] for k > i, 1 / L_ii on the diagonal.
+    // cov^-1 = X^T X: A operand (row i, k-slot 4 s + kq) and B operand (k-slot, column i) are the same register.
+    double x[4];
+    const double dg = ldv[n < 15 ? n : 0];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) x[s4] = T[(n < 15 ? n : 0) * kLd + (4 * s4 + kq)];
+    VIO_SCHED_FENCE();
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const int k = 4 * s4 + kq;
+      const double xv = (n < 15 && k < 15) ? (k > n ? x[s4] : (k == n ? dg : 0.0)) : 0.0;
+      acc = mfma_f64(xv, xv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = kq + 4 * r;
+      if (row < 15 && n < 15) v.imu_info[f * 225 + row * 15 + n] = acc[r];
+    }
+    __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by the wave's next factor)
+  }
+  if (__builtin_amdgcn_ballot_w64(!all_good) != 0 && lane == 0) mbox[nw * kTile] = 1.0;
+  VIO_SYNC();
+  const bool fallback = mbox[nw * kTile] == 1.0;
+  VIO_SYNC();
+  if (fallback) setup_imu_info_gj(cx, v, mbox);
 }
 #endif  // !VIO_EMUL
 

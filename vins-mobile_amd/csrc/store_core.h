@@ -95,6 +95,7 @@ VIO_DEV Lds carve_lds(const Dims &d, PI ibase, PD *dbase_out) {
 
 struct Cx {
   int tid, nt;
+  int wave64 = 0;  // (VIO_TID of solver_core.h)
 };
 
 #ifdef VIO_HOST_BUILD

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kThreads) void pnp_window_kernel(PnpBatch B) {
   v.Jraw = B.Jraw + (size_t)b * (F - 1) * 450;
   v.s_info = B.s_info, v.gravity = B.gravity, v.cauchy_b = B.cauchy_b;
   Ctx cx;
+  cx.wave64 = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
   cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.lprof = nullptr;
   pnp::Work<ldsd> w;
   pnp::carve<ldsd>(v.n, kThreads, (ldsd)pnp_smem, &w, &cx);

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kPgThreads) void posegraph_kernel(PgPtrs P) {
   const int ld = P.ld;
   v.x = lds, v.xc = lds + ld, v.g = lds + 2 * ld, v.scale = lds + 3 * ld, v.diag = lds + 4 * ld, v.bm = lds + 5 * ld, v.ldinv = lds + 6 * ld;
   Ctx cx;
+  cx.wave64 = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
   cx.tid = threadIdx.x, cx.nt = blockDim.x, cx.prof = nullptr, cx.lprof = nullptr;
   cx.red = lds + 7 * ld;
   ldsi ints = reinterpret_cast<ldsi>(lds + 7 * ld + 6 * (kPgThreads / 64) + 2);

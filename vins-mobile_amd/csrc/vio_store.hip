@@ -51,7 +51,7 @@ __global__ __launch_bounds__(st::kThreads) void store_ingest_kernel(StoreDev S) 
     if (threadIdx.x < 6) side[threadIdx.x] = src[kPreintDoubles + threadIdx.x];
   }
   if (!S.active[slot]) return;
-  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63)};
   ldsd dbase;
   st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
   if (slot == 0) l.prof = S.prof;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(st::kThreads) void store_pack_kernel(StoreDev S, Ba
   extern __shared__ int lds_raw[];
   const int slot = blockIdx.x;
   if (!S.active[slot]) return;
-  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63)};
   ldsd dbase;
   st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
   if (slot == 0) l.prof = S.prof;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(st::kThreads) void store_finish_kernel(StoreDev S, 
   extern __shared__ int lds_raw[];
   const int slot = blockIdx.x;
   if (!S.active[slot]) return;
-  st::Cx cx{(int)threadIdx.x, (int)blockDim.x};
+  st::Cx cx{(int)threadIdx.x, (int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63)};
   ldsd dbase;
   st::Lds l = st::carve_lds<ldsi, ldsd>(S.d, (ldsi)lds_raw, &dbase);
   if (slot == 0) l.prof = S.prof;
