@@ -308,3 +308,28 @@ def test_cooperative_windows_match_the_reference(name, monkeypatch):
         else:  # the widths differ in summation order only
             assert H.pose_relerr(got.pose, ref_pose) < 1e-8, width
 
+
+
+def test_cooperative_window_timeout_is_reported(monkeypatch):
+    """The wait between the workgroups of a cooperative window gives up instead of hanging the device (csrc/solver_core.h,
+    coop_spin): with the helpers told to stay away (VIO_AMD_COOP_FAULT, a test hook of the launcher) and a short poll budget the
+    owner's first wait times out, every later wait of the window returns at once, the window reads FAILURE (termination 2), its
+    next prior is dropped and the call returns VIO_ETIMEOUT; the same context then solves the window correctly again."""
+    cfg, w, d = H.load_golden_window("win_c3_w20")
+    monkeypatch.setenv("VIO_AMD_COOP", "2")
+    monkeypatch.setenv("VIO_AMD_COOP_FAULT", "1")
+    monkeypatch.setenv("VIO_AMD_COOP_SPIN", "2000")
+    solver = pkg.backend.WindowSolver(cfg, max_batch=4)
+    got = [w.copy(), w.copy()]
+    try:
+        solver.solve(got)
+        raised = None
+    except RuntimeError as e:
+        raised = str(e)
+    assert raised is not None and ("rc=%d" % abi.VIO_ETIMEOUT) in raised, raised
+    monkeypatch.delenv("VIO_AMD_COOP_FAULT")
+    monkeypatch.delenv("VIO_AMD_COOP_SPIN")
+    again = w.copy()
+    stats = solver.solve([again])[0]
+    H.check_solution(again, stats, d, tol=TOL, tol_prior=TOL_PRIOR)
+    solver.close()

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 VIO_OK = 0
-VIO_EINVAL, VIO_ENODEV, VIO_ENOMEM, VIO_ECAP, VIO_ESTATE = -1, -2, -3, -4, -5
+VIO_EINVAL, VIO_ENODEV, VIO_ENOMEM, VIO_ECAP, VIO_ESTATE, VIO_ETIMEOUT = -1, -2, -3, -4, -5, -6
 VIO_MAX_PRIOR_BLOCKS = 96
 VIO_MAX_TRACE = 64
 VIO_BLOCK_POSE, VIO_BLOCK_SPEEDBIAS, VIO_BLOCK_EXPOSE = 0, 1, 2

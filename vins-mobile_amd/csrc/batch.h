@@ -117,7 +117,9 @@ inline BatchStrides make_strides(const BatchDims &d) {
   s.s_gpiece = o, o += (gram_piece_capacity(d) + 1) / 2;  // ints: the Gram pieces of the window (solver_core.h, build_gram_pieces)
   s.s_gstart = o, o += (gram_chunk_capacity(d) + 1) / 2;  // ints: first piece of every staging chunk
   s.scratch = (o + 7) / 8 * 8;
-  s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16;  // the pose matrix when it lives in global memory
+  // the pose matrix when it lives in global memory, and behind it the fill panels V_k of the band (factor_band_lds):
+  // [Pcap][tile columns][3][64] in operand layout, consumed by ONE rank-9 P product per factorization
+  s.hm = tri_doubles(6 * d.nblk_cap + 1) + 16 + (size_t)d.Pcap * ((6 * (size_t)d.nblk_cap + 1 + 15) / 16) * 192;
   s.out_pose = s.pose, s.out_sb = s.sb, s.out_feat = s.feat, s.out_loop = 7;
   s.stats_d = kStatsDoubles, s.stats_i = kStatsInts;
   return s;
@@ -280,6 +282,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   ldsd app = nullptr;
   if (lds_matrix) app = take(napp);
   w.App = MatPick<MP>::get(lds_matrix, app, hm_global);
+  w.VG = lds_matrix || !hm_global ? nullptr : hm_global + napp + 16;
   // (pose matrix in global scratch: the band, the fill-tile buffer and what LDS is left over sit behind the vectors,
   // contiguous, and stage the Jacobian rows -- see below)
   if (lds_matrix) w.Dss = take(2 * (size_t)d.Pcap * kSS), w.Css = w.Dss + (size_t)d.Pcap * kSS;

@@ -319,6 +319,7 @@ struct WorkT {
   ldsd rot;                 // (P+2) x 9: rotation matrices of the poses under evaluation, then r_ic
   ldsd ppd;                 // (P+1) x 36: diagonal pose-pose blocks of the projection Gram products
   ldsd vbuf;                // general panel path only: [nT][3][64] fill tiles V_k^T (else null)
+  double *VG;               // pose matrix in global scratch only: the fill panels of all band blocks, [P][nT][3][64] (batch.h, s.hm)
 };
 
 VIO_DEV int off_pose(const WinView &v, int i) { return kBS * i; }  // loop pose: i == P -> 15 P
@@ -360,7 +361,7 @@ VIO_DEV void red_put(const WinView &v, WK &w, int fr, int cr, int fc, int cc, do
 // writer). Everything serial (band / pose factorization, trust-region logic, marginalization) stays with the owner.
 // Ordering: payload stores, workgroup barrier, device-scope fence, flag store by one lane | flag load by one lane, barrier,
 // device-scope fence by EVERY wave (their vector L1 may hold the previous round's lines), payload loads.
-enum CoopCmd { COOP_EXIT = 1, COOP_EVAL = 2, COOP_SCHUR = 3 };
+enum CoopCmd { COOP_EXIT = 1, COOP_EVAL = 2, COOP_SCHUR = 3, COOP_SYRK = 4 };
 constexpr unsigned kCoopSpinLimit = 1u << 24;  // polls (s_sleep 8 between them) before a wait gives up: seconds (Ctx::coop_spin)
 constexpr int kCoopMax = 4;
 struct CoopLayout {
@@ -2789,53 +2790,140 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
   return true;
 }
 
-// The same with the fill tiles in LDS (w.vbuf: [nT][3][64], accumulator = operand layout, updated in place) for pose
-// matrices of any size: the tiles of a step are shared out over the waves, a barrier hands them over.
+// The same for pose matrices of any size that live in GLOBAL scratch (W > 12; round 6, the cooperative factorization).
+// Rounds 3-5 walked the band slot by slot: band block on wave 0, barrier, the fill tiles V_k through LDS, barrier, then a
+// read-modify-write of EVERY tile of the pose matrix in global memory -- W + 1 times per factorization, three barriers and two
+// dependent L2 round trips per slot (c_wait + c_trsm: 25 % of a W = 30 solve, on the owner alone in a cooperative window).
+// Now:
+//   (A) the chain wave runs the band blocks at its own pace and posts a flag per block (like factor_band_regs). Column tile t of
+//       the fill, V_k^T[t] = L_k^-1 (Asp_k^T[t] - E_{k+1} V_{k+1}^T[t]), depends on tile t of the previous step ONLY: every
+//       panel wave owns whole tile columns, keeps the running tile in registers (accumulator layout = B-operand layout) down
+//       the chain and stores each V_k^T[t] once, in operand layout, into the window's global panel buffer w.VG. No barrier.
+//   (B) App -= sum_k V_k V_k^T as ONE product: every lower tile (I, J) has one writer, which loads it once, runs over the
+//       blocks k that reach tile column J (the fill of s_k starts at pose column w.sbr[2 k]: about half of all (tile, k) pairs
+//       are structurally zero) and stores it once. The tiles are dealt out heaviest first over the waves -- of ALL workgroups of
+//       a cooperative window (command COOP_SYRK: the helpers read w.VG and the matrix from the XCD's L2).
+// Reference: the reduced system's factorization, CSI/schur_complement_solver.cc:161-224 (result, not route).
+template <class WK>
+VIO_DEV int band_tile_reach(const WinView &v, const WK &w, int t) {  // largest k whose fill reaches tile column t
+  int flo = v.n6;
+  for (int k = v.W; k > 0; k--) {
+    flo = flo < w.sbr[2 * k] ? flo : w.sbr[2 * k];
+    if (t >= (flo >> 4)) return k;
+  }
+  return 0;
+}
+template <class WK>
+VIO_DEV void band_syrk_share(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
+  const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
+  const int li = lane & 15, kq = lane >> 4, nT = v.nT;
+  const int ntiles = nT * (nT + 1) / 2, nwk = nshare * nw, me = share * nw + wave;
+  const double *VG = w.VG;
+  for (int r = 0;; r++) {
+    // (heaviest first -- tile column nT - 1 is reached by every block, column 0 by the last few --, dealt out in snake order)
+    const int q = r * nwk + ((r & 1) ? nwk - 1 - me : me);
+    if (r * nwk >= ntiles) break;
+    if (q >= ntiles) continue;
+    int c = 0;
+    while ((c + 1) * (c + 2) / 2 <= q) c++;
+    const int J = nT - 1 - c, I = J + (q - c * (c + 1) / 2);
+    auto C = w.App + tri_off(I) + 16 * J;
+    const int ld = tri_ld(I), rows = v.nrows - 16 * I;
+    v4d acc = tile_load_acc(C, ld, rows, li, kq);
+    const int kmax = band_tile_reach(v, w, J);
+    constexpr int KB = 4;  // blocks per operand batch: 24 loads in flight ahead of 12 matrix instructions
+    for (int k0 = kmax; k0 >= 0; k0 -= KB) {
+      double a[KB][3], b[KB][3];
+#pragma unroll
+      for (int u = 0; u < KB; u++) {
+        const int k = k0 - u >= 0 ? k0 - u : 0;
+        const double *pa = VG + ((size_t)(k * nT + I) * 3) * 64 + lane, *pb = VG + ((size_t)(k * nT + J) * 3) * 64 + lane;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) a[u][s3] = pa[64 * s3], b[u][s3] = pb[64 * s3];
+      }
+      VIO_SCHED_FENCE();
+#pragma unroll
+      for (int u = 0; u < KB; u++) {
+        const bool on = k0 - u >= 0;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) acc = mfma_f64(on ? -a[u][s3] : 0.0, b[u][s3], acc);
+      }
+    }
+    tile_store_acc(C, ld, rows, li, kq, acc);
+  }
+}
 template <class WK>
 VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
   const int tid_ = VIO_TID(cx), wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), nw = cx.nt >> 6, lane = tid_ & 63;
   const int li = lane & 15, kq = lane >> 4;
-  const int W = v.W, nT = v.nT;
-  for (int k = W; k >= 0; k--) {
-    ldsd Vc = w.vbuf;  // V_{k+1}^T on entry, V_k^T behind the panel phase: element (t, s) of a lane is private to it
-    if (wave == 0) band_step(cx, v, w, k, 2, lane);
-    VIO_SYNC();
-    stamp(cx, ST_C_AHEAD);
-    if (w.flag[2]) return false;
-    double e[3] = {0.0, 0.0, 0.0}, linv[4];
-    if (k < W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
-    load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
-    for (int t = wave; t < nT; t += nw) {
-      v4d Tt = panel_load_tile(v, w, k, t, li, kq);
-      if (k < W) {
+  const int W = v.W, nT = v.nT, n6 = v.n6;
+  double *VG = w.VG;
+  if (wave == 0) {
+    VIO_PRIO(3);
+    for (int kb = W; kb >= 0; kb--) {
+      band_step(cx, v, w, kb, 2, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_wave_barrier();  // (every lane's stores of the block precede the flag)
+      if (lane == 0) VIO_FLAG_STORE(w.ready + kb, 1);
+      stamp(cx, ST_C_AHEAD);
+    }
+    VIO_PRIO(0);
+  } else {
+    for (int t = wave - 1; t < nT; t += nw - 1) {
+      double V[3] = {0.0, 0.0, 0.0};
+      int flo = n6;
+      bool started = false;
+      for (int k = W; k >= 0; k--) {
+        while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + k)) == 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        flo = flo < w.sbr[2 * k] ? flo : w.sbr[2 * k];  // (0 for the block the prior keeps)
+        if (t < (flo >> 4)) continue;                   // the fill has not reached this tile column yet
+        // Asp_k^T tile t (+ the gradient of s_k in column n6): the coupling rows are global in this variant -- fetched only where
+        // the 18 IMU columns of block k (or the prior's dense row) fall into the tile
+        const bool is_pr = w.sbr[2 * k + 1] != 0;
+        const int alo = 6 * (k > 0 ? k - 1 : 0);
+        v4d Tt;
+        if (is_pr || (16 * t + 15 >= alo && 16 * t < alo + kAW)) {
+          Tt = panel_load_tile(v, w, k, t, li, kq);
+        } else {
+          Tt = v4d{0.0, 0.0, 0.0, 0.0};
+          if (16 * t + li == n6) {
 #pragma unroll
-        for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], Vc[(t * 3 + s) * 64 + lane], Tt);
+            for (int r = 0; r < 3; r++)
+              if (kq + 4 * r < kSB) Tt[r] = w.gp[kBS * k + 6 + kq + 4 * r];
+          }
+        }
+        double e[3], linv[4];
+        if (started) {
+          load_op9(w.Css + (k + 1) * kSS, li, kq, e);
+#pragma unroll
+          for (int s3 = 0; s3 < 3; s3++) Tt = mfma_f64(-e[s3], V[s3], Tt);
+        }
+        load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
+        v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) Vn = mfma_f64(linv[s3], Tt[s3], Vn);
+        double *dst = VG + ((size_t)(k * nT + t) * 3) * 64 + lane;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) V[s3] = Vn[s3], dst[64 * s3] = Vn[s3];
+        started = true;
       }
-      v4d Vn = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 3; s++) Vn = mfma_f64(linv[s], Tt[s], Vn);
-#pragma unroll
-      for (int s = 0; s < 3; s++) Vc[(t * 3 + s) * 64 + lane] = Vn[s];
+      stamp(cx, ST_D2);
     }
-    VIO_SYNC();
-    stamp(cx, ST_C_TRSM);
-    const int ntiles = nT * (nT + 1) / 2;
-    for (int q = wave; q < ntiles; q += nw) {
-      int I = 0;
-      while ((I + 1) * (I + 2) / 2 <= q) I++;
-      const int J = q - I * (I + 1) / 2;
-      auto C = w.App + tri_off(I) + 16 * J;
-      const int ld = tri_ld(I), rows = v.nrows - 16 * I;
-      v4d acc = tile_load_acc(C, ld, rows, li, kq);
-#pragma unroll
-      for (int s = 0; s < 3; s++) acc = mfma_f64(-Vc[(I * 3 + s) * 64 + lane], Vc[(J * 3 + s) * 64 + lane], acc);
-      tile_store_acc(C, ld, rows, li, kq, acc);
-    }
-    // (the next step's band work only touches Dss / Css; the barrier behind it orders this update before the next
-    // panel phase overwrites vbuf)
-    stamp(cx, ST_C_WAIT);
   }
+  VIO_SYNC();  // (the panels are global stores: visible to the whole workgroup behind this barrier)
+  stamp(cx, ST_C_TRSM);
+  if (w.flag[2]) return false;
+#ifndef VIO_HOST_BUILD
+  if (cx.coop > 1) {
+    coop_post(cx, v, COOP_SYRK);
+    band_syrk_share(cx, v, w, 0, cx.coop);
+    coop_wait_helpers(cx, v);
+  } else
+#endif
+    band_syrk_share(cx, v, w, 0, 1);
   VIO_SYNC();
+  stamp(cx, ST_C_WAIT);
   return true;
 }
 
@@ -3594,6 +3682,18 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
   VIO_SYNC();
 }
 
+// first pose column speed-bias block k couples to: the IMU chain reaches the frame and both neighbours, the block the
+// prior keeps reaches every pose of the prior
+template <class WK>
+VIO_DEV void init_band_reach(const Ctx &cx, const WinView &v, WK &w) {
+  VIO_PARFOR(k, v.P) {
+    int lo = 6 * (k > 0 ? k - 1 : 0), pr = 0;
+    for (int b = 0; b < v.prior_nb; b++)
+      if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, pr = 1;
+    w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = pr;
+  }
+}
+
 #ifndef VIO_HOST_BUILD
 // A helper workgroup of a cooperative window (member >= 1): serves the owner's commands until COOP_EXIT. Its LDS has the
 // owner's layout; it only ever touches the staging area, the evaluation point and the accumulators of its partial sums.
@@ -3603,6 +3703,8 @@ VIO_DEV void coop_helper(const Ctx &cx, const WinView &v, WK &w) {
   const int np = v.np, F = v.F, nFr = v.P + v.has_loop;
   const size_t fs = ((size_t)v.Fcap + 7) & ~(size_t)7;
   double *part = v.coop + L.o_part + (size_t)(cx.member - 1) * L.part;
+  init_band_reach(cx, v, w);  // (the band's trailing product, COOP_SYRK, skips the tiles a block's fill does not reach)
+  VIO_SYNC();
   for (;;) {
     const int cmd = coop_wait_cmd(cx, v);
     if (cmd == COOP_EVAL) {
@@ -3639,6 +3741,8 @@ VIO_DEV void coop_helper(const Ctx &cx, const WinView &v, WK &w) {
       VIO_PARFOR(f, F) w.einv[f] = v.coop[L.o_einv + f], w.tf[f] = v.coop[L.o_tf + f];
       VIO_SYNC();
       schur_general(cx, v, w, cx.member, cx.coop);
+    } else if (cmd == COOP_SYRK) {
+      band_syrk_share(cx, v, w, cx.member, cx.coop);
     } else {
       break;  // COOP_EXIT (or a timed-out wait)
     }
@@ -3661,14 +3765,7 @@ VIO_DEV void solve_window(const Ctx &cx, const WinView &v, WK &w, const VP &fres
   if (v.has_loop) VIO_PARFOR(q, 7) w.xpose[7 * P + q] = v.pose0[7 * v.loop_frame + q];  // VINS.cpp:590-591
   VIO_PARFOR(q, v.nblk * kBS) w.t1[q] = 0.0, w.t2[q] = 0.0;
   if (cx.tid == 0) w.flag[0] = w.flag[1] = w.flag[2] = w.flag[3] = 0;
-  // first pose column speed-bias block k couples to: the IMU chain reaches the frame and both neighbours, the block the
-  // prior keeps reaches every pose of the prior
-  VIO_PARFOR(k, P) {
-    int lo = 6 * (k > 0 ? k - 1 : 0), pr = 0;
-    for (int b = 0; b < v.prior_nb; b++)
-      if (v.pr_kind[b] == 1 && v.pr_index[b] == k) lo = 0, pr = 1;
-    w.sbr[2 * k] = lo, w.sbr[2 * k + 1] = pr;
-  }
+  init_band_reach(cx, v, w);
   VIO_SYNC();
 #ifndef VIO_EMUL
   if (cx.prof && cx.tid == cx.prof_tid) {
