@@ -2819,6 +2819,8 @@ VIO_DEV void band_syrk_share(const Ctx &cx, const WinView &v, WK &w, int share, 
   const int li = lane & 15, kq = lane >> 4, nT = v.nT;
   const int ntiles = nT * (nT + 1) / 2, nwk = nshare * nw, me = share * nw + wave;
   const double *VG = w.VG;
+  // (lane t walks the reach table for tile column t once: a walk per tile was 30 dependent LDS reads ahead of its first fetch)
+  const int my_reach = band_tile_reach(v, w, lane < nT ? lane : nT - 1);
   for (int r = 0;; r++) {
     // (heaviest first -- tile column nT - 1 is reached by every block, column 0 by the last few --, dealt out in snake order)
     const int q = r * nwk + ((r & 1) ? nwk - 1 - me : me);
@@ -2829,25 +2831,39 @@ VIO_DEV void band_syrk_share(const Ctx &cx, const WinView &v, WK &w, int share, 
     const int J = nT - 1 - c, I = J + (q - c * (c + 1) / 2);
     auto C = w.App + tri_off(I) + 16 * J;
     const int ld = tri_ld(I), rows = v.nrows - 16 * I;
-    v4d acc = tile_load_acc(C, ld, rows, li, kq);
-    const int kmax = band_tile_reach(v, w, J);
-    constexpr int KB = 4;  // blocks per operand batch: 24 loads in flight ahead of 12 matrix instructions
-    for (int k0 = kmax; k0 >= 0; k0 -= KB) {
-      double a[KB][3], b[KB][3];
+    v4d acc = tile_load_acc_raw(C, ld, rows, li, kq);  // (masked below, behind the first operand fetch)
+    const int kmax = __builtin_amdgcn_readlane(my_reach, J);
+    // operand batches of KB blocks, the next batch's loads in flight behind this one's matrix instructions
+    constexpr int KB = 3;
+    double a[2][KB][3], b[2][KB][3];
+    auto fetch = [&](int k0, double (&aa)[KB][3], double (&bb)[KB][3]) {
 #pragma unroll
       for (int u = 0; u < KB; u++) {
         const int k = k0 - u >= 0 ? k0 - u : 0;
         const double *pa = VG + ((size_t)(k * nT + I) * 3) * 64 + lane, *pb = VG + ((size_t)(k * nT + J) * 3) * 64 + lane;
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) a[u][s3] = pa[64 * s3], b[u][s3] = pb[64 * s3];
+        for (int s3 = 0; s3 < 3; s3++) aa[u][s3] = pa[64 * s3], bb[u][s3] = pb[64 * s3];
       }
-      VIO_SCHED_FENCE();
+    };
+    auto multiply = [&](int k0, const double (&aa)[KB][3], const double (&bb)[KB][3]) {
 #pragma unroll
       for (int u = 0; u < KB; u++) {
         const bool on = k0 - u >= 0;
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) acc = mfma_f64(on ? -a[u][s3] : 0.0, b[u][s3], acc);
+        for (int s3 = 0; s3 < 3; s3++) acc = mfma_f64(on ? -aa[u][s3] : 0.0, bb[u][s3], acc);
       }
+    };
+    fetch(kmax, a[0], b[0]);
+    VIO_SCHED_FENCE();
+    acc = tile_mask_acc(acc, rows, kq);
+    for (int k0 = kmax; k0 >= 0; k0 -= 2 * KB) {
+      if (k0 - KB >= 0) fetch(k0 - KB, a[1], b[1]);
+      VIO_SCHED_FENCE();
+      multiply(k0, a[0], b[0]);
+      if (k0 - KB < 0) break;
+      if (k0 - 2 * KB >= 0) fetch(k0 - 2 * KB, a[0], b[0]);
+      VIO_SCHED_FENCE();
+      multiply(k0 - KB, a[1], b[1]);
     }
     tile_store_acc(C, ld, rows, li, kq, acc);
   }
@@ -2869,44 +2885,63 @@ VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
     }
     VIO_PRIO(0);
   } else {
-    for (int t = wave - 1; t < nT; t += nw - 1) {
-      double V[3] = {0.0, 0.0, 0.0};
+    // (two tile columns of a wave walk down the chain together: one flag wait and one batch of LDS operands per block)
+    constexpr int NTW = 2;
+    for (int t0 = wave - 1; t0 < nT; t0 += NTW * (nw - 1)) {
+      double V[NTW][3];
+      bool started[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; j++) V[j][0] = V[j][1] = V[j][2] = 0.0, started[j] = false;
+      // (a wave joins the chain at the first block whose fill reaches one of its tile columns: until then it sleeps in long
+      // intervals instead of polling every block's flag beside the chain wave)
+      const int t1 = t0 + (nw - 1) < nT ? t0 + (nw - 1) : t0;
+      const int kstart = __builtin_amdgcn_readfirstlane(band_tile_reach(v, w, t1));
       int flo = n6;
-      bool started = false;
-      for (int k = W; k >= 0; k--) {
-        while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + k)) == 0) __builtin_amdgcn_s_sleep(1);
+      for (int k = W; k > kstart; k--) flo = flo < w.sbr[2 * k] ? flo : w.sbr[2 * k];
+      while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + kstart)) == 0) __builtin_amdgcn_s_sleep(8);
+      for (int k = kstart; k >= 0; k--) {
+        while (__builtin_amdgcn_readfirstlane(VIO_FLAG_LOAD(w.ready + k)) == 0) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         flo = flo < w.sbr[2 * k] ? flo : w.sbr[2 * k];  // (0 for the block the prior keeps)
-        if (t < (flo >> 4)) continue;                   // the fill has not reached this tile column yet
-        // Asp_k^T tile t (+ the gradient of s_k in column n6): the coupling rows are global in this variant -- fetched only where
-        // the 18 IMU columns of block k (or the prior's dense row) fall into the tile
         const bool is_pr = w.sbr[2 * k + 1] != 0;
         const int alo = 6 * (k > 0 ? k - 1 : 0);
-        v4d Tt;
-        if (is_pr || (16 * t + 15 >= alo && 16 * t < alo + kAW)) {
-          Tt = panel_load_tile(v, w, k, t, li, kq);
-        } else {
-          Tt = v4d{0.0, 0.0, 0.0, 0.0};
-          if (16 * t + li == n6) {
+        bool act[NTW];
+        v4d Tt[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; j++) {
+          const int t = t0 + j * (nw - 1);
+          act[j] = t < nT && t >= (flo >> 4);  // (else: the fill has not reached this tile column yet)
+          Tt[j] = v4d{0.0, 0.0, 0.0, 0.0};
+          if (!act[j]) continue;
+          // Asp_k^T tile t (+ the gradient of s_k in column n6): the coupling rows are global in this variant -- fetched only where
+          // the 18 IMU columns of block k (or the prior's dense row) fall into the tile
+          if (is_pr || (16 * t + 15 >= alo && 16 * t < alo + kAW)) {
+            Tt[j] = panel_load_tile(v, w, k, t, li, kq);
+          } else if (16 * t + li == n6) {
 #pragma unroll
             for (int r = 0; r < 3; r++)
-              if (kq + 4 * r < kSB) Tt[r] = w.gp[kBS * k + 6 + kq + 4 * r];
+              if (kq + 4 * r < kSB) Tt[j][r] = w.gp[kBS * k + 6 + kq + 4 * r];
           }
         }
-        double e[3], linv[4];
-        if (started) {
-          load_op9(w.Css + (k + 1) * kSS, li, kq, e);
-#pragma unroll
-          for (int s3 = 0; s3 < 3; s3++) Tt = mfma_f64(-e[s3], V[s3], Tt);
-        }
+        if (!act[0] && !act[1]) continue;
+        double e[3] = {0.0, 0.0, 0.0}, linv[4];
+        if (k < W) load_op9(w.Css + (k + 1) * kSS, li, kq, e);
         load_linv9(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
-        v4d Vn = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) Vn = mfma_f64(linv[s3], Tt[s3], Vn);
-        double *dst = VG + ((size_t)(k * nT + t) * 3) * 64 + lane;
+        for (int j = 0; j < NTW; j++) {
+          if (!act[j]) continue;
+          if (started[j]) {
 #pragma unroll
-        for (int s3 = 0; s3 < 3; s3++) V[s3] = Vn[s3], dst[64 * s3] = Vn[s3];
-        started = true;
+            for (int s3 = 0; s3 < 3; s3++) Tt[j] = mfma_f64(-e[s3], V[j][s3], Tt[j]);
+          }
+          v4d Vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s3 = 0; s3 < 3; s3++) Vn = mfma_f64(linv[s3], Tt[j][s3], Vn);
+          double *dst = VG + ((size_t)(k * nT + t0 + j * (nw - 1)) * 3) * 64 + lane;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; s3++) V[j][s3] = Vn[s3], dst[64 * s3] = Vn[s3];
+          started[j] = true;
+        }
       }
       stamp(cx, ST_D2);
     }
