@@ -14,7 +14,7 @@ import sys
 
 # kernels of one front-end step (bench.py's `roofline_frontend` label names the same set), matched by base name: the
 # demangled names carry template arguments (lk_track_kernel<1>, detect_kernel<false>)
-FRONTEND = ["copy_frames_kernel", "pyr_down_kernel", "pyr_down4_kernel", "lk_track_kernel", "track_update_kernel", "detect_kernel", "detect2_kernel", "corner_select_kernel"]
+FRONTEND = ["copy_frames_kernel", "pyr_down_kernel", "pyr_down4_kernel", "lk_track_kernel", "track_update_kernel", "detect_kernel", "corner_select_kernel"]
 ONCE_PER_STEP = "corner_select_kernel"   # every bench step publishes: its dispatch count is the number of steps
 
 

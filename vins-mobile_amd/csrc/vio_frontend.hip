@@ -1335,6 +1335,10 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
 //   * the mask is either an image (stand-alone operator) or the discs setMask painted (feature_tracker.cpp:80),
 //     rasterised once per workgroup into one 64-bit word per (wave, row).
 // The quality threshold needs the global maximum, so it is applied later by the selection kernel.
+// (Round 6 built the two-pixels-per-lane form with v_pk_add / v_pk_mul / v_pk_fma_f32 for everything that takes no DPP operand --
+// bit-exact, 124 outputs per wave -- and measured it SLOWER, 500 vs 406 us per 512 frames: 228 M against 209 M vector instructions
+// per launch. What packs is a third of a row's instructions; the DPP neighbour sums, the square-root selects, the 3x3 maximum and
+// the candidate tests are per pixel either way, and building the operand pairs costs moves. commit 3f94e20 has the kernel.)
 constexpr int kDetW = 60;      // output columns per wave
 constexpr int kDetWaves = 4;   // waves per workgroup, side by side
 constexpr int kDetR = 32;      // output rows per strip (64 halves the halo rows but its 31 KB candidate buffer halves the resident
@@ -1504,193 +1508,8 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   if (tid == 0 && smax) atomicMax(&max_bits[segi], smax);
 }
 
-// ---- the same, two pixels per lane (round 6) ----------------------------------------------------------------------------
-// detect_kernel above is bound by vector-instruction issue: ~75 instructions per row of 60 pixels, about half of them plain
-// fp32 adds / multiplies. Here a lane owns TWO adjacent columns (a wave: 128 extended columns = 124 outputs + 2 halo columns each
-// side) and every add / multiply / fma that does not take a DPP operand is one v_pk_*_f32 on the pair. Packed operations round
-// each half like the scalar instruction (contraction is off in this translation unit), the order of operations is the one of
-// detect_kernel, so the results are the same bits. Of the horizontal neighbours only the outer ones cross lanes: the left
-// neighbour of the odd pixel and the right neighbour of the even one are the lane's own other pixel. The candidate buffer in LDS
-// is sized for typical images (one pixel in twelve) instead of the worst case (one in four): a candidate that finds it full goes
-// to the strip's segment in global memory directly -- the smaller buffer is what keeps eight waves per SIMD resident.
-typedef float det_f2 __attribute__((ext_vector_type(2)));
-constexpr int kDet2W = 124;     // output columns per wave
-constexpr int kDet2Waves = 3;   // waves per workgroup, side by side (640 columns: two workgroups)
-constexpr int kDet2Cand = 1024; // candidate keys staged in LDS per workgroup
-
-template <bool IMG_MASK>
-__global__ __launch_bounds__(64 * kDet2Waves) void detect2_kernel(const uint8_t *img_base, size_t img_stride, const uint8_t *mask_base,
-                                                                  size_t mask_stride, const int *kept_xy, const int *n_kept, int cap,
-                                                                  const int *hw, int radius, unsigned *max_bits, int rows, int cols,
-                                                                  unsigned long long *cand_base, int seg_cap, int *n_cand,
-                                                                  const int *n_have, int max_corners) {
-  if (n_have && n_have[blockIdx.z] >= max_corners) return;  // (feature_tracker.cpp:256-266, like detect_kernel)
-  constexpr int NT = 64 * kDet2Waves;
-  __shared__ unsigned long long s_mask[kDet2Waves][kDetR][2];  // [..][0]: even extended columns (pixel A of lane l = bit l), [1]: odd
-  __shared__ unsigned long long s_cand[kDet2Cand];
-  __shared__ unsigned smax;
-  __shared__ int s_ncand, s_base, s_ndisc;
-  __shared__ int2 s_disc[kMaxCap];
-  const int seq = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const uint8_t *img = img_base + (size_t)seq * img_stride;
-  const int XB = blockIdx.x * (kDet2Waves * kDet2W), Y0 = blockIdx.y * kDetR;
-  const int X0 = XB + wave * kDet2W;  // first output column of this wave; lane l <-> extended columns X0 - 2 + 2 l, + 1
-  const int nseg = gridDim.y;
-  const size_t segi = (size_t)seq * nseg + blockIdx.y;
-  if (tid == 0) smax = 0, s_ncand = 0, s_ndisc = 0;
-  for (int i = tid; i < kDet2Waves * kDetR * 2; i += NT) (&s_mask[0][0][0])[i] = 0ull;
-  __syncthreads();
-  if (!IMG_MASK) {
-    const int nk = n_kept[seq];
-    for (int k = tid; k < nk; k += NT) {
-      const int cx = kept_xy[((size_t)seq * cap + k) * 2], cy = kept_xy[((size_t)seq * cap + k) * 2 + 1];
-      if (cy + radius >= Y0 && cy - radius < Y0 + kDetR && cx + radius >= XB - 2 && cx - radius < XB + kDet2Waves * kDet2W + 2) {
-        const int slot = atomicAdd(&s_ndisc, 1);
-        s_disc[slot] = make_int2(cx, cy);
-      }
-    }
-    __syncthreads();
-    const int nd = s_ndisc;
-    for (int it = tid; it < nd * kDetR * kDet2Waves; it += NT) {
-      const int wv = it % kDet2Waves, r = (it / kDet2Waves) % kDetR, dsc = it / (kDet2Waves * kDetR);
-      const int cx = s_disc[dsc].x, dy = Y0 + r - s_disc[dsc].y;
-      if (dy < -radius || dy > radius) continue;
-      const int h = hw[radius + dy];
-      const int e0 = max(cx - h - (XB + wv * kDet2W - 2), 0), e1 = min(cx + h - (XB + wv * kDet2W - 2), 127);
-      if (e0 > e1) continue;
-      // even columns 2 l in [e0, e1]: l in [(e0 + 1) / 2, e1 / 2]; odd columns 2 l + 1: l in [e0 / 2, (e1 - 1) / 2]
-      auto span = [](int l0, int l1) { return l0 > l1 ? 0ull : ((l1 - l0 == 63 ? ~0ull : ((1ull << (l1 - l0 + 1)) - 1ull)) << l0); };
-      const unsigned long long ba = span((e0 + 1) >> 1, e1 >> 1), bb = e1 >= 1 ? span(e0 >> 1, (e1 - 1) >> 1) : 0ull;
-      if (ba) atomicOr(&s_mask[wv][r][0], ba);
-      if (bb) atomicOr(&s_mask[wv][r][1], bb);
-    }
-    __syncthreads();
-  }
-  const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
-  const float s2 = s * 2.f;
-  const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, rows * cols, 0x00020000);
-  const int xeA = X0 - 2 + 2 * lane, xeB = xeA + 1;
-  const int xrA = reflect101(min(max(xeA, -cols + 1), 2 * cols - 2), cols), xrB = reflect101(min(max(xeB, -cols + 1), 2 * cols - 2), cols);
-  const int xmA = reflect101(xrA - 1, cols), xpA = reflect101(xrA + 1, cols), xmB = reflect101(xrB - 1, cols), xpB = reflect101(xrB + 1, cols);
-  // every extended column of the wave and its two neighbours inside the image: the six bytes of a row are four consecutive ones
-  const bool xfast = __builtin_amdgcn_readfirstlane(X0 - 3 >= 0 && X0 - 2 + 128 < cols);
-  det_f2 hxx0 = {0.f, 0.f}, hxx1 = hxx0, hxy0 = hxx0, hxy1 = hxx0, hyy0 = hxx0, hyy1 = hxx0, e0 = hxx0, e1 = hxx0;
-  float my_max = -INFINITY;
-  int prev_yr = -1, prev_yp = -1;
-  det_f2 pd1 = hxx0, pt1 = hxx0, pd2 = hxx0, pt2 = hxx0;
-  const bool out_lane = lane >= 1 && lane <= 62;
-  auto shr = [](float v) { return dpp_f32<0x138>(v); };  // value of lane - 1
-  auto shl = [](float v) { return dpp_f32<0x130>(v); };  // value of lane + 1
-  auto emit = [&](float v, int xe, int y) {
-    const int slot = atomicAdd(&s_ncand, 1);
-    const unsigned idx = (unsigned)y << 16 | (unsigned)xe;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
-    if (slot < kDet2Cand) s_cand[slot] = key;
-    else {  // (the staging buffer is full: straight to the strip's segment)
-      const int g = atomicAdd(&n_cand[segi], 1);
-      if (g < seg_cap) cand_base[segi * seg_cap + g] = key;
-    }
-  };
-#pragma unroll 6
-  for (int step = 0; step < kDetR + 4; step++) {
-    const int ye = Y0 - 2 + step;
-    const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
-    const int ym = reflect101(yr - 1, rows), yp = reflect101(yr + 1, rows);
-    auto row_dt = [&](int y, det_f2 &d, det_f2 &t) {
-      const int ro = __builtin_amdgcn_readfirstlane(y * cols);
-      det_f2 a0, a1, a2;
-      if (xfast) {
-        const unsigned q = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, xeA - 1, ro, 0);
-        const float b0 = (float)(q & 0xffu), b1 = (float)((q >> 8) & 0xffu), b2 = (float)((q >> 16) & 0xffu), b3 = (float)(q >> 24);
-        a0 = det_f2{b0, b1}, a1 = det_f2{b1, b2}, a2 = det_f2{b2, b3};
-      } else {
-        a0 = det_f2{(float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xmA, ro, 0), (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xmB, ro, 0)};
-        a1 = det_f2{(float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xrA, ro, 0), (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xrB, ro, 0)};
-        a2 = det_f2{(float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xpA, ro, 0), (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xpB, ro, 0)};
-      }
-      d = a2 - a0;
-      t = s2 * a1 + s * (a0 + a2);
-    };
-    det_f2 d0, t0, d1, t1, d2, t2;
-    if (step > 0 && ym == prev_yr && yr == prev_yp) {
-      d0 = pd1, t0 = pt1, d1 = pd2, t1 = pt2;
-      row_dt(yp, d2, t2);
-    } else {
-      row_dt(ym, d0, t0), row_dt(yr, d1, t1), row_dt(yp, d2, t2);
-    }
-    prev_yr = yr, prev_yp = yp, pd1 = d1, pt1 = t1, pd2 = d2, pt2 = t2;
-    const det_f2 dx = s2 * d1 + s * (d0 + d2);
-    const det_f2 dy = t2 - t0;
-    const det_f2 pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
-    // 3-tap horizontal sums, (left + centre) + right: even pixel: left = the odd pixel of lane - 1, right = this lane's odd pixel;
-    // odd pixel: left = this lane's even pixel, right = the even pixel of lane + 1
-    auto hsum = [&](det_f2 p) { return det_f2{(shr(p.y) + p.x) + p.y, (p.x + p.y) + shl(p.x)}; };
-    const det_f2 hxx2 = hsum(pxx), hxy2 = hsum(pxy), hyy2 = hsum(pyy);
-    det_f2 e2 = {0.f, 0.f};
-    if (step >= 2) {
-      const det_f2 a = ((hxx0 + hxx1) + hxx2) * 0.5f;
-      const det_f2 b = (hxy0 + hxy1) + hxy2;
-      const det_f2 c = ((hyy0 + hyy1) + hyy2) * 0.5f;
-      const det_f2 x = (a - c) * (a - c) + b * b;
-      // sqrt_rn_normal on both halves: the estimates and the selects are per pixel, the two residuals are packed fmas
-      const det_f2 r = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
-      const det_f2 rm = {__int_as_float(__float_as_int(r.x) - 1), __int_as_float(__float_as_int(r.y) - 1)};
-      const det_f2 rp = {__int_as_float(__float_as_int(r.x) + 1), __int_as_float(__float_as_int(r.y) + 1)};
-      const det_f2 em = __builtin_elementwise_fma(-rm, r, x), ep = __builtin_elementwise_fma(-rp, r, x);
-      det_f2 q;
-      q.x = em.x <= 0.f ? rm.x : r.x, q.x = ep.x > 0.f ? rp.x : q.x, q.x = (x.x == 0.f || __builtin_isinf(x.x)) ? x.x : q.x;
-      q.y = em.y <= 0.f ? rm.y : r.y, q.y = ep.y > 0.f ? rp.y : q.y, q.y = (x.y == 0.f || __builtin_isinf(x.y)) ? x.y : q.y;
-      e2 = (a + c) - q;
-    }
-    if (step >= 4) {
-      const int y = ye - 2, r = step - 4;
-      const float mA0 = fmaxf(fmaxf(e0.x, e1.x), e2.x), mB0 = fmaxf(fmaxf(e0.y, e1.y), e2.y);
-      const float mA = fmaxf(mA0, fmaxf(shr(mB0), mB0)), mB = fmaxf(mB0, fmaxf(mA0, shl(mA0)));
-      if (out_lane && y < rows) {
-        bool unA, unB;
-        if (IMG_MASK) {
-          const uint8_t *mrow = mask_base + (size_t)seq * mask_stride + (size_t)y * cols;
-          unA = xeA < cols && mrow[xeA] != 0, unB = xeB < cols && mrow[xeB] != 0;
-        } else {
-          unA = ((s_mask[wave][r][0] >> lane) & 1ull) == 0ull, unB = ((s_mask[wave][r][1] >> lane) & 1ull) == 0ull;
-        }
-        if (unA && xeA < cols) {
-          my_max = fmaxf(my_max, e1.x);
-          if (xeA >= 1 && y >= 1 && xeA < cols - 1 && y < rows - 1 && e1.x > 0.f && e1.x == mA) emit(e1.x, xeA, y);
-        }
-        if (unB && xeB < cols) {
-          my_max = fmaxf(my_max, e1.y);
-          if (xeB >= 1 && y >= 1 && xeB < cols - 1 && y < rows - 1 && e1.y > 0.f && e1.y == mB) emit(e1.y, xeB, y);
-        }
-      }
-    }
-    hxx0 = hxx1, hxx1 = hxx2, hxy0 = hxy1, hxy1 = hxy2, hyy0 = hyy1, hyy1 = hyy2;
-    e0 = e1, e1 = e2;
-  }
-  {
-    unsigned m = my_max == -INFINITY ? 0u : ordered_bits(my_max);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if (lane == 0 && m) atomicMax(&smax, m);
-  }
-  __syncthreads();
-  const int nc = min(s_ncand, kDet2Cand);
-  if (tid == 0 && nc) s_base = atomicAdd(&n_cand[segi], nc);
-  __syncthreads();
-  for (int i = tid; i < nc; i += NT) {
-    const int slot = s_base + i;
-    if (slot < seg_cap) cand_base[segi * seg_cap + slot] = s_cand[i];
-  }
-  if (tid == 0 && smax) atomicMax(&max_bits[segi], smax);
-}
 #undef LANE_LEFT
 #undef LANE_RIGHT
-
-// VIO_AMD_DETECT2=0 launches the one-pixel-per-lane kernel of rounds 3-5 instead (A/B measurements; same results)
-static bool detect_two_pixels() {
-  static const bool on = !(getenv("VIO_AMD_DETECT2") && getenv("VIO_AMD_DETECT2")[0] == '0');
-  return on;
-}
 
 struct SelectParams {
   int cap, rows, cols, max_corners;
@@ -2164,17 +1983,10 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   int rcu = launch_track_update(fe, publish, st);
   if (rcu != VIO_OK) return rcu;
   if (publish) {
-    if (detect_two_pixels()) {
-      dim3 tb(64 * kDet2Waves), tg((cols + kDet2Waves * kDet2W - 1) / (kDet2Waves * kDet2W), fe->nseg, S);
-      hipLaunchKernelGGL(detect2_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
-                         fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
-                         fe->seg_cap, fe->n_cand, fe->detect_always ? (const int *)nullptr : fe->n_forw, fe->cfg.max_corners);
-    } else {
-      dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
-      hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
-                         fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
-                         fe->seg_cap, fe->n_cand, fe->detect_always ? (const int *)nullptr : fe->n_forw, fe->cfg.max_corners);
-    }
+    dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
+    hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
+                       fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
+                       fe->seg_cap, fe->n_cand, fe->detect_always ? (const int *)nullptr : fe->n_forw, fe->cfg.max_corners);
     SelectParams SP;
     SP.cap = cap, SP.rows = rows, SP.cols = cols, SP.max_corners = fe->cfg.max_corners, SP.min_dist = (float)fe->cfg.min_dist;
     SP.fx = fe->cfg.fx, SP.fy = fe->cfg.fy, SP.cx = fe->cfg.cx, SP.cy = fe->cfg.cy;
@@ -2691,15 +2503,9 @@ int vio_good_features(const VioConfig *cfg, const uint8_t *img, const uint8_t *m
   if (hipMemset(fe->max_bits, 0, sizeof(unsigned) * fe->nseg) != hipSuccess ||
       hipMemset(fe->n_cand, 0, sizeof(int) * fe->nseg) != hipSuccess)
     return fail(VIO_ENODEV);
-  if (detect_two_pixels()) {
-    dim3 tb(64 * kDet2Waves), tg((cols + kDet2Waves * kDet2W - 1) / (kDet2Waves * kDet2W), fe->nseg, 1);
-    hipLaunchKernelGGL(detect2_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
-                       fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand, (const int *)nullptr, 0);
-  } else {
-    dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, 1);
-    hipLaunchKernelGGL(detect_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
-                       fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand, (const int *)nullptr, 0);
-  }
+  dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, 1);
+  hipLaunchKernelGGL(detect_kernel<true>, tg, tb, 0, st, fe->pyr[0], fe->ld.pyr_bytes, fe->mask, px, fe->kept_xy, fe->n_kept,
+                     fe->cap, fe->hw, c.min_dist, fe->max_bits, rows, cols, fe->cand, fe->seg_cap, fe->n_cand, (const int *)nullptr, 0);
   SelectParams SP;
   SP.cap = fe->cap, SP.rows = rows, SP.cols = cols, SP.max_corners = max_corners, SP.min_dist = (float)c.min_dist;
   SP.fx = c.fx, SP.fy = c.fy, SP.cx = c.cx, SP.cy = c.cy;
