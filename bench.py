@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (MI355X_MICROARCH.md / SURVEY §8d)
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")   # written by tools/rocpd_pmc_summary.py from the rocprofv3 --pmc passes
 
 
 def algorithmic_flops_per_solve(W, M, n_prior, iters, n_features=150):
