@@ -1175,7 +1175,7 @@ VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k
     const double h = 0.5 * dcc;
     y = y * fma(-h * y, y, 1.5);  // (v_rsq_f64 is specified to 2^29 ulp, ~2^-23 relative: one Newton step leaves ~1.5 e^2 = ~2^-45
                                   //  in every pivot, nine orders below the 1e-6 bar against the reference
-                                  //  (tests/test_backend_gpu.py::test_ill_conditioned_windows holds near-degenerate windows at
+                                  //  (tests/test_backend_gpu.py::test_step_quality_traces_on_badly_conditioned_windows holds low-parallax windows at
                                   //  the smallest mu to it); the second step cost 3 dependent operations on the pivot chain)
     const bool sel = kq == (c & 3);
     const double a = sel ? A[c >> 2] * y : 0.0;  // v: l[n] = L[n][c] for n < 9 (n == c: dcc / sqrt(dcc)), e[n - 9] = L^-1[c][n - 9] right of it
