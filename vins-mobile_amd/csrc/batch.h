@@ -291,6 +291,7 @@ VIO_HD Carved<MP, AP> carve_all(const BatchDims &d, bool lds_matrix, int nthread
   w.AspI = MatPick<AP>::get(lds_asp, aspi, asp_global);
   w.stage = app, w.nstage = lds_matrix ? (int)(o - o_mat) : 0;
   w.asp_ring = lds_matrix && !lds_asp;
+  w.asp_lds = lds_asp;
   w.aspring = w.asp_ring ? take(2 * (size_t)kAS + 4) : nullptr;
   w.gp = take(npc), w.sp = take(npc), w.dp = take(npc);
   // Aliases. While the Jacobians are evaluated the candidate pose / speed-bias and the Gauss-Newton step are dead: the

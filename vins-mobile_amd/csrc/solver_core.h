@@ -29,6 +29,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vio_math.h"
 
 // Three builds of this file:
@@ -295,6 +297,7 @@ struct WorkT {
   AP AspI;        // [P][9][18]: behind Css in LDS, or in the window's global scratch (WinView::AspG)
   ldsd aspring;   // AspI in global scratch next to an LDS pose matrix: two blocks of it in LDS, refilled by the chain wave
   bool asp_ring;  // one slot ahead of the panel waves (factor_band_regs)
+  bool asp_lds;   // AspI itself is in LDS (16 doubles of padding behind it: the zero the panel steps read through clamped addresses)
   ldsd xpose, xsb, xfeat;   // current iterate: (P+1)*7, P*9, F
   ldsd cpose, csb, cfeat;   // candidate
   ldsd ex;                  // 7
@@ -1821,6 +1824,12 @@ VIO_DEV double evaluate(const Ctx &cx, const WinView &v, WK &w, cldsd pose, clds
         }
       }
       VIO_PARFOR(q, v.P * kAS) w.AspI[q] = 0.0;
+      // (the zero the panel steps read where a tile has no coupling entry: the pad behind the LDS copy of the coupling, panel_step_static)
+      if (w.asp_ring) {
+        if (tid_ < 4) w.aspring[2 * kAS + tid_] = 0.0;
+      } else if (w.asp_lds && tid_ < 16) {
+        w.AspI[v.Pcap * kAS + tid_] = 0.0;
+      }
       if (do_prior) {
         VIO_PARFOR(b, v.prior_nb) {
           int kind = v.pr_kind[b], idx = v.pr_index[b], o = v.pr_offset[b];
@@ -2574,8 +2583,11 @@ constexpr int panel_count() { return panel_slot<NT, NPW, PW>(NT, 0); }
 // per-lane row bases (the generic form spends ~600 instructions per step on predicates and address arithmetic).
 // (ISPR: block k is the speed-bias block the prior keeps -- one step of a factorization --: its coupling has the prior's dense
 // row in global memory on top of the IMU chain's 18 columns. The common instantiation carries neither the loads nor the selects.)
-template <int NT, int NPW, int PW, bool ISPR, class WK>
-VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, int tlo, VTile (&V)[NT], int lane_) {
+// (TLO: first tile column the fill reaches, a compile-time value since round 6 -- it only takes the values 0 .. NT - 2 along the
+// chain --: every "tile >= tlo" test of the step folds, nothing branches around a tile)
+template <int NT, int NPW, int PW, bool ISPR, int TLO, class WK>
+VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, VTile (&V)[NT], int lane_) {
+  constexpr int tlo = TLO;
   const int lane = VIO_OPAQUE(lane_), li = lane & 15, kq = lane >> 4;
   double e[3] = {0.0, 0.0, 0.0}, linv[4], gr[3];
   typedef PanelMap<NT, NPW, PW> Map;
@@ -2587,9 +2599,35 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
   // The IMU chain couples s_k to the 18 pose columns from alo on: two of the five tiles. A tile outside them (and outside the
   // prior's row, ISPR) is zero except for the right-hand side column (last tile): nothing to fetch, nothing to select.
   auto touches = [&](int t) { return ISPR || (16 * t + 15 >= alo && 16 * t < alo + kAW); };  // (uniform)
+  // Round 6: a lane reads its entry of Asp_k^T tile t THROUGH ITS ADDRESS -- the coupling where the tile has one, the gradient of
+  // s_k in the right-hand side column, a zero (the pad behind the coupling's LDS copy) everywhere else -- instead of reading a
+  // clamped address and selecting on the 64-bit value afterwards: one 32-bit select per element where there were 2-3 pairs.
+  constexpr bool kLdsAsp = std::is_same<decltype(w.AspI), ldsd>::value;
+  constexpr bool kByAddress = !ISPR;
+  cldsd asp_src = nullptr, zero_src = nullptr;
+  if constexpr (kLdsAsp) {
+    if (w.asp_lds) asp_src = w.AspI + k * kAS, zero_src = w.AspI + v.Pcap * kAS;
+  }
+  if (w.asp_ring) asp_src = w.aspring + (k & 1) * kAS, zero_src = w.aspring + 2 * kAS;
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    if (!(Map::needs(t) && t >= tlo) || !touches(t)) continue;
+    if (!(Map::needs(t) && t >= tlo)) continue;
+    if (kByAddress && ((kLdsAsp && w.asp_lds) || w.asp_ring)) {
+      if (!touches(t) && t != NT - 1) continue;
+      const int j = 16 * t + li;
+      const bool inr = j >= alo && j < alo + kAW && j < n6, isr = t == NT - 1 && j == n6;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int c = kq + 4 * r;
+        const bool rowok = r < 2 || kq == 0;  // (rows kq + 4 r >= 9 only exist for r = 2, kq >= 1: zero)
+        cldsd p = zero_src;
+        p = (inr && rowok) ? asp_src + (j - alo) + c * kAW : p;
+        p = (isr && rowok) ? w.gp + (kBS * k + 6 + c) : p;
+        X[t][r] = *p;
+      }
+      continue;
+    }
+    if (!touches(t)) continue;
     const int j = 16 * t + li;
     const bool inr = j >= alo && j < alo + kAW && j < n6;
     const int ao = inr ? j - alo : 0;
@@ -2601,6 +2639,8 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
       if (ISPR) Xp[t][r] = v.Apri[c * v.jp + (j < n6 ? j : 0)];
     }
   }
+  // (E_{k+1} and L_k^-1 through clamped addresses + value selects: fetching them "by address" like the tiles above traded 220
+  // selects for as many scalar / move instructions and measured 1 % slower)
   if (k < v.W) load_op9_raw(w.Css + (k + 1) * kSS, li, kq, e);
   load_linv9_raw(w.Dss + k * kSS, w.ldinv + kSB * k, li, kq, linv);
 #pragma unroll
@@ -2615,6 +2655,7 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (I < NT - 1) a[r] = rowbase[4 * r * tri_ld(I) + 16 * J];
+          else if (4 * r >= rows_last) a[r] = 0.0;  // (no lane holds a row of this element: W = 10 without a loop pose has 3 rows here -- r = 0 only)
           else a[r] = rowbase[(kq + 4 * r < rows_last ? 4 * r * tri_ld(I) : -kq * tri_ld(I)) + 16 * J];
         }
         acc[panel_slot<NT, NPW, PW>(I, J)] = a;
@@ -2635,22 +2676,26 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
     // Asp_k^T tile t in accumulator layout: element r = A(s_k[kq + 4 r], pose index 16 t + li); column n6 (last tile) = the
     // gradient of s_k. Rows kq + 4 r >= 9 only exist for r = 2, kq >= 1.
     v4d Tt = {0.0, 0.0, 0.0, 0.0};
-    if (touches(t)) {
-      const int j = 16 * t + li;
-      const bool inr = j >= alo && j < alo + kAW && j < n6;
+    if (kByAddress && ((kLdsAsp && w.asp_lds) || w.asp_ring)) {
+      if (touches(t) || t == NT - 1) Tt[0] = X[t][0], Tt[1] = X[t][1], Tt[2] = X[t][2];
+    } else {
+      if (touches(t)) {
+        const int j = 16 * t + li;
+        const bool inr = j >= alo && j < alo + kAW && j < n6;
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
-        double x = inr ? X[t][r] : 0.0;
-        if (ISPR) x += j < n6 ? Xp[t][r] : 0.0;
-        Tt[r] = x;
+        for (int r = 0; r < 3; r++) {
+          double x = inr ? X[t][r] : 0.0;
+          if (ISPR) x += j < n6 ? Xp[t][r] : 0.0;
+          Tt[r] = x;
+        }
       }
-    }
-    if (t == NT - 1) {  // (the right-hand side column: n6 = 66 or 72 sits in the last tile)
-      const bool isr = 16 * t + li == n6;
+      if (t == NT - 1) {  // (the right-hand side column: n6 = 66 or 72 sits in the last tile)
+        const bool isr = 16 * t + li == n6;
 #pragma unroll
-      for (int r = 0; r < 3; r++) Tt[r] = isr ? gr[r] : Tt[r];
+        for (int r = 0; r < 3; r++) Tt[r] = isr ? gr[r] : Tt[r];
+      }
+      Tt[2] = kq == 0 ? Tt[2] : 0.0;
     }
-    Tt[2] = kq == 0 ? Tt[2] : 0.0;
     if (k < v.W) {
 #pragma unroll
       for (int s = 0; s < 3; s++) Tt = mfma_f64(-e[s], V[t].x[s], Tt);
@@ -2666,8 +2711,9 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
 #pragma unroll
     for (int J = 0; J <= I; J++) {
       if (Map::owns(I, J) && J >= tlo) {
+        // (rows of the last tile row past the matrix hold whatever the clamped load fetched: a row of the product only depends on
+        // the same row of the accumulator, and those rows are stored to the padding element -- no masking)
         v4d c = acc[panel_slot<NT, NPW, PW>(I, J)];
-        if (I == NT - 1) c = tile_mask_acc(c, rows_last, kq);
 #pragma unroll
         for (int s = 0; s < 3; s++) c = mfma_f64(-V[I].x[s], V[J].x[s], c);
         acc[panel_slot<NT, NPW, PW>(I, J)] = c;
@@ -2688,6 +2734,7 @@ VIO_DEV void panel_step_static(const Ctx &cx, const WinView &v, WK &w, int k, in
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           if (I < NT - 1) rowbase[4 * r * tri_ld(I) + 16 * J] = c[r];
+          else if (4 * r >= rows_last) continue;
           else {
             // (rows past the matrix: the store goes to the padding element behind row 0 of this tile row -- every row is
             // 16 (I + 1) + 1 long and its last element is never read -- instead of an exec-masked region per store)
@@ -2707,15 +2754,19 @@ VIO_DEV void panel_step_dispatch(const Ctx &cx, const WinView &v, WK &w, int k, 
   }
   if constexpr (NPW == 3) {
     const bool is_pr = __builtin_amdgcn_readfirstlane(w.sbr[2 * k + 1]) != 0;
-    if (is_pr) {
-      if (pw == 0) panel_step_static<NT, 3, 0, true>(cx, v, w, k, tlo, V, lane);
-      else if (pw == 1) panel_step_static<NT, 3, 1, true>(cx, v, w, k, tlo, V, lane);
-      else panel_step_static<NT, 3, 2, true>(cx, v, w, k, tlo, V, lane);
-    } else {
-      if (pw == 0) panel_step_static<NT, 3, 0, false>(cx, v, w, k, tlo, V, lane);
-      else if (pw == 1) panel_step_static<NT, 3, 1, false>(cx, v, w, k, tlo, V, lane);
-      else panel_step_static<NT, 3, 2, false>(cx, v, w, k, tlo, V, lane);
-    }
+    auto run = [&](auto PWc) {
+      constexpr int PW = decltype(PWc)::value;
+      if (is_pr || tlo <= 0) {  // (the prior's block reaches every column)
+        if (is_pr) panel_step_static<NT, 3, PW, true, 0>(cx, v, w, k, V, lane);
+        else panel_step_static<NT, 3, PW, false, 0>(cx, v, w, k, V, lane);
+      } else if (tlo == 1) panel_step_static<NT, 3, PW, false, 1>(cx, v, w, k, V, lane);
+      else if (tlo == 2) panel_step_static<NT, 3, PW, false, 2>(cx, v, w, k, V, lane);
+      else if (tlo == 3) panel_step_static<NT, 3, PW, false, 3>(cx, v, w, k, V, lane);
+      else panel_step_static<NT, 3, PW, false, NT - 1>(cx, v, w, k, V, lane);
+    };
+    if (pw == 0) run(std::integral_constant<int, 0>{});
+    else if (pw == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
   } else {
     panel_step_regs<NT, NPW>(cx, v, w, k, tlo, V, lane, pw);
   }
