@@ -17,6 +17,9 @@ using namespace vio;
 // variant: 1 = matrix in "LDS" (vio_window_kernel<true, true>), 2 = the same with the IMU coupling in global scratch
 // (<true, false>: the layout of windows with many landmarks), 0 = matrix in global scratch (<false, false>), -1 = what the
 // launcher would pick. Returns VIO_ECAP when the requested variant does not fit the CU's LDS.
+// how many cooperative shares the band's trailing product is dealt out to (run one after the other by the one emulated workgroup)
+extern "C" void simt_set_syrk_shares(int n) { vio::simt_syrk_shares() = n < 1 ? 1 : n; }
+
 extern "C" int simt_solve_window(const VioConfig *cfg, VioWindow *win, VioSolveStats *stats, int nthreads, int variant,
                                  int order) {
   if (nthreads != 256 && nthreads != 512) return VIO_EINVAL;

@@ -69,3 +69,18 @@ def test_device_sections_odd_shapes(W, F, loop, seed, simt):
     assert H.pose_relerr(got.pose, ref.pose) < 1e-6
     assert H.relerr(got.inv_depth, ref.inv_depth) < 1e-6
     assert got.next_prior.n == ref.next_prior.n
+
+
+@pytest.mark.parametrize("shares", [2, 4])
+@pytest.mark.parametrize("name", ["win_c3_w20", "win_c5_w30_b_prior_loop"])
+def test_band_product_shares_cover_every_tile_once(name, shares, simt):
+    """The deferred product of the band phase, App -= sum V_k V_k^T (csrc/solver_core.h, band_syrk_share), is dealt out tile by tile over
+    the waves of all workgroups of a cooperative window. The emulator has one workgroup: it runs the shares one after the other -- a tile
+    that two shares took, or none, changes the factorization and the golden comparison fails."""
+    cfg, w, d = H.load_golden_window(name)
+    simt.simt_set_syrk_shares(shares)
+    try:
+        got, stats = H.solve_with(run(simt, 512, -1, 0), cfg, w)
+    finally:
+        simt.simt_set_syrk_shares(1)
+    H.check_solution(got, stats, d, tol=1e-6, tol_prior=1e-5)

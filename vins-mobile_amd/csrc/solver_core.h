@@ -2855,6 +2855,12 @@ VIO_DEV bool factor_band_regs(const Ctx &cx, const WinView &v, WK &w) {
 //       are structurally zero) and stores it once. The tiles are dealt out heaviest first over the waves -- of ALL workgroups of
 //       a cooperative window (command COOP_SYRK: the helpers read w.VG and the matrix from the XCD's L2).
 // Reference: the reduced system's factorization, CSI/schur_complement_solver.cc:161-224 (result, not route).
+#ifdef VIO_SIMT
+inline int &simt_syrk_shares() {  // (test hook of the SIMT emulator build, tests/emul/simt_backend.cpp)
+  static int n = 1;
+  return n;
+}
+#endif
 template <class WK>
 VIO_DEV int band_tile_reach(const WinView &v, const WK &w, int t) {  // largest k whose fill reaches tile column t
   int flo = v.n6;
@@ -3007,7 +3013,13 @@ VIO_DEV bool factor_band_lds(const Ctx &cx, const WinView &v, WK &w) {
     coop_wait_helpers(cx, v);
   } else
 #endif
+#ifdef VIO_SIMT
+  // (tests: the shares of a cooperative window one after the other on the emulated workgroup -- every tile must be written exactly once)
+  for (int sh = 1; sh < simt_syrk_shares(); sh++) band_syrk_share(cx, v, w, sh, simt_syrk_shares());
+  band_syrk_share(cx, v, w, 0, simt_syrk_shares());
+#else
     band_syrk_share(cx, v, w, 0, 1);
+#endif
   VIO_SYNC();
   stamp(cx, ST_C_WAIT);
   return true;
