@@ -110,10 +110,11 @@ __device__ __forceinline__ bool potrf9_variant(ldsd D, ldsd ldinv_k, int lane) {
   return __builtin_amdgcn_ballot_w64(n < kSB && !(myinv > 0.0)) == 0;
 }
 
-enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_P9_ROWS, M_P9_ROWS_CHECK, M_V_OLD, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_COUNT };
+enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_P9_ROWS, M_P9_ROWS_CHECK, M_V_OLD, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_BAND_BESIDE_PANELS, M_COUNT };
 static const char *kNames[M_COUNT] = {"potrf9 (product: inverse in the tile border)", "potrf9 (product) + E update", "9x9 trsm (loads, 3 mfma, store)", "15 mfma, 5 accumulators x 3",
                                       "15 mfma, one accumulator", "5 tiles: acc load, 3 mfma, store", "potrf16 (16 pivots)",
-                                      "9x9 mat-vec x2 by v_readlane", "dependent ds_read round trip"};
+                                      "9x9 mat-vec x2 by v_readlane", "dependent ds_read round trip",
+                                      "potrf9 + E update beside 3 waves of panel-like LDS / matrix traffic"};
 
 template <int mode>
 __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double *gout, long long *cyc, int reps) {
@@ -127,8 +128,44 @@ __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double 
     for (int i = tid; i < 16 * 81 * 5; i += 256) T[i] = (i % 82 == 0) ? 40.0 : 0.01 * (i % 7);
     if (tid < 16) ldinv[tid] = 0.5;
     __syncthreads();
+    if (mode == M_BAND_BESIDE_PANELS && wave > 0) {
+      // the three panel waves of the window: tile loads, rank-9 updates, tile stores, for as long as the band block takes
+      double x = D[lane] * 1e-3, y = E[lane] * 1e-3;
+      for (int it = 0; it < 3; it++) {
+        v4d acc[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc[q] = tile_load_acc_raw(T + q * 16 * 81, 81, 16, li, kq);
+        VIO_SCHED_FENCE();
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+          v4d c = acc[q];
+#pragma unroll
+          for (int s3 = 0; s3 < 3; s3++) c = mfma_f64(x, y, c);
+          acc[q] = c;
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) tile_store_acc(T + q * 16 * 81, 81, 16, li, kq, acc[q]);
+      }
+    }
     if (wave == 0) {
       const long long t0 = clock64();
+      if (mode == M_BAND_BESIDE_PANELS) {
+        potrf9_inv_wave(D, E, true, ldinv, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double a[3], b[4];
+        load_op9_raw(C, li, kq, a), load_linv9_raw(D, ldinv, li, kq, b);
+        VIO_SCHED_FENCE();
+        mask_op9(li, kq, a), mask_linv9(li, kq, b);
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s3 = 0; s3 < 3; s3++) acc = mfma_f64(a[s3], b[s3], acc);
+        if (li < kSB)
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+            if (kq + 4 * r < kSB) C[(kq + 4 * r) * kSB + li] = acc[r];
+      }
       if (mode == M_V_NOE) potrf9_variant<false, true>(D, ldinv, lane);
       if (mode == M_V_NONEWTON) potrf9_variant<true, false>(D, ldinv, lane);
       if (mode == M_V_NEITHER) potrf9_variant<false, false>(D, ldinv, lane);
@@ -251,6 +288,6 @@ int main() {
   run<M_V_OLD>(dD, dout, dcyc), run<M_P9_ROWS>(dD, dout, dcyc), run<M_P9_ROWS_CHECK>(dD, dout, dcyc);
   run<M_POTRF9>(dD, dout, dcyc), run<M_POTRF9_UPD>(dD, dout, dcyc), run<M_TRSM9>(dD, dout, dcyc), run<M_MFMA_CHAIN15>(dD, dout, dcyc);
   run<M_MFMA_DEP15>(dD, dout, dcyc), run<M_TILE_RMW5>(dD, dout, dcyc), run<M_POTRF16>(dD, dout, dcyc), run<M_READLANE_MV>(dD, dout, dcyc);
-  run<M_LDS_RT>(dD, dout, dcyc);
+  run<M_LDS_RT>(dD, dout, dcyc), run<M_BAND_BESIDE_PANELS>(dD, dout, dcyc);
   return 0;
 }
