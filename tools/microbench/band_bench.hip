@@ -110,11 +110,12 @@ __device__ __forceinline__ bool potrf9_variant(ldsd D, ldsd ldinv_k, int lane) {
   return __builtin_amdgcn_ballot_w64(n < kSB && !(myinv > 0.0)) == 0;
 }
 
-enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_P9_ROWS, M_P9_ROWS_CHECK, M_V_OLD, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_BAND_BESIDE_PANELS, M_COUNT };
+enum { M_V_NOE = 100, M_V_NONEWTON, M_V_NEITHER, M_P9_ROWS, M_P9_ROWS_CHECK, M_V_OLD, M_POTRF9 = 0, M_POTRF9_UPD, M_TRSM9, M_MFMA_CHAIN15, M_MFMA_DEP15, M_TILE_RMW5, M_POTRF16, M_READLANE_MV, M_LDS_RT, M_BAND_BESIDE_PANELS, M_POTRF16_RANK1, M_COUNT };
 static const char *kNames[M_COUNT] = {"potrf9 (product: inverse in the tile border)", "potrf9 (product) + E update", "9x9 trsm (loads, 3 mfma, store)", "15 mfma, 5 accumulators x 3",
-                                      "15 mfma, one accumulator", "5 tiles: acc load, 3 mfma, store", "potrf16 (16 pivots)",
+                                      "15 mfma, one accumulator", "5 tiles: acc load, 3 mfma, store", "potrf16 (16 pivots, four per step)",
                                       "9x9 mat-vec x2 by v_readlane", "dependent ds_read round trip",
-                                      "potrf9 + E update beside 3 waves of panel-like LDS / matrix traffic"};
+                                      "potrf9 + E update beside 3 waves of panel-like LDS / matrix traffic",
+                                      "potrf16, one pivot per step (rounds 2-5)"};
 
 template <int mode>
 __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double *gout, long long *cyc, int reps) {
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void bench_kernel(const double *gD, double 
         for (int q = 0; q < 5; q++) tile_store_acc(T + q * 16 * 81, 81, 16, li, kq, acc[q]);
       }
       if (mode == M_POTRF16) potrf16_wave(T, T, 81, 16, 16, false, ldinv + 16, lane);
+      if (mode == M_POTRF16_RANK1) potrf16_wave_rank1(T, T, 81, 16, 16, false, ldinv + 16, lane);
       if (mode == M_READLANE_MV) {
         double er[kSB], lr[kSB], prev = D[lane % 9], val = E[lane % 9];
 #pragma unroll
@@ -288,6 +290,6 @@ int main() {
   run<M_V_OLD>(dD, dout, dcyc), run<M_P9_ROWS>(dD, dout, dcyc), run<M_P9_ROWS_CHECK>(dD, dout, dcyc);
   run<M_POTRF9>(dD, dout, dcyc), run<M_POTRF9_UPD>(dD, dout, dcyc), run<M_TRSM9>(dD, dout, dcyc), run<M_MFMA_CHAIN15>(dD, dout, dcyc);
   run<M_MFMA_DEP15>(dD, dout, dcyc), run<M_TILE_RMW5>(dD, dout, dcyc), run<M_POTRF16>(dD, dout, dcyc), run<M_READLANE_MV>(dD, dout, dcyc);
-  run<M_LDS_RT>(dD, dout, dcyc), run<M_BAND_BESIDE_PANELS>(dD, dout, dcyc);
+  run<M_LDS_RT>(dD, dout, dcyc), run<M_BAND_BESIDE_PANELS>(dD, dout, dcyc), run<M_POTRF16_RANK1>(dD, dout, dcyc);
   return 0;
 }

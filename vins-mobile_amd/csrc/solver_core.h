@@ -1261,8 +1261,98 @@ VIO_DEV void tile_store_acc(MP C, int ld, int rows, int li, int kq, v4d a) {
 // Diagonal tile of the pose matrix: like potrf9_inv_wave on 16 x 16. nvalid rows / columns of the tile exist, the first
 // npiv of them are pivots; rows past npiv (the carried right-hand side) are eliminated along and end up as their row of L.
 // with_update: D -= Lprev Lprev^T first (the panel tile left of D, same tile row).
+// Round 6: FOUR pivots per step. A rank-1 update used one of the four k-slots of the matrix instruction (a = b = the scaled pivot
+// row in the lanes kq == c & 3, zeros elsewhere) and every pivot paid the chain matrix instruction -> vector read -> two broadcasts
+// -> reciprocal root: ~306 cycles x 16. The rows 4 cb .. 4 cb + 3 of the running matrix are accumulator element cb of ALL lanes, i.e.
+// exactly the B operand of one k-step: with M = L44^-1, the inverse Cholesky factor of the 4 x 4 diagonal block (ten broadcasts, then
+// formed redundantly by every lane: four reciprocal roots, ~40 multiply-adds),
+//     V = M R          one matrix instruction (A operand: M in the lanes li < 4; B operand: accumulator element cb)
+//     T -= V^T V       one matrix instruction with a = b = V -- its four rows land in element 0 of the lanes kq = row: operand layout
+// eliminates four pivots; the same M applied to the rows of the inverse's accumulator gives its four rows. 4 matrix instructions per
+// four pivots instead of 8, and one broadcast / reciprocal-root round per block instead of four.
 template <class MP>
 VIO_DEV bool potrf16_wave(MP D, MP Lprev, int ld, int nvalid, int npiv, bool with_update, ldsd ldinv_k, int lane) {
+  const int n = lane & 15, kq = lane >> 4;
+  v4d A, E;
+  double l[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    const bool ok = m < nvalid && n < nvalid;
+    const int hi = m > n ? m : n, lo = m > n ? n : m;
+    A[r] = D[ok ? hi * ld + lo : 0];
+  }
+  tile_load_op_raw(Lprev, ld, nvalid, n, kq, l);
+  VIO_SCHED_FENCE();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int m = kq + 4 * r;
+    A[r] = (m < nvalid && n < nvalid) ? A[r] : 0.0;
+    E[r] = (m == n) ? 1.0 : 0.0;
+  }
+  if (with_update) {
+    tile_mask_op(nvalid, n, l);
+#pragma unroll
+    for (int s = 0; s < 4; s++) A = mfma_f64(-l[s], l[s], A);
+  }
+  double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
+  const int mi = (n < 4 && kq <= n) ? n * (n + 1) / 2 + kq : -1;  // which entry of M this lane feeds into the A operand
+#pragma unroll
+  for (int cb = 0; cb < 4; cb++) {
+    if (4 * cb < npiv) {  // (uniform)
+      // the diagonal block: element (row 4 cb + i, column 4 cb + j) is accumulator element cb of lane (n = 4 cb + j, kq = i)
+      double b[10];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) b[i * (i + 1) / 2 + j] = lane_bcast(A[cb], 16 * i + 4 * cb + j);
+      const bool p1 = 4 * cb + 1 < npiv, p2 = 4 * cb + 2 < npiv, p3 = 4 * cb + 3 < npiv;  // (pivots past npiv: their row of M is zero)
+      auto rsq1 = [](double d) {
+        double y = __builtin_amdgcn_rsq(d);
+        return y * fma(-(0.5 * d) * y, y, 1.5);  // (one Newton step: potrf9_inv_wave)
+      };
+      const double y0 = rsq1(b[0]);
+      const double l10 = b[1] * y0, l20 = b[3] * y0, l30 = b[6] * y0;
+      const double y1 = rsq1(fma(-l10, l10, b[2]));
+      const double l21 = fma(-l20, l10, b[4]) * y1, l31 = fma(-l30, l10, b[7]) * y1;
+      const double y2 = rsq1(fma(-l21, l21, fma(-l20, l20, b[5])));
+      const double l32 = fma(-l31, l21, fma(-l30, l20, b[8])) * y2;
+      const double y3 = rsq1(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, b[9]))));
+      // M = L44^-1 (lower), row i scaled by y_i
+      double M[10];
+      M[0] = y0;
+      M[1] = p1 ? -(l10 * y0) * y1 : 0.0, M[2] = p1 ? y1 : 0.0;
+      M[3] = p2 ? -fma(l21, M[1], l20 * y0) * y2 : 0.0, M[4] = p2 ? -(l21 * M[2]) * y2 : 0.0, M[5] = p2 ? y2 : 0.0;
+      M[6] = p3 ? -fma(l32, M[3], fma(l31, M[1], l30 * y0)) * y3 : 0.0, M[7] = p3 ? -fma(l32, M[4], l31 * M[2]) * y3 : 0.0;
+      M[8] = p3 ? -(l32 * M[5]) * y3 : 0.0, M[9] = p3 ? y3 : 0.0;
+      double mop = 0.0;
+#pragma unroll
+      for (int q = 0; q < 10; q++) mop = mi == q ? M[q] : mop;
+      const v4d z = {0.0, 0.0, 0.0, 0.0};
+      const v4d V = mfma_f64(mop, A[cb], z), VE = mfma_f64(mop, E[cb], z);
+      const double vv = V[0], ve = VE[0];
+      A = mfma_f64(-vv, vv, A);
+      E = mfma_f64(-vv, ve, E);
+      const int c = 4 * cb + kq;  // this lane's pivot of the block: column c of L below the diagonal, row c of L^-1 left of it
+      keep[cb] = n >= c ? vv : ve;
+      const double yn = (n & 3) == 0 ? y0 : (n & 3) == 1 ? y1 : (n & 3) == 2 ? y2 : y3;  // (1 / L_nn in every lane of column n)
+      myinv = (n >> 2) == cb ? yn : myinv;
+    }
+  }
+  if (n < nvalid) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = kq + 4 * j;
+      if (c < npiv) D[n * ld + c] = keep[j];
+    }
+    if (kq == 0 && n < npiv) ldinv_k[n] = myinv;
+  }
+  const bool bad = n < npiv && !(myinv > 0.0 && myinv < 1.7976931348623157e308);
+  return __builtin_amdgcn_ballot_w64(bad) == 0;
+}
+// (the rank-1 form of rounds 2-5: one pivot per step; tools/microbench/band_bench.hip times the two side by side)
+template <class MP>
+VIO_DEV bool potrf16_wave_rank1(MP D, MP Lprev, int ld, int nvalid, int npiv, bool with_update, ldsd ldinv_k, int lane) {
   const int n = lane & 15, kq = lane >> 4;
   v4d A, E;
   double l[4];
