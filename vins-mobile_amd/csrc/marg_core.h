@@ -171,28 +171,50 @@ VIO_DEV void potrf16_cut_wave(MP D, LP Lprev, int ld, int nvalid, bool with_upda
       A = mfma_f64(-ls, ls, A);
     }
   }
+  // (round 6: four pivots per step like potrf16_wave of solver_core.h -- M = the inverse Cholesky factor of the 4 x 4 diagonal block,
+  // V = M R and T -= V^T V one matrix instruction each; a cut pivot has y = 0: its row of M, hence its column of L, its row of L^-1
+  // and its reciprocal are zero, exactly what the rank-1 form left)
   double keep[4] = {0.0, 0.0, 0.0, 0.0}, myinv = 0.0;
-  double dcc = lane_bcast(A[0], 0);
+  const int mi = (n < 4 && kq <= n) ? n * (n + 1) / 2 + kq : -1;
+  auto rsq_cut = [](double d, double tol) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return (d > tol) ? y : 0.0;  // cut pivot (also NaN): the direction carries no information
+  };
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const double tol_c = lane_bcast(tolv, c);
-    double y = __builtin_amdgcn_rsq(dcc);
-    const double h = 0.5 * dcc;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    y = (dcc > tol_c) ? y : 0.0;  // cut pivot (also NaN): the direction carries no information
-    const bool sel = kq == (c & 3);
-    const double a = sel ? A[c >> 2] * y : 0.0;  // L[n][c]
-    const double e = sel ? E[c >> 2] * y : 0.0;  // Linv[c][n]
-    keep[c >> 2] = sel ? (n >= c ? a : e) : keep[c >> 2];
-    myinv = (n == c) ? y : myinv;
-    if (c + 1 < 16) {
-      const double lnext = lane_bcast(a, 16 * (c & 3) + c + 1);
-      const double dold = lane_bcast(A[(c + 1) >> 2], 16 * ((c + 1) & 3) + c + 1);
-      dcc = fma(-lnext, lnext, dold);
+  for (int cb = 0; cb < 4; cb++) {
+    double b[10], tol[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      tol[i] = lane_bcast(tolv, 4 * cb + i);
+#pragma unroll
+      for (int j = 0; j <= i; j++) b[i * (i + 1) / 2 + j] = lane_bcast(A[cb], 16 * i + 4 * cb + j);
     }
-    A = mfma_f64(-a, a, A);
-    E = mfma_f64(-a, e, E);
+    const double y0 = rsq_cut(b[0], tol[0]);
+    const double l10 = b[1] * y0, l20 = b[3] * y0, l30 = b[6] * y0;
+    const double y1 = rsq_cut(fma(-l10, l10, b[2]), tol[1]);
+    const double l21 = fma(-l20, l10, b[4]) * y1, l31 = fma(-l30, l10, b[7]) * y1;
+    const double y2 = rsq_cut(fma(-l21, l21, fma(-l20, l20, b[5])), tol[2]);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, b[8])) * y2;
+    const double y3 = rsq_cut(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, b[9]))), tol[3]);
+    double M[10];
+    M[0] = y0;
+    M[1] = -(l10 * y0) * y1, M[2] = y1;
+    M[3] = -fma(l21, M[1], l20 * y0) * y2, M[4] = -(l21 * M[2]) * y2, M[5] = y2;
+    M[6] = -fma(l32, M[3], fma(l31, M[1], l30 * y0)) * y3, M[7] = -fma(l32, M[4], l31 * M[2]) * y3, M[8] = -(l32 * M[5]) * y3, M[9] = y3;
+    double mop = 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; q++) mop = mi == q ? M[q] : mop;
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    const v4d V = mfma_f64(mop, A[cb], z), VE = mfma_f64(mop, E[cb], z);
+    const double vv = V[0], ve = VE[0];
+    A = mfma_f64(-vv, vv, A);
+    E = mfma_f64(-vv, ve, E);
+    keep[cb] = n >= 4 * cb + kq ? vv : ve;
+    const double yn = (n & 3) == 0 ? y0 : (n & 3) == 1 ? y1 : (n & 3) == 2 ? y2 : y3;
+    myinv = (n >> 2) == cb ? yn : myinv;
   }
   if (n < nvalid) {
 #pragma unroll

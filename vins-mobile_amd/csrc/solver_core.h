@@ -1137,6 +1137,9 @@ VIO_DEV void load_linv9(cldsd D, cldsd ldinv_k, int li, int kq, double out[4]) {
 // (E = the factored coupling block to the frame eliminated before, operand layout from LDS) -- the look-ahead of the
 // band. Stored: L in the lower triangle (with diagonal), L^-1's strict lower part TRANSPOSED in the strict upper
 // triangle, 1 / L_cc in ldinv_k. Returns false if a pivot is <= 0.
+// (Four pivots per step like potrf16_wave -- 4 + 4 + 1 -- was built for this block as well: 2 196 against 2 124 cycles alone, 2 473
+// against 2 440 with the E update, window kernel +0.5 %: with ONE matrix instruction per pivot and the next pivot's reciprocal root in
+// its shadow the rank-1 form is already at the cost of the blocked one. Not kept.)
 VIO_DEV bool potrf9_inv_wave(ldsd D, cldsd Eprev, bool with_update, ldsd ldinv_k, int lane) {
   // Round 6: ONE matrix instruction per pivot. The block only fills 9 x 9 of the 16 x 16 tile; the inverse rides in the rest of
   // the SAME tile as a symmetric border:  T = [ A  E ; E^T  * ],  E = columns 0..6 of the running inverse (rows 0..8, tile
