@@ -352,7 +352,18 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
       static_assert(kIP % RPT == 0, "whole trips");
       int vs[TB];
 #pragma unroll
-      for (int t = 0; t < TB; t++) vs[t] = I[(unsigned)(__mul24(reflect101(ipy - 1 + (lane >> 5) + RPT * t, rows), cols) + x)];
+      for (int t = 0; t < TB; t++) {
+        if constexpr (FPW == 1) {
+          // (one feature per wave: the patch origin is the same in every lane, so the reflected ROW of a trip is one of two scalars
+          // -- even / odd half of the wave -- and comes off the scalar unit: 2 vector instructions per trip instead of ~16; the
+          // border path is not rare: 58 % of the features take it at level 3, 32 % at level 2)
+          const int s_y0 = __builtin_amdgcn_readfirstlane(ipy) - 1 + RPT * t;
+          const int ro_a = reflect101(s_y0, rows) * cols, ro_b = reflect101(s_y0 + 1, rows) * cols;
+          vs[t] = I[(unsigned)(((lane >> 5) ? ro_b : ro_a) + x)];
+        } else {
+          vs[t] = I[(unsigned)(__mul24(reflect101(ipy - 1 + (lane >> 5) + RPT * t, rows), cols) + x)];
+        }
+      }
 #pragma unroll
       for (int t = 0; t < TB; t++) {
         const int ly = (lane >> 5) + RPT * t, v = vs[t];
@@ -518,8 +529,15 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
         int vs[TB];
 #pragma unroll
         for (int t = 0; t < TB; t++) {
-          const int y = reflect101(min(max(joy + (lane >> 5) + RPT * t, -rows + 1), 2 * rows - 2), rows);
-          vs[t] = J[(unsigned)(__mul24(y, cols) + x)];
+          if constexpr (FPW == 1) {  // (rows on the scalar unit, as in the template patch's border path)
+            const int s_y0 = __builtin_amdgcn_readfirstlane(joy) + RPT * t;
+            const int ro_a = reflect101(min(max(s_y0, -rows + 1), 2 * rows - 2), rows) * cols;
+            const int ro_b = reflect101(min(max(s_y0 + 1, -rows + 1), 2 * rows - 2), rows) * cols;
+            vs[t] = J[(unsigned)(((lane >> 5) ? ro_b : ro_a) + x)];
+          } else {
+            const int y = reflect101(min(max(joy + (lane >> 5) + RPT * t, -rows + 1), 2 * rows - 2), rows);
+            vs[t] = J[(unsigned)(__mul24(y, cols) + x)];
+          }
         }
 #pragma unroll
         for (int t = 0; t < TB; t++) {
