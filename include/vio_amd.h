@@ -310,6 +310,20 @@ int vio_frontend_submit_images_async(vio_frontend_t *fe, const uint8_t *gray, in
 int vio_frontend_collect(vio_frontend_t *fe, VioObs *out_obs /* [n_seq][max_corners] */,
                          int32_t *n_obs /* [n_seq] */);
 
+/* Host frame buffers registered once (camera / decoder ring buffers, the cv::Mat
+ * storage behind `_img` in FeatureTracker::readImage, feature_tracker.cpp:162):
+ * the range is page-locked in place, and read_images / submit_images(_async)
+ * whose `gray` lies inside a registered range (with stride == cols) send the
+ * frames to the device by DMA from where they are, without the gathering pass
+ * through the library's own page-locked staging. Results are the same either
+ * way. Process-wide (every context and device sees the registration);
+ * overlapping a registered range or unregistering an unknown pointer is
+ * VIO_ESTATE, pages that cannot be locked VIO_ENOMEM. Unregister (with the
+ * pointer that was registered) before the memory is freed; it waits for the
+ * device first.                                                               */
+int vio_host_register(void *ptr, size_t bytes);
+int vio_host_unregister(void *ptr);
+
 /* Resident form for throughput runs: frames already in HBM.                  */
 int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t n_frames,
                                int32_t rows, int32_t cols, int32_t stride);

@@ -59,3 +59,37 @@ def test_asynchronous_submit_gives_the_same_observations_and_reports_its_errors(
     b = TP.run(n_seq=6, n_frames=15, overlap=2, n_worlds=2, quiet=True, freq=1)
     assert b["overlap"] == 2 and abs(a["position_error_m_max"] - b["position_error_m_max"]) < 1e-6
     ref.close(), got.close()
+
+
+def test_registered_host_frames_give_the_same_observations():
+    """vio_host_register: frames inside a registered buffer go to the device by DMA from where they are (no gathering pass).
+    Bit-identical observations to the pageable route, frame by frame, with the synchronous and the asynchronous submit; the
+    registry refuses overlaps and unknown pointers; frames OUTSIDE the range still take the gathering route."""
+    import ctypes as C
+    import numpy as np
+    from helpers import abi, pkg
+    cfg = abi.default_config(max_corners=60, min_dist=25, image_rows=240, image_cols=320)
+    streams = [pkg.synth.make_image_stream(40 + q, 6, rows=240, cols=320)[0] for q in range(3)]
+    frames = np.ascontiguousarray(np.stack(streams, axis=1))              # [frame][sequence][rows][cols], ONE buffer
+    ref = pkg.frontend.FeatureTracker(cfg, n_seq=3)
+    got = pkg.frontend.FeatureTracker(cfg, n_seq=3)
+    got.register_host(frames)
+    lib = got.lib
+    assert lib.vio_host_register(C.c_void_p(frames.ctypes.data + 64), 1024) == abi.VIO_ESTATE     # overlaps
+    assert lib.vio_host_unregister(C.c_void_p(frames.ctypes.data + 64)) == abi.VIO_ESTATE         # not a registered base
+    outside = frames[0].copy()                                            # a pageable frame next to the registered ring
+    for k in range(frames.shape[0]):
+        want = ref.read_images(frames[k].copy(), True)                    # (a copy: pageable, gathered)
+        if k == 3:
+            assert not np.shares_memory(outside, frames)
+        got.submit(frames[k], True, asynchronous=bool(k & 1))             # a view into the registered buffer
+        have = got.collect()
+        for (ia, xa), (ib, xb) in zip(want, have):
+            assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    got.unregister_host(frames)
+    assert lib.vio_host_unregister(C.c_void_p(frames.ctypes.data)) == abi.VIO_ESTATE              # already gone
+    want = ref.read_images(outside, True)
+    have = got.read_images(outside, True)                                 # after unregistering: the gathering route again
+    for (ia, xa), (ib, xb) in zip(want, have):
+        assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    ref.close(), got.close()

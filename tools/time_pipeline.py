@@ -7,7 +7,7 @@ in the call order of the app (ViewController.mm:458 readImage, :688-724 processI
 rendered beforehand from textured planes filmed along synthetic trajectories (tools/replay_synthetic.py ImageWorld), so
 the observations the estimator receives are the ones the front-end publishes and IMU / images are consistent.
 
-    tools/time_pipeline.py [n_seq] [n_frames] [overlap] [freq]
+    tools/time_pipeline.py [n_seq] [n_frames] [overlap] [freq] [registered]
         overlap = 1: the front-end of camera frame k+1 is submitted before the estimator of frame k runs
                      (vio_frontend_submit_images / vio_frontend_collect), 0: strictly one call after the other,
                      2: the same with vio_frontend_submit_images_async (the gathering of the pageable frames and the queueing
@@ -33,7 +33,7 @@ abi = pkg.abi
 _dp, _ip, _u8p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
 
 
-def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
+def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1, registered=False):
     cfg = abi.default_config(max_corners=150, min_dist=20)
     W, cap = cfg.window_size, cfg.max_corners
     # (published frames stay 0.1 s apart: the camera runs freq times faster, the IMU freq x 10 samples per published frame)
@@ -44,6 +44,9 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
     # one pageable buffer per camera frame holding the image of every sequence (sequence q films world q % nw)
     frames = [np.ascontiguousarray(np.stack([rendered[q % nw][c] for q in range(n_seq)])) for c in range(n_cam)]
     fe = pkg.frontend.FeatureTracker(cfg, n_seq=n_seq)
+    if registered:
+        for f in frames:
+            fe.register_host(f)
     est = pkg.estimator.Estimator(cfg, worlds[0].tic, worlds[0].ric, n_seq=n_seq)
     lib = est.lib
     have_async = overlap and hasattr(lib, "vio_frontend_submit_images")
@@ -126,6 +129,9 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
     for q in range(min(n_seq, 2 * nw)):
         win = est.window(q)
         errs.append(float(np.linalg.norm(win["Ps"][W] - worlds[q % nw].truth(n_cam - 1)[0])))
+    if registered:
+        for f in frames:
+            fe.unregister_host(f)
     fe.close(), est.close()
     steady = slice(W + 3, n_frames)
     per_frame = float(np.mean(t_frame[steady]))
@@ -134,6 +140,7 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
            "camera_frames_per_s": n_seq * freq / per_frame, "solves_per_s": n_seq / per_frame,
            "ms_frontend_calls": float(np.mean(t_fe[steady])) * 1e3,
            "ms_estimator_calls": float(np.mean(t_est[steady])) * 1e3, "overlap": int(overlap) if have_async else 0,
+           "registered_host_frames": bool(registered),
            "mean_published_features": float(np.mean(tracked[steady])), "position_error_m_max": max(errs),
            "ms_every_published_frame": [round(t * 1e3, 2) for t in t_frame]}
     if not quiet:
@@ -144,4 +151,4 @@ def run(n_seq=256, n_frames=22, overlap=True, n_worlds=4, quiet=False, freq=1):
 if __name__ == "__main__":
     a = sys.argv[1:]
     run(int(a[0]) if a else 256, int(a[1]) if len(a) > 1 else 22, int(a[2]) if len(a) > 2 else 1,
-        freq=int(a[3]) if len(a) > 3 else 1)
+        freq=int(a[3]) if len(a) > 3 else 1, registered=bool(int(a[4])) if len(a) > 4 else False)

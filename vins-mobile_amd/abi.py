@@ -471,6 +471,8 @@ def load_product():
     lib.vio_frontend_submit_images.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_submit_images_async.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_collect.argtypes = [vp, C.POINTER(VioObs), _ip]
+    lib.vio_host_register.argtypes = [vp, C.c_size_t]
+    lib.vio_host_unregister.argtypes = [vp]
     lib.vio_frontend_upload_frames.argtypes = [vp, u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.vio_frontend_step_resident.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.vio_frontend_sync.argtypes = [vp]

@@ -115,6 +115,10 @@ struct LkParams {
   float epsilon_sq_f;  // screen of the convergence test: a float sum of squares above it cannot pass the double compare
   double epsilon_sq;
   float min_eig;
+  // level 0 of either pyramid outside its pyramid buffer (resident frames are tracked where they lie: `forw_img = _img` is a
+  // reference to the caller's pixels in the reference too, feature_tracker.cpp:169); null: level 0 is the pyramid's own copy
+  const uint8_t *prev0, *next0;
+  size_t stride0;  // bytes between the sequences' frames there
 };
 
 // Wave-wide integer sum on the DPP network (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips. The total lands
@@ -298,6 +302,10 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
   for (int level = max_level; level >= 0; level--) {
     const int rows = P.ld.rows[level], cols = P.ld.cols[level];
     const uint8_t *I = pp + P.ld.off[level], *J = np + P.ld.off[level];
+    if (level == 0) {  // (scalar selects)
+      if (P.prev0) I = P.prev0 + (size_t)seq * P.stride0;
+      if (P.next0) J = P.next0 + (size_t)seq * P.stride0;
+    }
     const float scale = __int_as_float((127 - level) << 23);  // (float)(1. / (1 << level)) = 2^-level, without the double division
     float px = ptx * scale, py = pty * scale;
     float qx, qy;
@@ -1379,7 +1387,9 @@ __device__ __forceinline__ float sqrt_rn_normal(float x) {
   const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
   float y = em <= 0.f ? rm : r;
   y = ep > 0.f ? rp : y;
-  return (x == 0.f || __builtin_isinf(x)) ? x : y;
+  // x == 0 needs no case of its own: r = 0, rm is a NaN pattern (0 - 1 ulp), so em is NaN and `em <= 0` is false; rp is the smallest
+  // denormal, ep = fma(-rp, 0, 0) = 0 and `ep > 0` is false: y = r = 0. (Infinity cannot occur: the products are bounded by 255^2.)
+  return y;
 }
 
 template <bool IMG_MASK>
@@ -1762,6 +1772,9 @@ struct vio_frontend {
   uint8_t *pyr[2] = {nullptr, nullptr};  // [n_seq][pyr_bytes]; cur = pyr[cur_idx], forw = pyr[1 - cur_idx]
   int cur_idx = 0;
   bool have_img = false;
+  // level 0 of pyr[k] when it is NOT the pyramid's own copy: the frame inside the resident ring (vio_frontend_upload_frames) the
+  // pyramid was built from -- the ring belongs to the context and outlives the two steps that read the frame
+  const uint8_t *lvl0[2] = {nullptr, nullptr};
   uint8_t *mask = nullptr;      // [rows*cols], only the stand-alone vio_good_features uses a mask image
   unsigned *max_bits = nullptr;
   unsigned long long *cand = nullptr;
@@ -1942,7 +1955,9 @@ int launch_track_update(vio_frontend *fe, int publish, hipStream_t st) {
   return VIO_OK;
 }
 
-int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on device */, int publish, hipStream_t st) {
+// keep_frames: d_frames stays valid and unchanged until the frame after the next one has been tracked (the context's resident ring):
+// level 0 is then read where it lies instead of being copied into the pyramid.
+int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on device */, int publish, hipStream_t st, bool keep_frames = false) {
   const int S = fe->n_seq, rows = fe->cfg.image_rows, cols = fe->cfg.image_cols, cap = fe->cap;
   const size_t img_bytes = (size_t)rows * cols;
   // forw_img = _img : level 0 of the forw pyramid
@@ -1952,6 +1967,8 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   const bool fused0 = fe->ld.levels >= 2 && cols % 4 == 0 && fe->ld.cols[1] % 4 == 0 && cols >= 8 && fe->ld.pyr_bytes % 4 == 0 &&
                       img_bytes % 4 == 0 && (uintptr_t)d_frames % 4 == 0 && (uintptr_t)forw % 4 == 0 && fe->ld.off[1] % 4 == 0 &&
                       !(getenv("VIO_AMD_PYR_UNFUSED") && getenv("VIO_AMD_PYR_UNFUSED")[0] == '1');
+  const bool alias0 = keep_frames && fused0 && !(getenv("VIO_AMD_COPY_LEVEL0") && getenv("VIO_AMD_COPY_LEVEL0")[0] == '1');
+  fe->lvl0[fidx] = alias0 ? d_frames : nullptr;
   if (!fused0) {
     const int vec_ok = img_bytes % 16 == 0 && fe->ld.pyr_bytes % 16 == 0 && (uintptr_t)d_frames % 16 == 0 &&
                        (uintptr_t)forw % 16 == 0;
@@ -1965,7 +1982,11 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     const int sc = fe->ld.cols[l - 1], dc = fe->ld.cols[l];
     if (l == 1 && fused0) {
       dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[1] + kPd4H - 1) / kPd4H, S);
-      hipLaunchKernelGGL(pyr_down4_kernel<true>, grd, blk, 0, st, d_frames, img_bytes, dp, fe->ld.pyr_bytes, rows, cols, fe->ld.rows[1], dc, forw);
+      if (alias0)
+        hipLaunchKernelGGL(pyr_down4_kernel<false>, grd, blk, 0, st, d_frames, img_bytes, dp, fe->ld.pyr_bytes, rows, cols, fe->ld.rows[1], dc,
+                           (uint8_t *)nullptr);
+      else
+        hipLaunchKernelGGL(pyr_down4_kernel<true>, grd, blk, 0, st, d_frames, img_bytes, dp, fe->ld.pyr_bytes, rows, cols, fe->ld.rows[1], dc, forw);
       continue;
     }
     // whole-dword rows on both sides (and at least two staged dwords of image): 4 pixels per load and per store
@@ -1988,6 +2009,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     P.max_count = std::min(std::max(fe->cfg.lk_max_iters, 0), 100);
     double eps = std::min(std::max(fe->cfg.lk_eps, 0.), 10.);
     P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)fe->cfg.lk_min_eig;
+    P.prev0 = fe->lvl0[fe->cur_idx], P.next0 = fe->lvl0[fidx], P.stride0 = img_bytes;
     dim3 grd((cap + 4 * kLkFpw - 1) / (4 * kLkFpw), S);
     // (the counting variant is a kernel of its own: STATS = [2 * levels] iterations run / (feature, level) visits of this launch,
     // vio_frontend_lk_iterations; the product kernel sits at 80 registers for six waves per SIMD and has none to spare)
@@ -2002,7 +2024,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
   if (rcu != VIO_OK) return rcu;
   if (publish) {
     dim3 tb(256), tg((cols + kDetWaves * kDetW - 1) / (kDetWaves * kDetW), fe->nseg, S);
-    hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, forw, fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
+    hipLaunchKernelGGL(detect_kernel<false>, tg, tb, 0, st, alias0 ? d_frames : forw, alias0 ? img_bytes : fe->ld.pyr_bytes, (const uint8_t *)nullptr, (size_t)0,
                        fe->kept_xy, fe->n_kept, cap, fe->hw, fe->cfg.min_dist, fe->max_bits, rows, cols, fe->cand,
                        fe->seg_cap, fe->n_cand, fe->detect_always ? (const int *)nullptr : fe->n_forw, fe->cfg.max_corners);
     SelectParams SP;
@@ -2143,6 +2165,14 @@ int vio_frontend_upload_frames(vio_frontend_t *fe, const uint8_t *gray, int32_t 
   if (rows != fe->cfg.image_rows || cols != fe->cfg.image_cols || stride < cols) return VIO_EINVAL;
   VIO_ON_DEVICE_OF(fe);
   const size_t px = (size_t)rows * cols, total = (size_t)n_frames * fe->n_seq;
+  if (fe->pending) return VIO_ESTATE;
+  // the current image may still be read in place from the ring that is about to go: it moves into its pyramid first
+  HIP_OK(hipDeviceSynchronize());
+  for (int k = 0; k < 2; k++) {
+    if (fe->lvl0[k])
+      HIP_OK(hipMemcpy2D(fe->pyr[k], fe->ld.pyr_bytes, fe->lvl0[k], px, px, fe->n_seq, hipMemcpyDeviceToDevice));
+    fe->lvl0[k] = nullptr;
+  }
   if (fe->frames) (void)hipFree(fe->frames), fe->frames = nullptr;
   if (dev_alloc(&fe->frames, total * px) != VIO_OK) return VIO_ENOMEM;
   HIP_OK(hipMemcpy2D(fe->frames, cols, gray, stride, cols, total * rows, hipMemcpyHostToDevice));
@@ -2168,7 +2198,7 @@ int vio_frontend_step_resident(vio_frontend_t *fe, int32_t frame_index, int32_t 
   auto &ev = fe->events[fe->events_used++];
   HIP_OK(hipEventRecord(ev.first, st));
   const size_t px = (size_t)fe->cfg.image_rows * fe->cfg.image_cols;
-  int rc = fe_step(fe, fe->frames + (size_t)frame_index * fe->n_seq * px, publish, st);
+  int rc = fe_step(fe, fe->frames + (size_t)frame_index * fe->n_seq * px, publish, st, true);
   if (rc != VIO_OK) return rc;
   HIP_OK(hipEventRecord(ev.second, st));
   return VIO_OK;
@@ -2197,6 +2227,61 @@ int vio_frontend_kernel_ms(vio_frontend_t *fe, double *ms_avg, int32_t *launches
   return VIO_OK;
 }
 
+// Host buffers the caller registered (vio_host_register): page-locked in place, so their frames go to the device by DMA straight
+// from where the camera / decoder wrote them -- no gathering pass over them on the host pool.
+namespace {
+struct HostRange {
+  const uint8_t *p;
+  size_t n;
+};
+std::mutex g_host_reg_m;
+std::vector<HostRange> g_host_reg;
+bool host_range_registered(const void *ptr, size_t bytes) {
+  const uint8_t *b = static_cast<const uint8_t *>(ptr);
+  std::lock_guard<std::mutex> lk(g_host_reg_m);
+  for (const HostRange &r : g_host_reg)
+    if (b >= r.p && b + bytes <= r.p + r.n) return true;
+  return false;
+}
+}  // namespace
+
+int vio_host_register(void *ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return VIO_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || !vio::single_hip_runtime()) return VIO_ENODEV;
+  {
+    std::lock_guard<std::mutex> lk(g_host_reg_m);
+    const uint8_t *b = static_cast<const uint8_t *>(ptr);
+    for (const HostRange &r : g_host_reg)
+      if (b < r.p + r.n && r.p < b + bytes) return VIO_ESTATE;  // overlaps a registered range: unregister that one first
+  }
+  if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return VIO_ENOMEM;  // (the pages could not be locked: RLIMIT_MEMLOCK, or not the caller's memory)
+  }
+  std::lock_guard<std::mutex> lk(g_host_reg_m);
+  g_host_reg.push_back({static_cast<const uint8_t *>(ptr), bytes});
+  return VIO_OK;
+}
+
+int vio_host_unregister(void *ptr) {
+  if (!ptr) return VIO_EINVAL;
+  {
+    std::lock_guard<std::mutex> lk(g_host_reg_m);
+    size_t i = 0;
+    for (; i < g_host_reg.size(); i++)
+      if (g_host_reg[i].p == static_cast<const uint8_t *>(ptr)) break;
+    if (i == g_host_reg.size()) return VIO_ESTATE;
+    g_host_reg.erase(g_host_reg.begin() + (long)i);
+  }
+  // (a transfer still queued from this range must not lose its pages under it)
+  if (hipDeviceSynchronize() != hipSuccess || hipHostUnregister(ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return VIO_ENODEV;
+  }
+  return VIO_OK;
+}
+
 // The two halves of read_images. submit: gathers the caller's (pageable) frames into page-locked memory, queues their
 // transfer, every kernel of the frame and the copy of the published observations on the context's stream and returns
 // without waiting for the device; collect: waits and hands the observations over. A caller that submits frame k+1 before
@@ -2216,8 +2301,11 @@ static int submit_body(vio_frontend_t *fe, const uint8_t *gray, int32_t rows, in
   // The caller's frames are pageable memory: a direct copy bounces through the runtime's staging at ~5 GB/s. They are
   // gathered into page-locked memory by the host pool (one sequence per task, rows packed) in a few chunks, each chunk
   // going to the device as soon as it is complete, so the DMA of one overlaps the gathering of the next.
-  if (!fe->p_frames && hipHostMalloc((void **)&fe->p_frames, S * px, hipHostMallocDefault) != hipSuccess) return VIO_ENOMEM;
-  {
+  if (stride == cols && host_range_registered(gray, S * px)) {
+    // frames in a buffer the caller registered: one DMA from where they are
+    HIP_OK(hipMemcpyAsync(fe->d_stage, gray, S * px, hipMemcpyHostToDevice, st));
+  } else {
+    if (!fe->p_frames && hipHostMalloc((void **)&fe->p_frames, S * px, hipHostMallocDefault) != hipSuccess) return VIO_ENOMEM;
     const size_t n_chunks = S >= 32 ? 8 : 1, per = (S + n_chunks - 1) / n_chunks;
     for (size_t c0 = 0; c0 < S; c0 += per) {
       const size_t c1 = std::min(S, c0 + per);
@@ -2487,6 +2575,7 @@ int vio_klt_track(const VioConfig *cfg, const uint8_t *prev, const uint8_t *next
   P.ld = fe->ld, P.cap = fe->cap, P.max_count = std::min(std::max(c.lk_max_iters, 0), 100);
   double eps = std::min(std::max(c.lk_eps, 0.), 10.);
   P.epsilon_sq = eps * eps, P.epsilon_sq_f = lk_eps_screen(eps * eps), P.min_eig = (float)c.lk_min_eig;
+  P.prev0 = P.next0 = nullptr, P.stride0 = 0;
   hipLaunchKernelGGL((lk_track_kernel<kLkFpw, false>), dim3((fe->cap + 4 * kLkFpw - 1) / (4 * kLkFpw), 1), dim3(256), 0, st, fe->pyr[0], fe->pyr[1], P, fe->n_pts,
                      fe->cur_pts, fe->forw_pts, fe->lk_status, fe->lk_err, (unsigned long long *)nullptr);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail(VIO_ENODEV);

@@ -72,6 +72,14 @@ class FeatureTracker:
             out.append((o["id"].copy(), np.stack([o["x"], o["y"], o["z"]], axis=1)))
         return out
 
+    def register_host(self, array):
+        """vio_host_register on a numpy buffer of frames: read_images / submit of frames inside it skip the gathering pass."""
+        assert array.flags["C_CONTIGUOUS"]
+        self._check(self.lib.vio_host_register(C.c_void_p(array.ctypes.data), array.nbytes), "host_register")
+
+    def unregister_host(self, array):
+        self._check(self.lib.vio_host_unregister(C.c_void_p(array.ctypes.data)), "host_unregister")
+
     def submit(self, frames, publish, asynchronous=False):
         """vio_frontend_submit_images (asynchronous: ..._async, the submit's host work on the context's own thread; the frame
         buffer is kept alive here until collect)."""
