@@ -1829,72 +1829,112 @@ constexpr int kPd4H = 16, kPd4Dw = (2 * kPdW + 8) / 4;  // 34 dwords per staged 
 // COPY: the source is the caller's frame (forw_img = _img, feature_tracker.cpp:169): the workgroup also writes the core of
 // its staged patch to level 0 of the pyramid, so the frame is read ONCE for the copy and for level 1 (a separate copy kernel
 // plus the level-1 kernel read it twice and the copy wrote what the level-1 kernel read again).
+// A workgroup walks kPd4T tiles down its column of the image: the loads of the NEXT tile's patch are issued (into registers) before
+// the barriers and the arithmetic of this one, so a workgroup always has a patch in flight -- with one tile per workgroup the load
+// phase was a third of a workgroup's life and the kernel ran at a third of the memory system's rate (2.2 TB/s on level 1).
+#ifndef VIO_PD4T
+#define VIO_PD4T 3
+#endif
+constexpr int kPd4T = VIO_PD4T;
 template <bool COPY>
 __global__ __launch_bounds__(256) void pyr_down4_kernel(const uint8_t *src_base, size_t src_stride, uint8_t *dst_base, size_t seq_stride,
                                                         int srows, int scols, int drows, int dcols, uint8_t *copy_base) {
   constexpr int SH = 2 * kPd4H + 4;
+  constexpr int NE = (SH * kPd4Dw + 255) / 256;  // staged dwords per work-item: 5 (the last one only for some)
   __shared__ uint32_t raw[SH][kPd4Dw + 1];
   __shared__ uint32_t hsum[SH / 2][kPdW + 1];
   const uint8_t *src = src_base + (size_t)blockIdx.z * src_stride;
   uint8_t *dst = dst_base + (size_t)blockIdx.z * seq_stride;
-  const int ox = blockIdx.x * kPdW, oy = blockIdx.y * kPd4H;
+  const int ox = blockIdx.x * kPdW;
   const int tid = threadIdx.x;
   const int ndw = scols >> 2, dw0 = (2 * ox - 4) >> 2;  // dwords per source row; dword index of the patch's first column
-  for (int e = tid; e < SH * kPd4Dw; e += 256) {
-    const int ly = e / kPd4Dw, lx = e - ly * kPd4Dw;
-    const int y = reflect101(min(2 * oy + ly - 2, 2 * srows - 2), srows);
-    const int d = min(max(dw0 + lx, 0), ndw - 1);
-    const uint32_t v = reinterpret_cast<const uint32_t *>(src + (size_t)y * scols)[d];
-    raw[ly][lx] = v;
-    if (COPY) {  // core of the patch: rows 2 oy .. 2 oy + 2 kPd4H - 1, columns 2 ox .. 2 ox + 2 kPdW - 1 (staged dwords 1 .. 32)
-      const int yy = 2 * oy + ly - 2, dd = dw0 + lx;
-      if (ly >= 2 && ly < SH - 2 && lx >= 1 && lx <= (2 * kPdW) / 4 && yy < srows && dd < ndw)
-        reinterpret_cast<uint32_t *>(copy_base + (size_t)blockIdx.z * seq_stride + (size_t)yy * scols)[dd] = v;
-    }
-  }
-  __syncthreads();
-  // columns -2, -1 (left-most tile) and scols, scols + 1 (the tile that holds them): BORDER_REFLECT_101
-  if (tid < SH) {
-    if (ox == 0) {  // dword 0 = columns -4 .. -1, dword 1 = columns 0 .. 3
-      const uint32_t d1 = raw[tid][1];
-      raw[tid][0] = ((d1 >> 16) & 0xffu) << 16 | ((d1 >> 8) & 0xffu) << 24;  // col -2 <- col 2, col -1 <- col 1
-    }
-    const int lr = ndw - dw0;  // staged dword that starts at column scols
-    if (lr >= 1 && lr < kPd4Dw) {
-      const uint32_t dl = raw[tid][lr - 1];  // columns scols - 4 .. scols - 1
-      raw[tid][lr] = ((dl >> 16) & 0xffu) | ((dl >> 8) & 0xffu) << 8;  // col scols <- col scols - 2, col scols + 1 <- col scols - 3
-    }
-  }
-  __syncthreads();
-  // horizontal pass, two source rows per item: output column ox + lx reads columns 2 lx - 2 .. 2 lx + 2 of the tile = staged
-  // bytes 2 lx + 2 .. 2 lx + 6: four of them cut out of a dword pair with one funnel shift and weighted by ONE byte dot product
-  // (1 4 6 4), the fifth is its accumulator. The sums (<= 16 * 255) of rows 2 p and 2 p + 1 share a dword, so that the vertical
-  // pass below is two 16-bit dot products per output.
-  for (int e = tid; e < (SH / 2) * kPdW; e += 256) {
-    const int p = e / kPdW, lx = e - p * kPdW;
-    const int b = 2 * lx + 2, dwi = b >> 2, sh = (b & 3) * 8;
-    auto hrow = [&](int ly) {
-      const uint32_t lo = raw[ly][dwi], hi = raw[ly][dwi + 1];
-      return __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(hi, lo, sh), 0x04060401u, __builtin_amdgcn_ubfe(hi, sh, 8), false);
-    };
-    hsum[p][lx] = hrow(2 * p) | hrow(2 * p + 1) << 16;
-  }
-  __syncthreads();
-  {
-    const int ly = tid >> 4, lx = (tid & 15) * 4;
-    const int x = ox + lx, y = oy + ly;
-    if (x < dcols && y < drows) {
-      uint32_t out = 0;
-      const lk_us2 w14 = {1, 4}, w64 = {6, 4};
+  // this work-item's elements of a patch: the same (row, dword) in every tile
+  int e_ly[NE], e_d[NE];
+  bool e_ok[NE];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {  // source rows 2 ly .. 2 ly + 4 = pairs ly, ly + 1 and the low half of pair ly + 2
-        lk_us2 p0, p1;
-        __builtin_memcpy(&p0, &hsum[ly][lx + i], 4), __builtin_memcpy(&p1, &hsum[ly + 1][lx + i], 4);
-        const uint32_t v = __builtin_amdgcn_udot2(p0, w14, __builtin_amdgcn_udot2(p1, w64, hsum[ly + 2][lx + i] & 0xffffu, false), false);
-        out |= ((v + 128) >> 8) << (8 * i);
-      }
-      *reinterpret_cast<uint32_t *>(dst + (size_t)y * dcols + x) = out;  // (dcols % 4 == 0: x + 3 < dcols)
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + 256 * i;
+    e_ok[i] = e < SH * kPd4Dw;
+    const int ec = e_ok[i] ? e : 0;
+    e_ly[i] = ec / kPd4Dw;
+    e_d[i] = min(max(dw0 + ec - e_ly[i] * kPd4Dw, 0), ndw - 1);
+  }
+  const int tile0 = blockIdx.y * kPd4T;
+  auto fetch = [&](int oy, uint32_t (&v)[NE]) {
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int y = reflect101(min(2 * oy + e_ly[i] - 2, 2 * srows - 2), srows);
+      v[i] = reinterpret_cast<const uint32_t *>(src + (size_t)y * scols)[e_d[i]];
     }
+  };
+  uint32_t cur[NE], nxt[NE];
+  fetch(tile0 * kPd4H, cur);
+#pragma unroll 1
+  for (int t = 0; t < kPd4T; t++) {
+    const int oy = (tile0 + t) * kPd4H;
+    if (oy >= drows) break;  // (uniform)
+    const bool more = t + 1 < kPd4T && oy + kPd4H < drows;
+    if (more) fetch(oy + kPd4H, nxt);
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      if (!e_ok[i]) continue;
+      const int ly = e_ly[i], lx = tid + 256 * i - ly * kPd4Dw;
+      raw[ly][lx] = cur[i];
+      if (COPY) {  // core of the patch: rows 2 oy .. 2 oy + 2 kPd4H - 1, columns 2 ox .. 2 ox + 2 kPdW - 1 (staged dwords 1 .. 32)
+        const int yy = 2 * oy + ly - 2, dd = dw0 + lx;
+        if (ly >= 2 && ly < SH - 2 && lx >= 1 && lx <= (2 * kPdW) / 4 && yy < srows && dd < ndw)
+          reinterpret_cast<uint32_t *>(copy_base + (size_t)blockIdx.z * seq_stride + (size_t)yy * scols)[dd] = cur[i];
+      }
+    }
+    __syncthreads();
+    // columns -2, -1 (left-most tile) and scols, scols + 1 (the tile that holds them): BORDER_REFLECT_101
+    if (tid < SH) {
+      if (ox == 0) {  // dword 0 = columns -4 .. -1, dword 1 = columns 0 .. 3
+        const uint32_t d1 = raw[tid][1];
+        raw[tid][0] = ((d1 >> 16) & 0xffu) << 16 | ((d1 >> 8) & 0xffu) << 24;  // col -2 <- col 2, col -1 <- col 1
+      }
+      const int lr = ndw - dw0;  // staged dword that starts at column scols
+      if (lr >= 1 && lr < kPd4Dw) {
+        const uint32_t dl = raw[tid][lr - 1];  // columns scols - 4 .. scols - 1
+        raw[tid][lr] = ((dl >> 16) & 0xffu) | ((dl >> 8) & 0xffu) << 8;  // col scols <- col scols - 2, col scols + 1 <- col scols - 3
+      }
+    }
+    __syncthreads();
+    // horizontal pass, two source rows per item: output column ox + lx reads columns 2 lx - 2 .. 2 lx + 2 of the tile = staged
+    // bytes 2 lx + 2 .. 2 lx + 6: four of them cut out of a dword pair with one funnel shift and weighted by ONE byte dot product
+    // (1 4 6 4), the fifth is its accumulator. The sums (<= 16 * 255) of rows 2 p and 2 p + 1 share a dword, so that the vertical
+    // pass below is two 16-bit dot products per output.
+    for (int e = tid; e < (SH / 2) * kPdW; e += 256) {
+      const int p = e / kPdW, lx = e - p * kPdW;
+      const int b = 2 * lx + 2, dwi = b >> 2, sh = (b & 3) * 8;
+      auto hrow = [&](int ly) {
+        const uint32_t lo = raw[ly][dwi], hi = raw[ly][dwi + 1];
+        return __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(hi, lo, sh), 0x04060401u, __builtin_amdgcn_ubfe(hi, sh, 8), false);
+      };
+      hsum[p][lx] = hrow(2 * p) | hrow(2 * p + 1) << 16;
+    }
+    __syncthreads();
+    {
+      const int ly = tid >> 4, lx = (tid & 15) * 4;
+      const int x = ox + lx, y = oy + ly;
+      if (x < dcols && y < drows) {
+        uint32_t out = 0;
+        const lk_us2 w14 = {1, 4}, w64 = {6, 4};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {  // source rows 2 ly .. 2 ly + 4 = pairs ly, ly + 1 and the low half of pair ly + 2
+          lk_us2 p0, p1;
+          __builtin_memcpy(&p0, &hsum[ly][lx + i], 4), __builtin_memcpy(&p1, &hsum[ly + 1][lx + i], 4);
+          const uint32_t v = __builtin_amdgcn_udot2(p0, w14, __builtin_amdgcn_udot2(p1, w64, hsum[ly + 2][lx + i] & 0xffffu, false), false);
+          out |= ((v + 128) >> 8) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)y * dcols + x) = out;  // (dcols % 4 == 0: x + 3 < dcols)
+      }
+    }
+    if (!more) break;
+    // (the next tile's patch overwrites `raw` behind this tile's horizontal pass, which the barrier above closed; `hsum` is rewritten
+    // behind the next tile's two barriers)
+#pragma unroll
+    for (int i = 0; i < NE; i++) cur[i] = nxt[i];
   }
 }
 
@@ -1981,7 +2021,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     uint8_t *dp = forw + fe->ld.off[l];
     const int sc = fe->ld.cols[l - 1], dc = fe->ld.cols[l];
     if (l == 1 && fused0) {
-      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[1] + kPd4H - 1) / kPd4H, S);
+      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[1] + kPd4H * kPd4T - 1) / (kPd4H * kPd4T), S);
       if (alias0)
         hipLaunchKernelGGL(pyr_down4_kernel<false>, grd, blk, 0, st, d_frames, img_bytes, dp, fe->ld.pyr_bytes, rows, cols, fe->ld.rows[1], dc,
                            (uint8_t *)nullptr);
@@ -1992,7 +2032,7 @@ int fe_step(vio_frontend *fe, const uint8_t *d_frames /* [n_seq][rows*cols] on d
     // whole-dword rows on both sides (and at least two staged dwords of image): 4 pixels per load and per store
     const bool dwords = sc % 4 == 0 && dc % 4 == 0 && sc >= 8 && fe->ld.pyr_bytes % 4 == 0 && (uintptr_t)sp % 4 == 0 && (uintptr_t)dp % 4 == 0;
     if (dwords) {
-      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPd4H - 1) / kPd4H, S);
+      dim3 blk(256), grd((dc + kPdW - 1) / kPdW, (fe->ld.rows[l] + kPd4H * kPd4T - 1) / (kPd4H * kPd4T), S);
       hipLaunchKernelGGL(pyr_down4_kernel<false>, grd, blk, 0, st, sp, fe->ld.pyr_bytes, dp, fe->ld.pyr_bytes, fe->ld.rows[l - 1], sc, fe->ld.rows[l], dc,
                          (uint8_t *)nullptr);
     } else {
