@@ -1582,6 +1582,39 @@ VIO_DEV void build_gram_pieces(const Ctx &cx, const WinView &v, WK &w) {
     v.gstart[c] = sacc;
   }
   VIO_SYNC();
+  // Balance: the waves take the pieces of a chunk round-robin and meet at a barrier, so a chunk's Gram phase lasts as long as its
+  // busiest wave -- in slot order one wave regularly drew the long pieces (wave 0: 242 k against 188 k cycles of matrix instructions
+  // per solve). The pieces of every chunk are put in descending order of their length and dealt out in a snake (rounds of nw pieces:
+  // wave 0 .. nw - 1, then nw - 1 .. 0): longest-first, the classic greedy for equal finishing times. Once per solve, in LDS.
+  {
+    int total = 0;
+    for (int c = 0; c <= nchunks; c++) total += cc[c];
+    ldsi pd = cc + nchunks + 2, pc = pd + total;  // descriptors and chunk of every piece (the staging area has room for thousands)
+    if ((int)(pc - reinterpret_cast<ldsi>(w.stage)) + total <= 2 * w.nstage) {
+      VIO_PARFOR(i, total) {
+        pd[i] = v.gpiece[i];
+        int c = 0, lo = 0;
+        while (c < nchunks && lo + cc[c + 1] <= i) lo += cc[c + 1], c++;
+        pc[i] = c | (lo << 8);
+      }
+      VIO_SYNC();
+      const int nw = (int)cx.nt >> 6;
+      VIO_PARFOR(i, total) {
+        const int c = pc[i] & 255, lo = pc[i] >> 8, cnt = cc[c + 1];
+        const int len = (pd[i] >> 10) & 31;
+        int rank = 0;
+        for (int q = lo; q < lo + cnt; q++) {
+          const int lq = (pd[q] >> 10) & 31;
+          rank += (lq > len || (lq == len && q < i)) ? 1 : 0;
+        }
+        const int g = rank / nw, k = rank - g * nw;
+        const bool whole = (g + 1) * nw <= cnt;  // (the last, partial round keeps its order: its positions must stay below cnt)
+        const int pos = g * nw + ((whole && (g & 1)) ? nw - 1 - k : k);
+        v.gpiece[lo + pos] = pd[i];
+      }
+      VIO_SYNC();
+    }
+  }
 }
 
 // Projection factors with Jacobians. The (not yet assembled) matrix buffer is used as a staging area: every factor
@@ -1623,6 +1656,16 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
   for (int c0 = share * CH; c0 < v.nslots; c0 += nshare * CH) {
     stamp(cx, ST_P_ZERO);
     const int nsl = v.nslots - c0 < CH ? v.nslots - c0 : CH;
+    // this chunk's Gram pieces: the descriptors of this wave's first round (piece p_lo + wave + nw lane in lane `lane`) are fetched
+    // HERE, ahead of the factor arithmetic -- fetched behind the barrier they were a dependent global round trip (~1.2 k cycles) at
+    // the head of every chunk's Gram phase
+    const int g_ci = c0 / CH;
+    int p_lo, p_hi;
+    if (g_ci < 63) p_lo = __builtin_amdgcn_readlane(g_start, g_ci), p_hi = __builtin_amdgcn_readlane(g_start, g_ci + 1);
+    else p_lo = v.gstart[g_ci], p_hi = v.gstart[g_ci + 1];
+    const int g_wave = __builtin_amdgcn_readfirstlane(VIO_TID(cx) >> 6), g_nw = (int)cx.nt >> 6;
+    const int g_pl0 = p_lo + g_wave + g_lane * g_nw;
+    const int m_desc0 = g_pl0 < p_hi ? v.gpiece[g_pl0] : 0;
     VIO_PARFOR(slot, nsl) {  // slot order: every lane of every wave has a factor (bar the odd tails)
       int rec;
       double pij[6];
@@ -1702,10 +1745,6 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       // instructions on ONE batch of operand reads, the next piece's reads are in flight while this one multiplies. Pieces of one
       // bucket meet through atomics -- LDS for the diagonal blocks and the gradient, no-return global atomics for the off-diagonal
       // block in PP, which every linearization finds zeroed (evaluate()).
-      const int ci = c0 / CH;
-      int p_lo, p_hi;
-      if (ci < 63) p_lo = __builtin_amdgcn_readlane(g_start, ci), p_hi = __builtin_amdgcn_readlane(g_start, ci + 1);
-      else p_lo = v.gstart[ci], p_hi = v.gstart[ci + 1];
       // column li of G = [Ji | Jj | r]: staged entry; its sign (the translation part of the target's Jacobian is the negated
       // host's) is applied to the PRODUCT: element (row, col) of G^T G carries sign(row) sign(col)
       const int src = li < 6 ? li : li < 9 ? li - 6 : li < 12 ? li - 3 : li < 13 ? 9 : 0;
@@ -1728,14 +1767,15 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       auto consume = [&](int desc, double (&a)[8]) {
         const int n = (desc >> 10) & 31, h = (desc >> 15) & 63, t = (desc >> 21) & 63;
         const int total = (n + 1) >> 1;  // matrix instructions: two factors each, an odd last factor is a masked half step
+        const int full = n >> 1;         // ... of which `full` take both factors: nothing to mask inside the loops
         v4d acc = {0.0, 0.0, 0.0, 0.0};
+        // the odd last factor: the step's operand (every batch repeats the piece's last step in its unused entries: entry 7 of the
+        // batch that holds it) with the lanes kq >= 2 -- they read the padding slot behind the bucket -- zeroed, once per piece
+        double xo = 0.0;
+        if (n & 1) xo = kq < 2 ? a[full < 8 ? 7 : 0] : 0.0;  // (full >= 8: taken from the second batch below)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          if (j < total) {  // (uniform)
-            double x = a[j];
-            if ((n & 1) && j == total - 1) x = kq < 2 ? x : 0.0;  // (lanes kq >= 2 read the padding slot behind the bucket)
-            acc = mfma_f64(x, x, acc);
-          }
+          if (j < full) acc = mfma_f64(a[j], a[j], acc);  // (uniform)
         }
         if (kGramPiece > 16 && total > 8) {  // (the second half of a long piece: its own batch of reads)
           const int off = desc & 1023, last = total - 1;
@@ -1744,15 +1784,13 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
 #pragma unroll
           for (int j = 0; j < 8; j++) a2[j] = g[(8 + j < last ? 8 + j : last) * 2 * kGSlot];
           VIO_SCHED_FENCE();
+          if (n & 1) xo = kq < 2 ? a2[7] : 0.0;
 #pragma unroll
           for (int j = 0; j < 8; j++) {
-            if (8 + j < total) {
-              double x = a2[j];
-              if ((n & 1) && 8 + j == total - 1) x = kq < 2 ? x : 0.0;
-              acc = mfma_f64(x, x, acc);
-            }
+            if (8 + j < full) acc = mfma_f64(a2[j], a2[j], acc);
           }
         }
+        if (n & 1) acc = mfma_f64(xo, xo, acc);
 #pragma unroll
         for (int r4 = 0; r4 < 4; r4++) {
           const double val = acc[r4] * sgn[r4];
@@ -1765,7 +1803,7 @@ VIO_DEV double projections_jac(const Ctx &cx, const WinView &v, WK &w, cldsd pos
       };
       for (int pb = p_lo + wave; pb < p_hi; pb += 64 * nw) {  // (rounds of 64 pieces per wave: one is enough below 64 nw pieces per chunk)
         const int pl = pb + lane * nw;
-        const int m_desc = pl < p_hi ? v.gpiece[pl] : 0;
+        const int m_desc = pb == p_lo + wave ? m_desc0 : (pl < p_hi ? v.gpiece[pl] : 0);  // (uniform choice; later rounds: > 64 nw pieces in a chunk)
         const int cnt = (p_hi - pb + nw - 1) / nw < 64 ? (p_hi - pb + nw - 1) / nw : 64;
         double A[8], Bq[8];
         issue(__builtin_amdgcn_readlane(m_desc, 0), A);
