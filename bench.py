@@ -363,7 +363,8 @@ def compact_secondary(sec):
                   "frontend_ms": g(sec, key, "kernel_ms", "frontend_step"), "frac": g(sec, key, "roofline", "frac"),
                   "frac_frontend": g(sec, key, "roofline", "frontend", "frac_at_measured_lk_iterations")}
     c["end_to_end_full"] = {"256": g(sec, "end_to_end_full", "value"), "512": g(sec, "end_to_end_full", "at_512_sequences", "camera_frames_per_s"),
-                            "freq3_256": g(sec, "end_to_end_full", "app_cadence_freq3", "camera_frames_per_s")}
+                            "freq3_256": g(sec, "end_to_end_full", "app_cadence_freq3", "camera_frames_per_s"),
+                            "512_registered_host_frames": g(sec, "end_to_end_full", "registered_host_frames_at_512_sequences", "camera_frames_per_s")}
     c["end_to_end_solves_per_s"] = g(sec, "end_to_end", "value")
     c["resident_256"] = {"frames_per_s": g(sec, "resident_256", "value"), "window_ms": g(sec, "resident_256", "kernel_ms", "window_solve"),
                          "frac": g(sec, "resident_256", "roofline_frac_window_kernel")}
@@ -596,10 +597,12 @@ def end_to_end_full(n_seq):
     frames rendered from textured planes along synthetic trajectories, so the estimator receives what the tracker
     publishes. `value`: every camera frame published and solved (the headline's convention); `app_cadence_freq3`: the
     app's FREQ = 3, every third camera frame published."""
-    run = lambda n, frames, overlap, freq, env=None: _tool(
-        "import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %d, quiet=True, freq=%d)))" % (n, frames, overlap, freq), env)
+    run = lambda n, frames, overlap, freq, env=None, registered=False: _tool(
+        "import time_pipeline as TP; print(json.dumps(TP.run(%d, %d, %d, quiet=True, freq=%d, registered=%s)))" % (n, frames, overlap, freq, bool(registered)), env)
     every, twice, sync_submit, serial, app = run(n_seq, 44, 2, 1), run(2 * n_seq, 34, 2, 1), run(n_seq, 22, 1, 1), run(n_seq, 22, 0, 1), run(n_seq, 20, 2, 3)   # (the headline legs time ~30 / ~20 frames: one host hiccup of 10 ms in 15 frames moved the mean by 15 %)
     host_lists = run(n_seq, 22, 1, 1, {"VIO_AMD_RESIDENT": "0", "VIO_AMD_HOST_THREADS": "64"})
+    # the frame buffers registered once with vio_host_register (a camera ring): DMA from where the frames lie, no gathering pass
+    registered = run(2 * n_seq, 34, 2, 1, registered=True)
     return {"value": every["camera_frames_per_s"], "unit": "camera frames/s, every frame published and solved", "sequences": n_seq,
             "path": "pageable frames in -> vio_frontend_submit_images_async (gather to page-locked memory, H2D, kernels and the D2H "
                     "of the observations queued by the context's own host thread) -> vio_frontend_collect -> "
@@ -608,6 +611,7 @@ def end_to_end_full(n_seq):
                     "measured in a process of its own",
             "every_frame_published": every, "at_%d_sequences" % (2 * n_seq): twice, "synchronous_submit": sync_submit,
             "one_call_after_the_other": serial, "app_cadence_freq3": app,
+            "registered_host_frames_at_%d_sequences" % (2 * n_seq): registered,
             "host_side_lists_synchronous_submit": host_lists}
 
 
