@@ -173,6 +173,44 @@ def test_resident_stepping_equals_read_images():
     a.close(), b.close()
 
 
+def test_resident_frames_are_tracked_in_place_across_a_new_upload():
+    """vio_frontend_step_resident reads level 0 of both pyramids where the frames lie in the context's ring (no copy). A second
+    vio_frontend_upload_frames frees that ring while the current image still lives in it: the image must move into the pyramid's
+    own storage first. Stepping through two rings, and then on through the host path, equals read_images frame by frame -- with the
+    in-place reading and with VIO_AMD_COPY_LEVEL0=1."""
+    import os
+    cfg = abi.default_config(max_corners=100, min_dist=25)
+    S, T = 2, 6
+    streams = np.stack([np.stack([synth.make_image_stream(50 + s, T)[0][f] for s in range(S)]) for f in range(T)])
+    want = fe.FeatureTracker(cfg, n_seq=S)
+    ref_states = []
+    for f in range(T):
+        want.read_images(streams[f], f % 2 == 0)
+        ref_states.append([want.state(s) for s in range(S)])
+    want.close()
+    for copy0 in ("0", "1"):
+        os.environ["VIO_AMD_COPY_LEVEL0"] = copy0
+        try:
+            a = fe.FeatureTracker(cfg, n_seq=S)
+            a.upload_frames(streams[:3])
+            for f in range(3):
+                a.step(f, f % 2 == 0)
+            a.upload_frames(np.ascontiguousarray(streams[3:5]))   # the ring of frames 0..2 goes away; frame 2 is the current image
+            for f in range(3, 5):
+                a.step(f - 3, f % 2 == 0)
+                a.sync()
+                for s in range(S):
+                    for x, y in zip(a.state(s), ref_states[f][s]):
+                        assert np.array_equal(x, y), (copy0, f, s)
+            a.read_images(streams[5], False)                      # host path behind resident frames: previous image still in the ring
+            for s in range(S):
+                for x, y in zip(a.state(s), ref_states[5][s]):
+                    assert np.array_equal(x, y), (copy0, 5, s)
+            a.close()
+        finally:
+            os.environ.pop("VIO_AMD_COPY_LEVEL0", None)
+
+
 def test_submit_collect_equals_read_images():
     """The two halves of read_images (vio_frontend_submit_images / vio_frontend_collect) with host work between them
     publish what the one call publishes; a second submit or a collect out of order is VIO_ESTATE."""
