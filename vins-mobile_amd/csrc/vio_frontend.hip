@@ -1447,72 +1447,77 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
   const int xe = X0 - 2 + lane;
   const int xr = reflect101(min(max(xe, -cols + 1), 2 * cols - 2), cols);
   const int xm = reflect101(xr - 1, cols), xp = reflect101(xr + 1, cols);
-  float hxx0 = 0.f, hxx1 = 0.f, hxy0 = 0.f, hxy1 = 0.f, hyy0 = 0.f, hyy1 = 0.f;  // horizontal sums of rows -2, -1
-  float e0 = 0.f, e1 = 0.f;                                                        // eigenvalues of rows -2, -1
+  // Everything that slides down the strip has period three -- the (d, t) pairs of the three image rows in flight, the horizontal sums of
+  // three product rows, three rows of eigenvalues --: each lives in a ring of three registers and the row loop is unrolled by three, so
+  // that the slot of "the row that enters at this step" is a compile-time constant and NOTHING is moved when the window slides (with
+  // named variables shifted at the end of a step the compiler kept ~11 register moves per row, a seventh of the loop's vector instructions:
+  // the reload path of the border rows turned the shifted values into phi nodes it could not coalesce).
+  float D[3] = {0.f, 0.f, 0.f}, T[3] = {0.f, 0.f, 0.f};                                  // slot s % 3: the image row that enters at step s
+  float Hxx[3] = {0.f, 0.f, 0.f}, Hxy[3] = {0.f, 0.f, 0.f}, Hyy[3] = {0.f, 0.f, 0.f};    // slot s % 3: horizontal sums of step s's product row
+  float E[3] = {0.f, 0.f, 0.f};                                                           // slot s % 3: eigenvalues formed at step s
   float my_max = -INFINITY;  // running masked maximum of this lane's column (one v_max per row; mapped to ordered bits once)
-  int prev_yr = -1, prev_yp = -1;               // rows of the previous step (uniform) and their (d, t)
-  float pd1 = 0.f, pt1 = 0.f, pd2 = 0.f, pt2 = 0.f;
+  int prev_yr = -1, prev_yp = -1;               // rows of the previous step (uniform)
   const bool out_lane = lane >= 2 && lane < 2 + kDetW && xe < cols;
-#pragma unroll 6  // (the carried rows rotate with periods 2 and 3: unrolled by 6 the rotation is register renaming, not moves)
-  for (int step = 0; step < kDetR + 4; step++) {
-    const int ye = Y0 - 2 + step;  // extended product row (uniform)
-    const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
-    const int ym = reflect101(yr - 1, rows), yp = reflect101(yr + 1, rows);
-    // Per image row the Sobel pair needs two numbers per column: the horizontal difference d = a(x+1) - a(x-1) and the
-    // horizontal smoothing t = 2s a(x) + s (a(x-1) + a(x+1)); dx = 2s d(y) + s (d(y-1) + d(y+1)), dy = t(y+1) - t(y-1). Inside
-    // the image the rows (y-1, y) of this step are the rows (y, y+1) of the previous one: only the entering row is loaded.
-    auto row_dt = [&](int y, float &d, float &t) {
-      // buffer loads: the row offset rides in the scalar offset operand, the column in the lane offset -- no address arithmetic
-      // on the vector unit (three 64-bit adds per row with flat pointers)
-      const int ro = __builtin_amdgcn_readfirstlane(y * cols);
-      const float a0 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xm, ro, 0), a1 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xr, ro, 0),
-                  a2 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xp, ro, 0);
-      d = a2 - a0;
-      t = s2 * a1 + s * (a0 + a2);
-    };
-    float d0, t0, d1, t1, d2, t2;
-    if (step > 0 && ym == prev_yr && yr == prev_yp) {
-      d0 = pd1, t0 = pt1, d1 = pd2, t1 = pt2;
-      row_dt(yp, d2, t2);
-    } else {
-      row_dt(ym, d0, t0), row_dt(yr, d1, t1), row_dt(yp, d2, t2);
-    }
-    prev_yr = yr, prev_yp = yp, pd1 = d1, pt1 = t1, pd2 = d2, pt2 = t2;
-    const float dx = s2 * d1 + s * (d0 + d2);
-    const float dy = t2 - t0;
-    const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
-    // 3-tap horizontal sums (left + centre) + right, then the 3-row vertical sums (top + middle) + bottom
-    const float hxx2 = (LANE_LEFT(pxx) + pxx) + LANE_RIGHT(pxx);
-    const float hxy2 = (LANE_LEFT(pxy) + pxy) + LANE_RIGHT(pxy);
-    const float hyy2 = (LANE_LEFT(pyy) + pyy) + LANE_RIGHT(pyy);
-    float e2 = 0.f;
-    if (step >= 2) {  // eigenvalue of extended row ye - 1
-      const float a = ((hxx0 + hxx1) + hxx2) * 0.5f;
-      const float b = (hxy0 + hxy1) + hxy2;
-      const float c = ((hyy0 + hyy1) + hyy2) * 0.5f;
-      e2 = (a + c) - sqrt_rn_normal((a - c) * (a - c) + b * b);
-    }
-    if (step >= 4) {  // output row ye - 2: centre e1, neighbours e0 / e2 and the lanes left and right
-      const int y = ye - 2, r = step - 4;
-      float m = fmaxf(fmaxf(e0, e1), e2);
-      m = fmaxf(m, fmaxf(LANE_LEFT(m), LANE_RIGHT(m)));
-      if (out_lane && y < rows) {
-        const float v = e1;
-        bool unmasked;
-        if (IMG_MASK) unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + xe] != 0;
-        else unmasked = ((s_mask[wave][r] >> lane) & 1ull) == 0ull;
-        if (unmasked) {
-          my_max = fmaxf(my_max, v);
-          if (xe >= 1 && y >= 1 && xe < cols - 1 && y < rows - 1 && v > 0.f && v == m) {
-            const int slot = atomicAdd(&s_ncand, 1);
-            const unsigned idx = (unsigned)y << 16 | (unsigned)xe;  // (row-major order like y * cols + x, and no division to take it apart)
-            if (slot < kCandLds) s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+  static_assert((kDetR + 4) % 3 == 0, "the row loop is unrolled by the rotation period");
+#pragma unroll 2
+  for (int s0 = 0; s0 < kDetR + 4; s0 += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int step = s0 + u;
+      const int jn = u, jm = (u + 1) % 3, jr = (u + 2) % 3;  // slots of the entering row (y + 1), of row y - 1 and of row y
+      const int ye = Y0 - 2 + step;  // extended product row (uniform)
+      const int yr = reflect101(min(max(ye, -rows + 1), 2 * rows - 2), rows);
+      const int ym = reflect101(yr - 1, rows), yp = reflect101(yr + 1, rows);
+      // Per image row the Sobel pair needs two numbers per column: the horizontal difference d = a(x+1) - a(x-1) and the
+      // horizontal smoothing t = 2s a(x) + s (a(x-1) + a(x+1)); dx = 2s d(y) + s (d(y-1) + d(y+1)), dy = t(y+1) - t(y-1). Inside
+      // the image the rows (y-1, y) of this step are the rows (y, y+1) of the previous one: only the entering row is loaded.
+      auto row_dt = [&](int y, float &d, float &t) {
+        // buffer loads: the row offset rides in the scalar offset operand, the column in the lane offset -- no address arithmetic
+        // on the vector unit (three 64-bit adds per row with flat pointers)
+        const int ro = __builtin_amdgcn_readfirstlane(y * cols);
+        const float a0 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xm, ro, 0), a1 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xr, ro, 0),
+                    a2 = (float)__builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xp, ro, 0);
+        d = a2 - a0;
+        t = s2 * a1 + s * (a0 + a2);
+      };
+      if (!(step > 0 && ym == prev_yr && yr == prev_yp)) row_dt(ym, D[jm], T[jm]), row_dt(yr, D[jr], T[jr]);  // (image border: reflected rows)
+      row_dt(yp, D[jn], T[jn]);
+      prev_yr = yr, prev_yp = yp;
+      const float dx = s2 * D[jr] + s * (D[jm] + D[jn]);
+      const float dy = T[jn] - T[jm];
+      const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
+      // 3-tap horizontal sums (left + centre) + right, then the 3-row vertical sums (top + middle) + bottom
+      Hxx[jn] = (LANE_LEFT(pxx) + pxx) + LANE_RIGHT(pxx);
+      Hxy[jn] = (LANE_LEFT(pxy) + pxy) + LANE_RIGHT(pxy);
+      Hyy[jn] = (LANE_LEFT(pyy) + pyy) + LANE_RIGHT(pyy);
+      float e2 = 0.f;
+      if (step >= 2) {  // eigenvalue of extended row ye - 1
+        const float a = ((Hxx[jm] + Hxx[jr]) + Hxx[jn]) * 0.5f;
+        const float b = (Hxy[jm] + Hxy[jr]) + Hxy[jn];
+        const float c = ((Hyy[jm] + Hyy[jr]) + Hyy[jn]) * 0.5f;
+        e2 = (a + c) - sqrt_rn_normal((a - c) * (a - c) + b * b);
+      }
+      E[jn] = e2;
+      if (step >= 4) {  // output row ye - 2: centre E[jr], neighbours E[jm] / E[jn] and the lanes left and right
+        const int y = ye - 2, r = step - 4;
+        float m = fmaxf(fmaxf(E[jm], E[jr]), E[jn]);
+        m = fmaxf(m, fmaxf(LANE_LEFT(m), LANE_RIGHT(m)));
+        if (out_lane && y < rows) {
+          const float v = E[jr];
+          bool unmasked;
+          if (IMG_MASK) unmasked = mask_base[(size_t)seq * mask_stride + (size_t)y * cols + xe] != 0;
+          else unmasked = ((s_mask[wave][r] >> lane) & 1ull) == 0ull;
+          if (unmasked) {
+            my_max = fmaxf(my_max, v);
+            if (xe >= 1 && y >= 1 && xe < cols - 1 && y < rows - 1 && v > 0.f && v == m) {
+              const int slot = atomicAdd(&s_ncand, 1);
+              const unsigned idx = (unsigned)y << 16 | (unsigned)xe;  // (row-major order like y * cols + x, and no division to take it apart)
+              if (slot < kCandLds) s_cand[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (0xffffffffu - idx);
+            }
           }
         }
       }
     }
-    hxx0 = hxx1, hxx1 = hxx2, hxy0 = hxy1, hxy1 = hxy2, hyy0 = hyy1, hyy1 = hyy2;
-    e0 = e1, e1 = e2;
   }
   // masked maximum: wave max on the DPP/shuffle network, then one LDS atomic per wave
   {
