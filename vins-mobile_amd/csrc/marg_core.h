@@ -679,48 +679,11 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
                       if (rr >= 0) VIO_ATOMIC_ADD(m.bm + rr, -val);
                     });
     } else {
-      const int T = (n6m + 15) / 16, npairs_t = T * (T + 1) / 2;
-      const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
-      const int li = lane & 15, kq = lane >> 4;
-      const int ksteps = (F + 3) / 4;
-      for (int p = wave; p < npairs_t; p += nw) {
-        int ti = 0;
-        while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
-        const int tj = p - ti * (ti + 1) / 2;
-        const int ra = 16 * ti + li, rb = 16 * tj + li;
-        const bool va = ra < n6m, vb = rb < n6m;
-        const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
-        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        constexpr int kChunk = 12;  // k-steps whose operands are fetched together
-        for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
-          double av[kChunk], bv[kChunk], ev[kChunk];
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) {
-            const int f = 4 * (s0 + j) + kq;
-            const int fc = (f < F && s0 + j < ksteps) ? f : 0;
-            av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = m.einv[fc];
-          }
-          VIO_SCHED_FENCE();
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) {
-            const int f = 4 * (s0 + j) + kq;
-            const bool vf = f < F && s0 + j < ksteps;
-            av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
-          }
-#pragma unroll
-          for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
-        }
-        acc += acc1;
-        const int bcol = 16 * tj + li;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {  // (one wave per tile)
-          const int arow = 16 * ti + kq + 4 * r4;
-          if (arow < n6m && bcol < n6m && bcol <= arow) {
-            const int rr = dense_col(arow), cc2 = dense_col(bcol);
-            if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -acc[r4]);
-          }
-        }
-      }
+      // (the solver's blocked K-split product, solver_core.h schur_blocks; every element through the atomic add_lower)
+      schur_blocks(cx, v.WTf, v.n6cap, n6m, F, m.einv, 0, 1, [&](int arow, int bcol, double val, bool) {
+        const int rr = dense_col(arow), cc2 = dense_col(bcol);
+        if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -val);
+      });
       // b -= W (g_f / E_f): (pose-type index, feature chunk) items, one fetch batch each
       const int nch = (F + kWStrip - 1) / kWStrip, chunk = kWStrip;
       VIO_PARFOR(q, n6m * nch) {

@@ -2378,51 +2378,102 @@ VIO_DEV void schur_ksplit5(const Ctx &cx, const double *Wf, int ldw, int n6, int
   }
 }
 
-// The landmark Schur term of the general path (more than 5 tile rows: one wave per tile pair, K = F in chunks of 12 k-steps)
-// and the right-hand side row: App -= (W E^-1) W^T, App[n6][:] -= W (g_f / E_f). share / nshare: the tile pairs and right-hand
-// side items of THIS workgroup of a cooperative window (every tile has one writer; App is global scratch in this variant).
-template <class WK>
-VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
-  const int n6 = v.n6, F = v.F;
-  const int T = (n6 + 15) / 16, npairs = T * (T + 1) / 2;
+// (App of the general path is global scratch on the device -- several workgroups may add to a tile: device scope, no return --, a
+// plain array under the host emulation)
+VIO_DEV void schur_add(double *p, double v) { atomic_add_noret(p, v); }
+#ifndef VIO_HOST_BUILD
+VIO_DEV void schur_add(ldsd p, double v) { atomic_add(p, v); }
+#endif
+
+// C = (W E^-1) W^T over the lower 16 x 16 tiles of an index space of any size (more than the five tile rows schur_ksplit5 keeps in
+// registers), W feature-major [F][ldw], on the matrix cores in BLOCKS of 2 x 2 tiles: a k-step of a block is FOUR loads (two strips
+// of W as A operands, two as B) for four matrix instructions (three on the diagonal, whose upper tile is not needed). With one tile
+// per wave (rounds 3-6) a matrix instruction took two loads of its own and the CU's address unit -- ~16 cycles per load instruction,
+// eight waves -- was busy twice as long as the matrix pipes. K-split: with fewer blocks than waves (W = 20: ten blocks for the 32
+// waves of a window on four workgroups) or a ragged last round the feature range of a block is cut into ksplit parts (whole fetch
+// chunks) that meet through atomic adds: the split that minimises rounds x chunks per part, ceil(nblocks k / waves) x ceil(chunks / k)
+// over k = 1 .. 4. share / nshare: this workgroup's units of a cooperative window.
+// flush(row, col <= row, value, parts): parts = true -> the element has several writers, add atomically.
+template <class FT>
+VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, int share, int nshare, FT flush_el) {
+  const int T = (n6 + 15) / 16, NB = (T + 1) / 2, nblocks = NB * (NB + 1) / 2;
   const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int ksteps = (F + 3) / 4;
-  for (int p = share * nw + wave; p < npairs; p += nshare * nw) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
-    const int tj = p - ti * (ti + 1) / 2;
-    const int ra = 16 * ti + li, rb = 16 * tj + li;
-    const bool va = ra < n6, vb = rb < n6;
-    const double *pa = v.WTf + (va ? ra : 0), *pb = v.WTf + (vb ? rb : 0);  // feature-major: 16 lanes = 128 B
-    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    constexpr int kChunk = 12;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
-    for (int s0 = 0; s0 < ksteps; s0 += kChunk) {
-      double av[kChunk], bv[kChunk], ev[kChunk];
+  constexpr int kChunk = 6;  // k-steps whose operands are fetched together: 24 global loads in flight per lane
+  const int nchunks = (ksteps + kChunk - 1) / kChunk;
+  int ksplit = 1;
+  {
+    const int waves = nshare * nw;
+    int best = ((nblocks + waves - 1) / waves) * nchunks;  // cost in chunks: rounds x chunks per part
+    for (int k = 2; k <= 4; k++) {
+      const int cost = ((nblocks * k + waves - 1) / waves) * ((nchunks + k - 1) / k);
+      if (cost < best) best = cost, ksplit = k;
+    }
+  }
+  const int ks_part = (nchunks + ksplit - 1) / ksplit * kChunk;  // whole chunks per part
+  for (int u = share * nw + wave; u < nblocks * ksplit; u += nshare * nw) {
+    const int p = u / ksplit, part = u - p * ksplit;
+    const int s_lo = part * ks_part, s_hi = s_lo + ks_part < ksteps ? s_lo + ks_part : ksteps;
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= p) I++;
+    const int J = p - I * (I + 1) / 2;
+    const bool diag = I == J;
+    const int ta[2] = {2 * I, 2 * I + 1}, tb[2] = {2 * J, 2 * J + 1};
+    bool va[2], vb[2];
+    const double *pa[2], *pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      va[q] = ta[q] < T && 16 * ta[q] + li < n6, vb[q] = tb[q] < T && 16 * tb[q] + li < n6;
+      pa[q] = Wf + (va[q] ? 16 * ta[q] + li : 0), pb[q] = Wf + (vb[q] ? 16 * tb[q] + li : 0);  // feature-major: 16 lanes = 128 B
+    }
+    v4d c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;  // c_xy: row tile ta[x], column tile tb[y]
+    for (int s0 = s_lo; s0 < s_hi; s0 += kChunk) {
+      double av[2][kChunk], bv[2][kChunk], ev[kChunk];
 #pragma unroll
       for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
         const int f = 4 * (s0 + j) + kq;
-        const int fc = (f < F && s0 + j < ksteps) ? f : 0;
-        av[j] = pa[(size_t)fc * v.n6cap], bv[j] = pb[(size_t)fc * v.n6cap], ev[j] = w.einv[fc];
+        const size_t fo = (size_t)((f < F && s0 + j < s_hi) ? f : 0) * ldw;
+        av[0][j] = pa[0][fo], av[1][j] = pa[1][fo], bv[0][j] = pb[0][fo], bv[1][j] = pb[1][fo];
+        ev[j] = einv[(f < F && s0 + j < s_hi) ? f : 0];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      VIO_SCHED_FENCE();
 #pragma unroll
       for (int j = 0; j < kChunk; j++) {
         const int f = 4 * (s0 + j) + kq;
-        const bool vf = f < F && s0 + j < ksteps;
-        av[j] = (va && vf) ? av[j] * ev[j] : 0.0, bv[j] = (vb && vf) ? bv[j] : 0.0;
+        const bool vf = f < F && s0 + j < s_hi;
+#pragma unroll
+        for (int q = 0; q < 2; q++) av[q][j] = (va[q] && vf) ? av[q][j] * ev[j] : 0.0, bv[q][j] = (vb[q] && vf) ? bv[q][j] : 0.0;
       }
 #pragma unroll
-      for (int j = 0; j < kChunk; j += 2) acc = mfma_f64(av[j], bv[j], acc), acc1 = mfma_f64(av[j + 1], bv[j + 1], acc1);
+      for (int j = 0; j < kChunk; j++) {
+        c00 = mfma_f64(av[0][j], bv[0][j], c00), c10 = mfma_f64(av[1][j], bv[0][j], c10), c11 = mfma_f64(av[1][j], bv[1][j], c11);
+        if (!diag) c01 = mfma_f64(av[0][j], bv[1][j], c01);  // (uniform; on the diagonal that tile lies above it)
+      }
     }
-    acc += acc1;
-    const int bcol = 16 * tj + li;
+    auto flush = [&](int tr, int tc, const v4d &acc) {
+      const int bcol = 16 * tc + li;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {  // (one wave per tile: plain read-modify-write)
-      const int arow = 16 * ti + kq + 4 * r;
-      if (arow < n6 && bcol <= arow) w.App[tri_at(arow, bcol)] -= acc[r];
-    }
+      for (int r = 0; r < 4; r++) {
+        const int arow = 16 * tr + kq + 4 * r;
+        if (tr < T && tc < T && arow < n6 && bcol < n6 && bcol <= arow) flush_el(arow, bcol, acc[r], ksplit > 1);
+      }
+    };
+    flush(ta[0], tb[0], c00), flush(ta[1], tb[0], c10), flush(ta[1], tb[1], c11);
+    if (!diag) flush(ta[0], tb[1], c01);
   }
+}
+
+// The landmark Schur term of the general path (more than 5 tile rows) and the right-hand side row: App -= (W E^-1) W^T,
+// App[n6][:] -= W (g_f / E_f). share / nshare: the units and right-hand side items of THIS workgroup of a cooperative window (App
+// is global scratch in this variant).
+template <class WK>
+VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
+  const int n6 = v.n6, F = v.F;
+  schur_blocks(cx, v.WTf, v.n6cap, n6, F, w.einv, share, nshare, [&](int arow, int bcol, double val, bool parts) {
+    if (parts) schur_add(w.App + tri_at(arow, bcol), -val);
+    else w.App[tri_at(arow, bcol)] -= val;  // (one writer per tile: plain read-modify-write)
+  });
   stamp(cx, ST_SCHUR);
   // rhs_p -= sum_f W_f (g_f / E_f): (row, feature-chunk) items
   const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
