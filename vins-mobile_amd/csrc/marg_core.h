@@ -680,23 +680,16 @@ VIO_DEV void marginalize_window_impl(const Ctx &cx, const WinView &v, cldsd xpos
                     });
     } else {
       // (the solver's blocked K-split product, solver_core.h schur_blocks; every element through the atomic add_lower)
-      schur_blocks(cx, v.WTf, v.n6cap, n6m, F, m.einv, 0, 1, [&](int arow, int bcol, double val, bool) {
-        const int rr = dense_col(arow), cc2 = dense_col(bcol);
-        if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -val);
-      });
-      // b -= W (g_f / E_f): (pose-type index, feature chunk) items, one fetch batch each
-      const int nch = (F + kWStrip - 1) / kWStrip, chunk = kWStrip;
-      VIO_PARFOR(q, n6m * nch) {
-        const int ch = q / n6m, a = q - ch * n6m;
-        const int f0 = ch * chunk, nb = F - f0 < chunk ? F - f0 : chunk;
-        const int rr = dense_col(a);
-        if (rr < 0 || nb <= 0) continue;
-        double x[kWStrip], sacc = 0;
-        wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);
-#pragma unroll
-        for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * m.gf[f0 + (j < nb ? j : 0)];
-        VIO_ATOMIC_ADD(m.bm + rr, -sacc);
-      }
+      schur_blocks(
+          cx, v.WTf, v.n6cap, n6m, F, m.einv, m.gf, 0, 1,
+          [&](int arow, int bcol, double val, bool) {
+            const int rr = dense_col(arow), cc2 = dense_col(bcol);
+            if (rr >= 0 && cc2 >= 0) add_lower(rr, cc2, -val);
+          },
+          [&](int a, double val) {  // b -= W (g_f / E_f)
+            const int rr = dense_col(a);
+            if (rr >= 0) VIO_ATOMIC_ADD(m.bm + rr, -val);
+          });
     }
     VIO_SYNC();
   }

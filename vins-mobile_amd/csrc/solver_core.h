@@ -2394,8 +2394,11 @@ VIO_DEV void schur_add(ldsd p, double v) { atomic_add(p, v); }
 // chunks) that meet through atomic adds: the split that minimises rounds x chunks per part, ceil(nblocks k / waves) x ceil(chunks / k)
 // over k = 1 .. 4. share / nshare: this workgroup's units of a cooperative window.
 // flush(row, col <= row, value, parts): parts = true -> the element has several writers, add atomically.
-template <class FT>
-VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, int share, int nshare, FT flush_el) {
+// ge / flush_rhs: the same fetch also yields c = W (g_f / E_f) -- the diagonal blocks, which have a matrix instruction to spare, multiply
+// the two strips they load by ge[f] on the way; flush_rhs(index, partial) is called by every lane group and part (add atomically).
+template <class FT, class FR>
+VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, cldsd ge, int share, int nshare, FT flush_el,
+                          FR flush_rhs) {
   const int T = (n6 + 15) / 16, NB = (T + 1) / 2, nblocks = NB * (NB + 1) / 2;
   const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -2428,14 +2431,16 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
       pa[q] = Wf + (va[q] ? 16 * ta[q] + li : 0), pb[q] = Wf + (vb[q] ? 16 * tb[q] + li : 0);  // feature-major: 16 lanes = 128 B
     }
     v4d c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;  // c_xy: row tile ta[x], column tile tb[y]
+    double rp[2] = {0.0, 0.0};
     for (int s0 = s_lo; s0 < s_hi; s0 += kChunk) {
-      double av[2][kChunk], bv[2][kChunk], ev[kChunk];
+      double av[2][kChunk], bv[2][kChunk], ev[kChunk], gv[kChunk];
 #pragma unroll
       for (int j = 0; j < kChunk; j++) {  // issue every load of the chunk before anything consumes one
         const int f = 4 * (s0 + j) + kq;
         const size_t fo = (size_t)((f < F && s0 + j < s_hi) ? f : 0) * ldw;
         av[0][j] = pa[0][fo], av[1][j] = pa[1][fo], bv[0][j] = pb[0][fo], bv[1][j] = pb[1][fo];
         ev[j] = einv[(f < F && s0 + j < s_hi) ? f : 0];
+        gv[j] = diag ? ge[(f < F && s0 + j < s_hi) ? f : 0] : 0.0;
       }
       VIO_SCHED_FENCE();
 #pragma unroll
@@ -2443,7 +2448,11 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
         const int f = 4 * (s0 + j) + kq;
         const bool vf = f < F && s0 + j < s_hi;
 #pragma unroll
-        for (int q = 0; q < 2; q++) av[q][j] = (va[q] && vf) ? av[q][j] * ev[j] : 0.0, bv[q][j] = (vb[q] && vf) ? bv[q][j] : 0.0;
+        for (int q = 0; q < 2; q++) {
+          const double a_raw = (va[q] && vf) ? av[q][j] : 0.0;
+          if (diag) rp[q] = fma(a_raw, gv[j], rp[q]);  // (uniform)
+          av[q][j] = a_raw * ev[j], bv[q][j] = (vb[q] && vf) ? bv[q][j] : 0.0;
+        }
       }
 #pragma unroll
       for (int j = 0; j < kChunk; j++) {
@@ -2461,6 +2470,11 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
     };
     flush(ta[0], tb[0], c00), flush(ta[1], tb[0], c10), flush(ta[1], tb[1], c11);
     if (!diag) flush(ta[0], tb[1], c01);
+    if (diag) {
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (va[q] && rp[q] != 0.0) flush_rhs(16 * ta[q] + li, rp[q]);
+    }
   }
 }
 
@@ -2470,24 +2484,14 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
 template <class WK>
 VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
   const int n6 = v.n6, F = v.F;
-  schur_blocks(cx, v.WTf, v.n6cap, n6, F, w.einv, share, nshare, [&](int arow, int bcol, double val, bool parts) {
-    if (parts) schur_add(w.App + tri_at(arow, bcol), -val);
-    else w.App[tri_at(arow, bcol)] -= val;  // (one writer per tile: plain read-modify-write)
-  });
+  schur_blocks(
+      cx, v.WTf, v.n6cap, n6, F, w.einv, w.tf, share, nshare,
+      [&](int arow, int bcol, double val, bool parts) {
+        if (parts) schur_add(w.App + tri_at(arow, bcol), -val);
+        else w.App[tri_at(arow, bcol)] -= val;  // (one writer per tile: plain read-modify-write)
+      },
+      [&](int a, double val) { schur_add(w.App + tri_at(n6, a), -val); });  // rhs_p -= sum_f W_f (g_f / E_f)
   stamp(cx, ST_SCHUR);
-  // rhs_p -= sum_f W_f (g_f / E_f): (row, feature-chunk) items
-  const int nch = (F + kWStrip - 1) / kWStrip > 7 ? (F + kWStrip - 1) / kWStrip : 7, chunk = (F + nch - 1) / nch;
-  for (int q = share * (int)cx.nt + VIO_TID(cx); q < n6 * nch; q += nshare * (int)cx.nt) {
-    int ch = q / n6, a = q - ch * n6;  // neighbouring lanes walk neighbouring rows
-    int f0 = ch * chunk, f1 = f0 + chunk < F ? f0 + chunk : F;
-    double x[kWStrip], sacc = 0;
-    const int nb = f1 - f0;  // <= kWStrip by the choice of nch
-    if (nb <= 0) continue;   // (more chunks than features: nothing to fetch, and tf[f0] would be out of range)
-    wt_strip_load(v.WTf + (size_t)f0 * v.n6cap + a, v.n6cap, nb, x);  // feature-major copy: lanes = consecutive rows
-#pragma unroll
-    for (int j = 0; j < kWStrip; j++) sacc += (j < nb ? x[j] : 0.0) * w.tf[f0 + (j < nb ? j : 0)];
-    VIO_ATOMIC_ADD(w.App + tri_at(n6, a), -sacc);
-  }
 }
 
 // In place: (H + mu C) on the diagonals, then the landmark Schur term  App -= (W E^-1) W^T  and the right-hand side row
