@@ -2396,9 +2396,11 @@ VIO_DEV void schur_add(ldsd p, double v) { atomic_add(p, v); }
 // flush(row, col <= row, value, parts): parts = true -> the element has several writers, add atomically.
 // ge / flush_rhs: the same fetch also yields c = W (g_f / E_f) -- the diagonal blocks, which have a matrix instruction to spare, multiply
 // the two strips they load by ge[f] on the way; flush_rhs(index, partial) is called by every lane group and part (add atomically).
+// up / tq (optional): the diagonal blocks also leave tq[f] += sum_a W[f][a] up[a] over their 32 columns (the W part of the Cauchy point's
+// quadratic form, as in schur_ksplit5) -- tq zeroed by the caller, LDS atomics: every feature meets every diagonal block once.
 template <class FT, class FR>
 VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int F, cldsd einv, cldsd ge, int share, int nshare, FT flush_el,
-                          FR flush_rhs) {
+                          FR flush_rhs, cldsd up = nullptr, ldsd tq = nullptr) {
   const int T = (n6 + 15) / 16, NB = (T + 1) / 2, nblocks = NB * (NB + 1) / 2;
   const int tid_ = VIO_TID(cx), wave = tid_ >> 6, lane = tid_ & 63, nw = cx.nt >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -2432,6 +2434,12 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
     }
     v4d c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;  // c_xy: row tile ta[x], column tile tb[y]
     double rp[2] = {0.0, 0.0};
+    const bool do_tq = diag && tq != nullptr;
+    double u2[2] = {0.0, 0.0};
+    if (do_tq) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) u2[q] = va[q] ? up[16 * ta[q] + li] : 0.0;
+    }
     for (int s0 = s_lo; s0 < s_hi; s0 += kChunk) {
       double av[2][kChunk], bv[2][kChunk], ev[kChunk], gv[kChunk];
 #pragma unroll
@@ -2447,11 +2455,20 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
       for (int j = 0; j < kChunk; j++) {
         const int f = 4 * (s0 + j) + kq;
         const bool vf = f < F && s0 + j < s_hi;
+        double pq = 0.0;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
           const double a_raw = (va[q] && vf) ? av[q][j] : 0.0;
           if (diag) rp[q] = fma(a_raw, gv[j], rp[q]);  // (uniform)
+          if (do_tq) pq = fma(a_raw, u2[q], pq);
           av[q][j] = a_raw * ev[j], bv[q][j] = (vb[q] && vf) ? bv[q][j] : 0.0;
+        }
+        if (do_tq) {  // (uniform) this block's part of row f against up: the 16 lanes of the row (total in lane 15)
+          pq += dpp_move_f64<0x111, 0xf>(pq);
+          pq += dpp_move_f64<0x112, 0xf>(pq);
+          pq += dpp_move_f64<0x114, 0xf>(pq);
+          pq += dpp_move_f64<0x118, 0xf>(pq);
+          if (li == 15 && vf) VIO_ATOMIC_ADD(tq + f, pq);
         }
       }
 #pragma unroll
@@ -2481,8 +2498,9 @@ VIO_DEV void schur_blocks(const Ctx &cx, const double *Wf, int ldw, int n6, int 
 // The landmark Schur term of the general path (more than 5 tile rows) and the right-hand side row: App -= (W E^-1) W^T,
 // App[n6][:] -= W (g_f / E_f). share / nshare: the units and right-hand side items of THIS workgroup of a cooperative window (App
 // is global scratch in this variant).
+// tq (optional, zeroed by the caller): += W^T u_p of this workgroup's diagonal blocks, u_p by pose index in w.xt.
 template <class WK>
-VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare) {
+VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, int nshare, ldsd tq = nullptr) {
   const int n6 = v.n6, F = v.F;
   schur_blocks(
       cx, v.WTf, v.n6cap, n6, F, w.einv, w.tf, share, nshare,
@@ -2490,7 +2508,8 @@ VIO_DEV void schur_general(const Ctx &cx, const WinView &v, WK &w, int share, in
         if (parts) schur_add(w.App + tri_at(arow, bcol), -val);
         else w.App[tri_at(arow, bcol)] -= val;  // (one writer per tile: plain read-modify-write)
       },
-      [&](int a, double val) { schur_add(w.App + tri_at(n6, a), -val); });  // rhs_p -= sum_f W_f (g_f / E_f)
+      [&](int a, double val) { schur_add(w.App + tri_at(n6, a), -val); },  // rhs_p -= sum_f W_f (g_f / E_f)
+      w.xt, tq);
   stamp(cx, ST_SCHUR);
 }
 
@@ -2512,6 +2531,8 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
     w.tf[f] = w.gf[f] * ei;  // g_f / E_f
     if (!(e > 0.0)) w.flag[0] = 1;
   }
+  const bool tq_general = tq != nullptr && ((v.n6 + 15) >> 4) > 5;  // (the general path accumulates tq: zeroed here, ahead of the barrier)
+  if (tq_general) VIO_PARFOR(f, F) tq[f] = 0.0;
   VIO_PARFOR(i, np) {
     const int f = i / kBS, c = i - f * kBS;
     const double cc = w.dp[i] * rcp_f(w.sp[i]);
@@ -2544,12 +2565,20 @@ VIO_DEV bool build_reduced_system(const Ctx &cx, const WinView &v, WK &w, double
         // share of the tile pairs, the owner goes on when all of them are done
         const CoopLayout L = CoopLayout::make(v.Pcap, v.Fcap, v.nblk_cap);
         VIO_PARFOR(f, F) v.coop[L.o_einv + f] = w.einv[f], v.coop[L.o_tf + f] = w.tf[f];
+        if (tq) VIO_PARFOR(q, 16 * T) v.coop[L.o_pose + q] = w.xt[q];  // u_p for the helpers' part of W^T u_p (the pose slot is free here)
         coop_post(cx, v, COOP_SCHUR);
-        schur_general(cx, v, w, 0, cx.coop);
+        schur_general(cx, v, w, 0, cx.coop, tq);
         coop_wait_helpers(cx, v);
+        if (tq) {  // the helpers' parts of W^T u_p (left in the per-landmark slot of their partial records)
+          VIO_SYNC();
+          for (int m = 1; m < cx.coop; m++) {
+            const double *pr = v.coop + L.o_part + (size_t)(m - 1) * L.part;
+            VIO_PARFOR(f, F) tq[f] += pr[L.p_f + f];
+          }
+        }
       } else
 #endif
-        schur_general(cx, v, w, 0, 1);
+        schur_general(cx, v, w, 0, 1, tq);
     }
   }
   VIO_SYNC();
@@ -3729,7 +3758,7 @@ VIO_DEV void minimize(const Ctx &cx, const WinView &v, WK &w_whole, const VP &fr
       // (pose matrices of up to five tile rows: the W part of the form, 2 u_f^T W^T u_p, comes out of the Schur sweep of
       // build_reduced_system -- tq -> cfeat, dead between a linearization and the next Plus -- and joins the reductions of the
       // dogleg step below: one pass over W in global memory and one barrier less per iteration)
-      const bool fuse_qw = ((v.n6 + 15) >> 4) <= 5;
+      const bool fuse_qw = true;  // (round 6: the general path's blocked product accumulates it as well, schur_blocks)
       const double qf_h0 = quad_form_H(cx, fresh(), w, w.t2, w.stf, /*prepared=*/true, /*w_part=*/!fuse_qw);
       stamp(cx, ST_QUADFORM);
       // Gauss-Newton step: (S H S + mu D^2) y = S g, features eliminated (dogleg_strategy.cc:515-612)
@@ -4022,9 +4051,12 @@ VIO_DEV void coop_helper(const Ctx &cx, const WinView &v, WK &w) {
       }
       if (cx.tid == 0) part[L.p_cost] = cost;
     } else if (cmd == COOP_SCHUR) {
-      VIO_PARFOR(f, F) w.einv[f] = v.coop[L.o_einv + f], w.tf[f] = v.coop[L.o_tf + f];
+      VIO_PARFOR(f, F) w.einv[f] = v.coop[L.o_einv + f], w.tf[f] = v.coop[L.o_tf + f], w.cfeat[f] = 0.0;
+      VIO_PARFOR(q, 16 * ((v.n6 + 15) >> 4)) w.xt[q] = v.coop[L.o_pose + q];  // u_p (only meaningful when the owner fuses W^T u_p: read either way)
       VIO_SYNC();
-      schur_general(cx, v, w, cx.member, cx.coop);
+      schur_general(cx, v, w, cx.member, cx.coop, w.cfeat);
+      VIO_SYNC();
+      VIO_PARFOR(f, F) part[L.p_f + f] = w.cfeat[f];
     } else if (cmd == COOP_SYRK) {
       band_syrk_share(cx, v, w, cx.member, cx.coop);
     } else {
