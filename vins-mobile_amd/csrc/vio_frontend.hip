@@ -1481,8 +1481,10 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
     b[2] = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, xp, ro, 0);
   };
   fetch_raw(entering_row(0), RB[2]);
-#pragma unroll 2
-  for (int s0 = 0; s0 < kDetR + 4; s0 += 3) {
+  // (three steps; HEAD: the first six of a strip, which still test whether an eigenvalue / an output row exists -- the loop behind them
+  // does not: two scalar compares and branches per step less)
+  auto three_steps = [&](int s0, auto head_tag) {
+    constexpr bool HEAD = decltype(head_tag)::value;
 #pragma unroll
     for (int u = 0; u < 3; u++) {
       const int step = s0 + u;
@@ -1518,14 +1520,14 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
       Hxy[jn] = (LANE_LEFT(pxy) + pxy) + LANE_RIGHT(pxy);
       Hyy[jn] = (LANE_LEFT(pyy) + pyy) + LANE_RIGHT(pyy);
       float e2 = 0.f;
-      if (step >= 2) {  // eigenvalue of extended row ye - 1
+      if (!HEAD || step >= 2) {  // eigenvalue of extended row ye - 1
         const float a = ((Hxx[jm] + Hxx[jr]) + Hxx[jn]) * 0.5f;
         const float b = (Hxy[jm] + Hxy[jr]) + Hxy[jn];
         const float c = ((Hyy[jm] + Hyy[jr]) + Hyy[jn]) * 0.5f;
         e2 = (a + c) - sqrt_rn_normal((a - c) * (a - c) + b * b);
       }
       E[jn] = e2;
-      if (step >= 4) {  // output row ye - 2: centre E[jr], neighbours E[jm] / E[jn] and the lanes left and right
+      if (!HEAD || step >= 4) {  // output row ye - 2: centre E[jr], neighbours E[jm] / E[jn] and the lanes left and right
         const int y = ye - 2, r = step - 4;
         float m = fmaxf(fmaxf(E[jm], E[jr]), E[jn]);
         m = fmaxf(m, fmaxf(LANE_LEFT(m), LANE_RIGHT(m)));
@@ -1545,7 +1547,11 @@ __global__ __launch_bounds__(256) void detect_kernel(const uint8_t *img_base, si
         }
       }
     }
-  }
+  };  // three_steps
+  static_assert(kDetR + 4 > 6 && (kDetR + 4) % 6 == 0, "two head rounds, then rounds of six steps");
+  three_steps(0, std::true_type{}), three_steps(3, std::true_type{});
+#pragma unroll 1
+  for (int s0 = 6; s0 < kDetR + 4; s0 += 6) three_steps(s0, std::false_type{}), three_steps(s0 + 3, std::false_type{});
   };  // strip
   if (inner_rows) strip(std::true_type{});
   else strip(std::false_type{});
