@@ -217,7 +217,26 @@ __device__ __forceinline__ double feat_sum_exact(int p, int sub) {
 
 // Two exact sums at once (one feature per wave): the four 32-bit chains advance in lockstep, so that every DPP step finds
 // its operand written three instructions earlier (a chain on its own waits two issue slots after every step).
+// (every partial below 2^24 in magnitude -- what a window of ordinary contrast gives: the bounds are 2^28 -- means the 64-lane sums fit
+// 32 bits unsplit: half the chains. The split form stays for the rest; both give the exact integer, rounded once.)
+__device__ __forceinline__ bool wave_all_small(int p, int q, int r = 0) {
+  const bool small = (unsigned)(p + (1 << 24)) < (1u << 25) && (unsigned)(q + (1 << 24)) < (1u << 25) && (unsigned)(r + (1 << 24)) < (1u << 25);
+  return __builtin_amdgcn_ballot_w64(!small) == 0ull;
+}
 __device__ __forceinline__ void wave_sum_exact2(int p, int q, float &sp, float &sq) {
+  if (wave_all_small(p, q)) {  // (uniform)
+    int u[2] = {p, q};
+#define VIO_DPPS(ctrl, rmask)                                                  \
+  {                                                                            \
+    const int t0 = __builtin_amdgcn_update_dpp(0, u[0], ctrl, rmask, 0xf, false); \
+    const int t1 = __builtin_amdgcn_update_dpp(0, u[1], ctrl, rmask, 0xf, false); \
+    u[0] += t0, u[1] += t1;                                                    \
+  }
+    VIO_DPPS(0x111, 0xf) VIO_DPPS(0x112, 0xf) VIO_DPPS(0x114, 0xf) VIO_DPPS(0x118, 0xf) VIO_DPPS(0x142, 0xa) VIO_DPPS(0x143, 0xc)
+#undef VIO_DPPS
+    sp = (float)__builtin_amdgcn_readlane(u[0], 63), sq = (float)__builtin_amdgcn_readlane(u[1], 63);
+    return;
+  }
   int a = p & 0xffff, b = q & 0xffff, c = p >> 16, d = q >> 16;
 #define VIO_DPP4(ctrl, rmask)                                              \
   {                                                                        \
@@ -240,6 +259,19 @@ __device__ __forceinline__ void wave_sum_exact2(int p, int q, float &sp, float &
 // fits 32 bits (< 1.87e9), so the four in-row steps run on the three unsplit values; only the two cross-row steps need the
 // 16-bit halves (six chains).
 __device__ __forceinline__ void wave_sum_exact3(int p, int q, int r, float &sp, float &sq, float &sr) {
+  if (wave_all_small(p, q, r)) {  // (uniform)
+    int w[3] = {p, q, r};
+#define VIO_DPPS3(ctrl, rmask)                                                                                       \
+  {                                                                                                                   \
+    int t[3];                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) t[k] = __builtin_amdgcn_update_dpp(0, w[k], ctrl, rmask, 0xf, false); \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) w[k] += t[k];                                                       \
+  }
+    VIO_DPPS3(0x111, 0xf) VIO_DPPS3(0x112, 0xf) VIO_DPPS3(0x114, 0xf) VIO_DPPS3(0x118, 0xf) VIO_DPPS3(0x142, 0xa) VIO_DPPS3(0x143, 0xc)
+#undef VIO_DPPS3
+    sp = (float)__builtin_amdgcn_readlane(w[0], 63), sq = (float)__builtin_amdgcn_readlane(w[1], 63), sr = (float)__builtin_amdgcn_readlane(w[2], 63);
+    return;
+  }
   int u[3] = {p, q, r};
 #define VIO_DPPN(N, arr, ctrl, rmask)                                               \
   {                                                                                 \
