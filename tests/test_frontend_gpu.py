@@ -36,6 +36,32 @@ def test_klt_track_bit_exact(stream):
     assert np.array_equal(gerr[ok], rerr[ok])
 
 
+def test_klt_extreme_contrast_takes_the_split_sums():
+    """The wave sums of the LK system run unsplit while every lane's partial is below 2^24 and fall back to the 16-bit split otherwise
+    (vio_frontend.hip wave_all_small). A black / white block pattern drives the derivative products far past that bound
+    (7 pixels x 4080^2 per lane): the split form must give the oracle's bits too, on the same call as ordinary windows."""
+    rng = np.random.default_rng(7)
+    soft = synth.make_image_stream(3, 2)[0]
+    rows, cols = soft[0].shape
+    half = cols // 2
+    blocks = (rng.integers(0, 2, (rows // 6 + 1, cols // 6 + 1)) * 255).astype(np.uint8)
+    img0 = np.ascontiguousarray(np.kron(blocks, np.ones((6, 6), np.uint8))[:rows, :cols])
+    img1 = np.ascontiguousarray(np.roll(img0, (1, 2), axis=(0, 1)))         # a shift LK can follow
+    img0[:, half:], img1[:, half:] = soft[0][:, half:], soft[1][:, half:]   # ordinary contrast on the right half: the unsplit form
+    cfg = abi.default_config(max_corners=150, min_dist=20)
+    gy, gx = np.meshgrid(np.arange(40, rows - 40, 40), np.arange(40, cols - 40, 40), indexing="ij")
+    pts = np.stack([gx.ravel(), gy.ravel()], axis=1).astype(np.float32) + rng.uniform(-0.5, 0.5, (gx.size, 2)).astype(np.float32)
+    got, gst, gerr = fe.klt_track(cfg, img0, img1, pts)
+    ref, rst, rerr = H.oracle_klt(cfg, img0, img1, pts)
+    assert (gst == rst).all() and rst.sum() >= 40
+    ok = rst > 0
+    assert np.array_equal(got[ok], ref[ok]), np.abs(got[ok] - ref[ok]).max()
+    assert np.array_equal(gerr[ok], rerr[ok])
+    # the pattern really is past the bound: a 21 x 21 window of it holds derivative products above 64 x 2^24 in sum
+    gxs = np.abs(np.diff(img0[:, :half].astype(np.int64), axis=1)).max()
+    assert gxs == 255
+
+
 def test_klt_small_image_and_levels():
     frames, _ = synth.make_image_stream(9, 2, rows=120, cols=96)  # only 2 pyramid levels hold a 21x21 window
     cfg = abi.default_config(max_corners=40, min_dist=10, image_rows=120, image_cols=96)
