@@ -413,40 +413,42 @@ __global__ __launch_bounds__(256, FPW == 1 ? 6 : 1) void lk_track_kernel(const u
     }
     wave_lds_fence();
     if (FPW == 1) {
-      // Scharr derivatives by COLUMN WALK: lanes 0..43 = 22 columns x two segments of 11 rows. Per input row a lane reads its
-      // two pair words once and forms the row's horizontal difference h = p2 - p0 and smoothing v = 3 p0 + 10 p1 + 3 p2;
-      // an output row is dx = 3 (h0 + h2) + 10 h1, dy = v2 - v0 of three consecutive input rows -- the same integers as the
-      // 3 x 3 sums of calcSharrDeriv, from 2 LDS reads and ~8 instructions per output instead of 6 reads and ~27.
-      constexpr int R = kDP / 2;
-      static_assert(kDP % 2 == 0 && 2 * kDP <= 64, "two segments of kDP / 2 rows");
+      // Scharr derivatives by COLUMN-PAIR WALK on packed 16-bit arithmetic: lanes 0..54 = 11 column pairs x five segments of five
+      // output rows (the last one starts at row 17 and repeats three rows of its neighbour). A staged dword is a pixel pair
+      // (I[x] | I[x+1] << 16), so the three pair words at columns c, c + 1, c + 2 are the left / centre / right taps of the derivative
+      // columns c AND c + 1 at once: per input row h = P2 - P0 and v = 3 (P0 + P2) + 10 P1, per output row dx = 3 (h0 + h2) + 10 h1 and
+      // dy = v2 - v0, each ONE v_pk_* instruction for both columns (|values| <= 16 x 255: exact in 16 bits) -- the same integers as the
+      // 3 x 3 sums of calcSharrDeriv. (The one-column walk on 32-bit values, rounds 4-6: 168 vector instructions per level on 44 lanes,
+      // a seventh of the kernel's; this form: ~75 on 55 lanes.)
+      constexpr int SEG = 5, NSEG = 5, NCP = kDP / 2;
+      static_assert(kDP % 2 == 0 && NCP * NSEG <= 64 && SEG * NSEG >= kDP && kDP >= SEG, "column pairs x segments");
       const bool inside = ipx >= 0 && ipx + kDP <= cols && ipy >= 0 && ipy + kDP <= rows;  // every derivative position is in the image
-      if (lane < 2 * kDP) {
-        const int seg = lane >= kDP ? 1 : 0, col = lane - kDP * seg, r0 = seg * R;
-        const uint32_t *Ip = &L.I[0][0] + (__mul24(r0, kIS) + col);
-        uint32_t *Dp = reinterpret_cast<uint32_t *>(&L.dI[0][0]) + (__mul24(r0, kDP) + col);
-        const lk_s2 c310 = {3, 10}, c03 = {0, 3};
+      if (lane < NCP * NSEG) {
+        const int seg = lane / NCP, cp = lane - NCP * seg, c = 2 * cp;
+        const int r0 = seg * SEG < kDP - SEG ? seg * SEG : kDP - SEG;
+        const uint32_t *Ip = &L.I[0][0] + (__mul24(r0, kIS) + c);
+        uint32_t *Dp = reinterpret_cast<uint32_t *>(&L.dI[0][0]) + (__mul24(r0, kDP) + c);
+        const lk_s2 k3 = {3, 3}, k10 = {10, 10};
         auto walk = [&](auto checked) {  // (checked: the patch leaves the image -- derivI's BORDER_CONSTANT zeros)
-          const bool colok = (unsigned)(ipx + col) < (unsigned)cols;
-          int h0 = 0, h1 = 0, v0 = 0, v1 = 0;
-          lk_s2 w0s[R + 2], w1s[R + 2];  // (p0, p1), (p1, p2) of input row r0 + r: the staged patch holds reflected values at the image border
+          const unsigned ok0 = (unsigned)(ipx + c) < (unsigned)cols, ok1 = (unsigned)(ipx + c + 1) < (unsigned)cols;
+          lk_s2 P0[SEG + 2], P1[SEG + 2], P2[SEG + 2];  // pair words of input row r0 + r: the staged patch holds reflected values at the image border
 #pragma unroll
-          for (int r = 0; r < R + 2; r++)  // (all reads ahead of the first write: one wait instead of one per row)
-            __builtin_memcpy(&w0s[r], Ip + r * kIS, 4), __builtin_memcpy(&w1s[r], Ip + r * kIS + 1, 4);
+          for (int r = 0; r < SEG + 2; r++)  // (all reads ahead of the first write: one wait instead of one per row)
+            __builtin_memcpy(&P0[r], Ip + r * kIS, 4), __builtin_memcpy(&P1[r], Ip + r * kIS + 1, 4), __builtin_memcpy(&P2[r], Ip + r * kIS + 2, 4);
+          lk_s2 h[SEG + 2], v[SEG + 2];
 #pragma unroll
-          for (int r = 0; r < R + 2; r++) {
-            const lk_s2 w0 = w0s[r], w1 = w1s[r];
-            const int h2 = (int)w1.y - (int)w0.x;
-            const int v2 = __builtin_amdgcn_sdot2(w0, c310, __builtin_amdgcn_sdot2(w1, c03, 0, false), false);
-            if (r >= 2) {
-              const int dx = __mul24(3, h0 + h2) + __mul24(10, h1), dy = v2 - v0;
-              uint32_t d = __builtin_amdgcn_perm((uint32_t)dy, (uint32_t)dx, 0x05040100u);  // short2 {dx, dy}
-              if (decltype(checked)::value) {
-                const unsigned ok = (unsigned)colok & (unsigned)((unsigned)(ipy + r0 + r - 2) < (unsigned)rows);
-                d &= 0u - ok;
-              }
-              Dp[(r - 2) * kDP] = d;
+          for (int r = 0; r < SEG + 2; r++) h[r] = P2[r] - P0[r], v[r] = (P0[r] + P2[r]) * k3 + P1[r] * k10;
+#pragma unroll
+          for (int r = 2; r < SEG + 2; r++) {
+            const lk_s2 dx = (h[r - 2] + h[r]) * k3 + h[r - 1] * k10, dy = v[r] - v[r - 2];
+            uint32_t ux, uy;
+            __builtin_memcpy(&ux, &dx, 4), __builtin_memcpy(&uy, &dy, 4);
+            uint32_t d0 = __builtin_amdgcn_perm(uy, ux, 0x05040100u), d1 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);  // short2 {dx, dy} of columns c, c + 1
+            if (decltype(checked)::value) {
+              const unsigned rok = (unsigned)(ipy + r0 + r - 2) < (unsigned)rows;
+              d0 &= 0u - (ok0 & rok), d1 &= 0u - (ok1 & rok);
             }
-            h0 = h1, h1 = h2, v0 = v1, v1 = v2;
+            Dp[(r - 2) * kDP] = d0, Dp[(r - 2) * kDP + 1] = d1;
           }
         };
         if (inside) walk(std::false_type{});
