@@ -154,7 +154,7 @@ constexpr int kIP = kWin + 3;              // 24: window + 1 (bilinear) + 2 (Sch
 constexpr int kDP = kWin + 1;              // 22: derivative positions
 constexpr int kJMargin = 3;
 constexpr int kJP = kWin + 1 + 2 * kJMargin;  // 28
-constexpr int kJS = kJP + 1;                  // row stride of the staged J region (dwords; odd: rows start on different banks)
+constexpr int kJS = 43;  // row stride of the staged J region (dwords): the three lane groups of an iteration read rows 0 / 1 / 2 of 21 columns each -- at 43 (and 2 x 43 = 22 mod 64) their bank ranges [0, 21), [43, 64), [22, 43) do not meet (29: 15 two-way conflicts per read; lk_track 539 -> 532 us)
 constexpr int kIS = kIP + 1;                  // row stride of the staged I patch (dwords)
 // Every staged pixel is ONE ALIGNED DWORD holding the pair (v[x] | v[x+1] << 16): sub-dword and unaligned LDS accesses
 // crawl on this hardware (the byte-array version of this kernel spent 40 % of its wave cycles in LDS issue stalls).
